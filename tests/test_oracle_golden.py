@@ -1,0 +1,214 @@
+"""Pins oracle/ (the CPU restatement) against golden vectors produced by the reference itself.
+
+CPU-only; runs in the build container and on the GPU box alike (no /root/reference needed).
+Tolerance: the oracle executes the same torch-CPU ops as the reference, so results agree to fp32
+rounding noise; 2e-6 relative is asserted (most cases are bit-identical).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nf_oracle as O
+from oracle import diffusion_oracle as D
+from tests.util import load_golden, meta_of, synth_sd, T, assert_close, relerr
+from tests.golden.synth import synth_tensor
+
+TOL = 2e-6
+torch.set_num_threads(8)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return load_golden("ops.npz")
+
+
+@pytest.mark.parametrize("c", [4, 12, 48])
+def test_actnorm(ops, c):
+    x = T(ops[f"actnorm{c}_x"])
+    s, b = O.actnorm_init(x)
+    assert_close(s, ops[f"actnorm{c}_scale"], TOL, "scale")
+    assert_close(b, ops[f"actnorm{c}_bias"], TOL, "bias")
+    y, ldj = O.actnorm_fwd(x, s, b, torch.zeros(4, dtype=torch.float64))
+    assert_close(y, ops[f"actnorm{c}_y"], TOL, "y")
+    assert_close(ldj, ops[f"actnorm{c}_ldj"], TOL, "ldj")
+    assert_close(O.actnorm_inv(y, s, b), ops[f"actnorm{c}_inv"], TOL, "inv")
+
+
+@pytest.mark.parametrize("c", [4, 12, 48])
+def test_invconv(ops, c):
+    x, w = T(ops[f"invconv{c}_x"]), T(ops[f"invconv{c}_w"])
+    y, ldj = O.invconv_fwd(x, w, torch.zeros(4, dtype=torch.float64))
+    assert_close(y, ops[f"invconv{c}_y"], TOL, "y")
+    assert_close(ldj, ops[f"invconv{c}_ldj"], TOL, "ldj")
+    assert_close(O.invconv_inv(y, w), ops[f"invconv{c}_inv"], 1e-5, "inv")
+
+
+def test_squeeze_bit_exact(ops):
+    x = T(ops["squeeze_x"])
+    y = O.squeeze(x)
+    assert torch.equal(y, T(ops["squeeze_y"]))
+    assert torch.equal(O.unsqueeze(y), T(ops["squeeze_inv"]))
+    assert torch.equal(O.unsqueeze(y), x)
+
+
+@pytest.mark.parametrize("tag,c,nf", [("a", 4, 64), ("b", 12, 64), ("c", 4, 512), ("d", 48, 512)])
+def test_coupling(ops, tag, c, nf):
+    p = "flows.0.affcoupling.net."
+    spec = [("0._Conv2dActNorm__conv.weight", (nf, c // 2, 3, 3)), ("0._Conv2dActNorm__actnorm.scale", (nf, 1, 1)),
+            ("0._Conv2dActNorm__actnorm.bias", (nf, 1, 1)), ("2._Conv2dActNorm__conv.weight", (nf, nf, 1, 1)),
+            ("2._Conv2dActNorm__actnorm.scale", (nf, 1, 1)), ("2._Conv2dActNorm__actnorm.bias", (nf, 1, 1)),
+            ("4.weight", (c, nf, 3, 3)), ("4.bias", (c,)), ("4.logs", (1, c, 1, 1))]
+    sd = {p + k: v for k, v in synth_sd(spec, 2, prefix=p).items()}
+    x = T(ops[f"coup{tag}_x"])
+    y, ldj = O.coupling_fwd(x, sd, p, torch.zeros(2, dtype=torch.float64))
+    assert_close(y, ops[f"coup{tag}_y"], TOL, "y")
+    assert_close(ldj, ops[f"coup{tag}_ldj"], TOL, "ldj")
+    assert_close(O.coupling_inv(y, sd, p), ops[f"coup{tag}_inv"], TOL, "inv")
+
+
+@pytest.mark.parametrize("c", [4, 24])
+def test_split(ops, c):
+    p = "blocks.0.split."
+    spec = [("conv.weight", (c, c // 2, 3, 3)), ("conv.bias", (c,)), ("conv.logs", (1, c, 1, 1))]
+    sd = {p + k: v for k, v in synth_sd(spec, 3, prefix=p).items()}
+    x = T(ops[f"split{c}_x"])
+    y, z, logp = O.split_fwd(x, sd, p, torch.zeros(2, dtype=torch.float64))
+    assert torch.equal(y, T(ops[f"split{c}_y"])) and torch.equal(z, T(ops[f"split{c}_z"]))
+    assert_close(logp, ops[f"split{c}_logp"], TOL, "logp")
+    assert torch.equal(O.split_inv(y, sd, p, z, 1.0, None), T(ops[f"split{c}_inv_given"]))
+    inv = O.split_inv(y, sd, p, None, 0.7, T(ops[f"split{c}_eps"]))
+    assert_close(inv, ops[f"split{c}_inv_sampled"], TOL, "sampled")
+
+
+@pytest.mark.parametrize("c", [16, 48])
+def test_gaussian_prior(ops, c):
+    spec = [("_GaussianPrior__conv.weight", (2 * c, 2 * c, 3, 3)), ("_GaussianPrior__conv.bias", (2 * c,)),
+            ("_GaussianPrior__conv.logs", (1, 2 * c, 1, 1))]
+    sd = synth_sd(spec, 4)
+    x = T(ops[f"gprior{c}_x"])
+    assert_close(O.gaussian_prior_logp(x, sd), ops[f"gprior{c}_logp"], TOL, "logp")
+    s = O.gaussian_prior_sample((3, c, 4, 4), sd, 0.8, T(ops[f"gprior{c}_eps"]))
+    assert_close(s, ops[f"gprior{c}_sample"], TOL, "sample")
+
+
+def test_pre_post_bpd(ops):
+    b01 = T(ops["pp_u8"]).float() / 255.0
+    for nb in (5, 8):
+        assert torch.equal(O.preprocess(b01, nb), T(ops[f"pre{nb}"]))
+    assert torch.equal(O.postprocess(T(ops["post_x"]), 32.0), T(ops["post5"]))
+    assert_close(O.bits_per_dim(T(ops["bpd_ll"]), 32.0, 3072.0), ops["bpd"], 1e-12, "bpd")
+    assert np.array_equal(np.array(O.output_shapes(3, 3, 32)), ops["shapes_3_3_32"])
+    assert np.array_equal(np.array(O.output_shapes(5, 3, 128)), ops["shapes_5_3_128"])
+    with pytest.raises(ValueError):
+        O.output_shapes(3, 3, 30 // 2 * 2 + 1)
+
+
+@pytest.mark.parametrize("tag", ["M", "N"])
+def test_glow_composite(tag):
+    g = load_golden(f"glow_{tag}.npz")
+    m = meta_of(g)
+    L, K, B, C = m["L"], m["K"], m["B"], m["C"]
+    sd = synth_sd(m["flow_spec"], m["seed"])
+    psd = synth_sd(m["prior_spec"], m["seed"])
+    x = T(g["x"])
+    zs, ldj, logp, bpd = O.fwd_nll(x, sd, psd, L, K)
+    for i, z in enumerate(zs):
+        assert_close(z, g[f"z{i}"], TOL, f"z{i}")
+    assert_close(ldj, g["ldj"], TOL, "ldj")
+    assert_close(logp, g["logp"], TOL, "logp")
+    assert_close(bpd, g["bpd"], TOL, "bpd")
+    assert_close(O.glow_inv(zs, sd, L, K), g["x_rec"], 2e-5, "x_rec")
+    eps = [T(g[f"eps{j}"]) for j in range(L - 1)]
+    assert_close(O.glow_inv([zs[-1]], sd, L, K, 0.7, eps), g["x_sampled"], 2e-5, "x_sampled")
+    xs0 = O.glow_inv([zs[-1]], sd, L, K, 0.0, [torch.zeros_like(e) for e in eps])
+    post = O.postprocess(xs0, 32.0)
+    assert (post.int() - T(g["x_sampled_post"]).int()).abs().max() <= 8   # one 5-bit bin at most (floor edge)
+    assert (post != T(g["x_sampled_post"])).float().mean() < 1e-3
+
+
+def test_glow_data_dependent_init():
+    g = load_golden("glow_init.npz")
+    m = meta_of(g)
+    L, K, B, C = m["L"], m["K"], m["B"], m["C"]
+    shapes = {}
+    # init-state dict: zeros everywhere except synthesised conv / invconv weights (as make_goldens.gen_glow_init)
+    from tests.util import load_golden as _lg
+    spec = meta_of(_lg("glow_N.npz"))["flow_spec"]
+    sd = {}
+    for k, s in spec:
+        if k.endswith("_Conv2dActNorm__conv.weight") or k.endswith("invconv2d.weight"):
+            sd[k] = T(synth_tensor(k, s, m["seed"]))
+        elif k.endswith("is_initialized"):
+            sd[k] = torch.tensor(0, dtype=torch.uint8)
+        else:
+            sd[k] = torch.zeros(*s)
+    c_last = 2 ** (L + 1) * C
+    psd = {"_GaussianPrior__conv.weight": torch.zeros(2 * c_last, 2 * c_last, 3, 3),
+           "_GaussianPrior__conv.bias": torch.zeros(2 * c_last), "_GaussianPrior__conv.logs": torch.zeros(1, 2 * c_last, 1, 1)}
+    zs, ldj, logp, bpd = O.fwd_nll(T(g["x"]), sd, psd, L, K, init=True)
+    for i, z in enumerate(zs):
+        assert_close(z, g[f"z{i}"], 1e-5, f"z{i}")
+    assert_close(ldj, g["ldj"], 1e-6, "ldj")
+    assert_close(bpd, g["bpd"], 1e-6, "bpd")
+    for k in [k for k in g if k.startswith("p:")]:
+        assert_close(sd[k[2:]], g[k], 1e-5, k)
+    zs2, ldj2, logp2 = O.glow_fwd(T(g["x2"]), sd, L, K, torch.zeros(B, dtype=torch.float64), torch.zeros(B, dtype=torch.float64))
+    assert_close(zs2[-1], g["z2_last"], 1e-5, "z2_last")
+    assert_close(ldj2, g["ldj2"], 1e-6, "ldj2")
+
+
+# ----------------------------------------------------------------------------- diffusion
+@pytest.fixture(scope="module")
+def dg():
+    return load_golden("diffusion.npz")
+
+
+@pytest.mark.parametrize("sched", ["cosine", "linear", "sigmoid"])
+def test_schedule_buffers(dg, sched):
+    buf = D.diffusion_buffers(sched, 1000)
+    for name in D.BUFFER_NAMES:
+        assert_close(buf[name], dg[f"buf_{sched}_{name}"], 1e-6, name)
+    with pytest.raises(ValueError):
+        D.betas_for("nope", 10)
+
+
+@pytest.mark.parametrize("tag", ["m0", "m2", "c0", "c5"])
+def test_unet_forward(dg, tag):
+    m = meta_of(dg)[tag]
+    sd = synth_sd(m["spec"], 21)
+    y = D.unet_forward(T(dg[f"unet{tag}_x"]), T(dg[f"unet{tag}_t"]), sd, 64, m["mults"], m["groups"])
+    assert_close(y, dg[f"unet{tag}_y"], 1e-5, "unet")
+
+
+def test_diffusion_process(dg):
+    m = meta_of(dg)["m0"]
+    sd = synth_sd(m["spec"], 21)
+    model = lambda x, t: D.unet_forward(x, t, sd, 64, m["mults"], m["groups"])
+    buf = D.diffusion_buffers("cosine", 1000)
+    x0, eps, t = T(dg["d_x0"]), T(dg["d_eps"]), T(dg["d_t"])
+    assert_close(D.q_sample(buf, x0, t, eps), dg["d_q_sample"], TOL, "q_sample")
+    assert_close(D.predict_start_from_noise(buf, x0, t, eps), dg["d_pred_x0"], TOL, "pred_x0")
+    pm, pv, plv = D.q_posterior(buf, x0, eps, t)
+    assert_close(pm, dg["d_post_mean"], TOL, "pm")
+    assert_close(pv, dg["d_post_var"], TOL, "pv")
+    assert_close(plv, dg["d_post_logvar"], TOL, "plv")
+    assert_close(D.p_losses(buf, model, x0, t, eps, "l2"), dg["d_p_losses_l2"], 1e-5, "l2")
+    assert_close(D.p_losses(buf, model, x0, t, eps, "l1"), dg["d_p_losses_l1"], 1e-5, "l1")
+    assert_close(D.p_losses(buf, model, x0, T(dg["d_fwd_t"]), T(dg["d_fwd_noise"]), "l2"), dg["d_fwd_loss"], 1e-5, "fwd")
+    for step in (0, 1, 500, 999):
+        img, xs = D.p_sample(buf, model, x0, step, T(dg[f"d_psample{step}_noise"]))
+        assert_close(img, dg[f"d_psample{step}_img"], 1e-5, f"img{step}")
+        assert_close(xs, dg[f"d_psample{step}_x0"], 1e-5, f"x0{step}")
+    with pytest.raises(ValueError):
+        D.p_losses(buf, model, x0, t, eps, "huber")
+
+
+def test_sampling_loops(dg):
+    m = meta_of(dg)["m0"]
+    sd = synth_sd(m["spec"], 21)
+    model = lambda x, t: D.unet_forward(x, t, sd, 64, m["mults"], m["groups"])
+    buf8 = D.diffusion_buffers("cosine", 8)
+    out = D.p_sample_loop(buf8, model, T(dg["loop8_xT"]), list(T(dg["loop8_noises"])))
+    assert_close(out, dg["loop8_out"], 2e-5, "loop8")
+    out = D.ddim_sample(buf8, model, T(dg["ddim_xT"]), 4, 1.0, list(T(dg["ddim_noises"])))
+    assert_close(out, dg["ddim_out"], 2e-5, "ddim")

@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from /root/reference).
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python tools/make_goldens.py
+The reference never travels to the GPU box; only these small input/output fixtures do.
+Weights are not stored: they are synthesised from (key, shape, seed) by tests/golden/synth.py and
+loaded into the reference modules with load_state_dict(strict=True), which also pins state-dict
+key compatibility.  All randomness the reference draws (dequantisation noise aside, which is an
+input) is recorded by replaying torch.manual_seed on the CPU generator.
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import numpy as np
+import torch
+
+from ref_import import import_reference
+from tests.golden.synth import synth_tensor, synth_input, images_5bit
+
+R = import_reference()
+T = R["transforms"]
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_num_threads(8)
+
+
+def load_synth(module, seed, overrides=None):
+    sd = module.state_dict()
+    new = {k: torch.from_numpy(np.array(synth_tensor(k, v.shape, seed))) for k, v in sd.items()}
+    if overrides:
+        new.update(overrides)
+    module.load_state_dict(new, strict=True)
+    return [(k, list(v.shape)) for k, v in sd.items()]
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def n(x):
+    return x.detach().cpu().numpy()
+
+
+def f64z(b):
+    return torch.zeros(b, dtype=torch.float64)
+
+
+# ------------------------------------------------------------------ per-op goldens
+@torch.no_grad()
+def gen_ops():
+    g = {}
+    # ActNorm: data-dependent init + fwd + inv  (transforms.py:56-94)
+    for c in (4, 12, 48):
+        x = t(synth_input(f"actnorm{c}", (4, c, 8, 8), 1)) * 1.7 + 0.3
+        m = T.ActNorm(c)
+        y, ldj, _ = m.transform(x, f64z(4), None)
+        g[f"actnorm{c}_x"], g[f"actnorm{c}_y"], g[f"actnorm{c}_ldj"] = n(x), n(y), n(ldj)
+        g[f"actnorm{c}_scale"], g[f"actnorm{c}_bias"] = n(m.scale), n(m.bias)
+        g[f"actnorm{c}_inv"] = n(m.invert(y))
+    # InvConv2d  (transforms.py:116-145)
+    for c in (4, 12, 48):
+        x = t(synth_input(f"invconv{c}", (4, c, 8, 8), 1))
+        m = T.InvConv2d(c)
+        w = t(synth_tensor("x.invconv2d.weight", (c, c, 1, 1), 1))
+        m.load_state_dict({"weight": w})
+        y, ldj, _ = m.transform(x, f64z(4), None)
+        g[f"invconv{c}_x"], g[f"invconv{c}_w"], g[f"invconv{c}_y"], g[f"invconv{c}_ldj"] = n(x), n(w), n(y), n(ldj)
+        g[f"invconv{c}_inv"] = n(m.invert(y))
+    # Squeeze on exact integers  (transforms.py:212-239)
+    x = torch.arange(2 * 3 * 8 * 8, dtype=torch.float32).reshape(2, 3, 8, 8)
+    sq = T.Squeeze()
+    y = sq.transform(x, None, None)[0]
+    g["squeeze_x"], g["squeeze_y"] = n(x), n(y)
+    g["squeeze_inv"] = n(sq.invert(y))
+    # AffineCoupling, non-zero ZeroConv  (transforms.py:166-201)
+    for tag, c, nf, hw in (("a", 4, 64, 8), ("b", 12, 64, 8), ("c", 4, 512, 8), ("d", 48, 512, 4)):
+        x = t(synth_input(f"coup{tag}", (2, c, hw, hw), 1))
+        m = T.AffineCoupling(c, n_features=nf)
+        pref = "flows.0.affcoupling."
+        sd = {k: t(synth_tensor(pref + k, v.shape, 2)) for k, v in m.state_dict().items()}
+        m.load_state_dict(sd, strict=True)
+        y, ldj, _ = m.transform(x, f64z(2), None)
+        g[f"coup{tag}_x"], g[f"coup{tag}_y"], g[f"coup{tag}_ldj"] = n(x), n(y), n(ldj)
+        g[f"coup{tag}_inv"] = n(m.invert(y))
+    # Split: logp, inverse with given z, inverse with sampling (eps replayed)  (transforms.py:270-309)
+    for c in (4, 24):
+        x = t(synth_input(f"split{c}", (2, c, 8, 8), 1))
+        m = T.Split(c)
+        sd = {k: t(synth_tensor("blocks.0.split." + k, v.shape, 3)) for k, v in m.state_dict().items()}
+        m.load_state_dict(sd, strict=True)
+        y, _, z, logp = m.transform(x, None, f64z(2))
+        g[f"split{c}_x"], g[f"split{c}_y"], g[f"split{c}_z"], g[f"split{c}_logp"] = n(x), n(y), n(z), n(logp)
+        g[f"split{c}_inv_given"] = n(m.invert(y, z))
+        torch.manual_seed(77)
+        inv = m.invert(y, None, temperature=0.7)
+        torch.manual_seed(77)
+        eps = torch.zeros(2, c // 2, 8, 8).normal_()
+        g[f"split{c}_inv_sampled"], g[f"split{c}_eps"] = n(inv), n(eps)
+    # GaussianPrior  (prior.py:53-99)
+    for c in (16, 48):
+        x = t(synth_input(f"gprior{c}", (3, c, 4, 4), 1))
+        m = R["prior"].GaussianPrior(c)
+        load_synth(m, 4)
+        g[f"gprior{c}_x"], g[f"gprior{c}_logp"] = n(x), n(m.compute_log_prob(x))
+        torch.manual_seed(5)
+        s = m.sample((3, c, 4, 4), temperature=0.8)
+        torch.manual_seed(5)
+        eps = torch.zeros(3, c, 4, 4).normal_()
+        g[f"gprior{c}_sample"], g[f"gprior{c}_eps"] = n(s), n(eps)
+    # pre/post-process + bpd  (utils.py:175-210, 244-256)
+    U = R["nf_utils"]
+    u8 = t(synth_input("pp", (2, 3, 8, 8), 1, "u8"))
+    b01 = u8.float() / 255.0
+    for nb in (5, 8):
+        g[f"pre{nb}"] = n(U.preprocess_batch(b01, nb, 2.0 ** nb))
+    g["pp_u8"] = n(u8)
+    xs = t(synth_input("post", (2, 3, 8, 8), 1)) * 0.4
+    g["post_x"], g["post5"] = n(xs), n(U.postprocess_batch(xs, 32.0))
+    ll = t(synth_input("ll", (6,), 1)).double() * 100 - 7000
+    g["bpd_ll"], g["bpd"] = n(ll), n(U.calculate_loss(ll, 32.0, 32 * 32 * 3.0))
+    g["shapes_3_3_32"] = np.array(U.calculate_output_shapes(3, 3, 32))
+    g["shapes_5_3_128"] = np.array(U.calculate_output_shapes(5, 3, 128))
+    np.savez_compressed(os.path.join(OUT, "ops.npz"), **g)
+    print("ops.npz", len(g), "arrays")
+
+
+# ------------------------------------------------------------------ Glow composite goldens
+@torch.no_grad()
+def gen_glow(tag, C, L, K, B, seed):
+    U = R["nf_utils"]
+    flow = R["glow"].Glow(in_channel=C, L=L, K=K)
+    prior = R["prior"].GaussianPrior(2 ** (L + 1) * C)
+    spec = load_synth(flow, seed)
+    pspec = load_synth(prior, seed)
+    x_np, u8, dq = images_5bit(f"glow{tag}", (B, C, 32, 32), seed)
+    x = t(x_np)
+    # sanity: same as reference preprocessing  (trainer.py:152-155)
+    ref_x = U.preprocess_batch(t(u8).float() / 255.0, 5, 32.0) + t(dq) / 32.0
+    assert torch.equal(ref_x, x), (ref_x - x).abs().max()
+    ldj, logp = f64z(B), f64z(B)
+    zs, ldj, logp = flow.transform(x, ldj, logp)
+    logp_flow = logp.clone()
+    logp = logp + prior.compute_log_prob(zs[-1])
+    bpd = U.calculate_loss(ldj + logp, 32.0, 32 * 32 * 3.0)
+    g = {"x": x_np, "ldj": n(ldj), "logp_flow": n(logp_flow), "logp": n(logp), "bpd": n(bpd)}
+    for i, z in enumerate(zs):
+        g[f"z{i}"] = n(z)
+    # NFBackbone path: logp=None  (normalizing_flow/__init__.py:81)
+    zs2, ldj2, _ = flow.transform(x, f64z(B), None)
+    assert all(torch.equal(a, b) for a, b in zip(zs, zs2))
+    g["x_rec"] = n(flow.invert(zs))
+    torch.manual_seed(11)
+    xs = flow.invert([zs[-1]], temperature=0.7)
+    torch.manual_seed(11)
+    shapes = U.calculate_output_shapes(L, C, 32)
+    eps = [torch.zeros(B, *shapes[i]).normal_() for i in reversed(range(L - 1))]
+    g["x_sampled"] = n(xs)
+    for j, e in enumerate(eps):
+        g[f"eps{j}"] = n(e)
+    g["x_sampled_post"] = n(flow.sample([zs[-1]], postprocess_func=lambda v: U.postprocess_batch(v, 32.0), temperature=0.0))
+    meta = {"C": C, "L": L, "K": K, "B": B, "seed": seed, "flow_spec": spec, "prior_spec": pspec}
+    g["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, f"glow_{tag}.npz"), **g)
+    print(f"glow_{tag}.npz bpd={float(bpd):.6f}  |z_last|max={float(zs[-1].abs().max()):.3f} "
+          f"rec_err={float((flow.invert(zs) - x).abs().max()):.2e}")
+
+
+@torch.no_grad()
+def gen_glow_init(C=3, L=3, K=2, B=8, seed=5):
+    """Init-state weights: reference ctor defaults (zero ZeroConvs, is_initialized=0) with synthesised
+    conv / invconv weights; the first transform performs the data-dependent ActNorm init."""
+    U = R["nf_utils"]
+    flow = R["glow"].Glow(in_channel=C, L=L, K=K)
+    sd = flow.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k.endswith("_Conv2dActNorm__conv.weight") or k.endswith("invconv2d.weight"):
+            new[k] = t(synth_tensor(k, v.shape, seed))
+        else:
+            new[k] = v.clone()
+    flow.load_state_dict(new, strict=True)
+    prior = R["prior"].GaussianPrior(2 ** (L + 1) * C)
+    x_np, _, _ = images_5bit("glowinit", (B, C, 32, 32), seed)
+    x = t(x_np)
+    zs, ldj, logp = flow.transform(x, f64z(B), f64z(B))
+    logp = logp + prior.compute_log_prob(zs[-1])
+    bpd = U.calculate_loss(ldj + logp, 32.0, 32 * 32 * 3.0)
+    g = {"x": x_np, "ldj": n(ldj), "logp": n(logp), "bpd": n(bpd)}
+    for i, z in enumerate(zs):
+        g[f"z{i}"] = n(z)
+    after = flow.state_dict()
+    for k in ("blocks.0.flows.0.actnorm.scale", "blocks.0.flows.0.actnorm.bias",
+              "blocks.1.flows.1.affcoupling.net.0._Conv2dActNorm__actnorm.scale",
+              "blocks.1.flows.1.affcoupling.net.2._Conv2dActNorm__actnorm.bias",
+              "final_flows.1.actnorm.scale", "final_flows.1.affcoupling.net.2._Conv2dActNorm__actnorm.scale"):
+        g["p:" + k] = n(after[k])
+    assert all(int(v) == 1 for k, v in after.items() if k.endswith("is_initialized"))
+    # second batch through the now-initialised flow
+    x2_np, _, _ = images_5bit("glowinit2", (B, C, 32, 32), seed)
+    zs2, ldj2, logp2 = flow.transform(t(x2_np), f64z(B), f64z(B))
+    g["x2"], g["ldj2"], g["logp2_flow"], g["z2_last"] = x2_np, n(ldj2), n(logp2), n(zs2[-1])
+    g["meta"] = np.array(json.dumps({"C": C, "L": L, "K": K, "B": B, "seed": seed}))
+    np.savez_compressed(os.path.join(OUT, "glow_init.npz"), **g)
+    print(f"glow_init.npz bpd={float(bpd):.6f}")
+
+
+# ------------------------------------------------------------------ diffusion goldens
+@torch.no_grad()
+def gen_diffusion():
+    GD = R["gd"]
+    g = {}
+    # schedules + buffers  (gaussian_diffusion.py:501-634)
+    dummy = GD.Unet(dim=8, dim_mults=(1,), channels=2)
+    for sched in ("cosine", "linear", "sigmoid"):
+        d = GD.GaussianDiffusion(dummy, image_size=4, timesteps=1000, beta_schedule=sched, auto_normalize=False)
+        for name, buf in d.named_buffers(recurse=False):
+            g[f"buf_{sched}_{name}"] = n(buf)
+    # U-Net forwards  (gaussian_diffusion.py:451-490)
+    specs = {}
+    for tag, ch, size, mults, groups, B in (("m0", 2, 16, (1, 2), 8, 2), ("m2", 16, 4, (1, 2), 8, 2),
+                                            ("c0", 6, 16, (1, 2), 8, 2), ("c5", 12, 16, (1, 2, 2), 16, 1)):
+        u = GD.Unet(dim=64, dim_mults=mults, channels=ch, resnet_block_groups=groups)
+        specs[tag] = {"spec": load_synth(u, 21), "ch": ch, "size": size, "mults": list(mults), "groups": groups}
+        x = t(synth_input(f"unet{tag}", (B, ch, size, size), 21))
+        tt = torch.tensor([3, 977][:B], dtype=torch.long)
+        g[f"unet{tag}_x"], g[f"unet{tag}_t"], g[f"unet{tag}_y"] = n(x), n(tt), n(u(x, tt))
+        if tag == "m0":
+            unet_m0 = u
+    # diffusion process around the m0 U-Net, T=1000 cosine  (gaussian_diffusion.py:641-715, 806-859)
+    d = GD.GaussianDiffusion(unet_m0, image_size=16, timesteps=1000, beta_schedule="cosine", loss_type="l2",
+                             auto_normalize=False)
+    x0 = t(synth_input("x0", (2, 2, 16, 16), 22)) * 0.8
+    eps = t(synth_input("eps", (2, 2, 16, 16), 23))
+    tt = torch.tensor([10, 700], dtype=torch.long)
+    g["d_x0"], g["d_eps"], g["d_t"] = n(x0), n(eps), n(tt)
+    g["d_q_sample"] = n(d.q_sample(x0, tt, eps))
+    g["d_pred_x0"] = n(d.predict_start_from_noise(x0, tt, eps))
+    pm, pv, plv = d.q_posterior(x0, eps, tt)
+    g["d_post_mean"], g["d_post_var"], g["d_post_logvar"] = n(pm), n(pv), n(plv)
+    g["d_p_losses_l2"] = n(d.p_losses(x0, tt, noise=eps))
+    d.loss_type = "l1"
+    g["d_p_losses_l1"] = n(d.p_losses(x0, tt, noise=eps))
+    d.loss_type = "l2"
+    for step in (0, 1, 500, 999):
+        torch.manual_seed(100 + step)
+        img, xs = d.p_sample(x0.clone(), step)
+        torch.manual_seed(100 + step)
+        nz = torch.randn_like(x0)
+        g[f"d_psample{step}_img"], g[f"d_psample{step}_x0"], g[f"d_psample{step}_noise"] = n(img), n(xs), n(nz)
+    # forward(): t drawn by randint  (gaussian_diffusion.py:861-867)
+    torch.manual_seed(9)
+    loss = d(x0)
+    torch.manual_seed(9)
+    t_drawn = torch.randint(0, 1000, (2,)).long()
+    nz = torch.randn_like(x0)
+    g["d_fwd_loss"], g["d_fwd_t"], g["d_fwd_noise"] = n(loss), n(t_drawn), n(nz)
+    # short full loops, T=8  (gaussian_diffusion.py:717-783)
+    d8 = GD.GaussianDiffusion(unet_m0, image_size=16, timesteps=8, beta_schedule="cosine", auto_normalize=False)
+    torch.manual_seed(31)
+    s = d8.sample(batch_size=2)
+    torch.manual_seed(31)
+    xT = torch.randn(2, 2, 16, 16)
+    nzs = [torch.randn(2, 2, 16, 16) for _ in range(7)]
+    g["loop8_out"], g["loop8_xT"], g["loop8_noises"] = n(s), n(xT), n(torch.stack(nzs))
+    dd = GD.GaussianDiffusion(unet_m0, image_size=16, timesteps=8, sampling_timesteps=4, beta_schedule="cosine",
+                              ddim_sampling_eta=1.0, auto_normalize=False)
+    torch.manual_seed(32)
+    s = dd.sample(batch_size=2)
+    torch.manual_seed(32)
+    xT = torch.randn(2, 2, 16, 16)
+    nzs = [torch.randn(2, 2, 16, 16) for _ in range(3)]
+    g["ddim_out"], g["ddim_xT"], g["ddim_noises"] = n(s), n(xT), n(torch.stack(nzs))
+    g["meta"] = np.array(json.dumps(specs))
+    np.savez_compressed(os.path.join(OUT, "diffusion.npz"), **g)
+    print("diffusion.npz", len(g), "arrays")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion"]
+    if "ops" in which:
+        gen_ops()
+    if "glow" in which:
+        gen_glow("M", 1, 3, 4, 4, 1)      # BASELINE configs[0] shape (MNIST 1x32x32, L3 K4)
+        gen_glow("N", 3, 3, 2, 2, 2)      # north-star shape with reduced K
+    if "init" in which:
+        gen_glow_init()
+    if "diffusion" in which:
+        gen_diffusion()
+    leftovers = [r for r, dnames, _ in os.walk("/root/reference") if "__pycache__" in dnames]
+    assert not leftovers, leftovers
