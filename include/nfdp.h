@@ -1,0 +1,148 @@
+/* nfdp.h — C ABI of the MI355X (gfx950) kernel library for the Glow + diffusion-prior hot path.
+ *
+ * The reference (davitpapikyan/Normalizing-Flow-with-Diffusion-Prior-Model) has no FFI: its
+ * boundary is a Python class surface whose methods dispatch torch ops.  Each entry point below
+ * replaces the torch-op sequence of one reference method (cited as file:line relative to the
+ * reference root).  Python binds these with ctypes; nothing here depends on
+ * torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates, frees
+ *     or retains memory and keeps no global mutable state (re-entrant per stream);
+ *   - activations are fp32 (or bf16 where stated), physical layout NHWC: element (b,h,w,c) of a
+ *     [B,H,W,C] tensor is at ((b*H+h)*W+w)*ld + c with ld >= C the pixel stride in ELEMENTS
+ *     (ld lets a kernel address a channel-half of a wider tensor in place);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it;
+ *   - return value: NFDP_OK or a negative error; nfdp_last_error() gives thread-local text.
+ *     Asynchronous HIP faults surface at the caller's next synchronisation.
+ */
+#ifndef NFDP_H
+#define NFDP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFDP_OK 0
+#define NFDP_EINVAL (-1)       /* null pointer / bad enum */
+#define NFDP_ESHAPE (-2)       /* shape the kernel cannot take (odd H/W, C not divisible, ...) */
+#define NFDP_EUNSUPPORTED (-3) /* valid request this build has no kernel for */
+#define NFDP_EHIP (-4)         /* a HIP runtime call failed (launch error) */
+
+#define NFDP_F32 0
+#define NFDP_BF16 1
+
+typedef void* nfdp_stream_t;
+
+int nfdp_version(void);
+const char* nfdp_last_error(void);
+
+/* ---------------------------------------------------------------- layout / index reshuffles (bit-exact) */
+/* logical NCHW contiguous <-> NHWC contiguous (boundary conversion for reference-style tensors). */
+int nfdp_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int H, int W, nfdp_stream_t stream);
+int nfdp_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, nfdp_stream_t stream);
+/* Squeeze.transform, normalizing_flow/transforms.py:226:  y[b,h,w,4c+2h1+w1] = x[b,2h+h1,2w+w1,c].
+ * x is [B,H,W,C] with pixel stride x_ld >= C (reads the kept half of a Split in place), H,W even;
+ * y is [B,H/2,W/2,4C] contiguous. */
+int nfdp_squeeze_nhwc_f32(const float* x, int x_ld, float* y, int B, int C, int H, int W, nfdp_stream_t stream);
+/* Squeeze.invert, transforms.py:238: y is [B,h,w,C4] -> x [B,2h,2w,C4/4]. */
+int nfdp_unsqueeze_nhwc_f32(const float* y, float* x, int B, int C4, int h, int w, nfdp_stream_t stream);
+/* channel slice copy: dst[p, 0:n) = src[p, off:off+n) for npix pixels (Split / chunk / concat plumbing). */
+int nfdp_copy_channels_f32(const float* src, int src_ld, float* dst, int dst_ld, long npix, int n, nfdp_stream_t stream);
+
+/* ---------------------------------------------------------------- ActNorm (transforms.py:56-94) */
+/* Data-dependent init, transforms.py:74-78: scale[c] = -log(std_unbiased + 1e-6), bias[c] = -mean over
+ * npix pixels.  fp64 two-pass reduction, deterministic.  ws: >= nfdp_actnorm_init_ws_bytes(C) bytes. */
+size_t nfdp_actnorm_init_ws_bytes(int C);
+int nfdp_actnorm_init_f32(const float* x, int ld, long npix, int C, float* scale, float* bias, void* ws,
+                          nfdp_stream_t stream);
+/* y = exp(scale)*(x+bias)  (transforms.py:80) and x = y*exp(-scale)-bias (transforms.py:93).  In place allowed. */
+int nfdp_actnorm_fwd_f32(const float* x, float* y, long npix, int C, const float* scale, const float* bias,
+                         nfdp_stream_t stream);
+int nfdp_actnorm_inv_f32(const float* y, float* x, long npix, int C, const float* scale, const float* bias,
+                         nfdp_stream_t stream);
+
+/* ---------------------------------------------------------------- invertible 1x1 conv (transforms.py:116-145) */
+/* For n matrices W_i [C,C] fp32 (row-major, out x in): logabsdet[i] = (float) log|det W_i| via fp64 elimination
+ * (transforms.py:131) and, if winv != NULL, winv_i = (float) W_i^-1 (transforms.py:144).
+ * ws: >= nfdp_invconv_prepare_ws_bytes(n, C) bytes. */
+size_t nfdp_invconv_prepare_ws_bytes(int n, int C);
+int nfdp_invconv_prepare_f32(const float* w, int n, int C, float* logabsdet, float* winv, void* ws,
+                             nfdp_stream_t stream);
+/* y[p,:] = W x[p,:]   (conv2d with a [C,C,1,1] kernel, transforms.py:132 / :144 with W^-1). */
+int nfdp_invconv_apply_f32(const float* x, float* y, long npix, int C, const float* w, nfdp_stream_t stream);
+/* Fused flow head, glow.py:46-47: y = W (exp(scale)*(x+bias)). */
+int nfdp_actnorm_invconv_fwd_f32(const float* x, float* y, long npix, int C, const float* scale, const float* bias,
+                                 const float* w, nfdp_stream_t stream);
+/* Fused inverse, glow.py:61-62: x = (W^-1 y)*exp(-scale) - bias. */
+int nfdp_invconv_actnorm_inv_f32(const float* y, float* x, long npix, int C, const float* scale, const float* bias,
+                                 const float* winv, nfdp_stream_t stream);
+
+/* ---------------------------------------------------------------- convolution (MFMA implicit GEMM) */
+/* Replaces F.conv2d inside Conv2dActNorm / ZeroConv2d (normalizing_flow/utils.py:43-44, 67-69) and the U-Net
+ * convs (diffusion_prior/gaussian_diffusion.py).  stride 1, zero padding (KH-1)/2.
+ * Weights are first packed from torch's OIHW fp32 into [Cout_pad][K_pad], k = (ky*KW+kx)*Cin+ci, in the compute
+ * dtype.  Epilogue per output channel n:  v = (acc + add[n]) * m[n]; if (relu) v = max(v,0)  (add/mul may be NULL),
+ * with m[n] = mul[n] if mul_exp == 0 else exp(mul[n]*mul_exp) — mul_exp = 1 gives ActNorm's exp(scale)
+ * (transforms.py:80), mul_exp = 3 ZeroConv2d's exp(3*logs) (utils.py:44) straight from the raw parameters.
+ * compute = NFDP_F32 uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain); NFDP_BF16 uses v_mfma_f32_16x16x32_bf16
+ * with fp32 accumulation.  x/y dtypes: NFDP_F32 or NFDP_BF16 storage (bf16 storage only with bf16 compute). */
+size_t nfdp_conv_packed_bytes(int Cout, int Cin, int KH, int KW, int compute);
+int nfdp_conv_pack_weights(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, int compute,
+                           nfdp_stream_t stream);
+int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
+                     int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
+                     float mul_exp, int relu, int compute, nfdp_stream_t stream);
+
+/* ---------------------------------------------------------------- affine coupling (transforms.py:166-201) */
+/* x: [B,HW,C] flow tensor (x_a = channels [0,C/2), x_b = [C/2,C)); h: NN output [B,HW,C] (log_s | t).
+ * fwd (transforms.py:181-184): s = sigmoid(log_s+2); x_b <- (x_b+t)*s in place; ldj[b] += sum log(s+1e-6) (fp64).
+ * If ldj_const != NULL, ldj[b] first receives (double)ldj_const[0] + (double)ldj_const[1] — the batch-independent
+ * ActNorm and 1x1-conv log-dets of the same flow step (transforms.py:81, :131), added in the reference's order.
+ * ldj may be NULL (no accumulation).  inv (transforms.py:198-199): x_b <- y_b/(s+1e-6) - t. */
+int nfdp_coupling_fwd_f32(float* x, const float* h, int B, int HW, int C, double* ldj, const float* ldj_const,
+                          nfdp_stream_t stream);
+int nfdp_coupling_inv_f32(float* y, const float* h, int B, int HW, int C, nfdp_stream_t stream);
+/* ldj[b] += (double)(hw * (float)sum(v[0..n_sum)))  (fp32 product): the standalone ActNorm / InvConv2d log-det terms. */
+int nfdp_ldj_add_scaled_f32(double* ldj, int B, const float* v, int n_sum, float hw, nfdp_stream_t stream);
+/* out2[0] = hw*sum(scale[0..C)) (transforms.py:81), out2[1] = hw*logabsdet[0] (transforms.py:131), fp32: the two
+ * batch-independent log-det terms of one flow step, consumed by nfdp_coupling_fwd_f32's ldj_const. */
+int nfdp_flow_ldj_consts_f32(const float* scale, int C, const float* logabsdet, float hw, float* out2,
+                             nfdp_stream_t stream);
+
+/* ---------------------------------------------------------------- Gaussian prior (normalizing_flow/prior.py) */
+/* logp[b] += sum_{p,c} -0.5(log2pi + 2 logs + (z-mean)^2 exp(-2 logs))   (prior.py:36-37).
+ * z: [B,HW,Cz] with pixel stride z_ld.  mean/logs come from h: mean = h[..., 0:Cz), logs = h[..., Cz:2Cz).
+ * h_mode 0: h is [B,HW,2Cz] (Split prior, transforms.py:266-268); h_mode 1: h is [2Cz] broadcast over b,p
+ * (GaussianPrior with zero input, prior.py:79-82). */
+int nfdp_gauss_logp_f32(const float* z, int z_ld, const float* h, int h_mode, int B, int HW, int Cz, double* logp,
+                        nfdp_stream_t stream);
+/* out = mean + exp(logs)*temperature*eps  (prior.py:49-50); eps [B,HW,Cz] supplied by the caller. */
+int nfdp_gauss_sample_f32(const float* h, int h_mode, const float* eps, float* out, int out_ld, int B, int HW, int Cz,
+                          float temperature, nfdp_stream_t stream);
+/* GaussianPrior's degenerate conv on zeros (prior.py:79-80): h[n] = bias[n]*exp(3*logs[n]). */
+int nfdp_zeroconv_bias_only_f32(const float* bias, const float* logs, float* h, int n, nfdp_stream_t stream);
+
+/* ---------------------------------------------------------------- NLL plumbing (normalizing_flow/utils.py) */
+/* out[0] = sum_b bpd_b, out[1] = B, with bpd_b = (log(n_bins)*n_pixel - (ldj_b+logp_b))*log2(e)/n_pixel
+ * (utils.py:255-256; the mean is out[0]/out[1], left to the caller so ranks can all-reduce the pair). */
+int nfdp_bpd_sum_f64(const double* ldj, const double* logp, int B, double n_bins, double n_pixel, double* out,
+                     nfdp_stream_t stream);
+/* preprocess_batch + dequantisation noise, utils.py:189-196 + trainer.py:155:
+ * y = floor(u8 / 2^(8-n_bits)) / 2^n_bits - 0.5 + noise/2^n_bits   (noise may be NULL).  NCHW u8 in, NHWC f32 out. */
+int nfdp_preprocess_u8_nchw_to_nhwc_f32(const uint8_t* u8, const float* noise_nchw, float* y, int B, int C, int H,
+                                        int W, int n_bits, nfdp_stream_t stream);
+/* Same arithmetic for a float batch in [0,1] (what the reference's loaders deliver), elementwise, any layout:
+ * y = floor(x*255 / 2^(8-n_bits)) / 2^n_bits - 0.5 (+ noise/2^n_bits).  utils.py:189-196. */
+int nfdp_preprocess_f32(const float* x, const float* noise, float* y, long n, int n_bits, nfdp_stream_t stream);
+/* postprocess_batch, utils.py:210: clip(floor((x+.5)*n_bins)*256/n_bins, 0, 255) -> u8; NHWC f32 in, NCHW u8 out. */
+int nfdp_postprocess_nhwc_to_u8_nchw(const float* x, uint8_t* u8, int B, int C, int H, int W, float n_bins,
+                                     nfdp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFDP_H */

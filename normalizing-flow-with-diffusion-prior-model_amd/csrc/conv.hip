@@ -1,0 +1,401 @@
+// Stride-1 "same" convolution on NHWC tensors as an MFMA implicit GEMM for gfx950.
+//
+// Replaces the F.conv2d calls of the coupling network (normalizing_flow/utils.py:43-44, 67-69: 3x3 C/2->512,
+// 1x1 512->512, 3x3 512->C with the ActNorm / exp(3*logs) scale folded into the epilogue) and of the U-Net
+// (diffusion_prior/gaussian_diffusion.py: 7x7, 3x3, 1x1).
+//
+// GEMM view: D[p][n] = sum_k A[p][k] * Wp[n][k],  p = output pixel (M), n = output channel (N),
+//            k = (ky*KW+kx)*Cin + ci (K), A gathered on the fly (implicit im2col, zero padding).
+// MFMA:      compute=F32  -> v_mfma_f32_16x16x4_f32   (exact fp32 FMA chain; the 1e-4 parity mode)
+//            compute=BF16 -> v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the speed mode)
+// Both use the same 32-deep K tile: lane (r = lane&15, q = lane>>4) owns k = 8q..8q+7 of the tile for its row,
+// read from LDS as one (bf16) or two (fp32) 16-byte chunks.  For fp32 the eight 16x16x4 steps take k = 8q+kk,
+// kk = 0..7 — a permutation of the K order that A and B share, so the sum is unchanged.
+// LDS rows are 32 k wide (64 B bf16 / 128 B fp32) with the 16-byte chunk index XORed by (row>>1) so the
+// ds_read_b128 of 16 consecutive rows hits 16 distinct bank groups.
+// Pipeline: register-staged prefetch (global loads for tile t+1 issued before the MFMAs of tile t, written to
+// the other LDS buffer after them), one barrier per K tile.
+// Block->tile map is XCD-aware: the N tiles of one M tile run back to back on the same XCD (blockIdx%8 labels
+// the XCD group), so the gathered A rows are served from that XCD's L2 instead of HBM for N tiles 2..Nt.
+#include <type_traits>
+#include "nfdp_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int BK = 32;
+
+struct ConvParams {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* add;
+    const float* mul;
+    long npix;
+    int x_ld, y_ld, y_bf16;
+    int H, W, Cin, Cout, KH, KW, pad;
+    int K, Kpad, Mt, Nt, relu;
+    float mul_exp;
+};
+
+__device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
+    bf16x4 h;
+    h[0] = (__bf16)v.x; h[1] = (__bf16)v.y; h[2] = (__bf16)v.z; h[3] = (__bf16)v.w;
+    return __builtin_bit_cast(uint2, h);
+}
+
+template <bool BF16, bool XBF16, bool VEC, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    static_assert(!XBF16 || BF16, "bf16 storage needs bf16 compute");
+    constexpr int ROWB = BF16 ? 64 : 128;              // LDS bytes per 32-k row
+    constexpr int NCH = ROWB / 16;                     // 16-byte chunks per row
+    constexpr int SWZ = NCH - 1;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    constexpr int AR = BM / 32;                        // A rows staged per thread
+    constexpr int BCH = (BN * NCH + kThreads - 1) / kThreads;   // B chunks staged per thread
+    constexpr bool BFULL = (BN * NCH) % kThreads == 0;          // every thread stages BCH chunks: no bounds test
+    using AReg = typename std::conditional<XBF16, uint2, float4>::type;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // buffer b: A at smem + b*(A_BYTES+B_BYTES), B right behind it (computed, not table-indexed: stays in registers)
+
+    // ---- XCD-aware block -> (M tile, N tile)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int nt = slot % P.Nt;
+    const int mt = (slot / P.Nt) * 8 + xcd;
+    if (mt >= P.Mt) return;                            // whole block leaves together
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WTM, wn0 = (wave % WAVES_N) * WTN;
+    const int r16 = lane & 15, q = lane >> 4;
+
+    // ---- per-thread A staging rows
+    const int kq = tid & 7, rbase = tid >> 3;
+    int rp[AR], roy[AR], rox[AR];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const long p = m0 + rbase + 32 * i;
+        if (p < P.npix) {
+            rp[i] = (int)p;
+            rox[i] = (int)(p % P.W);
+            roy[i] = (int)((p / P.W) % P.H);
+        } else {
+            rp[i] = -1; rox[i] = 0; roy[i] = 0;
+        }
+    }
+    AReg areg[AR];
+    uint4 breg[BCH];
+
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + kq * 4;
+        if constexpr (VEC) {
+            const int tap = k / P.Cin, ci = k - tap * P.Cin;
+            const int ky = tap / P.KW, kx = tap - ky * P.KW;
+            const int dy = ky - P.pad, dx = kx - P.pad;
+            const bool kok = k < P.K;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int iy = roy[i] + dy, ix = rox[i] + dx;
+                const bool ok = kok && rp[i] >= 0 && (unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W;
+                const long off = ((long)rp[i] + dy * P.W + dx) * P.x_ld + ci;
+                if constexpr (XBF16) {
+                    uint2 v = make_uint2(0u, 0u);
+                    if (ok) v = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(P.x) + off);
+                    areg[i] = __builtin_bit_cast(AReg, v);
+                } else {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ok) v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(P.x) + off);
+                    areg[i] = __builtin_bit_cast(AReg, v);
+                }
+            }
+        } else {
+            int tapj[4], cij[4];
+            bool kokj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = k + j;
+                tapj[j] = kk / P.Cin;
+                cij[j] = kk - tapj[j] * P.Cin;
+                kokj[j] = kk < P.K;
+            }
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ky = tapj[j] / P.KW, kx = tapj[j] - ky * P.KW;
+                    const int dy = ky - P.pad, dx = kx - P.pad;
+                    const int iy = roy[i] + dy, ix = rox[i] + dx;
+                    const bool ok = kokj[j] && rp[i] >= 0 && (unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W;
+                    const long off = ((long)rp[i] + dy * P.W + dx) * P.x_ld + cij[j];
+                    float v = 0.f;
+                    if (ok) v = XBF16 ? (float)reinterpret_cast<const __bf16*>(P.x)[off] : reinterpret_cast<const float*>(P.x)[off];
+                    e[j] = v;
+                }
+                const float4 f = make_float4(e[0], e[1], e[2], e[3]);
+                if constexpr (XBF16) areg[i] = __builtin_bit_cast(AReg, pack_bf16x4(f));
+                else areg[i] = __builtin_bit_cast(AReg, f);
+            }
+        }
+        // weights: packed [Cout_pad][Kpad], 16-byte chunks of the current k tile
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int idx = tid + i * kThreads;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (BFULL || idx < BN * NCH) {
+                const int n = idx / NCH, c = idx % NCH;
+                const char* src = reinterpret_cast<const char*>(P.w) +
+                                  ((long)(n0 + n) * P.Kpad + (long)kt * BK) * (BF16 ? 2 : 4) + c * 16;
+                v = *reinterpret_cast<const uint4*>(src);
+            }
+            breg[i] = v;
+        }
+    };
+
+    auto store_tile = [&](int buf) {
+        char* A = smem + buf * (A_BYTES + B_BYTES);
+        char* Bs = A + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int r = rbase + 32 * i;
+            if constexpr (BF16) {
+                uint2 v;
+                if constexpr (XBF16) v = __builtin_bit_cast(uint2, areg[i]);
+                else v = pack_bf16x4(__builtin_bit_cast(float4, areg[i]));
+                *reinterpret_cast<uint2*>(A + r * ROWB + (((kq >> 1) ^ ((r >> 1) & SWZ)) << 4) + ((kq & 1) << 3)) = v;
+            } else {
+                *reinterpret_cast<float4*>(A + r * ROWB + ((kq ^ ((r >> 1) & SWZ)) << 4)) = __builtin_bit_cast(float4, areg[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BCH; ++i) {
+            const int idx = tid + i * kThreads;
+            if (BFULL || idx < BN * NCH) {
+                const int n = idx / NCH, c = idx % NCH;
+                *reinterpret_cast<uint4*>(Bs + n * ROWB + ((c ^ ((n >> 1) & SWZ)) << 4)) = breg[i];
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute_tile = [&](int buf) {
+        const char* A = smem + buf * (A_BYTES + B_BYTES);
+        const char* Bs = A + A_BYTES;
+        if constexpr (BF16) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm0 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const bf16x8*>(A + r * ROWB + ((q ^ ((r >> 1) & SWZ)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn0 + j * 16 + r16;
+                b[j] = *reinterpret_cast<const bf16x8*>(Bs + n * ROWB + ((q ^ ((n >> 1) & SWZ)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        } else {
+            float a[TM][8], b[TN][8];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm0 + i * 16 + r16;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 v = *reinterpret_cast<const float4*>(A + r * ROWB + (((2 * q + h) ^ ((r >> 1) & SWZ)) << 4));
+                    a[i][4 * h] = v.x; a[i][4 * h + 1] = v.y; a[i][4 * h + 2] = v.z; a[i][4 * h + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn0 + j * 16 + r16;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 v = *reinterpret_cast<const float4*>(Bs + n * ROWB + (((2 * q + h) ^ ((n >> 1) & SWZ)) << 4));
+                    b[j][4 * h] = v.x; b[j][4 * h + 1] = v.y; b[j][4 * h + 2] = v.z; b[j][4 * h + 3] = v.w;
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nkt = P.Kpad / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) load_tile(kt + 1);
+        compute_tile(cur);
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: v = (acc + add[n]) * mul[n]; relu; store fp32 or bf16
+    //      C/D map of the 16x16 MFMA: col = lane&15 (n), row = 4*(lane>>4) + reg (pixel)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 16 + r16;
+        const bool nok = n < P.Cout;
+        const float addv = (nok && P.add) ? P.add[n] : 0.f;
+        float mulv = (nok && P.mul) ? P.mul[n] : 1.f;
+        if (P.mul && P.mul_exp != 0.f) mulv = expf(__fmul_rn(mulv, P.mul_exp));   // exp(scale) / exp(3*logs)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const long p = m0 + wm0 + i * 16 + 4 * q + rg;
+                if (nok && p < P.npix) {
+                    float v = acc[i][j][rg];
+                    if (P.add) v = __fadd_rn(v, addv);
+                    if (P.mul) v = __fmul_rn(v, mulv);
+                    if (P.relu) v = fmaxf(v, 0.f);
+                    if (P.y_bf16) reinterpret_cast<__bf16*>(P.y)[p * P.y_ld + n] = (__bf16)v;
+                    else reinterpret_cast<float*>(P.y)[p * P.y_ld + n] = v;
+                }
+            }
+        }
+    }
+}
+
+// OIHW fp32 -> [Cout_pad][Kpad] in the compute dtype, k = (ky*KW+kx)*Cin+ci, zero padded
+template <bool BF16>
+__global__ void pack_weights_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int KH, int KW,
+                                    int K, int Kpad, long total) {
+    for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const int k = (int)(i % Kpad);
+        const int n = (int)(i / Kpad);
+        float v = 0.f;
+        if (n < Cout && k < K) {
+            const int tap = k / Cin, ci = k - tap * Cin;
+            const int ky = tap / KW, kx = tap - ky * KW;
+            v = w[(((long)n * Cin + ci) * KH + ky) * KW + kx];
+        }
+        if (BF16) reinterpret_cast<__bf16*>(out)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(out)[i] = v;
+    }
+}
+
+inline int tile_n_for(int Cout) {
+    if (Cout <= 16) return 16;
+    if (Cout <= 32) return 32;
+    if (Cout <= 48) return 48;
+    if (Cout <= 64) return 64;
+    return 128;
+}
+inline int cout_pad_for(int Cout) {
+    const int bn = tile_n_for(Cout);
+    return (int)(cdiv(Cout, bn) * bn);
+}
+inline int kpad_for(int Cin, int KH, int KW) { return (int)(cdiv((long)Cin * KH * KW, BK) * BK); }
+
+template <bool BF16, bool XBF16, bool VEC, int BM, int BN, int WAVES_M, int WAVES_N>
+void launch_cfg(ConvParams& P, hipStream_t s) {
+    P.Mt = (int)cdiv(P.npix, BM);
+    P.Nt = cout_pad_for(P.Cout) / BN;
+    const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
+    const size_t lds = 2 * (size_t)(BM + BN) * (BF16 ? 64 : 128);
+    static bool attr_set = false;   // > 64 KB of dynamic LDS must be opted into once per kernel
+    if (lds > 65536 && !attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BF16, XBF16, VEC, BM, BN, WAVES_M, WAVES_N>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_kernel<BF16, XBF16, VEC, BM, BN, WAVES_M, WAVES_N>), dim3(grid), dim3(kThreads), lds, s, P);
+}
+
+template <bool BF16, bool XBF16, bool VEC>
+void launch_by_cout(ConvParams& P, hipStream_t s) {
+    switch (tile_n_for(P.Cout)) {
+        case 16: launch_cfg<BF16, XBF16, VEC, 256, 16, 4, 1>(P, s); break;
+        case 32: launch_cfg<BF16, XBF16, VEC, 256, 32, 4, 1>(P, s); break;
+        case 48: launch_cfg<BF16, XBF16, VEC, 256, 48, 4, 1>(P, s); break;
+        case 64: launch_cfg<BF16, XBF16, VEC, 128, 64, 4, 1>(P, s); break;
+        default: launch_cfg<BF16, XBF16, VEC, 128, 128, 2, 2>(P, s); break;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t nfdp_conv_packed_bytes(int Cout, int Cin, int KH, int KW, int compute) {
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
+    return (size_t)cout_pad_for(Cout) * kpad_for(Cin, KH, KW) * (compute == NFDP_BF16 ? 2 : 4);
+}
+
+extern "C" int nfdp_conv_pack_weights(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, int compute,
+                                      nfdp_stream_t stream) {
+    NFDP_REQUIRE(w_oihw && w_packed, NFDP_EINVAL, "conv_pack_weights: null pointer");
+    NFDP_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW > 0, NFDP_ESHAPE, "conv_pack_weights: bad shape");
+    NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_BF16, NFDP_EINVAL, "conv_pack_weights: compute=%d", compute);
+    const int K = Cin * KH * KW, Kpad = kpad_for(Cin, KH, KW);
+    const long total = (long)cout_pad_for(Cout) * Kpad;
+    const int grid = stream_grid(total, kThreads);
+    if (compute == NFDP_BF16)
+        hipLaunchKernelGGL((pack_weights_kernel<true>), dim3(grid), dim3(kThreads), 0, as_stream(stream), w_oihw, w_packed,
+                           Cout, Cin, KH, KW, K, Kpad, total);
+    else
+        hipLaunchKernelGGL((pack_weights_kernel<false>), dim3(grid), dim3(kThreads), 0, as_stream(stream), w_oihw, w_packed,
+                           Cout, Cin, KH, KW, K, Kpad, total);
+    NFDP_CHECK_LAUNCH("conv_pack_weights");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
+                                int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
+                                float mul_exp, int relu, int compute, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && w_packed && y, NFDP_EINVAL, "conv2d: null pointer");
+    NFDP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NFDP_ESHAPE, "conv2d: bad shape");
+    NFDP_REQUIRE(KH == KW && (KH % 2) == 1 && KH <= 7, NFDP_EUNSUPPORTED, "conv2d: kernel %dx%d (odd square <= 7 only)", KH, KW);
+    NFDP_REQUIRE(x_ld >= Cin && y_ld >= Cout, NFDP_ESHAPE, "conv2d: ld smaller than channel count");
+    NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_BF16, NFDP_EINVAL, "conv2d: compute=%d", compute);
+    NFDP_REQUIRE((x_dtype == NFDP_F32 || x_dtype == NFDP_BF16) && (y_dtype == NFDP_F32 || y_dtype == NFDP_BF16), NFDP_EINVAL,
+                 "conv2d: bad dtype");
+    NFDP_REQUIRE(compute == NFDP_BF16 || (x_dtype == NFDP_F32 && y_dtype == NFDP_F32), NFDP_EUNSUPPORTED,
+                 "conv2d: bf16 storage requires bf16 compute");
+    const long npix = (long)B * H * W;
+    NFDP_REQUIRE(npix < (1L << 31) - 4096, NFDP_ESHAPE, "conv2d: too many pixels (%ld)", npix);
+    if (npix == 0) return NFDP_OK;
+    ConvParams P;
+    P.x = x; P.w = w_packed; P.y = y; P.add = add; P.mul = mul; P.npix = npix;
+    P.x_ld = x_ld; P.y_ld = y_ld; P.y_bf16 = (y_dtype == NFDP_BF16);
+    P.H = H; P.W = W; P.Cin = Cin; P.Cout = Cout; P.KH = KH; P.KW = KW; P.pad = (KH - 1) / 2;
+    P.K = Cin * KH * KW; P.Kpad = kpad_for(Cin, KH, KW); P.relu = relu; P.Mt = 0; P.Nt = 0; P.mul_exp = mul_exp;
+    const int esz = (x_dtype == NFDP_BF16) ? 2 : 4;
+    // vector path: 4 consecutive k stay inside one tap and the 4-element load is naturally aligned
+    const bool vec = (Cin % 4 == 0) && (x_ld % 4 == 0) && (((uintptr_t)x) % (4 * esz) == 0);
+    hipStream_t s = as_stream(stream);
+    if (compute == NFDP_F32) {
+        if (vec) launch_by_cout<false, false, true>(P, s);
+        else launch_by_cout<false, false, false>(P, s);
+    } else if (x_dtype == NFDP_BF16) {
+        if (vec) launch_by_cout<true, true, true>(P, s);
+        else launch_by_cout<true, true, false>(P, s);
+    } else {
+        if (vec) launch_by_cout<true, false, true>(P, s);
+        else launch_by_cout<true, false, false>(P, s);
+    }
+    NFDP_CHECK_LAUNCH("conv2d");
+    return NFDP_OK;
+}

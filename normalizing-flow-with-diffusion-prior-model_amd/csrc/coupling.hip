@@ -1,0 +1,242 @@
+// Affine-coupling epilogue, Gaussian log-density / sampling, and the bits-per-dim reduction.
+// Reference: AffineCoupling.transform/invert  normalizing_flow/transforms.py:179-185, :196-200
+//            IsotropicGaussian               normalizing_flow/prior.py:36-37, :49-50
+//            GaussianPrior (zero-input conv) normalizing_flow/prior.py:79-82
+//            calculate_loss                  normalizing_flow/utils.py:255-256
+// All per-sample sums run in one workgroup per sample with fp64 partials and a fixed combine order
+// (lane shuffle tree -> wave partials in LDS -> serial over the 4 waves), so results are deterministic.
+#include "nfdp_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr float kLog2Pi = 1.8378770664093453f;   // float(np.log(2*np.pi)), prior.py:24
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = wave_sum_d(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < kBlock / 64; ++i) s += red[i];
+    return s;   // valid in thread 0
+}
+
+__device__ __forceinline__ float sigmoid_p2(float log_s) {   // torch.sigmoid(log_s + 2.0)
+    const float v = __fadd_rn(log_s, 2.0f);
+    return 1.0f / (1.0f + expf(-v));
+}
+
+template <bool INV>
+__global__ void __launch_bounds__(kBlock) coupling_kernel(float* __restrict__ x, const float* __restrict__ h, int HW,
+                                                          int C, double* __restrict__ ldj,
+                                                          const float* __restrict__ ldj_const) {
+    __shared__ double red[kBlock / 64];
+    const int Ch = C >> 1;
+    const long base = (long)blockIdx.x * HW * C;
+    const int n = HW * Ch;
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n; e += kBlock) {
+        const int p = e / Ch, c = e - p * Ch;
+        const long row = base + (long)p * C;
+        const float log_s = h[row + c];
+        const float t = h[row + Ch + c];
+        const float s = sigmoid_p2(log_s);
+        const float xb = x[row + Ch + c];
+        if (!INV) {
+            x[row + Ch + c] = __fmul_rn(__fadd_rn(xb, t), s);                        // (x_b + t) * s
+            acc += (double)logf(__fadd_rn(s, 1e-6f));
+        } else {
+            x[row + Ch + c] = __fsub_rn(__fdiv_rn(xb, __fadd_rn(s, 1e-6f)), t);       // y_b/(s+1e-6) - t
+        }
+    }
+    if (!INV && ldj) {
+        const double s = block_sum_d(acc, red);
+        if (threadIdx.x == 0) {
+            double v = ldj[blockIdx.x];
+            if (ldj_const) v = (v + (double)ldj_const[0]) + (double)ldj_const[1];
+            ldj[blockIdx.x] = v + s;
+        }
+    }
+}
+
+// H_MODE 0: h [B,HW,2Cz]; 1: h [2Cz] broadcast
+template <int H_MODE>
+__global__ void __launch_bounds__(kBlock) gauss_logp_kernel(const float* __restrict__ z, int z_ld,
+                                                            const float* __restrict__ h, int HW, int Cz,
+                                                            double* __restrict__ logp) {
+    __shared__ double red[kBlock / 64];
+    const long zb = (long)blockIdx.x * HW * z_ld;
+    const long hb = (long)blockIdx.x * HW * 2 * Cz;
+    const int n = HW * Cz;
+    double acc = 0.0;
+    for (int e = threadIdx.x; e < n; e += kBlock) {
+        const int p = e / Cz, c = e - p * Cz;
+        const float zv = z[zb + (long)p * z_ld + c];
+        const float mean = H_MODE == 0 ? h[hb + (long)p * 2 * Cz + c] : h[c];
+        const float logs = H_MODE == 0 ? h[hb + (long)p * 2 * Cz + Cz + c] : h[Cz + c];
+        const float d = __fsub_rn(zv, mean);
+        // -0.5 * (Log2PI + 2*logs + d^2 * exp(-2*logs)), fp32 op by op as prior.py:36
+        const float t = __fmul_rn(__fmul_rn(d, d), expf(__fmul_rn(-2.0f, logs)));
+        const float lp = __fmul_rn(-0.5f, __fadd_rn(__fadd_rn(kLog2Pi, __fmul_rn(2.0f, logs)), t));
+        acc += (double)lp;
+    }
+    const double s = block_sum_d(acc, red);
+    if (threadIdx.x == 0) logp[blockIdx.x] += s;
+}
+
+template <int H_MODE>
+__global__ void __launch_bounds__(kBlock) gauss_sample_kernel(const float* __restrict__ h, const float* __restrict__ eps,
+                                                              float* __restrict__ out, int out_ld, long total, int HW,
+                                                              int Cz, float temperature) {
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const int c = (int)(i % Cz);
+        const long bp = i / Cz;
+        const float mean = H_MODE == 0 ? h[bp * 2 * Cz + c] : h[c];
+        const float logs = H_MODE == 0 ? h[bp * 2 * Cz + Cz + c] : h[Cz + c];
+        // mean + (exp(logs) * T) * eps, prior.py:50
+        out[bp * out_ld + c] = __fadd_rn(mean, __fmul_rn(__fmul_rn(expf(logs), temperature), eps[i]));
+    }
+}
+
+__global__ void zeroconv_bias_only_kernel(const float* __restrict__ bias, const float* __restrict__ logs,
+                                          float* __restrict__ h, int n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) h[i] = __fmul_rn(bias[i], expf(__fmul_rn(logs[i], 3.0f)));   // (0 + bias) * exp(logs*3), utils.py:44
+}
+
+// ldj[b] += (double)( hw * (float)sum_i v[i] )
+__global__ void __launch_bounds__(kBlock) ldj_add_scaled_kernel(double* __restrict__ ldj, int B,
+                                                                const float* __restrict__ v, int n_sum, float hw) {
+    __shared__ double red[kBlock / 64];
+    __shared__ float term;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_sum; i += kBlock) acc += (double)v[i];
+    const double s = block_sum_d(acc, red);
+    if (threadIdx.x == 0) term = __fmul_rn(hw, (float)s);
+    __syncthreads();
+    const double t = (double)term;
+    for (int b = threadIdx.x; b < B; b += kBlock) ldj[b] += t;
+}
+
+// out[0] = hw*sum(scale) (transforms.py:81), out[1] = hw*logabsdet (transforms.py:131), both fp32
+__global__ void __launch_bounds__(kBlock) flow_ldj_consts_kernel(const float* __restrict__ scale, int C,
+                                                                 const float* __restrict__ logabsdet, float hw,
+                                                                 float* __restrict__ out) {
+    __shared__ double red[kBlock / 64];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < C; i += kBlock) acc += (double)scale[i];
+    const double s = block_sum_d(acc, red);
+    if (threadIdx.x == 0) {
+        out[0] = __fmul_rn(hw, (float)s);
+        out[1] = __fmul_rn(hw, logabsdet[0]);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) bpd_sum_kernel(const double* __restrict__ ldj, const double* __restrict__ logp,
+                                                         int B, double n_bins, double n_pixel, double* __restrict__ out) {
+    __shared__ double red[kBlock / 64];
+    const double c = 1.4426950408889634 / n_pixel;        // np.log2(np.e) / n_pixel
+    const double k = log(n_bins) * n_pixel;
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < B; b += kBlock) {
+        const double ll = ldj[b] + (logp ? logp[b] : 0.0);
+        acc += (k - ll) * c;
+    }
+    const double s = block_sum_d(acc, red);
+    if (threadIdx.x == 0) {
+        out[0] = s;
+        out[1] = (double)B;
+    }
+}
+
+}  // namespace
+
+extern "C" int nfdp_coupling_fwd_f32(float* x, const float* h, int B, int HW, int C, double* ldj, const float* ldj_const,
+                                     nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && h, NFDP_EINVAL, "coupling_fwd: null pointer");
+    NFDP_REQUIRE(B >= 0 && HW > 0 && C > 0, NFDP_ESHAPE, "coupling_fwd: bad shape");
+    NFDP_REQUIRE(C % 2 == 0, NFDP_ESHAPE, "coupling_fwd: C=%d must be even", C);
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL((coupling_kernel<false>), dim3(B), dim3(kBlock), 0, as_stream(stream), x, h, HW, C, ldj, ldj_const);
+    NFDP_CHECK_LAUNCH("coupling_fwd");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_coupling_inv_f32(float* y, const float* h, int B, int HW, int C, nfdp_stream_t stream) {
+    NFDP_REQUIRE(y && h, NFDP_EINVAL, "coupling_inv: null pointer");
+    NFDP_REQUIRE(B >= 0 && HW > 0 && C > 0, NFDP_ESHAPE, "coupling_inv: bad shape");
+    NFDP_REQUIRE(C % 2 == 0, NFDP_ESHAPE, "coupling_inv: C=%d must be even", C);
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL((coupling_kernel<true>), dim3(B), dim3(kBlock), 0, as_stream(stream), y, h, HW, C, nullptr, nullptr);
+    NFDP_CHECK_LAUNCH("coupling_inv");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_ldj_add_scaled_f32(double* ldj, int B, const float* v, int n_sum, float hw, nfdp_stream_t stream) {
+    NFDP_REQUIRE(ldj && v, NFDP_EINVAL, "ldj_add_scaled: null pointer");
+    NFDP_REQUIRE(B >= 0 && n_sum > 0, NFDP_ESHAPE, "ldj_add_scaled: bad shape");
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL(ldj_add_scaled_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), ldj, B, v, n_sum, hw);
+    NFDP_CHECK_LAUNCH("ldj_add_scaled");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_flow_ldj_consts_f32(const float* scale, int C, const float* logabsdet, float hw, float* out2,
+                                        nfdp_stream_t stream) {
+    NFDP_REQUIRE(scale && logabsdet && out2, NFDP_EINVAL, "flow_ldj_consts: null pointer");
+    NFDP_REQUIRE(C > 0, NFDP_ESHAPE, "flow_ldj_consts: bad C");
+    hipLaunchKernelGGL(flow_ldj_consts_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), scale, C, logabsdet, hw, out2);
+    NFDP_CHECK_LAUNCH("flow_ldj_consts");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_gauss_logp_f32(const float* z, int z_ld, const float* h, int h_mode, int B, int HW, int Cz,
+                                   double* logp, nfdp_stream_t stream) {
+    NFDP_REQUIRE(z && h && logp, NFDP_EINVAL, "gauss_logp: null pointer");
+    NFDP_REQUIRE(B >= 0 && HW > 0 && Cz > 0 && z_ld >= Cz, NFDP_ESHAPE, "gauss_logp: bad shape");
+    NFDP_REQUIRE(h_mode == 0 || h_mode == 1, NFDP_EINVAL, "gauss_logp: h_mode=%d", h_mode);
+    if (B == 0) return NFDP_OK;
+    if (h_mode == 0)
+        hipLaunchKernelGGL((gauss_logp_kernel<0>), dim3(B), dim3(kBlock), 0, as_stream(stream), z, z_ld, h, HW, Cz, logp);
+    else
+        hipLaunchKernelGGL((gauss_logp_kernel<1>), dim3(B), dim3(kBlock), 0, as_stream(stream), z, z_ld, h, HW, Cz, logp);
+    NFDP_CHECK_LAUNCH("gauss_logp");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_gauss_sample_f32(const float* h, int h_mode, const float* eps, float* out, int out_ld, int B, int HW,
+                                     int Cz, float temperature, nfdp_stream_t stream) {
+    NFDP_REQUIRE(h && eps && out, NFDP_EINVAL, "gauss_sample: null pointer");
+    NFDP_REQUIRE(B >= 0 && HW > 0 && Cz > 0 && out_ld >= Cz, NFDP_ESHAPE, "gauss_sample: bad shape");
+    NFDP_REQUIRE(h_mode == 0 || h_mode == 1, NFDP_EINVAL, "gauss_sample: h_mode=%d", h_mode);
+    const long total = (long)B * HW * Cz;
+    if (total == 0) return NFDP_OK;
+    if (h_mode == 0)
+        hipLaunchKernelGGL((gauss_sample_kernel<0>), dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, as_stream(stream),
+                           h, eps, out, out_ld, total, HW, Cz, temperature);
+    else
+        hipLaunchKernelGGL((gauss_sample_kernel<1>), dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, as_stream(stream),
+                           h, eps, out, out_ld, total, HW, Cz, temperature);
+    NFDP_CHECK_LAUNCH("gauss_sample");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_zeroconv_bias_only_f32(const float* bias, const float* logs, float* h, int n, nfdp_stream_t stream) {
+    NFDP_REQUIRE(bias && logs && h, NFDP_EINVAL, "zeroconv_bias_only: null pointer");
+    NFDP_REQUIRE(n > 0, NFDP_ESHAPE, "zeroconv_bias_only: bad n");
+    hipLaunchKernelGGL(zeroconv_bias_only_kernel, dim3((int)cdiv(n, kBlock)), dim3(kBlock), 0, as_stream(stream), bias, logs,
+                       h, n);
+    NFDP_CHECK_LAUNCH("zeroconv_bias_only");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_bpd_sum_f64(const double* ldj, const double* logp, int B, double n_bins, double n_pixel, double* out,
+                                nfdp_stream_t stream) {
+    NFDP_REQUIRE(ldj && out, NFDP_EINVAL, "bpd_sum: null pointer");
+    NFDP_REQUIRE(B > 0 && n_bins > 0 && n_pixel > 0, NFDP_ESHAPE, "bpd_sum: bad arguments");
+    hipLaunchKernelGGL(bpd_sum_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), ldj, logp, B, n_bins, n_pixel, out);
+    NFDP_CHECK_LAUNCH("bpd_sum");
+    return NFDP_OK;
+}

@@ -1,0 +1,238 @@
+// ActNorm and the invertible 1x1 convolution on NHWC fp32 tensors, standalone and fused.
+//
+// Reference arithmetic:  ActNorm.transform/invert  normalizing_flow/transforms.py:80, :93
+//                        InvConv2d.transform/invert normalizing_flow/transforms.py:132, :144
+//                        StepFlow ordering          normalizing_flow/glow.py:46-47, :61-62
+//
+// Both ops are HBM-bound (2*C*4 bytes per pixel, C..C^2 FMAs).  Design for gfx950:
+//   * affine-only kernels stream float4 per lane (16 B/lane coalesced), exp(scale) staged once per block in LDS;
+//   * the per-pixel CxC product stages a 256-pixel tile through LDS with coalesced float4 global loads, gives
+//     each lane one pixel (row stride C+1 words -> conflict-free ds_read_b32), keeps the pixel's C values in
+//     VGPRs and reads W through the scalar cache (uniform addresses -> s_load, W lives in SGPRs), so the VALU
+//     does one v_fma per MAC and nothing else; results go back through the same LDS tile and leave with
+//     coalesced float4 stores.  ActNorm is folded in as a pre-affine (forward) or post-affine (inverse), so a
+//     flow head costs one HBM round trip instead of two.
+#include "nfdp_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+enum Mode { kMatvec = 0, kPreAffine = 1, kPostAffine = 2 };
+
+// ----------------------------------------------------------------------------- affine-only (ActNorm alone)
+template <bool INV, bool VEC4>
+__global__ void __launch_bounds__(kBlock) actnorm_kernel(const float* __restrict__ x, float* __restrict__ y, long total,
+                                                         int C, const float* __restrict__ scale,
+                                                         const float* __restrict__ bias) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [C] exp(+-scale), [C] bias
+    float* es = smem;
+    float* bs = smem + C;
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+        es[c] = expf(INV ? -scale[c] : scale[c]);
+        bs[c] = bias[c];
+    }
+    __syncthreads();
+    if (VEC4) {
+        const long n4 = total >> 2;
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4* y4 = reinterpret_cast<float4*>(y);
+        for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < n4; i += (long)gridDim.x * kBlock) {
+            const int c = (int)((i << 2) % C);
+            float4 v = x4[i];
+            if (!INV) {
+                v.x = es[c] * (v.x + bs[c]);
+                v.y = es[c + 1] * (v.y + bs[c + 1]);
+                v.z = es[c + 2] * (v.z + bs[c + 2]);
+                v.w = es[c + 3] * (v.w + bs[c + 3]);
+            } else {
+                v.x = __fsub_rn(__fmul_rn(v.x, es[c]), bs[c]);
+                v.y = __fsub_rn(__fmul_rn(v.y, es[c + 1]), bs[c + 1]);
+                v.z = __fsub_rn(__fmul_rn(v.z, es[c + 2]), bs[c + 2]);
+                v.w = __fsub_rn(__fmul_rn(v.w, es[c + 3]), bs[c + 3]);
+            }
+            y4[i] = v;
+        }
+    } else {
+        for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+            const int c = (int)(i % C);
+            const float v = x[i];
+            y[i] = INV ? __fsub_rn(__fmul_rn(v, es[c]), bs[c]) : es[c] * (v + bs[c]);
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- per-pixel CxC product, C templated
+// One 256-pixel tile per block iteration (grid-stride over tiles).
+template <int C, int MODE>
+__global__ void __launch_bounds__(kBlock) pixel_linear_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              long npix, const float* __restrict__ w,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ bias) {
+    constexpr int LD = C + 1;                       // odd word stride: lane l reads bank (l*LD+c)%32, all distinct
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tile = smem;                             // [kBlock][LD]
+    float* es = smem + kBlock * LD;                 // [C]
+    float* bs = es + C;                             // [C]
+    if (MODE != kMatvec) {
+        for (int c = threadIdx.x; c < C; c += kBlock) {
+            es[c] = expf(MODE == kPostAffine ? -scale[c] : scale[c]);
+            bs[c] = bias[c];
+        }
+    }
+    const long ntiles = (npix + kBlock - 1) / kBlock;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const long p0 = t * kBlock;
+        const int np = (int)((npix - p0) < kBlock ? (npix - p0) : kBlock);
+        const int nval = np * C;
+        __syncthreads();                            // previous iteration's stores done with the tile; es/bs visible
+        const float* src = x + p0 * C;
+        if (C % 4 == 0) {
+            const float4* src4 = reinterpret_cast<const float4*>(src);
+            for (int i = threadIdx.x; i < (nval >> 2); i += kBlock) {
+                const float4 v = src4[i];
+                const int e = i << 2;
+                const int r = e / C, c = e % C;      // C%4==0: the 4 values stay inside one pixel row
+                float* d = tile + r * LD + c;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int e = threadIdx.x; e < nval; e += kBlock) tile[(e / C) * LD + (e % C)] = src[e];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < np) {
+            float* row = tile + threadIdx.x * LD;
+            float v[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                v[c] = row[c];
+                if (MODE == kPreAffine) v[c] = es[c] * (v[c] + bs[c]);
+            }
+#pragma unroll 4
+            for (int o = 0; o < C; ++o) {
+                const float* wr = w + o * C;         // uniform address -> scalar loads
+                float acc = 0.0f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc = fmaf(wr[c], v[c], acc);
+                if (MODE == kPostAffine) acc = __fsub_rn(__fmul_rn(acc, es[o]), bs[o]);
+                row[o] = acc;                        // own row only: no hazard with other lanes
+            }
+        }
+        __syncthreads();
+        float* dst = y + p0 * C;
+        if (C % 4 == 0) {
+            float4* dst4 = reinterpret_cast<float4*>(dst);
+            for (int i = threadIdx.x; i < (nval >> 2); i += kBlock) {
+                const int e = i << 2;
+                const float* s = tile + (e / C) * LD + (e % C);
+                dst4[i] = make_float4(s[0], s[1], s[2], s[3]);
+            }
+        } else {
+            for (int e = threadIdx.x; e < nval; e += kBlock) dst[e] = tile[(e / C) * LD + (e % C)];
+        }
+    }
+}
+
+// Any C (runtime): one thread per output element; x row re-read through L1, W through L2.  Correctness path for
+// channel counts without a templated instance (the MFMA 1x1 conv serves large C on the fast path).
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) pixel_linear_generic_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                      long total, int C, const float* __restrict__ w,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ bias) {
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const int o = (int)(i % C);
+        const long p = i / C;
+        const float* xr = x + p * C;
+        const float* wr = w + (long)o * C;
+        float acc = 0.0f;
+        for (int c = 0; c < C; ++c) {
+            float v = xr[c];
+            if (MODE == kPreAffine) v = expf(scale[c]) * (v + bias[c]);
+            acc = fmaf(wr[c], v, acc);
+        }
+        if (MODE == kPostAffine) acc = __fsub_rn(__fmul_rn(acc, expf(-scale[o])), bias[o]);
+        y[i] = acc;
+    }
+}
+
+template <int C, int MODE>
+int launch_templated(const float* x, float* y, long npix, const float* w, const float* scale, const float* bias,
+                     hipStream_t s) {
+    const size_t lds = ((size_t)kBlock * (C + 1) + 2 * C) * sizeof(float);
+    const long ntiles = cdiv(npix, kBlock);
+    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
+    hipLaunchKernelGGL((pixel_linear_kernel<C, MODE>), dim3(grid), dim3(kBlock), lds, s, x, y, npix, w, scale, bias);
+    return NFDP_OK;
+}
+
+template <int MODE>
+int dispatch(const char* what, const float* x, float* y, long npix, int C, const float* w, const float* scale,
+             const float* bias, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && y && w, NFDP_EINVAL, "%s: null pointer", what);
+    NFDP_REQUIRE(MODE == kMatvec || (scale && bias), NFDP_EINVAL, "%s: null scale/bias", what);
+    NFDP_REQUIRE(npix >= 0 && C > 0, NFDP_ESHAPE, "%s: bad shape npix=%ld C=%d", what, npix, C);
+    if (npix == 0) return NFDP_OK;
+    hipStream_t s = as_stream(stream);
+    switch (C) {
+        case 4: launch_templated<4, MODE>(x, y, npix, w, scale, bias, s); break;
+        case 8: launch_templated<8, MODE>(x, y, npix, w, scale, bias, s); break;
+        case 12: launch_templated<12, MODE>(x, y, npix, w, scale, bias, s); break;
+        case 16: launch_templated<16, MODE>(x, y, npix, w, scale, bias, s); break;
+        case 24: launch_templated<24, MODE>(x, y, npix, w, scale, bias, s); break;
+        case 48: launch_templated<48, MODE>(x, y, npix, w, scale, bias, s); break;
+        default: {
+            NFDP_REQUIRE(x != y, NFDP_EINVAL, "%s: in-place needs a templated C (got %d)", what, C);
+            const long total = npix * C;
+            hipLaunchKernelGGL((pixel_linear_generic_kernel<MODE>), dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, s,
+                               x, y, total, C, w, scale, bias);
+        }
+    }
+    NFDP_CHECK_LAUNCH(what);
+    return NFDP_OK;
+}
+
+template <bool INV>
+int launch_actnorm(const char* what, const float* x, float* y, long npix, int C, const float* scale, const float* bias,
+                   nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && y && scale && bias, NFDP_EINVAL, "%s: null pointer", what);
+    NFDP_REQUIRE(npix >= 0 && C > 0 && C <= 8192, NFDP_ESHAPE, "%s: bad shape npix=%ld C=%d", what, npix, C);
+    if (npix == 0) return NFDP_OK;
+    const long total = npix * C;
+    const size_t lds = 2 * (size_t)C * sizeof(float);
+    const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL((actnorm_kernel<INV, true>), dim3(stream_grid(total >> 2, kBlock)), dim3(kBlock), lds,
+                           as_stream(stream), x, y, total, C, scale, bias);
+    else
+        hipLaunchKernelGGL((actnorm_kernel<INV, false>), dim3(stream_grid(total, kBlock)), dim3(kBlock), lds,
+                           as_stream(stream), x, y, total, C, scale, bias);
+    NFDP_CHECK_LAUNCH(what);
+    return NFDP_OK;
+}
+
+}  // namespace
+
+extern "C" int nfdp_actnorm_fwd_f32(const float* x, float* y, long npix, int C, const float* scale, const float* bias,
+                                    nfdp_stream_t stream) {
+    return launch_actnorm<false>("actnorm_fwd", x, y, npix, C, scale, bias, stream);
+}
+
+extern "C" int nfdp_actnorm_inv_f32(const float* y, float* x, long npix, int C, const float* scale, const float* bias,
+                                    nfdp_stream_t stream) {
+    return launch_actnorm<true>("actnorm_inv", y, x, npix, C, scale, bias, stream);
+}
+
+extern "C" int nfdp_invconv_apply_f32(const float* x, float* y, long npix, int C, const float* w, nfdp_stream_t stream) {
+    return dispatch<kMatvec>("invconv_apply", x, y, npix, C, w, nullptr, nullptr, stream);
+}
+
+extern "C" int nfdp_actnorm_invconv_fwd_f32(const float* x, float* y, long npix, int C, const float* scale,
+                                            const float* bias, const float* w, nfdp_stream_t stream) {
+    return dispatch<kPreAffine>("actnorm_invconv_fwd", x, y, npix, C, w, scale, bias, stream);
+}
+
+extern "C" int nfdp_invconv_actnorm_inv_f32(const float* y, float* x, long npix, int C, const float* scale,
+                                            const float* bias, const float* winv, nfdp_stream_t stream) {
+    return dispatch<kPostAffine>("invconv_actnorm_inv", y, x, npix, C, winv, scale, bias, stream);
+}

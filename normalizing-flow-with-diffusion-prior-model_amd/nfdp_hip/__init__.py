@@ -1,0 +1,361 @@
+"""ctypes binding of the nfdp C ABI (include/nfdp.h) + thin torch-tensor wrappers.
+
+torch is used here only as plumbing: device memory (torch.empty), the current HIP stream, and
+tensor metadata.  Every arithmetic op on the hot path is a hand-written gfx950 kernel reached
+through the C ABI.  There is NO CPU or eager-torch fallback: if the shared library is missing
+or no GPU is visible, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnfdp_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "nfdp.h")
+
+F32, BF16 = 0, 1
+_COMPUTE_NAMES = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
+_default_compute = os.environ.get("NFDP_COMPUTE", "f32")
+
+
+class NfdpError(RuntimeError):
+    pass
+
+
+def set_default_compute(name: str) -> None:
+    """'f32' (exact-fp32 MFMA, parity mode) or 'bf16' (bf16 MFMA, fp32 accumulate; speed mode)."""
+    global _default_compute
+    if name not in _COMPUTE_NAMES:
+        raise ValueError(f"unknown compute mode {name!r}")
+    _default_compute = name
+
+
+def get_default_compute() -> str:
+    return _default_compute
+
+
+def compute_enum(name: Optional[str]) -> int:
+    name = name or _default_compute
+    if name not in _COMPUTE_NAMES:
+        raise ValueError(f"unknown compute mode {name!r}")
+    return _COMPUTE_NAMES[name]
+
+
+# ----------------------------------------------------------------------------- header-driven binding
+_CTYPE = {
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+    "size_t": ctypes.c_size_t, "nfdp_stream_t": ctypes.c_void_p,
+}
+
+
+def parse_header(path: str = HEADER_PATH) -> Dict[str, tuple]:
+    """{name: (restype, [argtypes])} for every `nfdp_*` prototype in include/nfdp.h."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(nfdp_\w+)\s*\(([^;{}]*?)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret:
+            continue
+        restype = ctypes.c_char_p if "char" in ret else _CTYPE[ret.replace("const", "").strip()]
+        argtypes = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CTYPE[a.replace("const", "").split()[0]])
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+_lib = None
+
+
+def lib():
+    """The loaded shared library; raises NfdpError if it has not been built (python -m nfdp_hip.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NfdpError(f"{LIB_PATH} not found: build it with __graft_entry__.build() / nfdp_hip/build.py. "
+                            "There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in parse_header().items():
+            fn = getattr(l, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = l
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise NfdpError(f"nfdp error {rc}: {lib().nfdp_last_error().decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, what: str) -> None:
+    if not t.is_cuda:
+        raise NfdpError(f"{what}: tensor is on {t.device}; the HIP path needs a GPU tensor (no CPU fallback)")
+    if t.dtype != dtype:
+        raise NfdpError(f"{what}: expected {dtype}, got {t.dtype}")
+
+
+def _dense(t: torch.Tensor, what: str) -> None:
+    if not t.is_contiguous():
+        raise NfdpError(f"{what}: tensor must be contiguous")
+
+
+# ----------------------------------------------------------------------------- NHWC plumbing
+def is_nhwc_view(x: torch.Tensor) -> bool:
+    """True if logical-NCHW `x` is physically NHWC-dense (channels_last) so permute(0,2,3,1) is contiguous."""
+    return x.dim() == 4 and x.permute(0, 2, 3, 1).is_contiguous()
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Logical NCHW fp32 tensor -> physical [B,H,W,C] contiguous tensor (zero-copy when already channels_last)."""
+    _need(x, torch.float32, "to_nhwc")
+    if is_nhwc_view(x):
+        return x.permute(0, 2, 3, 1)
+    x = x.contiguous()
+    b, c, h, w = x.shape
+    y = torch.empty((b, h, w, c), device=x.device, dtype=torch.float32)
+    _check(lib().nfdp_nchw_to_nhwc_f32(_ptr(x), _ptr(y), b, c, h, w, _stream()))
+    return y
+
+
+def as_nchw(xh: torch.Tensor) -> torch.Tensor:
+    """[B,H,W,C] physical -> logical NCHW view (channels_last strides, zero-copy)."""
+    return xh.permute(0, 3, 1, 2)
+
+
+def to_nchw_contiguous(xh: torch.Tensor) -> torch.Tensor:
+    _need(xh, torch.float32, "to_nchw_contiguous")
+    _dense(xh, "to_nchw_contiguous")
+    b, h, w, c = xh.shape
+    y = torch.empty((b, c, h, w), device=xh.device, dtype=torch.float32)
+    _check(lib().nfdp_nhwc_to_nchw_f32(_ptr(xh), _ptr(y), b, c, h, w, _stream()))
+    return y
+
+
+def _ld(xh: torch.Tensor, what: str) -> int:
+    """Pixel stride (elements) of a [B,H,W,C] tensor that may be a channel slice of a wider dense tensor."""
+    b, h, w, c = xh.shape
+    sb, sh, sw, sc = xh.stride()
+    if c > 1 and sc != 1:
+        raise NfdpError(f"{what}: channel stride must be 1")
+    ld = sw if w > 1 else (sh if h > 1 else (sb if b > 1 else c))
+    ok = (w == 1 or sw == ld) and (h == 1 or sh == ld * w) and (b == 1 or sb == ld * w * h)
+    if not ok or ld < c:
+        raise NfdpError(f"{what}: tensor is not a pixel-strided NHWC view (shape {tuple(xh.shape)}, strides {xh.stride()})")
+    return ld
+
+
+def squeeze(xh: torch.Tensor) -> torch.Tensor:
+    _need(xh, torch.float32, "squeeze")
+    b, h, w, c = xh.shape
+    if h % 2 or w % 2:
+        raise ValueError("The input dimension is not divisible by 2!")
+    y = torch.empty((b, h // 2, w // 2, 4 * c), device=xh.device, dtype=torch.float32)
+    _check(lib().nfdp_squeeze_nhwc_f32(_ptr(xh), _ld(xh, "squeeze"), _ptr(y), b, c, h, w, _stream()))
+    return y
+
+
+def unsqueeze(yh: torch.Tensor) -> torch.Tensor:
+    _need(yh, torch.float32, "unsqueeze")
+    _dense(yh, "unsqueeze")
+    b, h, w, c4 = yh.shape
+    x = torch.empty((b, 2 * h, 2 * w, c4 // 4), device=yh.device, dtype=torch.float32)
+    _check(lib().nfdp_unsqueeze_nhwc_f32(_ptr(yh), _ptr(x), b, c4, h, w, _stream()))
+    return x
+
+
+def copy_channels(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst[..., :] = src[..., :] for two [B,H,W,n] pixel-strided views."""
+    _need(src, torch.float32, "copy_channels")
+    _need(dst, torch.float32, "copy_channels")
+    b, h, w, n = src.shape
+    assert dst.shape == src.shape
+    _check(lib().nfdp_copy_channels_f32(_ptr(src), _ld(src, "copy_channels"), _ptr(dst), _ld(dst, "copy_channels"),
+                                        b * h * w, n, _stream()))
+
+
+# ----------------------------------------------------------------------------- ActNorm / InvConv
+def actnorm_init(xh: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor) -> None:
+    """Writes data-dependent scale/bias (flat [C] views of the parameters) from the batch."""
+    b, h, w, c = xh.shape
+    ws = torch.empty(lib().nfdp_actnorm_init_ws_bytes(c), device=xh.device, dtype=torch.uint8)
+    _check(lib().nfdp_actnorm_init_f32(_ptr(xh), _ld(xh, "actnorm_init"), b * h * w, c, _ptr(scale), _ptr(bias), _ptr(ws),
+                                       _stream()))
+
+
+def actnorm_fwd(xh, scale, bias, out=None):
+    _need(xh, torch.float32, "actnorm_fwd"); _dense(xh, "actnorm_fwd")
+    out = torch.empty_like(xh) if out is None else out
+    c = xh.shape[-1]
+    _check(lib().nfdp_actnorm_fwd_f32(_ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(scale), _ptr(bias), _stream()))
+    return out
+
+
+def actnorm_inv(yh, scale, bias, out=None):
+    _need(yh, torch.float32, "actnorm_inv"); _dense(yh, "actnorm_inv")
+    out = torch.empty_like(yh) if out is None else out
+    c = yh.shape[-1]
+    _check(lib().nfdp_actnorm_inv_f32(_ptr(yh), _ptr(out), yh.numel() // c, c, _ptr(scale), _ptr(bias), _stream()))
+    return out
+
+
+def invconv_prepare(w: torch.Tensor, want_inverse: bool):
+    """w: [n,C,C] (or [C,C]) fp32 -> (logabsdet [n] fp32, winv [n,C,C] fp32 or None); one launch for all n."""
+    _need(w, torch.float32, "invconv_prepare"); _dense(w, "invconv_prepare")
+    c = w.shape[-1]
+    n = w.numel() // (c * c)
+    lad = torch.empty(n, device=w.device, dtype=torch.float32)
+    winv = torch.empty((n, c, c), device=w.device, dtype=torch.float32) if want_inverse else None
+    ws = torch.empty(lib().nfdp_invconv_prepare_ws_bytes(n, c), device=w.device, dtype=torch.uint8)
+    _check(lib().nfdp_invconv_prepare_f32(_ptr(w), n, c, _ptr(lad), _ptr(winv), _ptr(ws), _stream()))
+    return lad, winv
+
+
+def invconv_apply(xh, w, out=None):
+    _need(xh, torch.float32, "invconv_apply"); _dense(xh, "invconv_apply")
+    out = torch.empty_like(xh) if out is None else out
+    c = xh.shape[-1]
+    _check(lib().nfdp_invconv_apply_f32(_ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(w), _stream()))
+    return out
+
+
+def actnorm_invconv_fwd(xh, scale, bias, w, out=None):
+    _need(xh, torch.float32, "actnorm_invconv_fwd"); _dense(xh, "actnorm_invconv_fwd")
+    out = torch.empty_like(xh) if out is None else out
+    c = xh.shape[-1]
+    _check(lib().nfdp_actnorm_invconv_fwd_f32(_ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(w),
+                                              _stream()))
+    return out
+
+
+def invconv_actnorm_inv(yh, scale, bias, winv, out=None):
+    _need(yh, torch.float32, "invconv_actnorm_inv"); _dense(yh, "invconv_actnorm_inv")
+    out = torch.empty_like(yh) if out is None else out
+    c = yh.shape[-1]
+    _check(lib().nfdp_invconv_actnorm_inv_f32(_ptr(yh), _ptr(out), yh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(winv),
+                                              _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- convolution
+def conv_pack(w_oihw: torch.Tensor, compute: int) -> torch.Tensor:
+    _need(w_oihw, torch.float32, "conv_pack"); _dense(w_oihw, "conv_pack")
+    co, ci, kh, kw = w_oihw.shape
+    nbytes = lib().nfdp_conv_packed_bytes(co, ci, kh, kw, compute)
+    packed = torch.empty(nbytes, device=w_oihw.device, dtype=torch.uint8)
+    _check(lib().nfdp_conv_pack_weights(_ptr(w_oihw), _ptr(packed), co, ci, kh, kw, compute, _stream()))
+    return packed
+
+
+_TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def conv2d(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, *, add=None, mul=None, mul_exp: float = 0.0,
+           relu: bool = False, compute: int = F32, out_dtype: int = F32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """xh: [B,H,W,Cin] pixel-strided view (fp32 or bf16) -> [B,H,W,cout] (fp32 or bf16)."""
+    if not xh.is_cuda:
+        raise NfdpError("conv2d: the HIP path needs a GPU tensor (no CPU fallback)")
+    b, h, w, cin = xh.shape
+    x_dt = BF16 if xh.dtype == torch.bfloat16 else F32
+    if out is None:
+        out = torch.empty((b, h, w, cout), device=xh.device, dtype=_TORCH_DT[out_dtype])
+    _check(lib().nfdp_conv2d_nhwc(_ptr(xh), x_dt, _ld(xh, "conv2d"), _ptr(packed), _ptr(out), out_dtype, _ld(out, "conv2d"),
+                                  b, h, w, cin, cout, k, k, _ptr(add), _ptr(mul), float(mul_exp), int(relu), compute,
+                                  _stream()))
+    return out
+
+
+# ----------------------------------------------------------------------------- coupling / priors / NLL
+def coupling_fwd(xh, hh, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.Tensor]):
+    _dense(xh, "coupling_fwd"); _dense(hh, "coupling_fwd")
+    b, h, w, c = xh.shape
+    if ldj is not None:
+        _need(ldj, torch.float64, "coupling_fwd ldj")
+    _check(lib().nfdp_coupling_fwd_f32(_ptr(xh), _ptr(hh), b, h * w, c, _ptr(ldj), _ptr(ldj_const), _stream()))
+
+
+def coupling_inv(yh, hh):
+    _dense(yh, "coupling_inv"); _dense(hh, "coupling_inv")
+    b, h, w, c = yh.shape
+    _check(lib().nfdp_coupling_inv_f32(_ptr(yh), _ptr(hh), b, h * w, c, _stream()))
+
+
+def ldj_add_scaled(ldj: torch.Tensor, v: torch.Tensor, n_sum: int, hw: float):
+    _need(ldj, torch.float64, "ldj_add_scaled")
+    _check(lib().nfdp_ldj_add_scaled_f32(_ptr(ldj), ldj.numel(), _ptr(v), n_sum, float(hw), _stream()))
+
+
+def flow_ldj_consts(scale: torch.Tensor, logabsdet: torch.Tensor, hw: float) -> torch.Tensor:
+    out = torch.empty(2, device=scale.device, dtype=torch.float32)
+    _check(lib().nfdp_flow_ldj_consts_f32(_ptr(scale), scale.numel(), _ptr(logabsdet), float(hw), _ptr(out), _stream()))
+    return out
+
+
+def gauss_logp(zh: torch.Tensor, h: torch.Tensor, h_mode: int, logp: torch.Tensor):
+    _need(logp, torch.float64, "gauss_logp")
+    b, hh, ww, cz = zh.shape
+    _check(lib().nfdp_gauss_logp_f32(_ptr(zh), _ld(zh, "gauss_logp"), _ptr(h), h_mode, b, hh * ww, cz, _ptr(logp), _stream()))
+
+
+def gauss_sample(h: torch.Tensor, h_mode: int, eps: torch.Tensor, out: torch.Tensor, temperature: float):
+    _dense(eps, "gauss_sample")
+    b, hh, ww, cz = out.shape
+    _check(lib().nfdp_gauss_sample_f32(_ptr(h), h_mode, _ptr(eps), _ptr(out), _ld(out, "gauss_sample"), b, hh * ww, cz,
+                                       float(temperature), _stream()))
+
+
+def zeroconv_bias_only(bias: torch.Tensor, logs: torch.Tensor) -> torch.Tensor:
+    h = torch.empty(bias.numel(), device=bias.device, dtype=torch.float32)
+    _check(lib().nfdp_zeroconv_bias_only_f32(_ptr(bias), _ptr(logs), _ptr(h), bias.numel(), _stream()))
+    return h
+
+
+def bpd_sum(ldj: torch.Tensor, logp: Optional[torch.Tensor], n_bins: float, n_pixel: float) -> torch.Tensor:
+    """-> fp64 [2] = (sum_b bpd_b, B)."""
+    _need(ldj, torch.float64, "bpd_sum")
+    out = torch.empty(2, device=ldj.device, dtype=torch.float64)
+    _check(lib().nfdp_bpd_sum_f64(_ptr(ldj), _ptr(logp), ldj.numel(), float(n_bins), float(n_pixel), _ptr(out), _stream()))
+    return out
+
+
+def preprocess_u8(u8_nchw: torch.Tensor, noise_nchw: Optional[torch.Tensor], n_bits: int) -> torch.Tensor:
+    _need(u8_nchw, torch.uint8, "preprocess_u8"); _dense(u8_nchw, "preprocess_u8")
+    b, c, h, w = u8_nchw.shape
+    y = torch.empty((b, h, w, c), device=u8_nchw.device, dtype=torch.float32)
+    _check(lib().nfdp_preprocess_u8_nchw_to_nhwc_f32(_ptr(u8_nchw), _ptr(noise_nchw), _ptr(y), b, c, h, w, n_bits, _stream()))
+    return y
+
+
+def preprocess_f32(x: torch.Tensor, noise: Optional[torch.Tensor], n_bits: int) -> torch.Tensor:
+    _need(x, torch.float32, "preprocess_f32")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _check(lib().nfdp_preprocess_f32(_ptr(x), _ptr(noise), _ptr(y), x.numel(), n_bits, _stream()))
+    return y
+
+
+def postprocess_u8(xh: torch.Tensor, n_bins: float) -> torch.Tensor:
+    _need(xh, torch.float32, "postprocess_u8"); _dense(xh, "postprocess_u8")
+    b, h, w, c = xh.shape
+    u8 = torch.empty((b, c, h, w), device=xh.device, dtype=torch.uint8)
+    _check(lib().nfdp_postprocess_nhwc_to_u8_nchw(_ptr(xh), _ptr(u8), b, c, h, w, float(n_bins), _stream()))
+    return u8

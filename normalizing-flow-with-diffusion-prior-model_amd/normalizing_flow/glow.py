@@ -1,0 +1,189 @@
+"""Glow composition — mirrors reference normalizing_flow/glow.py: StepFlow :12-63, GlowBlock :66-137, Glow :140-246.
+
+MI355X execution plan for Glow.transform (forward + log-dets):
+  * the NCHW input is converted once to NHWC; each level owns ONE NHWC buffer and every flow updates it in
+    place (the reference allocates ~25 temporaries per flow);
+  * per level, log|det W| (and W^-1 for invert) of all K flows comes from ONE batched fp64 launch;
+  * per flow: [ActNorm -> 1x1 conv] fused in one HBM pass, three MFMA convs with fused epilogues, one coupling
+    launch that also adds the flow's batch-independent log-det terms — 5 launches instead of ~25 torch ops and
+    no host synchronisation (the reference's `.item()` per ActNorm per call is replaced by a host-side flag).
+"""
+from typing import Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+import nfdp_hip as K
+from .base import Transform, acc_in, acc_out
+from .transforms import ActNorm, InvConv2d, AffineCoupling, Squeeze, Split
+from .utils import get_item
+
+
+class StepFlow(Transform):
+    """actnorm -> invconv -> affine coupling  (reference glow.py:12-63)."""
+
+    def __init__(self, in_channels: int = 3, coupling_net_n_features: int = 512, compute: Optional[str] = None):
+        super().__init__()
+        self.actnorm = ActNorm(in_channels=in_channels)
+        self.invconv2d = InvConv2d(in_channels=in_channels)
+        self.affcoupling = AffineCoupling(in_channels=in_channels, n_features=coupling_net_n_features, compute=compute)
+
+    def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], logabsdet: Optional[Tensor] = None) -> Tensor:
+        """In place on xh.  logabsdet: this flow's [1] fp32 entry of the level's batched log|det| launch."""
+        an, ic = self.actnorm, self.invconv2d
+        if not an.initialized():
+            an.init_from(xh)
+        hw = xh.shape[1] * xh.shape[2]
+        const = None
+        if ldj is not None:
+            if logabsdet is None:
+                logabsdet, _ = K.invconv_prepare(ic._w(), want_inverse=False)
+            const = K.flow_ldj_consts(an.scale.view(-1), logabsdet, hw)
+        K.actnorm_invconv_fwd(xh, an.scale.view(-1), an.bias.view(-1), ic._w(), out=xh)
+        return self.affcoupling.transform_nhwc_(xh, ldj, const)
+
+    def invert_nhwc_(self, yh: Tensor, winv: Optional[Tensor] = None) -> Tensor:
+        an, ic = self.actnorm, self.invconv2d
+        self.affcoupling.invert_nhwc_(yh)
+        if winv is None:
+            _, winv = K.invconv_prepare(ic._w(), want_inverse=True)
+        return K.invconv_actnorm_inv(yh, an.scale.view(-1), an.bias.view(-1), winv, out=yh)
+
+    def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        w = acc_in(log_det_jac)
+        y = self.transform_nhwc_(K.to_nhwc(x).contiguous().clone(), w)
+        return K.as_nchw(y), acc_out(log_det_jac, w), logp
+
+    def invert(self, y: Tensor) -> Tensor:
+        return K.as_nchw(self.invert_nhwc_(K.to_nhwc(y).contiguous().clone()))
+
+
+def _run_flows_fwd(flows: Sequence[StepFlow], xh: Tensor, ldj: Optional[Tensor]) -> Tensor:
+    lads = None
+    if ldj is not None:
+        w = torch.stack([f.invconv2d._w() for f in flows])                      # [K,C,C] gather (plumbing)
+        lads, _ = K.invconv_prepare(w, want_inverse=False)                      # one fp64 launch per level
+    for i, f in enumerate(flows):
+        xh = f.transform_nhwc_(xh, ldj, None if lads is None else lads[i:i + 1])
+    return xh
+
+
+def _run_flows_inv(flows: Sequence[StepFlow], yh: Tensor) -> Tensor:
+    w = torch.stack([f.invconv2d._w() for f in flows])
+    _, winvs = K.invconv_prepare(w, want_inverse=True)
+    for i in reversed(range(len(flows))):
+        yh = flows[i].invert_nhwc_(yh, winvs[i])
+    return yh
+
+
+class GlowBlock(Transform):
+    """squeeze -> K flows -> split  (reference glow.py:66-137)."""
+
+    def __init__(self, in_channels: int = 3, K: int = 32, learn_prior_mean_logs: bool = True,
+                 compute: Optional[str] = None):
+        super().__init__()
+        flow_channels = 4 * in_channels
+        self.squeeze = Squeeze()
+        self.flows = nn.ModuleList([StepFlow(in_channels=flow_channels, compute=compute) for _ in range(K)])
+        self.split = Split(flow_channels, learn_prior_mean_logs=learn_prior_mean_logs, compute=compute)
+
+    def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor]):
+        yh = K.squeeze(xh)                       # fresh level buffer; flows then run in place
+        yh = _run_flows_fwd(self.flows, yh, ldj)
+        yv, z = self.split.transform_nhwc(yh, logp)
+        return yv, z
+
+    def invert_nhwc(self, yh: Tensor, zh: Optional[Tensor], temperature: float = 1.0, eps: Optional[Tensor] = None) -> Tensor:
+        xh = self.split.invert_nhwc(yh, zh, temperature, eps)
+        xh = _run_flows_inv(self.flows, xh)
+        return K.unsqueeze(xh)
+
+    def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor):
+        wl, wp = acc_in(log_det_jac), acc_in(logp)
+        yv, z = self.transform_nhwc(K.to_nhwc(x), wl, wp)
+        return K.as_nchw(yv), acc_out(log_det_jac, wl), K.as_nchw(z), acc_out(logp, wp)
+
+    def invert(self, y: Tensor, latent: Tensor = None, temperature: float = 1.0, eps: Optional[Tensor] = None) -> Tensor:
+        zh = None if latent is None else K.to_nhwc(latent)
+        eh = None if eps is None else K.to_nhwc(eps).contiguous()
+        return K.as_nchw(self.invert_nhwc(K.to_nhwc(y), zh, temperature, eh))
+
+
+class Glow(Transform):
+    """The Glow model  (reference glow.py:140-246).  `compute`: 'f32' | 'bf16' | None (library default)."""
+
+    def __init__(self, in_channel: int = 3, L: int = 3, K: int = 32, learn_prior_mean_logs: bool = True,
+                 compute: Optional[str] = None):
+        super().__init__()
+        self.L = L
+        self.K = K
+        self.in_channel = in_channel
+        self.blocks = nn.ModuleList(GlowBlock(in_channels=(2 ** i * self.in_channel), K=self.K,
+                                              learn_prior_mean_logs=learn_prior_mean_logs, compute=compute)
+                                    for i in range(self.L - 1))
+        self.final_squeeze = Squeeze()
+        self.final_flows = nn.ModuleList(
+            StepFlow(in_channels=(2 ** (self.L + 1) * self.in_channel), compute=compute) for _ in range(self.K)
+        )
+
+    def set_compute(self, compute: Optional[str]) -> None:
+        for m in self.modules():
+            if hasattr(m, "compute"):
+                m.compute = compute
+
+    def _check_no_grad(self):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "nfdp HIP path: backward kernels are not built yet (SURVEY.md §8f rank 1). Call under "
+                "torch.no_grad() or freeze the parameters; results would otherwise silently carry no gradient.")
+
+    def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor]):
+        """-> ([z_0 .. z_{L-1}] NHWC tensors, ldj, logp); accumulators fp64, updated in place."""
+        zs = []
+        yh = xh
+        for block in self.blocks:
+            yh, z = block.transform_nhwc(yh, ldj, logp)
+            zs.append(z)
+        yh = K.squeeze(yh)
+        yh = _run_flows_fwd(self.final_flows, yh, ldj)
+        zs.append(yh)
+        return zs
+
+    def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[list, Tensor, Tensor]:
+        """(reference glow.py:172-201) -> (latent parts, log_det_jac, logp); logp may be None (NFBackbone path)."""
+        self._check_no_grad()
+        wl, wp = acc_in(log_det_jac), acc_in(logp)
+        zs = self.transform_nhwc(K.to_nhwc(x), wl, wp)
+        return [K.as_nchw(z) for z in zs], acc_out(log_det_jac, wl), acc_out(logp, wp)
+
+    def invert_nhwc(self, latents: list, temperature: float = 1.0, eps: Optional[Sequence[Tensor]] = None) -> Tensor:
+        xh = latents[-1].contiguous().clone()                 # flows run in place; keep the caller's latent intact
+        xh = _run_flows_inv(self.final_flows, xh)
+        xh = K.unsqueeze(xh)
+        j = 0
+        for i, block in enumerate(reversed(self.blocks)):
+            latent = get_item(latents, -(i + 2))              # None -> Split samples from its learned prior
+            e = None
+            if latent is None and eps is not None:
+                e = eps[j]
+                j += 1
+            xh = block.invert_nhwc(xh, latent, temperature, e)
+        return xh
+
+    def invert(self, latents: list, temperature: float = 1.0, eps: Optional[Sequence[Tensor]] = None) -> Tensor:
+        """(reference glow.py:203-228).  eps: optional list of N(0,1) tensors (logical NCHW) for the Splits that
+        sample, in visiting order (deepest block first)."""
+        self._check_no_grad()
+        lat = [K.to_nhwc(z) for z in latents]
+        eh = None if eps is None else [K.to_nhwc(e).contiguous() for e in eps]
+        return K.as_nchw(self.invert_nhwc(lat, temperature, eh))
+
+    @torch.no_grad()
+    def sample(self, latents: list, postprocess_func=None, temperature: float = 1.0) -> Tensor:
+        """(reference glow.py:230-246)"""
+        self.eval()
+        new_samples = self.invert(latents, temperature)
+        final_output = postprocess_func(new_samples.float()) if postprocess_func else new_samples.float()
+        self.train()
+        return final_output

@@ -1,0 +1,206 @@
+"""Flow primitives on the MI355X kernel library — mirrors reference normalizing_flow/transforms.py:
+IdentityTransform :14-25, ActNorm :28-94, InvConv2d :97-145, AffineCoupling :148-201, Squeeze :204-239,
+Split :242-309.  Same constructor arguments, method names, return tuples (accumulators updated in place and
+returned) and state-dict keys.
+
+Public methods take/return logical-NCHW tensors like the reference; outputs are channels_last-strided views
+of the NHWC buffers the kernels work on (zero-copy).  `*_nhwc` methods are the internal fast path used by
+StepFlow / GlowBlock / Glow so a whole flow runs without layout round trips.
+Optional keyword extensions (never required): `eps=` injects the N(0,1) noise a sampling branch would draw.
+"""
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+import nfdp_hip as K
+from .base import Transform, Prior, acc_in, acc_out
+from .prior import IsotropicGaussian
+from .utils import coupling_network, ZeroConv2d
+
+
+class IdentityTransform(Transform):
+    """(reference transforms.py:14-25)"""
+
+    def transform(self, x, log_det_jac, logp):
+        return x, log_det_jac, logp
+
+    def invert(self, y):
+        return y
+
+
+class ActNorm(Transform):
+    """Per-channel affine layer with data-dependent initialisation  (reference transforms.py:28-94)."""
+
+    def __init__(self, in_channels: int = 3):
+        super().__init__()
+        self.scale = nn.Parameter(torch.zeros(size=(in_channels, 1, 1), device=self.device))
+        self.bias = nn.Parameter(torch.zeros(size=(in_channels, 1, 1), device=self.device))
+        self.register_buffer("is_initialized", torch.tensor(0, dtype=torch.uint8, device=self.device))
+        self._init_cache: Optional[bool] = None      # host mirror of the flag: the reference syncs (.item()) every call
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._init_cache = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def initialized(self) -> bool:
+        if self._init_cache is None:
+            self._init_cache = bool(self.is_initialized.item() != 0)   # one sync per (re)load, not per call
+        return self._init_cache
+
+    @torch.no_grad()
+    def init_from(self, xh: Tensor) -> None:
+        """scale = -log(std+1e-6), bias = -mean over (B,H,W)  (reference transforms.py:74-78)."""
+        K.actnorm_init(xh, self.scale.view(-1), self.bias.view(-1))
+        self.is_initialized.fill_(1)
+        self._init_cache = True
+
+    def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor]) -> Tensor:
+        if not self.initialized():
+            self.init_from(xh)
+        y = K.actnorm_fwd(xh, self.scale.view(-1), self.bias.view(-1))
+        if ldj is not None:
+            K.ldj_add_scaled(ldj, self.scale.view(-1), self.scale.numel(), xh.shape[1] * xh.shape[2])
+        return y
+
+    def invert_nhwc(self, yh: Tensor) -> Tensor:
+        return K.actnorm_inv(yh, self.scale.view(-1), self.bias.view(-1))
+
+    def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        w = acc_in(log_det_jac)
+        y = self.transform_nhwc(K.to_nhwc(x).contiguous(), w)
+        return K.as_nchw(y), acc_out(log_det_jac, w), logp
+
+    def invert(self, y: Tensor) -> Tensor:
+        return K.as_nchw(self.invert_nhwc(K.to_nhwc(y).contiguous()))
+
+
+class InvConv2d(Transform):
+    """Invertible 1x1 convolution  (reference transforms.py:97-145)."""
+
+    def __init__(self, in_channels: int = 3):
+        super().__init__()
+        random_matrix = torch.randn(size=(in_channels, in_channels), dtype=torch.float32)
+        w_init, _ = torch.linalg.qr(random_matrix)                       # host-side init only (transforms.py:112-114)
+        self.weight = nn.Parameter(w_init.reshape(in_channels, in_channels, 1, 1).to(self.device))
+
+    def _w(self) -> Tensor:
+        c = self.weight.shape[0]
+        return self.weight.detach().view(c, c)
+
+    def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor]) -> Tensor:
+        if ldj is not None:
+            lad, _ = K.invconv_prepare(self._w(), want_inverse=False)    # fp64 log|det| every call, as the reference
+            K.ldj_add_scaled(ldj, lad, 1, xh.shape[1] * xh.shape[2])
+        return K.invconv_apply(xh, self._w())
+
+    def invert_nhwc(self, yh: Tensor) -> Tensor:
+        _, winv = K.invconv_prepare(self._w(), want_inverse=True)
+        return K.invconv_apply(yh, winv)
+
+    def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        w = acc_in(log_det_jac)
+        y = self.transform_nhwc(K.to_nhwc(x).contiguous(), w)
+        return K.as_nchw(y), acc_out(log_det_jac, w), logp
+
+    def invert(self, y: Tensor) -> Tensor:
+        return K.as_nchw(self.invert_nhwc(K.to_nhwc(y).contiguous()))
+
+
+class AffineCoupling(Transform):
+    """Affine coupling layer  (reference transforms.py:148-201).  `compute` ('f32' | 'bf16' | None = library
+    default) selects the MFMA mode of the coupling network."""
+
+    def __init__(self, in_channels: int = 2, n_features: int = 512, compute: Optional[str] = None):
+        super().__init__()
+        self.compute = compute
+        self.net = coupling_network(in_channels=in_channels // 2, n_features=n_features,
+                                    out_channels=in_channels).to(self.device)
+
+    def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], ldj_const: Optional[Tensor] = None) -> Tensor:
+        """In place on xh's second channel half.  ldj_const: device [2] fp32 added before the coupling sum."""
+        c = xh.shape[-1]
+        h = self.net.forward_nhwc(xh[..., : c // 2], compute=self.compute)
+        K.coupling_fwd(xh, h, ldj, ldj_const)
+        return xh
+
+    def invert_nhwc_(self, yh: Tensor) -> Tensor:
+        c = yh.shape[-1]
+        h = self.net.forward_nhwc(yh[..., : c // 2], compute=self.compute)
+        K.coupling_inv(yh, h)
+        return yh
+
+    def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        w = acc_in(log_det_jac)
+        y = self.transform_nhwc_(K.to_nhwc(x).contiguous().clone(), w)
+        return K.as_nchw(y), acc_out(log_det_jac, w), logp
+
+    def invert(self, y: Tensor) -> Tensor:
+        return K.as_nchw(self.invert_nhwc_(K.to_nhwc(y).contiguous().clone()))
+
+
+class Squeeze(Transform):
+    """Space-to-depth by 2  (reference transforms.py:204-239); bit-exact index reshuffle."""
+
+    def transform_nhwc(self, xh: Tensor) -> Tensor:
+        return K.squeeze(xh)
+
+    def invert_nhwc(self, yh: Tensor) -> Tensor:
+        return K.unsqueeze(yh)
+
+    def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        return K.as_nchw(K.squeeze(K.to_nhwc(x))), log_det_jac, logp
+
+    def invert(self, y: Tensor) -> Tensor:
+        return K.as_nchw(K.unsqueeze(K.to_nhwc(y).contiguous()))
+
+
+class Split(Transform):
+    """Channel split with a learned Gaussian prior on the dropped half  (reference transforms.py:242-309)."""
+
+    def __init__(self, in_channels, learn_prior_mean_logs: bool = True, compute: Optional[str] = None):
+        super().__init__()
+        self.compute = compute
+        self.conv = ZeroConv2d(in_channels // 2, in_channels, padding=(3 - 1) // 2) if learn_prior_mean_logs else None
+        if self.conv is not None:
+            self.conv.to(self.device)
+
+    def _mean_logs_nhwc(self, yh: Tensor) -> Tensor:
+        """h = (mean | logs) [B,H,W,2*Cy]  (reference transforms.py:256-268; zeros when nothing is learned)."""
+        if self.conv is not None:
+            return self.conv.forward_nhwc(yh, compute=self.compute)
+        b, h, w, c = yh.shape
+        return torch.zeros((b, h, w, 2 * c), device=yh.device, dtype=torch.float32)
+
+    def transform_nhwc(self, xh: Tensor, logp: Optional[Tensor]):
+        """-> (y view, z contiguous copy); logp updated in place (skipped when None, transforms.py:287)."""
+        c = xh.shape[-1]
+        yv, zv = xh[..., : c // 2], xh[..., c // 2:]
+        if logp is not None:
+            K.gauss_logp(zv, self._mean_logs_nhwc(yv), 0, logp)
+        z = torch.empty(zv.shape, device=xh.device, dtype=torch.float32)
+        K.copy_channels(zv, z)
+        return yv, z
+
+    def invert_nhwc(self, yh: Tensor, zh: Optional[Tensor], temperature: float = 1.0, eps: Optional[Tensor] = None) -> Tensor:
+        b, h, w, c = yh.shape
+        out = torch.empty((b, h, w, 2 * c), device=yh.device, dtype=torch.float32)
+        K.copy_channels(yh, out[..., :c])
+        if zh is None:
+            if eps is None:
+                eps = torch.randn((b, h, w, c), device=yh.device, dtype=torch.float32)
+            K.gauss_sample(self._mean_logs_nhwc(yh), 0, eps.contiguous(), out[..., c:], temperature)
+        else:
+            K.copy_channels(zh, out[..., c:])
+        return out
+
+    def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor):
+        w = acc_in(logp)
+        yv, z = self.transform_nhwc(K.to_nhwc(x).contiguous(), w)
+        return K.as_nchw(yv), log_det_jac, K.as_nchw(z), acc_out(logp, w)
+
+    def invert(self, y: Tensor, inv_y_split: Tensor = None, temperature: float = 1.0, eps: Optional[Tensor] = None) -> Tensor:
+        zh = None if inv_y_split is None else K.to_nhwc(inv_y_split)
+        eh = None if eps is None else K.to_nhwc(eps).contiguous()
+        return K.as_nchw(self.invert_nhwc(K.to_nhwc(y), zh, temperature, eh))

@@ -1,0 +1,216 @@
+"""Flow helper modules + NLL math — mirrors reference normalizing_flow/utils.py (hot-path symbols only:
+ZeroConv2d :17-44, Conv2dActNorm :47-69, coupling_network :72-90, calculate_output_shapes :93-117,
+init_optimizer :120-137, preprocess_batch :175-196, postprocess_batch :199-210, calculate_loss :244-256,
+initialize_with_zeros :259-272, data_dependent_nf_initialization :275-292, get_item :295-300).
+
+All convolutions run as MFMA implicit GEMMs (csrc/conv.hip) on NHWC tensors with the ActNorm / exp(3*logs)
+scaling and the ReLU folded into the epilogue.  Modules hold parameters in the reference's layout and under
+the reference's state-dict names; kernel-layout copies (packed weights) are cached per parameter version.
+"""
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+import nfdp_hip as K
+from .base import default_device
+
+LatentDim = Tuple[int, int, int]  # Channels, height, width.
+
+
+class _PackedCache:
+    """Kernel-layout copy of a conv weight, rebuilt when the parameter (version / storage / mode) changes."""
+
+    def __init__(self):
+        self._key = None
+        self._packed = None
+
+    def get(self, weight: Tensor, compute: int) -> Tensor:
+        key = (weight.data_ptr(), weight._version, compute, weight.device)
+        if key != self._key:
+            self._packed = K.conv_pack(weight.detach(), compute)
+            self._key = key
+        return self._packed
+
+
+class _ConvWeights(nn.Module):
+    """Parameter container with nn.Conv2d's names, shapes and default init (never calls a torch conv)."""
+
+    def __init__(self, in_channels: int, out_channels: int, k: int, bias: bool):
+        super().__init__()
+        self.in_channels, self.out_channels, self.k = in_channels, out_channels, k
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k))
+        self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
+        bound = 1.0 / math.sqrt(in_channels * k * k)          # == kaiming_uniform_(a=sqrt(5)) of nn.Conv2d
+        nn.init.uniform_(self.weight, -bound, bound)
+        if bias:
+            nn.init.uniform_(self.bias, -bound, bound)
+        self._cache = _PackedCache()
+
+    def packed(self, compute: int) -> Tensor:
+        return self._cache.get(self.weight, compute)
+
+
+class ZeroConv2d(nn.Module):
+    """Zero-initialised 3x3 conv whose output is scaled by exp(logs*3)  (reference utils.py:17-44).
+
+    State-dict keys: weight [O,I,3,3], bias [O], logs [1,O,1,1].
+    """
+
+    def __init__(self, in_channels: int, out_channels: int, filter_size: int = 3, stride: int = 1, padding: int = 0,
+                 logscale: float = 3.):
+        super().__init__()
+        if stride != 1 or padding != (filter_size - 1) // 2:
+            raise ValueError("the HIP conv implements stride 1 / 'same' padding (all the reference's call sites)")
+        self.in_channels, self.out_channels, self.filter_size = in_channels, out_channels, filter_size
+        self.weight = nn.Parameter(torch.zeros(out_channels, in_channels, filter_size, filter_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.register_parameter("logs", nn.Parameter(torch.zeros(1, out_channels, 1, 1)))
+        self.logscale_factor = logscale
+        self._cache = _PackedCache()
+
+    def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None) -> Tensor:
+        c = K.compute_enum(compute)
+        return K.conv2d(xh, self._cache.get(self.weight, c), self.out_channels, self.filter_size, add=self.bias,
+                        mul=self.logs.view(-1), mul_exp=self.logscale_factor, relu=False, compute=c, out_dtype=K.F32)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return K.as_nchw(self.forward_nhwc(K.to_nhwc(x)))
+
+
+class Conv2dActNorm(nn.Module):
+    """Bias-free conv followed by ActNorm  (reference utils.py:47-69); keys _Conv2dActNorm__conv.weight,
+    _Conv2dActNorm__actnorm.{scale,bias,is_initialized}."""
+
+    def __init__(self, in_channels: int, out_channels: int, filter_size: int, stride: int = 1, padding: int = None):
+        super().__init__()
+        from .transforms import ActNorm
+        if stride != 1:
+            raise ValueError("stride 1 only")
+        self.filter_size = filter_size
+        self.__conv = _ConvWeights(in_channels, out_channels, filter_size, bias=False)
+        self.__actnorm = ActNorm(out_channels)
+
+    @property
+    def actnorm(self):
+        return self.__actnorm
+
+    @property
+    def conv(self):
+        return self.__conv
+
+    def forward_nhwc(self, xh: Tensor, relu: bool = False, compute: Optional[str] = None, out_dtype: int = K.F32) -> Tensor:
+        c = K.compute_enum(compute)
+        an, cv = self.__actnorm, self.__conv
+        packed = cv.packed(c)
+        if not an.initialized():
+            # data-dependent init (transforms.py:74-78) on the raw conv output, then the fused pass below
+            raw = K.conv2d(xh, packed, cv.out_channels, self.filter_size, compute=c, out_dtype=K.F32)
+            an.init_from(raw)
+        return K.conv2d(xh, packed, cv.out_channels, self.filter_size, add=an.bias.view(-1), mul=an.scale.view(-1),
+                        mul_exp=1.0, relu=relu, compute=c, out_dtype=out_dtype)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return K.as_nchw(self.forward_nhwc(K.to_nhwc(x)))
+
+
+class CouplingNet(nn.Sequential):
+    """The coupling network as ONE fused launch sequence: conv3x3+ActNorm+ReLU -> conv1x1+ActNorm+ReLU ->
+    ZeroConv3x3, hidden activations kept in bf16 in bf16 mode.  Indexing/keys identical to the reference's
+    nn.Sequential (net.0, net.2, net.4; ReLUs at 1 and 3)."""
+
+    def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None) -> Tensor:
+        c = K.compute_enum(compute)
+        hid = K.BF16 if c == K.BF16 else K.F32
+        h = self[0].forward_nhwc(xh, relu=True, compute=compute, out_dtype=hid)
+        h = self[2].forward_nhwc(h, relu=True, compute=compute, out_dtype=hid)
+        return self[4].forward_nhwc(h, compute=compute)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return K.as_nchw(self.forward_nhwc(K.to_nhwc(x)))
+
+
+def coupling_network(in_channels: int, n_features: int = 512, out_channels: int = None):
+    """(reference utils.py:72-90)"""
+    return CouplingNet(
+        Conv2dActNorm(in_channels, n_features, 3, padding=1),
+        nn.ReLU(inplace=True),
+        Conv2dActNorm(n_features, n_features, 1, padding=0),
+        nn.ReLU(inplace=True),
+        ZeroConv2d(n_features, out_channels or in_channels, padding=1),
+    )
+
+
+def calculate_output_shapes(L: int, in_channels: int, size: int) -> List[LatentDim]:
+    """Latent part shapes, e.g. L=3,C=3,size=32 -> [(6,16,16),(12,8,8),(48,4,4)]  (reference utils.py:93-117)."""
+    z_shapes = []
+    for _ in range(L - 1):
+        if size % 2 != 0:
+            raise ValueError("The input dimension is not divisible by 2!")
+        in_channels *= 2
+        size //= 2
+        z_shapes.append((in_channels, size, size))
+    z_shapes.append((in_channels * 4, size // 2, size // 2))
+    return z_shapes
+
+
+def init_optimizer(name: str, params, lr: float) -> torch.optim.Optimizer:
+    """(reference utils.py:120-137)"""
+    if name == "adam":
+        from torch.optim import Adam as Optimizer
+    elif name == "adamw":
+        from torch.optim import AdamW as Optimizer
+    else:
+        raise ValueError("Unknown optimizer")
+    return Optimizer(params, lr=lr if lr else params[0]["lr"])
+
+
+@torch.no_grad()
+def preprocess_batch(batch: Tensor, n_bits: int, n_bins: int) -> Tensor:
+    """[0,1] images -> n_bits quantised, centred  (reference utils.py:175-196).  uint8 input is also accepted
+    (then batch/255 is applied in-kernel exactly as torchvision's ToTensor would have)."""
+    if batch.dtype == torch.uint8:
+        return K.as_nchw(K.preprocess_u8(batch.contiguous(), None, n_bits))
+    return K.preprocess_f32(batch, None, n_bits)
+
+
+@torch.no_grad()
+def postprocess_batch(batch: Tensor, n_bins: int) -> Tensor:
+    """-> uint8 on the host  (reference utils.py:199-210)."""
+    return K.postprocess_u8(K.to_nhwc(batch).contiguous(), n_bins).to("cpu")
+
+
+def calculate_loss(log_likelihood: Tensor, n_bins: float, n_pixel: float):
+    """Bits per dimension, mean over the batch  (reference utils.py:244-256)."""
+    ll = log_likelihood if log_likelihood.dtype == torch.float64 else log_likelihood.double()
+    s = K.bpd_sum(ll.contiguous(), None, n_bins, n_pixel)
+    return s[0] / s[1]
+
+
+def initialize_with_zeros(n: int, batch_size: int, device: torch.device):
+    """n fp64 zero accumulators  (reference utils.py:259-272)."""
+    if n == 1:
+        return torch.zeros(batch_size, device=device, dtype=torch.float64)
+    return (torch.zeros(batch_size, device=device, dtype=torch.float64) for _ in range(n))
+
+
+@torch.no_grad()
+def data_dependent_nf_initialization(flow, dataloader, device: torch.device, n_bits: int, n_bins: int) -> None:
+    """Runs one batch through the flow so the ActNorms initialise  (reference utils.py:275-292)."""
+    flow.eval()
+    sample = next(iter(dataloader))
+    batch = sample[0].to(device) if isinstance(sample, list) else sample.to(device)
+    batch = preprocess_batch(batch, n_bits, n_bins)
+    log_likelihood, logp = initialize_with_zeros(2, batch.size(0), device)
+    _ = flow.transform(batch + torch.rand_like(batch) / n_bins, log_likelihood, logp)
+
+
+def get_item(sequence: Sequence, index: int):
+    """sequence[index] or None  (reference utils.py:295-300)."""
+    try:
+        return sequence[index]
+    except IndexError:
+        return None
