@@ -83,9 +83,13 @@ class InvConv2d(Transform):
         super().__init__()
         random_matrix = torch.randn(size=(in_channels, in_channels), dtype=torch.float32)
         w_init, _ = torch.linalg.qr(random_matrix)                       # host-side init only (transforms.py:112-114)
-        self.weight = nn.Parameter(w_init.reshape(in_channels, in_channels, 1, 1).to(self.device))
+        # linalg.qr returns a column-major Q: force the row-major [out,in] layout the kernels (and OIHW) assume
+        self.weight = nn.Parameter(w_init.contiguous().reshape(in_channels, in_channels, 1, 1).contiguous().to(self.device))
 
     def _w(self) -> Tensor:
+        """Row-major [C,C] view of the parameter (re-densified in place if something re-strided it)."""
+        if not self.weight.is_contiguous():
+            self.weight.data = self.weight.data.contiguous()
         c = self.weight.shape[0]
         return self.weight.detach().view(c, c)
 

@@ -16,8 +16,16 @@ def _rs(key: str, seed: int) -> np.random.RandomState:
     return np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
 
 
-def synth_tensor(key: str, shape, seed: int) -> np.ndarray:
-    """'Trained-like' value for one state-dict entry (see SURVEY.md §8(d) weights (b))."""
+GOLDEN = {"invconv_noise": 0.3, "zero_gain": 0.5, "flow_scale_mean": 0.0}
+# Deep stacks (K=16): near-orthogonal 1x1 weights, gentler coupling scales and an ActNorm gain that offsets the
+# coupling's contraction (s ~ sigmoid(2) = 0.88 on half the channels), so that 48 flows stay norm-preserving in
+# BOTH directions like a trained Glow — fp32 round trips and temperature sampling stay meaningful.
+DEEP = {"invconv_noise": 0.05, "zero_gain": 0.2, "flow_scale_mean": 0.064}
+
+
+def synth_tensor(key: str, shape, seed: int, profile: dict = GOLDEN) -> np.ndarray:
+    """'Trained-like' value for one state-dict entry (see SURVEY.md §8(d) weights (b)).  The golden files were
+    generated with the default GOLDEN profile; do not change it."""
     shape = tuple(int(s) for s in shape)
     rs = _rs(key, seed)
     leaf = key.rsplit(".", 1)[-1]
@@ -29,6 +37,8 @@ def synth_tensor(key: str, shape, seed: int) -> np.ndarray:
         v = 0.1 * g
     elif leaf == "scale":
         v = 0.05 * g
+        if key.endswith(".actnorm.scale") and "_Conv2dActNorm" not in key:
+            v = v + profile["flow_scale_mean"]
     elif leaf == "g":
         v = 1.0 + 0.05 * g
     elif leaf == "bias":
@@ -42,11 +52,11 @@ def synth_tensor(key: str, shape, seed: int) -> np.ndarray:
             sign = np.where(rs.rand(c) < 0.5, -1.0, 1.0)
             q = np.zeros((c, c))
             q[np.arange(c), perm] = sign
-            v = (q + 0.3 * g.reshape(c, c) / np.sqrt(c)).reshape(shape)
+            v = (q + profile["invconv_noise"] * g.reshape(c, c) / np.sqrt(c)).reshape(shape)
         else:
             fan_in = int(np.prod(shape[1:]))
             if key.endswith(ZERO_CONV_SUFFIXES):
-                std = 0.5 / np.sqrt(fan_in)
+                std = profile["zero_gain"] / np.sqrt(fan_in)
             elif key.endswith("net.2._Conv2dActNorm__conv.weight"):
                 std = np.sqrt(2.0 / fan_in)
             else:

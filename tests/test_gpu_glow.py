@@ -8,7 +8,7 @@ import torch
 import nfdp_hip as K
 from oracle import nf_oracle as O
 from tests.util import load_golden, meta_of, synth_sd, T, assert_close, relerr
-from tests.golden.synth import synth_tensor, images_5bit
+from tests.golden.synth import synth_tensor, images_5bit, DEEP
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4          # BASELINE.json: fp32 bits/dim and sampled pixels within 1e-4 relative
@@ -108,8 +108,9 @@ def _north_star(compute, K_flows=16):
     from normalizing_flow import Glow, GaussianPrior
     flow = Glow(in_channel=3, L=3, K=K_flows, compute=compute)
     prior = GaussianPrior(48)
-    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 7)) for k, v in flow.state_dict().items()}, strict=True)
-    prior.load_state_dict({k: T(synth_tensor(k, v.shape, 7)) for k, v in prior.state_dict().items()}, strict=True)
+    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 7, DEEP)) for k, v in flow.state_dict().items()},
+                         strict=True)
+    prior.load_state_dict({k: T(synth_tensor(k, v.shape, 7, DEEP)) for k, v in prior.state_dict().items()}, strict=True)
     return flow, prior
 
 
@@ -146,6 +147,19 @@ def test_north_star_full_size_properties():
     assert_close(logp[:4], logp_o, TOL, "logp vs oracle")
     bpd4 = calculate_loss((ldj + logp)[:4].contiguous(), 32.0, 3072.0)
     assert_close(bpd4, bpd_o, TOL, "bpd vs oracle")
+    # inverse + Split sampling (sampled pixels) on the same slice with the same injected noise.  A 48-flow fp32
+    # inverse carries its own rounding noise in ANY implementation, so the yardstick is the oracle evaluated in
+    # fp64: the HIP result must be within 1e-4 of it, or no further from it than 2x the fp32 oracle itself.
+    sd64 = {k: v.double() for k, v in sd.items()}
+    z_in = [z[:4].cpu().contiguous() for z in zs]
+    eps = [torch.randn(4, 12, 8, 8), torch.randn(4, 6, 16, 16)]
+    for what, lat, kw in (("x_rec", z_in, {}), ("sampled pixels", [z_in[-1]], {"temperature": 0.7, "eps": eps})):
+        truth = O.glow_inv([z.double() for z in lat], sd64, 3, 16, kw.get("temperature", 1.0),
+                           [e.double() for e in eps] if kw else None)
+        ref32 = O.glow_inv(lat, sd, 3, 16, kw.get("temperature", 1.0), eps if kw else None)
+        hip = flow.invert([z.to(DEV) for z in lat], **({"temperature": 0.7, "eps": [e.to(DEV) for e in eps]} if kw else {}))
+        e_hip, e_ref = relerr(hip, truth), relerr(ref32, truth)
+        assert e_hip <= max(TOL, 2 * e_ref), f"{what}: hip {e_hip:.2e} vs fp64 truth, fp32 oracle {e_ref:.2e}"
 
 
 @torch.no_grad()

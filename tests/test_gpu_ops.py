@@ -166,8 +166,9 @@ def test_gaussian_prior(ops, c):
 def test_pre_post_bpd(ops):
     from normalizing_flow import preprocess_batch, postprocess_batch, calculate_loss
     u8 = cu(ops["pp_u8"])
+    b01 = (T(ops["pp_u8"]).float() / 255.0).to(DEV)        # ToTensor runs on the host in the reference's loaders
     for nb in (5, 8):
-        assert torch.equal(preprocess_batch(u8.float() / 255.0, nb, 2.0 ** nb).cpu(), T(ops[f"pre{nb}"]))
+        assert torch.equal(preprocess_batch(b01, nb, 2.0 ** nb).cpu(), T(ops[f"pre{nb}"]))
         assert torch.equal(preprocess_batch(u8, nb, 2.0 ** nb).cpu(), T(ops[f"pre{nb}"]))
     assert torch.equal(postprocess_batch(cu(ops["post_x"]), 32.0), T(ops["post5"]))
     assert_close(calculate_loss(cu(ops["bpd_ll"]), 32.0, 3072.0), ops["bpd"], 1e-12, "bpd")
