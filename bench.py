@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json's headline metric on MI355X: images/sec (+ bits/dim) for Glow L=3 K=16 on 32x32x3,
+forward + NLL, one rank per GPU (weak scaling: fixed per-GPU batch).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = the body of the reference's loop normalizing_flow/trainer.py:152-161 on one synthetic batch already
+resident in HBM: preprocess (5-bit) + dequantisation noise -> Glow.transform -> GaussianPrior.compute_log_prob ->
+bits/dim.  Weights: deterministic 'trained-like' synthetic weights (tests/golden/synth.py, DEEP profile) — there
+is no network for checkpoints.  The 1x1-conv log|det| is recomputed every step (as the reference does); packed
+(kernel-layout) copies of the conv weights are rebuilt only when a parameter changes.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest share of step time, timed live with
+HIP events on the launch stream during extra profiled steps after the timed region; `cpu_baseline` is the CPU
+oracle (a torch-CPU restatement of the reference, kind "port") on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "normalizing-flow-with-diffusion-prior-model_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+PEAK = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def build_models(L, K, compute, device, seed=1):
+    from normalizing_flow import Glow, GaussianPrior
+    from tests.golden.synth import synth_tensor, DEEP
+    flow = Glow(in_channel=3, L=L, K=K, compute=compute)
+    prior = GaussianPrior(2 ** (L + 1) * 3)
+    fsd = {k: torch.from_numpy(np.array(synth_tensor(k, v.shape, seed, DEEP))) for k, v in flow.state_dict().items()}
+    psd = {k: torch.from_numpy(np.array(synth_tensor(k, v.shape, seed, DEEP))) for k, v in prior.state_dict().items()}
+    flow.load_state_dict(fsd)
+    prior.load_state_dict(psd)
+    return flow.to(device), prior.to(device), fsd, psd
+
+
+def make_batch(B, rank, device):
+    g = torch.Generator().manual_seed(1234 + rank)
+    u8 = torch.randint(0, 256, (B, 3, 32, 32), generator=g, dtype=torch.uint8)
+    noise = torch.rand((B, 3, 32, 32), generator=g, dtype=torch.float32)
+    return u8, noise, u8.to(device), noise.to(device)
+
+
+def step(flow, prior, u8_d, noise_d, n_bits=5):
+    """trainer.py:152-161 without the optimizer: returns the device fp64 pair (sum_b bpd_b, B)."""
+    import nfdp_hip as K
+    B = u8_d.shape[0]
+    xh = K.preprocess_u8(u8_d, noise_d, n_bits)                       # preprocess_batch + rand/n_bins, NHWC out
+    ldj = torch.zeros(B, dtype=torch.float64, device=u8_d.device)     # initialize_with_zeros
+    logp = torch.zeros(B, dtype=torch.float64, device=u8_d.device)
+    zs = flow.transform_nhwc(xh, ldj, logp)                           # Glow.transform
+    prior.accumulate_log_prob_nhwc(zs[-1], logp)                      # logp += prior.compute_log_prob(latents[-1])
+    return K.bpd_sum(ldj, logp, 2.0 ** n_bits, 32 * 32 * 3.0)         # calculate_loss (sum, count)
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores(cap=16):
+    """CPU threads this process may really use: affinity ∩ cgroup quota, capped (a 1-GPU box has a 16-CPU share;
+    oversubscribing torch's intra-op pool beyond the quota makes the CPU leg crawl)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return max(1, min(n, int(os.environ.get("NFDP_CPU_THREADS", cap))))
+
+
+def cpu_baseline(fsd, psd, L, K, u8, noise, n_bits=5, budget_s=12.0):
+    """The oracle (port of the reference's CPU path) on the host cores: a bounded sample of the same workload."""
+    from oracle import nf_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    bs = 16
+    x = O.preprocess(u8.float() / 255.0, n_bits) + noise / 2.0 ** n_bits
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.fwd_nll(x[:4], fsd, psd, L, K)                                # warm-up
+        log(f"cpu_baseline: {cores} threads, warm-up 4 images {time.perf_counter() - t0:.1f} s")
+        n, t0 = 0, time.perf_counter()
+        while n < 2 * bs or (time.perf_counter() - t0 < budget_s and n + bs <= x.shape[0]):
+            _, _, _, bpd = O.fwd_nll(x[n:n + bs], fsd, psd, L, K)
+            n += bs
+            log(f"cpu_baseline: {n} images, {time.perf_counter() - t0:.1f} s")
+        dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} images in batches of {bs} (fp32, torch-CPU oracle, {cores} threads), {dt:.1f} s",
+            "bits_per_dim_last_batch": float(bpd)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--L", type=int, default=3)
+    ap.add_argument("--K", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)      # RCCL over xGMI
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import nfdp_hip as KH
+    log(f"rank {rank}/{world}: building Glow L{args.L}K{args.K} ({args.compute}) and the synthetic batch")
+    flow, prior, fsd, psd = build_models(args.L, args.K, args.compute, device)
+    u8, noise, u8_d, noise_d = make_batch(args.batch, rank, device)
+    log("models ready; warm-up")
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = step(flow, prior, u8_d, noise_d)
+        barrier()
+        log("timed region")
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(flow, prior, u8_d, noise_d)
+        barrier()
+        elapsed = time.perf_counter() - t0
+
+        # global bits/dim: all-reduce SUM of (sum_b bpd_b, count); max over ranks of the elapsed time
+        stats = torch.cat([out, torch.tensor([elapsed], dtype=torch.float64, device=device)])
+        if world > 1:
+            tmax = stats[2:].clone()
+            dist.all_reduce(stats[:2], op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            stats[2] = tmax[0]
+        bpd_sum, count, elapsed = (float(v) for v in stats.cpu())
+
+        log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
+        roofline = None
+        if rank == 0 and not args.no_roofline:
+            KH.start_trace()
+            n_prof = 3
+            for _ in range(n_prof):
+                step(flow, prior, u8_d, noise_d)
+            tr = KH.stop_trace()
+            agg = {}
+            for e in tr:
+                a = agg.setdefault(e["label"], {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
+                a["ms"] += e["ms"]; a["n"] += 1; a["flops"] += e["flops"]; a["bytes"] += e["bytes"]
+            total_ms = sum(a["ms"] for a in agg.values())
+            lbl, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            avg_s = a["ms"] / a["n"] * 1e-3
+            if a["flops"] > 0 and lbl.startswith("conv"):
+                ach = a["flops"] / a["n"] / avg_s / 1e12
+                roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.compute], "unit": "TFLOP/s",
+                            "frac": round(ach / PEAK[args.compute], 4), "traffic": None}
+            else:
+                ach = a["bytes"] / a["n"] / avg_s / 1e9
+                roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+            roofline.update({"kernel": lbl, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": a["n"] // n_prof,
+                             "share_of_step_kernel_time": round(a["ms"] / total_ms, 3)})
+            top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]
+            roofline["top_kernels"] = [
+                {"kernel": k, "share": round(v["ms"] / total_ms, 3), "avg_us": round(v["ms"] / v["n"] * 1e3, 1),
+                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["flops"] else None,
+                 "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None} for k, v in top]
+
+    if rank == 0:
+        imgs = args.batch * world * args.steps
+        res = {
+            "metric": f"images/sec, Glow L{args.L}K{args.K} 32x32x3 fwd+NLL",
+            "value": round(imgs / elapsed, 1), "unit": "images/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.compute, "data": "synthetic",
+            "config": {"workload": f"Glow L={args.L} K={args.K} forward+NLL (bits/dim) on 32x32x3, 5-bit, "
+                                   f"batch={args.batch}/GPU (BASELINE configs[1] shape, trainer.py:152-161 body)",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "weights": "synthetic trained-like (tests/golden/synth.py DEEP, seed 1)"},
+            "bits_per_dim": round(bpd_sum / count, 6),
+        }
+        if roofline is not None:
+            res["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(fsd, psd, args.L, args.K, u8, noise)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

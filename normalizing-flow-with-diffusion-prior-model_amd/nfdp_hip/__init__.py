@@ -99,6 +99,35 @@ def _check(rc: int) -> None:
         raise NfdpError(f"nfdp error {rc}: {lib().nfdp_last_error().decode()}")
 
 
+# ---- optional launch tracing (bench.py / profiling only): HIP events on the launch stream around every kernel
+_trace = None
+
+
+def start_trace() -> None:
+    global _trace
+    _trace = []
+
+
+def stop_trace():
+    """-> list of dicts {label, ms, flops, bytes}; synchronises the device."""
+    global _trace
+    t, _trace = _trace, None
+    torch.cuda.synchronize()
+    return [{"label": lb, "ms": e0.elapsed_time(e1), "flops": fl, "bytes": by} for lb, e0, e1, fl, by in (t or [])]
+
+
+def _call(name: str, *args, label: Optional[str] = None, flops: float = 0.0, nbytes: float = 0.0) -> None:
+    fn = getattr(lib(), name)
+    if _trace is None:
+        _check(fn(*args))
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    _check(fn(*args))
+    e1.record()
+    _trace.append((label or name, e0, e1, flops, nbytes))
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -133,7 +162,7 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     x = x.contiguous()
     b, c, h, w = x.shape
     y = torch.empty((b, h, w, c), device=x.device, dtype=torch.float32)
-    _check(lib().nfdp_nchw_to_nhwc_f32(_ptr(x), _ptr(y), b, c, h, w, _stream()))
+    _call("nfdp_nchw_to_nhwc_f32", _ptr(x), _ptr(y), b, c, h, w, _stream())
     return y
 
 
@@ -147,7 +176,7 @@ def to_nchw_contiguous(xh: torch.Tensor) -> torch.Tensor:
     _dense(xh, "to_nchw_contiguous")
     b, h, w, c = xh.shape
     y = torch.empty((b, c, h, w), device=xh.device, dtype=torch.float32)
-    _check(lib().nfdp_nhwc_to_nchw_f32(_ptr(xh), _ptr(y), b, c, h, w, _stream()))
+    _call("nfdp_nhwc_to_nchw_f32", _ptr(xh), _ptr(y), b, c, h, w, _stream())
     return y
 
 
@@ -170,7 +199,7 @@ def squeeze(xh: torch.Tensor) -> torch.Tensor:
     if h % 2 or w % 2:
         raise ValueError("The input dimension is not divisible by 2!")
     y = torch.empty((b, h // 2, w // 2, 4 * c), device=xh.device, dtype=torch.float32)
-    _check(lib().nfdp_squeeze_nhwc_f32(_ptr(xh), _ld(xh, "squeeze"), _ptr(y), b, c, h, w, _stream()))
+    _call("nfdp_squeeze_nhwc_f32", _ptr(xh), _ld(xh, "squeeze"), _ptr(y), b, c, h, w, _stream())
     return y
 
 
@@ -179,7 +208,7 @@ def unsqueeze(yh: torch.Tensor) -> torch.Tensor:
     _dense(yh, "unsqueeze")
     b, h, w, c4 = yh.shape
     x = torch.empty((b, 2 * h, 2 * w, c4 // 4), device=yh.device, dtype=torch.float32)
-    _check(lib().nfdp_unsqueeze_nhwc_f32(_ptr(yh), _ptr(x), b, c4, h, w, _stream()))
+    _call("nfdp_unsqueeze_nhwc_f32", _ptr(yh), _ptr(x), b, c4, h, w, _stream())
     return x
 
 
@@ -189,8 +218,8 @@ def copy_channels(src: torch.Tensor, dst: torch.Tensor) -> None:
     _need(dst, torch.float32, "copy_channels")
     b, h, w, n = src.shape
     assert dst.shape == src.shape
-    _check(lib().nfdp_copy_channels_f32(_ptr(src), _ld(src, "copy_channels"), _ptr(dst), _ld(dst, "copy_channels"),
-                                        b * h * w, n, _stream()))
+    _call("nfdp_copy_channels_f32", _ptr(src), _ld(src, "copy_channels"), _ptr(dst), _ld(dst, "copy_channels"),
+                                        b * h * w, n, _stream())
 
 
 # ----------------------------------------------------------------------------- ActNorm / InvConv
@@ -198,15 +227,16 @@ def actnorm_init(xh: torch.Tensor, scale: torch.Tensor, bias: torch.Tensor) -> N
     """Writes data-dependent scale/bias (flat [C] views of the parameters) from the batch."""
     b, h, w, c = xh.shape
     ws = torch.empty(lib().nfdp_actnorm_init_ws_bytes(c), device=xh.device, dtype=torch.uint8)
-    _check(lib().nfdp_actnorm_init_f32(_ptr(xh), _ld(xh, "actnorm_init"), b * h * w, c, _ptr(scale), _ptr(bias), _ptr(ws),
-                                       _stream()))
+    _call("nfdp_actnorm_init_f32", _ptr(xh), _ld(xh, "actnorm_init"), b * h * w, c, _ptr(scale), _ptr(bias), _ptr(ws),
+                                       _stream())
 
 
 def actnorm_fwd(xh, scale, bias, out=None):
     _need(xh, torch.float32, "actnorm_fwd"); _dense(xh, "actnorm_fwd")
     out = torch.empty_like(xh) if out is None else out
     c = xh.shape[-1]
-    _check(lib().nfdp_actnorm_fwd_f32(_ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(scale), _ptr(bias), _stream()))
+    _call("nfdp_actnorm_fwd_f32", _ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(scale), _ptr(bias), _stream(),
+          label=f"actnorm_kernel<fwd> C{c}", nbytes=8.0 * xh.numel())
     return out
 
 
@@ -214,7 +244,7 @@ def actnorm_inv(yh, scale, bias, out=None):
     _need(yh, torch.float32, "actnorm_inv"); _dense(yh, "actnorm_inv")
     out = torch.empty_like(yh) if out is None else out
     c = yh.shape[-1]
-    _check(lib().nfdp_actnorm_inv_f32(_ptr(yh), _ptr(out), yh.numel() // c, c, _ptr(scale), _ptr(bias), _stream()))
+    _call("nfdp_actnorm_inv_f32", _ptr(yh), _ptr(out), yh.numel() // c, c, _ptr(scale), _ptr(bias), _stream())
     return out
 
 
@@ -226,7 +256,7 @@ def invconv_prepare(w: torch.Tensor, want_inverse: bool):
     lad = torch.empty(n, device=w.device, dtype=torch.float32)
     winv = torch.empty((n, c, c), device=w.device, dtype=torch.float32) if want_inverse else None
     ws = torch.empty(lib().nfdp_invconv_prepare_ws_bytes(n, c), device=w.device, dtype=torch.uint8)
-    _check(lib().nfdp_invconv_prepare_f32(_ptr(w), n, c, _ptr(lad), _ptr(winv), _ptr(ws), _stream()))
+    _call("nfdp_invconv_prepare_f32", _ptr(w), n, c, _ptr(lad), _ptr(winv), _ptr(ws), _stream())
     return lad, winv
 
 
@@ -234,7 +264,8 @@ def invconv_apply(xh, w, out=None):
     _need(xh, torch.float32, "invconv_apply"); _dense(xh, "invconv_apply")
     out = torch.empty_like(xh) if out is None else out
     c = xh.shape[-1]
-    _check(lib().nfdp_invconv_apply_f32(_ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(w), _stream()))
+    _call("nfdp_invconv_apply_f32", _ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(w), _stream(),
+          label=f"pixel_linear_kernel<{c},matvec>", flops=2.0 * xh.numel() * c, nbytes=8.0 * xh.numel())
     return out
 
 
@@ -242,8 +273,8 @@ def actnorm_invconv_fwd(xh, scale, bias, w, out=None):
     _need(xh, torch.float32, "actnorm_invconv_fwd"); _dense(xh, "actnorm_invconv_fwd")
     out = torch.empty_like(xh) if out is None else out
     c = xh.shape[-1]
-    _check(lib().nfdp_actnorm_invconv_fwd_f32(_ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(w),
-                                              _stream()))
+    _call("nfdp_actnorm_invconv_fwd_f32", _ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(w),
+          _stream(), label=f"pixel_linear_kernel<{c},pre_affine>", flops=2.0 * xh.numel() * c, nbytes=8.0 * xh.numel())
     return out
 
 
@@ -251,8 +282,8 @@ def invconv_actnorm_inv(yh, scale, bias, winv, out=None):
     _need(yh, torch.float32, "invconv_actnorm_inv"); _dense(yh, "invconv_actnorm_inv")
     out = torch.empty_like(yh) if out is None else out
     c = yh.shape[-1]
-    _check(lib().nfdp_invconv_actnorm_inv_f32(_ptr(yh), _ptr(out), yh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(winv),
-                                              _stream()))
+    _call("nfdp_invconv_actnorm_inv_f32", _ptr(yh), _ptr(out), yh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(winv),
+          _stream(), label=f"pixel_linear_kernel<{c},post_affine>", flops=2.0 * yh.numel() * c, nbytes=8.0 * yh.numel())
     return out
 
 
@@ -262,7 +293,7 @@ def conv_pack(w_oihw: torch.Tensor, compute: int) -> torch.Tensor:
     co, ci, kh, kw = w_oihw.shape
     nbytes = lib().nfdp_conv_packed_bytes(co, ci, kh, kw, compute)
     packed = torch.empty(nbytes, device=w_oihw.device, dtype=torch.uint8)
-    _check(lib().nfdp_conv_pack_weights(_ptr(w_oihw), _ptr(packed), co, ci, kh, kw, compute, _stream()))
+    _call("nfdp_conv_pack_weights", _ptr(w_oihw), _ptr(packed), co, ci, kh, kw, compute, _stream())
     return packed
 
 
@@ -278,9 +309,16 @@ def conv2d(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, *, add=Non
     x_dt = BF16 if xh.dtype == torch.bfloat16 else F32
     if out is None:
         out = torch.empty((b, h, w, cout), device=xh.device, dtype=_TORCH_DT[out_dtype])
-    _check(lib().nfdp_conv2d_nhwc(_ptr(xh), x_dt, _ld(xh, "conv2d"), _ptr(packed), _ptr(out), out_dtype, _ld(out, "conv2d"),
-                                  b, h, w, cin, cout, k, k, _ptr(add), _ptr(mul), float(mul_exp), int(relu), compute,
-                                  _stream()))
+    lbl = None
+    if _trace is not None:
+        bn = 16 if cout <= 16 else 32 if cout <= 32 else 48 if cout <= 48 else 64 if cout <= 64 else 128
+        vec = cin % 4 == 0 and _ld(xh, "conv2d") % 4 == 0
+        lbl = (f"conv_kernel<{'bf16' if compute == BF16 else 'f32'},x{'bf16' if x_dt == BF16 else 'f32'},"
+               f"{'vec' if vec else 'scalar'},{256 if bn <= 48 else 128}x{bn}> k{k} {cin}->{cout} hw{h}")
+    _call("nfdp_conv2d_nhwc", _ptr(xh), x_dt, _ld(xh, "conv2d"), _ptr(packed), _ptr(out), out_dtype, _ld(out, "conv2d"),
+          b, h, w, cin, cout, k, k, _ptr(add), _ptr(mul), float(mul_exp), int(relu), compute, _stream(),
+          label=lbl, flops=2.0 * b * h * w * cin * k * k * cout,
+          nbytes=float(b * h * w) * (cin * xh.element_size() + cout * out.element_size()))
     return out
 
 
@@ -290,42 +328,43 @@ def coupling_fwd(xh, hh, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.
     b, h, w, c = xh.shape
     if ldj is not None:
         _need(ldj, torch.float64, "coupling_fwd ldj")
-    _check(lib().nfdp_coupling_fwd_f32(_ptr(xh), _ptr(hh), b, h * w, c, _ptr(ldj), _ptr(ldj_const), _stream()))
+    _call("nfdp_coupling_fwd_f32", _ptr(xh), _ptr(hh), b, h * w, c, _ptr(ldj), _ptr(ldj_const), _stream(),
+          label="coupling_kernel<fwd>", nbytes=4.0 * xh.numel() * 2)
 
 
 def coupling_inv(yh, hh):
     _dense(yh, "coupling_inv"); _dense(hh, "coupling_inv")
     b, h, w, c = yh.shape
-    _check(lib().nfdp_coupling_inv_f32(_ptr(yh), _ptr(hh), b, h * w, c, _stream()))
+    _call("nfdp_coupling_inv_f32", _ptr(yh), _ptr(hh), b, h * w, c, _stream())
 
 
 def ldj_add_scaled(ldj: torch.Tensor, v: torch.Tensor, n_sum: int, hw: float):
     _need(ldj, torch.float64, "ldj_add_scaled")
-    _check(lib().nfdp_ldj_add_scaled_f32(_ptr(ldj), ldj.numel(), _ptr(v), n_sum, float(hw), _stream()))
+    _call("nfdp_ldj_add_scaled_f32", _ptr(ldj), ldj.numel(), _ptr(v), n_sum, float(hw), _stream())
 
 
 def flow_ldj_consts(scale: torch.Tensor, logabsdet: torch.Tensor, hw: float) -> torch.Tensor:
     out = torch.empty(2, device=scale.device, dtype=torch.float32)
-    _check(lib().nfdp_flow_ldj_consts_f32(_ptr(scale), scale.numel(), _ptr(logabsdet), float(hw), _ptr(out), _stream()))
+    _call("nfdp_flow_ldj_consts_f32", _ptr(scale), scale.numel(), _ptr(logabsdet), float(hw), _ptr(out), _stream())
     return out
 
 
 def gauss_logp(zh: torch.Tensor, h: torch.Tensor, h_mode: int, logp: torch.Tensor):
     _need(logp, torch.float64, "gauss_logp")
     b, hh, ww, cz = zh.shape
-    _check(lib().nfdp_gauss_logp_f32(_ptr(zh), _ld(zh, "gauss_logp"), _ptr(h), h_mode, b, hh * ww, cz, _ptr(logp), _stream()))
+    _call("nfdp_gauss_logp_f32", _ptr(zh), _ld(zh, "gauss_logp"), _ptr(h), h_mode, b, hh * ww, cz, _ptr(logp), _stream())
 
 
 def gauss_sample(h: torch.Tensor, h_mode: int, eps: torch.Tensor, out: torch.Tensor, temperature: float):
     _dense(eps, "gauss_sample")
     b, hh, ww, cz = out.shape
-    _check(lib().nfdp_gauss_sample_f32(_ptr(h), h_mode, _ptr(eps), _ptr(out), _ld(out, "gauss_sample"), b, hh * ww, cz,
-                                       float(temperature), _stream()))
+    _call("nfdp_gauss_sample_f32", _ptr(h), h_mode, _ptr(eps), _ptr(out), _ld(out, "gauss_sample"), b, hh * ww, cz,
+                                       float(temperature), _stream())
 
 
 def zeroconv_bias_only(bias: torch.Tensor, logs: torch.Tensor) -> torch.Tensor:
     h = torch.empty(bias.numel(), device=bias.device, dtype=torch.float32)
-    _check(lib().nfdp_zeroconv_bias_only_f32(_ptr(bias), _ptr(logs), _ptr(h), bias.numel(), _stream()))
+    _call("nfdp_zeroconv_bias_only_f32", _ptr(bias), _ptr(logs), _ptr(h), bias.numel(), _stream())
     return h
 
 
@@ -333,7 +372,7 @@ def bpd_sum(ldj: torch.Tensor, logp: Optional[torch.Tensor], n_bins: float, n_pi
     """-> fp64 [2] = (sum_b bpd_b, B)."""
     _need(ldj, torch.float64, "bpd_sum")
     out = torch.empty(2, device=ldj.device, dtype=torch.float64)
-    _check(lib().nfdp_bpd_sum_f64(_ptr(ldj), _ptr(logp), ldj.numel(), float(n_bins), float(n_pixel), _ptr(out), _stream()))
+    _call("nfdp_bpd_sum_f64", _ptr(ldj), _ptr(logp), ldj.numel(), float(n_bins), float(n_pixel), _ptr(out), _stream())
     return out
 
 
@@ -341,7 +380,7 @@ def preprocess_u8(u8_nchw: torch.Tensor, noise_nchw: Optional[torch.Tensor], n_b
     _need(u8_nchw, torch.uint8, "preprocess_u8"); _dense(u8_nchw, "preprocess_u8")
     b, c, h, w = u8_nchw.shape
     y = torch.empty((b, h, w, c), device=u8_nchw.device, dtype=torch.float32)
-    _check(lib().nfdp_preprocess_u8_nchw_to_nhwc_f32(_ptr(u8_nchw), _ptr(noise_nchw), _ptr(y), b, c, h, w, n_bits, _stream()))
+    _call("nfdp_preprocess_u8_nchw_to_nhwc_f32", _ptr(u8_nchw), _ptr(noise_nchw), _ptr(y), b, c, h, w, n_bits, _stream())
     return y
 
 
@@ -349,7 +388,7 @@ def preprocess_f32(x: torch.Tensor, noise: Optional[torch.Tensor], n_bits: int) 
     _need(x, torch.float32, "preprocess_f32")
     x = x.contiguous()
     y = torch.empty_like(x)
-    _check(lib().nfdp_preprocess_f32(_ptr(x), _ptr(noise), _ptr(y), x.numel(), n_bits, _stream()))
+    _call("nfdp_preprocess_f32", _ptr(x), _ptr(noise), _ptr(y), x.numel(), n_bits, _stream())
     return y
 
 
@@ -357,5 +396,5 @@ def postprocess_u8(xh: torch.Tensor, n_bins: float) -> torch.Tensor:
     _need(xh, torch.float32, "postprocess_u8"); _dense(xh, "postprocess_u8")
     b, h, w, c = xh.shape
     u8 = torch.empty((b, c, h, w), device=xh.device, dtype=torch.uint8)
-    _check(lib().nfdp_postprocess_nhwc_to_u8_nchw(_ptr(xh), _ptr(u8), b, c, h, w, float(n_bins), _stream()))
+    _call("nfdp_postprocess_nhwc_to_u8_nchw", _ptr(xh), _ptr(u8), b, c, h, w, float(n_bins), _stream())
     return u8
