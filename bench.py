@@ -163,13 +163,9 @@ def main():
         elapsed = time.perf_counter() - t0
 
         # global bits/dim: all-reduce SUM of (sum_b bpd_b, count); max over ranks of the elapsed time
-        stats = torch.cat([out, torch.tensor([elapsed], dtype=torch.float64, device=device)])
-        if world > 1:
-            tmax = stats[2:].clone()
-            dist.all_reduce(stats[:2], op=dist.ReduceOp.SUM)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            stats[2] = tmax[0]
-        bpd_sum, count, elapsed = (float(v) for v in stats.cpu())
+        from nfdp_hip.dist import global_bits_per_dim, max_over_ranks
+        bits_per_dim = float(global_bits_per_dim(out))
+        elapsed = max_over_ranks(elapsed, device)
 
         log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
         roofline = None
@@ -215,7 +211,7 @@ def main():
                                    f"batch={args.batch}/GPU (BASELINE configs[1] shape, trainer.py:152-161 body)",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "weights": "synthetic trained-like (tests/golden/synth.py DEEP, seed 1)"},
-            "bits_per_dim": round(bpd_sum / count, 6),
+            "bits_per_dim": round(bits_per_dim, 6),
         }
         if roofline is not None:
             res["roofline"] = roofline

@@ -1,0 +1,70 @@
+"""N>1 host path on CPU: world_size=2 over gloo.  Each rank evaluates the oracle NLL on its shard of a batch; the
+(sum, count) all-reduce must reproduce the single-process bits/dim of the whole batch (weak-scaling semantics of
+bench.py), for even and ragged shards."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "normalizing-flow-with-diffusion-prior-model_amd")]
+    from nfdp_hip.dist import shard_range, global_bits_per_dim, max_over_ranks
+    from oracle import nf_oracle as O
+    from tests.util import load_golden, meta_of, synth_sd, T
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    g = load_golden("glow_M.npz")
+    m = meta_of(g)
+    sd, psd = synth_sd(m["flow_spec"], m["seed"]), synth_sd(m["prior_spec"], m["seed"])
+    x = T(g["x"])[:n_total]
+    lo, hi = shard_range(n_total, rank, world)
+    _, ldj, logp, _ = O.fwd_nll(x[lo:hi], sd, psd, m["L"], m["K"])
+    c = 1.4426950408889634 / 3072.0
+    pair = torch.stack([(((torch.log(torch.tensor(32.0, dtype=torch.float64)) * 3072.0) - (ldj + logp)) * c).sum(),
+                        torch.tensor(float(hi - lo), dtype=torch.float64)])
+    bpd = global_bits_per_dim(pair)
+    tmax = max_over_ranks(float(rank + 1), "cpu")
+    if rank == 0:
+        _, l_all, p_all, bpd_all = O.fwd_nll(x, sd, psd, m["L"], m["K"])
+        out.put((float(bpd), float(bpd_all), tmax))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [4, 3])
+def test_world2_gloo_global_bpd(n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got, ref, tmax = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert abs(got - ref) <= 1e-12 * abs(ref)
+    assert tmax == 2.0
+
+
+def test_shard_range_covers_everything():
+    import sys
+    from nfdp_hip.dist import shard_range
+    for n in (0, 1, 7, 512, 513):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
