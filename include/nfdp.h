@@ -106,6 +106,21 @@ int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed,
 int nfdp_coupling_fwd_f32(float* x, const float* h, int B, int HW, int C, double* ldj, const float* ldj_const,
                           nfdp_stream_t stream);
 int nfdp_coupling_inv_f32(float* y, const float* h, int B, int HW, int C, nfdp_stream_t stream);
+/* Fused coupling layer (bf16 MFMA, fp32 accumulate, fp32 flow state): the whole coupling network
+ * (utils.py:83-89) and the coupling epilogue above in ONE launch; the 512-wide hidden activations stay in
+ * registers, weights stream through LDS from a pre-packed MFMA register image.  x: [B,H,W,C] contiguous, updated in
+ * place (x_b half).  Geometry: n_features = 512, H = W in {16,8,4} with C in {4|12, 8|24, 16|48} respectively
+ * (nfdp_coupling_fused_supported returns 1); anything else returns NFDP_EUNSUPPORTED and callers use
+ * nfdp_conv2d_nhwc + nfdp_coupling_*_f32.  `packed` (nfdp_coupling_fused_packed_bytes(C) bytes) is built by
+ * nfdp_coupling_fused_pack from the nine parameter tensors of one coupling network in the reference's layouts:
+ * w1 [512,C/2,3,3], scale1/bias1 [512], w2 [512,512(,1,1)], scale2/bias2 [512], w3 [C,512,3,3], bias3 [C], logs3 [C]. */
+int nfdp_coupling_fused_supported(int H, int W, int C, int n_features);
+size_t nfdp_coupling_fused_packed_bytes(int C);
+int nfdp_coupling_fused_pack(const float* w1, const float* scale1, const float* bias1, const float* w2,
+                             const float* scale2, const float* bias2, const float* w3, const float* bias3,
+                             const float* logs3, void* packed, int C, nfdp_stream_t stream);
+int nfdp_coupling_fused_bf16(float* x, const void* packed, int B, int H, int W, int C, double* ldj,
+                             const float* ldj_const, int inverse, nfdp_stream_t stream);
 /* ldj[b] += (double)(hw * (float)sum(v[0..n_sum)))  (fp32 product): the standalone ActNorm / InvConv2d log-det terms. */
 int nfdp_ldj_add_scaled_f32(double* ldj, int B, const float* v, int n_sum, float hw, nfdp_stream_t stream);
 /* out2[0] = hw*sum(scale[0..C)) (transforms.py:81), out2[1] = hw*logabsdet[0] (transforms.py:131), fp32: the two

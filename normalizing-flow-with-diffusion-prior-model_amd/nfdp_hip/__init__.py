@@ -338,6 +338,34 @@ def coupling_inv(yh, hh):
     _call("nfdp_coupling_inv_f32", _ptr(yh), _ptr(hh), b, h * w, c, _stream())
 
 
+def coupling_fused_supported(h: int, w: int, c: int, n_features: int) -> bool:
+    return bool(lib().nfdp_coupling_fused_supported(h, w, c, n_features))
+
+
+def coupling_fused_pack(w1, s1, b1, w2, s2, b2, w3, b3, l3) -> torch.Tensor:
+    c = w3.shape[0]
+    packed = torch.empty(lib().nfdp_coupling_fused_packed_bytes(c), device=w1.device, dtype=torch.uint8)
+    for t in (w1, s1, b1, w2, s2, b2, w3, b3, l3):
+        _need(t, torch.float32, "coupling_fused_pack"); _dense(t, "coupling_fused_pack")
+    _call("nfdp_coupling_fused_pack", _ptr(w1), _ptr(s1), _ptr(b1), _ptr(w2), _ptr(s2), _ptr(b2), _ptr(w3), _ptr(b3),
+          _ptr(l3), _ptr(packed), c, _stream())
+    return packed
+
+
+def coupling_fused(xh: torch.Tensor, packed: torch.Tensor, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.Tensor],
+                   inverse: bool) -> None:
+    """In place on xh [B,H,W,C]: the whole coupling layer (network + affine + log-det) in one launch (bf16 MFMA)."""
+    _need(xh, torch.float32, "coupling_fused"); _dense(xh, "coupling_fused")
+    b, h, w, c = xh.shape
+    if ldj is not None:
+        _need(ldj, torch.float64, "coupling_fused ldj")
+    ch = c // 2
+    flops = 2.0 * b * h * w * (9 * ch * 512 + 512 * 512 + 9 * 512 * c)
+    _call("nfdp_coupling_fused_bf16", _ptr(xh), _ptr(packed), b, h, w, c, _ptr(ldj), _ptr(ldj_const), int(inverse),
+          _stream(), label=f"coupling_fused_kernel<{c},{w}> {'inv' if inverse else 'fwd'}", flops=flops,
+          nbytes=8.0 * xh.numel())
+
+
 def ldj_add_scaled(ldj: torch.Tensor, v: torch.Tensor, n_sum: int, hw: float):
     _need(ldj, torch.float64, "ldj_add_scaled")
     _call("nfdp_ldj_add_scaled_f32", _ptr(ldj), ldj.numel(), _ptr(v), n_sum, float(hw), _stream())

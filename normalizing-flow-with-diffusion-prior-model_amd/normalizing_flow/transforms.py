@@ -116,20 +116,38 @@ class AffineCoupling(Transform):
     """Affine coupling layer  (reference transforms.py:148-201).  `compute` ('f32' | 'bf16' | None = library
     default) selects the MFMA mode of the coupling network."""
 
-    def __init__(self, in_channels: int = 2, n_features: int = 512, compute: Optional[str] = None):
+    def __init__(self, in_channels: int = 2, n_features: int = 512, compute: Optional[str] = None, fused: bool = True):
         super().__init__()
         self.compute = compute
+        self.fused = fused          # allow the one-launch fused kernel (bf16 mode, supported geometry)
+        self.n_features = n_features
         self.net = coupling_network(in_channels=in_channels // 2, n_features=n_features,
                                     out_channels=in_channels).to(self.device)
 
+    def _fused_pack(self, xh: Tensor):
+        if not self.fused or K.compute_enum(self.compute) != K.BF16:
+            return None
+        _, h, w, c = xh.shape
+        if not K.coupling_fused_supported(h, w, c, self.n_features):
+            return None
+        return self.net.fused_packed()
+
     def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], ldj_const: Optional[Tensor] = None) -> Tensor:
         """In place on xh's second channel half.  ldj_const: device [2] fp32 added before the coupling sum."""
+        packed = self._fused_pack(xh)
+        if packed is not None:
+            K.coupling_fused(xh, packed, ldj, ldj_const, inverse=False)
+            return xh
         c = xh.shape[-1]
         h = self.net.forward_nhwc(xh[..., : c // 2], compute=self.compute)
         K.coupling_fwd(xh, h, ldj, ldj_const)
         return xh
 
     def invert_nhwc_(self, yh: Tensor) -> Tensor:
+        packed = self._fused_pack(yh)
+        if packed is not None:
+            K.coupling_fused(yh, packed, None, None, inverse=True)
+            return yh
         c = yh.shape[-1]
         h = self.net.forward_nhwc(yh[..., : c // 2], compute=self.compute)
         K.coupling_inv(yh, h)

@@ -118,9 +118,24 @@ class Conv2dActNorm(nn.Module):
 
 
 class CouplingNet(nn.Sequential):
-    """The coupling network as ONE fused launch sequence: conv3x3+ActNorm+ReLU -> conv1x1+ActNorm+ReLU ->
-    ZeroConv3x3, hidden activations kept in bf16 in bf16 mode.  Indexing/keys identical to the reference's
-    nn.Sequential (net.0, net.2, net.4; ReLUs at 1 and 3)."""
+    """The coupling network: conv3x3+ActNorm+ReLU -> conv1x1+ActNorm+ReLU -> ZeroConv3x3 as three MFMA launches
+    with fused epilogues (hidden activations bf16 in bf16 mode), or — see fused_packed() — folded with the
+    coupling epilogue into ONE launch.  Indexing/keys identical to the reference's nn.Sequential (net.0, net.2,
+    net.4; ReLUs at 1 and 3)."""
+
+    def fused_packed(self):
+        """MFMA-register-image pack of all nine parameter tensors for nfdp_coupling_fused_bf16, rebuilt when any
+        of them changes.  None while a hidden ActNorm still awaits its data-dependent init."""
+        c1, c2, zc = self[0], self[2], self[4]
+        if not (c1.actnorm.initialized() and c2.actnorm.initialized()):
+            return None
+        ts = (c1.conv.weight, c1.actnorm.scale, c1.actnorm.bias, c2.conv.weight, c2.actnorm.scale, c2.actnorm.bias,
+              zc.weight, zc.bias, zc.logs)
+        key = tuple((t.data_ptr(), t._version) for t in ts)
+        if getattr(self, "_fused_key", None) != key:
+            self._fused = K.coupling_fused_pack(*[t.detach().reshape(-1) if t.dim() != 4 else t.detach() for t in ts])
+            self._fused_key = key
+        return self._fused
 
     def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None) -> Tensor:
         c = K.compute_enum(compute)

@@ -1,0 +1,93 @@
+"""Fused coupling-layer kernel (csrc/coupling_fused.hip) vs the unfused HIP path in the same bf16 mode (identical
+rounding points -> agreement to summation order, occasionally one bf16 ulp on a hidden unit) and vs the fp32 CPU
+oracle, for every supported geometry, ragged batch tails (partial last workgroup), forward and inverse."""
+import pytest
+import torch
+
+import nfdp_hip as K
+from oracle import nf_oracle as O
+from tests.util import T, assert_close, relerr
+from tests.golden.synth import synth_tensor, synth_input, DEEP
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+GEOMS = [(4, 16, 3), (12, 16, 5), (8, 8, 5), (24, 8, 7), (16, 4, 11), (48, 4, 19)]   # (C, H=W, ragged B)
+
+
+def make(c, fused):
+    from normalizing_flow import AffineCoupling
+    m = AffineCoupling(c, n_features=512, compute="bf16", fused=fused)
+    sd = {k: T(synth_tensor("flows.3.affcoupling." + k, v.shape, 11, DEEP)) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, strict=True)
+    return m, {"flows.3.affcoupling." + k: v for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("c,hw,b", GEOMS)
+@torch.no_grad()
+def test_fused_matches_unfused_and_oracle(c, hw, b):
+    assert K.coupling_fused_supported(hw, hw, c, 512)
+    fused, sd = make(c, True)
+    plain, _ = make(c, False)
+    x = T(synth_input(f"fx{c}", (b, c, hw, hw), 5)) * 0.6
+    xd = x.to(DEV)
+    l1 = torch.zeros(b, dtype=torch.float64, device=DEV)
+    l2 = torch.zeros(b, dtype=torch.float64, device=DEV)
+    K.start_trace()
+    y1, _, _ = fused.transform(xd, l1, None)
+    labels = [e["label"] for e in K.stop_trace()]
+    assert any(lb.startswith("coupling_fused_kernel") for lb in labels), labels      # the fused kernel really ran
+    y2, _, _ = plain.transform(xd, l2, None)
+    assert torch.equal(y1[:, : c // 2], xd[:, : c // 2])
+    assert_close(y1, y2, 3e-3, "fused vs unfused y")
+    assert_close(l1, l2, 3e-3, "fused vs unfused ldj")
+    yo, lo = O.coupling_fwd(x, sd, "flows.3.affcoupling.net.", torch.zeros(b, dtype=torch.float64))
+    assert_close(y1, yo, 2e-2, "fused vs fp32 oracle y")
+    assert_close(l1, lo, 2e-2, "fused vs fp32 oracle ldj")
+    i1, i2 = fused.invert(y1), plain.invert(y1)
+    assert_close(i1, i2, 3e-3, "fused vs unfused inverse")
+    assert relerr(i1, xd) < 2e-2                                                     # round trip at bf16 accuracy
+    # determinism
+    y1b, _, _ = fused.transform(xd, torch.zeros(b, dtype=torch.float64, device=DEV), None)
+    assert torch.equal(y1, y1b)
+
+
+@torch.no_grad()
+def test_fused_ldj_const_and_none():
+    fused, _ = make(12, True)
+    x = (T(synth_input("fc", (4, 12, 16, 16), 6)) * 0.5).to(DEV)
+    xh = K.to_nhwc(x).contiguous()
+    base = torch.full((4,), 10.0, dtype=torch.float64, device=DEV)
+    const = torch.tensor([1.5, -0.25], device=DEV)
+    a, b = xh.clone(), xh.clone()
+    l0 = torch.zeros(4, dtype=torch.float64, device=DEV)
+    fused.transform_nhwc_(a, l0, None)
+    l1 = base.clone()
+    fused.transform_nhwc_(b, l1, const)
+    assert torch.equal(a, b)
+    assert_close(l1, l0 + 10.0 + 1.5 - 0.25, 1e-12, "ldj const")
+    c2 = xh.clone()
+    fused.transform_nhwc_(c2, None, None)                                             # no accumulator: still transforms
+    assert torch.equal(a, c2)
+
+
+@torch.no_grad()
+def test_glow_m_golden_in_bf16_fused():
+    """MNIST-shaped Glow (BASELINE configs[0] geometry) through the fused kernels vs the reference golden."""
+    from normalizing_flow import Glow, GaussianPrior, calculate_loss
+    from tests.util import load_golden, meta_of, synth_sd
+    g = load_golden("glow_M.npz")
+    m = meta_of(g)
+    flow = Glow(in_channel=m["C"], L=m["L"], K=m["K"], compute="bf16")
+    prior = GaussianPrior(2 ** (m["L"] + 1) * m["C"])
+    flow.load_state_dict(synth_sd(m["flow_spec"], m["seed"]))
+    prior.load_state_dict(synth_sd(m["prior_spec"], m["seed"]))
+    x = T(g["x"]).to(DEV)
+    ldj = torch.zeros(m["B"], dtype=torch.float64, device=DEV)
+    logp = torch.zeros(m["B"], dtype=torch.float64, device=DEV)
+    K.start_trace()
+    zs, _, _ = flow.transform(x, ldj, logp)
+    n_fused = sum(e["label"].startswith("coupling_fused_kernel") for e in K.stop_trace())
+    assert n_fused == m["L"] * m["K"]
+    logp += prior.compute_log_prob(zs[-1])
+    assert_close(calculate_loss(ldj + logp, 32.0, 3072.0), g["bpd"], 2e-3, "bpd (bf16, golden weights are ill-conditioned)")
+    assert_close(zs[-1], g[f"z{m['L'] - 1}"], 5e-2, "z_last")
