@@ -29,11 +29,14 @@
 //
 // Supported geometry: hidden width 512, square images with H*W in {16, 64, 256} (every level of a 32x32 Glow),
 // C in {4,8,16} (1-channel data) and {12,24,48} (3-channel data).  Other shapes use the unfused kernels.
+#include <type_traits>
+#include <utility>
 #include "nfdp_common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int PF = 4;            // A-fragment prefetch distance (k-steps in flight ahead of the MFMAs)
 constexpr int HID = 512;
 constexpr int NHB = HID / 32;
 
@@ -174,6 +177,60 @@ __device__ __forceinline__ void actnorm_relu(f32x16& v, const char* params, int 
 
 constexpr int round16(int v) { return (v + 15) & ~15; }
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// compile-time unrolled loop whose index is a constant expression (usable as an asm immediate)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// A-fragment stream: hand-issued LDS reads with hand-counted waits (cdna_hip_programming.md §5.7 form ii).
+// hipcc's own waits for this pattern are always lgkmcnt(0), which with one wave per SIMD exposes a full LDS
+// latency per group; LDS returns in order, so "all but the N youngest" is exact.
+template <int OFF>
+__device__ __forceinline__ void lds_read_frag(bf16x8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_frag(bf16x8& frag) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "i"(N));
+    __builtin_amdgcn_sched_barrier(0);          // keep the consuming MFMAs below the wait (rule 18)
+}
+
+// Pipelined A stream of NA fragments starting at LDS byte address `base` (1 KiB apart): `use(i, frag)` is called
+// for i = 0..NA-1 with fragment i ready; up to PF reads are in flight.
+template <int NA, class Use>
+__device__ __forceinline__ void a_stream(unsigned base, Use&& use) {
+    bf16x8 ab[PF];
+    static_for<(PF < NA ? PF : NA)>([&](auto i) { lds_read_frag<decltype(i)::value * 1024>(ab[decltype(i)::value], base); });
+    static_for<NA>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int after = (NA - 1 - i) < (PF - 1) ? (NA - 1 - i) : (PF - 1);     // reads issued after fragment i
+        lds_wait_frag<after>(ab[i % PF]);
+        use(ic, ab[i % PF]);
+        if constexpr (i + PF < NA) lds_read_frag<(i + PF) * 1024>(ab[i % PF], base);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// Where an H1 fragment lives: the accumulator half of the register file (AGPR) holds the MFMA accumulators first;
+// H1 fragments fill what is left, the rest stay in arch VGPRs.  Pinning the class at creation stops hipcc from
+// parking them in scratch / shuffling them through v_mov before every MFMA.
+template <int C, int NCT>
+struct RegPlan {
+    static constexpr int NACC = 16 * NCT * (1 + Geo<C>::NRT);                   // acc + accT registers
+    static constexpr int AFREE = 256 - NACC - 8 > 0 ? 256 - NACC - 8 : 0;
+    static constexpr int FRAGS_IN_AGPR = AFREE / 4 < 32 * NCT ? AFREE / 4 : 32 * NCT;
+};
+template <bool IN_AGPR>
+__device__ __forceinline__ void pin_frag(bf16x8& f) {
+    if constexpr (IN_AGPR) asm volatile("" : "+a"(f));
+    else asm volatile("" : "+v"(f));
+}
+
 template <int C, int WD, int NCT>
 struct Lds {
     using G = Geo<C>;
@@ -260,8 +317,9 @@ coupling_fused_kernel(float* __restrict__ x, const char* __restrict__ packed, in
 
     // ---- 2. GEMM1 + ActNorm + ReLU -> H1 kept as B fragments (k-steps 2*hb, 2*hb+1 of GEMM2)
     bf16x8 H1[NCT][2 * NHB];
-#pragma unroll
-    for (int hb = 0; hb < NHB; ++hb) {
+    using RP = RegPlan<C, NCT>;
+    static_for<NHB>([&](auto hbc) {
+        constexpr int hb = decltype(hbc)::value;
         char* cur = ring + (hb & 1) * G::BLOB_B;
         char* nxt = ring + ((hb + 1) & 1) * G::BLOB_B;
         if (hb + 1 < NHB) stream_blob<G::BLOB_A>(blobA + (size_t)(hb + 1) * G::BLOB_A, nxt, wave, lane);
@@ -271,25 +329,23 @@ coupling_fused_kernel(float* __restrict__ x, const char* __restrict__ packed, in
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < G::KS1; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + ks * 1024 + lane * 16);
+        const unsigned abase1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(cur) + lane * 16;
+        a_stream<G::KS1>(abase1, [&](auto ks, const bf16x8& a) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bim[ct][ks], acc[ct], 0, 0, 0);
-        }
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bim[ct][decltype(ks)::value], acc[ct], 0, 0, 0);
+        });
+        static_for<NCT>([&](auto ctc) {
+            constexpr int ct = decltype(ctc)::value;
             actnorm_relu(acc[ct], cur + G::KS1 * 1024, h);
             H1[ct][2 * hb] = pack8(acc[ct], 0);
             H1[ct][2 * hb + 1] = pack8(acc[ct], 1);
-            // Pin the fragments into the accumulator half of the register file NOW: they are consumed only as
-            // MFMA B operands (which may be AGPRs).  Left alone, hipcc parks them in scratch until phase 3.
-            asm volatile("" : "+a"(H1[ct][2 * hb]));
-            asm volatile("" : "+a"(H1[ct][2 * hb + 1]));
-        }
+            // fragment order for the plan: f = ks * NCT + ct  (the last FRAGS_IN_AGPR fragments go to AGPRs)
+            pin_frag<((2 * hb) * NCT + ct >= 32 * NCT - RP::FRAGS_IN_AGPR)>(H1[ct][2 * hb]);
+            pin_frag<((2 * hb + 1) * NCT + ct >= 32 * NCT - RP::FRAGS_IN_AGPR)>(H1[ct][2 * hb + 1]);
+        });
         __syncthreads();
-    }
+    });
 
     // ---- 3. GEMM2 (+ActNorm+ReLU) chained into GEMM3 (tap contributions), hidden block by hidden block
     f32x16 accT[G::NRT][NCT];
@@ -308,29 +364,32 @@ coupling_fused_kernel(float* __restrict__ x, const char* __restrict__ packed, in
         for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 32; ++ks) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + ks * 1024 + lane * 16);
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, H1[ct][ks], acc[ct], 0, 0, 0);
-        }
+        // A stream of one stage (contiguous in the blob): 32 W2 k-steps, then 2*NRT W3 fragments; the GEMM2
+        // epilogue (ActNorm+ReLU, bf16 pack) runs at the seam while the first W3 fragments are already in flight.
+        constexpr int NA = 32 + 2 * G::NRT;
+        const unsigned abase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(cur) + lane * 16;
         bf16x8 H2[NCT][2];
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            actnorm_relu(acc[ct], cur + (32 + 2 * G::NRT) * 1024, h);
-            H2[ct][0] = pack8(acc[ct], 0);
-            H2[ct][1] = pack8(acc[ct], 1);
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int rt = 0; rt < G::NRT; ++rt) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(cur + (32 + s * G::NRT + rt) * 1024 + lane * 16);
+        a_stream<NA>(abase, [&](auto ic, const bf16x8& a) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i < 32) {
 #pragma unroll
                 for (int ct = 0; ct < NCT; ++ct)
-                    accT[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, H2[ct][s], accT[rt][ct], 0, 0, 0);
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, H1[ct][i], acc[ct], 0, 0, 0);
+            } else {
+                if constexpr (i == 32) {
+#pragma unroll
+                    for (int ct = 0; ct < NCT; ++ct) {
+                        actnorm_relu(acc[ct], cur + (32 + 2 * G::NRT) * 1024, h);
+                        H2[ct][0] = pack8(acc[ct], 0);
+                        H2[ct][1] = pack8(acc[ct], 1);
+                    }
+                }
+                constexpr int sidx = (i - 32) / G::NRT, rt = (i - 32) % G::NRT;
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct)
+                    accT[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, H2[ct][sidx], accT[rt][ct], 0, 0, 0);
             }
+        });
         __syncthreads();
     }
 
