@@ -77,6 +77,11 @@ int nfdp_invconv_apply_f32(const float* x, float* y, long npix, int C, const flo
 /* Fused flow head, glow.py:46-47: y = W (exp(scale)*(x+bias)). */
 int nfdp_actnorm_invconv_fwd_f32(const float* x, float* y, long npix, int C, const float* scale, const float* bias,
                                  const float* w, nfdp_stream_t stream);
+/* Same, and additionally writes the flow's two batch-independent log-det terms for nfdp_coupling_*'s ldj_const:
+ * ldj_const_out[0] = hw*sum(scale) (transforms.py:81), [1] = hw*logabsdet[0] (transforms.py:131), fp32.
+ * C must be one of {4,8,12,16,24,48} (templated kernels); otherwise NFDP_EUNSUPPORTED (use nfdp_flow_ldj_consts_f32). */
+int nfdp_flow_head_fwd_f32(const float* x, float* y, long npix, int C, const float* scale, const float* bias,
+                           const float* w, const float* logabsdet, float hw, float* ldj_const_out, nfdp_stream_t stream);
 /* Fused inverse, glow.py:61-62: x = (W^-1 y)*exp(-scale) - bias. */
 int nfdp_invconv_actnorm_inv_f32(const float* y, float* x, long npix, int C, const float* scale, const float* bias,
                                  const float* winv, nfdp_stream_t stream);

@@ -63,59 +63,84 @@ __global__ void __launch_bounds__(kBlock) actnorm_kernel(const float* __restrict
 }
 
 // ----------------------------------------------------------------------------- per-pixel CxC product, C templated
-// One 256-pixel tile per block iteration (grid-stride over tiles).
+// One workgroup = 64 pixels x 4 waves.  Lane = pixel, wave = quarter of the output channels: every lane keeps its
+// pixel's C inputs in VGPRs (conflict-free LDS row reads, stride C+1 words) and produces C/4 outputs with W rows
+// fetched through the scalar cache (wave-uniform addresses -> s_load, SGPR operands: one v_fma per MAC).  Splitting
+// by output channel instead of giving a lane the whole CxC product quarters the serial FMA chain and quadruples
+// the number of workgroups (128 at the 4x4 level of a B=512 batch instead of 32).  Tiles are staged through LDS so
+// global loads/stores are coalesced float4.  Workgroup 0 also emits the flow's two batch-independent log-det
+// terms (transforms.py:81, :131) so no extra launch is needed for them.
+constexpr int kTilePx = 64;
+
 template <int C, int MODE>
 __global__ void __launch_bounds__(kBlock) pixel_linear_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               long npix, const float* __restrict__ w,
                                                               const float* __restrict__ scale,
-                                                              const float* __restrict__ bias) {
-    constexpr int LD = C + 1;                       // odd word stride: lane l reads bank (l*LD+c)%32, all distinct
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ logabsdet, float hw,
+                                                              float* __restrict__ ldj_const_out) {
+    constexpr int LD = C + 1;
+    constexpr int OPW = (C + 3) / 4;                 // outputs per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* tile = smem;                             // [kBlock][LD]
-    float* es = smem + kBlock * LD;                 // [C]
-    float* bs = es + C;                             // [C]
+    float* xin = smem;                               // [64][LD]
+    float* yout = smem + kTilePx * LD;               // [64][LD]
+    float* es = yout + kTilePx * LD;                 // [C]
+    float* bs = es + C;                              // [C]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (MODE != kMatvec) {
         for (int c = threadIdx.x; c < C; c += kBlock) {
             es[c] = expf(MODE == kPostAffine ? -scale[c] : scale[c]);
             bs[c] = bias[c];
         }
     }
-    const long ntiles = (npix + kBlock - 1) / kBlock;
+    if (ldj_const_out != nullptr && blockIdx.x == 0 && wave == 0) {
+        double sacc = 0.0;
+        for (int c = lane; c < C; c += 64) sacc += (double)scale[c];
+        sacc = wave_sum_d(sacc);
+        if (lane == 0) {
+            ldj_const_out[0] = __fmul_rn(hw, (float)sacc);
+            ldj_const_out[1] = __fmul_rn(hw, logabsdet[0]);
+        }
+    }
+    const long ntiles = (npix + kTilePx - 1) / kTilePx;
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const long p0 = t * kBlock;
-        const int np = (int)((npix - p0) < kBlock ? (npix - p0) : kBlock);
+        const long p0 = t * kTilePx;
+        const int np = (int)((npix - p0) < kTilePx ? (npix - p0) : kTilePx);
         const int nval = np * C;
-        __syncthreads();                            // previous iteration's stores done with the tile; es/bs visible
+        __syncthreads();                             // previous tile's stores done; es/bs visible
         const float* src = x + p0 * C;
         if (C % 4 == 0) {
             const float4* src4 = reinterpret_cast<const float4*>(src);
             for (int i = threadIdx.x; i < (nval >> 2); i += kBlock) {
                 const float4 v = src4[i];
                 const int e = i << 2;
-                const int r = e / C, c = e % C;      // C%4==0: the 4 values stay inside one pixel row
-                float* d = tile + r * LD + c;
+                float* d = xin + (e / C) * LD + (e % C);
                 d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
             }
         } else {
-            for (int e = threadIdx.x; e < nval; e += kBlock) tile[(e / C) * LD + (e % C)] = src[e];
+            for (int e = threadIdx.x; e < nval; e += kBlock) xin[(e / C) * LD + (e % C)] = src[e];
         }
         __syncthreads();
-        if ((int)threadIdx.x < np) {
-            float* row = tile + threadIdx.x * LD;
+        if (lane < np) {
+            const float* row = xin + lane * LD;
             float v[C];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 v[c] = row[c];
                 if (MODE == kPreAffine) v[c] = es[c] * (v[c] + bs[c]);
             }
-#pragma unroll 4
-            for (int o = 0; o < C; ++o) {
-                const float* wr = w + o * C;         // uniform address -> scalar loads
-                float acc = 0.0f;
 #pragma unroll
-                for (int c = 0; c < C; ++c) acc = fmaf(wr[c], v[c], acc);
-                if (MODE == kPostAffine) acc = __fsub_rn(__fmul_rn(acc, es[o]), bs[o]);
-                row[o] = acc;                        // own row only: no hazard with other lanes
+            for (int j = 0; j < OPW; ++j) {
+                const int o = wave * OPW + j;        // wave-uniform
+                if (o < C) {
+                    const float* wr = w + o * C;     // uniform address -> scalar loads
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc = fmaf(wr[c], v[c], acc);
+                    if (MODE == kPostAffine) acc = __fsub_rn(__fmul_rn(acc, es[o]), bs[o]);
+                    yout[lane * LD + o] = acc;
+                }
             }
         }
         __syncthreads();
@@ -124,11 +149,11 @@ __global__ void __launch_bounds__(kBlock) pixel_linear_kernel(const float* __res
             float4* dst4 = reinterpret_cast<float4*>(dst);
             for (int i = threadIdx.x; i < (nval >> 2); i += kBlock) {
                 const int e = i << 2;
-                const float* s = tile + (e / C) * LD + (e % C);
-                dst4[i] = make_float4(s[0], s[1], s[2], s[3]);
+                const float* q = yout + (e / C) * LD + (e % C);
+                dst4[i] = make_float4(q[0], q[1], q[2], q[3]);
             }
         } else {
-            for (int e = threadIdx.x; e < nval; e += kBlock) dst[e] = tile[(e / C) * LD + (e % C)];
+            for (int e = threadIdx.x; e < nval; e += kBlock) dst[e] = yout[(e / C) * LD + (e % C)];
         }
     }
 }
@@ -158,31 +183,33 @@ __global__ void __launch_bounds__(kBlock) pixel_linear_generic_kernel(const floa
 
 template <int C, int MODE>
 int launch_templated(const float* x, float* y, long npix, const float* w, const float* scale, const float* bias,
-                     hipStream_t s) {
-    const size_t lds = ((size_t)kBlock * (C + 1) + 2 * C) * sizeof(float);
-    const long ntiles = cdiv(npix, kBlock);
-    const int grid = (int)(ntiles < 2048 ? ntiles : 2048);
-    hipLaunchKernelGGL((pixel_linear_kernel<C, MODE>), dim3(grid), dim3(kBlock), lds, s, x, y, npix, w, scale, bias);
+                     const float* lad, float hw, float* cst, hipStream_t s) {
+    const size_t lds = ((size_t)2 * kTilePx * (C + 1) + 2 * C) * sizeof(float);
+    const long ntiles = cdiv(npix, kTilePx);
+    const int grid = (int)(ntiles < 4096 ? ntiles : 4096);
+    hipLaunchKernelGGL((pixel_linear_kernel<C, MODE>), dim3(grid), dim3(kBlock), lds, s, x, y, npix, w, scale, bias, lad, hw,
+                       cst);
     return NFDP_OK;
 }
 
 template <int MODE>
 int dispatch(const char* what, const float* x, float* y, long npix, int C, const float* w, const float* scale,
-             const float* bias, nfdp_stream_t stream) {
+             const float* bias, nfdp_stream_t stream, const float* lad = nullptr, float hw = 0.f, float* cst = nullptr) {
     NFDP_REQUIRE(x && y && w, NFDP_EINVAL, "%s: null pointer", what);
     NFDP_REQUIRE(MODE == kMatvec || (scale && bias), NFDP_EINVAL, "%s: null scale/bias", what);
     NFDP_REQUIRE(npix >= 0 && C > 0, NFDP_ESHAPE, "%s: bad shape npix=%ld C=%d", what, npix, C);
     if (npix == 0) return NFDP_OK;
     hipStream_t s = as_stream(stream);
     switch (C) {
-        case 4: launch_templated<4, MODE>(x, y, npix, w, scale, bias, s); break;
-        case 8: launch_templated<8, MODE>(x, y, npix, w, scale, bias, s); break;
-        case 12: launch_templated<12, MODE>(x, y, npix, w, scale, bias, s); break;
-        case 16: launch_templated<16, MODE>(x, y, npix, w, scale, bias, s); break;
-        case 24: launch_templated<24, MODE>(x, y, npix, w, scale, bias, s); break;
-        case 48: launch_templated<48, MODE>(x, y, npix, w, scale, bias, s); break;
+        case 4: launch_templated<4, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 8: launch_templated<8, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 12: launch_templated<12, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 16: launch_templated<16, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 24: launch_templated<24, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 48: launch_templated<48, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
         default: {
             NFDP_REQUIRE(x != y, NFDP_EINVAL, "%s: in-place needs a templated C (got %d)", what, C);
+            NFDP_REQUIRE(cst == nullptr, NFDP_EUNSUPPORTED, "%s: fused log-det constants need a templated C (got %d)", what, C);
             const long total = npix * C;
             hipLaunchKernelGGL((pixel_linear_generic_kernel<MODE>), dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, s,
                                x, y, total, C, w, scale, bias);
@@ -230,6 +257,13 @@ extern "C" int nfdp_invconv_apply_f32(const float* x, float* y, long npix, int C
 extern "C" int nfdp_actnorm_invconv_fwd_f32(const float* x, float* y, long npix, int C, const float* scale,
                                             const float* bias, const float* w, nfdp_stream_t stream) {
     return dispatch<kPreAffine>("actnorm_invconv_fwd", x, y, npix, C, w, scale, bias, stream);
+}
+
+extern "C" int nfdp_flow_head_fwd_f32(const float* x, float* y, long npix, int C, const float* scale, const float* bias,
+                                      const float* w, const float* logabsdet, float hw, float* ldj_const_out,
+                                      nfdp_stream_t stream) {
+    NFDP_REQUIRE(logabsdet && ldj_const_out, NFDP_EINVAL, "flow_head_fwd: null pointer");
+    return dispatch<kPreAffine>("flow_head_fwd", x, y, npix, C, w, scale, bias, stream, logabsdet, hw, ldj_const_out);
 }
 
 extern "C" int nfdp_invconv_actnorm_inv_f32(const float* y, float* x, long npix, int C, const float* scale,

@@ -278,6 +278,26 @@ def actnorm_invconv_fwd(xh, scale, bias, w, out=None):
     return out
 
 
+_FLOW_HEAD_C = (4, 8, 12, 16, 24, 48)
+
+
+def flow_head_fwd(xh, scale, bias, w, logabsdet, out=None):
+    """ActNorm -> 1x1 conv in one pass (in place if out is xh) and the flow's two log-det constants as a device
+    fp32 [2] tensor (consumed by coupling_fwd / coupling_fused).  Falls back to two launches for untemplated C."""
+    _need(xh, torch.float32, "flow_head_fwd"); _dense(xh, "flow_head_fwd")
+    out = torch.empty_like(xh) if out is None else out
+    b, h, wd, c = xh.shape
+    if c not in _FLOW_HEAD_C:
+        cst = flow_ldj_consts(scale, logabsdet, h * wd)
+        actnorm_invconv_fwd(xh, scale, bias, w, out=out)
+        return out, cst
+    cst = torch.empty(2, device=xh.device, dtype=torch.float32)
+    _call("nfdp_flow_head_fwd_f32", _ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(w),
+          _ptr(logabsdet), float(h * wd), _ptr(cst), _stream(),
+          label=f"pixel_linear_kernel<{c},pre_affine>", flops=2.0 * xh.numel() * c, nbytes=8.0 * xh.numel())
+    return out, cst
+
+
 def invconv_actnorm_inv(yh, scale, bias, winv, out=None):
     _need(yh, torch.float32, "invconv_actnorm_inv"); _dense(yh, "invconv_actnorm_inv")
     out = torch.empty_like(yh) if out is None else out

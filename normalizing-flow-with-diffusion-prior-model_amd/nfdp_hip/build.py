@@ -15,6 +15,8 @@ OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(HERE, "libnfdp_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function", "-Wno-unused-result"]
+# per-file extras: the V-form fused kernels want MFMA accumulators in arch VGPRs (hidden fragments own the AGPRs)
+EXTRA = {"coupling_fused_v.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def sources():
@@ -30,10 +32,10 @@ def _stale(target, deps):
 
 def _compile(src, verbose):
     obj = os.path.join(OBJ, os.path.basename(src).rsplit(".", 1)[0] + ".o")
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     headers.append(os.path.join(os.path.dirname(PKG), "include", "nfdp.h"))
     if _stale(obj, [src] + headers):
-        cmd = ["hipcc", "-x", "hip"] + FLAGS + ["-c", src, "-o", obj]
+        cmd = ["hipcc", "-x", "hip"] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

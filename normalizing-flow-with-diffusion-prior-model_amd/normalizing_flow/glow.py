@@ -34,13 +34,13 @@ class StepFlow(Transform):
         an, ic = self.actnorm, self.invconv2d
         if not an.initialized():
             an.init_from(xh)
-        hw = xh.shape[1] * xh.shape[2]
         const = None
         if ldj is not None:
             if logabsdet is None:
                 logabsdet, _ = K.invconv_prepare(ic._w(), want_inverse=False)
-            const = K.flow_ldj_consts(an.scale.view(-1), logabsdet, hw)
-        K.actnorm_invconv_fwd(xh, an.scale.view(-1), an.bias.view(-1), ic._w(), out=xh)
+            _, const = K.flow_head_fwd(xh, an.scale.view(-1), an.bias.view(-1), ic._w(), logabsdet, out=xh)
+        else:
+            K.actnorm_invconv_fwd(xh, an.scale.view(-1), an.bias.view(-1), ic._w(), out=xh)
         return self.affcoupling.transform_nhwc_(xh, ldj, const)
 
     def invert_nhwc_(self, yh: Tensor, winv: Optional[Tensor] = None) -> Tensor:
@@ -59,11 +59,16 @@ class StepFlow(Transform):
         return K.as_nchw(self.invert_nhwc_(K.to_nhwc(y).contiguous().clone()))
 
 
-def _run_flows_fwd(flows: Sequence[StepFlow], xh: Tensor, ldj: Optional[Tensor]) -> Tensor:
-    lads = None
-    if ldj is not None:
-        w = torch.stack([f.invconv2d._w() for f in flows])                      # [K,C,C] gather (plumbing)
-        lads, _ = K.invconv_prepare(w, want_inverse=False)                      # one fp64 launch per level
+def _level_logdets(flows: Sequence[StepFlow]) -> Tensor:
+    """log|det W| of all K flows of a level in ONE fp64 launch (the reference runs K slogdets, transforms.py:131)."""
+    w = torch.stack([f.invconv2d._w() for f in flows])                          # [K,C,C] gather (plumbing)
+    lads, _ = K.invconv_prepare(w, want_inverse=False)
+    return lads
+
+
+def _run_flows_fwd(flows: Sequence[StepFlow], xh: Tensor, ldj: Optional[Tensor], lads: Optional[Tensor] = None) -> Tensor:
+    if ldj is not None and lads is None:
+        lads = _level_logdets(flows)
     for i, f in enumerate(flows):
         xh = f.transform_nhwc_(xh, ldj, None if lads is None else lads[i:i + 1])
     return xh
@@ -88,9 +93,9 @@ class GlowBlock(Transform):
         self.flows = nn.ModuleList([StepFlow(in_channels=flow_channels, compute=compute) for _ in range(K)])
         self.split = Split(flow_channels, learn_prior_mean_logs=learn_prior_mean_logs, compute=compute)
 
-    def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor]):
+    def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor], lads: Optional[Tensor] = None):
         yh = K.squeeze(xh)                       # fresh level buffer; flows then run in place
-        yh = _run_flows_fwd(self.flows, yh, ldj)
+        yh = _run_flows_fwd(self.flows, yh, ldj, lads)
         yv, z = self.split.transform_nhwc(yh, logp)
         return yv, z
 
@@ -142,11 +147,16 @@ class Glow(Transform):
         """-> ([z_0 .. z_{L-1}] NHWC tensors, ldj, logp); accumulators fp64, updated in place."""
         zs = []
         yh = xh
-        for block in self.blocks:
-            yh, z = block.transform_nhwc(yh, ldj, logp)
+        # every level's 1x1-conv log-dets up front: they depend only on the weights, and issuing them first keeps
+        # the three small fp64 launches off the critical path between levels
+        lads = [None] * self.L
+        if ldj is not None:
+            lads = [_level_logdets(b.flows) for b in self.blocks] + [_level_logdets(self.final_flows)]
+        for i, block in enumerate(self.blocks):
+            yh, z = block.transform_nhwc(yh, ldj, logp, lads[i])
             zs.append(z)
         yh = K.squeeze(yh)
-        yh = _run_flows_fwd(self.final_flows, yh, ldj)
+        yh = _run_flows_fwd(self.final_flows, yh, ldj, lads[-1])
         zs.append(yh)
         return zs
 
