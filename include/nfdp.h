@@ -78,7 +78,8 @@ int nfdp_invconv_apply_f32(const float* x, float* y, long npix, int C, const flo
 int nfdp_actnorm_invconv_fwd_f32(const float* x, float* y, long npix, int C, const float* scale, const float* bias,
                                  const float* w, nfdp_stream_t stream);
 /* Same, and additionally writes the flow's two batch-independent log-det terms for nfdp_coupling_*'s ldj_const:
- * ldj_const_out[0] = hw*sum(scale) (transforms.py:81), [1] = hw*logabsdet[0] (transforms.py:131), fp32.
+ * ldj_const_out[0] = hw*sum(scale) (transforms.py:81), [1] = hw*logabsdet[0] (transforms.py:131), fp32
+ * ([1] = 0 when logabsdet is NULL: the caller adds the 1x1-conv log-dets itself, e.g. from a side stream).
  * C must be one of {4,8,12,16,24,48} (templated kernels); otherwise NFDP_EUNSUPPORTED (use nfdp_flow_ldj_consts_f32). */
 int nfdp_flow_head_fwd_f32(const float* x, float* y, long npix, int C, const float* scale, const float* bias,
                            const float* w, const float* logabsdet, float hw, float* ldj_const_out, nfdp_stream_t stream);
@@ -126,6 +127,13 @@ int nfdp_coupling_fused_pack(const float* w1, const float* scale1, const float* 
                              const float* logs3, void* packed, int C, nfdp_stream_t stream);
 int nfdp_coupling_fused_bf16(float* x, const void* packed, int B, int H, int W, int C, double* ldj,
                              const float* ldj_const, int inverse, nfdp_stream_t stream);
+/* One whole flow step in one launch (StepFlow.transform / invert, glow.py:46-48, :60-62): the flow head
+ * y = W (exp(scale)(x+bias)) is applied to the tile in LDS before the coupling layer (forward), or
+ * x = (W y) exp(-scale) - bias after it (inverse; pass W^-1 as `w`).  Same geometry/packing as above.
+ * ldj[b] += H*W*sum(scale) (computed in-kernel, fp32) + (logdet_term ? logdet_term[0] : 0) + sum log(s+1e-6). */
+int nfdp_stepflow_fused_bf16(float* x, const void* packed, int B, int H, int W, int C, const float* scale,
+                             const float* bias, const float* w, double* ldj, const float* logdet_term, int inverse,
+                             nfdp_stream_t stream);
 /* ldj[b] += (double)(hw * (float)sum(v[0..n_sum)))  (fp32 product): the standalone ActNorm / InvConv2d log-det terms. */
 int nfdp_ldj_add_scaled_f32(double* ldj, int B, const float* v, int n_sum, float hw, nfdp_stream_t stream);
 /* out2[0] = hw*sum(scale[0..C)) (transforms.py:81), out2[1] = hw*logabsdet[0] (transforms.py:131), fp32: the two

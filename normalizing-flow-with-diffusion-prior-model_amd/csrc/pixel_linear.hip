@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(kBlock) pixel_linear_kernel(const float* __res
         sacc = wave_sum_d(sacc);
         if (lane == 0) {
             ldj_const_out[0] = __fmul_rn(hw, (float)sacc);
-            ldj_const_out[1] = __fmul_rn(hw, logabsdet[0]);
+            ldj_const_out[1] = logabsdet ? __fmul_rn(hw, logabsdet[0]) : 0.0f;
         }
     }
     const long ntiles = (npix + kTilePx - 1) / kTilePx;
@@ -262,7 +262,7 @@ extern "C" int nfdp_actnorm_invconv_fwd_f32(const float* x, float* y, long npix,
 extern "C" int nfdp_flow_head_fwd_f32(const float* x, float* y, long npix, int C, const float* scale, const float* bias,
                                       const float* w, const float* logabsdet, float hw, float* ldj_const_out,
                                       nfdp_stream_t stream) {
-    NFDP_REQUIRE(logabsdet && ldj_const_out, NFDP_EINVAL, "flow_head_fwd: null pointer");
+    NFDP_REQUIRE(ldj_const_out, NFDP_EINVAL, "flow_head_fwd: null pointer");
     return dispatch<kPreAffine>("flow_head_fwd", x, y, npix, C, w, scale, bias, stream, logabsdet, hw, ldj_const_out);
 }
 

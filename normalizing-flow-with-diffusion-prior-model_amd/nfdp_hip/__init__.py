@@ -288,6 +288,8 @@ def flow_head_fwd(xh, scale, bias, w, logabsdet, out=None):
     out = torch.empty_like(xh) if out is None else out
     b, h, wd, c = xh.shape
     if c not in _FLOW_HEAD_C:
+        if logabsdet is None:
+            logabsdet = torch.zeros(1, device=xh.device, dtype=torch.float32)
         cst = flow_ldj_consts(scale, logabsdet, h * wd)
         actnorm_invconv_fwd(xh, scale, bias, w, out=out)
         return out, cst
@@ -384,6 +386,20 @@ def coupling_fused(xh: torch.Tensor, packed: torch.Tensor, ldj: Optional[torch.T
     _call("nfdp_coupling_fused_bf16", _ptr(xh), _ptr(packed), b, h, w, c, _ptr(ldj), _ptr(ldj_const), int(inverse),
           _stream(), label=f"coupling_fused_kernel<{c},{w}> {'inv' if inverse else 'fwd'}", flops=flops,
           nbytes=8.0 * xh.numel())
+
+
+def stepflow_fused(xh: torch.Tensor, packed: torch.Tensor, scale, bias, w, ldj: Optional[torch.Tensor],
+                   logdet_term: Optional[torch.Tensor], inverse: bool) -> None:
+    """In place on xh [B,H,W,C]: ActNorm -> 1x1 conv -> coupling layer (or the exact reverse) in ONE launch."""
+    _need(xh, torch.float32, "stepflow_fused"); _dense(xh, "stepflow_fused")
+    b, h, wd, c = xh.shape
+    if ldj is not None:
+        _need(ldj, torch.float64, "stepflow_fused ldj")
+    ch = c // 2
+    flops = 2.0 * b * h * wd * (9 * ch * 512 + 512 * 512 + 9 * 512 * c + c * c)
+    _call("nfdp_stepflow_fused_bf16", _ptr(xh), _ptr(packed), b, h, wd, c, _ptr(scale), _ptr(bias), _ptr(w), _ptr(ldj),
+          _ptr(logdet_term), int(inverse), _stream(),
+          label=f"coupling_fused_kernel<{c},{wd}>+head {'inv' if inverse else 'fwd'}", flops=flops, nbytes=8.0 * xh.numel())
 
 
 def ldj_add_scaled(ldj: torch.Tensor, v: torch.Tensor, n_sum: int, hw: float):

@@ -29,14 +29,24 @@ class StepFlow(Transform):
         self.invconv2d = InvConv2d(in_channels=in_channels)
         self.affcoupling = AffineCoupling(in_channels=in_channels, n_features=coupling_net_n_features, compute=compute)
 
-    def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], logabsdet: Optional[Tensor] = None) -> Tensor:
-        """In place on xh.  logabsdet: this flow's [1] fp32 entry of the level's batched log|det| launch."""
+    def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], logabsdet: Optional[Tensor] = None,
+                        defer_logdet: bool = False) -> Tensor:
+        """In place on xh.  logabsdet: this flow's [1] fp32 entry of the level's batched log|det| launch;
+        defer_logdet=True leaves the 1x1-conv log-det out (the caller adds the level's sum at the end)."""
         an, ic = self.actnorm, self.invconv2d
         if not an.initialized():
             an.init_from(xh)
+        packed = self.affcoupling._fused_pack(xh)
+        if packed is not None and (ldj is None or defer_logdet or logabsdet is not None):
+            # whole flow step in one launch; a per-flow log|det| (if not deferred) is pre-scaled to H*W*log|det W|
+            term = None
+            if ldj is not None and logabsdet is not None:
+                term = K.flow_ldj_consts(an.scale.view(-1), logabsdet, xh.shape[1] * xh.shape[2])[1:]
+            K.stepflow_fused(xh, packed, an.scale.view(-1), an.bias.view(-1), ic._w(), ldj, term, inverse=False)
+            return xh
         const = None
         if ldj is not None:
-            if logabsdet is None:
+            if logabsdet is None and not defer_logdet:
                 logabsdet, _ = K.invconv_prepare(ic._w(), want_inverse=False)
             _, const = K.flow_head_fwd(xh, an.scale.view(-1), an.bias.view(-1), ic._w(), logabsdet, out=xh)
         else:
@@ -45,9 +55,13 @@ class StepFlow(Transform):
 
     def invert_nhwc_(self, yh: Tensor, winv: Optional[Tensor] = None) -> Tensor:
         an, ic = self.actnorm, self.invconv2d
-        self.affcoupling.invert_nhwc_(yh)
         if winv is None:
             _, winv = K.invconv_prepare(ic._w(), want_inverse=True)
+        packed = self.affcoupling._fused_pack(yh)
+        if packed is not None:
+            K.stepflow_fused(yh, packed, an.scale.view(-1), an.bias.view(-1), winv.reshape(-1), None, None, inverse=True)
+            return yh
+        self.affcoupling.invert_nhwc_(yh)
         return K.invconv_actnorm_inv(yh, an.scale.view(-1), an.bias.view(-1), winv, out=yh)
 
     def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
@@ -66,12 +80,24 @@ def _level_logdets(flows: Sequence[StepFlow]) -> Tensor:
     return lads
 
 
-def _run_flows_fwd(flows: Sequence[StepFlow], xh: Tensor, ldj: Optional[Tensor], lads: Optional[Tensor] = None) -> Tensor:
-    if ldj is not None and lads is None:
+def _run_flows_fwd(flows: Sequence[StepFlow], xh: Tensor, ldj: Optional[Tensor], lads: Optional[Tensor] = None,
+                   defer_logdet: bool = False) -> Tensor:
+    if ldj is not None and lads is None and not defer_logdet:
         lads = _level_logdets(flows)
     for i, f in enumerate(flows):
-        xh = f.transform_nhwc_(xh, ldj, None if lads is None else lads[i:i + 1])
+        xh = f.transform_nhwc_(xh, ldj, None if lads is None else lads[i:i + 1], defer_logdet)
     return xh
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    """One auxiliary HIP stream per device for weight-only work that can overlap the flow kernels."""
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
 
 
 def _run_flows_inv(flows: Sequence[StepFlow], yh: Tensor) -> Tensor:
@@ -93,9 +119,10 @@ class GlowBlock(Transform):
         self.flows = nn.ModuleList([StepFlow(in_channels=flow_channels, compute=compute) for _ in range(K)])
         self.split = Split(flow_channels, learn_prior_mean_logs=learn_prior_mean_logs, compute=compute)
 
-    def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor], lads: Optional[Tensor] = None):
+    def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor], lads: Optional[Tensor] = None,
+                       defer_logdet: bool = False):
         yh = K.squeeze(xh)                       # fresh level buffer; flows then run in place
-        yh = _run_flows_fwd(self.flows, yh, ldj, lads)
+        yh = _run_flows_fwd(self.flows, yh, ldj, lads, defer_logdet)
         yv, z = self.split.transform_nhwc(yh, logp)
         return yv, z
 
@@ -147,17 +174,32 @@ class Glow(Transform):
         """-> ([z_0 .. z_{L-1}] NHWC tensors, ldj, logp); accumulators fp64, updated in place."""
         zs = []
         yh = xh
-        # every level's 1x1-conv log-dets up front: they depend only on the weights, and issuing them first keeps
-        # the three small fp64 launches off the critical path between levels
-        lads = [None] * self.L
+        # The 1x1-conv log-dets depend only on the weights.  Their fp64 eliminations (one latency-bound workgroup
+        # per matrix, ~100 us per level) run on a side stream concurrently with the flow kernels; the per-level
+        # sums  H*W * sum_k log|det W_k|  are folded into ldj once at the end (an fp64 re-association of the
+        # reference's per-flow adds, transforms.py:131).
+        lads, done = None, None
         if ldj is not None:
-            lads = [_level_logdets(b.flows) for b in self.blocks] + [_level_logdets(self.final_flows)]
+            main = torch.cuda.current_stream()
+            side = _side_stream(xh.device)
+            side.wait_stream(main)                       # weights written on the main stream are visible
+            with torch.cuda.stream(side):
+                lads = [_level_logdets(b.flows) for b in self.blocks] + [_level_logdets(self.final_flows)]
+                done = torch.cuda.Event()
+                done.record(side)
+        hws = []
         for i, block in enumerate(self.blocks):
-            yh, z = block.transform_nhwc(yh, ldj, logp, lads[i])
+            yh, z = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True)
+            hws.append(z.shape[1] * z.shape[2])
             zs.append(z)
         yh = K.squeeze(yh)
-        yh = _run_flows_fwd(self.final_flows, yh, ldj, lads[-1])
+        hws.append(yh.shape[1] * yh.shape[2])
+        yh = _run_flows_fwd(self.final_flows, yh, ldj, None, defer_logdet=True)
         zs.append(yh)
+        if ldj is not None:
+            torch.cuda.current_stream().wait_event(done)
+            for lad, hw in zip(lads, hws):
+                K.ldj_add_scaled(ldj, lad, lad.numel(), hw)
         return zs
 
     def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[list, Tensor, Tensor]:
