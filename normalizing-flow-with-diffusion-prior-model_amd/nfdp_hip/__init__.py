@@ -15,7 +15,7 @@ from typing import Dict, Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnfdp_hip.so")
+LIB_PATH = os.environ.get("NFDP_LIB_PATH") or os.path.join(_HERE, "libnfdp_hip.so")   # override: profiling builds
 HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "nfdp.h")
 
 F32, BF16 = 0, 1
