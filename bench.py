@@ -182,7 +182,7 @@ def main():
             total_ms = sum(a["ms"] for a in agg.values())
             lbl, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
             avg_s = a["ms"] / a["n"] * 1e-3
-            if a["flops"] > 0 and lbl.startswith("conv"):
+            if a["flops"] > 0 and lbl.startswith(("conv", "coupling_fused")):
                 ach = a["flops"] / a["n"] / avg_s / 1e12
                 roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.compute], "unit": "TFLOP/s",
                             "frac": round(ach / PEAK[args.compute], 4), "traffic": None}
@@ -190,6 +190,17 @@ def main():
                 ach = a["bytes"] / a["n"] / avg_s / 1e9
                 roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+            # HBM traffic of the same kernel/shape from a separate rocprofv3 --pmc pass (committed summary):
+            # FETCH_SIZE doubled for wide coalesced reads on gfx950 (MI355X_MICROARCH.md §HBM) + WRITE_SIZE, per launch
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_fused_pmc_summary.json")))
+                key = {"coupling_fused_kernel<12,16>": "<12, 16, 2, ", "coupling_fused_kernel<24,8>": "<24, 8, 1, f",
+                       "coupling_fused_kernel<48,4>": "<48, 4, 1, f"}.get(lbl.split("+")[0].split(" ")[0])
+                if key and args.batch == 512:
+                    roofline["traffic"] = int((2 * pmc[key]["FETCH_SIZE_KB_raw"] + pmc[key]["WRITE_SIZE_KB"]) * 1024)
+                    roofline["traffic_note"] = "bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r01_e_fused_pmc_summary.json"
+            except (OSError, KeyError, ValueError):
+                pass
             roofline.update({"kernel": lbl, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": a["n"] // n_prof,
                              "share_of_step_kernel_time": round(a["ms"] / total_ms, 3)})
             top = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]
