@@ -154,6 +154,51 @@ int nfdp_gauss_sample_f32(const float* h, int h_mode, const float* eps, float* o
 /* GaussianPrior's degenerate conv on zeros (prior.py:79-80): h[n] = bias[n]*exp(3*logs[n]). */
 int nfdp_zeroconv_bias_only_f32(const float* bias, const float* logs, float* h, int n, nfdp_stream_t stream);
 
+/* ---------------------------------------------------------------- diffusion prior: U-Net blocks
+ * (diffusion_prior/gaussian_diffusion.py; the convolutions themselves use nfdp_conv2d_nhwc) */
+/* WeightStandardizedConv2d.forward :189-197: out[o] = (w[o]-mean_o) * rsqrt(var_o(biased) + eps) over fan_in. */
+int nfdp_ws_standardize_f32(const float* w, float* out, int Cout, int fan_in, float eps, nfdp_stream_t stream);
+/* Block.forward :267-276 after the conv: GroupNorm(groups) -> x*(scale+1)+shift (scale_shift [B][2C] or NULL) -> SiLU. */
+int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
+                            const float* beta, const float* scale_shift, float eps, nfdp_stream_t stream);
+/* LayerNorm.forward :205-209 (channel LayerNorm, gain only) + optional residual add (Residual :160-166). */
+int nfdp_chan_layernorm_f32(const float* x, float* y, long npix, int C, const float* gain, float eps,
+                            const float* residual, nfdp_stream_t stream);
+/* nn.Linear with fused activations (time_mlp :407-412, ResnetBlock.mlp :282-285):
+ * out = post(bias + pre(in) W^T); pre_act 0 none / 1 SiLU; post_act 0 none / 1 GELU(erf). */
+int nfdp_linear_f32(const float* in, const float* w, const float* bias, float* out, int B, int I, int O, int pre_act,
+                    int post_act, nfdp_stream_t stream);
+/* SinusoidalPosEmb.forward :231-237; t is int64 [B]. */
+int nfdp_sinusoidal_emb_f32(const long* t, float* out, int B, int dim, nfdp_stream_t stream);
+/* LinearAttention.forward :320-332 between to_qkv and to_out; qkv [B][n][3*heads*32] -> out [B][n][heads*32]. */
+int nfdp_linear_attention_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale,
+                              nfdp_stream_t stream);
+/* Attention.forward :347-357 between to_qkv and to_out (softmax over keys), n <= 256 pixels. */
+int nfdp_attention_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale,
+                       nfdp_stream_t stream);
+/* nn.Upsample(scale_factor=2, mode='nearest') :171;  x [B,H,W,C] -> y [B,2H,2W,C]. */
+int nfdp_upsample_nearest2x_f32(const float* x, float* y, int B, int C, int H, int W, nfdp_stream_t stream);
+int nfdp_add_f32(const float* a, const float* b, float* out, long n, nfdp_stream_t stream);
+
+/* ---------------------------------------------------------------- diffusion prior: Gaussian diffusion steps
+ * The [T] fp32 schedule buffers (GaussianDiffusion.__init__ :603-634) stay on the device and are indexed by t[b]. */
+/* q_sample :806-812. */
+int nfdp_q_sample_f32(const float* x0, const float* noise, const long* t, const float* sqrt_ac, const float* sqrt_1mac,
+                      float* out, int B, int per_sample, nfdp_stream_t stream);
+/* p_sample :706-715 around the eps prediction: predict_start_from_noise :641-645, clamp :700-701, q_posterior
+ * :665-672, + exp(0.5 logvar) * noise (noise NULL at t == 0).  x0_out may be NULL. */
+int nfdp_p_sample_f32(const float* x, const float* eps_hat, const float* noise, const long* t,
+                      const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, const float* post_coef1,
+                      const float* post_coef2, const float* post_logvar, float* out, float* x0_out, int B,
+                      int per_sample, int clip_x0, nfdp_stream_t stream);
+/* one ddim_sample iteration :749-773 with the step's scalars computed by the caller. */
+int nfdp_ddim_step_f32(const float* x, const float* eps_hat, const float* noise, float* out, long n, float sr,
+                       float srm1, float sqrt_alpha_next, float c, float sigma, int last, nfdp_stream_t stream);
+/* p_losses :855-859: out[0] = mean_b( mean_chw(|pred-target|^p) * p2_weight[t_b] ), p = 2 (l1=0) or 1 (l1=1);
+ * per_sample_ws: B floats of workspace. */
+int nfdp_diffusion_loss_f32(const float* pred, const float* target, const long* t, const float* p2_weight, int B,
+                            int per_sample, int l1, float* per_sample_ws, float* out, nfdp_stream_t stream);
+
 /* ---------------------------------------------------------------- NLL plumbing (normalizing_flow/utils.py) */
 /* out[0] = sum_b bpd_b, out[1] = B, with bpd_b = (log(n_bins)*n_pixel - (ldj_b+logp_b))*log2(e)/n_pixel
  * (utils.py:255-256; the mean is out[0]/out[1], left to the caller so ranks can all-reduce the pair). */

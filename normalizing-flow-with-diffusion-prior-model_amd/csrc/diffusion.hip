@@ -1,0 +1,133 @@
+// Gaussian-diffusion elementwise steps with on-device schedule lookup (no host sync: the [T] coefficient buffers
+// stay in HBM and are indexed by the per-sample timestep inside the kernel).
+// Reference: diffusion_prior/gaussian_diffusion.py
+//   q_sample :806-812             predict_start_from_noise :641-645      q_posterior :665-672
+//   p_mean_variance :696-704 (x0 clamp to [-1,1])   p_sample :706-715    ddim_sample :735-777   p_losses :855-859
+#include "nfdp_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// x_t = sqrt(ac[t]) x0 + sqrt(1-ac[t]) eps
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long* __restrict__ t,
+                                const float* __restrict__ sqrt_ac, const float* __restrict__ sqrt_1mac,
+                                float* __restrict__ out, long total, int per_sample) {
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const long tb = t[i / per_sample];
+        out[i] = __fadd_rn(__fmul_rn(sqrt_ac[tb], x0[i]), __fmul_rn(sqrt_1mac[tb], noise[i]));
+    }
+}
+
+// One reverse step:  x0 = clamp(sr[t] x - srm1[t] eps, -1, 1);  mean = c1[t] x0 + c2[t] x;
+//                    out = mean + exp(0.5 logvar[t]) * noise   (noise == nullptr at t == 0)
+__global__ void p_sample_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
+                                const long* __restrict__ t, const float* __restrict__ sr, const float* __restrict__ srm1,
+                                const float* __restrict__ c1, const float* __restrict__ c2, const float* __restrict__ logvar,
+                                float* __restrict__ out, float* __restrict__ x0_out, long total, int per_sample, int clip) {
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const long tb = t[i / per_sample];
+        const float xv = x[i];
+        float x0 = __fsub_rn(__fmul_rn(sr[tb], xv), __fmul_rn(srm1[tb], eps[i]));
+        if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float v = __fadd_rn(__fmul_rn(c1[tb], x0), __fmul_rn(c2[tb], xv));
+        if (noise) v = __fadd_rn(v, __fmul_rn(expf(__fmul_rn(0.5f, logvar[tb])), noise[i]));
+        out[i] = v;
+        if (x0_out) x0_out[i] = x0;
+    }
+}
+
+// DDIM step with host-side scalars:  x0 = clamp(sr x - srm1 eps);  last ? x0 : x0*sqrt_an + c*eps + sigma*noise
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
+                                 float* __restrict__ out, long total, float sr, float srm1, float sqrt_an, float c, float sigma,
+                                 int last) {
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const float e = eps[i];
+        float x0 = __fsub_rn(__fmul_rn(sr, x[i]), __fmul_rn(srm1, e));
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float v = x0;
+        if (!last) v = __fadd_rn(__fadd_rn(__fmul_rn(x0, sqrt_an), __fmul_rn(c, e)), __fmul_rn(sigma, noise[i]));
+        out[i] = v;
+    }
+}
+
+// out[0] = mean_b( mean_chw(|pred-target|^p) * w[t_b] );  one workgroup per sample writes its term, then a finisher
+__global__ void __launch_bounds__(kBlock) loss_per_sample_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                                const long* __restrict__ t, const float* __restrict__ w,
+                                                                int per_sample, int l1, float* __restrict__ per) {
+    __shared__ double red[4];
+    const long base = (long)blockIdx.x * per_sample;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < per_sample; i += kBlock) {
+        const float d = __fsub_rn(pred[base + i], target[base + i]);
+        acc += (double)(l1 ? fabsf(d) : __fmul_rn(d, d));
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = (float)((red[0] + red[1] + red[2] + red[3]) / per_sample);
+        per[blockIdx.x] = __fmul_rn(m, w[t[blockIdx.x]]);
+    }
+}
+
+__global__ void mean_kernel(const float* __restrict__ per, int B, float* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int b = 0; b < B; ++b) s += (double)per[b];
+        out[0] = (float)(s / B);
+    }
+}
+
+}  // namespace
+
+extern "C" int nfdp_q_sample_f32(const float* x0, const float* noise, const long* t, const float* sqrt_ac,
+                                 const float* sqrt_1mac, float* out, int B, int per_sample, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x0 && noise && t && sqrt_ac && sqrt_1mac && out, NFDP_EINVAL, "q_sample: null pointer");
+    NFDP_REQUIRE(B >= 0 && per_sample > 0, NFDP_ESHAPE, "q_sample: bad shape");
+    const long total = (long)B * per_sample;
+    if (total == 0) return NFDP_OK;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, as_stream(stream), x0, noise, t, sqrt_ac,
+                       sqrt_1mac, out, total, per_sample);
+    NFDP_CHECK_LAUNCH("q_sample");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_p_sample_f32(const float* x, const float* eps_hat, const float* noise, const long* t,
+                                 const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, const float* post_coef1,
+                                 const float* post_coef2, const float* post_logvar, float* out, float* x0_out, int B,
+                                 int per_sample, int clip_x0, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && eps_hat && t && sqrt_recip_ac && sqrt_recipm1_ac && post_coef1 && post_coef2 && post_logvar && out,
+                 NFDP_EINVAL, "p_sample: null pointer");
+    NFDP_REQUIRE(B >= 0 && per_sample > 0, NFDP_ESHAPE, "p_sample: bad shape");
+    const long total = (long)B * per_sample;
+    if (total == 0) return NFDP_OK;
+    hipLaunchKernelGGL(p_sample_kernel, dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, as_stream(stream), x, eps_hat, noise, t,
+                       sqrt_recip_ac, sqrt_recipm1_ac, post_coef1, post_coef2, post_logvar, out, x0_out, total, per_sample,
+                       clip_x0);
+    NFDP_CHECK_LAUNCH("p_sample");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_ddim_step_f32(const float* x, const float* eps_hat, const float* noise, float* out, long n, float sr,
+                                  float srm1, float sqrt_alpha_next, float c, float sigma, int last, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && eps_hat && out && (last || noise), NFDP_EINVAL, "ddim_step: null pointer");
+    NFDP_REQUIRE(n >= 0, NFDP_ESHAPE, "ddim_step: bad size");
+    if (n == 0) return NFDP_OK;
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), x, eps_hat, noise, out, n,
+                       sr, srm1, sqrt_alpha_next, c, sigma, last);
+    NFDP_CHECK_LAUNCH("ddim_step");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_diffusion_loss_f32(const float* pred, const float* target, const long* t, const float* p2_weight,
+                                       int B, int per_sample, int l1, float* per_sample_ws, float* out,
+                                       nfdp_stream_t stream) {
+    NFDP_REQUIRE(pred && target && t && p2_weight && per_sample_ws && out, NFDP_EINVAL, "diffusion_loss: null pointer");
+    NFDP_REQUIRE(B > 0 && per_sample > 0, NFDP_ESHAPE, "diffusion_loss: bad shape");
+    hipLaunchKernelGGL(loss_per_sample_kernel, dim3(B), dim3(kBlock), 0, as_stream(stream), pred, target, t, p2_weight, per_sample, l1,
+                       per_sample_ws);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, as_stream(stream), per_sample_ws, B, out);
+    NFDP_CHECK_LAUNCH("diffusion_loss");
+    return NFDP_OK;
+}

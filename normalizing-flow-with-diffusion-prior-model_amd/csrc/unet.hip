@@ -1,0 +1,368 @@
+// U-Net building blocks of the diffusion prior's eps-predictor on NHWC fp32 tensors (the convolutions themselves
+// run in conv.hip).  Reference: diffusion_prior/gaussian_diffusion.py
+//   WeightStandardizedConv2d :183-197   LayerNorm :200-209      SinusoidalPosEmb :225-237   time_mlp :407-412
+//   Block :260-276 (GroupNorm + scale/shift + SiLU)             ResnetBlock mlp :282-285
+//   LinearAttention :305-333            Attention :336-358      Upsample :169-173
+// These are HBM/latency-bound glue ops; each is one launch with fp64 statistics where the reference reduces.
+#include "nfdp_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double block_sum256(double v, double* red) {
+    v = wave_sum_d(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double s = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+    return s;                                   // valid in every thread
+}
+
+// ----------------------------------------------------------------------------- weight standardisation (:189-197)
+// one workgroup per output channel: w' = (w - mean) * rsqrt(var_biased + eps)
+__global__ void __launch_bounds__(kBlock) ws_standardize_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                               int fan_in, float eps) {
+    __shared__ double red[4];
+    const float* wr = w + (long)blockIdx.x * fan_in;
+    float* orow = out + (long)blockIdx.x * fan_in;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < fan_in; i += kBlock) s += (double)wr[i];
+    const double mean = block_sum256(s, red) / fan_in;
+    double q = 0.0;
+    for (int i = threadIdx.x; i < fan_in; i += kBlock) {
+        const double d = (double)wr[i] - mean;
+        q += d * d;
+    }
+    const double var = block_sum256(q, red) / fan_in;
+    const float m = (float)mean, r = rsqrtf(__fadd_rn((float)var, eps));
+    for (int i = threadIdx.x; i < fan_in; i += kBlock) orow[i] = __fmul_rn(__fsub_rn(wr[i], m), r);
+}
+
+// ----------------------------------------------------------------------------- GroupNorm + scale/shift + SiLU (:267-276)
+// one workgroup per (sample, group); x,y: [B][HW][C]; ss: [B][2C] (scale | shift) or null
+__global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __restrict__ x, float* __restrict__ y, int HW,
+                                                               int C, int groups, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ ss, float eps) {
+    __shared__ double red[4];
+    const int b = blockIdx.x / groups, g = blockIdx.x % groups;
+    const int cpg = C / groups, n = HW * cpg;
+    const long base = (long)b * HW * C + (long)g * cpg;
+    double s = 0.0;
+    for (int e = threadIdx.x; e < n; e += kBlock) s += (double)x[base + (long)(e / cpg) * C + (e % cpg)];
+    const double mean = block_sum256(s, red) / n;
+    double q = 0.0;
+    for (int e = threadIdx.x; e < n; e += kBlock) {
+        const double d = (double)x[base + (long)(e / cpg) * C + (e % cpg)] - mean;
+        q += d * d;
+    }
+    const double var = block_sum256(q, red) / n;
+    const float m = (float)mean, r = (float)(1.0 / sqrt(var + (double)eps));
+    for (int e = threadIdx.x; e < n; e += kBlock) {
+        const int c = g * cpg + (e % cpg);
+        const long idx = base + (long)(e / cpg) * C + (e % cpg);
+        float v = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x[idx], m), r), gamma[c]), beta[c]);
+        if (ss) v = __fadd_rn(__fmul_rn(v, __fadd_rn(ss[(long)b * 2 * C + c], 1.0f)), ss[(long)b * 2 * C + C + c]);
+        y[idx] = v / (1.0f + expf(-v));                      // SiLU = v * sigmoid(v)
+    }
+}
+
+// ----------------------------------------------------------------------------- channel LayerNorm, gain only (:205-209)
+// one wave per pixel; optional residual add (Residual(PreNorm(...)) :160-166 folds in at the caller's choice)
+__global__ void __launch_bounds__(kBlock) chan_layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               long npix, int C, const float* __restrict__ gain, float eps,
+                                                               const float* __restrict__ residual) {
+    const int lane = threadIdx.x & 63;
+    for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < npix; p += (long)gridDim.x * 4) {
+        const float* xr = x + p * C;
+        double s = 0.0;
+        for (int c = lane; c < C; c += 64) s += (double)xr[c];
+        const double mean = wave_sum_d(s) / C;
+        double q = 0.0;
+        for (int c = lane; c < C; c += 64) {
+            const double d = (double)xr[c] - mean;
+            q += d * d;
+        }
+        const double var = wave_sum_d(q) / C;
+        const float m = (float)mean, r = rsqrtf(__fadd_rn((float)var, eps));
+        for (int c = lane; c < C; c += 64) {
+            float v = __fmul_rn(__fmul_rn(__fsub_rn(xr[c], m), r), gain[c]);
+            if (residual) v = __fadd_rn(v, residual[p * C + c]);
+            y[p * C + c] = v;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- small linear with fused activations
+// out[b][o] = post( bias[o] + sum_i pre(in[b][i]) * W[o][i] );  pre: 0 none, 1 SiLU;  post: 0 none, 1 GELU(erf)
+__global__ void __launch_bounds__(kBlock) linear_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ out, int B, int I,
+                                                       int O, int pre, int post) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= B * O) return;
+    const int b = idx / O, o = idx % O;
+    const float* ir = in + (long)b * I;
+    const float* wr = w + (long)o * I;
+    float acc = 0.f;
+    for (int i = 0; i < I; ++i) {
+        float v = ir[i];
+        if (pre == 1) v = v / (1.0f + expf(-v));
+        acc = fmaf(v, wr[i], acc);
+    }
+    if (bias) acc = __fadd_rn(acc, bias[o]);
+    if (post == 1) acc = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));
+    out[idx] = acc;
+}
+
+// sinusoidal position embedding (:231-237): [sin(t f_j) | cos(t f_j)], f_j = exp(-j log(10000)/(half-1))
+__global__ void sinusoidal_kernel(const long* __restrict__ t, float* __restrict__ out, int B, int dim) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    const int half = dim / 2;
+    if (idx >= B * half) return;
+    const int b = idx / half, j = idx % half;
+    const float step = (float)(-(9.210340371976184 / (double)(half - 1)));       // -log(10000)/(half-1)
+    const float f = expf(__fmul_rn((float)j, step));
+    const float a = __fmul_rn((float)t[b], f);
+    out[(long)b * dim + j] = sinf(a);
+    out[(long)b * dim + half + j] = cosf(a);
+}
+
+// ----------------------------------------------------------------------------- linear attention core (:320-332)
+// qkv: [B][n][3*H*32] (q | k | v, head-major inside each third); out: [B][n][H*32].  One workgroup per (b, head):
+//   q <- softmax_d(q) * scale,  k <- softmax_n(k),  v <- v/n,  ctx[d][e] = sum_n k[d][n] v[e][n],
+//   out[e][n] = sum_d ctx[d][e] q[d][n]
+constexpr int DH = 32;
+__global__ void __launch_bounds__(kBlock) linear_attention_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 int n, int heads, float scale) {
+    __shared__ float kmax[DH], ksum[DH], ctx[DH][DH + 1];
+    __shared__ float part[8][DH];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int HD = heads * DH, ld = 3 * HD;
+    const float* base = qkv + (long)b * n * ld;
+    const float* qp = base + hd * DH;
+    const float* kp = base + HD + hd * DH;
+    const float* vp = base + 2 * HD + hd * DH;
+    const int d = threadIdx.x % DH, grp = threadIdx.x / DH;          // 8 groups stride over n
+    // 1. column max of k over n
+    float m = -INFINITY;
+    for (int i = grp; i < n; i += 8) m = fmaxf(m, kp[(long)i * ld + d]);
+    part[grp][d] = m;
+    __syncthreads();
+    if (threadIdx.x < DH) {
+        float mm = part[0][d];
+        for (int g = 1; g < 8; ++g) mm = fmaxf(mm, part[g][d]);
+        kmax[d] = mm;
+    }
+    __syncthreads();
+    // 2. column sum of exp(k - max)
+    float s = 0.f;
+    for (int i = grp; i < n; i += 8) s += expf(kp[(long)i * ld + d] - kmax[d]);
+    part[grp][d] = s;
+    __syncthreads();
+    if (threadIdx.x < DH) {
+        float ss = 0.f;
+        for (int g = 0; g < 8; ++g) ss += part[g][d];
+        ksum[d] = ss;
+    }
+    __syncthreads();
+    // 3. ctx[d][e], thread owns d and e in [4*grp, 4*grp+4)
+    {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float inv_n = 1.0f / (float)n;
+        const float km = kmax[d], ks = ksum[d];
+        for (int i = 0; i < n; ++i) {
+            const float p = expf(kp[(long)i * ld + d] - km) / ks;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(p, vp[(long)i * ld + 4 * grp + j] * inv_n, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ctx[d][4 * grp + j] = acc[j];
+    }
+    __syncthreads();
+    // 4. per pixel: softmax over d of q, times scale, then out[e] = sum_d ctx[d][e] q[d]
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        float q[DH];
+        float mq = -INFINITY;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) { q[dd] = qp[(long)i * ld + dd]; mq = fmaxf(mq, q[dd]); }
+        float sq = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) { q[dd] = expf(q[dd] - mq); sq += q[dd]; }
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) q[dd] = __fmul_rn(q[dd] / sq, scale);
+        float* orow = out + ((long)b * n + i) * HD + hd * DH;
+        for (int e = 0; e < DH; ++e) {
+            float acc = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < DH; ++dd) acc = fmaf(ctx[dd][e], q[dd], acc);
+            orow[e] = acc;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------- full attention core (:351-357), n <= 256
+// one workgroup per (b, head); K and V staged in LDS; thread i owns query i
+__global__ void __launch_bounds__(kBlock) attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n,
+                                                          int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // K[n][33], V[n][33]
+    float* Ks = sm;
+    float* Vs = sm + n * (DH + 1);
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int HD = heads * DH, ld = 3 * HD;
+    const float* base = qkv + (long)b * n * ld;
+    for (int e = threadIdx.x; e < n * DH; e += kBlock) {
+        const int i = e / DH, dd = e % DH;
+        Ks[i * (DH + 1) + dd] = base[(long)i * ld + HD + hd * DH + dd];
+        Vs[i * (DH + 1) + dd] = base[(long)i * ld + 2 * HD + hd * DH + dd];
+    }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    float q[DH];
+#pragma unroll
+    for (int dd = 0; dd < DH; ++dd) q[dd] = __fmul_rn(base[(long)i * ld + hd * DH + dd], scale);
+    float mx = -INFINITY;
+    for (int j = 0; j < n; ++j) {
+        float sdot = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) sdot = fmaf(q[dd], Ks[j * (DH + 1) + dd], sdot);
+        mx = fmaxf(mx, sdot);
+    }
+    float o[DH];
+#pragma unroll
+    for (int dd = 0; dd < DH; ++dd) o[dd] = 0.f;
+    float den = 0.f;
+    for (int j = 0; j < n; ++j) {
+        float sdot = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) sdot = fmaf(q[dd], Ks[j * (DH + 1) + dd], sdot);
+        const float p = expf(sdot - mx);
+        den += p;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) o[dd] = fmaf(p, Vs[j * (DH + 1) + dd], o[dd]);
+    }
+    float* orow = out + ((long)b * n + i) * HD + hd * DH;
+#pragma unroll
+    for (int dd = 0; dd < DH; ++dd) orow[dd] = o[dd] / den;
+}
+
+__global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C, int H, int W) {
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int ox = (int)(r % (2 * W));
+        r /= 2 * W;
+        const int oy = (int)(r % (2 * H));
+        const long b = r / (2 * H);
+        y[i] = x[((b * H + (oy >> 1)) * W + (ox >> 1)) * C + c];
+    }
+}
+
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) out[i] = __fadd_rn(a[i], b[i]);
+}
+
+}  // namespace
+
+extern "C" int nfdp_ws_standardize_f32(const float* w, float* out, int Cout, int fan_in, float eps, nfdp_stream_t stream) {
+    NFDP_REQUIRE(w && out, NFDP_EINVAL, "ws_standardize: null pointer");
+    NFDP_REQUIRE(Cout > 0 && fan_in > 0, NFDP_ESHAPE, "ws_standardize: bad shape");
+    hipLaunchKernelGGL(ws_standardize_kernel, dim3(Cout), dim3(kBlock), 0, as_stream(stream), w, out, fan_in, eps);
+    NFDP_CHECK_LAUNCH("ws_standardize");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
+                                       const float* beta, const float* scale_shift, float eps, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && y && gamma && beta, NFDP_EINVAL, "groupnorm_silu: null pointer");
+    NFDP_REQUIRE(B >= 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, NFDP_ESHAPE, "groupnorm_silu: bad shape");
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL(groupnorm_silu_kernel, dim3(B * groups), dim3(kBlock), 0, as_stream(stream), x, y, HW, C, groups, gamma,
+                       beta, scale_shift, eps);
+    NFDP_CHECK_LAUNCH("groupnorm_silu");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_chan_layernorm_f32(const float* x, float* y, long npix, int C, const float* gain, float eps,
+                                       const float* residual, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && y && gain, NFDP_EINVAL, "chan_layernorm: null pointer");
+    NFDP_REQUIRE(npix >= 0 && C > 0, NFDP_ESHAPE, "chan_layernorm: bad shape");
+    if (npix == 0) return NFDP_OK;
+    const long g = cdiv(npix, 4);
+    hipLaunchKernelGGL(chan_layernorm_kernel, dim3((int)(g < 4096 ? g : 4096)), dim3(kBlock), 0, as_stream(stream), x, y, npix, C,
+                       gain, eps, residual);
+    NFDP_CHECK_LAUNCH("chan_layernorm");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_linear_f32(const float* in, const float* w, const float* bias, float* out, int B, int I, int O, int pre_act,
+                               int post_act, nfdp_stream_t stream) {
+    NFDP_REQUIRE(in && w && out, NFDP_EINVAL, "linear: null pointer");
+    NFDP_REQUIRE(B >= 0 && I > 0 && O > 0, NFDP_ESHAPE, "linear: bad shape");
+    NFDP_REQUIRE(pre_act >= 0 && pre_act <= 1 && post_act >= 0 && post_act <= 1, NFDP_EINVAL, "linear: bad activation enum");
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL(linear_kernel, dim3((int)cdiv((long)B * O, kBlock)), dim3(kBlock), 0, as_stream(stream), in, w, bias, out, B,
+                       I, O, pre_act, post_act);
+    NFDP_CHECK_LAUNCH("linear");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_sinusoidal_emb_f32(const long* t, float* out, int B, int dim, nfdp_stream_t stream) {
+    NFDP_REQUIRE(t && out, NFDP_EINVAL, "sinusoidal_emb: null pointer");
+    NFDP_REQUIRE(B >= 0 && dim >= 4 && dim % 2 == 0, NFDP_ESHAPE, "sinusoidal_emb: bad shape");
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL(sinusoidal_kernel, dim3((int)cdiv((long)B * (dim / 2), kBlock)), dim3(kBlock), 0, as_stream(stream), t, out,
+                       B, dim);
+    NFDP_CHECK_LAUNCH("sinusoidal_emb");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_linear_attention_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale,
+                                         nfdp_stream_t stream) {
+    NFDP_REQUIRE(qkv && out, NFDP_EINVAL, "linear_attention: null pointer");
+    NFDP_REQUIRE(B >= 0 && n > 0 && heads > 0, NFDP_ESHAPE, "linear_attention: bad shape");
+    NFDP_REQUIRE(dim_head == DH, NFDP_EUNSUPPORTED, "linear_attention: dim_head=%d (32 only)", dim_head);
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL(linear_attention_kernel, dim3(B * heads), dim3(kBlock), 0, as_stream(stream), qkv, out, n, heads, scale);
+    NFDP_CHECK_LAUNCH("linear_attention");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_attention_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale,
+                                  nfdp_stream_t stream) {
+    NFDP_REQUIRE(qkv && out, NFDP_EINVAL, "attention: null pointer");
+    NFDP_REQUIRE(B >= 0 && n > 0 && heads > 0, NFDP_ESHAPE, "attention: bad shape");
+    NFDP_REQUIRE(dim_head == DH, NFDP_EUNSUPPORTED, "attention: dim_head=%d (32 only)", dim_head);
+    NFDP_REQUIRE(n <= kBlock, NFDP_EUNSUPPORTED, "attention: n=%d pixels (<= 256 in this build)", n);
+    if (B == 0) return NFDP_OK;
+    const size_t lds = (size_t)2 * n * (DH + 1) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * kBlock * (DH + 1) * (int)sizeof(float));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(kBlock), lds, as_stream(stream), qkv, out, n, heads, scale);
+    NFDP_CHECK_LAUNCH("attention");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_upsample_nearest2x_f32(const float* x, float* y, int B, int C, int H, int W, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && y, NFDP_EINVAL, "upsample: null pointer");
+    NFDP_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0, NFDP_ESHAPE, "upsample: bad shape");
+    const long total = (long)B * C * H * W * 4;
+    if (total == 0) return NFDP_OK;
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, as_stream(stream), x, y, total, C, H, W);
+    NFDP_CHECK_LAUNCH("upsample");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_add_f32(const float* a, const float* b, float* out, long n, nfdp_stream_t stream) {
+    NFDP_REQUIRE(a && b && out, NFDP_EINVAL, "add: null pointer");
+    NFDP_REQUIRE(n >= 0, NFDP_ESHAPE, "add: bad size");
+    if (n == 0) return NFDP_OK;
+    hipLaunchKernelGGL(add_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), a, b, out, n);
+    NFDP_CHECK_LAUNCH("add");
+    return NFDP_OK;
+}

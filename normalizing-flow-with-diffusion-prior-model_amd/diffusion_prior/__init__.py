@@ -1,0 +1,4 @@
+"""MI355X-native drop-in for the reference's `diffusion_prior` package (hot-path symbols)."""
+from .gaussian_diffusion import Unet, GaussianDiffusion, ModelPrediction
+from .latent_formaters import IdentityFormater, get_formater
+from .model import DiffusionModel, DiffusionPrior

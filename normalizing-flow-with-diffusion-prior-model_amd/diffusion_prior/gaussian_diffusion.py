@@ -1,0 +1,554 @@
+"""U-Net eps-predictor and Gaussian diffusion on the MI355X kernel library — mirrors the hot-path symbols of the
+reference's diffusion_prior/gaussian_diffusion.py (a trimmed denoising-diffusion-pytorch):
+  Unet :363-490 (+ blocks :160-358), schedules :501-537, GaussianDiffusion :540-867.
+
+Same constructor arguments, attribute names, method names/returns and the same module tree, so state_dict keys are
+identical.  Modules hold parameters in the reference's layouts; `forward` runs hand-written HIP kernels on NHWC
+tensors through the C ABI (convs: MFMA implicit GEMM with weight standardisation folded into the weight pack;
+GroupNorm+scale/shift+SiLU, channel LayerNorm(+residual), linear/full attention cores, time MLP, and the fused
+reverse-diffusion step with on-device schedule lookup are one launch each).  All randomness can be injected
+(`noise=` / `noises=`) for reproducible parity tests.
+
+Not built (raise NotImplementedError): objectives other than 'pred_noise', self-conditioning, learned / random
+sinusoidal embeddings, the VLB loop.
+"""
+import math
+from collections import namedtuple
+from functools import partial
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn, Tensor
+
+import nfdp_hip as K
+
+ModelPrediction = namedtuple('ModelPrediction', ['pred_noise', 'pred_x_start'])
+
+
+def exists(x):
+    return x is not None
+
+
+def default(val, d):
+    if exists(val):
+        return val
+    return d() if callable(d) else d
+
+
+def identity(t, *args, **kwargs):
+    return t
+
+
+def normalize_to_neg_one_to_one(img):
+    raise NotImplementedError("auto_normalize=True is not on the hot path (DiffusionModel passes False, model.py:37-38)")
+
+
+# ----------------------------------------------------------------------------- parameter holders
+class _Conv(nn.Module):
+    """nn.Conv2d's parameter names/shapes/default init; forward = MFMA implicit GEMM (+ optional weight standardisation)."""
+
+    def __init__(self, cin, cout, k, bias=True, standardize=False):
+        super().__init__()
+        self.cin, self.cout, self.k, self.standardize = cin, cout, k, standardize
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        bound = 1.0 / math.sqrt(cin * k * k)
+        nn.init.uniform_(self.weight, -bound, bound)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout))
+            nn.init.uniform_(self.bias, -bound, bound)
+        else:
+            self.register_parameter("bias", None)
+        self._key, self._packed = None, None
+
+    def packed(self, compute: int) -> Tensor:
+        key = (self.weight.data_ptr(), self.weight._version, compute)
+        if key != self._key:
+            w = self.weight.detach()
+            if self.standardize:                       # WeightStandardizedConv2d.forward :189-195, eps 1e-5 (fp32)
+                w = K.ws_standardize(w, 1e-5)
+            self._packed, self._key = K.conv_pack(w, compute), key
+        return self._packed
+
+    def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None) -> Tensor:
+        c = K.compute_enum(compute)
+        return K.conv2d(xh, self.packed(c), self.cout, self.k, add=self.bias, compute=c, out_dtype=K.F32)
+
+
+class WeightStandardizedConv2d(_Conv):
+    """(reference :183-197)"""
+
+    def __init__(self, cin, cout, k, padding=1):
+        super().__init__(cin, cout, k, bias=True, standardize=True)
+
+
+class _Linear(nn.Module):
+    def __init__(self, fin, fout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(fout, fin))
+        self.bias = nn.Parameter(torch.empty(fout))
+        bound = 1.0 / math.sqrt(fin)
+        nn.init.uniform_(self.weight, -bound, bound)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _GroupNormParams(nn.Module):
+    def __init__(self, groups, dim):
+        super().__init__()
+        self.num_groups = groups
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+
+class _Marker(nn.Module):
+    """Parameter-free placeholder keeping the reference's nn.Sequential indices (Rearrange / nn.Upsample / SiLU / GELU)."""
+
+    def __init__(self, what):
+        super().__init__()
+        self.what = what
+
+
+# ----------------------------------------------------------------------------- small helper modules (:160-255)
+class Residual(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+
+
+class LayerNorm(nn.Module):
+    """Channel LayerNorm with a gain only  (reference :200-209)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(1, dim, 1, 1))
+
+
+class PreNorm(nn.Module):
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.fn = fn
+        self.norm = LayerNorm(dim)
+
+
+def Upsample(dim, dim_out=None):
+    return nn.Sequential(_Marker("nearest2x"), _Conv(dim, default(dim_out, dim), 3))
+
+
+def Downsample(dim, dim_out=None):
+    return nn.Sequential(_Marker("squeeze2x2"), _Conv(dim * 4, default(dim_out, dim), 1))
+
+
+class SinusoidalPosEmb(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+
+
+class Block(nn.Module):
+    """WS-conv3x3 -> GroupNorm -> x*(scale+1)+shift -> SiLU  (reference :260-276)."""
+
+    def __init__(self, dim, dim_out, groups=8):
+        super().__init__()
+        self.proj = WeightStandardizedConv2d(dim, dim_out, 3, padding=1)
+        self.norm = _GroupNormParams(groups, dim_out)
+        self.act = _Marker("silu")
+
+    def forward_nhwc(self, xh, scale_shift=None, compute=None):
+        h = self.proj.forward_nhwc(xh, compute)
+        return K.groupnorm_silu(h, self.norm.num_groups, self.norm.weight, self.norm.bias, scale_shift, 1e-5)
+
+
+class ResnetBlock(nn.Module):
+    """(reference :279-302)"""
+
+    def __init__(self, dim, dim_out, *, time_emb_dim=None, groups=8):
+        super().__init__()
+        self.mlp = nn.Sequential(_Marker("silu"), _Linear(time_emb_dim, dim_out * 2)) if exists(time_emb_dim) else None
+        self.block1 = Block(dim, dim_out, groups=groups)
+        self.block2 = Block(dim_out, dim_out, groups=groups)
+        self.res_conv = _Conv(dim, dim_out, 1) if dim != dim_out else nn.Identity()
+
+    def forward_nhwc(self, xh, temb=None, compute=None):
+        ss = None
+        if exists(self.mlp) and exists(temb):
+            ss = K.linear(temb, self.mlp[1].weight, self.mlp[1].bias, pre_act=1)     # SiLU -> Linear: [B, scale | shift]
+        h = self.block1.forward_nhwc(xh, ss, compute)
+        h = self.block2.forward_nhwc(h, None, compute)
+        res = self.res_conv.forward_nhwc(xh, compute) if isinstance(self.res_conv, _Conv) else xh
+        return K.add(h, res.contiguous())
+
+
+class LinearAttention(nn.Module):
+    """(reference :305-333)"""
+
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        self.scale = dim_head ** -0.5
+        self.heads, self.dim_head = heads, dim_head
+        hidden_dim = dim_head * heads
+        self.to_qkv = _Conv(dim, hidden_dim * 3, 1, bias=False)
+        self.to_out = nn.Sequential(_Conv(hidden_dim, dim, 1), LayerNorm(dim))
+
+
+class Attention(nn.Module):
+    """(reference :336-358)"""
+
+    def __init__(self, dim, heads=4, dim_head=32):
+        super().__init__()
+        self.scale = dim_head ** -0.5
+        self.heads, self.dim_head = heads, dim_head
+        hidden_dim = dim_head * heads
+        self.to_qkv = _Conv(dim, hidden_dim * 3, 1, bias=False)
+        self.to_out = _Conv(hidden_dim, dim, 1)
+
+
+def _attn_block_nhwc(res: Residual, xh: Tensor, compute=None) -> Tensor:
+    """Residual(PreNorm(dim, LinearAttention | Attention))  (reference :160-166, :212-220)."""
+    pre = res.fn
+    att = pre.fn
+    xn = K.chan_layernorm(xh, pre.norm.g.view(-1))
+    qkv = att.to_qkv.forward_nhwc(xn, compute)
+    if isinstance(att, LinearAttention):
+        a = K.linear_attention(qkv, att.heads, att.dim_head, att.scale)
+        o = att.to_out[0].forward_nhwc(a, compute)
+        return K.chan_layernorm(o, att.to_out[1].g.view(-1), residual=xh)       # LayerNorm(to_out conv) + x
+    a = K.attention(qkv, att.heads, att.dim_head, att.scale)
+    return K.add(att.to_out.forward_nhwc(a, compute), xh)
+
+
+# ----------------------------------------------------------------------------- model (:363-490)
+class Unet(nn.Module):
+    def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=3, self_condition=False,
+                 resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
+                 random_fourier_features=False, learned_sinusoidal_dim=16, compute: Optional[str] = None):
+        super().__init__()
+        if self_condition or learned_sinusoidal_cond or random_fourier_features:
+            raise NotImplementedError("self-conditioning / learned sinusoidal embeddings are not on the hot path")
+        self.compute = compute
+        self.dim = dim
+        self.channels = channels
+        self.self_condition = self_condition
+        input_channels = channels
+        init_dim = default(init_dim, dim)
+        self.init_conv = _Conv(input_channels, init_dim, 7)
+        dims = [init_dim, *map(lambda m: dim * m, dim_mults)]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        block_klass = partial(ResnetBlock, groups=resnet_block_groups)
+        time_dim = dim * 4
+        self.random_or_learned_sinusoidal_cond = False
+        self.time_mlp = nn.Sequential(SinusoidalPosEmb(dim), _Linear(dim, time_dim), _Marker("gelu"), _Linear(time_dim, time_dim))
+        self.downs = nn.ModuleList([])
+        self.ups = nn.ModuleList([])
+        num_resolutions = len(in_out)
+        for ind, (dim_in, dim_out) in enumerate(in_out):
+            is_last = ind >= (num_resolutions - 1)
+            self.downs.append(nn.ModuleList([
+                block_klass(dim_in, dim_in, time_emb_dim=time_dim),
+                block_klass(dim_in, dim_in, time_emb_dim=time_dim),
+                Residual(PreNorm(dim_in, LinearAttention(dim_in))),
+                Downsample(dim_in, dim_out) if not is_last else _Conv(dim_in, dim_out, 3)
+            ]))
+        mid_dim = dims[-1]
+        self.mid_block1 = block_klass(mid_dim, mid_dim, time_emb_dim=time_dim)
+        self.mid_attn = Residual(PreNorm(mid_dim, Attention(mid_dim)))
+        self.mid_block2 = block_klass(mid_dim, mid_dim, time_emb_dim=time_dim)
+        for ind, (dim_in, dim_out) in enumerate(reversed(in_out)):
+            is_last = ind == (len(in_out) - 1)
+            self.ups.append(nn.ModuleList([
+                block_klass(dim_out + dim_in, dim_out, time_emb_dim=time_dim),
+                block_klass(dim_out + dim_in, dim_out, time_emb_dim=time_dim),
+                Residual(PreNorm(dim_out, LinearAttention(dim_out))),
+                Upsample(dim_out, dim_in) if not is_last else _Conv(dim_out, dim_in, 3)
+            ]))
+        default_out_dim = channels * (1 if not learned_variance else 2)
+        self.out_dim = default(out_dim, default_out_dim)
+        self.final_res_block = block_klass(dim * 2, dim, time_emb_dim=time_dim)
+        self.final_conv = _Conv(dim, self.out_dim, 1)
+
+    def time_embedding(self, time: Tensor) -> Tensor:
+        """sinusoidal -> Linear -> GELU -> Linear  (reference :407-412)."""
+        e = K.sinusoidal_emb(time.long(), self.dim)
+        e = K.linear(e, self.time_mlp[1].weight, self.time_mlp[1].bias, post_act=1)
+        return K.linear(e, self.time_mlp[3].weight, self.time_mlp[3].bias)
+
+    def forward_nhwc(self, xh: Tensor, time: Tensor) -> Tensor:
+        c = self.compute
+        x = self.init_conv.forward_nhwc(xh, c)
+        r = x
+        t = self.time_embedding(time)
+        hs = []
+        for block1, block2, attn, downsample in self.downs:
+            x = block1.forward_nhwc(x, t, c)
+            hs.append(x)
+            x = block2.forward_nhwc(x, t, c)
+            x = _attn_block_nhwc(attn, x, c)
+            hs.append(x)
+            if isinstance(downsample, nn.Sequential):
+                x = downsample[1].forward_nhwc(K.squeeze(x), c)          # Rearrange(p1 p2) + 1x1  (:176-180)
+            else:
+                x = downsample.forward_nhwc(x, c)
+        x = self.mid_block1.forward_nhwc(x, t, c)
+        x = _attn_block_nhwc(self.mid_attn, x, c)
+        x = self.mid_block2.forward_nhwc(x, t, c)
+        for block1, block2, attn, upsample in self.ups:
+            x = block1.forward_nhwc(K.concat_channels(x, hs.pop()), t, c)
+            x = block2.forward_nhwc(K.concat_channels(x, hs.pop()), t, c)
+            x = _attn_block_nhwc(attn, x, c)
+            if isinstance(upsample, nn.Sequential):
+                x = upsample[1].forward_nhwc(K.upsample2x(x), c)         # nearest x2 + 3x3  (:169-173)
+            else:
+                x = upsample.forward_nhwc(x, c)
+        x = self.final_res_block.forward_nhwc(K.concat_channels(x, r), t, c)
+        return self.final_conv.forward_nhwc(x, c)
+
+    def forward(self, x, time, x_self_cond=None):
+        """(reference :451-490)"""
+        if x_self_cond is not None:
+            raise NotImplementedError("self-conditioning is not on the hot path")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("nfdp HIP path: backward kernels are not built yet; call under torch.no_grad()")
+        return K.as_nchw(self.forward_nhwc(K.to_nhwc(x).contiguous(), time))
+
+
+# ----------------------------------------------------------------------------- schedules (:495-537)
+def extract(a, t, x_shape):
+    b, *_ = t.shape
+    out = a.gather(-1, t)
+    return out.reshape(b, *((1,) * (len(x_shape) - 1)))
+
+
+def linear_beta_schedule(timesteps):
+    scale = 1000 / timesteps
+    return torch.linspace(scale * 0.0001, scale * 0.02, timesteps, dtype=torch.float64)
+
+
+def cosine_beta_schedule(timesteps, s=0.008):
+    steps = timesteps + 1
+    t = torch.linspace(0, timesteps, steps, dtype=torch.float64) / timesteps
+    alphas_cumprod = torch.cos((t + s) / (1 + s) * math.pi * 0.5) ** 2
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.999)
+
+
+def sigmoid_beta_schedule(timesteps, start=-3, end=3, tau=1, clamp_min=1e-5):
+    steps = timesteps + 1
+    t = torch.linspace(0, timesteps, steps, dtype=torch.float64) / timesteps
+    v_start = torch.tensor(start / tau).sigmoid()
+    v_end = torch.tensor(end / tau).sigmoid()
+    alphas_cumprod = (-((t * (end - start) + start) / tau).sigmoid() + v_end) / (v_end - v_start)
+    alphas_cumprod = alphas_cumprod / alphas_cumprod[0]
+    betas = 1 - (alphas_cumprod[1:] / alphas_cumprod[:-1])
+    return torch.clip(betas, 0, 0.999)
+
+
+# ----------------------------------------------------------------------------- GaussianDiffusion (:540-867)
+class GaussianDiffusion(nn.Module):
+    def __init__(self, model, *, image_size, timesteps=1000, sampling_timesteps=None, loss_type='l1',
+                 objective='pred_noise', beta_schedule='sigmoid', schedule_fn_kwargs=dict(), p2_loss_weight_gamma=0.,
+                 p2_loss_weight_k=1, ddim_sampling_eta=0., auto_normalize=True):
+        super().__init__()
+        assert not (type(self) == GaussianDiffusion and model.channels != model.out_dim)
+        assert not model.random_or_learned_sinusoidal_cond
+        self.model = model
+        self.channels = self.model.channels
+        self.self_condition = self.model.self_condition
+        self.image_size = image_size
+        self.objective = objective
+        assert objective in {'pred_noise', 'pred_x0', 'pred_v'}, 'objective must be either pred_noise, pred_x0 or pred_v'
+        if objective != 'pred_noise':
+            raise NotImplementedError("only objective='pred_noise' is built (the reference's recipes use it)")
+        if beta_schedule == 'linear':
+            beta_schedule_fn = linear_beta_schedule
+        elif beta_schedule == 'cosine':
+            beta_schedule_fn = cosine_beta_schedule
+        elif beta_schedule == 'sigmoid':
+            beta_schedule_fn = sigmoid_beta_schedule
+        else:
+            raise ValueError(f'unknown beta schedule {beta_schedule}')
+        betas = beta_schedule_fn(timesteps, **schedule_fn_kwargs)
+        alphas = 1. - betas
+        alphas_cumprod = torch.cumprod(alphas, dim=0)
+        alphas_cumprod_prev = torch.nn.functional.pad(alphas_cumprod[:-1], (1, 0), value=1.)
+        timesteps, = betas.shape
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        self.sampling_timesteps = default(sampling_timesteps, timesteps)
+        assert self.sampling_timesteps <= timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        register_buffer = lambda name, val: self.register_buffer(name, val.to(torch.float32))
+        register_buffer('betas', betas)
+        register_buffer('alphas_cumprod', alphas_cumprod)
+        register_buffer('alphas_cumprod_prev', alphas_cumprod_prev)
+        register_buffer('sqrt_alphas_cumprod', torch.sqrt(alphas_cumprod))
+        register_buffer('sqrt_one_minus_alphas_cumprod', torch.sqrt(1. - alphas_cumprod))
+        register_buffer('log_one_minus_alphas_cumprod', torch.log(1. - alphas_cumprod))
+        register_buffer('sqrt_recip_alphas_cumprod', torch.sqrt(1. / alphas_cumprod))
+        register_buffer('sqrt_recipm1_alphas_cumprod', torch.sqrt(1. / alphas_cumprod - 1))
+        posterior_variance = betas * (1. - alphas_cumprod_prev) / (1. - alphas_cumprod)
+        register_buffer('posterior_variance', posterior_variance)
+        register_buffer('posterior_log_variance_clipped', torch.log(posterior_variance.clamp(min=1e-20)))
+        register_buffer('posterior_mean_coef1', betas * torch.sqrt(alphas_cumprod_prev) / (1. - alphas_cumprod))
+        register_buffer('posterior_mean_coef2', (1. - alphas_cumprod_prev) * torch.sqrt(alphas) / (1. - alphas_cumprod))
+        register_buffer('p2_loss_weight', (p2_loss_weight_k + alphas_cumprod / (1 - alphas_cumprod)) ** -p2_loss_weight_gamma)
+        # kernel-side helper (not part of the reference's state): -sqrt(1/ac - 1) so x0 = a[t]*x + b[t]*eps is one launch
+        self.register_buffer('_neg_sqrt_recipm1', -self.sqrt_recipm1_alphas_cumprod.clone(), persistent=False)
+        if auto_normalize:
+            raise NotImplementedError("auto_normalize=True is not on the hot path (DiffusionModel passes False)")
+        self.normalize = identity
+        self.unnormalize = identity
+
+    # ---- closed-form pieces
+    def predict_start_from_noise(self, x_t, t, noise):
+        """sqrt(1/ac) x_t - sqrt(1/ac - 1) eps  (reference :641-645)."""
+        xh, nh = K.to_nhwc(x_t).contiguous(), K.to_nhwc(noise).contiguous()
+        return K.as_nchw(K.q_sample(xh, nh, t.contiguous(), self.sqrt_recip_alphas_cumprod, self._neg_sqrt_recipm1))
+
+    def q_posterior(self, x_start, x_t, t):
+        """(reference :665-672)"""
+        xs, xt = K.to_nhwc(x_start).contiguous(), K.to_nhwc(x_t).contiguous()
+        mean = K.as_nchw(K.q_sample(xs, xt, t.contiguous(), self.posterior_mean_coef1, self.posterior_mean_coef2))
+        return mean, extract(self.posterior_variance, t, x_t.shape), extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    def model_predictions(self, x, t, x_self_cond=None, clip_x_start=False):
+        """(reference :674-694)"""
+        xh = K.to_nhwc(x).contiguous()
+        eps = self.model.forward_nhwc(xh, t)
+        _, x0 = K.p_sample(xh, eps, None, t.contiguous(), self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
+                           self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
+                           want_x0=True, clip=clip_x_start)
+        return ModelPrediction(K.as_nchw(eps), K.as_nchw(x0))
+
+    def p_mean_variance(self, x, t, x_self_cond=None, clip_denoised=True):
+        """(reference :696-704)"""
+        xh = K.to_nhwc(x).contiguous()
+        eps = self.model.forward_nhwc(xh, t)
+        mean, x0 = K.p_sample(xh, eps, None, t.contiguous(), self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
+                              self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
+                              want_x0=True, clip=clip_denoised)
+        return (K.as_nchw(mean), extract(self.posterior_variance, t, x.shape),
+                extract(self.posterior_log_variance_clipped, t, x.shape), K.as_nchw(x0))
+
+    def _p_sample_nhwc(self, xh: Tensor, t: int, noise: Optional[Tensor], want_x0: bool):
+        b = xh.shape[0]
+        tb = torch.full((b,), t, device=xh.device, dtype=torch.long)
+        eps = self.model.forward_nhwc(xh, tb)
+        if t > 0 and noise is None:
+            noise = torch.randn_like(xh)
+        return K.p_sample(xh, eps, noise if t > 0 else None, tb, self.sqrt_recip_alphas_cumprod,
+                          self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1, self.posterior_mean_coef2,
+                          self.posterior_log_variance_clipped, want_x0=want_x0, clip=True)
+
+    @torch.no_grad()
+    def p_sample(self, x, t: int, x_self_cond=None, noise: Optional[Tensor] = None):
+        """One reverse step (reference :706-715); `noise` (logical NCHW) replaces the randn_like draw."""
+        nh = None if noise is None else K.to_nhwc(noise).contiguous()
+        img, x0 = self._p_sample_nhwc(K.to_nhwc(x).contiguous(), t, nh, True)
+        return K.as_nchw(img), K.as_nchw(x0)
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, return_all_timesteps=False, x_T: Optional[Tensor] = None,
+                      noises: Optional[Sequence[Tensor]] = None):
+        """T sequential reverse steps (reference :717-733).  x_T / noises (one per step t = T-1..1, logical NCHW)
+        replace the device RNG draws."""
+        device = self.betas.device
+        b, c, h, w = shape
+        img = torch.randn((b, h, w, c), device=device) if x_T is None else K.to_nhwc(x_T.to(device)).contiguous()
+        imgs = [img]
+        for i, t in enumerate(reversed(range(0, self.num_timesteps))):
+            nz = None if noises is None or t == 0 else K.to_nhwc(noises[i].to(device)).contiguous()
+            img, _ = self._p_sample_nhwc(img, t, nz, False)
+            if return_all_timesteps:
+                imgs.append(img)
+        ret = K.as_nchw(img) if not return_all_timesteps else torch.stack([K.as_nchw(i) for i in imgs], dim=1)
+        return self.unnormalize(ret)
+
+    @torch.no_grad()
+    def ddim_sample(self, shape, return_all_timesteps=False, x_T: Optional[Tensor] = None,
+                    noises: Optional[Sequence[Tensor]] = None):
+        """(reference :735-777); the per-step scalars are computed in fp32 on the host from the schedule."""
+        device, total, S, eta = self.betas.device, self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+        times = torch.linspace(-1, total - 1, steps=S + 1)
+        times = list(reversed(times.int().tolist()))
+        time_pairs = list(zip(times[:-1], times[1:]))
+        b, c, h, w = shape
+        img = torch.randn((b, h, w, c), device=device) if x_T is None else K.to_nhwc(x_T.to(device)).contiguous()
+        imgs = [img]
+        ac = self.alphas_cumprod.detach().cpu()
+        sr, srm1 = self.sqrt_recip_alphas_cumprod.detach().cpu(), self.sqrt_recipm1_alphas_cumprod.detach().cpu()
+        j = 0
+        for time, time_next in time_pairs:
+            tb = torch.full((b,), time, device=device, dtype=torch.long)
+            eps = self.model.forward_nhwc(img, tb)
+            if time_next < 0:
+                img = K.ddim_step(img, eps, None, float(sr[time]), float(srm1[time]), 0.0, 0.0, 0.0, last=True)
+            else:
+                alpha, alpha_next = ac[time], ac[time_next]
+                sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+                cc = (1 - alpha_next - sigma ** 2).sqrt()
+                nz = torch.randn_like(img) if noises is None else K.to_nhwc(noises[j].to(device)).contiguous()
+                j += 1
+                img = K.ddim_step(img, eps, nz, float(sr[time]), float(srm1[time]), float(alpha_next.sqrt()), float(cc),
+                                  float(sigma), last=False)
+            if return_all_timesteps:
+                imgs.append(img)
+        ret = K.as_nchw(img) if not return_all_timesteps else torch.stack([K.as_nchw(i) for i in imgs], dim=1)
+        return self.unnormalize(ret)
+
+    @torch.no_grad()
+    def sample(self, batch_size=16, return_all_timesteps=False):
+        """(reference :779-783)"""
+        image_size, channels = self.image_size, self.channels
+        sample_fn = self.p_sample_loop if not self.is_ddim_sampling else self.ddim_sample
+        return sample_fn((batch_size, channels, image_size, image_size), return_all_timesteps=return_all_timesteps)
+
+    @torch.no_grad()
+    def interpolate(self, x1=None, x2=None, t=None, lam=0.5):
+        """(reference :785-804)"""
+        b, device = x1.shape[0], x1.device
+        t = default(t, self.num_timesteps - 1)
+        assert x1.shape == x2.shape
+        tb = torch.full((b,), t, device=device, dtype=torch.long)
+        xt1, xt2 = self.q_sample(x1, t=tb), self.q_sample(x2, t=tb)
+        img = K.to_nhwc((1 - lam) * xt1 + lam * xt2).contiguous()
+        for i in reversed(range(0, t)):
+            img, _ = self._p_sample_nhwc(img, i, None, False)
+        return K.as_nchw(img)
+
+    def q_sample(self, x_start, t, noise=None):
+        """(reference :806-812)"""
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        out = K.q_sample(K.to_nhwc(x_start).contiguous(), K.to_nhwc(noise).contiguous(), t.contiguous(),
+                         self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+        return K.as_nchw(out)
+
+    @property
+    def loss_fn(self):
+        """Name check only: the reduction itself is the nfdp_diffusion_loss_f32 kernel  (reference :814-821)."""
+        if self.loss_type in ('l1', 'l2'):
+            return self.loss_type
+        raise ValueError(f'invalid loss type {self.loss_type}')
+
+    def p_losses(self, x_start, t, noise=None):
+        """mean_b(mean_chw(|eps_hat - eps|^p) * p2w[t])  (reference :823-859)."""
+        kind = self.loss_fn
+        noise = default(noise, lambda: torch.randn_like(x_start))
+        x0h, nh = K.to_nhwc(x_start).contiguous(), K.to_nhwc(noise).contiguous()
+        t = t.contiguous()
+        xh = K.q_sample(x0h, nh, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
+            raise NotImplementedError("nfdp HIP path: backward kernels are not built yet; call under torch.no_grad()")
+        out = self.model.forward_nhwc(xh, t)
+        return K.diffusion_loss(out, nh, t, self.p2_loss_weight, l1=(kind == 'l1'))
+
+    def forward(self, img, *args, **kwargs):
+        """(reference :861-867)"""
+        b, c, h, w = img.shape
+        assert h == self.image_size and w == self.image_size, f'height and width of image must be {self.image_size}'
+        t = torch.randint(0, self.num_timesteps, (b,), device=img.device).long()
+        img = self.normalize(img)
+        return self.p_losses(img, t, *args, **kwargs)
+
+    def calc_neg_log_likelihood_loop(self, *a, **k):
+        raise NotImplementedError("VLB / NLL evaluation loop is a 'next' row (SURVEY.md §8f rank 3)")

@@ -462,3 +462,125 @@ def postprocess_u8(xh: torch.Tensor, n_bins: float) -> torch.Tensor:
     u8 = torch.empty((b, c, h, w), device=xh.device, dtype=torch.uint8)
     _call("nfdp_postprocess_nhwc_to_u8_nchw", _ptr(xh), _ptr(u8), b, c, h, w, float(n_bins), _stream())
     return u8
+
+
+# ----------------------------------------------------------------------------- diffusion prior: U-Net blocks
+def ws_standardize(w: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    _need(w, torch.float32, "ws_standardize"); _dense(w, "ws_standardize")
+    out = torch.empty_like(w)
+    _call("nfdp_ws_standardize_f32", _ptr(w), _ptr(out), w.shape[0], w.numel() // w.shape[0], float(eps), _stream())
+    return out
+
+
+def groupnorm_silu(xh: torch.Tensor, groups: int, gamma, beta, scale_shift: Optional[torch.Tensor], eps: float = 1e-5):
+    _need(xh, torch.float32, "groupnorm_silu"); _dense(xh, "groupnorm_silu")
+    b, h, w, c = xh.shape
+    y = torch.empty_like(xh)
+    _call("nfdp_groupnorm_silu_f32", _ptr(xh), _ptr(y), b, h * w, c, groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift),
+          float(eps), _stream(), label="groupnorm_silu_kernel", nbytes=8.0 * xh.numel())
+    return y
+
+
+def chan_layernorm(xh: torch.Tensor, gain: torch.Tensor, residual: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    _need(xh, torch.float32, "chan_layernorm"); _dense(xh, "chan_layernorm")
+    c = xh.shape[-1]
+    y = torch.empty_like(xh)
+    _call("nfdp_chan_layernorm_f32", _ptr(xh), _ptr(y), xh.numel() // c, c, _ptr(gain), float(eps), _ptr(residual), _stream(),
+          label="chan_layernorm_kernel", nbytes=8.0 * xh.numel())
+    return y
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], pre_act: int = 0, post_act: int = 0):
+    """x [B,I] -> [B,O]; pre_act 1 = SiLU, post_act 1 = GELU(erf)."""
+    _need(x, torch.float32, "linear"); _dense(x, "linear"); _dense(w, "linear")
+    b, i = x.shape
+    o = w.shape[0]
+    out = torch.empty((b, o), device=x.device, dtype=torch.float32)
+    _call("nfdp_linear_f32", _ptr(x), _ptr(w), _ptr(bias), _ptr(out), b, i, o, pre_act, post_act, _stream())
+    return out
+
+
+def sinusoidal_emb(t: torch.Tensor, dim: int) -> torch.Tensor:
+    _need(t, torch.int64, "sinusoidal_emb")
+    out = torch.empty((t.numel(), dim), device=t.device, dtype=torch.float32)
+    _call("nfdp_sinusoidal_emb_f32", _ptr(t.contiguous()), _ptr(out), t.numel(), dim, _stream())
+    return out
+
+
+def linear_attention(qkv: torch.Tensor, heads: int, dim_head: int, scale: float) -> torch.Tensor:
+    _need(qkv, torch.float32, "linear_attention"); _dense(qkv, "linear_attention")
+    b, h, w, _ = qkv.shape
+    out = torch.empty((b, h, w, heads * dim_head), device=qkv.device, dtype=torch.float32)
+    _call("nfdp_linear_attention_f32", _ptr(qkv), _ptr(out), b, h * w, heads, dim_head, float(scale), _stream(),
+          label="linear_attention_kernel")
+    return out
+
+
+def attention(qkv: torch.Tensor, heads: int, dim_head: int, scale: float) -> torch.Tensor:
+    _need(qkv, torch.float32, "attention"); _dense(qkv, "attention")
+    b, h, w, _ = qkv.shape
+    out = torch.empty((b, h, w, heads * dim_head), device=qkv.device, dtype=torch.float32)
+    _call("nfdp_attention_f32", _ptr(qkv), _ptr(out), b, h * w, heads, dim_head, float(scale), _stream(), label="attention_kernel")
+    return out
+
+
+def upsample2x(xh: torch.Tensor) -> torch.Tensor:
+    _need(xh, torch.float32, "upsample2x"); _dense(xh, "upsample2x")
+    b, h, w, c = xh.shape
+    y = torch.empty((b, 2 * h, 2 * w, c), device=xh.device, dtype=torch.float32)
+    _call("nfdp_upsample_nearest2x_f32", _ptr(xh), _ptr(y), b, c, h, w, _stream())
+    return y
+
+
+def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    _dense(a, "add"); _dense(b, "add")
+    out = torch.empty_like(a)
+    _call("nfdp_add_f32", _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream())
+    return out
+
+
+def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat((a, b), dim=channel) for NHWC tensors, as two strided channel copies."""
+    bb, h, w, ca = a.shape
+    cb = b.shape[-1]
+    out = torch.empty((bb, h, w, ca + cb), device=a.device, dtype=torch.float32)
+    copy_channels(a, out[..., :ca])
+    copy_channels(b, out[..., ca:])
+    return out
+
+
+# ----------------------------------------------------------------------------- diffusion prior: process steps
+def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac):
+    _dense(x0, "q_sample"); _dense(noise, "q_sample")
+    out = torch.empty_like(x0)
+    b = x0.shape[0]
+    _call("nfdp_q_sample_f32", _ptr(x0), _ptr(noise), _ptr(t), _ptr(sqrt_ac), _ptr(sqrt_1mac), _ptr(out), b, x0.numel() // b,
+          _stream())
+    return out
+
+
+def p_sample(x, eps_hat, noise, t, sr, srm1, c1, c2, logvar, want_x0: bool = True, clip: bool = True):
+    _dense(x, "p_sample"); _dense(eps_hat, "p_sample")
+    out = torch.empty_like(x)
+    x0 = torch.empty_like(x) if want_x0 else None
+    b = x.shape[0]
+    _call("nfdp_p_sample_f32", _ptr(x), _ptr(eps_hat), _ptr(noise), _ptr(t), _ptr(sr), _ptr(srm1), _ptr(c1), _ptr(c2), _ptr(logvar),
+          _ptr(out), _ptr(x0), b, x.numel() // b, int(clip), _stream())
+    return out, x0
+
+
+def ddim_step(x, eps_hat, noise, sr, srm1, sqrt_an, c, sigma, last: bool):
+    out = torch.empty_like(x)
+    _call("nfdp_ddim_step_f32", _ptr(x), _ptr(eps_hat), _ptr(noise), _ptr(out), x.numel(), float(sr), float(srm1), float(sqrt_an),
+          float(c), float(sigma), int(last), _stream())
+    return out
+
+
+def diffusion_loss(pred, target, t, p2w, l1: bool) -> torch.Tensor:
+    _dense(pred, "diffusion_loss"); _dense(target, "diffusion_loss")
+    b = pred.shape[0]
+    ws = torch.empty(b, device=pred.device, dtype=torch.float32)
+    out = torch.empty(1, device=pred.device, dtype=torch.float32)
+    _call("nfdp_diffusion_loss_f32", _ptr(pred), _ptr(target), _ptr(t), _ptr(p2w), b, pred.numel() // b, int(l1), _ptr(ws), _ptr(out),
+          _stream())
+    return out[0]

@@ -1,0 +1,133 @@
+"""GPU parity of the diffusion-prior path (U-Net eps-predictor, Gaussian diffusion steps/loops, composition) against
+golden vectors captured from the reference (tests/golden/diffusion.npz) with all randomness injected.
+fp32 mode: 1e-4 relative (BASELINE.json gate); bf16 MFMA mode at a separately stated looser tolerance."""
+import pytest
+import torch
+
+import nfdp_hip as K
+from tests.util import load_golden, meta_of, synth_sd, T, assert_close, relerr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dg():
+    return load_golden("diffusion.npz")
+
+
+def make_unet(m, compute="f32"):
+    from diffusion_prior import Unet
+    u = Unet(dim=64, dim_mults=tuple(m["mults"]), channels=m["ch"], resnet_block_groups=m["groups"], compute=compute)
+    u.load_state_dict(synth_sd(m["spec"], 21), strict=True)
+    return u.to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["m0", "m2", "c0", "c5"])
+@torch.no_grad()
+def test_unet_forward_golden(dg, tag):
+    m = meta_of(dg)[tag]
+    x, t = T(dg[f"unet{tag}_x"]).to(DEV), T(dg[f"unet{tag}_t"]).to(DEV)
+    y = make_unet(m)(x, t)
+    assert tuple(y.shape) == dg[f"unet{tag}_y"].shape
+    assert_close(y, dg[f"unet{tag}_y"], TOL, "unet f32")
+    yb = make_unet(m, "bf16")(x, t)
+    assert_close(yb, dg[f"unet{tag}_y"], 3e-2, "unet bf16")
+
+
+def make_diffusion(dg, timesteps=1000, **kw):
+    from diffusion_prior import GaussianDiffusion
+    u = make_unet(meta_of(dg)["m0"])
+    return GaussianDiffusion(u, image_size=16, timesteps=timesteps, beta_schedule="cosine", loss_type="l2",
+                             auto_normalize=False, **kw).to(DEV)
+
+
+@torch.no_grad()
+def test_schedule_buffers_golden(dg):
+    from diffusion_prior import GaussianDiffusion
+    from oracle.diffusion_oracle import BUFFER_NAMES
+    u = make_unet(meta_of(dg)["m0"])
+    for sched in ("cosine", "linear", "sigmoid"):
+        d = GaussianDiffusion(u, image_size=16, timesteps=1000, beta_schedule=sched, auto_normalize=False)
+        for name in BUFFER_NAMES:
+            assert_close(getattr(d, name), dg[f"buf_{sched}_{name}"], 1e-6, name)
+        assert [k for k, _ in d.named_buffers(recurse=False)] == list(BUFFER_NAMES) + ["_neg_sqrt_recipm1"]
+        assert "_neg_sqrt_recipm1" not in d.state_dict()
+    with pytest.raises(ValueError):
+        GaussianDiffusion(u, image_size=16, beta_schedule="nope", auto_normalize=False)
+
+
+@torch.no_grad()
+def test_diffusion_process_golden(dg):
+    d = make_diffusion(dg)
+    x0, eps, t = T(dg["d_x0"]).to(DEV), T(dg["d_eps"]).to(DEV), T(dg["d_t"]).to(DEV)
+    assert_close(d.q_sample(x0, t, eps), dg["d_q_sample"], TOL, "q_sample")
+    assert_close(d.predict_start_from_noise(x0, t, eps), dg["d_pred_x0"], TOL, "pred_x0")
+    pm, pv, plv = d.q_posterior(x0, eps, t)
+    assert_close(pm, dg["d_post_mean"], TOL, "post mean")
+    assert_close(pv, dg["d_post_var"], TOL, "post var")
+    assert_close(plv, dg["d_post_logvar"], TOL, "post logvar")
+    assert_close(d.p_losses(x0, t, noise=eps), dg["d_p_losses_l2"], TOL, "l2")
+    d.loss_type = "l1"
+    assert_close(d.p_losses(x0, t, noise=eps), dg["d_p_losses_l1"], TOL, "l1")
+    d.loss_type = "l2"
+    assert_close(d.p_losses(x0, T(dg["d_fwd_t"]).to(DEV), noise=T(dg["d_fwd_noise"]).to(DEV)), dg["d_fwd_loss"], TOL, "fwd")
+    assert torch.isfinite(d(x0))                                   # forward(): t from the device RNG
+    d.loss_type = "huber"
+    with pytest.raises(ValueError):
+        d.p_losses(x0, t, noise=eps)
+    with pytest.raises(AssertionError):
+        d(torch.zeros(1, 2, 8, 8, device=DEV))                     # wrong image size (reference :863)
+
+
+@pytest.mark.parametrize("step", [0, 1, 500, 999])
+@torch.no_grad()
+def test_p_sample_golden(dg, step):
+    d = make_diffusion(dg)
+    x = T(dg["d_x0"]).to(DEV)
+    img, x0 = d.p_sample(x, step, noise=T(dg[f"d_psample{step}_noise"]).to(DEV))
+    assert_close(img, dg[f"d_psample{step}_img"], TOL, "img")
+    assert_close(x0, dg[f"d_psample{step}_x0"], TOL, "x0")
+    assert float(x0.abs().max()) <= 1.0                            # x0 clamp kept although latents are not normalised
+    mp = d.model_predictions(x, torch.full((2,), step, device=DEV, dtype=torch.long), clip_x_start=True)
+    assert_close(mp.pred_x_start, dg[f"d_psample{step}_x0"], TOL, "model_predictions")
+
+
+@torch.no_grad()
+def test_sampling_loops_golden(dg):
+    d8 = make_diffusion(dg, timesteps=8)
+    out = d8.p_sample_loop((2, 2, 16, 16), x_T=T(dg["loop8_xT"]), noises=list(T(dg["loop8_noises"])))
+    assert_close(out, dg["loop8_out"], TOL, "p_sample_loop T=8")
+    dd = make_diffusion(dg, timesteps=8, sampling_timesteps=4, ddim_sampling_eta=1.0)
+    assert dd.is_ddim_sampling
+    out = dd.ddim_sample((2, 2, 16, 16), x_T=T(dg["ddim_xT"]), noises=list(T(dg["ddim_noises"])))
+    assert_close(out, dg["ddim_out"], TOL, "ddim T=8 S=4")
+    s = d8.sample(batch_size=3)                                    # device RNG path
+    assert s.shape == (3, 2, 16, 16) and torch.isfinite(s).all()
+    allt = d8.sample(batch_size=2, return_all_timesteps=True)
+    assert allt.shape == (2, 9, 2, 16, 16)
+
+
+@torch.no_grad()
+def test_diffusion_prior_composition_with_glow():
+    """run_diffusion_prior_experiment.py wiring: frozen Glow encodes, one diffusion model per latent part."""
+    from normalizing_flow import NFBackbone, calculate_output_shapes
+    from diffusion_prior import DiffusionPrior, IdentityFormater
+    nf = NFBackbone(None, in_channel=1, L=3, K=1, learn_prior_mean_logs=True, freeze_flow=True)
+    fmt = IdentityFormater(3, 1, 32)
+    shapes = fmt.get_input_shapes()
+    assert [tuple(s) for s in shapes] == calculate_output_shapes(3, 1, 32)
+    prior = DiffusionPrior(latent_formater=fmt, unet_kwargs=dict(dim=64, dim_mults=(1, 2), resnet_block_groups=8),
+                           diffusion_kwargs=dict(timesteps=4, sampling_timesteps=4, loss_type="l2", beta_schedule="cosine"),
+                           image_sizes=[int(s[1]) for s in shapes], latent_channels=[int(s[0]) for s in shapes])
+    assert len(prior.state_dict()) > 0                             # the reference's list-held priors have 0 keys
+    assert sum(p.numel() for p in prior.parameters()) > 9e6
+    x = torch.rand(4, 1, 32, 32, device=DEV) - 0.5
+    lat, _ = nf.transform(x, torch.zeros(4, dtype=torch.float64, device=DEV))
+    losses = prior(lat)
+    assert len(losses) == 3 and all(torch.isfinite(l) for l in losses)
+    zs = prior.sample_latents(2)
+    assert [tuple(z.shape[1:]) for z in zs] == [tuple(int(v) for v in s) for s in shapes]
+    img = nf.sample(zs)
+    assert img.shape == (2, 1, 32, 32) and torch.isfinite(img).all()
