@@ -158,14 +158,16 @@ int nfdp_zeroconv_bias_only_f32(const float* bias, const float* logs, float* h, 
  * (diffusion_prior/gaussian_diffusion.py; the convolutions themselves use nfdp_conv2d_nhwc) */
 /* WeightStandardizedConv2d.forward :189-197: out[o] = (w[o]-mean_o) * rsqrt(var_o(biased) + eps) over fan_in. */
 int nfdp_ws_standardize_f32(const float* w, float* out, int Cout, int fan_in, float eps, nfdp_stream_t stream);
-/* Block.forward :267-276 after the conv: GroupNorm(groups) -> x*(scale+1)+shift (scale_shift [B][2C] or NULL) -> SiLU. */
+/* Block.forward :267-276 after the conv: GroupNorm(groups) -> x*(scale+1)+shift -> SiLU.  scale_shift (or NULL):
+ * row b holds (scale[C] | shift[C]) at scale_shift + b*ss_ld (ss_ld >= 2C lets all blocks' time-MLP outputs share
+ * one [B][sum 2C] buffer). */
 int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
-                            const float* beta, const float* scale_shift, float eps, nfdp_stream_t stream);
+                            const float* beta, const float* scale_shift, int ss_ld, float eps, nfdp_stream_t stream);
 /* LayerNorm.forward :205-209 (channel LayerNorm, gain only) + optional residual add (Residual :160-166). */
 int nfdp_chan_layernorm_f32(const float* x, float* y, long npix, int C, const float* gain, float eps,
                             const float* residual, nfdp_stream_t stream);
 /* nn.Linear with fused activations (time_mlp :407-412, ResnetBlock.mlp :282-285):
- * out = post(bias + pre(in) W^T); pre_act 0 none / 1 SiLU; post_act 0 none / 1 GELU(erf). */
+ * out = post(bias + pre(in) W^T); pre_act 0 none / 1 SiLU; post_act 0 none / 1 GELU(erf) / 2 SiLU; I <= 480. */
 int nfdp_linear_f32(const float* in, const float* w, const float* bias, float* out, int B, int I, int O, int pre_act,
                     int post_act, nfdp_stream_t stream);
 /* SinusoidalPosEmb.forward :231-237; t is int64 [B]. */

@@ -327,7 +327,23 @@ void launch_cfg(ConvParams& P, hipStream_t s) {
 }
 
 template <bool BF16, bool XBF16, bool VEC>
+void launch_cfg_small(ConvParams& P, hipStream_t s) {
+    constexpr int BM = 64, BN = 64;
+    P.Mt = (int)cdiv(P.npix, BM);
+    P.Nt = P.Cout / BN;                                   // Cout % 64 == 0: the packed rows (padded to 64/128) cover it
+    const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
+    const size_t lds = 2 * (size_t)(BM + BN) * (BF16 ? 64 : 128);
+    hipLaunchKernelGGL((conv_kernel<BF16, XBF16, VEC, BM, BN, 2, 2>), dim3(grid), dim3(kThreads), lds, s, P);
+}
+
+template <bool BF16, bool XBF16, bool VEC>
 void launch_by_cout(ConvParams& P, hipStream_t s) {
+    // Small problems (U-Net layers at 8x8 / 4x4, B <= 64) would fill only a few dozen CUs with 128-pixel tiles:
+    // use 64x64 tiles (4x the workgroups) whenever the big-tile grid is under one wave of the chip.
+    if (P.Cout >= 64 && P.Cout % 64 == 0 && cdiv(P.npix, 128) * cdiv(P.Cout, tile_n_for(P.Cout)) < 256) {
+        launch_cfg_small<BF16, XBF16, VEC>(P, s);
+        return;
+    }
     switch (tile_n_for(P.Cout)) {
         case 16: launch_cfg<BF16, XBF16, VEC, 256, 16, 4, 1>(P, s); break;
         case 32: launch_cfg<BF16, XBF16, VEC, 256, 32, 4, 1>(P, s); break;

@@ -44,11 +44,54 @@ __global__ void __launch_bounds__(kBlock) ws_standardize_kernel(const float* __r
 __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __restrict__ x, float* __restrict__ y, int HW,
                                                                int C, int groups, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
-                                                               const float* __restrict__ ss, float eps) {
+                                                               const float* __restrict__ ss, int ss_ld, float eps) {
     __shared__ double red[4];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups, n = HW * cpg;
     const long base = (long)b * HW * C + (long)g * cpg;
+    constexpr int RC = 16;                                  // register-cached elements per thread
+    if (n <= kBlock * RC && cpg % 4 == 0) {
+        // one global read: each thread keeps its float4 pieces (4 consecutive channels of one pixel) in registers
+        const int q = cpg / 4, nv = HW * q;
+        float4 v[RC / 4];
+        double s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < RC / 4; ++k) {
+            const int e = threadIdx.x + k * kBlock;
+            v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < nv) {
+                v[k] = *reinterpret_cast<const float4*>(x + base + (long)(e / q) * C + (e % q) * 4);
+                s1 += (double)v[k].x + (double)v[k].y + (double)v[k].z + (double)v[k].w;
+            }
+        }
+        const double mean_d = block_sum256(s1, red) / n;
+        double s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < RC / 4; ++k) {
+            if (threadIdx.x + k * kBlock < nv) {
+                const double d0 = v[k].x - mean_d, d1 = v[k].y - mean_d, d2 = v[k].z - mean_d, d3 = v[k].w - mean_d;
+                s2 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
+        }
+        const double var_d = block_sum256(s2, red) / n;
+        const float m = (float)mean_d, r = (float)(1.0 / sqrt(var_d + (double)eps));
+#pragma unroll
+        for (int k = 0; k < RC / 4; ++k) {
+            const int e = threadIdx.x + k * kBlock;
+            if (e < nv) {
+                const int c0 = g * cpg + (e % q) * 4;
+                float o[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[j], m), r), gamma[c0 + j]), beta[c0 + j]);
+                    if (ss) t = __fadd_rn(__fmul_rn(t, __fadd_rn(ss[(long)b * ss_ld + c0 + j], 1.0f)), ss[(long)b * ss_ld + C + c0 + j]);
+                    o[j] = t / (1.0f + expf(-t));
+                }
+                *reinterpret_cast<float4*>(y + base + (long)(e / q) * C + (e % q) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        return;
+    }
     double s = 0.0;
     for (int e = threadIdx.x; e < n; e += kBlock) s += (double)x[base + (long)(e / cpg) * C + (e % cpg)];
     const double mean = block_sum256(s, red) / n;
@@ -63,7 +106,7 @@ __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __r
         const int c = g * cpg + (e % cpg);
         const long idx = base + (long)(e / cpg) * C + (e % cpg);
         float v = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x[idx], m), r), gamma[c]), beta[c]);
-        if (ss) v = __fadd_rn(__fmul_rn(v, __fadd_rn(ss[(long)b * 2 * C + c], 1.0f)), ss[(long)b * 2 * C + C + c]);
+        if (ss) v = __fadd_rn(__fmul_rn(v, __fadd_rn(ss[(long)b * ss_ld + c], 1.0f)), ss[(long)b * ss_ld + C + c]);
         y[idx] = v / (1.0f + expf(-v));                      // SiLU = v * sigmoid(v)
     }
 }
@@ -95,24 +138,50 @@ __global__ void __launch_bounds__(kBlock) chan_layernorm_kernel(const float* __r
 }
 
 // ----------------------------------------------------------------------------- small linear with fused activations
-// out[b][o] = post( bias[o] + sum_i pre(in[b][i]) * W[o][i] );  pre: 0 none, 1 SiLU;  post: 0 none, 1 GELU(erf)
+// out[b][o] = post( bias[o] + sum_i pre(in[b][i]) * W[o][i] );  pre: 0 none, 1 SiLU;  post: 0 none, 1 GELU(erf), 2 SiLU
+// One workgroup = 16 output features x up to 64 batch rows: pre(in) [64][I] and W [16][I] are staged in LDS with
+// coalesced loads (rows padded by one word: conflict-free), each thread then owns 4 (b, o) pairs.
+constexpr int LIN_TO = 16, LIN_TB = 64;
 __global__ void __launch_bounds__(kBlock) linear_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ out, int B, int I,
-                                                       int O, int pre, int post) {
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= B * O) return;
-    const int b = idx / O, o = idx % O;
-    const float* ir = in + (long)b * I;
-    const float* wr = w + (long)o * I;
-    float acc = 0.f;
-    for (int i = 0; i < I; ++i) {
-        float v = ir[i];
+                                                       int O, int out_ld, int pre, int post) {
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    const int IP = I + 1;
+    float* xs = lsm;                   // [LIN_TB][IP]
+    float* ws = lsm + LIN_TB * IP;     // [LIN_TO][IP]
+    const int o0 = blockIdx.x * LIN_TO, b0 = blockIdx.y * LIN_TB;
+    for (int e = threadIdx.x; e < LIN_TB * I; e += kBlock) {
+        const int r = e / I, i = e % I;
+        float v = (b0 + r < B) ? in[(long)(b0 + r) * I + i] : 0.f;
         if (pre == 1) v = v / (1.0f + expf(-v));
-        acc = fmaf(v, wr[i], acc);
+        xs[r * IP + i] = v;
     }
-    if (bias) acc = __fadd_rn(acc, bias[o]);
-    if (post == 1) acc = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752440f));
-    out[idx] = acc;
+    for (int e = threadIdx.x; e < LIN_TO * I; e += kBlock) {
+        const int r = e / I, i = e % I;
+        ws[r * IP + i] = (o0 + r < O) ? w[(long)(o0 + r) * I + i] : 0.f;
+    }
+    __syncthreads();
+    const int bl = threadIdx.x % LIN_TB, og = threadIdx.x / LIN_TB;      // og in 0..3 -> outputs 4og..4og+3
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xr = xs + bl * IP;
+    for (int i = 0; i < I; ++i) {
+        const float xv = xr[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(xv, ws[(4 * og + j) * IP + i], acc[j]);
+    }
+    if (b0 + bl < B) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = o0 + 4 * og + j;
+            if (o < O) {
+                float v = acc[j];
+                if (bias) v = __fadd_rn(v, bias[o]);
+                if (post == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+                else if (post == 2) v = v / (1.0f + expf(-v));
+                out[(long)(b0 + bl) * out_ld + o] = v;
+            }
+        }
+    }
 }
 
 // sinusoidal position embedding (:231-237): [sin(t f_j) | cos(t f_j)], f_j = exp(-j log(10000)/(half-1))
@@ -138,12 +207,28 @@ __global__ void __launch_bounds__(kBlock) linear_attention_kernel(const float* _
     __shared__ float kmax[DH], ksum[DH], ctx[DH][DH + 1];
     __shared__ float part[8][DH];
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
-    const int HD = heads * DH, ld = 3 * HD;
+    const int HD = heads * DH;
+    int ld = 3 * HD;
+    const int qld = 3 * HD;
     const float* base = qkv + (long)b * n * ld;
     const float* qp = base + hd * DH;
     const float* kp = base + HD + hd * DH;
     const float* vp = base + 2 * HD + hd * DH;
     const int d = threadIdx.x % DH, grp = threadIdx.x / DH;          // 8 groups stride over n
+    // n <= 256: stage this head's k and v rows (128 B each, coalesced) in LDS once; every pass below reads LDS
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    const bool staged = n <= kBlock;
+    if (staged) {
+        float* ksm = lsm;
+        float* vsm = lsm + n * (DH + 1);
+        for (int e = threadIdx.x; e < n * DH; e += kBlock) {
+            const int i = e / DH, dd = e % DH;
+            ksm[i * (DH + 1) + dd] = kp[(long)i * ld + dd];
+            vsm[i * (DH + 1) + dd] = vp[(long)i * ld + dd];
+        }
+        __syncthreads();
+        kp = ksm; vp = vsm; ld = DH + 1;                              // same indexing, now in LDS
+    }
     // 1. column max of k over n
     float m = -INFINITY;
     for (int i = grp; i < n; i += 8) m = fmaxf(m, kp[(long)i * ld + d]);
@@ -185,7 +270,7 @@ __global__ void __launch_bounds__(kBlock) linear_attention_kernel(const float* _
         float q[DH];
         float mq = -INFINITY;
 #pragma unroll
-        for (int dd = 0; dd < DH; ++dd) { q[dd] = qp[(long)i * ld + dd]; mq = fmaxf(mq, q[dd]); }
+        for (int dd = 0; dd < DH; ++dd) { q[dd] = qp[(long)i * qld + dd]; mq = fmaxf(mq, q[dd]); }
         float sq = 0.f;
 #pragma unroll
         for (int dd = 0; dd < DH; ++dd) { q[dd] = expf(q[dd] - mq); sq += q[dd]; }
@@ -274,12 +359,14 @@ extern "C" int nfdp_ws_standardize_f32(const float* w, float* out, int Cout, int
 }
 
 extern "C" int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
-                                       const float* beta, const float* scale_shift, float eps, nfdp_stream_t stream) {
+                                       const float* beta, const float* scale_shift, int ss_ld, float eps,
+                                       nfdp_stream_t stream) {
     NFDP_REQUIRE(x && y && gamma && beta, NFDP_EINVAL, "groupnorm_silu: null pointer");
     NFDP_REQUIRE(B >= 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, NFDP_ESHAPE, "groupnorm_silu: bad shape");
     if (B == 0) return NFDP_OK;
+    NFDP_REQUIRE(!scale_shift || ss_ld >= 2 * C, NFDP_ESHAPE, "groupnorm_silu: ss_ld < 2C");
     hipLaunchKernelGGL(groupnorm_silu_kernel, dim3(B * groups), dim3(kBlock), 0, as_stream(stream), x, y, HW, C, groups, gamma,
-                       beta, scale_shift, eps);
+                       beta, scale_shift, ss_ld, eps);
     NFDP_CHECK_LAUNCH("groupnorm_silu");
     return NFDP_OK;
 }
@@ -300,10 +387,18 @@ extern "C" int nfdp_linear_f32(const float* in, const float* w, const float* bia
                                int post_act, nfdp_stream_t stream) {
     NFDP_REQUIRE(in && w && out, NFDP_EINVAL, "linear: null pointer");
     NFDP_REQUIRE(B >= 0 && I > 0 && O > 0, NFDP_ESHAPE, "linear: bad shape");
-    NFDP_REQUIRE(pre_act >= 0 && pre_act <= 1 && post_act >= 0 && post_act <= 1, NFDP_EINVAL, "linear: bad activation enum");
+    NFDP_REQUIRE(I <= 480, NFDP_EUNSUPPORTED, "linear: I=%d (<= 480: LDS-staged tiles)", I);
+    NFDP_REQUIRE(pre_act >= 0 && pre_act <= 1 && post_act >= 0 && post_act <= 2, NFDP_EINVAL, "linear: bad activation enum");
     if (B == 0) return NFDP_OK;
-    hipLaunchKernelGGL(linear_kernel, dim3((int)cdiv((long)B * O, kBlock)), dim3(kBlock), 0, as_stream(stream), in, w, bias, out, B,
-                       I, O, pre_act, post_act);
+    const size_t lds = (size_t)(LIN_TB + LIN_TO) * (I + 1) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (LIN_TB + LIN_TO) * 481 * (int)sizeof(float));      // 153,920 B <= 160 KiB
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(linear_kernel, dim3((int)cdiv(O, LIN_TO), (int)cdiv(B, LIN_TB)), dim3(kBlock), lds, as_stream(stream), in, w,
+                       bias, out, B, I, O, O, pre_act, post_act);
     NFDP_CHECK_LAUNCH("linear");
     return NFDP_OK;
 }
@@ -324,7 +419,14 @@ extern "C" int nfdp_linear_attention_f32(const float* qkv, float* out, int B, in
     NFDP_REQUIRE(B >= 0 && n > 0 && heads > 0, NFDP_ESHAPE, "linear_attention: bad shape");
     NFDP_REQUIRE(dim_head == DH, NFDP_EUNSUPPORTED, "linear_attention: dim_head=%d (32 only)", dim_head);
     if (B == 0) return NFDP_OK;
-    hipLaunchKernelGGL(linear_attention_kernel, dim3(B * heads), dim3(kBlock), 0, as_stream(stream), qkv, out, n, heads, scale);
+    const size_t la_lds = n <= kBlock ? (size_t)2 * n * (DH + 1) * sizeof(float) : 0;
+    static bool la_attr = false;
+    if (!la_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_attention_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBlock * (DH + 1) * (int)sizeof(float));
+        la_attr = true;
+    }
+    hipLaunchKernelGGL(linear_attention_kernel, dim3(B * heads), dim3(kBlock), la_lds, as_stream(stream), qkv, out, n, heads, scale);
     NFDP_CHECK_LAUNCH("linear_attention");
     return NFDP_OK;
 }

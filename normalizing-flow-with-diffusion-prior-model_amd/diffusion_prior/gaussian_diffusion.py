@@ -168,10 +168,12 @@ class ResnetBlock(nn.Module):
         self.block2 = Block(dim_out, dim_out, groups=groups)
         self.res_conv = _Conv(dim, dim_out, 1) if dim != dim_out else nn.Identity()
 
-    def forward_nhwc(self, xh, temb=None, compute=None):
-        ss = None
-        if exists(self.mlp) and exists(temb):
-            ss = K.linear(temb, self.mlp[1].weight, self.mlp[1].bias, pre_act=1)     # SiLU -> Linear: [B, scale | shift]
+    def forward_nhwc(self, xh, temb=None, compute=None, scale_shift=None):
+        """scale_shift: this block's precomputed [B, scale | shift] rows (the U-Net batches every block's time-MLP
+        into one GEMM); otherwise it is computed here from temb (SiLU -> Linear, reference :290-295)."""
+        ss = scale_shift
+        if ss is None and exists(self.mlp) and exists(temb):
+            ss = K.linear(temb, self.mlp[1].weight, self.mlp[1].bias, pre_act=1)
         h = self.block1.forward_nhwc(xh, ss, compute)
         h = self.block2.forward_nhwc(h, None, compute)
         res = self.res_conv.forward_nhwc(xh, compute) if isinstance(self.res_conv, _Conv) else xh
@@ -265,40 +267,67 @@ class Unet(nn.Module):
         self.final_res_block = block_klass(dim * 2, dim, time_emb_dim=time_dim)
         self.final_conv = _Conv(dim, self.out_dim, 1)
 
-    def time_embedding(self, time: Tensor) -> Tensor:
-        """sinusoidal -> Linear -> GELU -> Linear  (reference :407-412)."""
+    def time_embedding(self, time: Tensor, silu_out: bool = False) -> Tensor:
+        """sinusoidal -> Linear -> GELU -> Linear  (reference :407-412); silu_out additionally applies the SiLU every
+        ResnetBlock.mlp starts with (:282-283), once for all of them."""
         e = K.sinusoidal_emb(time.long(), self.dim)
         e = K.linear(e, self.time_mlp[1].weight, self.time_mlp[1].bias, post_act=1)
-        return K.linear(e, self.time_mlp[3].weight, self.time_mlp[3].bias)
+        return K.linear(e, self.time_mlp[3].weight, self.time_mlp[3].bias, post_act=2 if silu_out else 0)
+
+    def _resnet_blocks(self):
+        return [m for m in self.modules() if isinstance(m, ResnetBlock) and m.mlp is not None]
+
+    def _all_scale_shifts(self, t_act: Tensor) -> dict:
+        """Every ResnetBlock's time-MLP Linear (reference :284, 13 small GEMVs per forward) as ONE MFMA GEMM over the
+        concatenated weights: [B,256] x [256, sum 2*dim_out] -> per-block column slices of one [B, sum] buffer."""
+        blocks = self._resnet_blocks()
+        c = K.compute_enum(self.compute)
+        key = tuple((b.mlp[1].weight.data_ptr(), b.mlp[1].weight._version, b.mlp[1].bias._version) for b in blocks) + (c,)
+        if getattr(self, "_ss_key", None) != key:
+            wcat = torch.cat([b.mlp[1].weight.detach() for b in blocks], dim=0)              # [sumO, 256] (plumbing)
+            self._ss_bias = torch.cat([b.mlp[1].bias.detach() for b in blocks], dim=0).contiguous()
+            self._ss_packed = K.conv_pack(wcat.reshape(wcat.shape[0], wcat.shape[1], 1, 1).contiguous(), c)
+            self._ss_total = wcat.shape[0]
+            self._ss_key = key
+        bsz = t_act.shape[0]
+        ss_all = K.conv2d(t_act.view(bsz, 1, 1, -1), self._ss_packed, self._ss_total, 1, add=self._ss_bias, compute=c,
+                          out_dtype=K.F32).view(bsz, self._ss_total)
+        out, off = {}, 0
+        for b in blocks:
+            n = b.mlp[1].weight.shape[0]
+            out[id(b)] = ss_all[:, off:off + n]
+            off += n
+        return out
 
     def forward_nhwc(self, xh: Tensor, time: Tensor) -> Tensor:
         c = self.compute
         x = self.init_conv.forward_nhwc(xh, c)
         r = x
-        t = self.time_embedding(time)
+        ss = self._all_scale_shifts(self.time_embedding(time, silu_out=True))
+        rb = lambda blk, inp: blk.forward_nhwc(inp, None, c, scale_shift=ss[id(blk)])
         hs = []
         for block1, block2, attn, downsample in self.downs:
-            x = block1.forward_nhwc(x, t, c)
+            x = rb(block1, x)
             hs.append(x)
-            x = block2.forward_nhwc(x, t, c)
+            x = rb(block2, x)
             x = _attn_block_nhwc(attn, x, c)
             hs.append(x)
             if isinstance(downsample, nn.Sequential):
                 x = downsample[1].forward_nhwc(K.squeeze(x), c)          # Rearrange(p1 p2) + 1x1  (:176-180)
             else:
                 x = downsample.forward_nhwc(x, c)
-        x = self.mid_block1.forward_nhwc(x, t, c)
+        x = rb(self.mid_block1, x)
         x = _attn_block_nhwc(self.mid_attn, x, c)
-        x = self.mid_block2.forward_nhwc(x, t, c)
+        x = rb(self.mid_block2, x)
         for block1, block2, attn, upsample in self.ups:
-            x = block1.forward_nhwc(K.concat_channels(x, hs.pop()), t, c)
-            x = block2.forward_nhwc(K.concat_channels(x, hs.pop()), t, c)
+            x = rb(block1, K.concat_channels(x, hs.pop()))
+            x = rb(block2, K.concat_channels(x, hs.pop()))
             x = _attn_block_nhwc(attn, x, c)
             if isinstance(upsample, nn.Sequential):
                 x = upsample[1].forward_nhwc(K.upsample2x(x), c)         # nearest x2 + 3x3  (:169-173)
             else:
                 x = upsample.forward_nhwc(x, c)
-        x = self.final_res_block.forward_nhwc(K.concat_channels(x, r), t, c)
+        x = rb(self.final_res_block, K.concat_channels(x, r))
         return self.final_conv.forward_nhwc(x, c)
 
     def forward(self, x, time, x_self_cond=None):
@@ -398,6 +427,37 @@ class GaussianDiffusion(nn.Module):
             raise NotImplementedError("auto_normalize=True is not on the hot path (DiffusionModel passes False)")
         self.normalize = identity
         self.unnormalize = identity
+        # The reverse step is ~150 small launches (launch-bound in eager mode): p_sample_loop replays ONE captured
+        # hipGraph per timestep instead; set use_graph=False to force the eager loop.
+        self.use_graph = True
+        self._graphs = {}
+
+    # ---- hipGraph-captured reverse step: eps = Unet(x, t) -> fused p_sample in place -> t -= 1, state on the device
+    def _step_inplace(self, xh: Tensor, tb: Tensor) -> None:
+        eps = self.model.forward_nhwc(xh, tb)
+        K.p_sample(xh, eps, torch.randn_like(xh), tb, self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
+                   self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
+                   want_x0=False, clip=True, out=xh)
+        tb.sub_(1)
+
+    def _captured_step(self, shape_nhwc, device):
+        key = (tuple(shape_nhwc), str(device))
+        if key not in self._graphs:
+            xh = torch.zeros(shape_nhwc, device=device)
+            tb = torch.zeros(shape_nhwc[0], device=device, dtype=torch.long)
+            warm = torch.cuda.Stream(device=device)           # warm-up off the default stream: packs weights, sets
+            warm.wait_stream(torch.cuda.current_stream())     # kernel attributes, primes the allocator
+            with torch.cuda.stream(warm):
+                for _ in range(2):
+                    tb.fill_(1)
+                    self._step_inplace(xh, tb)
+            torch.cuda.current_stream().wait_stream(warm)
+            g = torch.cuda.CUDAGraph()
+            tb.fill_(1)
+            with torch.cuda.graph(g):
+                self._step_inplace(xh, tb)
+            self._graphs[key] = (g, xh, tb)
+        return self._graphs[key]
 
     # ---- closed-form pieces
     def predict_start_from_noise(self, x_t, t, noise):
@@ -454,6 +514,14 @@ class GaussianDiffusion(nn.Module):
         replace the device RNG draws."""
         device = self.betas.device
         b, c, h, w = shape
+        if self.use_graph and x_T is None and noises is None and not return_all_timesteps and self.num_timesteps > 1:
+            g, xh, tb = self._captured_step((b, h, w, c), device)
+            xh.normal_()
+            tb.fill_(self.num_timesteps - 1)
+            for _ in range(self.num_timesteps - 1):           # t = T-1 .. 1 (the graph decrements t itself)
+                g.replay()
+            img, _ = self._p_sample_nhwc(xh, 0, None, False)   # t = 0: no noise
+            return self.unnormalize(K.as_nchw(img))
         img = torch.randn((b, h, w, c), device=device) if x_T is None else K.to_nhwc(x_T.to(device)).contiguous()
         imgs = [img]
         for i, t in enumerate(reversed(range(0, self.num_timesteps))):

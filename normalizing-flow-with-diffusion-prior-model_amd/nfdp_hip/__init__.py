@@ -476,8 +476,12 @@ def groupnorm_silu(xh: torch.Tensor, groups: int, gamma, beta, scale_shift: Opti
     _need(xh, torch.float32, "groupnorm_silu"); _dense(xh, "groupnorm_silu")
     b, h, w, c = xh.shape
     y = torch.empty_like(xh)
+    ss_ld = 0
+    if scale_shift is not None:                       # [B, 2C] rows, possibly a column slice of a wider [B, sum] buffer
+        assert scale_shift.shape == (b, 2 * c) and scale_shift.stride(1) == 1
+        ss_ld = scale_shift.stride(0) if b > 1 else 2 * c
     _call("nfdp_groupnorm_silu_f32", _ptr(xh), _ptr(y), b, h * w, c, groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift),
-          float(eps), _stream(), label="groupnorm_silu_kernel", nbytes=8.0 * xh.numel())
+          ss_ld, float(eps), _stream(), label="groupnorm_silu_kernel", nbytes=8.0 * xh.numel())
     return y
 
 
@@ -491,7 +495,7 @@ def chan_layernorm(xh: torch.Tensor, gain: torch.Tensor, residual: Optional[torc
 
 
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], pre_act: int = 0, post_act: int = 0):
-    """x [B,I] -> [B,O]; pre_act 1 = SiLU, post_act 1 = GELU(erf)."""
+    """x [B,I] -> [B,O]; pre_act 1 = SiLU; post_act 1 = GELU(erf), 2 = SiLU."""
     _need(x, torch.float32, "linear"); _dense(x, "linear"); _dense(w, "linear")
     b, i = x.shape
     o = w.shape[0]
@@ -559,9 +563,9 @@ def q_sample(x0, noise, t, sqrt_ac, sqrt_1mac):
     return out
 
 
-def p_sample(x, eps_hat, noise, t, sr, srm1, c1, c2, logvar, want_x0: bool = True, clip: bool = True):
+def p_sample(x, eps_hat, noise, t, sr, srm1, c1, c2, logvar, want_x0: bool = True, clip: bool = True, out=None):
     _dense(x, "p_sample"); _dense(eps_hat, "p_sample")
-    out = torch.empty_like(x)
+    out = torch.empty_like(x) if out is None else out          # out may be x itself (elementwise, in place)
     x0 = torch.empty_like(x) if want_x0 else None
     b = x.shape[0]
     _call("nfdp_p_sample_f32", _ptr(x), _ptr(eps_hat), _ptr(noise), _ptr(t), _ptr(sr), _ptr(srm1), _ptr(c1), _ptr(c2), _ptr(logvar),

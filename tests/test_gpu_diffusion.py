@@ -103,7 +103,13 @@ def test_sampling_loops_golden(dg):
     assert dd.is_ddim_sampling
     out = dd.ddim_sample((2, 2, 16, 16), x_T=T(dg["ddim_xT"]), noises=list(T(dg["ddim_noises"])))
     assert_close(out, dg["ddim_out"], TOL, "ddim T=8 S=4")
-    s = d8.sample(batch_size=3)                                    # device RNG path
+    assert d8.use_graph
+    s = d8.sample(batch_size=3)                                    # device RNG path, hipGraph-captured step
+    assert (3, 16, 16, 2) in [k[0] for k in d8._graphs]
+    d8.use_graph = False
+    s2 = d8.sample(batch_size=3)                                   # eager loop
+    assert s2.shape == s.shape and torch.isfinite(s2).all()
+    d8.use_graph = True
     assert s.shape == (3, 2, 16, 16) and torch.isfinite(s).all()
     allt = d8.sample(batch_size=2, return_all_timesteps=True)
     assert allt.shape == (2, 9, 2, 16, 16)
