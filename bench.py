@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--compute", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--L", type=int, default=3)
     ap.add_argument("--K", type=int, default=16)
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -152,13 +153,38 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        run_step = lambda: step(flow, prior, u8_d, noise_d)
+        graph_used = False
+        if not args.no_graph:
+            # The step is ~60 launches + a side-stream fork/join; captured once as a hipGraph and replayed, so the
+            # host issues one call per step (the eager path spends about as long launching as the GPU spends computing).
+            try:
+                warm = torch.cuda.Stream()
+                warm.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(warm):
+                    for _ in range(2):
+                        step(flow, prior, u8_d, noise_d)
+                torch.cuda.current_stream().wait_stream(warm)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    g_out = step(flow, prior, u8_d, noise_d)
+
+                def run_step():
+                    g.replay()
+                    return g_out
+                graph_used = True
+            except Exception as e:                               # noqa: BLE001 - fall back to eager launches, loudly
+                log(f"hipGraph capture failed ({type(e).__name__}: {e}); running eager launches")
+                torch.cuda.synchronize()
+                run_step = lambda: step(flow, prior, u8_d, noise_d)
         for _ in range(args.warmup):
-            out = step(flow, prior, u8_d, noise_d)
+            out = run_step()
         barrier()
-        log("timed region")
+        log(f"timed region ({'hipGraph replay' if graph_used else 'eager launches'})")
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = step(flow, prior, u8_d, noise_d)
+            out = run_step()
         barrier()
         elapsed = time.perf_counter() - t0
 
@@ -221,7 +247,8 @@ def main():
             "config": {"workload": f"Glow L={args.L} K={args.K} forward+NLL (bits/dim) on 32x32x3, 5-bit, "
                                    f"batch={args.batch}/GPU (BASELINE configs[1] shape, trainer.py:152-161 body)",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "weights": "synthetic trained-like (tests/golden/synth.py DEEP, seed 1)"},
+                       "weights": "synthetic trained-like (tests/golden/synth.py DEEP, seed 1)",
+                       "launch": "hipGraph replay" if graph_used else "eager"},
             "bits_per_dim": round(bits_per_dim, 6),
         }
         if roofline is not None:
