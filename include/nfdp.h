@@ -46,9 +46,9 @@ int nfdp_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int H, int W, 
 int nfdp_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, nfdp_stream_t stream);
 /* Squeeze.transform, normalizing_flow/transforms.py:226:  y[b,h,w,4c+2h1+w1] = x[b,2h+h1,2w+w1,c].
  * x is [B,H,W,C] with pixel stride x_ld >= C (reads the kept half of a Split in place), H,W even;
- * y is [B,H/2,W/2,4C] contiguous. */
+ * y is [B,H/2,W/2,4C] contiguous, 16-byte aligned. */
 int nfdp_squeeze_nhwc_f32(const float* x, int x_ld, float* y, int B, int C, int H, int W, nfdp_stream_t stream);
-/* Squeeze.invert, transforms.py:238: y is [B,h,w,C4] -> x [B,2h,2w,C4/4]. */
+/* Squeeze.invert, transforms.py:238: y is [B,h,w,C4] (16-byte aligned) -> x [B,2h,2w,C4/4]. */
 int nfdp_unsqueeze_nhwc_f32(const float* y, float* x, int B, int C4, int h, int w, nfdp_stream_t stream);
 /* channel slice copy: dst[p, 0:n) = src[p, off:off+n) for npix pixels (Split / chunk / concat plumbing). */
 int nfdp_copy_channels_f32(const float* src, int src_ld, float* dst, int dst_ld, long npix, int n, nfdp_stream_t stream);

@@ -28,32 +28,39 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, float* __restri
 }
 
 // y[b,h,w,4c+2h1+w1] = x[b,2h+h1,2w+w1,c]     (reference transforms.py:226)
-__global__ void squeeze_nhwc_kernel(const float* __restrict__ x, int x_ld, float* __restrict__ y, long total, int C, int H,
+// One thread per output float4 = the four sub-pixels of one channel: four independent 4-byte loads (neighbouring
+// lanes read neighbouring channels of the same four pixels, so every fetched line is consumed by the wave) and one
+// coalesced 16-byte store.  `total4` = B*(H/2)*(W/2)*C.
+__global__ void squeeze_nhwc_kernel(const float* __restrict__ x, int x_ld, float4* __restrict__ y, long total4, int C, int H,
                                     int W) {
-    const int C4 = 4 * C, h2 = H / 2, w2 = W / 2;
-    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
-        int co = (int)(i % C4);
-        long r = i / C4;
-        int w = (int)(r % w2);
+    const int h2 = H / 2, w2 = W / 2;
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total4; i += (long)gridDim.x * kBlock) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int w = (int)(r % w2);
         r /= w2;
-        int h = (int)(r % h2);
-        long b = r / h2;
-        int c = co >> 2, h1 = (co >> 1) & 1, w1 = co & 1;
-        y[i] = x[((b * H + 2 * h + h1) * W + 2 * w + w1) * x_ld + c];
+        const int h = (int)(r % h2);
+        const long b = r / h2;
+        const float* p = x + ((b * H + 2 * h) * W + 2 * w) * (long)x_ld + c;
+        const long row = (long)W * x_ld;
+        y[i] = make_float4(p[0], p[x_ld], p[row], p[row + x_ld]);
     }
 }
 
-// x[b,2h+c1,2w+c2,c] = y[b,h,w,4c+2c1+c2]     (reference transforms.py:238); one thread per x element.
-__global__ void unsqueeze_nhwc_kernel(const float* __restrict__ y, float* __restrict__ x, long total, int C, int H, int W) {
-    const int C4 = 4 * C, w2 = W / 2, h2 = H / 2;
-    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
-        int c = (int)(i % C);
+// x[b,2h+c1,2w+c2,c] = y[b,h,w,4c+2c1+c2]     (reference transforms.py:238); one thread per y float4 (mirror of the above).
+__global__ void unsqueeze_nhwc_kernel(const float4* __restrict__ y, float* __restrict__ x, long total4, int C, int H, int W) {
+    const int w2 = W / 2, h2 = H / 2;
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total4; i += (long)gridDim.x * kBlock) {
+        const int c = (int)(i % C);
         long r = i / C;
-        int wx = (int)(r % W);
-        r /= W;
-        int hx = (int)(r % H);
-        long b = r / H;
-        x[i] = y[((b * h2 + (hx >> 1)) * w2 + (wx >> 1)) * C4 + 4 * c + 2 * (hx & 1) + (wx & 1)];
+        const int w = (int)(r % w2);
+        r /= w2;
+        const int h = (int)(r % h2);
+        const long b = r / h2;
+        const float4 v = y[i];
+        float* p = x + ((b * H + 2 * h) * W + 2 * w) * (long)C + c;
+        const long row = (long)W * C;
+        p[0] = v.x; p[C] = v.y; p[row] = v.z; p[row + C] = v.w;
     }
 }
 
@@ -148,7 +155,8 @@ extern "C" int nfdp_squeeze_nhwc_f32(const float* x, int x_ld, float* y, int B, 
     NFDP_REQUIRE(H % 2 == 0 && W % 2 == 0, NFDP_ESHAPE, "squeeze: H=%d W=%d must be even", H, W);
     long total = (long)B * C * H * W;
     if (total == 0) return NFDP_OK;
-    LAUNCH_1D(squeeze_nhwc_kernel, total, x, x_ld, y, total, C, H, W);
+    NFDP_REQUIRE(((uintptr_t)y & 15) == 0, NFDP_EINVAL, "squeeze: y must be 16-byte aligned");
+    LAUNCH_1D(squeeze_nhwc_kernel, total / 4, x, x_ld, reinterpret_cast<float4*>(y), total / 4, C, H, W);
     NFDP_CHECK_LAUNCH("squeeze");
     return NFDP_OK;
 }
@@ -159,7 +167,8 @@ extern "C" int nfdp_unsqueeze_nhwc_f32(const float* y, float* x, int B, int C4, 
     NFDP_REQUIRE(C4 % 4 == 0, NFDP_ESHAPE, "unsqueeze: C=%d must be divisible by 4", C4);
     long total = (long)B * C4 * h * w;
     if (total == 0) return NFDP_OK;
-    LAUNCH_1D(unsqueeze_nhwc_kernel, total, y, x, total, C4 / 4, 2 * h, 2 * w);
+    NFDP_REQUIRE(((uintptr_t)y & 15) == 0, NFDP_EINVAL, "unsqueeze: y must be 16-byte aligned");
+    LAUNCH_1D(unsqueeze_nhwc_kernel, total / 4, reinterpret_cast<const float4*>(y), x, total / 4, C4 / 4, 2 * h, 2 * w);
     NFDP_CHECK_LAUNCH("unsqueeze");
     return NFDP_OK;
 }
