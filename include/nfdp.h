@@ -200,6 +200,18 @@ int nfdp_ddim_step_f32(const float* x, const float* eps_hat, const float* noise,
  * per_sample_ws: B floats of workspace. */
 int nfdp_diffusion_loss_f32(const float* pred, const float* target, const long* t, const float* p2_weight, int B,
                             int per_sample, int l1, float* per_sample_ws, float* out, nfdp_stream_t stream);
+/* One term of the variational bound per sample, GaussianDiffusion._vb_terms_bpd :932-958 (with normal_kl :36-44,
+ * gaussian_log_likelihood :47-74, q_posterior :665-672 and the x0 clamp of p_mean_variance :696-704) for the
+ * fixed-variance eps-model:  out[b] = mean_chw( t_b == 0 ? decoder NLL : KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) ).
+ * x_start, x_t, eps_hat: [B, per_sample] in one common layout; total (nullable): fp64 [B], total[b] += out[b]
+ * (the running sum over timesteps of calc_neg_log_likelihood_loop :869-903). */
+int nfdp_vb_term_f32(const float* x_start, const float* x_t, const float* eps_hat, const long* t,
+                     const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, const float* post_coef1,
+                     const float* post_coef2, const float* post_logvar, int B, int per_sample, int clip_x0, float* out,
+                     double* total, nfdp_stream_t stream);
+/* GaussianDiffusion._prior_bpd :905-918: out[b] = mean_chw KL( q(x_T|x_0) || N(0,I) ), schedule rows read at t_index. */
+int nfdp_prior_kl_f32(const float* x_start, const float* sqrt_ac, const float* log_one_minus_ac, long t_index, int B,
+                      int per_sample, float* out, nfdp_stream_t stream);
 
 /* ---------------------------------------------------------------- NLL plumbing (normalizing_flow/utils.py) */
 /* out[0] = sum_b bpd_b, out[1] = B, with bpd_b = (log(n_bins)*n_pixel - (ldj_b+logp_b))*log2(e)/n_pixel

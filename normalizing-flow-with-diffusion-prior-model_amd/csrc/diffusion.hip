@@ -3,6 +3,7 @@
 // Reference: diffusion_prior/gaussian_diffusion.py
 //   q_sample :806-812             predict_start_from_noise :641-645      q_posterior :665-672
 //   p_mean_variance :696-704 (x0 clamp to [-1,1])   p_sample :706-715    ddim_sample :735-777   p_losses :855-859
+//   normal_kl :36-44   gaussian_log_likelihood :47-74   _prior_bpd :905-918   _vb_terms_bpd :932-958
 #include "nfdp_common.h"
 
 namespace {
@@ -79,6 +80,84 @@ __global__ void mean_kernel(const float* __restrict__ per, int B, float* __restr
     }
 }
 
+// One variational-bound term per sample (reference _vb_terms_bpd :932-958, fixed-variance model):
+//   x0   = clamp(sr[t] x_t - srm1[t] eps)                      model x0 prediction (p_mean_variance :696-704)
+//   mm   = c1[t] x0 + c2[t] x_t,  tm = c1[t] x_start + c2[t] x_t,  lv = posterior_log_variance_clipped[t]
+//   kl   = 0.5 * (-1 + lv - lv + exp(lv - lv) + (tm - mm)^2 exp(-lv))            normal_kl :36-44, literal fp32 order
+//   nll  = -log(max(cdf((x_start - mm + 0.1) e^{-lv/2}) - cdf((x_start - mm - 0.1) e^{-lv/2}), 1e-12))   :47-74
+//   out[b] = mean_chw( t[b] == 0 ? nll : kl );  total[b] += out[b]  (fp64 running sum over the T terms, optional)
+__device__ __forceinline__ float approx_std_normal_cdf(float x) {
+    // 0.5 * (1 + tanh(sqrt(2/pi) * (x + 0.044715 x^3))); the reference multiplies by a float64 numpy scalar that
+    // torch demotes to fp32 before the multiply.
+    const float x3 = __fmul_rn(__fmul_rn(x, x), x);
+    const float inner = __fmul_rn(0.7978845608028654f, __fadd_rn(x, __fmul_rn(0.044715f, x3)));
+    return __fmul_rn(0.5f, __fadd_rn(1.0f, tanhf(inner)));
+}
+
+__global__ void __launch_bounds__(kBlock) vb_term_kernel(const float* __restrict__ x_start, const float* __restrict__ x_t,
+                                                        const float* __restrict__ eps, const long* __restrict__ t,
+                                                        const float* __restrict__ sr, const float* __restrict__ srm1,
+                                                        const float* __restrict__ c1, const float* __restrict__ c2,
+                                                        const float* __restrict__ logvar, int per_sample, int clip,
+                                                        float* __restrict__ out, double* __restrict__ total) {
+    __shared__ double red[4];
+    const long base = (long)blockIdx.x * per_sample;
+    const long tb = t[blockIdx.x];
+    const float a = sr[tb], bm = srm1[tb], k1 = c1[tb], k2 = c2[tb], lv = logvar[tb];
+    const float inv_var = expf(-lv);
+    const float inv_std = expf(-__fmul_rn(0.5f, lv));
+    // (-1 + lv2 - lv1 + exp(lv1 - lv2)) with lv1 == lv2, evaluated left to right in fp32 like the reference
+    const float kl0 = __fadd_rn(__fsub_rn(__fadd_rn(-1.0f, lv), lv), expf(__fsub_rn(lv, lv)));
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < per_sample; i += kBlock) {
+        const float xt = x_t[base + i], xs = x_start[base + i];
+        float x0 = __fsub_rn(__fmul_rn(a, xt), __fmul_rn(bm, eps[base + i]));
+        if (clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        const float mm = __fadd_rn(__fmul_rn(k1, x0), __fmul_rn(k2, xt));
+        float term;
+        if (tb == 0) {
+            const float cx = __fsub_rn(xs, mm);
+            const float cp = approx_std_normal_cdf(__fmul_rn(inv_std, __fadd_rn(cx, 0.1f)));
+            const float cm = approx_std_normal_cdf(__fmul_rn(inv_std, __fsub_rn(cx, 0.1f)));
+            term = -logf(fmaxf(__fsub_rn(cp, cm), 1e-12f));
+        } else {
+            const float tm = __fadd_rn(__fmul_rn(k1, xs), __fmul_rn(k2, xt));
+            const float d = __fsub_rn(tm, mm);
+            term = __fmul_rn(0.5f, __fadd_rn(kl0, __fmul_rn(__fmul_rn(d, d), inv_var)));
+        }
+        acc += (double)term;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = (float)((red[0] + red[1] + red[2] + red[3]) / per_sample);
+        out[blockIdx.x] = m;
+        if (total) total[blockIdx.x] += (double)m;
+    }
+}
+
+// KL( q(x_T | x_0) || N(0, I) ) per sample (reference _prior_bpd :905-918 with q_mean_variance :920-930):
+//   mean1 = sqrt_ac[T-1] x0, lv1 = log(1 - ac[T-1]);  kl = 0.5 * (-1 + 0 - lv1 + exp(lv1 - 0) + (mean1 - 0)^2 exp(-0))
+__global__ void __launch_bounds__(kBlock) prior_kl_kernel(const float* __restrict__ x_start,
+                                                         const float* __restrict__ sqrt_ac_buf,
+                                                         const float* __restrict__ log_1mac_buf, long tidx, int per_sample,
+                                                         float* __restrict__ out) {
+    __shared__ double red[4];
+    const long base = (long)blockIdx.x * per_sample;
+    const float sqrt_ac = sqrt_ac_buf[tidx], lv1 = log_1mac_buf[tidx];
+    const float head = __fadd_rn(__fsub_rn(__fadd_rn(-1.0f, 0.0f), lv1), expf(__fsub_rn(lv1, 0.0f)));
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < per_sample; i += kBlock) {
+        const float m = __fmul_rn(sqrt_ac, x_start[base + i]);
+        acc += (double)__fmul_rn(0.5f, __fadd_rn(head, __fmul_rn(__fmul_rn(m, m), 1.0f)));
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (float)((red[0] + red[1] + red[2] + red[3]) / per_sample);
+}
+
 }  // namespace
 
 extern "C" int nfdp_q_sample_f32(const float* x0, const float* noise, const long* t, const float* sqrt_ac,
@@ -129,5 +208,31 @@ extern "C" int nfdp_diffusion_loss_f32(const float* pred, const float* target, c
                        per_sample_ws);
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, as_stream(stream), per_sample_ws, B, out);
     NFDP_CHECK_LAUNCH("diffusion_loss");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_vb_term_f32(const float* x_start, const float* x_t, const float* eps_hat, const long* t,
+                                const float* sqrt_recip_ac, const float* sqrt_recipm1_ac, const float* post_coef1,
+                                const float* post_coef2, const float* post_logvar, int B, int per_sample, int clip_x0,
+                                float* out, double* total, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x_start && x_t && eps_hat && t && sqrt_recip_ac && sqrt_recipm1_ac && post_coef1 && post_coef2 &&
+                     post_logvar && out,
+                 NFDP_EINVAL, "vb_term: null pointer");
+    NFDP_REQUIRE(B >= 0 && per_sample > 0, NFDP_ESHAPE, "vb_term: bad shape");
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL(vb_term_kernel, dim3(B), dim3(kBlock), 0, as_stream(stream), x_start, x_t, eps_hat, t, sqrt_recip_ac,
+                       sqrt_recipm1_ac, post_coef1, post_coef2, post_logvar, per_sample, clip_x0, out, total);
+    NFDP_CHECK_LAUNCH("vb_term");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_prior_kl_f32(const float* x_start, const float* sqrt_ac, const float* log_one_minus_ac, long t_index,
+                                 int B, int per_sample, float* out, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x_start && sqrt_ac && log_one_minus_ac && out, NFDP_EINVAL, "prior_kl: null pointer");
+    NFDP_REQUIRE(B >= 0 && per_sample > 0 && t_index >= 0, NFDP_ESHAPE, "prior_kl: bad shape");
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL(prior_kl_kernel, dim3(B), dim3(kBlock), 0, as_stream(stream), x_start, sqrt_ac, log_one_minus_ac,
+                       t_index, per_sample, out);
+    NFDP_CHECK_LAUNCH("prior_kl");
     return NFDP_OK;
 }

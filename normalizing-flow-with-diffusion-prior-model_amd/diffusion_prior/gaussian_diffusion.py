@@ -10,7 +10,7 @@ reverse-diffusion step with on-device schedule lookup are one launch each).  All
 (`noise=` / `noises=`) for reproducible parity tests.
 
 Not built (raise NotImplementedError): objectives other than 'pred_noise', self-conditioning, learned / random
-sinusoidal embeddings, the VLB loop.
+sinusoidal embeddings, auto_normalize.
 """
 import math
 from collections import namedtuple
@@ -618,5 +618,82 @@ class GaussianDiffusion(nn.Module):
         img = self.normalize(img)
         return self.p_losses(img, t, *args, **kwargs)
 
-    def calc_neg_log_likelihood_loop(self, *a, **k):
-        raise NotImplementedError("VLB / NLL evaluation loop is a 'next' row (SURVEY.md §8f rank 3)")
+    # ---- variational bound / NLL evaluation  (reference :869-958)
+    def q_mean_variance(self, x_start, t):
+        """q(x_t | x_0): (mean, variance, log_variance)  (reference :920-930)."""
+        xh = K.to_nhwc(x_start).contiguous()
+        mean = K.as_nchw(K.q_sample(xh, xh, t.contiguous(), self.sqrt_alphas_cumprod, torch.zeros_like(self.betas)))
+        return (mean, extract(1.0 - self.alphas_cumprod, t, x_start.shape),
+                extract(self.log_one_minus_alphas_cumprod, t, x_start.shape))
+
+    def _prior_bpd(self, x_start):
+        """mean_chw KL(q(x_T|x_0) || N(0,I)) per sample, one launch  (reference :905-918)."""
+        return K.prior_kl(K.to_nhwc(x_start).contiguous(), self.sqrt_alphas_cumprod, self.log_one_minus_alphas_cumprod,
+                          self.num_timesteps - 1)
+
+    def _vb_term_nhwc(self, x0h, xth, t, clip_denoised=True, total=None):
+        eps = self.model.forward_nhwc(xth, t)
+        return K.vb_term(x0h, xth, eps, t, self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
+                         self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
+                         clip=clip_denoised, total=total)
+
+    @torch.no_grad()
+    def _vb_terms_bpd(self, x_start, x_t, t, x_self_cond=None, clip_denoised=True, model_kwargs=None):
+        """One term of the bound per sample: decoder NLL where t == 0, KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) elsewhere
+        (reference :932-958).  U-Net forward + one fused launch (posterior means, normal_kl, tanh-CDF likelihood, mean)."""
+        if x_self_cond is not None:
+            raise NotImplementedError("self-conditioning is not on the hot path")
+        return self._vb_term_nhwc(K.to_nhwc(x_start).contiguous(), K.to_nhwc(x_t).contiguous(), t.contiguous(), clip_denoised)
+
+    def _vb_step_inplace(self, x0h: Tensor, tb: Tensor, total: Tensor) -> None:
+        xth = K.q_sample(x0h, torch.randn_like(x0h), tb, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+        self._vb_term_nhwc(x0h, xth, tb, True, total)
+        tb.sub_(1)
+
+    def _captured_vb_step(self, shape_nhwc, device):
+        key = ("vb", tuple(shape_nhwc), str(device))
+        if key not in self._graphs:
+            x0h = torch.zeros(shape_nhwc, device=device)
+            tb = torch.zeros(shape_nhwc[0], device=device, dtype=torch.long)
+            total = torch.zeros(shape_nhwc[0], device=device, dtype=torch.float64)
+            warm = torch.cuda.Stream(device=device)
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for _ in range(2):
+                    tb.fill_(1)
+                    self._vb_step_inplace(x0h, tb, total)
+            torch.cuda.current_stream().wait_stream(warm)
+            g = torch.cuda.CUDAGraph()
+            tb.fill_(1)
+            with torch.cuda.graph(g):
+                self._vb_step_inplace(x0h, tb, total)
+            self._graphs[key] = (g, x0h, tb, total)
+        return self._graphs[key]
+
+    @torch.no_grad()
+    def calc_neg_log_likelihood_loop(self, x_start, x_self_cond=None, clip_denoised=True,
+                                     noises: Optional[Sequence[Tensor]] = None):
+        """Whole variational bound per sample: sum over t = T-1..0 of the `_vb_terms_bpd` term at x_t ~ q(x_t|x_0), plus the
+        prior term (reference :869-903; like the reference, `clip_denoised` is accepted but the terms always clip).
+        The T terms are accumulated on the device in fp64 (the reference stacks them and sums in fp32); with device RNG
+        one timestep (q_sample -> U-Net -> fused term -> t -= 1) is a hipGraph replayed T times.  `noises` (one per
+        step, logical NCHW) replaces the randn_like draws."""
+        if x_self_cond is not None:
+            raise NotImplementedError("self-conditioning is not on the hot path")
+        x0h = K.to_nhwc(x_start).contiguous()
+        b = x0h.shape[0]
+        if self.use_graph and noises is None:
+            g, x0s, tb, total = self._captured_vb_step(tuple(x0h.shape), x0h.device)
+            x0s.copy_(x0h)
+            total.zero_()
+            tb.fill_(self.num_timesteps - 1)
+            for _ in range(self.num_timesteps):
+                g.replay()
+        else:
+            total = torch.zeros(b, device=x0h.device, dtype=torch.float64)
+            for i, t in enumerate(reversed(range(self.num_timesteps))):
+                tb = torch.full((b,), t, device=x0h.device, dtype=torch.long)
+                nz = torch.randn_like(x0h) if noises is None else K.to_nhwc(noises[i].to(x0h.device)).contiguous()
+                xth = K.q_sample(x0h, nz, tb, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+                self._vb_term_nhwc(x0h, xth, tb, True, total)
+        return total.float() + self._prior_bpd(x_start)

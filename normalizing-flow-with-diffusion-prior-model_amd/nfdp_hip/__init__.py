@@ -212,14 +212,17 @@ def unsqueeze(yh: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def copy_channels(src: torch.Tensor, dst: torch.Tensor) -> None:
-    """dst[..., :] = src[..., :] for two [B,H,W,n] pixel-strided views."""
+def copy_channels(src: torch.Tensor, dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dst[..., :] = src[..., :] for two [B,H,W,n] pixel-strided views (dst defaults to a new dense tensor)."""
     _need(src, torch.float32, "copy_channels")
+    if dst is None:
+        dst = torch.empty(src.shape, device=src.device, dtype=torch.float32)
     _need(dst, torch.float32, "copy_channels")
     b, h, w, n = src.shape
     assert dst.shape == src.shape
     _call("nfdp_copy_channels_f32", _ptr(src), _ld(src, "copy_channels"), _ptr(dst), _ld(dst, "copy_channels"),
                                         b * h * w, n, _stream())
+    return dst
 
 
 # ----------------------------------------------------------------------------- ActNorm / InvConv
@@ -588,3 +591,28 @@ def diffusion_loss(pred, target, t, p2w, l1: bool) -> torch.Tensor:
     _call("nfdp_diffusion_loss_f32", _ptr(pred), _ptr(target), _ptr(t), _ptr(p2w), b, pred.numel() // b, int(l1), _ptr(ws), _ptr(out),
           _stream())
     return out[0]
+
+
+def vb_term(x_start, x_t, eps, t, sr, srm1, c1, c2, logvar, clip: bool = True, total=None) -> torch.Tensor:
+    """Per-sample variational-bound term (fp32 [B]); `total` (fp64 [B]) accumulates it in place when given."""
+    for a in (x_start, x_t, eps):
+        _need(a, torch.float32, "vb_term"); _dense(a, "vb_term")
+    if x_t.shape != x_start.shape or eps.shape != x_start.shape:
+        raise ValueError(f"vb_term: shape mismatch {tuple(x_start.shape)} / {tuple(x_t.shape)} / {tuple(eps.shape)}")
+    _need(t, torch.int64, "vb_term")
+    b = x_start.shape[0]
+    if total is not None:
+        _need(total, torch.float64, "vb_term")
+    out = torch.empty(b, device=x_start.device, dtype=torch.float32)
+    _call("nfdp_vb_term_f32", _ptr(x_start), _ptr(x_t), _ptr(eps), _ptr(t), _ptr(sr), _ptr(srm1), _ptr(c1), _ptr(c2), _ptr(logvar),
+          b, x_start.numel() // max(b, 1), int(clip), _ptr(out), _ptr(total) if total is not None else None, _stream())
+    return out
+
+
+def prior_kl(x_start, sqrt_ac, log_one_minus_ac, t_index: int) -> torch.Tensor:
+    _need(x_start, torch.float32, "prior_kl"); _dense(x_start, "prior_kl")
+    b = x_start.shape[0]
+    out = torch.empty(b, device=x_start.device, dtype=torch.float32)
+    _call("nfdp_prior_kl_f32", _ptr(x_start), _ptr(sqrt_ac), _ptr(log_one_minus_ac), int(t_index), b, x_start.numel() // max(b, 1),
+          _ptr(out), _stream())
+    return out

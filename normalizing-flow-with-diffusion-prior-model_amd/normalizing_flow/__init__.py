@@ -13,7 +13,7 @@ from torch import Tensor
 
 from .base import Transform, Prior, default_device
 from .glow import StepFlow, GlowBlock, Glow
-from .prior import IsotropicGaussian, GaussianPrior, save_model
+from .prior import IsotropicGaussian, GaussianPrior, save_model, load_model, save_architecture, load_architecture
 from .transforms import InvConv2d, ActNorm, AffineCoupling, Squeeze, Split, IdentityTransform
 from .utils import (init_optimizer, preprocess_batch, postprocess_batch, initialize_with_zeros, calculate_output_shapes,
                     calculate_loss, data_dependent_nf_initialization, get_item, ZeroConv2d, Conv2dActNorm,

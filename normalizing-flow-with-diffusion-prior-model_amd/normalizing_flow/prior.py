@@ -3,6 +3,7 @@ save_model :102-115.  Log-densities are per-sample fp64 reductions in one HIP la
 N(0,1) noise from torch's device generator (or an injected `eps=` for reproducible parity tests).
 """
 import os
+import pickle
 from typing import Optional
 
 import numpy as np
@@ -91,3 +92,33 @@ def save_model(logger_obj, model, p_dist, optim, current_epoch, current_iteratio
         "optimizer": optim.state_dict(),
         "current_iter": current_iteration,
     }, os.path.join(checkpoint_directory, f"model_{prefix}_{str(current_epoch).zfill(3)}.pt"))
+
+
+def load_model(model, p_dist, checkpoint_directory, epoch, optim=None, map_location="cpu"):
+    """Reads a checkpoint written by `save_model` — or by the reference's `save_model` (prior.py:102-115; same file
+    names `model_{gaussian|diffusion}_{epoch:03d}.pt`, same keys, same state-dict layouts) — into `model` / `p_dist`
+    (and `optim` when given); returns the stored iteration counter.  This is what the reference's entry scripts do inline
+    (run_baseline_experiment.py:112-114, normalizing_flow/__init__.py:55-57)."""
+    if isinstance(p_dist, GaussianPrior):
+        keys, prefix = ("flow", "prior_dist"), "gaussian"
+    else:
+        keys, prefix = ("nf_backbone", "diffusion_prior"), "diffusion"
+    path = os.path.join(checkpoint_directory, f"model_{prefix}_{str(epoch).zfill(3)}.pt")
+    checkpoint = torch.load(path, map_location=map_location)
+    model.load_state_dict(checkpoint[keys[0]])
+    p_dist.load_state_dict(checkpoint[keys[1]])
+    if optim is not None and "optimizer" in checkpoint:
+        optim.load_state_dict(checkpoint["optimizer"])
+    return checkpoint.get("current_iter", 0)
+
+
+def save_architecture(workdir, L, K, learn_prior_mean_logs):
+    """`architecture.pkl` as the reference's baseline script writes it  (run_baseline_experiment.py:65-68)."""
+    with open(os.path.join(workdir, "architecture.pkl"), "wb") as f:
+        pickle.dump({"L": L, "K": K, "learn_prior_mean_logs": learn_prior_mean_logs}, f)
+
+
+def load_architecture(workdir):
+    """-> {"L", "K", "learn_prior_mean_logs"}  (read side: run_diffusion_prior_experiment.py)."""
+    with open(os.path.join(workdir, "architecture.pkl"), "rb") as f:
+        return pickle.load(f)

@@ -264,3 +264,57 @@ def p_losses(buf, eps_model, x0: Tensor, t: Tensor, noise: Tensor, loss_type: st
         raise ValueError(f"invalid loss type {loss_type}")
     l = l.reshape(l.shape[0], -1).mean(dim=1) * buf["p2_loss_weight"].gather(-1, t)
     return l.mean()
+
+
+# ----------------------------------------------------------------------------- variational bound (NLL evaluation)
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """KL between diagonal normals, reference operation order  (gaussian_diffusion.py:36-44)."""
+    if not isinstance(logvar2, torch.Tensor):
+        logvar2 = torch.tensor(logvar2).repeat(mean1.shape[0]).reshape(-1, 1, 1, 1)
+    return 0.5 * (-1.0 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+
+
+def gaussian_log_likelihood(x: Tensor, means: Tensor, log_scales: Tensor) -> Tensor:
+    """log of the N(means, e^{log_scales}) mass of [x-0.1, x+0.1] through the tanh CDF approximation, clamped at 1e-12
+    (gaussian_diffusion.py:47-74)."""
+    def cdf(v):
+        return 0.5 * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (v + 0.044715 * torch.pow(v, 3))))
+    centered = x - means
+    inv_stdv = torch.exp(-log_scales)
+    delta = cdf(inv_stdv * (centered + 1e-1)) - cdf(inv_stdv * (centered - 1e-1))
+    return torch.log(delta.clamp(min=1e-12))
+
+
+def _mean_flat(v: Tensor) -> Tensor:
+    return v.mean(dim=list(range(1, v.ndim)))
+
+
+def prior_bpd(buf, x0: Tensor) -> Tensor:
+    """KL(q(x_T|x_0) || N(0,I)) per sample  (gaussian_diffusion.py:905-930)."""
+    T = buf["betas"].shape[0]
+    t = torch.full((x0.shape[0],), T - 1, dtype=torch.long)
+    mean = _ext(buf["sqrt_alphas_cumprod"], t, x0.ndim) * x0
+    logvar = _ext(buf["log_one_minus_alphas_cumprod"], t, x0.ndim)
+    return _mean_flat(normal_kl(mean, logvar, 0.0, 0.0))
+
+
+def vb_term(buf, eps_model, x0: Tensor, x_t: Tensor, t: Tensor, clip_denoised: bool = True) -> Tensor:
+    """One term of the bound: decoder NLL at t == 0, posterior KL otherwise  (gaussian_diffusion.py:932-958)."""
+    true_mean, _, true_logvar = q_posterior(buf, x0, x_t, t)
+    x0_hat = predict_start_from_noise(buf, x_t, t, eps_model(x_t, t))
+    if clip_denoised:
+        x0_hat = x0_hat.clamp(-1.0, 1.0)
+    model_mean, _, model_logvar = q_posterior(buf, x0_hat, x_t, t)
+    kl = _mean_flat(normal_kl(true_mean, true_logvar, model_mean, model_logvar))
+    nll = _mean_flat(-gaussian_log_likelihood(x0, model_mean, 0.5 * model_logvar))
+    return torch.where(t == 0, nll, kl)
+
+
+def calc_neg_log_likelihood_loop(buf, eps_model, x0: Tensor, noises: Sequence[Tensor]) -> Tensor:
+    """sum_t vb_term(t) + prior term, t = T-1 .. 0; noises[i] is the i-th randn_like drawn  (gaussian_diffusion.py:869-903)."""
+    T = buf["betas"].shape[0]
+    vb = []
+    for i, t in enumerate(reversed(range(T))):
+        tb = torch.full((x0.shape[0],), t, dtype=torch.long)
+        vb.append(vb_term(buf, eps_model, x0, q_sample(buf, x0, tb, noises[i]), tb))
+    return torch.stack(vb, dim=1).sum(dim=1) + prior_bpd(buf, x0)

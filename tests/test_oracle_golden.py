@@ -212,3 +212,46 @@ def test_sampling_loops(dg):
     assert_close(out, dg["loop8_out"], 2e-5, "loop8")
     out = D.ddim_sample(buf8, model, T(dg["ddim_xT"]), 4, 1.0, list(T(dg["ddim_noises"])))
     assert_close(out, dg["ddim_out"], 2e-5, "ddim")
+
+
+# ----------------------------------------------------------------------------- variational bound + CatFormater index maps
+@pytest.fixture(scope="module")
+def vg():
+    return load_golden("vlb.npz")
+
+
+def test_vlb_terms_and_loop(vg):
+    m = meta_of(vg)
+    sd = synth_sd(m["spec"], 21)
+    model = lambda x, t: D.unet_forward(x, t, sd, 64, m["mults"], m["groups"])
+    buf = D.diffusion_buffers("cosine", 1000)
+    x0 = T(vg["x0"])
+    for tag in ("a", "b", "c"):
+        out = D.vb_term(buf, model, x0, T(vg[f"term_{tag}_xt"]), T(vg[f"term_{tag}_t"]))
+        assert_close(out, vg[f"term_{tag}_out"], 2e-5, f"vb term {tag}")
+    # the prior term is a cancellation residue (~1e-9 of O(1) operands): absolute tolerance
+    assert float((D.prior_bpd(buf, x0) - T(vg["prior_T1000"])).abs().max()) <= 1e-7
+    buf8 = D.diffusion_buffers("cosine", 8)
+    assert_close(D.prior_bpd(buf8, x0), vg["prior_T8"], 1e-5, "prior T8")
+    total = D.calc_neg_log_likelihood_loop(buf8, model, x0, list(T(vg["loop8_noises"])))
+    assert_close(total, vg["loop8_total"], 2e-5, "vlb loop8")
+
+
+def cat_reference_map(latents, target):
+    """CatFormater.process_latents restated with the oracle's squeeze/unsqueeze (latent_formaters.py:160-184)."""
+    parts = []
+    for i, z in enumerate(latents):
+        for _ in range(abs(target - i)):
+            z = O.squeeze(z) if target - i > 0 else O.unsqueeze(z)
+        parts.append(z)
+    return torch.cat(parts, dim=1)
+
+
+@pytest.mark.parametrize("tag", ["L3", "L5", "L4"])
+def test_cat_formater_index_map(vg, tag):
+    c = meta_of(vg)[f"cat_{tag}"]
+    dims = O.output_shapes(c["L"], c["C"], c["size"])
+    lat = [torch.arange(c["B"] * int(np.prod(d)), dtype=torch.float32).reshape(c["B"], *d) + 1000.0 * i
+           for i, d in enumerate(dims)]
+    out = cat_reference_map(lat, (c["L"] - 1) // 2)
+    assert torch.equal(out, T(vg[f"cat_{tag}_out"]))

@@ -30,8 +30,8 @@ def T(a):
 
 def relerr(a, b):
     """max |a-b| / max|b| — the 'relative' of BASELINE.json's 1e-4 gate (scale of the tensor)."""
-    a = torch.as_tensor(a).double().cpu()
-    b = torch.as_tensor(b).double().cpu()
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 

@@ -280,8 +280,50 @@ def gen_diffusion():
     print("diffusion.npz", len(g), "arrays")
 
 
+# ------------------------------------------------------------------ variational bound + CatFormater goldens
+@torch.no_grad()
+def gen_vlb():
+    GD, FM = R["gd"], R["formaters"]
+    g = {}
+    u = GD.Unet(dim=64, dim_mults=(1, 2), channels=2, resnet_block_groups=8)
+    spec = {"spec": load_synth(u, 21), "ch": 2, "size": 16, "mults": [1, 2], "groups": 8}
+    x0 = t(synth_input("x0", (2, 2, 16, 16), 22)) * 0.8
+    eps = t(synth_input("eps", (2, 2, 16, 16), 23))
+    g["x0"], g["eps"] = n(x0), n(eps)
+    # single terms, T=1000 cosine: decoder NLL (t=0) and posterior KL (t>0) in one batch  (gaussian_diffusion.py:932-958)
+    d = GD.GaussianDiffusion(u, image_size=16, timesteps=1000, beta_schedule="cosine", auto_normalize=False)
+    for tag, tv in (("a", [0, 700]), ("b", [1, 999]), ("c", [0, 0])):
+        tt = torch.tensor(tv, dtype=torch.long)
+        xt = d.q_sample(x0, tt, eps)
+        g[f"term_{tag}_t"], g[f"term_{tag}_xt"] = n(tt), n(xt)
+        g[f"term_{tag}_out"] = n(d._vb_terms_bpd(x_start=x0, x_t=xt, t=tt))
+    g["prior_T1000"] = n(d._prior_bpd(x0))
+    # full loop, T=8: noise drawn by randn_like once per step, t = T-1 .. 0  (gaussian_diffusion.py:869-903)
+    d8 = GD.GaussianDiffusion(u, image_size=16, timesteps=8, beta_schedule="cosine", auto_normalize=False)
+    torch.manual_seed(41)
+    total = d8.calc_neg_log_likelihood_loop(x0)
+    torch.manual_seed(41)
+    nzs = [torch.randn_like(x0) for _ in range(8)]
+    g["loop8_total"], g["loop8_noises"], g["prior_T8"] = n(total), n(torch.stack(nzs)), n(d8._prior_bpd(x0))
+    # CatFormater index maps (latent_formaters.py:135-244): integer-valued latents so equality is exact
+    for tag, L, C, size, B in (("L3", 3, 3, 32, 2), ("L5", 5, 3, 64, 1), ("L4", 4, 1, 32, 2)):
+        f = FM.CatFormater(L, C, size)
+        lat = [torch.arange(B * int(np.prod(dm)), dtype=torch.float32).reshape(B, *[int(v) for v in dm]) + 1000.0 * i
+               for i, dm in enumerate(f.latent_dims)]
+        out = f.process_latents([l.clone() for l in lat])
+        assert len(out) == 1
+        back = f.postprocess([out[0].clone()])
+        assert all(torch.equal(a, b) for a, b in zip(back, lat)), tag
+        g[f"cat_{tag}_out"] = n(out[0])
+        g[f"cat_{tag}_shape"] = np.array([int(v) for v in f.get_input_shapes()[0]])
+        spec[f"cat_{tag}"] = {"L": L, "C": C, "size": size, "B": B}
+    g["meta"] = np.array(json.dumps(spec))
+    np.savez_compressed(os.path.join(OUT, "vlb.npz"), **g)
+    print("vlb.npz", len(g), "arrays", {k: g[k].tolist() for k in ("term_a_out", "prior_T1000", "loop8_total")})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion"]
+    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion", "vlb"]
     if "ops" in which:
         gen_ops()
     if "glow" in which:
@@ -291,5 +333,7 @@ if __name__ == "__main__":
         gen_glow_init()
     if "diffusion" in which:
         gen_diffusion()
+    if "vlb" in which:
+        gen_vlb()
     leftovers = [r for r, dnames, _ in os.walk("/root/reference") if "__pycache__" in dnames]
     assert not leftovers, leftovers
