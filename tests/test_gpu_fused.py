@@ -91,3 +91,38 @@ def test_glow_m_golden_in_bf16_fused():
     logp += prior.compute_log_prob(zs[-1])
     assert_close(calculate_loss(ldj + logp, 32.0, 3072.0), g["bpd"], 2e-3, "bpd (bf16, golden weights are ill-conditioned)")
     assert_close(zs[-1], g[f"z{m['L'] - 1}"], 5e-2, "z_last")
+
+
+@pytest.mark.parametrize("C", [16, 48])
+@pytest.mark.parametrize("inverse", [False, True])
+@torch.no_grad()
+def test_rowsplit_kernel_bit_identical(C, inverse):
+    """The 4x4 level runs a row-split kernel (32-pixel workgroups, waves split the GEMM output rows, hidden tiles
+    exchanged through LDS).  Same packed weights, same k order and rounding points as the wave-per-pixel-tile kernel:
+    the two must agree bit for bit, for full and ragged batches."""
+    import ctypes
+    setter = K.lib().nfdp_debug_set_rowsplit
+    setter.argtypes, setter.restype = [ctypes.c_int], None
+    from normalizing_flow.glow import StepFlow
+    torch.manual_seed(C + inverse)
+    flow = StepFlow(C, 512, compute="bf16").to("cuda")
+    sd = flow.state_dict()
+    from tests.golden.synth import synth_tensor, DEEP
+    import numpy as np
+    flow.load_state_dict({k: torch.from_numpy(np.array(synth_tensor("flows.3." + k, v.shape, 5, DEEP))) for k, v in sd.items()})
+    for B in (1, 2, 7, 64):
+        x = torch.randn(B, 4, 4, C, device="cuda")
+        outs = []
+        for mode in (0, 1):
+            setter(mode)
+            xh = x.clone()
+            ldj = torch.zeros(B, dtype=torch.float64, device="cuda")
+            if inverse:
+                flow.invert_nhwc_(xh)
+            else:
+                flow.transform_nhwc_(xh, ldj)
+            outs.append((xh, ldj))
+        setter(-1)
+        assert torch.equal(outs[0][0], outs[1][0]), f"B={B}: state differs"
+        assert torch.equal(outs[0][1], outs[1][1]), f"B={B}: ldj differs"
+        assert torch.isfinite(outs[1][0]).all()
