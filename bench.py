@@ -106,8 +106,9 @@ def cpu_baseline(fsd, psd, L, K, u8, noise, n_bits=5, budget_s=12.0):
         O.fwd_nll(x[:4], fsd, psd, L, K)                                # warm-up
         log(f"cpu_baseline: {cores} threads, warm-up 4 images {time.perf_counter() - t0:.1f} s")
         n, t0 = 0, time.perf_counter()
-        while n < 2 * bs or (time.perf_counter() - t0 < budget_s and n + bs <= x.shape[0]):
-            _, _, _, bpd = O.fwd_nll(x[n:n + bs], fsd, psd, L, K)
+        while n < 2 * bs or time.perf_counter() - t0 < budget_s:       # ~budget_s of CPU work, wrapping over the batch
+            i0 = n % (x.shape[0] - bs + 1)
+            _, _, _, bpd = O.fwd_nll(x[i0:i0 + bs], fsd, psd, L, K)
             n += bs
             log(f"cpu_baseline: {n} images, {time.perf_counter() - t0:.1f} s")
         dt = time.perf_counter() - t0
@@ -134,11 +135,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the HIP path has no CPU fallback)"
+    # NFDP_DIST_BACKEND=gloo: rehearsal of the multi-process path on a box with fewer GPUs than ranks (ranks then share
+    # devices round-robin; RCCL refuses two ranks on one device).  The driver's runs use the default, RCCL.
+    backend = os.environ.get("NFDP_DIST_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)      # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import nfdp_hip as KH

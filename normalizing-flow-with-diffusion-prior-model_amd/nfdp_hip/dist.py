@@ -21,6 +21,8 @@ def global_bits_per_dim(pair: torch.Tensor) -> torch.Tensor:
     """pair = fp64 [2] (sum_b bpd_b, count) of this rank -> global mean bits/dim (same on all ranks)."""
     p = pair.clone()
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo":                 # CPU rehearsal backend: reduce on the host
+            p = p.cpu()
         dist.all_reduce(p, op=dist.ReduceOp.SUM)
     return p[0] / p[1]
 
@@ -28,5 +30,7 @@ def global_bits_per_dim(pair: torch.Tensor) -> torch.Tensor:
 def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])

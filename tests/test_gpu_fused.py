@@ -93,13 +93,13 @@ def test_glow_m_golden_in_bf16_fused():
     assert_close(zs[-1], g[f"z{m['L'] - 1}"], 5e-2, "z_last")
 
 
-@pytest.mark.parametrize("C", [16, 48])
+@pytest.mark.parametrize("C,hw", [(16, 4), (48, 4), (8, 8), (24, 8)])
 @pytest.mark.parametrize("inverse", [False, True])
 @torch.no_grad()
-def test_rowsplit_kernel_bit_identical(C, inverse):
-    """The 4x4 level runs a row-split kernel (32-pixel workgroups, waves split the GEMM output rows, hidden tiles
-    exchanged through LDS).  Same packed weights, same k order and rounding points as the wave-per-pixel-tile kernel:
-    the two must agree bit for bit, for full and ragged batches."""
+def test_rowsplit_kernel_bit_identical(C, hw, inverse):
+    """The 4x4 and 8x8 levels run row-split kernels (waves split the GEMM output rows of a 32- or 128-pixel workgroup,
+    hidden tiles exchanged through LDS).  Same packed weights, same k order and rounding points as the
+    wave-per-pixel-tile kernel: the two must agree bit for bit, for full and ragged batches."""
     import ctypes
     setter = K.lib().nfdp_debug_set_rowsplit
     setter.argtypes, setter.restype = [ctypes.c_int], None
@@ -111,7 +111,7 @@ def test_rowsplit_kernel_bit_identical(C, inverse):
     import numpy as np
     flow.load_state_dict({k: torch.from_numpy(np.array(synth_tensor("flows.3." + k, v.shape, 5, DEEP))) for k, v in sd.items()})
     for B in (1, 2, 7, 64):
-        x = torch.randn(B, 4, 4, C, device="cuda")
+        x = torch.randn(B, hw, hw, C, device="cuda")
         outs = []
         for mode in (0, 1):
             setter(mode)
