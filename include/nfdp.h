@@ -213,6 +213,34 @@ int nfdp_vb_term_f32(const float* x_start, const float* x_t, const float* eps_ha
 int nfdp_prior_kl_f32(const float* x_start, const float* sqrt_ac, const float* log_one_minus_ac, long t_index, int B,
                       int per_sample, float* out, nfdp_stream_t stream);
 
+/* ---------------------------------------------------------------- backward of the flow path (training step)
+ * What torch autograd computes for loss.backward() in normalizing_flow/trainer.py:163-164, exact fp32. */
+/* Weight gradient of a stride-1 'same' conv (F.conv2d in utils.py:43, :67; the 1x1 conv of InvConv2d, transforms.py:132):
+ * dw[o][ci][ky][kx] (OIHW) = sum_{b,y,x} dy[b,y,x,o] * x[b,y+ky-k/2,x+kx-k/2,ci], k in {1,3}.  x, dy: NHWC with pixel
+ * strides x_ld, dy_ld.  ws: nfdp_conv_wgrad_ws_bytes(...) bytes of workspace. */
+size_t nfdp_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int k);
+int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout, int k,
+                        float* dw, void* ws, nfdp_stream_t stream);
+/* wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: nfdp_conv2d_nhwc on pack(wt) is the data gradient of the conv with w. */
+int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int I, int k, nfdp_stream_t stream);
+/* Backward of y = act((u + add) * exp(f*mul)), act = ReLU (relu=1) or identity - ActNorm (transforms.py:80; f=1),
+ * Conv2dActNorm+ReLU (utils.py:67-69, :83-87; f=1), ZeroConv2d (utils.py:43-44; f=3):
+ *   dc = dy * [y>0] * exp(f*mul)   (gradient w.r.t. u; nullable),  dmul[c] = f * sum_p dy*y*[y>0],  dadd[c] = sum_p dc.
+ * y (the saved OUTPUT) and mul nullable: with both null this is a plain per-channel sum of dy into dadd.
+ * ws: nfdp_scale_bwd_ws_bytes(npix, C). */
+size_t nfdp_scale_bwd_ws_bytes(long npix, int C);
+int nfdp_scale_bwd_f32(const float* dy, int dy_ld, const float* y, int y_ld, const float* mul, float f, int relu, long npix,
+                       int C, float* dc, int dc_ld, float* dmul, float* dadd, void* ws, nfdp_stream_t stream);
+/* Backward of AffineCoupling.transform (transforms.py:179-185).  x: tensor before the coupling [B,HW,C] dense,
+ * h = (log_s | t) network output, dy: gradient w.r.t. the output, gl (nullable): fp64 [B] gradient w.r.t. the
+ * per-sample log-det increment.  dx, dh: [B,HW,C] dense. */
+int nfdp_coupling_bwd_f32(const float* x, const float* h, const float* dy, const double* gl, int B, int HW, int C, float* dx,
+                          float* dh, nfdp_stream_t stream);
+/* Backward of nfdp_gauss_logp_f32 (prior.py:36-37): gl fp64 [B] gradient w.r.t. logp; dz [B,HW,Cz] dense;
+ * dh [B,HW,2Cz] dense per element for both h modes (mode 1 callers sum it over pixels with nfdp_scale_bwd_f32). */
+int nfdp_gauss_logp_bwd_f32(const float* z, int z_ld, const float* h, int h_mode, const double* gl, int B, int HW, int Cz,
+                            float* dz, float* dh, nfdp_stream_t stream);
+
 /* ---------------------------------------------------------------- NLL plumbing (normalizing_flow/utils.py) */
 /* out[0] = sum_b bpd_b, out[1] = B, with bpd_b = (log(n_bins)*n_pixel - (ldj_b+logp_b))*log2(e)/n_pixel
  * (utils.py:255-256; the mean is out[0]/out[1], left to the caller so ranks can all-reduce the pair). */

@@ -616,3 +616,71 @@ def prior_kl(x_start, sqrt_ac, log_one_minus_ac, t_index: int) -> torch.Tensor:
     _call("nfdp_prior_kl_f32", _ptr(x_start), _ptr(sqrt_ac), _ptr(log_one_minus_ac), int(t_index), b, x_start.numel() // max(b, 1),
           _ptr(out), _stream())
     return out
+
+
+# ----------------------------------------------------------------------------- backward (training step)
+def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int) -> torch.Tensor:
+    """-> dw [Cout,Cin,k,k] fp32 of a stride-1 'same' conv; xh, dyh pixel-strided NHWC fp32."""
+    _need(xh, torch.float32, "conv_wgrad"); _need(dyh, torch.float32, "conv_wgrad")
+    b, h, w, cin = xh.shape
+    cout = dyh.shape[-1]
+    if tuple(dyh.shape[:3]) != (b, h, w):
+        raise ValueError(f"conv_wgrad: shape mismatch {tuple(xh.shape)} / {tuple(dyh.shape)}")
+    dw = torch.empty((cout, cin, k, k), device=xh.device, dtype=torch.float32)
+    ws = torch.empty(lib().nfdp_conv_wgrad_ws_bytes(b, h, w, cin, cout, k), device=xh.device, dtype=torch.uint8)
+    _call("nfdp_conv_wgrad_f32", _ptr(xh), _ld(xh, "conv_wgrad"), _ptr(dyh), _ld(dyh, "conv_wgrad"), b, h, w, cin, cout, k,
+          _ptr(dw), _ptr(ws), _stream(), label=f"conv_wgrad k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout * k * k)
+    return dw
+
+
+def conv_flip_weights(w_oihw: torch.Tensor) -> torch.Tensor:
+    _need(w_oihw, torch.float32, "conv_flip_weights"); _dense(w_oihw, "conv_flip_weights")
+    o, i, k, _ = w_oihw.shape
+    wt = torch.empty((i, o, k, k), device=w_oihw.device, dtype=torch.float32)
+    _call("nfdp_conv_flip_weights_f32", _ptr(w_oihw), _ptr(wt), o, i, k, _stream())
+    return wt
+
+
+def scale_bwd(dyh, yh=None, mul=None, f: float = 1.0, relu: bool = False, want_dc: bool = True):
+    """Backward of y = act((u + add) * exp(f*mul)) -> (dc or None, dmul [C] or None, dadd [C])."""
+    _need(dyh, torch.float32, "scale_bwd")
+    c = dyh.shape[-1]
+    npix = dyh.numel() // c
+    dev = dyh.device
+    dc = torch.empty(dyh.shape, device=dev, dtype=torch.float32) if want_dc else None
+    dmul = torch.empty(c, device=dev, dtype=torch.float32) if yh is not None else None
+    dadd = torch.empty(c, device=dev, dtype=torch.float32)
+    ws = torch.empty(lib().nfdp_scale_bwd_ws_bytes(npix, c), device=dev, dtype=torch.uint8)
+    _call("nfdp_scale_bwd_f32", _ptr(dyh), _ld4(dyh), _ptr(yh), _ld4(yh) if yh is not None else c, _ptr(mul), float(f), int(relu),
+          npix, c, _ptr(dc), c, _ptr(dmul), _ptr(dadd), _ptr(ws), _stream())
+    return dc, dmul, dadd
+
+
+def _ld4(t: torch.Tensor) -> int:
+    """Pixel stride of a [..., C] tensor of any rank >= 2 that is dense or a channel slice of a dense tensor."""
+    if t.dim() == 4:
+        return _ld(t, "backward")
+    if t.stride(-1) != 1 and t.shape[-1] > 1:
+        raise NfdpError("backward: channel stride must be 1")
+    return t.stride(-2) if t.dim() >= 2 and t.shape[-2] > 1 else t.shape[-1]
+
+
+def coupling_bwd(xh, hh, dyh, gl: Optional[torch.Tensor]):
+    for a in (xh, hh, dyh):
+        _need(a, torch.float32, "coupling_bwd"); _dense(a, "coupling_bwd")
+    b, h, w, c = xh.shape
+    dx, dh = torch.empty_like(xh), torch.empty_like(hh)
+    if gl is not None:
+        _need(gl, torch.float64, "coupling_bwd")
+    _call("nfdp_coupling_bwd_f32", _ptr(xh), _ptr(hh), _ptr(dyh), _ptr(gl), b, h * w, c, _ptr(dx), _ptr(dh), _stream())
+    return dx, dh
+
+
+def gauss_logp_bwd(zh, h, h_mode: int, gl: torch.Tensor):
+    _need(gl, torch.float64, "gauss_logp_bwd")
+    b, hh, ww, cz = zh.shape
+    dz = torch.empty((b, hh, ww, cz), device=zh.device, dtype=torch.float32)
+    dh = torch.empty((b, hh, ww, 2 * cz), device=zh.device, dtype=torch.float32)
+    _call("nfdp_gauss_logp_bwd_f32", _ptr(zh), _ld(zh, "gauss_logp_bwd"), _ptr(h), h_mode, _ptr(gl), b, hh * ww, cz, _ptr(dz),
+          _ptr(dh), _stream())
+    return dz, dh

@@ -167,8 +167,8 @@ class Glow(Transform):
     def _check_no_grad(self):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise NotImplementedError(
-                "nfdp HIP path: backward kernels are not built yet (SURVEY.md §8f rank 1). Call under "
-                "torch.no_grad() or freeze the parameters; results would otherwise silently carry no gradient.")
+                "nfdp HIP path: only Glow.transform has a backward (normalizing_flow/training.py); call invert/sample "
+                "under torch.no_grad() or freeze the parameters, results would otherwise silently carry no gradient.")
 
     def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor]):
         """-> ([z_0 .. z_{L-1}] NHWC tensors, ldj, logp); accumulators fp64, updated in place."""
@@ -203,8 +203,12 @@ class Glow(Transform):
         return zs
 
     def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[list, Tensor, Tensor]:
-        """(reference glow.py:172-201) -> (latent parts, log_det_jac, logp); logp may be None (NFBackbone path)."""
-        self._check_no_grad()
+        """(reference glow.py:172-201) -> (latent parts, log_det_jac, logp); logp may be None (NFBackbone path).
+        When gradients are required the differentiable exact-fp32 path runs (training.py: autograd Functions over the
+        HIP forward/backward kernels, nothing in place); otherwise the fused in-place inference path."""
+        from . import training
+        if training.grad_needed(self):
+            return training.glow_transform(self, x, log_det_jac, logp)
         wl, wp = acc_in(log_det_jac), acc_in(logp)
         zs = self.transform_nhwc(K.to_nhwc(x), wl, wp)
         return [K.as_nchw(z) for z in zs], acc_out(log_det_jac, wl), acc_out(logp, wp)

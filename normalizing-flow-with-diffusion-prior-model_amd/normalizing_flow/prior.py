@@ -64,8 +64,15 @@ class GaussianPrior(Prior):
         """logp[b] += log N(z_b)   (fp64, in place)."""
         K.gauss_logp(zh, self._h(zh.device), 1, logp)
 
+    @property
+    def conv(self):
+        return self.__conv
+
     def compute_log_prob(self, x: Tensor) -> Tensor:
-        """(reference prior.py:70-83) -> fp32 [B]."""
+        """(reference prior.py:70-83) -> fp32 [B]; differentiable when gradients are required (training.py)."""
+        from . import training
+        if torch.is_grad_enabled() and (x.requires_grad or training.grad_needed(self)):
+            return training.gaussian_prior_log_prob(self, x)
         logp = torch.zeros(x.size(0), device=x.device, dtype=torch.float64)
         self.accumulate_log_prob_nhwc(K.to_nhwc(x), logp)
         return logp.float()

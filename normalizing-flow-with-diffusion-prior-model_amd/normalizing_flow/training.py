@@ -1,0 +1,247 @@
+"""Differentiable (training) path of the flow: torch.autograd.Function wrappers over the HIP kernels.
+
+The reference trains through torch autograd (normalizing_flow/trainer.py:152-167: transform -> calculate_loss ->
+loss.backward() -> clips -> optimizer.step()).  Here every arithmetic op of that graph is a Function whose forward
+and backward are HIP launches through the C ABI (exact-fp32 MFMA convolutions; include/nfdp.h "backward of the flow
+path"); autograd only strings them together.  What stays in torch is glue of parameter size or smaller: the
+`H*W*sum(scale)` / `H*W*log|det W|` scalars added to the per-sample log-det, the [2C] prior vector
+`bias*exp(3*logs)`, channel slices and the per-sample adds of the fp64 accumulators.
+
+Layout: NHWC fp32 activations like the inference path, parameters in the reference's layouts; nothing is updated in
+place (autograd needs the inputs), so this path is selected only when gradients are required.
+"""
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.autograd import Function
+
+import nfdp_hip as K
+
+
+def grad_needed(module: torch.nn.Module) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
+
+
+# ----------------------------------------------------------------------------- Functions
+class ActNormFn(Function):
+    """y = exp(scale) * (x + bias)   (reference transforms.py:80)."""
+
+    @staticmethod
+    def forward(ctx, xh, scale, bias):
+        y = K.actnorm_fwd(xh.contiguous(), scale.detach().reshape(-1), bias.detach().reshape(-1))
+        ctx.save_for_backward(y, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, scale = ctx.saved_tensors
+        dx, dscale, dbias = K.scale_bwd(dy.contiguous(), y, scale.detach().reshape(-1), 1.0, False)
+        return dx, dscale.view_as(scale), dbias.view_as(scale)
+
+
+class InvConvFn(Function):
+    """y = conv2d(x, W) with W [C,C,1,1]   (reference transforms.py:132)."""
+
+    @staticmethod
+    def forward(ctx, xh, weight):
+        c = weight.shape[0]
+        xh = xh.contiguous()
+        y = K.invconv_apply(xh, weight.detach().reshape(c, c).contiguous())
+        ctx.save_for_backward(xh, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, weight = ctx.saved_tensors
+        c = weight.shape[0]
+        dy = dy.contiguous()
+        dx = K.invconv_apply(dy, weight.detach().reshape(c, c).t().contiguous())   # W^T dy (transpose: weight-sized glue)
+        dw = K.conv_wgrad(xh, dy, 1)
+        return dx, dw.view_as(weight)
+
+
+class LogAbsDetFn(Function):
+    """log|det W| in fp64 on the device, returned as fp32 [1]   (reference transforms.py:131); gradient g * W^-T."""
+
+    @staticmethod
+    def forward(ctx, weight):
+        c = weight.shape[0]
+        lad, winv = K.invconv_prepare(weight.detach().reshape(1, c, c).contiguous(), want_inverse=True)
+        ctx.save_for_backward(winv)
+        ctx.wshape = weight.shape
+        return lad
+
+    @staticmethod
+    def backward(ctx, g):
+        (winv,) = ctx.saved_tensors
+        return (g.reshape(()) * winv[0].t()).reshape(ctx.wshape)
+
+
+class ConvScaleFn(Function):
+    """y = act((conv(x, W) + add) * exp(f * mul)): Conv2dActNorm (+ReLU) with add/mul = ActNorm bias/scale, f = 1
+    (reference utils.py:67-69, :83-87) and ZeroConv2d with add/mul = bias/logs, f = 3 (utils.py:43-44).  One fused
+    MFMA launch forward; backward = one scale/ReLU-backward pass (+ per-channel parameter sums), the data gradient as
+    the same conv kernel on flipped/transposed weights, and the weight-gradient GEMM over pixels."""
+
+    @staticmethod
+    def forward(ctx, xh, weight, add, mul, f, relu, packed, k):
+        y = K.conv2d(xh, packed, weight.shape[0], k, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1),
+                     mul_exp=float(f), relu=bool(relu), compute=K.F32, out_dtype=K.F32)
+        ctx.save_for_backward(xh, weight, mul, y)
+        ctx.f, ctx.relu, ctx.k = float(f), bool(relu), int(k)
+        ctx.add_shape = add.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xh, weight, mul, y = ctx.saved_tensors
+        dc, dmul, dadd = K.scale_bwd(dy.contiguous(), y, mul.detach().reshape(-1), ctx.f, ctx.relu)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = K.conv_flip_weights(weight.detach().contiguous())
+            dx = K.conv2d(dc, K.conv_pack(wt, K.F32), weight.shape[1], ctx.k, compute=K.F32, out_dtype=K.F32)
+        dw = K.conv_wgrad(xh, dc, ctx.k)
+        return dx, dw, dadd.reshape(ctx.add_shape), dmul.view_as(mul), None, None, None, None
+
+
+class CouplingFn(Function):
+    """(x_a | x_b), (log_s | t) -> (x_a | (x_b + t) * sigmoid(log_s + 2)), per-sample sum log(s + 1e-6)
+    (reference transforms.py:179-185)."""
+
+    @staticmethod
+    def forward(ctx, xh, hh):
+        xh, hh = xh.contiguous(), hh.contiguous()
+        y = xh.clone()
+        inc = torch.zeros(xh.shape[0], device=xh.device, dtype=torch.float64)
+        K.coupling_fwd(y, hh, inc, None)
+        ctx.save_for_backward(xh, hh)
+        return y, inc
+
+    @staticmethod
+    def backward(ctx, dy, dinc):
+        xh, hh = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(xh)
+        return K.coupling_bwd(xh, hh, dy.contiguous(), None if dinc is None else dinc.contiguous())
+
+
+class GaussLogpFn(Function):
+    """Per-sample log N(z; mean, exp(logs)) with h = (mean | logs) per pixel (h_mode 0) or per channel (h_mode 1)
+    (reference prior.py:36-37)."""
+
+    @staticmethod
+    def forward(ctx, zh, h, h_mode):
+        inc = torch.zeros(zh.shape[0], device=zh.device, dtype=torch.float64)
+        h = h.contiguous()
+        K.gauss_logp(zh, h, h_mode, inc)
+        ctx.save_for_backward(zh, h)
+        ctx.h_mode = h_mode
+        return inc
+
+    @staticmethod
+    def backward(ctx, dinc):
+        zh, h = ctx.saved_tensors
+        dz, dh = K.gauss_logp_bwd(zh, h, ctx.h_mode, dinc.contiguous())
+        if ctx.h_mode == 1:
+            _, _, dh = K.scale_bwd(dh, want_dc=False)            # sum over batch and pixels -> [2C]
+            dh = dh.view_as(h)
+        return dz, dh, None
+
+
+class SqueezeFn(Function):
+    """Space-to-depth by 2 (reference transforms.py:226); the gradient is the inverse reshuffle."""
+
+    @staticmethod
+    def forward(ctx, xh):
+        return K.squeeze(xh)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.unsqueeze(dy.contiguous())
+
+
+# ----------------------------------------------------------------------------- module walkers
+def _conv_actnorm_relu(mod, xh: Tensor) -> Tensor:
+    """Conv2dActNorm followed by the ReLU of coupling_network (utils.py:83-87)."""
+    an, cv = mod.actnorm, mod.conv
+    packed = cv.packed(K.F32)
+    if not an.initialized():
+        with torch.no_grad():                                     # data-dependent init on the raw conv output
+            an.init_from(K.conv2d(xh.detach(), packed, cv.out_channels, mod.filter_size, compute=K.F32, out_dtype=K.F32))
+    return ConvScaleFn.apply(xh, cv.weight, an.bias, an.scale, 1.0, True, packed, mod.filter_size)
+
+
+def _zero_conv(mod, xh: Tensor) -> Tensor:
+    return ConvScaleFn.apply(xh, mod.weight, mod.bias, mod.logs, mod.logscale_factor, False,
+                             mod._cache.get(mod.weight, K.F32), mod.filter_size)
+
+
+def coupling_net(net, xa: Tensor) -> Tensor:
+    return _zero_conv(net[4], _conv_actnorm_relu(net[2], _conv_actnorm_relu(net[0], xa)))
+
+
+def step_flow(flow, xh: Tensor, ldj: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
+    """actnorm -> invconv -> affine coupling (reference glow.py:44-49), differentiable."""
+    an, ic, cp = flow.actnorm, flow.invconv2d, flow.affcoupling
+    hw = xh.shape[1] * xh.shape[2]
+    if not an.initialized():
+        with torch.no_grad():
+            an.init_from(xh.detach().contiguous())
+    y = ActNormFn.apply(xh, an.scale, an.bias)
+    y = InvConvFn.apply(y, ic.weight)
+    c = y.shape[-1]
+    y, inc = CouplingFn.apply(y, coupling_net(cp.net, y[..., : c // 2]))
+    if ldj is not None:
+        ldj = ldj + hw * an.scale.sum() + hw * LogAbsDetFn.apply(ic.weight) + inc
+    return y, ldj
+
+
+def split(mod, xh: Tensor, logp: Optional[Tensor]):
+    """(reference transforms.py:270-289) -> (kept half view, latent part, logp)."""
+    c = xh.shape[-1]
+    yv, zv = xh[..., : c // 2], xh[..., c // 2:]
+    if logp is not None:
+        if mod.conv is not None:
+            h = _zero_conv(mod.conv, yv)
+        else:
+            h = torch.zeros(xh.shape[:3] + (c,), device=xh.device, dtype=torch.float32)
+        logp = logp + GaussLogpFn.apply(zv, h, 0)
+    return yv, zv.contiguous(), logp
+
+
+def glow_transform(glow, x: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor]):
+    """Glow.transform with a gradient graph (reference glow.py:172-201): -> (latent parts NCHW views, ldj, logp)."""
+    yh = K.to_nhwc(x)
+    zs = []
+    for block in glow.blocks:
+        yh = SqueezeFn.apply(yh)
+        for flow in block.flows:
+            yh, ldj = step_flow(flow, yh, ldj)
+        yh, z, logp = split(block.split, yh, logp)
+        zs.append(K.as_nchw(z))
+    yh = SqueezeFn.apply(yh)
+    for flow in glow.final_flows:
+        yh, ldj = step_flow(flow, yh, ldj)
+    zs.append(K.as_nchw(yh))
+    return zs, ldj, logp
+
+
+def gaussian_prior_log_prob(prior, x: Tensor) -> Tensor:
+    """GaussianPrior.compute_log_prob with a gradient graph (reference prior.py:70-83): the zero-input ZeroConv2d
+    output is bias * exp(3 * logs) at every pixel."""
+    conv = prior.conv
+    c = x.shape[1]
+    if conv is None:
+        h = torch.zeros(2 * c, device=x.device, dtype=torch.float32)
+    else:
+        # the conv weight multiplies an all-zero input: its gradient is exactly zero, not absent (AdamW still decays it)
+        h = conv.bias * torch.exp(conv.logs.reshape(-1) * conv.logscale_factor) + 0.0 * conv.weight.sum()
+    return GaussLogpFn.apply(K.to_nhwc(x), h, 1).float()
+
+
+def bits_per_dim(log_likelihood: Tensor, n_bins: float, n_pixel: float) -> Tensor:
+    """calculate_loss with a gradient graph (reference utils.py:244-256); [B]-sized glue."""
+    import math
+    bpd_const = math.log2(math.e) / n_pixel
+    return ((math.log(n_bins) * n_pixel - log_likelihood) * bpd_const).mean(dim=0)

@@ -200,6 +200,9 @@ def postprocess_batch(batch: Tensor, n_bins: int) -> Tensor:
 
 def calculate_loss(log_likelihood: Tensor, n_bins: float, n_pixel: float):
     """Bits per dimension, mean over the batch  (reference utils.py:244-256)."""
+    if torch.is_grad_enabled() and log_likelihood.requires_grad:
+        from . import training
+        return training.bits_per_dim(log_likelihood, n_bins, n_pixel)
     ll = log_likelihood if log_likelihood.dtype == torch.float64 else log_likelihood.double()
     s = K.bpd_sum(ll.contiguous(), None, n_bins, n_pixel)
     return s[0] / s[1]

@@ -1,0 +1,170 @@
+"""Backward kernels and the differentiable training path against torch autograd: per op on the CPU
+(plain torch fp32 reference of the same op) and, for the whole Glow + Gaussian prior bits/dim, against autograd through
+the oracle on the same weights.  fp32, tolerance 1e-4 relative to the largest entry of each gradient tensor."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import nfdp_hip as K
+from oracle import nf_oracle as O
+from tests.util import T, assert_close, relerr
+from tests.golden.synth import synth_tensor, synth_input
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("b,hw,cin,cout,k", [(2, 8, 6, 512, 3), (3, 4, 512, 512, 1), (2, 8, 512, 12, 3), (5, 4, 24, 48, 3),
+                                             (1, 16, 3, 7, 3), (4, 4, 48, 48, 1), (2, 16, 64, 96, 3), (7, 2, 130, 33, 1)])
+def test_conv_wgrad_and_dgrad(b, hw, cin, cout, k):
+    x = rnd(b, cin, hw, hw, seed=1).requires_grad_()
+    w = rnd(cout, cin, k, k, seed=2, scale=0.1).requires_grad_()
+    dy = rnd(b, cout, hw, hw, seed=3)
+    F.conv2d(x, w, padding=k // 2).backward(dy)
+    xh = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyh = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dw = K.conv_wgrad(xh, dyh, k)
+    assert_close(dw, w.grad, TOL, "wgrad")
+    wt = K.conv_flip_weights(w.detach().to(DEV).contiguous())
+    dx = K.conv2d(dyh, K.conv_pack(wt, K.F32), cin, k, compute=K.F32, out_dtype=K.F32)
+    assert_close(dx.permute(0, 3, 1, 2), x.grad, TOL, "dgrad")
+    # pixel-strided operands (channel slices of wider tensors), as the coupling network sees them
+    wide = torch.zeros(b, hw, hw, cin + 5, device=DEV)
+    wide[..., 2:2 + cin] = xh
+    assert torch.equal(K.conv_wgrad(wide[..., 2:2 + cin], dyh, k), dw)
+    # determinism
+    assert torch.equal(K.conv_wgrad(xh, dyh, k), dw)
+
+
+@pytest.mark.parametrize("c,f,relu", [(12, 1.0, False), (512, 1.0, True), (48, 3.0, False), (130, 3.0, True)])
+def test_scale_bwd(c, f, relu):
+    u = rnd(3, 5, 7, c, seed=4).requires_grad_()
+    add = rnd(c, seed=5, scale=0.3).requires_grad_()
+    mul = rnd(c, seed=6, scale=0.2).requires_grad_()
+    y = (u + add) * torch.exp(f * mul)
+    if relu:
+        y = torch.relu(y)
+    dy = rnd(3, 5, 7, c, seed=7)
+    y.backward(dy)
+    dc, dmul, dadd = K.scale_bwd(dy.to(DEV), y.detach().to(DEV), mul.detach().to(DEV), f, relu)
+    assert_close(dc, u.grad, TOL, "dc")
+    assert_close(dmul, mul.grad, TOL, "dmul")
+    assert_close(dadd, add.grad, TOL, "dadd")
+    _, none, colsum = K.scale_bwd(dy.to(DEV), want_dc=False)
+    assert none is None
+    assert_close(colsum, dy.reshape(-1, c).sum(0), TOL, "column sum")
+
+
+@pytest.mark.parametrize("c", [4, 12, 48])
+def test_coupling_and_gauss_bwd(c):
+    b, hw = 3, 4
+    x = rnd(b, c, hw, hw, seed=8).requires_grad_()
+    h = rnd(b, c, hw, hw, seed=9, scale=0.7).requires_grad_()
+    gl = torch.tensor([0.3, -1.1, 0.8], dtype=torch.float64)
+    xa, xb = x.chunk(2, 1)
+    log_s, t = h.chunk(2, 1)
+    s = torch.sigmoid(log_s + 2.0)
+    y = torch.cat([xa, (xb + t) * s], 1)
+    inc = torch.log(s + 1e-6).flatten(1).sum(1)
+    dy = rnd(b, c, hw, hw, seed=10)
+    ((y * dy).sum() + (inc.double() * gl).sum()).backward()
+    nh = lambda a: a.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx, dh = K.coupling_bwd(nh(x), nh(h), nh(dy), gl.to(DEV))
+    assert_close(dx.permute(0, 3, 1, 2), x.grad, TOL, "coupling dx")
+    assert_close(dh.permute(0, 3, 1, 2), h.grad, TOL, "coupling dh")
+    # Gaussian log-density, both h layouts
+    z = rnd(b, c, hw, hw, seed=11).requires_grad_()
+    for mode in (0, 1):
+        hh = (rnd(b, 2 * c, hw, hw, seed=12, scale=0.4) if mode == 0 else rnd(2 * c, seed=13, scale=0.4)).requires_grad_()
+        z.grad = None
+        mean, logs = (hh.chunk(2, 1) if mode == 0 else [v.view(1, c, 1, 1) for v in hh.chunk(2, 0)])
+        lp = (-0.5 * (np.log(2 * np.pi) + 2.0 * logs + (z - mean) ** 2 * torch.exp(-2.0 * logs))).flatten(1).sum(1)
+        (lp.double() * gl).sum().backward()
+        hdev = nh(hh) if mode == 0 else hh.detach().to(DEV)
+        dz, dhh = K.gauss_logp_bwd(nh(z), hdev, mode, gl.to(DEV))
+        assert_close(dz.permute(0, 3, 1, 2), z.grad, TOL, f"gauss dz mode {mode}")
+        if mode == 0:
+            assert_close(dhh.permute(0, 3, 1, 2), hh.grad, TOL, "gauss dh")
+        else:
+            assert_close(K.scale_bwd(dhh, want_dc=False)[2], hh.grad, TOL, "gauss dh (per channel)")
+
+
+def build(C, L, Kf, seed):
+    from normalizing_flow import Glow, GaussianPrior
+    flow, prior = Glow(in_channel=C, L=L, K=Kf, learn_prior_mean_logs=True, compute="f32"), GaussianPrior(C * 2 ** (L + 1), True)
+    fsd = {k: T(synth_tensor(k, v.shape, seed)) for k, v in flow.state_dict().items()}
+    psd = {k: T(synth_tensor(k, v.shape, seed + 1)) for k, v in prior.state_dict().items()}
+    flow.load_state_dict(fsd, strict=True)
+    prior.load_state_dict(psd, strict=True)
+    return flow.to(DEV), prior.to(DEV), fsd, psd
+
+
+@pytest.mark.parametrize("C,L,Kf,B,size", [(3, 3, 2, 2, 32), (1, 2, 2, 3, 16)])
+def test_glow_training_gradients_match_oracle_autograd(C, L, Kf, B, size):
+    """loss = bits/dim of Glow + Gaussian prior (trainer.py:152-164): every parameter gradient of the HIP training path
+    against autograd through the CPU oracle on the same weights and inputs."""
+    from normalizing_flow import calculate_loss, initialize_with_zeros
+    flow, prior, fsd, psd = build(C, L, Kf, 31)
+    x = T(synth_input("train_x", (B, C, size, size), 5)) * 0.4
+    # oracle
+    fo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in fsd.items()}
+    po = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in psd.items()}
+    _, _, _, bpd_ref = O.fwd_nll(x, fo, po, L, Kf, img_size=size)
+    bpd_ref.backward()
+    # HIP training path, written like the reference's loop body
+    flow.train(); prior.train()
+    ll, logp = initialize_with_zeros(2, B, torch.device(DEV))
+    latents, ll, logp = flow.transform(x.to(DEV), ll, logp)
+    logp = logp + prior.compute_log_prob(latents[-1])
+    loss = calculate_loss(ll + logp, 2.0 ** 5, size * size * 3.0)
+    assert loss.requires_grad
+    assert_close(loss, bpd_ref.detach(), 1e-5, "bits/dim of the training path")
+    loss.backward()
+    worst = ("", 0.0)
+    for mod, ref in ((flow, fo), (prior, po)):
+        for k, p in mod.named_parameters():
+            g_ref = ref[k].grad
+            assert p.grad is not None, f"no gradient for {k}"
+            assert torch.isfinite(p.grad).all(), k
+            if g_ref is None or float(g_ref.abs().max()) == 0.0:
+                assert float(p.grad.abs().max()) <= 1e-12, f"{k}: expected a zero gradient"
+                continue
+            e = relerr(p.grad, g_ref)
+            if e > worst[1]:
+                worst = (k, e)
+            assert e <= TOL, f"grad {k}: rel err {e:.3e}"
+    print("worst gradient", worst)
+    # inference path is unchanged by the training path having run
+    with torch.no_grad():
+        ll2, lp2 = initialize_with_zeros(2, B, torch.device(DEV))
+        _, ll2, lp2 = flow.transform(x.to(DEV), ll2, lp2)
+        assert_close(ll2, ll.detach(), 1e-6, "ldj train vs inference path")
+        assert_close(lp2, (logp - prior.compute_log_prob(latents[-1])).detach(), 1e-5, "logp train vs inference path")
+
+
+def test_reference_style_training_step_runs():
+    """zero_grad -> backward -> clip_grad_value_ -> clip_grad_norm_ -> Adam step (trainer.py:163-167) lowers the loss."""
+    from normalizing_flow import calculate_loss, initialize_with_zeros, init_optimizer
+    flow, prior, _, _ = build(3, 2, 2, 41)
+    opt = init_optimizer("adam", [{"params": list(flow.parameters())}, {"params": list(prior.parameters())}], lr=1e-3)
+    x = (T(synth_input("train_x2", (8, 3, 16, 16), 6)) * 0.4).to(DEV)
+    losses = []
+    for _ in range(4):
+        ll, logp = initialize_with_zeros(2, 8, torch.device(DEV))
+        latents, ll, logp = flow.transform(x, ll, logp)
+        logp = logp + prior.compute_log_prob(latents[-1])
+        loss = calculate_loss(ll + logp, 32.0, 16 * 16 * 3.0)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(flow.parameters(), 1)
+        torch.nn.utils.clip_grad_norm_(flow.parameters(), 1)
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
