@@ -117,6 +117,56 @@ def cpu_baseline(fsd, psd, L, K, u8, noise, n_bits=5, budget_s=12.0):
             "bits_per_dim_last_batch": float(bpd)}
 
 
+def train_bench(args, rank, world, device, barrier):
+    """One training step per iteration, written like the reference's loop body (normalizing_flow/trainer.py:152-167)."""
+    import nfdp_hip as KH
+    from nfdp_hip.optim import FusedAdam
+    from nfdp_hip.dist import BucketedGradAllReduce, max_over_ranks
+    from normalizing_flow import calculate_loss, initialize_with_zeros
+    flow, prior, _, _ = build_models(args.L, args.K, "f32", device)
+    _, _, u8_d, noise_d = make_batch(args.batch, rank, device)
+    params = list(flow.parameters()) + list(prior.parameters())
+    opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-4, clip_value=1, max_norm=1)
+    reducer = BucketedGradAllReduce(params) if world > 1 else None
+    n_pixel = 32 * 32 * 3.0
+
+    def train_step():
+        x = KH.as_nchw(KH.preprocess_u8(u8_d, noise_d, 5))
+        ll, logp = initialize_with_zeros(2, args.batch, device)
+        latents, ll, logp = flow.transform(x, ll, logp)
+        logp = logp + prior.compute_log_prob(latents[-1])
+        loss = calculate_loss(ll + logp, 32.0, n_pixel)
+        opt.zero_grad()
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()                   # averaged gradients before the clips: single-process semantics
+        opt.step()                             # clip_grad_value_(1) + clip_grad_norm_(1) + Adam, two launches
+        return loss.detach()
+
+    for _ in range(max(args.warmup, 1)):
+        loss = train_step()
+    barrier()
+    log(f"training: timed region, loss {float(loss):.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step()
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"images/sec, Glow L{args.L}K{args.K} 32x32x3 training step", "value": round(args.batch * world * args.steps / elapsed, 1),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Glow L={args.L} K={args.K} training step on 32x32x3, 5-bit, batch={args.batch}/GPU "
+                                   "(BASELINE configs[2] shape; forward, bits/dim, backward, clip_grad_value_/norm_ 1, Adam lr 1e-4 - the synthetic trained-like weights diverge at the reference's 1e-3)",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "optimizer": "nfdp fused clip+Adam (flat buffers)",
+                       "gradient_allreduce": "bucketed, overlapped with backward" if world > 1 else "none"},
+            "loss_bits_per_dim": round(float(loss), 6) if bool(torch.isfinite(loss)) else None,
+            "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,6 +177,9 @@ def main():
     ap.add_argument("--L", type=int, default=3)
     ap.add_argument("--K", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--train", action="store_true",
+                    help="time the TRAINING step instead (BASELINE configs[2]: trainer.py:152-167 body, exact-fp32 HIP "
+                         "training path, fused clip+Adam, bucketed RCCL gradient all-reduce for N>1); not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -159,6 +212,13 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.train:
+        train_bench(args, rank, world, device, barrier)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     with torch.no_grad():
         run_step = lambda: step(flow, prior, u8_d, noise_d)

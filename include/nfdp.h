@@ -241,6 +241,16 @@ int nfdp_coupling_bwd_f32(const float* x, const float* h, const float* dy, const
 int nfdp_gauss_logp_bwd_f32(const float* z, int z_ld, const float* h, int h_mode, const double* gl, int B, int HW, int Cz,
                             float* dz, float* dh, nfdp_stream_t stream);
 
+/* Fused optimizer step on flat fp32 buffers (trainer.py:165-167 + utils.py:120-137): for the first n_clip elements
+ * g = clamp(g, +-clip_value) (clip_grad_value_; <= 0: off) then g *= min(1, max_norm / (||g[:n_clip]||_2 + 1e-6))
+ * (clip_grad_norm_; <= 0: off), then torch.optim.Adam (adamw=0: weight decay added to g) or AdamW (adamw=1: decoupled
+ * decay) on all n elements; step = 1-based iteration count.  The norm never leaves the device; norm_out (nullable)
+ * receives it.  ws: nfdp_fused_adam_ws_bytes() bytes. */
+size_t nfdp_fused_adam_ws_bytes(void);
+int nfdp_fused_adam_step_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int adamw, long step, void* ws,
+                             float* norm_out, nfdp_stream_t stream);
+
 /* ---------------------------------------------------------------- NLL plumbing (normalizing_flow/utils.py) */
 /* out[0] = sum_b bpd_b, out[1] = B, with bpd_b = (log(n_bins)*n_pixel - (ldj_b+logp_b))*log2(e)/n_pixel
  * (utils.py:255-256; the mean is out[0]/out[1], left to the caller so ranks can all-reduce the pair). */

@@ -62,7 +62,7 @@ class _Conv(nn.Module):
         self._key, self._packed = None, None
 
     def packed(self, compute: int) -> Tensor:
-        key = (self.weight.data_ptr(), self.weight._version, compute)
+        key = (self.weight.data_ptr(), self.weight._version, compute, K.param_epoch())
         if key != self._key:
             w = self.weight.detach()
             if self.standardize:                       # WeightStandardizedConv2d.forward :189-195, eps 1e-5 (fp32)
@@ -282,7 +282,7 @@ class Unet(nn.Module):
         concatenated weights: [B,256] x [256, sum 2*dim_out] -> per-block column slices of one [B, sum] buffer."""
         blocks = self._resnet_blocks()
         c = K.compute_enum(self.compute)
-        key = tuple((b.mlp[1].weight.data_ptr(), b.mlp[1].weight._version, b.mlp[1].bias._version) for b in blocks) + (c,)
+        key = tuple((b.mlp[1].weight.data_ptr(), b.mlp[1].weight._version, b.mlp[1].bias._version) for b in blocks) + (c, K.param_epoch())
         if getattr(self, "_ss_key", None) != key:
             wcat = torch.cat([b.mlp[1].weight.detach() for b in blocks], dim=0)              # [sumO, 256] (plumbing)
             self._ss_bias = torch.cat([b.mlp[1].bias.detach() for b in blocks], dim=0).contiguous()

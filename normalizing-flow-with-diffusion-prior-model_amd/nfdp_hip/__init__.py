@@ -103,6 +103,21 @@ def _check(rc: int) -> None:
 _trace = None
 
 
+# Kernel-layout copies of weights (conv packs, fused-kernel images) are cached per (storage, tensor version).  A HIP
+# kernel that updates parameters through an alias (nfdp_hip.optim.FusedAdam on its flat buffer) is invisible to torch's
+# version counters, so it bumps this epoch instead and every cache includes it in its key.
+_param_epoch = 0
+
+
+def param_epoch() -> int:
+    return _param_epoch
+
+
+def bump_param_epoch() -> None:
+    global _param_epoch
+    _param_epoch += 1
+
+
 def start_trace() -> None:
     global _trace
     _trace = []

@@ -29,7 +29,7 @@ class _PackedCache:
         self._packed = None
 
     def get(self, weight: Tensor, compute: int) -> Tensor:
-        key = (weight.data_ptr(), weight._version, compute, weight.device)
+        key = (weight.data_ptr(), weight._version, compute, weight.device, K.param_epoch())
         if key != self._key:
             self._packed = K.conv_pack(weight.detach(), compute)
             self._key = key
@@ -131,7 +131,7 @@ class CouplingNet(nn.Sequential):
             return None
         ts = (c1.conv.weight, c1.actnorm.scale, c1.actnorm.bias, c2.conv.weight, c2.actnorm.scale, c2.actnorm.bias,
               zc.weight, zc.bias, zc.logs)
-        key = tuple((t.data_ptr(), t._version) for t in ts)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (K.param_epoch(),)
         if getattr(self, "_fused_key", None) != key:
             self._fused = K.coupling_fused_pack(*[t.detach().reshape(-1) if t.dim() != 4 else t.detach() for t in ts])
             self._fused_key = key

@@ -68,3 +68,53 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _grad_worker(rank, world, port, out):
+    """Each rank backpropagates its shard of a batch through a small torch model; after BucketedGradAllReduce.finish()
+    every rank must hold the gradient of the mean loss over the WHOLE batch (what one process would compute)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "normalizing-flow-with-diffusion-prior-model_amd")]
+    from nfdp_hip.dist import BucketedGradAllReduce, shard_range
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(),
+                                torch.nn.Linear(16, 1))
+    unused = torch.nn.Parameter(torch.ones(3))                      # a parameter that never receives a gradient
+    params = list(model.parameters()) + [unused]
+    red = BucketedGradAllReduce(params, bucket_bytes=128)          # several small buckets
+    assert len(red.buckets) >= 3
+    x = torch.randn(8, 8, generator=torch.Generator().manual_seed(1))
+    y = torch.randn(8, 1, generator=torch.Generator().manual_seed(2))
+    lo, hi = shard_range(8, rank, world)
+    for _ in range(2):                                              # two steps: the reducer resets itself
+        for p in params:
+            p.grad = None
+        ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
+        red.finish()
+    mine = [p.grad.clone() for p in model.parameters()]
+    for p in params:
+        p.grad = None
+    ((model(x) - y) ** 2).mean().backward()                         # equal shards: mean of shard means = global mean
+    ref = [p.grad.clone() for p in model.parameters()]
+    err = max(float((a - b).abs().max()) for a, b in zip(mine, ref))
+    if rank == 0:
+        out.put(err)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_bucketed_gradient_allreduce():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert err <= 1e-6

@@ -166,5 +166,70 @@ def test_reference_style_training_step_runs():
         torch.nn.utils.clip_grad_value_(flow.parameters(), 1)
         torch.nn.utils.clip_grad_norm_(flow.parameters(), 1)
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("adamw,wd", [(False, 0.0), (False, 0.01), (True, 0.01)])
+def test_fused_adam_matches_torch(adamw, wd):
+    """nfdp_fused_adam_step_f32 (value clip + global-norm clip + Adam/AdamW on flat buffers) against
+    clip_grad_value_ + clip_grad_norm_ + torch.optim.Adam/AdamW, five steps, clipped and unclipped parameter groups."""
+    from nfdp_hip.optim import FusedAdam
+    shapes_a, shapes_b = [(512, 6, 3, 3), (512,), (12, 12, 1, 1), (33, 7)], [(96,), (5, 5)]
+    g = torch.Generator().manual_seed(3)
+    mk = lambda shapes: [torch.nn.Parameter((torch.randn(*s, generator=g) * 0.5).to(DEV)) for s in shapes]
+    pa, pb = mk(shapes_a), mk(shapes_b)
+    ra, rb = [torch.nn.Parameter(p.detach().clone()) for p in pa], [torch.nn.Parameter(p.detach().clone()) for p in pb]
+    fused = FusedAdam(clipped=pa, unclipped=pb, lr=1e-2, weight_decay=wd, adamw=adamw, clip_value=1.0, max_norm=1.0)
+    Ref = torch.optim.AdamW if adamw else torch.optim.Adam
+    ref = Ref([{"params": ra}, {"params": rb}], lr=1e-2, weight_decay=wd)
+    for step in range(5):
+        grads = [torch.randn(p.shape, generator=g).to(DEV) * (3.0 if step % 2 else 0.3) for p in pa + pb]
+        fused.zero_grad()
+        ref.zero_grad()
+        for p, r, gr in zip(pa + pb, ra + rb, grads):
+            (p * gr).sum().backward()                               # autograd accumulates into the flat-buffer views
+            r.grad = gr.clone()
+        torch.nn.utils.clip_grad_value_(ra, 1)
+        tn = torch.nn.utils.clip_grad_norm_(ra, 1)
+        ref.step()
+        fused.step()
+        assert_close(fused.grad_norm, tn.reshape(1), 1e-5, "global norm")
+        for p, r in zip(pa + pb, ra + rb):
+            assert_close(p, r, 2e-5, f"step {step} parameter {tuple(p.shape)}")
+    assert all(p.data_ptr() >= fused.flat_param.data_ptr() for p in pa + pb)
+
+
+def test_training_step_with_fused_optimizer_updates_kernel_weight_caches():
+    """The fused optimizer updates parameters through its flat buffer; the packed-weight caches of the inference path
+    must follow (parameter epoch), i.e. the no-grad forward after a step equals the oracle on the updated weights."""
+    from normalizing_flow import calculate_loss, initialize_with_zeros
+    from nfdp_hip.optim import FusedAdam
+    flow, prior, _, _ = build(3, 2, 2, 51)
+    opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-3, clip_value=1, max_norm=1)
+    x = (T(synth_input("train_x3", (4, 3, 16, 16), 7)) * 0.4).to(DEV)
+    dev = torch.device(DEV)
+
+    def nll_nograd():
+        with torch.no_grad():
+            ll, lp = initialize_with_zeros(2, 4, dev)
+            lat, ll, lp = flow.transform(x, ll, lp)
+            return float(calculate_loss(ll + lp + prior.compute_log_prob(lat[-1]), 32.0, 16 * 16 * 3.0))
+
+    before = nll_nograd()
+    losses = []
+    for _ in range(3):
+        ll, lp = initialize_with_zeros(2, 4, dev)
+        lat, ll, lp = flow.transform(x, ll, lp)
+        loss = calculate_loss(ll + lp + prior.compute_log_prob(lat[-1]), 32.0, 16 * 16 * 3.0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    after = nll_nograd()
+    assert abs(losses[0] - before) <= 1e-5 * abs(before)
+    assert all(np.isfinite(losses)) and abs(after - before) > 1e-4, (before, losses, after)   # the weights did move
+    fsd = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
+    psd = {k: v.detach().cpu() for k, v in prior.state_dict().items()}
+    _, _, _, bpd = O.fwd_nll(x.cpu(), fsd, psd, 2, 2, img_size=16)
+    assert abs(float(bpd) - after) <= 2e-5 * abs(after), (float(bpd), after)
