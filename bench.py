@@ -287,12 +287,14 @@ def main():
             # HBM traffic of the same kernel/shape from a separate rocprofv3 --pmc pass (committed summary):
             # FETCH_SIZE doubled for wide coalesced reads on gfx950 (MI355X_MICROARCH.md §HBM) + WRITE_SIZE, per launch
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_e_fused_pmc_summary.json")))
-                key = {"coupling_fused_kernel<12,16>": "<12, 16, 2, ", "coupling_fused_kernel<24,8>": "<24, 8, 1, f",
-                       "coupling_fused_kernel<48,4>": "<48, 4, 1, f"}.get(lbl.split("+")[0].split(" ")[0])
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_k_pmc_summary.json")))
+                key = {"coupling_fused_kernel<12,16>": "coupling_fused_kernel<12, 16, 2, false>",
+                       "coupling_fused_kernel<24,8>": "coupling_fused_rs2_kernel<24, 8, 4, false>",
+                       "coupling_fused_kernel<48,4>": "coupling_fused_rs_kernel<48, 4, false>"}.get(lbl.split("+")[0].split(" ")[0])
                 if key and args.batch == 512:
-                    roofline["traffic"] = int((2 * pmc[key]["FETCH_SIZE_KB_raw"] + pmc[key]["WRITE_SIZE_KB"]) * 1024)
-                    roofline["traffic_note"] = "bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r01_e_fused_pmc_summary.json"
+                    roofline["traffic"] = int(pmc[key]["hbm_bytes_per_launch"])
+                    roofline["traffic_note"] = ("bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2: gfx950 tallies 128-B reads at 64 B) + "
+                                                "WRITE_SIZE in separate passes, profiles/r01_k_pmc_summary.json (tools/profile_round.sh)")
             except (OSError, KeyError, ValueError):
                 pass
             roofline.update({"kernel": lbl, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": a["n"] // n_prof,
