@@ -276,7 +276,7 @@ def main():
             total_ms = sum(a["ms"] for a in agg.values())
             lbl, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
             avg_s = a["ms"] / a["n"] * 1e-3
-            if a["flops"] > 0 and lbl.startswith(("conv", "coupling_fused")):
+            if a["flops"] > 0 and lbl.startswith(("conv", "coupling_fused", "level_fused")):
                 ach = a["flops"] / a["n"] / avg_s / 1e12
                 roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.compute], "unit": "TFLOP/s",
                             "frac": round(ach / PEAK[args.compute], 4), "traffic": None}
@@ -287,14 +287,14 @@ def main():
             # HBM traffic of the same kernel/shape from a separate rocprofv3 --pmc pass (committed summary):
             # FETCH_SIZE doubled for wide coalesced reads on gfx950 (MI355X_MICROARCH.md §HBM) + WRITE_SIZE, per launch
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_k_pmc_summary.json")))
-                key = {"coupling_fused_kernel<12,16>": "coupling_fused_kernel<12, 16, 2, false>",
-                       "coupling_fused_kernel<24,8>": "coupling_fused_rs2_kernel<24, 8, 4, false>",
-                       "coupling_fused_kernel<48,4>": "coupling_fused_rs_kernel<48, 4, false>"}.get(lbl.split("+")[0].split(" ")[0])
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_l_pmc_summary.json")))
+                key = {"level_fused<12,16>": "coupling_fused_kernel<12, 16, 2, false>",
+                       "level_fused<24,8>": "coupling_fused_rs2_kernel<24, 8, 4, false>",
+                       "level_fused<48,4>": "coupling_fused_rs_kernel<48, 4, false>"}.get(lbl.split(" ")[0])
                 if key and args.batch == 512:
                     roofline["traffic"] = int(pmc[key]["hbm_bytes_per_launch"])
                     roofline["traffic_note"] = ("bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2: gfx950 tallies 128-B reads at 64 B) + "
-                                                "WRITE_SIZE in separate passes, profiles/r01_k_pmc_summary.json (tools/profile_round.sh)")
+                                                "WRITE_SIZE in separate passes, profiles/r01_l_pmc_summary.json (tools/profile_round.sh)")
             except (OSError, KeyError, ValueError):
                 pass
             roofline.update({"kernel": lbl, "avg_launch_us": round(avg_s * 1e6, 2), "launches_per_step": a["n"] // n_prof,

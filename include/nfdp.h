@@ -72,6 +72,10 @@ int nfdp_actnorm_inv_f32(const float* y, float* x, long npix, int C, const float
 size_t nfdp_invconv_prepare_ws_bytes(int n, int C);
 int nfdp_invconv_prepare_f32(const float* w, int n, int C, float* logabsdet, float* winv, void* ws,
                              nfdp_stream_t stream);
+/* log|det W_i| (fp64 LU with partial pivoting, returned as fp32) of n matrices of possibly DIFFERENT sizes C[i] <= 96 in one
+ * launch: every 1x1 convolution of a Glow forward pass (torch.slogdet(W.double())[1].float(), transforms.py:131, K*L times
+ * per pass in the reference).  w, C: HOST arrays of n device pointers / sizes; logabsdet: device [n]. */
+int nfdp_invconv_logdets_f32(const float* const* w, const int* C, int n, float* logabsdet, nfdp_stream_t stream);
 /* y[p,:] = W x[p,:]   (conv2d with a [C,C,1,1] kernel, transforms.py:132 / :144 with W^-1). */
 int nfdp_invconv_apply_f32(const float* x, float* y, long npix, int C, const float* w, nfdp_stream_t stream);
 /* Fused flow head, glow.py:46-47: y = W (exp(scale)*(x+bias)). */
@@ -134,6 +138,15 @@ int nfdp_coupling_fused_bf16(float* x, const void* packed, int B, int H, int W, 
 int nfdp_stepflow_fused_bf16(float* x, const void* packed, int B, int H, int W, int C, const float* scale,
                              const float* bias, const float* w, double* ldj, const float* logdet_term, int inverse,
                              nfdp_stream_t stream);
+/* n_flows consecutive flow steps of one Glow level (GlowBlock.transform / invert loop, glow.py:107-109, :128-130) in ONE
+ * persistent launch: a workgroup owns whole images, so its flow-state tile stays in LDS across all the flows and only the
+ * weights stream.  packed/scale/bias/w: HOST arrays of n_flows DEVICE pointers in forward flow order (the kernel receives
+ * them by value); inverse walks them backwards and expects W^-1 in `w`.  ldj[b] += sum over the flows of
+ * H*W*sum(scale) + sum log(s+1e-6) (the 1x1-conv log-dets are the caller's, nfdp_ldj_add_scaled_f32).  Results are
+ * bit-identical to n_flows calls of nfdp_stepflow_fused_bf16. */
+int nfdp_level_fused_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
+                          const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
+                          int inverse, nfdp_stream_t stream);
 /* ldj[b] += (double)(hw * (float)sum(v[0..n_sum)))  (fp32 product): the standalone ActNorm / InvConv2d log-det terms. */
 int nfdp_ldj_add_scaled_f32(double* ldj, int B, const float* v, int n_sum, float hw, nfdp_stream_t stream);
 /* out2[0] = hw*sum(scale[0..C)) (transforms.py:81), out2[1] = hw*logabsdet[0] (transforms.py:131), fp32: the two

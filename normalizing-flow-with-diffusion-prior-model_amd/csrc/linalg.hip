@@ -87,6 +87,188 @@ __global__ void __launch_bounds__(kBlock) gauss_jordan_kernel(const float* __res
     }
 }
 
+
+// ---- log|det| only, matrices of DIFFERENT sizes in one launch (all 1x1 convolutions of a Glow forward pass) --------
+// LU with implicit partial pivoting on W alone (no identity half): step k picks the unused row with the largest
+// |A[r][k]| (lowest r on ties, as above), and every other unused row i gets A[i][j] -= (A[i][k] / pv) * A[p][j] for
+// j > k.  Column k and the pivot row are only READ in step k, so nothing is staged: two barriers per step.  The pivots
+// are kept and log|.| is taken by C threads in parallel at the end, summed in step order (deterministic).
+constexpr int kMaxLogdetMats = 96;
+struct LogdetTable {
+    const float* w[kMaxLogdetMats];
+    int C[kMaxLogdetMats];
+};
+
+__global__ void __launch_bounds__(kBlock) logdet_multi_kernel(const LogdetTable tab, float* __restrict__ logabsdet) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int C = tab.C[blockIdx.x];
+    const float* __restrict__ wm = tab.w[blockIdx.x];
+    const int LD = C + 1;                                          // odd-ish row stride: column reads spread over banks
+    double* A = sm;                                                // [C][LD]
+    double* piv = A + (size_t)C * LD;                              // [C] pivots, then their logs
+    double* wval = piv + C;                                        // [4]
+    int* widx = reinterpret_cast<int*>(wval + 4);                  // [4]
+    int* used = widx + 4;                                          // [C]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < C * C; e += kBlock) A[(e / C) * LD + (e % C)] = (double)wm[e];
+    for (int i = tid; i < C; i += kBlock) used[i] = 0;
+    __syncthreads();
+    for (int k = 0; k < C; ++k) {
+        double best = -1.0;
+        int bi = 1 << 30;
+        if (tid < C && !used[tid]) { best = fabs(A[tid * LD + k]); bi = tid; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if (lane == 0) { wval[wave] = best; widx[wave] = bi; }
+        __syncthreads();
+        int p = widx[0];
+        double pb = wval[0];
+#pragma unroll
+        for (int q = 1; q < kBlock / 64; ++q)
+            if (wval[q] > pb || (wval[q] == pb && widx[q] < p)) { pb = wval[q]; p = widx[q]; }
+        const double pv = A[p * LD + k];
+        const double rp = 1.0 / pv;
+        const int nc = C - 1 - k;                                  // columns right of k
+        // row p is excluded below by i != p, so marking it used now cannot change what this step's updates do
+        if (tid == 0) { piv[k] = pv; used[p] = 1; }
+        (void)nc;
+        // fixed 2-D mapping (32 column lanes x 8 row groups): no runtime div/mod in the update
+        for (int i = tid >> 5; i < C; i += kBlock / 32) {
+            if (i == p || used[i]) continue;
+            const double f = A[i * LD + k] * rp;
+            for (int j = k + 1 + (tid & 31); j < C; j += 32) A[i * LD + j] -= f * A[p * LD + j];
+        }
+        __syncthreads();                                           // updates + used[] visible before the next argmax
+    }
+    if (tid < C) piv[tid] = log(fabs(piv[tid]));
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int k = 0; k < C; ++k) s += piv[k];
+        logabsdet[blockIdx.x] = (float)s;
+    }
+}
+
+
+// max over the 64 lanes of a wave without the LDS crossbar: prefix-max inside each row of 16 lanes with DPP row shifts
+// (lanes shifted in from outside a row read 0, the identity), then the four row results through readlane
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));   // row_shr:1
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));   // row_shr:2
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));   // row_shr:4
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));   // row_shr:8
+    const unsigned a = __builtin_amdgcn_readlane((int)v, 15), b = __builtin_amdgcn_readlane((int)v, 31);
+    const unsigned c = __builtin_amdgcn_readlane((int)v, 47), d = __builtin_amdgcn_readlane((int)v, 63);
+    return max(max(a, b), max(c, d));
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane_uniform);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane_uniform);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Register-resident variant for the channel counts Glow produces: lane = row, the row lives in C fp64 registers (the
+// loops are fully unrolled, so every index is static), the pivot row is broadcast with v_readlane - no LDS, no barrier
+// anywhere in the elimination.  Returns log|det| (valid in lane 0).
+template <int C>
+__device__ __forceinline__ double lu_logdet_regs(const float* __restrict__ wm, int lane) {
+    double a[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) a[j] = lane < C ? (double)wm[lane * C + j] : 0.0;
+    bool used = lane >= C;
+    double mypiv = 1.0;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const unsigned key = used ? 0u : ((__float_as_uint((float)fabs(a[k])) & ~63u) | (unsigned)(63 - lane));
+        const int p = 63 - (int)(wave_umax(key) & 63u);
+        const double pv = readlane_f64(a[k], p);
+        if (lane == k) mypiv = pv;
+        if (lane == p) used = true;
+        const double f = used ? 0.0 : a[k] * (1.0 / pv);
+#pragma unroll
+        for (int j = k + 1; j < C; ++j) a[j] -= f * readlane_f64(a[j], p);
+    }
+    const double lg = lane < C ? log(fabs(mypiv)) : 0.0;
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < C; ++k) sum += readlane_f64(lg, k);        // step order: deterministic
+    return sum;
+}
+
+// One WAVE per matrix (C <= 64): lane = row, so a step needs no workgroup barrier - the argmax is one DPP wave reduction,
+// the pivot row is read as LDS broadcasts, every lane updates its own row.  LDS ops of one wave execute in order.
+__global__ void __launch_bounds__(64) logdet_wave_kernel(const LogdetTable tab, float* __restrict__ logabsdet) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int C = tab.C[blockIdx.x];
+    const float* __restrict__ wm = tab.w[blockIdx.x];
+    const int lane = threadIdx.x;
+    {
+        double r = 0.0;
+        bool done = true;
+        switch (C) {                                               // wave-uniform
+            case 4: r = lu_logdet_regs<4>(wm, lane); break;
+            case 8: r = lu_logdet_regs<8>(wm, lane); break;
+            case 12: r = lu_logdet_regs<12>(wm, lane); break;
+            case 16: r = lu_logdet_regs<16>(wm, lane); break;
+            case 24: r = lu_logdet_regs<24>(wm, lane); break;
+            case 48: r = lu_logdet_regs<48>(wm, lane); break;
+            default: done = false;
+        }
+        if (done) {
+            if (lane == 0) logabsdet[blockIdx.x] = (float)r;
+            return;
+        }
+    }
+    const int LD = C + 1;
+    double* A = sm;                                                // [C][LD]   (generic sizes: rows in LDS)
+    for (int e = lane; e < C * C; e += 64) A[(e / C) * LD + (e % C)] = (double)wm[e];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    bool used = lane >= C;                                         // lanes beyond the matrix never pivot
+    double* row = A + (lane < C ? lane : 0) * LD;
+    double* piv = A + (size_t)C * LD;                              // [C] pivots: their logs are taken in parallel afterwards
+    for (int k = 0; k < C; ++k) {
+        // pivot = unused row with the largest |A[r][k]|: one 32-bit wave max over the key (fp32 magnitude bits, low 6
+        // bits replaced by 63 - lane: lowest row wins among magnitudes equal to ~1e-5 relative, enough for stability)
+        const unsigned key = used ? 0u : ((__float_as_uint((float)fabs(row[k])) & ~63u) | (unsigned)(63 - lane));
+        const int p = 63 - (int)(wave_umax(key) & 63u);
+        const double* prow = A + p * LD;
+        const double pv = prow[k];
+        if (lane == p) { used = true; piv[k] = pv; }
+        // row and prow alias the same LDS array, so a plain loop waits for every store before the next load: load 8
+        // columns of both rows into registers, then update and store (the pivot row itself is never written in step k)
+        const double f = used ? 0.0 : row[k] * (1.0 / pv);
+        for (int j0 = k + 1; j0 < C; j0 += 8) {
+            double r[8], q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u < C ? j0 + u : C - 1;
+                r[u] = row[j];
+                q[u] = prow[j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (!used && j0 + u < C) row[j0 + u] = r[u] - f * q[u];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane < C) piv[lane] = log(fabs(piv[lane]));                // one log per lane, off the serial chain
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        double sum = 0.0;
+        for (int k = 0; k < C; ++k) sum += piv[k];                 // step order: deterministic
+        logabsdet[blockIdx.x] = (float)sum;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t nfdp_invconv_prepare_ws_bytes(int n, int C) {
@@ -110,5 +292,31 @@ extern "C" int nfdp_invconv_prepare_f32(const float* w, int n, int C, float* log
                            winv, reinterpret_cast<double*>(ws));
     }
     NFDP_CHECK_LAUNCH("invconv_prepare");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_invconv_logdets_f32(const float* const* w, const int* C, int n, float* logabsdet, nfdp_stream_t stream) {
+    NFDP_REQUIRE(w && C && logabsdet, NFDP_EINVAL, "invconv_logdets: null pointer");
+    NFDP_REQUIRE(n >= 0, NFDP_ESHAPE, "invconv_logdets: bad count");
+    // w, C: HOST arrays (device pointers / sizes); the kernel receives them by value, kMaxLogdetMats per launch
+    for (int done = 0; done < n; done += kMaxLogdetMats) {
+        LogdetTable tab;
+        const int m = (n - done) < kMaxLogdetMats ? (n - done) : kMaxLogdetMats;
+        int cmax = 0;
+        for (int i = 0; i < m; ++i) {
+            NFDP_REQUIRE(w[done + i] && C[done + i] > 0 && C[done + i] <= 96, NFDP_ESHAPE,
+                         "invconv_logdets: matrix %d: null or C=%d outside [1,96]", done + i, C[done + i]);
+            tab.w[i] = w[done + i];
+            tab.C[i] = C[done + i];
+            cmax = C[done + i] > cmax ? C[done + i] : cmax;
+        }
+        for (int i = m; i < kMaxLogdetMats; ++i) { tab.w[i] = nullptr; tab.C[i] = 0; }
+        const size_t lds = ((size_t)cmax * (cmax + 1) + cmax + 4) * sizeof(double) + (size_t)(cmax + 4) * sizeof(int) + 16;
+        if (cmax <= 64)        // one wave per matrix, no barriers
+            hipLaunchKernelGGL(logdet_wave_kernel, dim3(m), dim3(64), lds, as_stream(stream), tab, logabsdet + done);
+        else
+            hipLaunchKernelGGL(logdet_multi_kernel, dim3(m), dim3(kBlock), lds, as_stream(stream), tab, logabsdet + done);
+    }
+    NFDP_CHECK_LAUNCH("invconv_logdets");
     return NFDP_OK;
 }

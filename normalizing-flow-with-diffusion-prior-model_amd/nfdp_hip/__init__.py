@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFDP_LIB_PATH") or os.path.join(_HERE, "libnfdp_hip.so")   # override: profiling builds
-HEADER_PATH = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "nfdp.h")
+HEADER_PATH = os.environ.get("NFDP_HEADER_PATH") or os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "nfdp.h")
 
 F32, BF16 = 0, 1
 _COMPUTE_NAMES = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
@@ -278,6 +278,18 @@ def invconv_prepare(w: torch.Tensor, want_inverse: bool):
     return lad, winv
 
 
+def invconv_logdets(ws) -> torch.Tensor:
+    """log|det W| (fp64 on the device, fp32 result [n]) of a list of square matrices of any sizes <= 96, ONE launch."""
+    n = len(ws)
+    for w in ws:
+        _need(w, torch.float32, "invconv_logdets"); _dense(w, "invconv_logdets")
+    out = torch.empty(n, device=ws[0].device, dtype=torch.float32)
+    ptrs = (ctypes.c_void_p * n)(*[w.data_ptr() for w in ws])
+    cs = (ctypes.c_int * n)(*[w.shape[-1] for w in ws])
+    _call("nfdp_invconv_logdets_f32", ptrs, cs, n, _ptr(out), _stream())
+    return out
+
+
 def invconv_apply(xh, w, out=None):
     _need(xh, torch.float32, "invconv_apply"); _dense(xh, "invconv_apply")
     out = torch.empty_like(xh) if out is None else out
@@ -418,6 +430,24 @@ def stepflow_fused(xh: torch.Tensor, packed: torch.Tensor, scale, bias, w, ldj: 
     _call("nfdp_stepflow_fused_bf16", _ptr(xh), _ptr(packed), b, h, wd, c, _ptr(scale), _ptr(bias), _ptr(w), _ptr(ldj),
           _ptr(logdet_term), int(inverse), _stream(),
           label=f"coupling_fused_kernel<{c},{wd}>+head {'inv' if inverse else 'fwd'}", flops=flops, nbytes=8.0 * xh.numel())
+
+
+def level_fused(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torch.Tensor], inverse: bool) -> None:
+    """In place on xh [B,H,W,C]: len(packed) consecutive flow steps (forward order; `ws` holds W, or W^-1 when inverse) in
+    ONE persistent launch - the flow-state tile stays in LDS across the flows."""
+    _need(xh, torch.float32, "level_fused"); _dense(xh, "level_fused")
+    b, h, wd, c = xh.shape
+    n = len(packed)
+    if not (len(scales) == len(biases) == len(ws) == n):
+        raise ValueError("level_fused: pointer tables of different lengths")
+    if ldj is not None:
+        _need(ldj, torch.float64, "level_fused ldj")
+    tab = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ch = c // 2
+    flops = n * 2.0 * b * h * wd * (9 * ch * 512 + 512 * 512 + 9 * 512 * c + c * c)
+    _call("nfdp_level_fused_bf16", _ptr(xh), b, h, wd, c, n, tab(packed), tab(scales), tab(biases), tab(ws), _ptr(ldj),
+          int(inverse), _stream(), label=f"level_fused<{c},{wd}> x{n} {'inv' if inverse else 'fwd'}", flops=flops,
+          nbytes=8.0 * xh.numel())
 
 
 def ldj_add_scaled(ldj: torch.Tensor, v: torch.Tensor, n_sum: int, hw: float):

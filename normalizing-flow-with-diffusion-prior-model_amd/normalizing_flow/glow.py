@@ -8,6 +8,7 @@ MI355X execution plan for Glow.transform (forward + log-dets):
     launch that also adds the flow's batch-independent log-det terms — 5 launches instead of ~25 torch ops and
     no host synchronisation (the reference's `.item()` per ActNorm per call is replaced by a host-side flag).
 """
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -80,8 +81,36 @@ def _level_logdets(flows: Sequence[StepFlow]) -> Tensor:
     return lads
 
 
+# Flows per persistent launch: by default a whole level (the kernel takes up to 32 flows per launch and the ABI entry
+# chunks longer levels).  A launch then holds every CU for ~1 ms, so nothing on another stream can interleave with it;
+# Glow.transform_nhwc therefore computes all 1x1-conv log-dets in one short launch on the same stream beforehand.
+LEVEL_CHUNK = int(os.environ.get("NFDP_LEVEL_CHUNK", "32"))
+
+
+def _level_tables(flows: Sequence[StepFlow], xh: Tensor):
+    """(packed images, ActNorm scales, biases) of every flow of a level when ALL of them can run on the fused kernel
+    (bf16 mode, supported geometry, ActNorms initialised), else None."""
+    packed = []
+    for f in flows:
+        if not f.actnorm.initialized():
+            return None
+        p = f.affcoupling._fused_pack(xh)
+        if p is None:
+            return None
+        packed.append(p)
+    return packed, [f.actnorm.scale.view(-1) for f in flows], [f.actnorm.bias.view(-1) for f in flows]
+
+
 def _run_flows_fwd(flows: Sequence[StepFlow], xh: Tensor, ldj: Optional[Tensor], lads: Optional[Tensor] = None,
                    defer_logdet: bool = False) -> Tensor:
+    if ldj is None or defer_logdet:
+        tabs = _level_tables(flows, xh)
+        if tabs is not None:                      # persistent launches, the tile stays in LDS across LEVEL_CHUNK flows
+            ws = [f.invconv2d._w() for f in flows]
+            for i in range(0, len(flows), LEVEL_CHUNK):
+                j = i + LEVEL_CHUNK
+                K.level_fused(xh, tabs[0][i:j], tabs[1][i:j], tabs[2][i:j], ws[i:j], ldj, inverse=False)
+            return xh
     if ldj is not None and lads is None and not defer_logdet:
         lads = _level_logdets(flows)
     for i, f in enumerate(flows):
@@ -103,6 +132,13 @@ def _side_stream(device) -> "torch.cuda.Stream":
 def _run_flows_inv(flows: Sequence[StepFlow], yh: Tensor) -> Tensor:
     w = torch.stack([f.invconv2d._w() for f in flows])
     _, winvs = K.invconv_prepare(w, want_inverse=True)
+    tabs = _level_tables(flows, yh)
+    if tabs is not None:
+        wl = [winvs[i] for i in range(len(flows))]
+        for j in range(len(flows), 0, -LEVEL_CHUNK):
+            i = max(j - LEVEL_CHUNK, 0)
+            K.level_fused(yh, tabs[0][i:j], tabs[1][i:j], tabs[2][i:j], wl[i:j], None, inverse=True)
+        return yh
     for i in reversed(range(len(flows))):
         yh = flows[i].invert_nhwc_(yh, winvs[i])
     return yh
@@ -174,19 +210,18 @@ class Glow(Transform):
         """-> ([z_0 .. z_{L-1}] NHWC tensors, ldj, logp); accumulators fp64, updated in place."""
         zs = []
         yh = xh
-        # The 1x1-conv log-dets depend only on the weights.  Their fp64 eliminations (one latency-bound workgroup
-        # per matrix, ~100 us per level) run on a side stream concurrently with the flow kernels; the per-level
-        # sums  H*W * sum_k log|det W_k|  are folded into ldj once at the end (an fp64 re-association of the
-        # reference's per-flow adds, transforms.py:131).
-        lads, done = None, None
+        # The 1x1-conv log-dets depend only on the weights: ONE launch computes all K*L of them (fp64 LU, one workgroup
+        # per matrix, ~10-20 us) ahead of the flow kernels; the per-level sums  H*W * sum_k log|det W_k|  are folded into
+        # ldj once at the end (an fp64 re-association of the reference's per-flow adds, transforms.py:131).
+        lads = None
         if ldj is not None:
-            main = torch.cuda.current_stream()
-            side = _side_stream(xh.device)
-            side.wait_stream(main)                       # weights written on the main stream are visible
-            with torch.cuda.stream(side):
-                lads = [_level_logdets(b.flows) for b in self.blocks] + [_level_logdets(self.final_flows)]
-                done = torch.cuda.Event()
-                done.record(side)
+            groups = [list(b.flows) for b in self.blocks] + [list(self.final_flows)]
+            allw = [f.invconv2d._w() for g in groups for f in g]
+            flat = K.invconv_logdets(allw)
+            lads, o = [], 0
+            for g in groups:
+                lads.append(flat[o:o + len(g)])
+                o += len(g)
         hws = []
         for i, block in enumerate(self.blocks):
             yh, z = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True)
@@ -197,7 +232,6 @@ class Glow(Transform):
         yh = _run_flows_fwd(self.final_flows, yh, ldj, None, defer_logdet=True)
         zs.append(yh)
         if ldj is not None:
-            torch.cuda.current_stream().wait_event(done)
             for lad, hw in zip(lads, hws):
                 K.ldj_add_scaled(ldj, lad, lad.numel(), hw)
         return zs

@@ -86,8 +86,10 @@ def test_glow_m_golden_in_bf16_fused():
     logp = torch.zeros(m["B"], dtype=torch.float64, device=DEV)
     K.start_trace()
     zs, _, _ = flow.transform(x, ldj, logp)
-    n_fused = sum(e["label"].startswith("coupling_fused_kernel") for e in K.stop_trace())
-    assert n_fused == m["L"] * m["K"]
+    labels = [e["label"] for e in K.stop_trace()]
+    n_level = sum(lb.startswith("level_fused") for lb in labels)
+    assert n_level == m["L"], labels                                  # one persistent launch per Glow level
+    assert not any(lb.startswith(("conv_kernel<", "coupling_kernel")) and "512" in lb for lb in labels)   # no unfused coupling nets
     logp += prior.compute_log_prob(zs[-1])
     assert_close(calculate_loss(ldj + logp, 32.0, 3072.0), g["bpd"], 2e-3, "bpd (bf16, golden weights are ill-conditioned)")
     assert_close(zs[-1], g[f"z{m['L'] - 1}"], 5e-2, "z_last")
@@ -126,3 +128,38 @@ def test_rowsplit_kernel_bit_identical(C, hw, inverse):
         assert torch.equal(outs[0][0], outs[1][0]), f"B={B}: state differs"
         assert torch.equal(outs[0][1], outs[1][1]), f"B={B}: ldj differs"
         assert torch.isfinite(outs[1][0]).all()
+
+
+@pytest.mark.parametrize("C,hw,B", [(12, 16, 5), (24, 8, 7), (48, 4, 9), (4, 16, 2), (8, 8, 3), (16, 4, 5)])
+@pytest.mark.parametrize("inverse", [False, True])
+@torch.no_grad()
+def test_level_launch_bit_identical_to_per_flow_launches(C, hw, B, inverse):
+    """nfdp_level_fused_bf16 (K flows in one persistent launch, tile resident in LDS) against K single-flow launches:
+    same arithmetic in the same order -> identical bits, log-det included; ragged batches."""
+    import numpy as np
+    from normalizing_flow.glow import StepFlow, _level_tables
+    nfl = 5
+    flows = []
+    for f in range(nfl):
+        m = StepFlow(C, 512, compute="bf16")
+        m.load_state_dict({k: torch.from_numpy(np.array(synth_tensor(f"flows.{f}." + k, v.shape, 9, DEEP)))
+                           for k, v in m.state_dict().items()})
+        flows.append(m.to("cuda"))
+    x = torch.randn(B, hw, hw, C, device="cuda") * 0.5
+    ws = torch.stack([f.invconv2d._w() for f in flows])
+    _, winvs = K.invconv_prepare(ws, want_inverse=True)
+    a, b = x.clone(), x.clone()
+    la = torch.zeros(B, dtype=torch.float64, device="cuda")
+    lb = torch.zeros(B, dtype=torch.float64, device="cuda")
+    if not inverse:
+        for f in flows:
+            f.transform_nhwc_(a, la, None, defer_logdet=True)
+    else:
+        for i in reversed(range(nfl)):
+            flows[i].invert_nhwc_(a, winvs[i])
+    packed, scales, biases = _level_tables(flows, b)
+    wl = [winvs[i] for i in range(nfl)] if inverse else [f.invconv2d._w() for f in flows]
+    K.level_fused(b, packed, scales, biases, wl, None if inverse else lb, inverse=inverse)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), "state differs"
+    assert torch.equal(la, lb), "log-det differs"

@@ -192,8 +192,14 @@ def test_nfbackbone_and_empty_batch():
     assert nf.sample(lat).shape == x.shape
 
 
-def test_grad_mode_raises_until_backward_exists():
+def test_grad_mode_selects_training_path_and_invert_still_raises():
+    """With trainable parameters and grad mode on, transform runs the differentiable path (tests/test_gpu_backward.py);
+    invert / sample have no backward and must say so instead of silently dropping the graph."""
     from normalizing_flow import Glow
-    flow = Glow(in_channel=1, L=2, K=1)
+    flow = Glow(in_channel=1, L=2, K=1, compute="f32")
+    zs, ldj, logp = flow.transform(torch.rand(2, 1, 8, 8, device=DEV) - 0.5, z64(2), z64(2))
+    assert ldj.requires_grad and logp.requires_grad and zs[-1].requires_grad
     with pytest.raises(NotImplementedError):
-        flow.transform(torch.zeros(2, 1, 8, 8, device=DEV), z64(2), z64(2))
+        flow.invert([z.detach() for z in zs])
+    with torch.no_grad():
+        flow.invert([z.detach() for z in zs])

@@ -1,7 +1,8 @@
 #!/bin/bash
 # Round-end profiling on the GPU box (run through gpurun from the repo root):
 #   1. rocprofv3 --kernel-trace --stats of the bench command (eager launches so every kernel is a dispatch)
-#   2. separate --pmc passes over the fused flow-step kernels (tools/time_fused_level.py: 16 distinct flows per level)
+#   2. separate --pmc passes over the fused flow-step kernels (tools/time_fused_level.py: one persistent launch per level,
+#      16 distinct flows each)
 # Outputs land in gpurun_out/prof_<tag>/; copy the summaries into profiles/.
 set -e -o pipefail
 TAG=${1:-r01}
@@ -12,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench --
 echo "stats pass done"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -- python3 tools/time_fused_level.py > "$OUT/pmc_$name.log" 2>&1
+  NFDP_LEVEL_ONLY=1 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$name" -- python3 tools/time_fused_level.py > "$OUT/pmc_$name.log" 2>&1
   echo "pmc pass $name done"
 done
 python3 tools/pmc_summary.py "$OUT/pmc_summary.json" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_WAVE_CYCLES "$OUT"/pmc_TCC_HIT_sum > /dev/null

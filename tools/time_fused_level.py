@@ -24,17 +24,30 @@ with torch.no_grad():
             flows.append(m.to(dev))
         x = torch.rand(B, hw, hw, c, device=dev) - 0.5
         ldj = torch.zeros(B, dtype=torch.float64, device=dev)
-        for _ in range(2):
-            for m in flows:
-                m.transform_nhwc_(x, ldj, None, defer_logdet=True)
-        torch.cuda.synchronize()
-        K.start_trace()
-        for _ in range(3):
-            for m in flows:
-                m.transform_nhwc_(x, ldj, None, defer_logdet=True)
-        recs = [r for r in K.stop_trace() if "fused" in r["label"]]
-        us = sorted(r["ms"] * 1e3 for r in recs)
-        print(f"C={c} hw={hw} B={B}: {len(us)} launches, median {us[len(us) // 2]:.1f} us, min {us[0]:.1f}, max {us[-1]:.1f}", flush=True)
+        if not os.environ.get("NFDP_LEVEL_ONLY"):            # per-flow launches (one kernel per flow step)
+            for _ in range(2):
+                for m in flows:
+                    m.transform_nhwc_(x, ldj, None, defer_logdet=True)
+            torch.cuda.synchronize()
+            K.start_trace()
+            for _ in range(3):
+                for m in flows:
+                    m.transform_nhwc_(x, ldj, None, defer_logdet=True)
+            recs = [r for r in K.stop_trace() if "fused" in r["label"]]
+            us = sorted(r["ms"] * 1e3 for r in recs)
+            print(f"C={c} hw={hw} B={B}: {len(us)} launches, median {us[len(us) // 2]:.1f} us, min {us[0]:.1f}, max {us[-1]:.1f}", flush=True)
+        if hasattr(K, "level_fused"):                       # the same 16 flows as ONE persistent launch
+            from normalizing_flow.glow import _level_tables
+            packed, scales, biases = _level_tables(flows, x)
+            ws = [f.invconv2d._w() for f in flows]
+            for _ in range(2):
+                K.level_fused(x, packed, scales, biases, ws, ldj, inverse=False)
+            torch.cuda.synchronize()
+            K.start_trace()
+            for _ in range(5):
+                K.level_fused(x, packed, scales, biases, ws, ldj, inverse=False)
+            lus = sorted(r["ms"] * 1e3 for r in K.stop_trace())
+            print(f"   level launch (16 flows): median {lus[len(lus) // 2]:.1f} us = {lus[len(lus) // 2] / 16:.1f} us per flow", flush=True)
         if os.environ.get("NFDP_READ_STAMPS"):                 # -DNFDP_FUSED_STAMPS build: start/end s_memtime of the last launch
             import ctypes
             buf = (ctypes.c_ulonglong * (512 * 16))()
