@@ -233,3 +233,46 @@ def test_training_step_with_fused_optimizer_updates_kernel_weight_caches():
     psd = {k: v.detach().cpu() for k, v in prior.state_dict().items()}
     _, _, _, bpd = O.fwd_nll(x.cpu(), fsd, psd, 2, 2, img_size=16)
     assert abs(float(bpd) - after) <= 2e-5 * abs(after), (float(bpd), after)
+
+
+def test_training_step_matches_reference_goldens():
+    """The reference's own training step on the glow_N weights/inputs (tests/golden/train_N.npz: generated by running
+    the reference): gradients before the clips, gradients after clip_grad_value_(1) + clip_grad_norm_(1), the clipped
+    norm, and the parameters after one Adam step - HIP training path + nfdp_fused_adam_step_f32."""
+    import json
+    from normalizing_flow import Glow, GaussianPrior, calculate_loss, initialize_with_zeros
+    from nfdp_hip.optim import FusedAdam
+    from tests.util import load_golden, meta_of, synth_sd
+    from tests.test_oracle_golden import close_summary
+    g = load_golden("train_N.npz")
+    m = meta_of(g)
+    flow = Glow(in_channel=m["C"], L=m["L"], K=m["K"], compute="f32")
+    prior = GaussianPrior(2 ** (m["L"] + 1) * m["C"])
+    flow.load_state_dict(synth_sd(m["flow_spec"], m["seed"]))
+    prior.load_state_dict(synth_sd(m["prior_spec"], m["seed"]))
+    flow.to(DEV); prior.to(DEV)
+    opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-3, clip_value=1, max_norm=1)
+    x = T(load_golden("glow_N.npz")["x"]).to(DEV)
+    ll, logp = initialize_with_zeros(2, m["B"], torch.device(DEV))
+    lat, ll, logp = flow.transform(x, ll, logp)
+    logp = logp + prior.compute_log_prob(lat[-1])
+    loss = calculate_loss(ll + logp, 32.0, 32 * 32 * 3.0)
+    assert_close(loss, g["bpd"], 1e-5, "bpd")
+    opt.zero_grad()
+    loss.backward()
+    names, pnames = dict(flow.named_parameters()), dict(prior.named_parameters())
+    keys, pkeys = json.loads(str(g["keys"])), json.loads(str(g["pkeys"]))
+    for i, k in enumerate(keys):
+        close_summary(names[k].grad, g[f"g{i}"], TOL, f"grad {k}")
+    for i, k in enumerate(pkeys):
+        if float(g[f"pg{i}"][-1]) > 0:
+            close_summary(pnames[k].grad, g[f"pg{i}"], TOL, f"prior grad {k}")
+    sumsq = sum(float((p.grad.double() ** 2).sum()) for p in flow.parameters())
+    assert abs(sumsq - float(g["sumsq_all"])) <= 2e-4 * float(g["sumsq_all"])
+    opt.step()                                        # value clip, norm clip (gradients scaled in place), Adam
+    assert_close(opt.grad_norm, g["total_norm_after_value_clip"].reshape(1), TOL, "clipped global norm")
+    for i, k in enumerate(keys):
+        close_summary(names[k].grad, g[f"c{i}"], TOL, f"clipped grad {k}")
+        close_summary(names[k], g[f"p{i}"], TOL, f"updated parameter {k}")
+    for i, k in enumerate(pkeys):
+        close_summary(pnames[k], g[f"pp{i}"], TOL, f"updated prior parameter {k}")

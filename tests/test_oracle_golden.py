@@ -255,3 +255,42 @@ def test_cat_formater_index_map(vg, tag):
            for i, d in enumerate(dims)]
     out = cat_reference_map(lat, (c["L"] - 1) // 2)
     assert torch.equal(out, T(vg[f"cat_{tag}_out"]))
+
+
+# ----------------------------------------------------------------------------- training-step goldens (reference autograd)
+def summary64(v):
+    f = torch.as_tensor(v).detach().double().reshape(-1).cpu()
+    return torch.cat([f[:64], torch.stack([f.sum(), (f * f).sum(), f.abs().max()])])
+
+
+def close_summary(got, ref, tol, what):
+    """[first 64 | sum | sumsq | max-abs] fixtures: values relative to the tensor's max-abs, the sum relative to sqrt(N)
+    times it (round-off of a long sum), sumsq and max-abs relative to themselves."""
+    got, ref = summary64(got), torch.as_tensor(ref).double()
+    n, scale = len(got) - 3, float(ref[-1]) if float(ref[-1]) > 0 else 1.0
+    assert float((got[:n] - ref[:n]).abs().max()) <= tol * scale, f"{what}: head values"
+    assert abs(float(got[-1] - ref[-1])) <= tol * scale, f"{what}: max-abs"
+    assert abs(float(got[-2] - ref[-2])) <= 2 * tol * max(float(ref[-2]), 1e-30), f"{what}: sum of squares"
+
+
+def test_oracle_autograd_matches_reference_training_gradients():
+    """trainer.py:152-164: autograd through the oracle reproduces the reference's own parameter gradients (fixture
+    tests/golden/train_N.npz, generated by running the reference), which pins the oracle as the gradient checker of
+    tests/test_gpu_backward.py."""
+    import json
+    g = load_golden("train_N.npz")
+    m = meta_of(g)
+    fsd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synth_sd(m["flow_spec"], m["seed"]).items()}
+    psd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in synth_sd(m["prior_spec"], m["seed"]).items()}
+    x = T(load_golden("glow_N.npz")["x"])
+    _, _, _, bpd = O.fwd_nll(x, fsd, psd, m["L"], m["K"])
+    assert_close(bpd, g["bpd"], 1e-6, "bpd")
+    bpd.backward()
+    for i, k in enumerate(json.loads(str(g["keys"]))):
+        close_summary(fsd[k].grad, g[f"g{i}"], 2e-5, f"grad {k}")
+    for i, k in enumerate(json.loads(str(g["pkeys"]))):
+        ref = T(g[f"pg{i}"])
+        if float(ref[-1]) == 0.0:
+            assert psd[k].grad is None or float(psd[k].grad.abs().max()) == 0.0
+        else:
+            close_summary(psd[k].grad, ref, 2e-5, f"prior grad {k}")

@@ -322,8 +322,57 @@ def gen_vlb():
     print("vlb.npz", len(g), "arrays", {k: g[k].tolist() for k in ("term_a_out", "prior_T1000", "loop8_total")})
 
 
+# ------------------------------------------------------------------ training-step goldens (trainer.py:152-167)
+def gen_train(C=3, L=3, K=2, B=2, seed=2):
+    """loss.backward() of the reference on the N-config golden weights: gradients of a spread of named parameters before
+    and after clip_grad_value_(flow.parameters(), 1) + clip_grad_norm_(flow.parameters(), 1), the total norm, and the
+    parameters after one Adam step (lr 1e-3) - the body of the reference's training loop."""
+    U = R["nf_utils"]
+    flow = R["glow"].Glow(in_channel=C, L=L, K=K)
+    prior = R["prior"].GaussianPrior(2 ** (L + 1) * C)
+    spec, pspec = load_synth(flow, seed), load_synth(prior, seed)
+    x_np, _, _ = images_5bit("glowN", (B, C, 32, 32), seed)          # same inputs/weights as glow_N.npz
+    x = t(x_np)
+    opt = U.init_optimizer("adam", [{"params": flow.parameters()}, {"params": prior.parameters()}], 1e-3)
+    ldj, logp = f64z(B), f64z(B)
+    zs, ldj, logp = flow.transform(x, ldj, logp)
+    logp = logp + prior.compute_log_prob(zs[-1])
+    loss = U.calculate_loss(ldj + logp, 32.0, 32 * 32 * 3.0)
+    opt.zero_grad()
+    loss.backward()
+    names = dict(list(flow.named_parameters()))
+    pnames = dict(list(prior.named_parameters()))
+    # a spread over levels, layer types and positions in the flow
+    keys = [k for k in names if any(k.startswith(p) for p in ("blocks.0.flows.0.", "blocks.1.flows.1.", "final_flows.0.", "final_flows.1."))
+            or ".split." in k]
+    def summary(v):
+        """[first 64 values | sum | sum of squares | max abs] in fp64: a fixture of a few hundred bytes per tensor."""
+        f = v.detach().double().reshape(-1)
+        return np.concatenate([f[:64].numpy(), [float(f.sum()), float((f * f).sum()), float(f.abs().max())]])
+
+    g = {"bpd": n(loss), "keys": np.array(json.dumps(keys)), "pkeys": np.array(json.dumps(list(pnames)))}
+    for i, k in enumerate(keys):
+        g[f"g{i}"] = summary(names[k].grad)
+    for i, k in enumerate(pnames):
+        g[f"pg{i}"] = summary(pnames[k].grad)
+    g["sumsq_all"] = np.array(sum(float((p.grad.double() ** 2).sum()) for p in flow.parameters()))
+    torch.nn.utils.clip_grad_value_(flow.parameters(), 1)
+    total = torch.nn.utils.clip_grad_norm_(flow.parameters(), 1)
+    g["total_norm_after_value_clip"] = n(total)
+    for i, k in enumerate(keys):
+        g[f"c{i}"] = summary(names[k].grad)
+    opt.step()
+    for i, k in enumerate(keys):
+        g[f"p{i}"] = summary(names[k])
+    for i, k in enumerate(pnames):
+        g[f"pp{i}"] = summary(pnames[k])
+    g["meta"] = np.array(json.dumps({"C": C, "L": L, "K": K, "B": B, "seed": seed, "flow_spec": spec, "prior_spec": pspec}))
+    np.savez_compressed(os.path.join(OUT, "train_N.npz"), **g)
+    print(f"train_N.npz bpd={float(loss):.6f} total_norm={float(total):.4f} n_keys={len(keys)}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion", "vlb"]
+    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion", "vlb", "train"]
     if "ops" in which:
         gen_ops()
     if "glow" in which:
@@ -335,5 +384,7 @@ if __name__ == "__main__":
         gen_diffusion()
     if "vlb" in which:
         gen_vlb()
+    if "train" in which:
+        gen_train()
     leftovers = [r for r, dnames, _ in os.walk("/root/reference") if "__pycache__" in dnames]
     assert not leftovers, leftovers
