@@ -229,7 +229,7 @@ int nfdp_prior_kl_f32(const float* x_start, const float* sqrt_ac, const float* l
 /* ---------------------------------------------------------------- backward of the flow path (training step)
  * What torch autograd computes for loss.backward() in normalizing_flow/trainer.py:163-164, exact fp32. */
 /* Weight gradient of a stride-1 'same' conv (F.conv2d in utils.py:43, :67; the 1x1 conv of InvConv2d, transforms.py:132):
- * dw[o][ci][ky][kx] (OIHW) = sum_{b,y,x} dy[b,y,x,o] * x[b,y+ky-k/2,x+kx-k/2,ci], k in {1,3}.  x, dy: NHWC with pixel
+ * dw[o][ci][ky][kx] (OIHW) = sum_{b,y,x} dy[b,y,x,o] * x[b,y+ky-k/2,x+kx-k/2,ci], odd k <= 7.  x, dy: NHWC with pixel
  * strides x_ld, dy_ld.  ws: nfdp_conv_wgrad_ws_bytes(...) bytes of workspace. */
 size_t nfdp_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int k);
 int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout, int k,
@@ -263,6 +263,32 @@ size_t nfdp_fused_adam_ws_bytes(void);
 int nfdp_fused_adam_step_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int adamw, long step, void* ws,
                              float* norm_out, nfdp_stream_t stream);
+
+/* ---------------------------------------------------------------- backward of the U-Net glue ops (diffusion-prior training:
+ * loss.backward() of diffusion_prior/trainer.py:134-150 through GaussianDiffusion.p_losses); the convolutions use
+ * nfdp_conv_wgrad_f32 / nfdp_conv_flip_weights_f32 above. */
+/* Block (gaussian_diffusion.py:267-276): x = input of the GroupNorm, dy = gradient of the SiLU output; scale_shift [B,2C]
+ * (scale | shift, row stride ss_ld) nullable together with dscale_shift [B,2C] dense.  dgamma_b, dbeta_b: [B,C] per-sample
+ * partial sums (sum them over B with nfdp_scale_bwd_f32's column-sum mode). */
+int nfdp_groupnorm_silu_bwd_f32(const float* x, const float* dy, int B, int HW, int C, int groups, const float* gamma,
+                                const float* beta, const float* scale_shift, int ss_ld, float eps, float* dx, float* dgamma_b,
+                                float* dbeta_b, float* dscale_shift, nfdp_stream_t stream);
+/* channel LayerNorm, gain only (:205-209): dx and dgx[p][c] = dy * xhat (column-sum it for the gain gradient). */
+int nfdp_chan_layernorm_bwd_f32(const float* x, const float* dy, long npix, int C, const float* gain, float eps, float* dx,
+                                float* dgx, nfdp_stream_t stream);
+/* LinearAttention core (:320-332) and Attention core (:351-357): qkv [B,n,3*heads*32], dout [B,n,heads*32] -> dqkv; n <= 256. */
+int nfdp_linear_attention_bwd_f32(const float* qkv, const float* dout, float* dqkv, int B, int n, int heads, int dim_head,
+                                  float scale, nfdp_stream_t stream);
+int nfdp_attention_bwd_f32(const float* qkv, const float* dout, float* dqkv, int B, int n, int heads, int dim_head, float scale,
+                           nfdp_stream_t stream);
+/* nn.Upsample(scale_factor=2, mode='nearest') (:169-173): dy [B,2H,2W,C] -> dx [B,H,W,C] (sum of each 2x2 block). */
+int nfdp_upsample_nearest2x_bwd_f32(const float* dy, float* dx, int B, int C, int H, int W, nfdp_stream_t stream);
+/* act: 1 = nn.GELU() (erf form, :409), 2 = nn.SiLU() (:283).  Forward y = act(x); backward dx = dy * act'(x). */
+int nfdp_act_fwd_f32(const float* x, float* y, long n, int act, nfdp_stream_t stream);
+int nfdp_act_bwd_f32(const float* x, const float* dy, float* dx, long n, int act, nfdp_stream_t stream);
+/* Gradient of nfdp_diffusion_loss_f32 w.r.t. pred; grad_out: device fp32 scalar (upstream gradient of the loss). */
+int nfdp_diffusion_loss_bwd_f32(const float* pred, const float* target, const long* t, const float* p2_weight,
+                                const float* grad_out, int B, int per_sample, int l1, float* dpred, nfdp_stream_t stream);
 
 /* ---------------------------------------------------------------- NLL plumbing (normalizing_flow/utils.py) */
 /* out[0] = sum_b bpd_b, out[1] = B, with bpd_b = (log(n_bins)*n_pixel - (ldj_b+logp_b))*log2(e)/n_pixel

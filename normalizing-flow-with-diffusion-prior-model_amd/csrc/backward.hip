@@ -301,7 +301,7 @@ extern "C" size_t nfdp_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cou
 extern "C" int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout,
                                    int k, float* dw, void* ws, nfdp_stream_t stream) {
     NFDP_REQUIRE(x && dy && dw && ws, NFDP_EINVAL, "conv_wgrad: null pointer");
-    NFDP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (k == 1 || k == 3), NFDP_ESHAPE,
+    NFDP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 7 && (k & 1), NFDP_ESHAPE,
                  "conv_wgrad: bad shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d", B, H, W, Cin, Cout, k);
     NFDP_REQUIRE(x_ld >= Cin && dy_ld >= Cout, NFDP_ESHAPE, "conv_wgrad: pixel stride smaller than the channel count");
     WgradParams p;

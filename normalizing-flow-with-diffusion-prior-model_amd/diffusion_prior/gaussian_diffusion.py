@@ -7,7 +7,8 @@ identical.  Modules hold parameters in the reference's layouts; `forward` runs h
 tensors through the C ABI (convs: MFMA implicit GEMM with weight standardisation folded into the weight pack;
 GroupNorm+scale/shift+SiLU, channel LayerNorm(+residual), linear/full attention cores, time MLP, and the fused
 reverse-diffusion step with on-device schedule lookup are one launch each).  All randomness can be injected
-(`noise=` / `noises=`) for reproducible parity tests.
+(`noise=` / `noises=`) for reproducible parity tests.  With trainable parameters and grad mode on, `Unet.forward` and
+`p_losses` run the differentiable path of diffusion_prior/training.py (autograd Functions over HIP forward/backward kernels).
 
 Not built (raise NotImplementedError): objectives other than 'pred_noise', self-conditioning, learned / random
 sinusoidal embeddings, auto_normalize.
@@ -335,7 +336,8 @@ class Unet(nn.Module):
         if x_self_cond is not None:
             raise NotImplementedError("self-conditioning is not on the hot path")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("nfdp HIP path: backward kernels are not built yet; call under torch.no_grad()")
+            from . import training                     # differentiable exact-fp32 path (diffusion_prior/training.py)
+            return K.as_nchw(training.unet_forward(self, K.to_nhwc(x).contiguous(), time))
         return K.as_nchw(self.forward_nhwc(K.to_nhwc(x).contiguous(), time))
 
 
@@ -601,12 +603,13 @@ class GaussianDiffusion(nn.Module):
     def p_losses(self, x_start, t, noise=None):
         """mean_b(mean_chw(|eps_hat - eps|^p) * p2w[t])  (reference :823-859)."""
         kind = self.loss_fn
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
+            from . import training                     # differentiable path: autograd Functions over the HIP kernels
+            return training.p_losses(self, x_start, t, noise)
         noise = default(noise, lambda: torch.randn_like(x_start))
         x0h, nh = K.to_nhwc(x_start).contiguous(), K.to_nhwc(noise).contiguous()
         t = t.contiguous()
         xh = K.q_sample(x0h, nh, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
-            raise NotImplementedError("nfdp HIP path: backward kernels are not built yet; call under torch.no_grad()")
         out = self.model.forward_nhwc(xh, t)
         return K.diffusion_loss(out, nh, t, self.p2_loss_weight, l1=(kind == 'l1'))
 

@@ -729,3 +729,84 @@ def gauss_logp_bwd(zh, h, h_mode: int, gl: torch.Tensor):
     _call("nfdp_gauss_logp_bwd_f32", _ptr(zh), _ld(zh, "gauss_logp_bwd"), _ptr(h), h_mode, _ptr(gl), b, hh * ww, cz, _ptr(dz),
           _ptr(dh), _stream())
     return dz, dh
+
+
+# ----------------------------------------------------------------------------- backward of the U-Net glue ops
+def groupnorm_silu_bwd(xh, dyh, groups: int, gamma, beta, scale_shift, eps: float):
+    """-> (dx, dgamma [C], dbeta [C], dscale_shift [B,2C] or None)."""
+    _need(xh, torch.float32, "groupnorm_silu_bwd"); _dense(xh, "groupnorm_silu_bwd"); _dense(dyh, "groupnorm_silu_bwd")
+    b, h, w, c = xh.shape
+    dev = xh.device
+    dx = torch.empty_like(xh)
+    dg_b = torch.empty((b, c), device=dev, dtype=torch.float32)
+    db_b = torch.empty((b, c), device=dev, dtype=torch.float32)
+    dss = torch.empty((b, 2 * c), device=dev, dtype=torch.float32) if scale_shift is not None else None
+    ss_ld = 0
+    if scale_shift is not None:
+        if scale_shift.shape != (b, 2 * c) or scale_shift.stride(1) != 1:
+            raise ValueError("groupnorm_silu_bwd: scale_shift must be a [B, 2C] row-strided view")
+        ss_ld = scale_shift.stride(0)
+    _call("nfdp_groupnorm_silu_bwd_f32", _ptr(xh), _ptr(dyh), b, h * w, c, groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld,
+          float(eps), _ptr(dx), _ptr(dg_b), _ptr(db_b), _ptr(dss), _stream())
+    dgamma = scale_bwd(dg_b, want_dc=False)[2]                   # sum over the batch (fixed order)
+    dbeta = scale_bwd(db_b, want_dc=False)[2]
+    return dx, dgamma, dbeta, dss
+
+
+def chan_layernorm_bwd(xh, dyh, gain, eps: float = 1e-5):
+    """-> (dx, dgain [C])."""
+    _need(xh, torch.float32, "chan_layernorm_bwd"); _dense(xh, "chan_layernorm_bwd"); _dense(dyh, "chan_layernorm_bwd")
+    c = xh.shape[-1]
+    dx, dgx = torch.empty_like(xh), torch.empty_like(xh)
+    _call("nfdp_chan_layernorm_bwd_f32", _ptr(xh), _ptr(dyh), xh.numel() // c, c, _ptr(gain), float(eps), _ptr(dx), _ptr(dgx), _stream())
+    return dx, scale_bwd(dgx, want_dc=False)[2]
+
+
+def _attn_bwd(name, qkv, dout, heads, dim_head, scale):
+    _need(qkv, torch.float32, name); _dense(qkv, name); _dense(dout, name)
+    b, h, w, _ = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    _call(name, _ptr(qkv), _ptr(dout), _ptr(dqkv), b, h * w, heads, dim_head, float(scale), _stream())
+    return dqkv
+
+
+def linear_attention_bwd(qkv, dout, heads: int, dim_head: int, scale: float):
+    return _attn_bwd("nfdp_linear_attention_bwd_f32", qkv, dout, heads, dim_head, scale)
+
+
+def attention_bwd(qkv, dout, heads: int, dim_head: int, scale: float):
+    return _attn_bwd("nfdp_attention_bwd_f32", qkv, dout, heads, dim_head, scale)
+
+
+def upsample2x_bwd(dyh):
+    _need(dyh, torch.float32, "upsample2x_bwd"); _dense(dyh, "upsample2x_bwd")
+    b, h2, w2, c = dyh.shape
+    dx = torch.empty((b, h2 // 2, w2 // 2, c), device=dyh.device, dtype=torch.float32)
+    _call("nfdp_upsample_nearest2x_bwd_f32", _ptr(dyh), _ptr(dx), b, c, h2 // 2, w2 // 2, _stream())
+    return dx
+
+
+GELU, SILU = 1, 2
+
+
+def act_fwd(x, act: int):
+    _need(x, torch.float32, "act_fwd"); _dense(x, "act_fwd")
+    y = torch.empty_like(x)
+    _call("nfdp_act_fwd_f32", _ptr(x), _ptr(y), x.numel(), act, _stream())
+    return y
+
+
+def act_bwd(x, dy, act: int):
+    _need(x, torch.float32, "act_bwd"); _dense(x, "act_bwd"); _dense(dy, "act_bwd")
+    dx = torch.empty_like(x)
+    _call("nfdp_act_bwd_f32", _ptr(x), _ptr(dy), _ptr(dx), x.numel(), act, _stream())
+    return dx
+
+
+def diffusion_loss_bwd(pred, target, t, p2w, grad_out, l1: bool):
+    _dense(pred, "diffusion_loss_bwd"); _dense(target, "diffusion_loss_bwd")
+    b = pred.shape[0]
+    dp = torch.empty_like(pred)
+    _call("nfdp_diffusion_loss_bwd_f32", _ptr(pred), _ptr(target), _ptr(t), _ptr(p2w), _ptr(grad_out), b, pred.numel() // b, int(l1),
+          _ptr(dp), _stream())
+    return dp
