@@ -156,6 +156,21 @@ class ActFn(Function):
         return K.act_bwd(x, dy.contiguous(), ctx.act), None
 
 
+class QSampleFn(Function):
+    """x_t = sqrt(ac[t]) x_0 + sqrt(1 - ac[t]) eps (reference :806-812); gradient to x_0 only (eps is data)."""
+
+    @staticmethod
+    def forward(ctx, x0h, nh, t, sqrt_ac, sqrt_1mac):
+        ctx.save_for_backward(t, sqrt_ac)
+        return K.q_sample(x0h.contiguous(), nh, t, sqrt_ac, sqrt_1mac)
+
+    @staticmethod
+    def backward(ctx, dy):
+        t, sqrt_ac = ctx.saved_tensors
+        dy = dy.contiguous()
+        return K.q_sample(dy, dy, t, sqrt_ac, torch.zeros_like(sqrt_ac)), None, None, None, None   # sqrt(ac[t]) * dy
+
+
 class DiffusionLossFn(Function):
     """mean_b( mean_chw(|pred - target|^p) * p2w[t_b] ) (reference p_losses :855-859)."""
 
@@ -244,13 +259,15 @@ def unet_forward(unet, xh: Tensor, time: Tensor) -> Tensor:
 
 
 def p_losses(diffusion, x_start: Tensor, t: Tensor, noise: Optional[Tensor] = None) -> Tensor:
-    """GaussianDiffusion.p_losses with a gradient graph (reference :823-859; objective pred_noise).  The noised sample is
-    built by the q_sample kernel (no gradient flows into x_start: the flow is the frozen encoder of trainer.py:134-141)."""
-    if x_start.requires_grad:
-        raise NotImplementedError("nfdp HIP path: gradients w.r.t. the latents (unfrozen flow inside the prior's loss) are not built")
+    """GaussianDiffusion.p_losses with a gradient graph (reference :823-859; objective pred_noise).  When the latents carry
+    a graph themselves (unfrozen flow, trainer.py:139-141) the gradient flows back into them through q_sample and the
+    U-Net's first convolution."""
     noise = torch.randn_like(x_start) if noise is None else noise
-    x0h, nh = K.to_nhwc(x_start).contiguous(), K.to_nhwc(noise).contiguous()
+    x0h, nh = K.to_nhwc(x_start), K.to_nhwc(noise.detach()).contiguous()
     t = t.contiguous()
-    xh = K.q_sample(x0h, nh, t, diffusion.sqrt_alphas_cumprod, diffusion.sqrt_one_minus_alphas_cumprod)
+    if x_start.requires_grad:
+        xh = QSampleFn.apply(x0h, nh, t, diffusion.sqrt_alphas_cumprod, diffusion.sqrt_one_minus_alphas_cumprod)
+    else:
+        xh = K.q_sample(x0h.contiguous(), nh, t, diffusion.sqrt_alphas_cumprod, diffusion.sqrt_one_minus_alphas_cumprod)
     out = unet_forward(diffusion.model, xh, t)
     return DiffusionLossFn.apply(out, nh, t, diffusion.p2_loss_weight, diffusion.loss_fn == "l1")

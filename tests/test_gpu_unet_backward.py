@@ -198,3 +198,54 @@ def test_diffusion_prior_training_step_runs():
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses))
     assert np.mean(losses[-4:]) < np.mean(losses[:4]), losses
+
+
+def test_joint_training_gradient_reaches_the_flow():
+    """Unfrozen flow (diffusion_prior/trainer.py:139-141): loss = sum of the prior's part losses + 0.5 * bits/dim; the
+    prior's loss must propagate through q_sample and the U-Net input into the flow's parameters.  Checked against autograd
+    through the oracles on the same weights, inputs, timesteps and noise."""
+    from oracle import nf_oracle as O
+    from normalizing_flow import NFBackbone, initialize_with_zeros, calculate_loss
+    from diffusion_prior import Unet, GaussianDiffusion
+    from tests.golden.synth import synth_tensor
+    nf = NFBackbone(model_dir="", in_channel=1, L=2, K=1, learn_prior_mean_logs=True, freeze_flow=False, compute="f32")
+    fsd = {k: T(synth_tensor(k, v.shape, 61)) for k, v in nf.model.state_dict().items()}
+    nf.model.load_state_dict(fsd)
+    nf.to(DEV)
+    u = Unet(dim=32, dim_mults=(1, 2), channels=8, resnet_block_groups=8, compute="f32")
+    usd = {k: T(synth_tensor(k, v.shape, 62)) for k, v in u.state_dict().items()}
+    u.load_state_dict(usd)
+    d = GaussianDiffusion(u.to(DEV), image_size=4, timesteps=100, beta_schedule="cosine", loss_type="l2",
+                          auto_normalize=False).to(DEV)
+    B = 2
+    x = rnd(B, 1, 16, 16, seed=63, scale=0.3)
+    eps = rnd(B, 8, 4, 4, seed=64)
+    t = torch.tensor([3, 77])
+    # oracle: last latent part of the L=2 flow (8 x 4 x 4) into the prior's loss, plus 0.5 * bpd of the flow alone
+    fo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in fsd.items()}
+    uo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in usd.items()}
+    zs, ldj, _ = O.glow_fwd(x, fo, 2, 1, torch.zeros(B, dtype=torch.float64), None)
+    buf = D.diffusion_buffers("cosine", 100)
+    model = lambda xx, tt: D.unet_forward(xx, tt, uo, 32, [1, 2], 8)
+    loss_ref = D.p_losses(buf, model, zs[-1], t, eps, "l2") + 0.5 * O.bits_per_dim(ldj, 32.0, 16 * 16 * 3.0)
+    loss_ref.backward()
+    # HIP
+    nf.set_train_mode()
+    u.train()
+    lat, ll = nf.transform(x.to(DEV), initialize_with_zeros(1, B, torch.device(DEV)))
+    assert lat[-1].requires_grad
+    loss = d.p_losses(lat[-1], t.to(DEV), noise=eps.to(DEV)) + 0.5 * calculate_loss(ll, 32.0, 16 * 16 * 3.0)
+    assert_close(loss, loss_ref.detach(), 1e-5, "joint loss")
+    loss.backward()
+    n_checked = 0
+    for k, p in nf.model.named_parameters():
+        if fo[k].grad is None:                      # Split priors are skipped on the NFBackbone path (logp=None): no gradient
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, k
+        if float(fo[k].grad.abs().max()) > 0:
+            assert relerr(p.grad, fo[k].grad) <= 2e-4, f"flow grad {k}: {relerr(p.grad, fo[k].grad):.3e}"
+            n_checked += 1
+    assert n_checked >= 10
+    for k, p in u.named_parameters():
+        assert relerr(p.grad, uo[k].grad) <= 2e-4, f"unet grad {k}"
