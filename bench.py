@@ -123,7 +123,7 @@ def train_bench(args, rank, world, device, barrier):
     from nfdp_hip.optim import FusedAdam
     from nfdp_hip.dist import BucketedGradAllReduce, max_over_ranks
     from normalizing_flow import calculate_loss, initialize_with_zeros
-    flow, prior, _, _ = build_models(args.L, args.K, "f32", device)
+    flow, prior, _, _ = build_models(args.L, args.K, args.compute, device)
     _, _, u8_d, noise_d = make_batch(args.batch, rank, device)
     params = list(flow.parameters()) + list(prior.parameters())
     opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-4, clip_value=1, max_norm=1)
@@ -157,7 +157,7 @@ def train_bench(args, rank, world, device, barrier):
             "metric": f"images/sec, Glow L{args.L}K{args.K} 32x32x3 training step", "value": round(args.batch * world * args.steps / elapsed, 1),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": args.compute, "data": "synthetic",
             "config": {"workload": f"Glow L={args.L} K={args.K} training step on 32x32x3, 5-bit, batch={args.batch}/GPU "
                                    "(BASELINE configs[2] shape; forward, bits/dim, backward, clip_grad_value_/norm_ 1, Adam lr 1e-4 - the synthetic trained-like weights diverge at the reference's 1e-3)",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
@@ -178,8 +178,8 @@ def main():
     ap.add_argument("--K", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--train", action="store_true",
-                    help="time the TRAINING step instead (BASELINE configs[2]: trainer.py:152-167 body, exact-fp32 HIP "
-                         "training path, fused clip+Adam, bucketed RCCL gradient all-reduce for N>1); not the headline metric")
+                    help="time the TRAINING step instead (BASELINE configs[2]: trainer.py:152-167 body, HIP training path in the "
+                         "--compute mode (fp32 activations), fused clip+Adam, bucketed RCCL gradient all-reduce for N>1); not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

@@ -234,6 +234,13 @@ int nfdp_prior_kl_f32(const float* x_start, const float* sqrt_ac, const float* l
 size_t nfdp_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int k);
 int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout, int k,
                         float* dw, void* ws, nfdp_stream_t stream);
+/* The same weight gradient with bf16 MFMA (operands rounded to bf16, fp32 accumulation): fp32 tiles are converted and
+ * transposed on their way into LDS.  Needs Cin % 4 == 0, Cout % 4 == 0, 16-byte aligned operands with pixel strides that are
+ * multiples of 4 (nfdp_conv_wgrad_bf16_supported); otherwise use nfdp_conv_wgrad_f32. */
+int nfdp_conv_wgrad_bf16_supported(int Cin, int Cout);
+size_t nfdp_conv_wgrad_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int k);
+int nfdp_conv_wgrad_bf16(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout, int k,
+                         float* dw, void* ws, nfdp_stream_t stream);
 /* wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: nfdp_conv2d_nhwc on pack(wt) is the data gradient of the conv with w. */
 int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int I, int k, nfdp_stream_t stream);
 /* Backward of y = act((u + add) * exp(f*mul)), act = ReLU (relu=1) or identity - ActNorm (transforms.py:80; f=1),

@@ -72,20 +72,27 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgradParams p) {
 
     const long p_begin = (long)ks * p.px_per_split;
     const long p_end = (p_begin + p.px_per_split) < p.npix ? (p_begin + p.px_per_split) : p.npix;
+    const bool pointwise = p.k == 1;                          // 1x1: no taps, no pixel decomposition (64-bit div/mod per step)
+#pragma unroll 4                                             // loads of several k-steps in flight (small tiles are latency-bound)
     for (long p0 = p_begin; p0 < p_end; p0 += 2) {
         const long px = p0 + kk;
         const bool pv = px < p_end;
-        const long b = px / HW;
-        const int r = (int)(px - b * HW);
-        const int y = r / p.W, xx = r - y * p.W;
         float a[MT], bv[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) a[i] = (pv && m_ok[i]) ? p.dy[px * p.dy_ld + m_idx[i]] : 0.f;
+        if (pointwise) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int yy = y + n_dy[j], xc = xx + n_dx[j];
-            const bool ok = pv && n_ok[j] && (unsigned)yy < (unsigned)p.H && (unsigned)xc < (unsigned)p.W;
-            bv[j] = ok ? p.x[((b * p.H + yy) * p.W + xc) * p.x_ld + n_ci[j]] : 0.f;
+            for (int j = 0; j < NT; ++j) bv[j] = (pv && n_ok[j]) ? p.x[px * p.x_ld + n_ci[j]] : 0.f;
+        } else {
+            const long b = px / HW;
+            const int r = (int)(px - b * HW);
+            const int y = r / p.W, xx = r - y * p.W;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int yy = y + n_dy[j], xc = xx + n_dx[j];
+                const bool ok = pv && n_ok[j] && (unsigned)yy < (unsigned)p.H && (unsigned)xc < (unsigned)p.W;
+                bv[j] = ok ? p.x[((b * p.H + yy) * p.W + xc) * p.x_ld + n_ci[j]] : 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -160,21 +167,37 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_kernel(const float* __restri
             const int c = cb + q * CT + tx;
             fac[q] = (mul != nullptr && c < C) ? expf(__fmul_rn(f, mul[c])) : 1.0f;
         }
-        for (long r = r0 + ty; r < r1; r += RT) {
+        // 4 rows per trip, all loads first: one row at a time leaves a single pair of 4-byte loads in flight per thread
+        constexpr int UR = 4;
+        for (long rb = r0 + ty; rb < r1; rb += (long)RT * UR) {
+            float gv[UR][MAXC], yv[UR][MAXC];
 #pragma unroll
-            for (int q = 0; q < MAXC; ++q) {
-                const int c = cb + q * CT + tx;
-                if (c < C) {
-                    float g = dy[r * dy_ld + c];
-                    float yv = 0.f;
-                    if (y != nullptr) {
-                        yv = y[r * y_ld + c];
-                        if (relu && !(yv > 0.f)) g = 0.f;
-                        s_mul[q] += (double)__fmul_rn(g, yv);
+            for (int u = 0; u < UR; ++u) {
+                const long r = rb + (long)u * RT;
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q) {
+                    const int c = cb + q * CT + tx;
+                    const bool ok = r < r1 && c < C;
+                    gv[u][q] = ok ? dy[r * dy_ld + c] : 0.f;
+                    yv[u][q] = (ok && y != nullptr) ? y[r * y_ld + c] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UR; ++u) {
+                const long r = rb + (long)u * RT;
+#pragma unroll
+                for (int q = 0; q < MAXC; ++q) {
+                    const int c = cb + q * CT + tx;
+                    if (r < r1 && c < C) {
+                        float g = gv[u][q];
+                        if (y != nullptr) {
+                            if (relu && !(yv[u][q] > 0.f)) g = 0.f;
+                            s_mul[q] += (double)__fmul_rn(g, yv[u][q]);
+                        }
+                        const float d = __fmul_rn(g, fac[q]);
+                        if (dc != nullptr) dc[r * dc_ld + c] = d;
+                        s_add[q] += (double)d;
                     }
-                    const float d = __fmul_rn(g, fac[q]);
-                    if (dc != nullptr) dc[r * dc_ld + c] = d;
-                    s_add[q] += (double)d;
                 }
             }
         }
@@ -195,17 +218,28 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_kernel(const float* __restri
     }
 }
 
-__global__ void scale_bwd_finish_kernel(const double* __restrict__ part, int nblk, int C, float f, float* __restrict__ dmul,
-                                        float* __restrict__ dadd) {
-    const int c = blockIdx.x * kBlock + threadIdx.x;
-    if (c >= C) return;
+// One workgroup per 32 channels: 8 lanes of partials per channel (lane g takes blocks g, g+8, ...), combined in lane order.
+// (With one thread per channel the whole partial buffer - tens of MB for C = 512 - went through C/256 = 2 CUs.)
+__global__ void __launch_bounds__(kBlock) scale_bwd_finish_kernel(const double* __restrict__ part, int nblk, int C, float f,
+                                                                 float* __restrict__ dmul, float* __restrict__ dadd) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double a = 0.0, b = 0.0;
-    for (int q = 0; q < nblk; ++q) {
-        a += part[((size_t)q * 2 + 0) * C + c];
-        b += part[((size_t)q * 2 + 1) * C + c];
+    if (c < C)
+        for (int q = g; q < nblk; q += 8) {
+            a += part[((size_t)q * 2 + 0) * C + c];
+            b += part[((size_t)q * 2 + 1) * C + c];
+        }
+    red[0][g][cl] = a;
+    red[1][g][cl] = b;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        double sa = 0.0, sb = 0.0;
+        for (int t = 0; t < 8; ++t) { sa += red[0][t][cl]; sb += red[1][t][cl]; }
+        if (dmul) dmul[c] = (float)(sa * (double)f);
+        if (dadd) dadd[c] = (float)sb;
     }
-    if (dmul) dmul[c] = (float)(a * (double)f);
-    if (dadd) dadd[c] = (float)b;
 }
 
 // ----------------------------------------------------------------------------- coupling backward
@@ -256,6 +290,120 @@ __global__ void gauss_logp_bwd_kernel(const float* __restrict__ z, int z_ld, con
         dh[pxl * 2 * Cz + c] = __fmul_rn(g, de);
         dh[pxl * 2 * Cz + Cz + c] = __fmul_rn(g, __fadd_rn(-1.0f, __fmul_rn(d, de)));
     }
+}
+
+// ----------------------------------------------------------------------------- conv weight gradient, bf16 MFMA
+// Same GEMM (reduction over pixels), operands rounded to bf16, fp32 accumulation: v_mfma_f32_32x32x16_bf16 wants 8
+// consecutive k (= pixels) per lane for one row/column (= channel), i.e. the TRANSPOSE of the NHWC tiles.  The fp32 tiles
+// are read with coalesced float4 loads (4 channels of one pixel), converted, and written to LDS transposed
+// ([channel][pixel], 16-bit scalar stores), so both MFMA operands are plain ds_read_b128.  A workgroup owns a 128 x 128
+// block of dW and a slice of the pixels (32 per stage, register-staged double buffering); 4 waves as 2 x 2, each 2 x 2
+// accumulator tiles.  Requires Cin % 4 == 0 (the 4 values of a float4 of the im2col row share a tap).
+constexpr int WB_BM = 128, WB_BN = 128, WB_KC = 32, WB_LD = WB_KC + 8;     // LDS row stride in bf16 elements (80 B)
+
+__global__ void __launch_bounds__(kBlock) wgrad_bf16_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) __bf16 At[2][WB_BM][WB_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 Bt[2][WB_BN][WB_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    const int nb = bid % p.nblocks; bid /= p.nblocks;
+    const int mb = bid % p.mblocks;
+    const int ks = bid / p.mblocks;
+    const int pad = p.k >> 1, HW = p.H * p.W;
+    const long p_begin = (long)ks * p.px_per_split;
+    const long p_end = (p_begin + p.px_per_split) < p.npix ? (p_begin + p.px_per_split) : p.npix;
+
+    // this thread's 4 float4 of each operand tile: element e = (tid + 256 i) * 4 -> pixel e / 128, channel e % 128
+    int a_m[4], b_ci[4], b_dy[4], b_dx[4];
+    bool a_ok[4], b_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c0 = ((tid + kBlock * i) * 4) % WB_BM;
+        a_m[i] = mb * WB_BM + c0;
+        a_ok[i] = a_m[i] < p.Cout;                          // Cout % 4 == 0 is required: the float4 is in or out as a whole
+        const int n = nb * WB_BN + c0;
+        b_ok[i] = n < p.N;
+        const int tap = b_ok[i] ? n / p.Cin : 0;
+        b_ci[i] = b_ok[i] ? n % p.Cin : 0;
+        b_dy[i] = tap / p.k - pad;
+        b_dx[i] = tap % p.k - pad;
+    }
+    float4 ra[4], rb[4];
+    auto load_stage = [&](long p0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px_l = ((tid + kBlock * i) * 4) / WB_BM;             // 0..31
+            const long px = p0 + px_l;
+            const bool pv = px < p_end;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pv && a_ok[i]) ra[i] = *reinterpret_cast<const float4*>(p.dy + px * p.dy_ld + a_m[i]);
+            if (pv && b_ok[i]) {
+                const long b = px / HW;
+                const int r = (int)(px - b * HW);
+                const int y = r / p.W + b_dy[i], xx = r % p.W + b_dx[i];
+                if ((unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
+                    rb[i] = *reinterpret_cast<const float4*>(p.x + ((b * p.H + y) * p.W + xx) * p.x_ld + b_ci[i]);
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = (tid + kBlock * i) * 4;
+            const int px_l = e / WB_BM, c0 = e % WB_BM;
+            At[buf][c0 + 0][px_l] = (__bf16)ra[i].x; At[buf][c0 + 1][px_l] = (__bf16)ra[i].y;
+            At[buf][c0 + 2][px_l] = (__bf16)ra[i].z; At[buf][c0 + 3][px_l] = (__bf16)ra[i].w;
+            Bt[buf][c0 + 0][px_l] = (__bf16)rb[i].x; Bt[buf][c0 + 1][px_l] = (__bf16)rb[i].y;
+            Bt[buf][c0 + 2][px_l] = (__bf16)rb[i].z; Bt[buf][c0 + 3][px_l] = (__bf16)rb[i].w;
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int c32 = lane & 31, g = lane >> 5;
+    load_stage(p_begin);
+    store_stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (long p0 = p_begin; p0 < p_end; p0 += WB_KC) {
+        const bool more = p0 + WB_KC < p_end;
+        if (more) load_stage(p0 + WB_KC);                  // global loads of the next stage fly under the MFMAs
+#pragma unroll
+        for (int kstep = 0; kstep < WB_KC / 16; ++kstep) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(&At[buf][wm * 64 + i * 32 + c32][kstep * 16 + 8 * g]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(&Bt[buf][wn * 64 + j * 32 + c32][kstep * 16 + 8 * g]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* out = p.ws + (size_t)ks * p.Mpad * p.Npad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb * WB_BM + wm * 64 + i * 32 + drow32(r, g);
+                const int n = nb * WB_BN + wn * 64 + j * 32 + c32;
+                out[(size_t)m * p.Npad + n] = acc[i][j][r];
+            }
 }
 
 template <int MT, int NT>
@@ -337,8 +485,8 @@ extern "C" int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int 
 }
 
 static int scale_bwd_blocks(long npix) {
-    long g = cdiv(npix, 64);
-    if (g > 1024) g = 1024;
+    long g = cdiv(npix, 32);
+    if (g > 2048) g = 2048;
     if (g < 1) g = 1;
     return (int)g;
 }
@@ -364,7 +512,7 @@ extern "C" int nfdp_scale_bwd_f32(const float* dy, int dy_ld, const float* y, in
     else
         hipLaunchKernelGGL((scale_bwd_kernel<16>), dim3(nblk), dim3(kBlock), 0, s, dy, dy_ld, y, y_ld, mul, f, relu, npix, C, dc,
                            dc_ld, part, rows);
-    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, kBlock)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
+    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 32)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
     NFDP_CHECK_LAUNCH("scale_bwd");
     return NFDP_OK;
 }
@@ -395,5 +543,52 @@ extern "C" int nfdp_gauss_logp_bwd_f32(const float* z, int z_ld, const float* h,
         hipLaunchKernelGGL((gauss_logp_bwd_kernel<1>), dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, as_stream(stream), z,
                            z_ld, h, gl, total, HW, Cz, dz, dh);
     NFDP_CHECK_LAUNCH("gauss_logp_bwd");
+    return NFDP_OK;
+}
+
+static void wgrad_bf16_plan(int B, int H, int W, int Cin, int Cout, int k, WgradParams* p) {
+    p->N = k * k * Cin;
+    p->mblocks = (int)cdiv(Cout, WB_BM);
+    p->nblocks = (int)cdiv(p->N, WB_BN);
+    p->Mpad = p->mblocks * WB_BM;
+    p->Npad = p->nblocks * WB_BN;
+    p->npix = (long)B * H * W;
+    long want = 1024 / ((long)p->mblocks * p->nblocks);     // ~4 workgroups per CU
+    if (want < 1) want = 1;
+    if (want > 256) want = 256;
+    long per = cdiv(p->npix, want);
+    per = cdiv(per, WB_KC) * WB_KC;
+    if (per < 4 * WB_KC) per = 4 * WB_KC;
+    p->px_per_split = per;
+    p->ksplit = (int)cdiv(p->npix, per);
+}
+
+extern "C" int nfdp_conv_wgrad_bf16_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 4 == 0; }
+
+extern "C" size_t nfdp_conv_wgrad_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int k) {
+    WgradParams p;
+    wgrad_bf16_plan(B, H, W, Cin, Cout, k, &p);
+    return (size_t)p.ksplit * p.Mpad * p.Npad * sizeof(float);
+}
+
+extern "C" int nfdp_conv_wgrad_bf16(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout,
+                                    int k, float* dw, void* ws, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && dy && dw && ws, NFDP_EINVAL, "conv_wgrad_bf16: null pointer");
+    NFDP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 7 && (k & 1), NFDP_ESHAPE,
+                 "conv_wgrad_bf16: bad shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d", B, H, W, Cin, Cout, k);
+    NFDP_REQUIRE(nfdp_conv_wgrad_bf16_supported(Cin, Cout), NFDP_EUNSUPPORTED,
+                 "conv_wgrad_bf16: Cin=%d and Cout=%d must be multiples of 4 (use nfdp_conv_wgrad_f32)", Cin, Cout);
+    NFDP_REQUIRE(x_ld >= Cin && dy_ld >= Cout && x_ld % 4 == 0 && dy_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
+                 NFDP_ESHAPE, "conv_wgrad_bf16: operands must be 16-byte aligned with pixel strides that are multiples of 4");
+    WgradParams p;
+    wgrad_bf16_plan(B, H, W, Cin, Cout, k, &p);
+    p.x = x; p.dy = dy; p.ws = reinterpret_cast<float*>(ws);
+    p.x_ld = x_ld; p.dy_ld = dy_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.k = k;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.mblocks * p.nblocks * p.ksplit), dim3(kBlock), 0, s, p);
+    const long total = (long)Cout * Cin * k * k;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, s, p.ws, dw, p.ksplit, p.Mpad,
+                       p.Npad, Cout, Cin, k);
+    NFDP_CHECK_LAUNCH("conv_wgrad_bf16");
     return NFDP_OK;
 }

@@ -20,14 +20,15 @@ from normalizing_flow.training import SqueezeFn, grad_needed   # noqa: F401  (re
 
 # ----------------------------------------------------------------------------- Functions
 class ConvFn(Function):
-    """y = conv2d(x, W, padding=k//2) + bias on NHWC tensors (nn.Conv2d / WeightStandardizedConv2d / nn.Linear as 1x1)."""
+    """y = conv2d(x, W, padding=k//2) + bias on NHWC tensors (nn.Conv2d / WeightStandardizedConv2d / nn.Linear as 1x1);
+    `compute` (K.F32 | K.BF16) applies to the forward, data-gradient and weight-gradient GEMMs."""
 
     @staticmethod
-    def forward(ctx, xh, weight, bias, k):
-        y = K.conv2d(xh, K.conv_pack(weight.detach().contiguous(), K.F32), weight.shape[0], k,
-                     add=None if bias is None else bias.detach(), compute=K.F32, out_dtype=K.F32)
+    def forward(ctx, xh, weight, bias, k, compute):
+        y = K.conv2d(xh, K.conv_pack(weight.detach().contiguous(), compute), weight.shape[0], k,
+                     add=None if bias is None else bias.detach(), compute=compute, out_dtype=K.F32)
         ctx.save_for_backward(xh, weight)
-        ctx.k, ctx.has_bias = int(k), bias is not None
+        ctx.k, ctx.has_bias, ctx.compute = int(k), bias is not None, compute
         return y
 
     @staticmethod
@@ -37,10 +38,10 @@ class ConvFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wt = K.conv_flip_weights(weight.detach().contiguous())
-            dx = K.conv2d(dy, K.conv_pack(wt, K.F32), weight.shape[1], ctx.k, compute=K.F32, out_dtype=K.F32)
-        dw = K.conv_wgrad(xh, dy, ctx.k)
+            dx = K.conv2d(dy, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute, out_dtype=K.F32)
+        dw = K.conv_wgrad(xh, dy, ctx.k, compute=ctx.compute)
         db = K.scale_bwd(dy, want_dc=False)[2] if ctx.has_bias else None
-        return dx, dw, db, None
+        return dx, dw, db, None, None
 
 
 class GroupNormSiLUFn(Function):
@@ -188,74 +189,76 @@ class DiffusionLossFn(Function):
 
 
 # ----------------------------------------------------------------------------- module walkers
-def _conv(mod, xh: Tensor) -> Tensor:
+def _conv(mod, xh: Tensor, c: int = K.F32) -> Tensor:
     """_Conv / WeightStandardizedConv2d; the standardisation (reference :189-195, eps 1e-5) is weight-sized torch glue."""
     w = mod.weight
     if mod.standardize:
         mean = w.mean(dim=(1, 2, 3), keepdim=True)
         var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
         w = (w - mean) * (var + 1e-5).rsqrt()
-    return ConvFn.apply(xh, w, mod.bias, mod.k)
+    return ConvFn.apply(xh, w, mod.bias, mod.k, c)
 
 
 def _linear(mod, x: Tensor) -> Tensor:
     """nn.Linear on [B, I] as a 1x1 convolution of a [B,1,1,I] image (same kernels, same gradients)."""
     b = x.shape[0]
-    y = ConvFn.apply(x.reshape(b, 1, 1, -1), mod.weight.reshape(mod.weight.shape[0], mod.weight.shape[1], 1, 1), mod.bias, 1)
+    y = ConvFn.apply(x.reshape(b, 1, 1, -1), mod.weight.reshape(mod.weight.shape[0], mod.weight.shape[1], 1, 1), mod.bias, 1, K.F32)
     return y.reshape(b, -1)
 
 
-def _block(blk, xh: Tensor, scale_shift: Optional[Tensor]) -> Tensor:
-    return GroupNormSiLUFn.apply(_conv(blk.proj, xh), blk.norm.weight, blk.norm.bias, scale_shift, blk.norm.num_groups)
+def _block(blk, xh: Tensor, scale_shift: Optional[Tensor], c: int) -> Tensor:
+    return GroupNormSiLUFn.apply(_conv(blk.proj, xh, c), blk.norm.weight, blk.norm.bias, scale_shift, blk.norm.num_groups)
 
 
-def _resnet_block(rb, xh: Tensor, t_act: Tensor) -> Tensor:
+def _resnet_block(rb, xh: Tensor, t_act: Tensor, c: int) -> Tensor:
     """(reference :290-302); t_act = SiLU(time embedding), shared by every block."""
     ss = _linear(rb.mlp[1], t_act) if rb.mlp is not None else None
-    h = _block(rb.block1, xh, ss)
-    h = _block(rb.block2, h, None)
-    res = _conv(rb.res_conv, xh) if not isinstance(rb.res_conv, nn.Identity) else xh
+    h = _block(rb.block1, xh, ss, c)
+    h = _block(rb.block2, h, None, c)
+    res = _conv(rb.res_conv, xh, c) if not isinstance(rb.res_conv, nn.Identity) else xh
     return AddFn.apply(h, res)
 
 
-def _attn_block(res, xh: Tensor) -> Tensor:
+def _attn_block(res, xh: Tensor, c: int) -> Tensor:
     from .gaussian_diffusion import LinearAttention
     pre = res.fn
     att = pre.fn
     xn = ChanLayerNormFn.apply(xh, pre.norm.g, None)
-    qkv = _conv(att.to_qkv, xn)
+    qkv = _conv(att.to_qkv, xn, c)
     if isinstance(att, LinearAttention):
         a = LinearAttentionFn.apply(qkv, att.heads, att.dim_head, att.scale)
-        return ChanLayerNormFn.apply(_conv(att.to_out[0], a), att.to_out[1].g, xh)        # LayerNorm(to_out conv) + x
+        return ChanLayerNormFn.apply(_conv(att.to_out[0], a, c), att.to_out[1].g, xh)        # LayerNorm(to_out conv) + x
     a = AttentionFn.apply(qkv, att.heads, att.dim_head, att.scale)
-    return AddFn.apply(_conv(att.to_out, a), xh)
+    return AddFn.apply(_conv(att.to_out, a, c), xh)
 
 
 def unet_forward(unet, xh: Tensor, time: Tensor) -> Tensor:
-    """Unet.forward with a gradient graph (reference :451-490); NHWC in, NHWC out."""
-    x = _conv(unet.init_conv, xh)
+    """Unet.forward with a gradient graph (reference :451-490); NHWC in, NHWC out.  The U-Net's compute mode applies to its
+    convolutions; the small time-MLP linears stay exact fp32."""
+    c = K.compute_enum(unet.compute)
+    x = _conv(unet.init_conv, xh, c)
     r = x
     e = K.sinusoidal_emb(time.long(), unet.dim)
     e = ActFn.apply(_linear(unet.time_mlp[1], e), K.GELU)
     t_act = ActFn.apply(_linear(unet.time_mlp[3], e), K.SILU)            # the SiLU every ResnetBlock.mlp starts with
     hs = []
     for block1, block2, attn, downsample in unet.downs:
-        x = _resnet_block(block1, x, t_act)
+        x = _resnet_block(block1, x, t_act, c)
         hs.append(x)
-        x = _resnet_block(block2, x, t_act)
-        x = _attn_block(attn, x)
+        x = _resnet_block(block2, x, t_act, c)
+        x = _attn_block(attn, x, c)
         hs.append(x)
-        x = _conv(downsample[1], SqueezeFn.apply(x)) if isinstance(downsample, nn.Sequential) else _conv(downsample, x)
-    x = _resnet_block(unet.mid_block1, x, t_act)
-    x = _attn_block(unet.mid_attn, x)
-    x = _resnet_block(unet.mid_block2, x, t_act)
+        x = _conv(downsample[1], SqueezeFn.apply(x), c) if isinstance(downsample, nn.Sequential) else _conv(downsample, x, c)
+    x = _resnet_block(unet.mid_block1, x, t_act, c)
+    x = _attn_block(unet.mid_attn, x, c)
+    x = _resnet_block(unet.mid_block2, x, t_act, c)
     for block1, block2, attn, upsample in unet.ups:
-        x = _resnet_block(block1, ConcatFn.apply(x, hs.pop()), t_act)
-        x = _resnet_block(block2, ConcatFn.apply(x, hs.pop()), t_act)
-        x = _attn_block(attn, x)
-        x = _conv(upsample[1], UpsampleFn.apply(x)) if isinstance(upsample, nn.Sequential) else _conv(upsample, x)
-    x = _resnet_block(unet.final_res_block, ConcatFn.apply(x, r), t_act)
-    return _conv(unet.final_conv, x)
+        x = _resnet_block(block1, ConcatFn.apply(x, hs.pop()), t_act, c)
+        x = _resnet_block(block2, ConcatFn.apply(x, hs.pop()), t_act, c)
+        x = _attn_block(attn, x, c)
+        x = _conv(upsample[1], UpsampleFn.apply(x), c) if isinstance(upsample, nn.Sequential) else _conv(upsample, x, c)
+    x = _resnet_block(unet.final_res_block, ConcatFn.apply(x, r), t_act, c)
+    return _conv(unet.final_conv, x, c)
 
 
 def p_losses(diffusion, x_start: Tensor, t: Tensor, noise: Optional[Tensor] = None) -> Tensor:

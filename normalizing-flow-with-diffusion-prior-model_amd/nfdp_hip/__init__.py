@@ -664,14 +664,26 @@ def prior_kl(x_start, sqrt_ac, log_one_minus_ac, t_index: int) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- backward (training step)
-def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int) -> torch.Tensor:
-    """-> dw [Cout,Cin,k,k] fp32 of a stride-1 'same' conv; xh, dyh pixel-strided NHWC fp32."""
+def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int, compute: int = F32) -> torch.Tensor:
+    """-> dw [Cout,Cin,k,k] fp32 of a stride-1 'same' conv; xh, dyh pixel-strided NHWC fp32.  compute=BF16 runs the bf16-MFMA
+    kernel where its alignment rules allow (channel counts and pixel strides multiples of 4), else the exact-fp32 one."""
     _need(xh, torch.float32, "conv_wgrad"); _need(dyh, torch.float32, "conv_wgrad")
     b, h, w, cin = xh.shape
     cout = dyh.shape[-1]
     if tuple(dyh.shape[:3]) != (b, h, w):
         raise ValueError(f"conv_wgrad: shape mismatch {tuple(xh.shape)} / {tuple(dyh.shape)}")
+    if compute == BF16 and k > 1 and cout * 4 <= cin and cin % 4 == 0 and cout % 4 == 0 and cout * k * k <= 512:
+        # narrow output (ZeroConv2d 512 -> C): gather the k*k taps over the NARROW tensor instead, so the wide one is read
+        # once instead of k*k times:  dW[o][i][ky][kx] = W'[i][o][k-1-ky][k-1-kx]  with  W' = wgrad(x := dy, dy := x)
+        return conv_flip_weights(conv_wgrad(dyh, xh, k, compute=compute))
     dw = torch.empty((cout, cin, k, k), device=xh.device, dtype=torch.float32)
+    if compute == BF16 and cin % 4 == 0 and cout % 4 == 0:
+        xl, dl = _ld(xh, "conv_wgrad"), _ld(dyh, "conv_wgrad")
+        if xl % 4 == 0 and dl % 4 == 0 and xh.data_ptr() % 16 == 0 and dyh.data_ptr() % 16 == 0:
+            ws = torch.empty(lib().nfdp_conv_wgrad_bf16_ws_bytes(b, h, w, cin, cout, k), device=xh.device, dtype=torch.uint8)
+            _call("nfdp_conv_wgrad_bf16", _ptr(xh), xl, _ptr(dyh), dl, b, h, w, cin, cout, k, _ptr(dw), _ptr(ws), _stream(),
+                  label=f"conv_wgrad_bf16 k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout * k * k)
+            return dw
     ws = torch.empty(lib().nfdp_conv_wgrad_ws_bytes(b, h, w, cin, cout, k), device=xh.device, dtype=torch.uint8)
     _call("nfdp_conv_wgrad_f32", _ptr(xh), _ld(xh, "conv_wgrad"), _ptr(dyh), _ld(dyh, "conv_wgrad"), b, h, w, cin, cout, k,
           _ptr(dw), _ptr(ws), _stream(), label=f"conv_wgrad k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout * k * k)

@@ -2,7 +2,8 @@
 
 The reference trains through torch autograd (normalizing_flow/trainer.py:152-167: transform -> calculate_loss ->
 loss.backward() -> clips -> optimizer.step()).  Here every arithmetic op of that graph is a Function whose forward
-and backward are HIP launches through the C ABI (exact-fp32 MFMA convolutions; include/nfdp.h "backward of the flow
+and backward are HIP launches through the C ABI (the module's compute mode - exact-fp32 or bf16 MFMA - applies to the
+convolutions' forward, data-gradient and weight-gradient GEMMs; activations stay fp32; include/nfdp.h "backward of the flow
 path"); autograd only strings them together.  What stays in torch is glue of parameter size or smaller: the
 `H*W*sum(scale)` / `H*W*log|det W|` scalars added to the per-sample log-det, the [2C] prior vector
 `bias*exp(3*logs)`, channel slices and the per-sample adds of the fp64 accumulators.
@@ -82,14 +83,15 @@ class ConvScaleFn(Function):
     """y = act((conv(x, W) + add) * exp(f * mul)): Conv2dActNorm (+ReLU) with add/mul = ActNorm bias/scale, f = 1
     (reference utils.py:67-69, :83-87) and ZeroConv2d with add/mul = bias/logs, f = 3 (utils.py:43-44).  One fused
     MFMA launch forward; backward = one scale/ReLU-backward pass (+ per-channel parameter sums), the data gradient as
-    the same conv kernel on flipped/transposed weights, and the weight-gradient GEMM over pixels."""
+    the same conv kernel on flipped/transposed weights, and the weight-gradient GEMM over pixels.  `compute` (K.F32 exact
+    fp32 MFMA | K.BF16 bf16 MFMA with fp32 accumulation) applies to all three GEMMs; activations stay fp32."""
 
     @staticmethod
-    def forward(ctx, xh, weight, add, mul, f, relu, packed, k):
+    def forward(ctx, xh, weight, add, mul, f, relu, packed, k, compute):
         y = K.conv2d(xh, packed, weight.shape[0], k, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1),
-                     mul_exp=float(f), relu=bool(relu), compute=K.F32, out_dtype=K.F32)
+                     mul_exp=float(f), relu=bool(relu), compute=compute, out_dtype=K.F32)
         ctx.save_for_backward(xh, weight, mul, y)
-        ctx.f, ctx.relu, ctx.k = float(f), bool(relu), int(k)
+        ctx.f, ctx.relu, ctx.k, ctx.compute = float(f), bool(relu), int(k), compute
         ctx.add_shape = add.shape
         return y
 
@@ -100,9 +102,9 @@ class ConvScaleFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wt = K.conv_flip_weights(weight.detach().contiguous())
-            dx = K.conv2d(dc, K.conv_pack(wt, K.F32), weight.shape[1], ctx.k, compute=K.F32, out_dtype=K.F32)
-        dw = K.conv_wgrad(xh, dc, ctx.k)
-        return dx, dw, dadd.reshape(ctx.add_shape), dmul.view_as(mul), None, None, None, None
+            dx = K.conv2d(dc, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute, out_dtype=K.F32)
+        dw = K.conv_wgrad(xh, dc, ctx.k, compute=ctx.compute)
+        return dx, dw, dadd.reshape(ctx.add_shape), dmul.view_as(mul), None, None, None, None, None
 
 
 class CouplingFn(Function):
@@ -162,23 +164,24 @@ class SqueezeFn(Function):
 
 
 # ----------------------------------------------------------------------------- module walkers
-def _conv_actnorm_relu(mod, xh: Tensor) -> Tensor:
+def _conv_actnorm_relu(mod, xh: Tensor, c: int) -> Tensor:
     """Conv2dActNorm followed by the ReLU of coupling_network (utils.py:83-87)."""
     an, cv = mod.actnorm, mod.conv
-    packed = cv.packed(K.F32)
+    packed = cv.packed(c)
     if not an.initialized():
         with torch.no_grad():                                     # data-dependent init on the raw conv output
-            an.init_from(K.conv2d(xh.detach(), packed, cv.out_channels, mod.filter_size, compute=K.F32, out_dtype=K.F32))
-    return ConvScaleFn.apply(xh, cv.weight, an.bias, an.scale, 1.0, True, packed, mod.filter_size)
+            an.init_from(K.conv2d(xh.detach(), packed, cv.out_channels, mod.filter_size, compute=c, out_dtype=K.F32))
+    return ConvScaleFn.apply(xh, cv.weight, an.bias, an.scale, 1.0, True, packed, mod.filter_size, c)
 
 
-def _zero_conv(mod, xh: Tensor) -> Tensor:
+def _zero_conv(mod, xh: Tensor, c: int) -> Tensor:
     return ConvScaleFn.apply(xh, mod.weight, mod.bias, mod.logs, mod.logscale_factor, False,
-                             mod._cache.get(mod.weight, K.F32), mod.filter_size)
+                             mod._cache.get(mod.weight, c), mod.filter_size, c)
 
 
-def coupling_net(net, xa: Tensor) -> Tensor:
-    return _zero_conv(net[4], _conv_actnorm_relu(net[2], _conv_actnorm_relu(net[0], xa)))
+def coupling_net(net, xa: Tensor, compute: Optional[str] = None) -> Tensor:
+    c = K.compute_enum(compute)
+    return _zero_conv(net[4], _conv_actnorm_relu(net[2], _conv_actnorm_relu(net[0], xa, c), c), c)
 
 
 def step_flow(flow, xh: Tensor, ldj: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
@@ -191,7 +194,7 @@ def step_flow(flow, xh: Tensor, ldj: Optional[Tensor]) -> Tuple[Tensor, Optional
     y = ActNormFn.apply(xh, an.scale, an.bias)
     y = InvConvFn.apply(y, ic.weight)
     c = y.shape[-1]
-    y, inc = CouplingFn.apply(y, coupling_net(cp.net, y[..., : c // 2]))
+    y, inc = CouplingFn.apply(y, coupling_net(cp.net, y[..., : c // 2], cp.compute))
     if ldj is not None:
         ldj = ldj + hw * an.scale.sum() + hw * LogAbsDetFn.apply(ic.weight) + inc
     return y, ldj
@@ -203,7 +206,7 @@ def split(mod, xh: Tensor, logp: Optional[Tensor]):
     yv, zv = xh[..., : c // 2], xh[..., c // 2:]
     if logp is not None:
         if mod.conv is not None:
-            h = _zero_conv(mod.conv, yv)
+            h = _zero_conv(mod.conv, yv, K.compute_enum(mod.compute))
         else:
             h = torch.zeros(xh.shape[:3] + (c,), device=xh.device, dtype=torch.float32)
         logp = logp + GaussLogpFn.apply(zv, h, 0)

@@ -276,3 +276,78 @@ def test_training_step_matches_reference_goldens():
         close_summary(names[k], g[f"p{i}"], TOL, f"updated parameter {k}")
     for i, k in enumerate(pkeys):
         close_summary(pnames[k], g[f"pp{i}"], TOL, f"updated prior parameter {k}")
+
+
+@pytest.mark.parametrize("b,hw,cin,cout,k", [(2, 8, 512, 512, 1), (2, 8, 12, 512, 3), (3, 4, 512, 48, 3), (5, 4, 24, 512, 3),
+                                             (2, 16, 64, 96, 3), (7, 2, 132, 36, 1)])
+def test_conv_wgrad_bf16(b, hw, cin, cout, k):
+    """bf16-MFMA weight gradient against the fp32 autograd result: operands rounded to bf16, fp32 accumulation."""
+    x = rnd(b, cin, hw, hw, seed=21).requires_grad_()
+    w = rnd(cout, cin, k, k, seed=22, scale=0.1).requires_grad_()
+    dy = rnd(b, cout, hw, hw, seed=23)
+    F.conv2d(x, w, padding=k // 2).backward(dy)
+    xh = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyh = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    K.start_trace()
+    dw = K.conv_wgrad(xh, dyh, k, compute=K.BF16)
+    labels = [e["label"] for e in K.stop_trace()]
+    assert any(lb.startswith("conv_wgrad_bf16") for lb in labels), labels
+    assert_close(dw, w.grad, 1e-2, "bf16 wgrad")
+    # exact when the operands are representable in bf16
+    xq, dq = xh.bfloat16().float(), dyh.bfloat16().float()
+    assert_close(K.conv_wgrad(xq, dq, k, compute=K.BF16), K.conv_wgrad(xq, dq, k), 1e-5, "bf16 kernel on bf16-exact data")
+    assert torch.equal(K.conv_wgrad(xh, dyh, k, compute=K.BF16), dw)                 # deterministic
+    # pixel-strided operand (channel slice) with aligned stride
+    if cin % 8 == 0:
+        wide = torch.zeros(b, hw, hw, 2 * cin, device=DEV)
+        wide[..., cin:] = xh
+        assert torch.equal(K.conv_wgrad(wide[..., cin:], dyh, k, compute=K.BF16), dw)
+
+
+def test_glow_training_in_bf16_mode_tracks_the_fp32_gradients():
+    """compute="bf16": the coupling networks' forward, data-gradient and weight-gradient GEMMs run on bf16 MFMA (fp32
+    activations and accumulation).  Gradients stay within bf16 round-off of autograd through the fp32 oracle - measured in
+    the Frobenius norm per tensor: single entries move more when a hidden unit's ReLU mask flips - and the reference-style
+    loop still lowers the loss."""
+    from normalizing_flow import calculate_loss, initialize_with_zeros
+    from nfdp_hip.optim import FusedAdam
+    from tests.golden.synth import DEEP
+    B = 8
+    flow, prior, _, _ = build(3, 3, 2, 31)
+    fsd = {k: T(synth_tensor(k, v.shape, 31, DEEP)) for k, v in flow.state_dict().items()}     # trained-like weights
+    psd = {k: T(synth_tensor(k, v.shape, 32, DEEP)) for k, v in prior.state_dict().items()}
+    flow.load_state_dict(fsd); prior.load_state_dict(psd)
+    flow.set_compute("bf16")
+    x = T(synth_input("train_x", (B, 3, 32, 32), 5)) * 0.4
+    fo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in fsd.items()}
+    po = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in psd.items()}
+    _, _, _, bpd_ref = O.fwd_nll(x, fo, po, 3, 2, img_size=32)
+    bpd_ref.backward()
+    ll, logp = initialize_with_zeros(2, B, torch.device(DEV))
+    K.start_trace()
+    latents, ll, logp = flow.transform(x.to(DEV), ll, logp)
+    loss = calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0)
+    loss.backward()
+    labels = [e["label"] for e in K.stop_trace()]
+    assert any(lb.startswith("conv_wgrad_bf16") for lb in labels) and any("conv_kernel<bf16" in lb for lb in labels)
+    assert_close(loss, bpd_ref.detach(), 2e-3, "bits/dim (bf16 coupling networks)")
+
+    def fro(a, b):
+        a, b = a.detach().double().cpu(), b.double()
+        return float((a - b).norm() / b.norm())
+    errs = {k: fro(p.grad, fo[k].grad) for k, p in flow.named_parameters() if float(fo[k].grad.abs().max()) > 0}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print("bf16 training gradients: median rel Frobenius err", float(np.median(list(errs.values()))), "worst", worst)
+    assert worst[1] <= 8e-2, worst
+    assert float(np.median(list(errs.values()))) <= 1e-2
+    opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=2e-4, clip_value=1, max_norm=1)
+    losses = []
+    for _ in range(4):
+        ll, logp = initialize_with_zeros(2, B, torch.device(DEV))
+        latents, ll, logp = flow.transform(x.to(DEV), ll, logp)
+        loss = calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses

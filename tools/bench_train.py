@@ -13,8 +13,9 @@ from normalizing_flow import Glow, GaussianPrior, calculate_loss, initialize_wit
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 Kf = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+COMPUTE = sys.argv[4] if len(sys.argv) > 4 else "f32"
 dev = torch.device("cuda", 0)
-flow = Glow(in_channel=3, L=3, K=Kf, learn_prior_mean_logs=True, compute="f32")
+flow = Glow(in_channel=3, L=3, K=Kf, learn_prior_mean_logs=True, compute=COMPUTE)
 prior = GaussianPrior(48, True)
 flow.load_state_dict({k: torch.from_numpy(np.array(synth_tensor(k, v.shape, 1, DEEP))) for k, v in flow.state_dict().items()})
 prior.load_state_dict({k: torch.from_numpy(np.array(synth_tensor(k, v.shape, 2, DEEP))) for k, v in prior.state_dict().items()})
@@ -46,7 +47,7 @@ for i in range(steps):
     l = step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(f"B={B} K={Kf}: {dt * 1e3:.1f} ms/step, {B / dt:.0f} images/s, loss {float(l.detach()):.4f}", flush=True)
+print(f"B={B} K={Kf} {COMPUTE}: {dt * 1e3:.1f} ms/step, {B / dt:.0f} images/s, loss {float(l.detach()):.4f}", flush=True)
 K.start_trace()
 step()
 recs = K.stop_trace()
