@@ -243,6 +243,12 @@ int nfdp_conv_wgrad_bf16(const float* x, int x_ld, const float* dy, int dy_ld, i
                          float* dw, void* ws, nfdp_stream_t stream);
 /* wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: nfdp_conv2d_nhwc on pack(wt) is the data gradient of the conv with w. */
 int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int I, int k, nfdp_stream_t stream);
+/* Second half of a narrow 3x3 'same' conv computed as a pointwise GEMM to tap contributions T [B,H,W,9*Co] (column
+ * tap*Co + co, taps row-major) plus this shift-sum: out[b,y,x,co] = act((sum_tap T[b,y+dy,x+dx,tap*Co+co] + add[co]) *
+ * exp(mul_exp*mul[co])), zero outside the image; add, mul nullable.  Used by the training path for Cin >> Cout convs
+ * (ZeroConv2d 512->C, utils.py:43, and the data gradient of the 3x3 C/2->512 conv, utils.py:67). */
+int nfdp_tap_shift_sum_f32(const float* T, float* out, int B, int H, int W, int Co, const float* add, const float* mul,
+                           float mul_exp, int relu, nfdp_stream_t stream);
 /* Backward of y = act((u + add) * exp(f*mul)), act = ReLU (relu=1) or identity - ActNorm (transforms.py:80; f=1),
  * Conv2dActNorm+ReLU (utils.py:67-69, :83-87; f=1), ZeroConv2d (utils.py:43-44; f=3):
  *   dc = dy * [y>0] * exp(f*mul)   (gradient w.r.t. u; nullable),  dmul[c] = f * sum_p dy*y*[y>0],  dadd[c] = sum_p dc.

@@ -406,6 +406,33 @@ __global__ void __launch_bounds__(kBlock) wgrad_bf16_kernel(const WgradParams p)
             }
 }
 
+// ----------------------------------------------------------------------------- tap shift-sum (narrow 3x3 convs)
+// A 3x3 conv with few output channels spends its time staging im2col rows.  Computed instead as a pointwise GEMM
+// T[p][tap*Co + co] = sum_ci x[p][ci] W[co][ci][tap] (a wide 1x1 conv: fast) followed by
+//   out[p][co] = act( (sum_tap T[p + d(tap)][tap*Co + co] + add[co]) * exp(f * mul[co]) ),  zero outside the image,
+// which is this kernel (the same decomposition as the fused flow-step kernel's GEMM3 + shift-sum).
+__global__ void tap_shift_sum_kernel(const float* __restrict__ T, float* __restrict__ out, long total, int H, int W, int Co,
+                                     const float* __restrict__ add, const float* __restrict__ mul, float f, int relu) {
+    const int ld = 9 * Co;
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const int co = (int)(i % Co);
+        const long px = i / Co;
+        const int xx = (int)(px % W);
+        const int y = (int)((px / W) % H);
+        float acc = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(xx + dx) < (unsigned)W)
+                acc += T[(px + (long)dy * W + dx) * ld + tap * Co + co];
+        }
+        if (add) acc = __fadd_rn(acc, add[co]);
+        if (mul) acc = __fmul_rn(acc, expf(__fmul_rn(f, mul[co])));
+        if (relu) acc = fmaxf(acc, 0.f);
+        out[i] = acc;
+    }
+}
+
 template <int MT, int NT>
 void launch_wgrad(const WgradParams& p, hipStream_t s) {
     hipLaunchKernelGGL((wgrad_kernel<MT, NT>), dim3(p.mblocks * p.nblocks * p.ksplit), dim3(64), 0, s, p);
@@ -590,5 +617,17 @@ extern "C" int nfdp_conv_wgrad_bf16(const float* x, int x_ld, const float* dy, i
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, s, p.ws, dw, p.ksplit, p.Mpad,
                        p.Npad, Cout, Cin, k);
     NFDP_CHECK_LAUNCH("conv_wgrad_bf16");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_tap_shift_sum_f32(const float* T, float* out, int B, int H, int W, int Co, const float* add, const float* mul,
+                                      float mul_exp, int relu, nfdp_stream_t stream) {
+    NFDP_REQUIRE(T && out, NFDP_EINVAL, "tap_shift_sum: null pointer");
+    NFDP_REQUIRE(B >= 0 && H > 0 && W > 0 && Co > 0, NFDP_ESHAPE, "tap_shift_sum: bad shape");
+    const long total = (long)B * H * W * Co;
+    if (total == 0) return NFDP_OK;
+    hipLaunchKernelGGL(tap_shift_sum_kernel, dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, as_stream(stream), T, out, total, H, W,
+                       Co, add, mul, mul_exp, relu);
+    NFDP_CHECK_LAUNCH("tap_shift_sum");
     return NFDP_OK;
 }

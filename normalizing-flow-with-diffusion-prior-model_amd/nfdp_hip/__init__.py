@@ -822,3 +822,22 @@ def diffusion_loss_bwd(pred, target, t, p2w, grad_out, l1: bool):
     _call("nfdp_diffusion_loss_bwd_f32", _ptr(pred), _ptr(target), _ptr(t), _ptr(p2w), _ptr(grad_out), b, pred.numel() // b, int(l1),
           _ptr(dp), _stream())
     return dp
+
+
+def conv3x3_narrow(xh: torch.Tensor, w_oihw: torch.Tensor, *, add=None, mul=None, mul_exp: float = 0.0, relu: bool = False,
+                   compute: int = F32) -> torch.Tensor:
+    """3x3 'same' conv with Cin >> Cout as a pointwise GEMM to the 9*Cout tap contributions (one wide, fast 1x1 conv)
+    followed by the tap shift-sum with the conv kernel's epilogue act((acc + add) * exp(mul_exp * mul))."""
+    co, ci, k, _ = w_oihw.shape
+    if k != 3:
+        raise ValueError("conv3x3_narrow: 3x3 only")
+    b, h, w, _ = xh.shape
+    wpt = w_oihw.detach().permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1).contiguous()        # [tap*Co + co][ci]: weight-sized plumbing
+    t = conv2d(xh, conv_pack(wpt, compute), 9 * co, 1, compute=compute, out_dtype=F32)
+    out = torch.empty((b, h, w, co), device=xh.device, dtype=torch.float32)
+    _call("nfdp_tap_shift_sum_f32", _ptr(t), _ptr(out), b, h, w, co, _ptr(add), _ptr(mul), float(mul_exp), int(relu), _stream())
+    return out
+
+
+def use_narrow_conv(cin: int, cout: int, k: int) -> bool:
+    return k == 3 and cout <= 64 and cin >= 4 * cout and cin >= 128

@@ -63,20 +63,25 @@ class InvConvFn(Function):
 
 
 class LogAbsDetFn(Function):
-    """log|det W| in fp64 on the device, returned as fp32 [1]   (reference transforms.py:131); gradient g * W^-T."""
+    """log|det W| in fp64 on the device, returned as fp32 [1]   (reference transforms.py:131); gradient g * W^-T.
+    `pre` = (lad [1], winv [C,C]) from a batched launch over all flows of a level (else computed here)."""
 
     @staticmethod
-    def forward(ctx, weight):
+    def forward(ctx, weight, pre):
         c = weight.shape[0]
-        lad, winv = K.invconv_prepare(weight.detach().reshape(1, c, c).contiguous(), want_inverse=True)
+        if pre is None:
+            lad, winv = K.invconv_prepare(weight.detach().reshape(1, c, c).contiguous(), want_inverse=True)
+            winv = winv[0]
+        else:
+            lad, winv = pre
         ctx.save_for_backward(winv)
         ctx.wshape = weight.shape
-        return lad
+        return lad.clone()
 
     @staticmethod
     def backward(ctx, g):
         (winv,) = ctx.saved_tensors
-        return (g.reshape(()) * winv[0].t()).reshape(ctx.wshape)
+        return (g.reshape(()) * winv.t()).reshape(ctx.wshape), None
 
 
 class ConvScaleFn(Function):
@@ -88,8 +93,12 @@ class ConvScaleFn(Function):
 
     @staticmethod
     def forward(ctx, xh, weight, add, mul, f, relu, packed, k, compute):
-        y = K.conv2d(xh, packed, weight.shape[0], k, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1),
-                     mul_exp=float(f), relu=bool(relu), compute=compute, out_dtype=K.F32)
+        if K.use_narrow_conv(weight.shape[1], weight.shape[0], k):       # 512 -> C: pointwise GEMM + tap shift-sum
+            y = K.conv3x3_narrow(xh, weight, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1), mul_exp=float(f),
+                                 relu=bool(relu), compute=compute)
+        else:
+            y = K.conv2d(xh, packed, weight.shape[0], k, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1),
+                         mul_exp=float(f), relu=bool(relu), compute=compute, out_dtype=K.F32)
         ctx.save_for_backward(xh, weight, mul, y)
         ctx.f, ctx.relu, ctx.k, ctx.compute = float(f), bool(relu), int(k), compute
         ctx.add_shape = add.shape
@@ -102,7 +111,10 @@ class ConvScaleFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wt = K.conv_flip_weights(weight.detach().contiguous())
-            dx = K.conv2d(dc, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute, out_dtype=K.F32)
+            if K.use_narrow_conv(weight.shape[0], weight.shape[1], ctx.k):   # data gradient of C/2 -> 512: a 512 -> C/2 conv
+                dx = K.conv3x3_narrow(dc, wt, compute=ctx.compute)
+            else:
+                dx = K.conv2d(dc, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute, out_dtype=K.F32)
         dw = K.conv_wgrad(xh, dc, ctx.k, compute=ctx.compute)
         return dx, dw, dadd.reshape(ctx.add_shape), dmul.view_as(mul), None, None, None, None, None
 
@@ -184,7 +196,7 @@ def coupling_net(net, xa: Tensor, compute: Optional[str] = None) -> Tensor:
     return _zero_conv(net[4], _conv_actnorm_relu(net[2], _conv_actnorm_relu(net[0], xa, c), c), c)
 
 
-def step_flow(flow, xh: Tensor, ldj: Optional[Tensor]) -> Tuple[Tensor, Optional[Tensor]]:
+def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None) -> Tuple[Tensor, Optional[Tensor]]:
     """actnorm -> invconv -> affine coupling (reference glow.py:44-49), differentiable."""
     an, ic, cp = flow.actnorm, flow.invconv2d, flow.affcoupling
     hw = xh.shape[1] * xh.shape[2]
@@ -196,7 +208,7 @@ def step_flow(flow, xh: Tensor, ldj: Optional[Tensor]) -> Tuple[Tensor, Optional
     c = y.shape[-1]
     y, inc = CouplingFn.apply(y, coupling_net(cp.net, y[..., : c // 2], cp.compute))
     if ldj is not None:
-        ldj = ldj + hw * an.scale.sum() + hw * LogAbsDetFn.apply(ic.weight) + inc
+        ldj = ldj + hw * an.scale.sum() + hw * LogAbsDetFn.apply(ic.weight, pre) + inc
     return y, ldj
 
 
@@ -213,19 +225,28 @@ def split(mod, xh: Tensor, logp: Optional[Tensor]):
     return yv, zv.contiguous(), logp
 
 
+def _level_logdets(flows):
+    """(lad [1], W^-1) of every flow of a level from ONE batched fp64 Gauss-Jordan launch (weights only)."""
+    w = torch.stack([f.invconv2d.weight.detach().reshape(f.invconv2d.weight.shape[0], -1) for f in flows]).contiguous()
+    lads, winvs = K.invconv_prepare(w, want_inverse=True)
+    return [(lads[i:i + 1], winvs[i]) for i in range(len(flows))]
+
+
 def glow_transform(glow, x: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor]):
     """Glow.transform with a gradient graph (reference glow.py:172-201): -> (latent parts NCHW views, ldj, logp)."""
     yh = K.to_nhwc(x)
     zs = []
     for block in glow.blocks:
         yh = SqueezeFn.apply(yh)
-        for flow in block.flows:
-            yh, ldj = step_flow(flow, yh, ldj)
+        pre = _level_logdets(block.flows) if ldj is not None else [None] * len(block.flows)
+        for flow, pr in zip(block.flows, pre):
+            yh, ldj = step_flow(flow, yh, ldj, pr)
         yh, z, logp = split(block.split, yh, logp)
         zs.append(K.as_nchw(z))
     yh = SqueezeFn.apply(yh)
-    for flow in glow.final_flows:
-        yh, ldj = step_flow(flow, yh, ldj)
+    pre = _level_logdets(glow.final_flows) if ldj is not None else [None] * len(glow.final_flows)
+    for flow, pr in zip(glow.final_flows, pre):
+        yh, ldj = step_flow(flow, yh, ldj, pr)
     zs.append(K.as_nchw(yh))
     return zs, ldj, logp
 

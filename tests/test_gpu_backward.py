@@ -351,3 +351,21 @@ def test_glow_training_in_bf16_mode_tracks_the_fp32_gradients():
         opt.step()
         losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("b,hw,cin,cout,relu", [(2, 8, 512, 12, False), (3, 4, 512, 48, True), (2, 16, 512, 6, False), (1, 5, 128, 3, True)])
+def test_conv3x3_narrow_matches_conv(b, hw, cin, cout, relu):
+    """Narrow 3x3 conv = pointwise GEMM to tap contributions + tap shift-sum, against F.conv2d with the same epilogue."""
+    x = rnd(b, cin, hw, hw, seed=41)
+    w = rnd(cout, cin, 3, 3, seed=42, scale=0.05)
+    add, mul = rnd(cout, seed=43, scale=0.2), rnd(cout, seed=44, scale=0.1)
+    ref = (F.conv2d(x, w, padding=1) + add.view(1, -1, 1, 1)) * torch.exp(3.0 * mul).view(1, -1, 1, 1)
+    if relu:
+        ref = torch.relu(ref)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    got = K.conv3x3_narrow(xh, w.to(DEV), add=add.to(DEV), mul=mul.to(DEV), mul_exp=3.0, relu=relu, compute=K.F32)
+    assert_close(got.permute(0, 3, 1, 2), ref, 1e-5, "narrow conv f32")
+    gb = K.conv3x3_narrow(xh, w.to(DEV), add=add.to(DEV), mul=mul.to(DEV), mul_exp=3.0, relu=relu, compute=K.BF16)
+    assert_close(gb.permute(0, 3, 1, 2), ref, 1e-2, "narrow conv bf16")
+    plain = K.conv3x3_narrow(xh, w.to(DEV), compute=K.F32)
+    assert_close(plain.permute(0, 3, 1, 2), F.conv2d(x, w, padding=1), 1e-5, "no epilogue")
