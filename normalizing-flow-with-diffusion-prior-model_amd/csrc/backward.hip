@@ -112,21 +112,36 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgradParams p) {
             }
 }
 
-// dw[o][ci][ky][kx] (OIHW) = sum over the pixel slices, in slice order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ksplit, int Mpad, int Npad,
-                                    int Cout, int Cin, int k) {
+// dw[o][ci][ky][kx] (OIHW) = sum over the pixel slices.  32 outputs x 8 lanes per workgroup: lane g sums slices g, g+8, ...
+// and the 8 lane sums are combined in lane order (fixed order -> deterministic; a tiny CxC output with 2048 slices would
+// otherwise be one workgroup walking them serially).
+__global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ksplit,
+                                                             int Mpad, int Npad, int Cout, int Cin, int k) {
+    __shared__ float red[8][32];
     const long total = (long)Cout * Cin * k * k;
-    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
-        const int kx = (int)(i % k);
-        long r = i / k;
-        const int ky = (int)(r % k);
-        r /= k;
-        const int ci = (int)(r % Cin);
-        const int o = (int)(r / Cin);
-        const int n = (ky * k + kx) * Cin + ci;
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (long i0 = (long)blockIdx.x * 32; i0 < total; i0 += (long)gridDim.x * 32) {
+        const long i = i0 + el;
         float s = 0.f;
-        for (int q = 0; q < ksplit; ++q) s += ws[((size_t)q * Mpad + o) * Npad + n];
-        dw[i] = s;
+        if (i < total) {
+            const int kx = (int)(i % k);
+            long r = i / k;
+            const int ky = (int)(r % k);
+            r /= k;
+            const int ci = (int)(r % Cin);
+            const int o = (int)(r / Cin);
+            const int n = (ky * k + kx) * Cin + ci;
+            for (int q = g; q < ksplit; q += 8) s += ws[((size_t)q * Mpad + o) * Npad + n];
+        }
+        __syncthreads();
+        red[g][el] = s;
+        __syncthreads();
+        if (g == 0 && i < total) {
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += red[j][el];
+            dw[i] = t;
+        }
     }
 }
 
@@ -456,10 +471,12 @@ static void wgrad_plan(int B, int H, int W, int Cin, int Cout, int k, WgradParam
     p->Mpad = p->mblocks * 32 * MT;
     p->Npad = p->nblocks * 32 * NT;
     p->npix = (long)B * H * W;
-    // ~2048 waves on the chip (256 CUs x 4 SIMDs x 2), at least 64 pixels per slice, at most 256 slices
+    // ~2048 waves on the chip (256 CUs x 4 SIMDs x 2), at least 64 pixels per slice; small outputs (the CxC gradient of
+    // the 1x1 flow convolution) get up to 2048 slices: one wave walks its slice serially, a load latency per step
     long want = 2048 / ((long)p->mblocks * p->nblocks);
     if (want < 1) want = 1;
-    if (want > 256) want = 256;
+    const long cap = ((long)p->Mpad * p->Npad <= 64 * 64) ? 2048 : 256;
+    if (want > cap) want = cap;
     long per = cdiv(p->npix, want);
     if (per < 64) per = 64;
     per = (per + 1) & ~1L;
@@ -496,7 +513,7 @@ extern "C" int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, in
     else if (MT == 1 && NT == 2) launch_wgrad<1, 2>(p, s);
     else launch_wgrad<1, 1>(p, s);
     const long total = (long)Cout * Cin * k * k;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, s, p.ws, dw, p.ksplit, p.Mpad,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(total, 32)), dim3(kBlock), 0, s, p.ws, dw, p.ksplit, p.Mpad,
                        p.Npad, Cout, Cin, k);
     NFDP_CHECK_LAUNCH("conv_wgrad");
     return NFDP_OK;
@@ -614,7 +631,7 @@ extern "C" int nfdp_conv_wgrad_bf16(const float* x, int x_ld, const float* dy, i
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.mblocks * p.nblocks * p.ksplit), dim3(kBlock), 0, s, p);
     const long total = (long)Cout * Cin * k * k;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(total, kBlock)), dim3(kBlock), 0, s, p.ws, dw, p.ksplit, p.Mpad,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(total, 32)), dim3(kBlock), 0, s, p.ws, dw, p.ksplit, p.Mpad,
                        p.Npad, Cout, Cin, k);
     NFDP_CHECK_LAUNCH("conv_wgrad_bf16");
     return NFDP_OK;

@@ -676,6 +676,12 @@ def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int, compute: int = F32) 
         # narrow output (ZeroConv2d 512 -> C): gather the k*k taps over the NARROW tensor instead, so the wide one is read
         # once instead of k*k times:  dW[o][i][ky][kx] = W'[i][o][k-1-ky][k-1-kx]  with  W' = wgrad(x := dy, dy := x)
         return conv_flip_weights(conv_wgrad(dyh, xh, k, compute=compute))
+    if compute == BF16 and cin % 4 != 0 and cout % 4 == 0 and _ld(xh, "conv_wgrad") >= (cin + 3) // 4 * 4:
+        # x is a channel slice (x_a = first C/2 channels, C/2 = 6) of a wider pixel row: run the bf16 kernel on the slice
+        # rounded up to a multiple of 4 channels (valid memory of the same row) and drop the extra input columns
+        c4 = (cin + 3) // 4 * 4
+        wide = xh.as_strided((b, h, w, c4), xh.stride())
+        return conv_wgrad(wide, dyh, k, compute=compute)[:, :cin].contiguous()
     dw = torch.empty((cout, cin, k, k), device=xh.device, dtype=torch.float32)
     if compute == BF16 and cin % 4 == 0 and cout % 4 == 0:
         xl, dl = _ld(xh, "conv_wgrad"), _ld(dyh, "conv_wgrad")

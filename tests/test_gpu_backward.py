@@ -369,3 +369,18 @@ def test_conv3x3_narrow_matches_conv(b, hw, cin, cout, relu):
     assert_close(gb.permute(0, 3, 1, 2), ref, 1e-2, "narrow conv bf16")
     plain = K.conv3x3_narrow(xh, w.to(DEV), compute=K.F32)
     assert_close(plain.permute(0, 3, 1, 2), F.conv2d(x, w, padding=1), 1e-5, "no epilogue")
+
+
+def test_conv_wgrad_bf16_on_channel_slice_not_multiple_of_4():
+    """x_a = the first 6 of 12 channels (level 0 of a 3-channel flow): the bf16 kernel reads 8 channels of the same pixel rows
+    and the 2 extra input columns are dropped."""
+    x = rnd(2, 12, 8, 8, seed=51).requires_grad_()
+    w = rnd(512, 6, 3, 3, seed=52, scale=0.1).requires_grad_()
+    dy = rnd(2, 512, 8, 8, seed=53)
+    F.conv2d(x[:, :6], w, padding=1).backward(dy)
+    xh = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    K.start_trace()
+    dw = K.conv_wgrad(xh[..., :6], dy.permute(0, 2, 3, 1).contiguous().to(DEV), 3, compute=K.BF16)
+    assert any(e["label"].startswith("conv_wgrad_bf16") for e in K.stop_trace())
+    assert tuple(dw.shape) == (512, 6, 3, 3)
+    assert_close(dw, w.grad, 1e-2, "bf16 wgrad on a 6-of-12 channel slice")
