@@ -147,8 +147,21 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+_empty_scratch: Dict[str, torch.Tensor] = {}
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
+    """Device address for the C ABI.  Empty tensors (an empty shard of a ragged data-parallel split) have a null data pointer,
+    which the ABI rejects as a missing argument; they get the address of a small per-device scratch instead - every entry
+    point returns before touching memory when a size is 0."""
+    if t is None:
+        return None
+    if t.numel() == 0 and t.is_cuda:
+        key = str(t.device)
+        if key not in _empty_scratch:
+            _empty_scratch[key] = torch.zeros(64, device=t.device, dtype=torch.uint8)
+        return _empty_scratch[key].data_ptr()
+    return t.data_ptr()
 
 
 def _need(t: torch.Tensor, dtype, what: str) -> None:
@@ -172,6 +185,9 @@ def is_nhwc_view(x: torch.Tensor) -> bool:
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     """Logical NCHW fp32 tensor -> physical [B,H,W,C] contiguous tensor (zero-copy when already channels_last)."""
     _need(x, torch.float32, "to_nhwc")
+    if x.numel() == 0:                                   # empty shard: strides of empty tensors carry no layout information
+        b, c, h, w = x.shape
+        return torch.empty((b, h, w, c), device=x.device, dtype=torch.float32)
     if is_nhwc_view(x):
         return x.permute(0, 2, 3, 1)
     x = x.contiguous()
@@ -198,6 +214,8 @@ def to_nchw_contiguous(xh: torch.Tensor) -> torch.Tensor:
 def _ld(xh: torch.Tensor, what: str) -> int:
     """Pixel stride (elements) of a [B,H,W,C] tensor that may be a channel slice of a wider dense tensor."""
     b, h, w, c = xh.shape
+    if xh.numel() == 0:
+        return c
     sb, sh, sw, sc = xh.stride()
     if c > 1 and sc != 1:
         raise NfdpError(f"{what}: channel stride must be 1")

@@ -163,3 +163,22 @@ def test_level_launch_bit_identical_to_per_flow_launches(C, hw, B, inverse):
     assert torch.isfinite(a).all()
     assert torch.equal(a, b), "state differs"
     assert torch.equal(la, lb), "log-det differs"
+
+
+@torch.no_grad()
+def test_empty_batch_is_a_no_op():
+    """B = 0 (an empty shard of a ragged data-parallel split) must be accepted by the flow entry points and change nothing."""
+    from normalizing_flow import Glow, GaussianPrior
+    flow = Glow(in_channel=3, L=3, K=2, compute="bf16").to("cuda")
+    for m in flow.modules():                                   # mark ActNorms initialised: nothing to initialise from
+        if hasattr(m, "is_initialized"):
+            m.is_initialized.fill_(1)
+            m._init_cache = None
+    x = torch.zeros(0, 3, 32, 32, device="cuda")
+    ldj = torch.zeros(0, dtype=torch.float64, device="cuda")
+    logp = torch.zeros(0, dtype=torch.float64, device="cuda")
+    zs, ldj, logp = flow.transform(x, ldj, logp)
+    assert [tuple(z.shape) for z in zs] == [(0, 6, 16, 16), (0, 12, 8, 8), (0, 48, 4, 4)]
+    assert ldj.numel() == 0 and logp.numel() == 0
+    xr = flow.invert(zs)
+    assert tuple(xr.shape) == (0, 3, 32, 32)
