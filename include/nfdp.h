@@ -236,11 +236,12 @@ int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, int dy_ld, in
                         float* dw, void* ws, nfdp_stream_t stream);
 /* The same weight gradient with bf16 MFMA (operands rounded to bf16, fp32 accumulation): fp32 tiles are converted and
  * transposed on their way into LDS.  Needs Cin % 4 == 0, Cout % 4 == 0, 16-byte aligned operands with pixel strides that are
- * multiples of 4 (nfdp_conv_wgrad_bf16_supported); otherwise use nfdp_conv_wgrad_f32. */
+ * multiples of 4 (nfdp_conv_wgrad_bf16_supported); otherwise use nfdp_conv_wgrad_f32.  x_dtype / dy_dtype: NFDP_F32 or NFDP_BF16
+ * storage of the operands (bf16 training mode keeps the hidden activations and their gradients in bf16). */
 int nfdp_conv_wgrad_bf16_supported(int Cin, int Cout);
 size_t nfdp_conv_wgrad_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int k);
-int nfdp_conv_wgrad_bf16(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout, int k,
-                         float* dw, void* ws, nfdp_stream_t stream);
+int nfdp_conv_wgrad_bf16(const void* x, int x_dtype, int x_ld, const void* dy, int dy_dtype, int dy_ld, int B, int H, int W,
+                         int Cin, int Cout, int k, float* dw, void* ws, nfdp_stream_t stream);
 /* wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: nfdp_conv2d_nhwc on pack(wt) is the data gradient of the conv with w. */
 int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int I, int k, nfdp_stream_t stream);
 /* Second half of a narrow 3x3 'same' conv computed as a pointwise GEMM to tap contributions T [B,H,W,9*Co] (column
@@ -255,6 +256,9 @@ int nfdp_tap_shift_sum_f32(const float* T, float* out, int B, int H, int W, int 
  * y (the saved OUTPUT) and mul nullable: with both null this is a plain per-channel sum of dy into dadd.
  * ws: nfdp_scale_bwd_ws_bytes(npix, C). */
 size_t nfdp_scale_bwd_ws_bytes(long npix, int C);
+/* The same with fp32 or bf16 storage of dy, y and dc; supported (dy, y, dc): (f32,f32,f32), (f32,bf16,bf16), (bf16,bf16,bf16). */
+int nfdp_scale_bwd(const void* dy, int dy_dtype, int dy_ld, const void* y, int y_dtype, int y_ld, const float* mul, float f, int relu,
+                   long npix, int C, void* dc, int dc_dtype, int dc_ld, float* dmul, float* dadd, void* ws, nfdp_stream_t stream);
 int nfdp_scale_bwd_f32(const float* dy, int dy_ld, const float* y, int y_ld, const float* mul, float f, int relu, long npix,
                        int C, float* dc, int dc_ld, float* dmul, float* dadd, void* ws, nfdp_stream_t stream);
 /* Backward of AffineCoupling.transform (transforms.py:179-185).  x: tensor before the coupling [B,HW,C] dense,

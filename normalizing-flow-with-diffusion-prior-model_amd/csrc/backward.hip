@@ -27,8 +27,8 @@ __host__ __device__ constexpr int drow32(int reg, int h) { return (reg & 3) + 8 
 
 // ----------------------------------------------------------------------------- conv weight gradient
 struct WgradParams {
-    const float* x;      // [B,H,W,Cin] pixel stride x_ld
-    const float* dy;     // [B,H,W,Cout] pixel stride dy_ld
+    const void* x;       // [B,H,W,Cin] pixel stride x_ld   (fp32; the bf16 kernel also takes bf16)
+    const void* dy;      // [B,H,W,Cout] pixel stride dy_ld
     float* ws;           // [ksplit][Mpad][Npad] partial sums
     int x_ld, dy_ld, B, H, W, Cin, Cout, k, N;   // N = k*k*Cin
     int mblocks, nblocks, ksplit, Mpad, Npad;
@@ -37,6 +37,8 @@ struct WgradParams {
 
 template <int MT, int NT>
 __global__ void __launch_bounds__(64) wgrad_kernel(const WgradParams p) {
+    const float* __restrict__ xf = reinterpret_cast<const float*>(p.x);
+    const float* __restrict__ dyf = reinterpret_cast<const float*>(p.dy);
     const int lane = threadIdx.x, c32 = lane & 31, kk = lane >> 5;
     int bid = blockIdx.x;
     const int nb = bid % p.nblocks; bid /= p.nblocks;
@@ -79,10 +81,10 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgradParams p) {
         const bool pv = px < p_end;
         float a[MT], bv[NT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = (pv && m_ok[i]) ? p.dy[px * p.dy_ld + m_idx[i]] : 0.f;
+        for (int i = 0; i < MT; ++i) a[i] = (pv && m_ok[i]) ? dyf[px * p.dy_ld + m_idx[i]] : 0.f;
         if (pointwise) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bv[j] = (pv && n_ok[j]) ? p.x[px * p.x_ld + n_ci[j]] : 0.f;
+            for (int j = 0; j < NT; ++j) bv[j] = (pv && n_ok[j]) ? xf[px * p.x_ld + n_ci[j]] : 0.f;
         } else {
             const long b = px / HW;
             const int r = (int)(px - b * HW);
@@ -91,7 +93,7 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgradParams p) {
             for (int j = 0; j < NT; ++j) {
                 const int yy = y + n_dy[j], xc = xx + n_dx[j];
                 const bool ok = pv && n_ok[j] && (unsigned)yy < (unsigned)p.H && (unsigned)xc < (unsigned)p.W;
-                bv[j] = ok ? p.x[((b * p.H + yy) * p.W + xc) * p.x_ld + n_ci[j]] : 0.f;
+                bv[j] = ok ? xf[((b * p.H + yy) * p.W + xc) * p.x_ld + n_ci[j]] : 0.f;
             }
         }
 #pragma unroll
@@ -112,15 +114,17 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgradParams p) {
             }
 }
 
-// dw[o][ci][ky][kx] (OIHW) = sum over the pixel slices.  32 outputs x 8 lanes per workgroup: lane g sums slices g, g+8, ...
-// and the 8 lane sums are combined in lane order (fixed order -> deterministic; a tiny CxC output with 2048 slices would
-// otherwise be one workgroup walking them serially).
+// dw[o][ci][ky][kx] (OIHW) = sum over the pixel slices.  256/LPO outputs x LPO lanes per workgroup: lane g sums slices g,
+// g+LPO, ... and the lane sums are combined in lane order (fixed order -> deterministic; a tiny CxC output with 2048
+// slices would otherwise be one workgroup walking them serially).  LPO = 64 for the tiny outputs, 8 otherwise.
+template <int LPO>
 __global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ksplit,
                                                              int Mpad, int Npad, int Cout, int Cin, int k) {
-    __shared__ float red[8][32];
+    constexpr int OPW = kBlock / LPO;
+    __shared__ float red[LPO][OPW];
     const long total = (long)Cout * Cin * k * k;
-    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
-    for (long i0 = (long)blockIdx.x * 32; i0 < total; i0 += (long)gridDim.x * 32) {
+    const int el = threadIdx.x % OPW, g = threadIdx.x / OPW;
+    for (long i0 = (long)blockIdx.x * OPW; i0 < total; i0 += (long)gridDim.x * OPW) {
         const long i = i0 + el;
         float s = 0.f;
         if (i < total) {
@@ -131,7 +135,7 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __res
             const int ci = (int)(r % Cin);
             const int o = (int)(r / Cin);
             const int n = (ky * k + kx) * Cin + ci;
-            for (int q = g; q < ksplit; q += 8) s += ws[((size_t)q * Mpad + o) * Npad + n];
+            for (int q = g; q < ksplit; q += LPO) s += ws[((size_t)q * Mpad + o) * Npad + n];
         }
         __syncthreads();
         red[g][el] = s;
@@ -139,10 +143,52 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __res
         if (g == 0 && i < total) {
             float t = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) t += red[j][el];
+            for (int j = 0; j < LPO; ++j) t += red[j][el];
             dw[i] = t;
         }
     }
+}
+
+// The same sum for the larger outputs, walking the padded [Mpad][Npad] slices as they lie in memory: a wave reads 1 KB
+// contiguous per slice (float4 per lane), the 4 waves take slices w, w+4, ... and are combined in wave order.
+__global__ void __launch_bounds__(kBlock) wgrad_reduce_vec_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ksplit,
+                                                                 int Mpad, int Npad, int Cout, int Cin, int k) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long slice = (long)Mpad * Npad;
+    const long e0 = ((long)blockIdx.x * 64 + lane) * 4;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (e0 < slice)
+        for (int q = wave; q < ksplit; q += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)q * slice + e0);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    red[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && e0 < slice) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { t[0] += red[w][lane].x; t[1] += red[w][lane].y; t[2] += red[w][lane].z; t[3] += red[w][lane].w; }
+        const int m = (int)(e0 / Npad), n0 = (int)(e0 % Npad), N = k * k * Cin;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + j;
+            if (m < Cout && n < N) dw[((size_t)m * Cin + n % Cin) * (k * k) + n / Cin] = t[j];
+        }
+    }
+}
+
+static void launch_wgrad_reduce(const float* ws, float* dw, int ksplit, int Mpad, int Npad, int Cout, int Cin, int k, hipStream_t s) {
+    const long slice = (long)Mpad * Npad;
+    if (slice >= 16384 && Npad % 4 == 0)
+        hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((int)cdiv(slice, 256)), dim3(kBlock), 0, s, ws, dw, ksplit, Mpad, Npad, Cout,
+                           Cin, k);
+    else if ((long)Cout * Cin * k * k <= 4096 && ksplit >= 256)
+        hipLaunchKernelGGL((wgrad_reduce_kernel<64>), dim3(stream_grid((long)Cout * Cin * k * k, 4)), dim3(kBlock), 0, s, ws, dw, ksplit,
+                           Mpad, Npad, Cout, Cin, k);
+    else
+        hipLaunchKernelGGL((wgrad_reduce_kernel<8>), dim3(stream_grid((long)Cout * Cin * k * k, 32)), dim3(kBlock), 0, s, ws, dw, ksplit,
+                           Mpad, Npad, Cout, Cin, k);
 }
 
 // wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: the forward conv kernel on wt is the data gradient of conv(., w)
@@ -162,10 +208,17 @@ __global__ void flip_weights_kernel(const float* __restrict__ w, float* __restri
 // ----------------------------------------------------------------------------- scale / ReLU backward + channel sums
 // dc[p][c] = dy[p][c] * [y[p][c] > 0 if relu] * exp(f * mul[c])          (dc nullable; mul nullable = factor 1)
 // part[blk][0][c] = sum_p dy*y (masked)      part[blk][1][c] = sum_p dc   (y nullable: first sum skipped)
-template <int CT>
-__global__ void __launch_bounds__(kBlock) scale_bwd_kernel(const float* __restrict__ dy, int dy_ld, const float* __restrict__ y,
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(__bf16* p, float v) { *p = (__bf16)v; }
+
+// TDY / TY / TDC: fp32 or bf16 storage of the incoming gradient, the saved output and the produced gradient (bf16 training
+// mode keeps the 512-channel hidden tensors and their gradients in bf16: they are bf16 MFMA operands anyway)
+template <int CT, typename TDY, typename TY, typename TDC>
+__global__ void __launch_bounds__(kBlock) scale_bwd_kernel(const TDY* __restrict__ dy, int dy_ld, const TY* __restrict__ y,
                                                           int y_ld, const float* __restrict__ mul, float f, int relu,
-                                                          long npix, int C, float* __restrict__ dc, int dc_ld,
+                                                          long npix, int C, TDC* __restrict__ dc, int dc_ld,
                                                           double* __restrict__ part, long rows_per_block) {
     constexpr int RT = kBlock / CT;
     constexpr int MAXC = 4;
@@ -193,8 +246,8 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_kernel(const float* __restri
                 for (int q = 0; q < MAXC; ++q) {
                     const int c = cb + q * CT + tx;
                     const bool ok = r < r1 && c < C;
-                    gv[u][q] = ok ? dy[r * dy_ld + c] : 0.f;
-                    yv[u][q] = (ok && y != nullptr) ? y[r * y_ld + c] : 0.f;
+                    gv[u][q] = ok ? ldf(dy + r * dy_ld + c) : 0.f;
+                    yv[u][q] = (ok && y != nullptr) ? ldf(y + r * y_ld + c) : 0.f;
                 }
             }
 #pragma unroll
@@ -210,7 +263,7 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_kernel(const float* __restri
                             s_mul[q] += (double)__fmul_rn(g, yv[u][q]);
                         }
                         const float d = __fmul_rn(g, fac[q]);
-                        if (dc != nullptr) dc[r * dc_ld + c] = d;
+                        if (dc != nullptr) stf(dc + r * dc_ld + c, d);
                         s_add[q] += (double)d;
                     }
                 }
@@ -233,16 +286,112 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_kernel(const float* __restri
     }
 }
 
-// One workgroup per 32 channels: 8 lanes of partials per channel (lane g takes blocks g, g+8, ...), combined in lane order.
-// (With one thread per channel the whole partial buffer - tens of MB for C = 512 - went through C/256 = 2 CUs.)
+// Vector form for C % 8 == 0 (the 512-channel hidden tensors): a thread owns 8 consecutive channels of a pixel, i.e. 16-byte
+// (bf16) or 2 x 16-byte (fp32) accesses.  The scalar kernel above issues one 4- or 2-byte access per lane and is bound by
+// the number of memory instructions, not by HBM: halving the bytes (bf16 storage) left its time unchanged.
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const __bf16* p, float (&v)[8]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8(__bf16* p, const float (&v)[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+template <int TPR, typename TDY, typename TY, typename TDC>
+__global__ void __launch_bounds__(kBlock) scale_bwd_vec_kernel(const TDY* __restrict__ dy, int dy_ld, const TY* __restrict__ y,
+                                                              int y_ld, const float* __restrict__ mul, float f, int relu,
+                                                              long npix, int C, TDC* __restrict__ dc, int dc_ld,
+                                                              double* __restrict__ part, long rows_per_block) {
+    constexpr int RT = kBlock / TPR;
+    constexpr int UR = 4;
+    __shared__ double red[2][RT][TPR * 8];
+    const int tx = threadIdx.x % TPR, ty = threadIdx.x / TPR;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = (r0 + rows_per_block) < npix ? (r0 + rows_per_block) : npix;
+    const int C8 = C >> 3;
+    for (int cb = 0; cb < C8; cb += TPR) {
+        const int cg = cb + tx;
+        const bool cok = cg < C8;
+        const int c = cg * 8;
+        double s_mul[8], s_add[8];
+        float fac[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s_mul[j] = 0.0; s_add[j] = 0.0;
+            fac[j] = (mul != nullptr && cok) ? expf(__fmul_rn(f, mul[c + j])) : 1.0f;
+        }
+        if (cok)
+            for (long rb = r0 + ty; rb < r1; rb += (long)RT * UR) {
+                float gv[UR][8], yv[UR][8];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const long r = rb + (long)u * RT;
+                    if (r < r1) {
+                        ld8(dy + r * dy_ld + c, gv[u]);
+                        if (y != nullptr) ld8(y + r * y_ld + c, yv[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const long r = rb + (long)u * RT;
+                    if (r < r1) {
+                        float d[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float g = gv[u][j];
+                            if (y != nullptr) {
+                                if (relu && !(yv[u][j] > 0.f)) g = 0.f;
+                                s_mul[j] += (double)__fmul_rn(g, yv[u][j]);
+                            }
+                            d[j] = __fmul_rn(g, fac[j]);
+                        }
+                        if (dc != nullptr) st8(dc + r * dc_ld + c, d);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) s_add[j] += (double)d[j];
+                    }
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[0][ty][tx * 8 + j] = s_mul[j];
+            red[1][ty][tx * 8 + j] = s_add[j];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 2 * TPR * 8; idx += kBlock) {
+            const int which = idx / (TPR * 8), col = idx % (TPR * 8);
+            const int ch = cb * 8 + col;
+            if (ch < C) {
+                double a = 0.0;
+                for (int t = 0; t < RT; ++t) a += red[which][t][col];
+                part[((size_t)blockIdx.x * 2 + which) * C + ch] = a;
+            }
+        }
+    }
+}
+
+// One workgroup per 16 channels: 16 lanes of partials per channel (lane g takes blocks g, g+16, ...), combined in lane
+// order.  (With one thread per channel the whole partial buffer - MBs for C = 512 - went through C/256 = 2 CUs.)
 __global__ void __launch_bounds__(kBlock) scale_bwd_finish_kernel(const double* __restrict__ part, int nblk, int C, float f,
                                                                  float* __restrict__ dmul, float* __restrict__ dadd) {
-    __shared__ double red[2][8][32];
-    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cl;
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int q = g; q < nblk; q += 8) {
+        for (int q = g; q < nblk; q += 16) {
             a += part[((size_t)q * 2 + 0) * C + c];
             b += part[((size_t)q * 2 + 1) * C + c];
         }
@@ -251,7 +400,7 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_finish_kernel(const double* 
     __syncthreads();
     if (g == 0 && c < C) {
         double sa = 0.0, sb = 0.0;
-        for (int t = 0; t < 8; ++t) { sa += red[0][t][cl]; sb += red[1][t][cl]; }
+        for (int t = 0; t < 16; ++t) { sa += red[0][t][cl]; sb += red[1][t][cl]; }
         if (dmul) dmul[c] = (float)(sa * (double)f);
         if (dadd) dadd[c] = (float)sb;
     }
@@ -309,16 +458,31 @@ __global__ void gauss_logp_bwd_kernel(const float* __restrict__ z, int z_ld, con
 
 // ----------------------------------------------------------------------------- conv weight gradient, bf16 MFMA
 // Same GEMM (reduction over pixels), operands rounded to bf16, fp32 accumulation: v_mfma_f32_32x32x16_bf16 wants 8
-// consecutive k (= pixels) per lane for one row/column (= channel), i.e. the TRANSPOSE of the NHWC tiles.  The fp32 tiles
-// are read with coalesced float4 loads (4 channels of one pixel), converted, and written to LDS transposed
-// ([channel][pixel], 16-bit scalar stores), so both MFMA operands are plain ds_read_b128.  A workgroup owns a 128 x 128
-// block of dW and a slice of the pixels (32 per stage, register-staged double buffering); 4 waves as 2 x 2, each 2 x 2
-// accumulator tiles.  Requires Cin % 4 == 0 (the 4 values of a float4 of the im2col row share a tap).
-constexpr int WB_BM = 128, WB_BN = 128, WB_KC = 32, WB_LD = WB_KC + 8;     // LDS row stride in bf16 elements (80 B)
+// consecutive k (= pixels) per lane for one row/column (= channel), i.e. the TRANSPOSE of the NHWC tiles.  The tiles are
+// staged in LDS as they lie in memory ([pixel][channel], 8-byte stores of 4 channels) and read with gfx950's transposing
+// ds_read_b64_tr_b16: per 16-lane group a 4-pixel x 16-channel block comes back channel-major, two reads make one
+// 8-pixel operand.  Row stride 320 B puts the 4 pixel rows of a 32-lane half on disjoint 64-byte bank groups (conflict-free).
+// A workgroup owns a 128 x 128 block of dW and a slice of the pixels (32 per stage, register-staged double buffering);
+// 4 waves as 2 x 2, each 2 x 2 accumulator tiles.  Requires Cin % 4 == 0 (4 staged values of the im2col row share a tap).
+constexpr int WB_BM = 128, WB_BN = 128, WB_KC = 32, WB_RS = WB_BM + 32;    // LDS row stride in bf16 elements (320 B)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// 8 consecutive pixels (rows r0..r0+7 of a [pixel][channel] image) of this lane's channel: `p` already holds the lane's
+// gather address (row q = (lane%16)/4, columns 4*(lane%4).. of its group's 16-channel block)
+__device__ __forceinline__ bf16x8 tr_read8(const __bf16* p) {
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)p);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * WB_RS));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// XB / DB: the x / dy operand is stored as bf16 (loaded 4 values = 8 bytes at a time, no conversion) instead of fp32
+template <bool XB, bool DB>
 __global__ void __launch_bounds__(kBlock) wgrad_bf16_kernel(const WgradParams p) {
-    __shared__ __attribute__((aligned(16))) __bf16 At[2][WB_BM][WB_LD];
-    __shared__ __attribute__((aligned(16))) __bf16 Bt[2][WB_BN][WB_LD];
+    __shared__ __attribute__((aligned(16))) __bf16 At[2][WB_KC][WB_RS];
+    __shared__ __attribute__((aligned(16))) __bf16 Bt[2][WB_KC][WB_RS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bid = blockIdx.x;
@@ -344,22 +508,32 @@ __global__ void __launch_bounds__(kBlock) wgrad_bf16_kernel(const WgradParams p)
         b_dy[i] = tap / p.k - pad;
         b_dx[i] = tap % p.k - pad;
     }
-    float4 ra[4], rb[4];
+    bf16x4 ra[4], rb[4];                                       // staged already rounded to bf16
+    auto load4 = [](const void* base, long off, bool is_bf16) -> bf16x4 {
+        bf16x4 r;
+        if (is_bf16) {
+            r = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(base) + off);
+        } else {
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+            r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;
+        }
+        return r;
+    };
     auto load_stage = [&](long p0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int px_l = ((tid + kBlock * i) * 4) / WB_BM;             // 0..31
             const long px = p0 + px_l;
             const bool pv = px < p_end;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pv && a_ok[i]) ra[i] = *reinterpret_cast<const float4*>(p.dy + px * p.dy_ld + a_m[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ra[i][j] = (__bf16)0.f; rb[i][j] = (__bf16)0.f; }
+            if (pv && a_ok[i]) ra[i] = load4(p.dy, px * p.dy_ld + a_m[i], DB);
             if (pv && b_ok[i]) {
                 const long b = px / HW;
                 const int r = (int)(px - b * HW);
                 const int y = r / p.W + b_dy[i], xx = r % p.W + b_dx[i];
                 if ((unsigned)y < (unsigned)p.H && (unsigned)xx < (unsigned)p.W)
-                    rb[i] = *reinterpret_cast<const float4*>(p.x + ((b * p.H + y) * p.W + xx) * p.x_ld + b_ci[i]);
+                    rb[i] = load4(p.x, ((b * p.H + y) * p.W + xx) * p.x_ld + b_ci[i], XB);
             }
         }
     };
@@ -368,10 +542,8 @@ __global__ void __launch_bounds__(kBlock) wgrad_bf16_kernel(const WgradParams p)
         for (int i = 0; i < 4; ++i) {
             const int e = (tid + kBlock * i) * 4;
             const int px_l = e / WB_BM, c0 = e % WB_BM;
-            At[buf][c0 + 0][px_l] = (__bf16)ra[i].x; At[buf][c0 + 1][px_l] = (__bf16)ra[i].y;
-            At[buf][c0 + 2][px_l] = (__bf16)ra[i].z; At[buf][c0 + 3][px_l] = (__bf16)ra[i].w;
-            Bt[buf][c0 + 0][px_l] = (__bf16)rb[i].x; Bt[buf][c0 + 1][px_l] = (__bf16)rb[i].y;
-            Bt[buf][c0 + 2][px_l] = (__bf16)rb[i].z; Bt[buf][c0 + 3][px_l] = (__bf16)rb[i].w;
+            *reinterpret_cast<bf16x4*>(&At[buf][px_l][c0]) = ra[i];
+            *reinterpret_cast<bf16x4*>(&Bt[buf][px_l][c0]) = rb[i];
         }
     };
     f32x16 acc[2][2];
@@ -383,6 +555,8 @@ __global__ void __launch_bounds__(kBlock) wgrad_bf16_kernel(const WgradParams p)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int c32 = lane & 31, g = lane >> 5;
+    // transposing-read gather address of this lane inside a 16-pixel x 32-channel operand block
+    const int tr_off = (8 * g + ((lane & 15) >> 2)) * WB_RS + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
     load_stage(p_begin);
     store_stage(0);
     __syncthreads();
@@ -394,11 +568,9 @@ __global__ void __launch_bounds__(kBlock) wgrad_bf16_kernel(const WgradParams p)
         for (int kstep = 0; kstep < WB_KC / 16; ++kstep) {
             bf16x8 af[2], bfr[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(&At[buf][wm * 64 + i * 32 + c32][kstep * 16 + 8 * g]);
+            for (int i = 0; i < 2; ++i) af[i] = tr_read8(&At[buf][kstep * 16][wm * 64 + i * 32] + tr_off);
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bfr[j] = *reinterpret_cast<const bf16x8*>(&Bt[buf][wn * 64 + j * 32 + c32][kstep * 16 + 8 * g]);
+            for (int j = 0; j < 2; ++j) bfr[j] = tr_read8(&Bt[buf][kstep * 16][wn * 64 + j * 32] + tr_off);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -512,9 +684,7 @@ extern "C" int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, in
     else if (MT == 1 && NT == 4) launch_wgrad<1, 4>(p, s);
     else if (MT == 1 && NT == 2) launch_wgrad<1, 2>(p, s);
     else launch_wgrad<1, 1>(p, s);
-    const long total = (long)Cout * Cin * k * k;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(total, 32)), dim3(kBlock), 0, s, p.ws, dw, p.ksplit, p.Mpad,
-                       p.Npad, Cout, Cin, k);
+    launch_wgrad_reduce(p.ws, dw, p.ksplit, p.Mpad, p.Npad, Cout, Cin, k, s);
     NFDP_CHECK_LAUNCH("conv_wgrad");
     return NFDP_OK;
 }
@@ -530,16 +700,44 @@ extern "C" int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int 
 
 static int scale_bwd_blocks(long npix) {
     long g = cdiv(npix, 32);
-    if (g > 2048) g = 2048;
+    if (g > 512) g = 512;            // 2 workgroups per CU; every block costs 2 C doubles of partials the finish kernel re-reads
     if (g < 1) g = 1;
     return (int)g;
 }
 
 extern "C" size_t nfdp_scale_bwd_ws_bytes(long npix, int C) { return (size_t)scale_bwd_blocks(npix) * 2 * C * sizeof(double); }
 
-extern "C" int nfdp_scale_bwd_f32(const float* dy, int dy_ld, const float* y, int y_ld, const float* mul, float f, int relu,
-                                  long npix, int C, float* dc, int dc_ld, float* dmul, float* dadd, void* ws,
-                                  nfdp_stream_t stream) {
+template <typename TDY, typename TY, typename TDC>
+static void launch_scale_bwd(const void* dy, int dy_ld, const void* y, int y_ld, const float* mul, float f, int relu, long npix,
+                             int C, void* dc, int dc_ld, double* part, int nblk, long rows, hipStream_t s) {
+    const TDY* a = reinterpret_cast<const TDY*>(dy);
+    const TY* b = reinterpret_cast<const TY*>(y);
+    TDC* c = reinterpret_cast<TDC*>(dc);
+    const bool vec = C >= 64 && C % 8 == 0 && dy_ld % 8 == 0 && (y == nullptr || y_ld % 8 == 0) && (dc == nullptr || dc_ld % 8 == 0) &&
+                     (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dc) & 15) == 0;
+    if (vec && C > 512)
+        hipLaunchKernelGGL((scale_bwd_vec_kernel<256, TDY, TY, TDC>), dim3(nblk), dim3(kBlock), 0, s, a, dy_ld, b, y_ld, mul, f, relu,
+                           npix, C, c, dc_ld, part, rows);
+    else if (vec && C > 128)
+        hipLaunchKernelGGL((scale_bwd_vec_kernel<64, TDY, TY, TDC>), dim3(nblk), dim3(kBlock), 0, s, a, dy_ld, b, y_ld, mul, f, relu,
+                           npix, C, c, dc_ld, part, rows);
+    else if (vec)
+        hipLaunchKernelGGL((scale_bwd_vec_kernel<16, TDY, TY, TDC>), dim3(nblk), dim3(kBlock), 0, s, a, dy_ld, b, y_ld, mul, f, relu,
+                           npix, C, c, dc_ld, part, rows);
+    else if (C > 128)
+        hipLaunchKernelGGL((scale_bwd_kernel<256, TDY, TY, TDC>), dim3(nblk), dim3(kBlock), 0, s, a, dy_ld, b, y_ld, mul, f, relu, npix,
+                           C, c, dc_ld, part, rows);
+    else if (C > 32)
+        hipLaunchKernelGGL((scale_bwd_kernel<64, TDY, TY, TDC>), dim3(nblk), dim3(kBlock), 0, s, a, dy_ld, b, y_ld, mul, f, relu, npix,
+                           C, c, dc_ld, part, rows);
+    else
+        hipLaunchKernelGGL((scale_bwd_kernel<16, TDY, TY, TDC>), dim3(nblk), dim3(kBlock), 0, s, a, dy_ld, b, y_ld, mul, f, relu, npix,
+                           C, c, dc_ld, part, rows);
+}
+
+extern "C" int nfdp_scale_bwd(const void* dy, int dy_dtype, int dy_ld, const void* y, int y_dtype, int y_ld, const float* mul,
+                              float f, int relu, long npix, int C, void* dc, int dc_dtype, int dc_ld, float* dmul, float* dadd,
+                              void* ws, nfdp_stream_t stream) {
     NFDP_REQUIRE(dy && ws, NFDP_EINVAL, "scale_bwd: null pointer");
     NFDP_REQUIRE(npix > 0 && C > 0 && C <= 4096 && dy_ld >= C, NFDP_ESHAPE, "scale_bwd: bad shape npix=%ld C=%d", npix, C);
     NFDP_REQUIRE((y == nullptr || y_ld >= C) && (dc == nullptr || dc_ld >= C), NFDP_ESHAPE, "scale_bwd: bad pixel stride");
@@ -547,18 +745,25 @@ extern "C" int nfdp_scale_bwd_f32(const float* dy, int dy_ld, const float* y, in
     const long rows = cdiv(npix, nblk);
     double* part = reinterpret_cast<double*>(ws);
     hipStream_t s = as_stream(stream);
-    if (C > 128)
-        hipLaunchKernelGGL((scale_bwd_kernel<256>), dim3(nblk), dim3(kBlock), 0, s, dy, dy_ld, y, y_ld, mul, f, relu, npix, C, dc,
-                           dc_ld, part, rows);
-    else if (C > 32)
-        hipLaunchKernelGGL((scale_bwd_kernel<64>), dim3(nblk), dim3(kBlock), 0, s, dy, dy_ld, y, y_ld, mul, f, relu, npix, C, dc,
-                           dc_ld, part, rows);
-    else
-        hipLaunchKernelGGL((scale_bwd_kernel<16>), dim3(nblk), dim3(kBlock), 0, s, dy, dy_ld, y, y_ld, mul, f, relu, npix, C, dc,
-                           dc_ld, part, rows);
-    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 32)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
+    const int combo = (dy_dtype == NFDP_BF16 ? 4 : 0) | ((y && y_dtype == NFDP_BF16) ? 2 : 0) | ((dc && dc_dtype == NFDP_BF16) ? 1 : 0);
+    switch (combo) {
+        case 0: launch_scale_bwd<float, float, float>(dy, dy_ld, y, y_ld, mul, f, relu, npix, C, dc, dc_ld, part, nblk, rows, s); break;
+        case 3: launch_scale_bwd<float, __bf16, __bf16>(dy, dy_ld, y, y_ld, mul, f, relu, npix, C, dc, dc_ld, part, nblk, rows, s); break;
+        case 7: launch_scale_bwd<__bf16, __bf16, __bf16>(dy, dy_ld, y, y_ld, mul, f, relu, npix, C, dc, dc_ld, part, nblk, rows, s); break;
+        default:
+            nfdp_set_error("scale_bwd: unsupported dtype combination dy=%d y=%d dc=%d (f32/f32/f32, f32/bf16/bf16, bf16/bf16/bf16)",
+                           dy_dtype, y_dtype, dc_dtype);
+            return NFDP_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 16)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
     NFDP_CHECK_LAUNCH("scale_bwd");
     return NFDP_OK;
+}
+
+extern "C" int nfdp_scale_bwd_f32(const float* dy, int dy_ld, const float* y, int y_ld, const float* mul, float f, int relu,
+                                  long npix, int C, float* dc, int dc_ld, float* dmul, float* dadd, void* ws,
+                                  nfdp_stream_t stream) {
+    return nfdp_scale_bwd(dy, NFDP_F32, dy_ld, y, NFDP_F32, y_ld, mul, f, relu, npix, C, dc, NFDP_F32, dc_ld, dmul, dadd, ws, stream);
 }
 
 extern "C" int nfdp_coupling_bwd_f32(const float* x, const float* h, const float* dy, const double* gl, int B, int HW, int C,
@@ -597,7 +802,7 @@ static void wgrad_bf16_plan(int B, int H, int W, int Cin, int Cout, int k, Wgrad
     p->Mpad = p->mblocks * WB_BM;
     p->Npad = p->nblocks * WB_BN;
     p->npix = (long)B * H * W;
-    long want = 1024 / ((long)p->mblocks * p->nblocks);     // ~4 workgroups per CU
+    long want = 512 / ((long)p->mblocks * p->nblocks);      // ~2 workgroups per CU: every pixel slice costs a partial tile the reduce re-reads
     if (want < 1) want = 1;
     if (want > 256) want = 256;
     long per = cdiv(p->npix, want);
@@ -615,24 +820,28 @@ extern "C" size_t nfdp_conv_wgrad_bf16_ws_bytes(int B, int H, int W, int Cin, in
     return (size_t)p.ksplit * p.Mpad * p.Npad * sizeof(float);
 }
 
-extern "C" int nfdp_conv_wgrad_bf16(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout,
-                                    int k, float* dw, void* ws, nfdp_stream_t stream) {
+extern "C" int nfdp_conv_wgrad_bf16(const void* x, int x_dtype, int x_ld, const void* dy, int dy_dtype, int dy_ld, int B, int H, int W,
+                                    int Cin, int Cout, int k, float* dw, void* ws, nfdp_stream_t stream) {
     NFDP_REQUIRE(x && dy && dw && ws, NFDP_EINVAL, "conv_wgrad_bf16: null pointer");
     NFDP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 7 && (k & 1), NFDP_ESHAPE,
                  "conv_wgrad_bf16: bad shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d", B, H, W, Cin, Cout, k);
     NFDP_REQUIRE(nfdp_conv_wgrad_bf16_supported(Cin, Cout), NFDP_EUNSUPPORTED,
                  "conv_wgrad_bf16: Cin=%d and Cout=%d must be multiples of 4 (use nfdp_conv_wgrad_f32)", Cin, Cout);
-    NFDP_REQUIRE(x_ld >= Cin && dy_ld >= Cout && x_ld % 4 == 0 && dy_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
-                 NFDP_ESHAPE, "conv_wgrad_bf16: operands must be 16-byte aligned with pixel strides that are multiples of 4");
+    const bool xb = x_dtype == NFDP_BF16, db = dy_dtype == NFDP_BF16;
+    NFDP_REQUIRE(x_ld >= Cin && dy_ld >= Cout && x_ld % 4 == 0 && dy_ld % 4 == 0 && ((uintptr_t)x & (xb ? 7 : 15)) == 0 &&
+                     ((uintptr_t)dy & (db ? 7 : 15)) == 0,
+                 NFDP_ESHAPE, "conv_wgrad_bf16: operands must be aligned to 4 elements with pixel strides that are multiples of 4");
     WgradParams p;
     wgrad_bf16_plan(B, H, W, Cin, Cout, k, &p);
     p.x = x; p.dy = dy; p.ws = reinterpret_cast<float*>(ws);
     p.x_ld = x_ld; p.dy_ld = dy_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.k = k;
     hipStream_t s = as_stream(stream);
-    hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(p.mblocks * p.nblocks * p.ksplit), dim3(kBlock), 0, s, p);
-    const long total = (long)Cout * Cin * k * k;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(stream_grid(total, 32)), dim3(kBlock), 0, s, p.ws, dw, p.ksplit, p.Mpad,
-                       p.Npad, Cout, Cin, k);
+    const dim3 grid(p.mblocks * p.nblocks * p.ksplit);
+    if (xb && db) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true>), grid, dim3(kBlock), 0, s, p);
+    else if (xb) hipLaunchKernelGGL((wgrad_bf16_kernel<true, false>), grid, dim3(kBlock), 0, s, p);
+    else if (db) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true>), grid, dim3(kBlock), 0, s, p);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false>), grid, dim3(kBlock), 0, s, p);
+    launch_wgrad_reduce(p.ws, dw, p.ksplit, p.Mpad, p.Npad, Cout, Cin, k, s);
     NFDP_CHECK_LAUNCH("conv_wgrad_bf16");
     return NFDP_OK;
 }

@@ -682,10 +682,19 @@ def prior_kl(x_start, sqrt_ac, log_one_minus_ac, t_index: int) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- backward (training step)
+def _dt(t: torch.Tensor) -> int:
+    return BF16 if t.dtype == torch.bfloat16 else F32
+
+
 def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int, compute: int = F32) -> torch.Tensor:
-    """-> dw [Cout,Cin,k,k] fp32 of a stride-1 'same' conv; xh, dyh pixel-strided NHWC fp32.  compute=BF16 runs the bf16-MFMA
-    kernel where its alignment rules allow (channel counts and pixel strides multiples of 4), else the exact-fp32 one."""
-    _need(xh, torch.float32, "conv_wgrad"); _need(dyh, torch.float32, "conv_wgrad")
+    """-> dw [Cout,Cin,k,k] fp32 of a stride-1 'same' conv; xh, dyh pixel-strided NHWC, fp32 (or bf16 with compute=BF16).
+    compute=BF16 runs the bf16-MFMA kernel where its alignment rules allow (channel counts and pixel strides multiples of 4),
+    else the exact-fp32 one."""
+    for a in (xh, dyh):
+        if not a.is_cuda:
+            raise NfdpError("conv_wgrad: the HIP path needs GPU tensors (no CPU fallback)")
+        if a.dtype not in (torch.float32, torch.bfloat16):
+            raise NfdpError(f"conv_wgrad: expected fp32 or bf16, got {a.dtype}")
     b, h, w, cin = xh.shape
     cout = dyh.shape[-1]
     if tuple(dyh.shape[:3]) != (b, h, w):
@@ -705,9 +714,11 @@ def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int, compute: int = F32) 
         xl, dl = _ld(xh, "conv_wgrad"), _ld(dyh, "conv_wgrad")
         if xl % 4 == 0 and dl % 4 == 0 and xh.data_ptr() % 16 == 0 and dyh.data_ptr() % 16 == 0:
             ws = torch.empty(lib().nfdp_conv_wgrad_bf16_ws_bytes(b, h, w, cin, cout, k), device=xh.device, dtype=torch.uint8)
-            _call("nfdp_conv_wgrad_bf16", _ptr(xh), xl, _ptr(dyh), dl, b, h, w, cin, cout, k, _ptr(dw), _ptr(ws), _stream(),
-                  label=f"conv_wgrad_bf16 k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout * k * k)
+            _call("nfdp_conv_wgrad_bf16", _ptr(xh), _dt(xh), xl, _ptr(dyh), _dt(dyh), dl, b, h, w, cin, cout, k, _ptr(dw), _ptr(ws),
+                  _stream(), label=f"conv_wgrad_bf16 k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout * k * k)
             return dw
+    if xh.dtype != torch.float32 or dyh.dtype != torch.float32:          # exact-fp32 kernel: fp32 operands only
+        xh, dyh = xh.float(), dyh.float()
     ws = torch.empty(lib().nfdp_conv_wgrad_ws_bytes(b, h, w, cin, cout, k), device=xh.device, dtype=torch.uint8)
     _call("nfdp_conv_wgrad_f32", _ptr(xh), _ld(xh, "conv_wgrad"), _ptr(dyh), _ld(dyh, "conv_wgrad"), b, h, w, cin, cout, k,
           _ptr(dw), _ptr(ws), _stream(), label=f"conv_wgrad k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout * k * k)
@@ -722,18 +733,23 @@ def conv_flip_weights(w_oihw: torch.Tensor) -> torch.Tensor:
     return wt
 
 
-def scale_bwd(dyh, yh=None, mul=None, f: float = 1.0, relu: bool = False, want_dc: bool = True):
-    """Backward of y = act((u + add) * exp(f*mul)) -> (dc or None, dmul [C] or None, dadd [C])."""
-    _need(dyh, torch.float32, "scale_bwd")
+def scale_bwd(dyh, yh=None, mul=None, f: float = 1.0, relu: bool = False, want_dc: bool = True, dc_dtype=None):
+    """Backward of y = act((u + add) * exp(f*mul)) -> (dc or None, dmul [C] or None, dadd [C]).  dyh / yh fp32 or bf16;
+    dc_dtype (torch dtype, default: dyh's... fp32 unless yh is bf16) selects the storage of dc."""
+    if dyh.dtype not in (torch.float32, torch.bfloat16) or not dyh.is_cuda:
+        raise NfdpError("scale_bwd: expected an fp32 or bf16 GPU tensor")
     c = dyh.shape[-1]
     npix = dyh.numel() // c
     dev = dyh.device
-    dc = torch.empty(dyh.shape, device=dev, dtype=torch.float32) if want_dc else None
+    if dc_dtype is None:
+        dc_dtype = torch.bfloat16 if (yh is not None and yh.dtype == torch.bfloat16) else torch.float32
+    dc = torch.empty(dyh.shape, device=dev, dtype=dc_dtype) if want_dc else None
     dmul = torch.empty(c, device=dev, dtype=torch.float32) if yh is not None else None
     dadd = torch.empty(c, device=dev, dtype=torch.float32)
     ws = torch.empty(lib().nfdp_scale_bwd_ws_bytes(npix, c), device=dev, dtype=torch.uint8)
-    _call("nfdp_scale_bwd_f32", _ptr(dyh), _ld4(dyh), _ptr(yh), _ld4(yh) if yh is not None else c, _ptr(mul), float(f), int(relu),
-          npix, c, _ptr(dc), c, _ptr(dmul), _ptr(dadd), _ptr(ws), _stream())
+    _call("nfdp_scale_bwd", _ptr(dyh), _dt(dyh), _ld4(dyh), _ptr(yh), _dt(yh) if yh is not None else F32,
+          _ld4(yh) if yh is not None else c, _ptr(mul), float(f), int(relu), npix, c, _ptr(dc), _dt(dc) if dc is not None else F32, c,
+          _ptr(dmul), _ptr(dadd), _ptr(ws), _stream())
     return dc, dmul, dadd
 
 

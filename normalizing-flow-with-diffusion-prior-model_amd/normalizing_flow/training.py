@@ -93,12 +93,15 @@ class ConvScaleFn(Function):
 
     @staticmethod
     def forward(ctx, xh, weight, add, mul, f, relu, packed, k, compute):
+        # bf16 mode: the 512-channel hidden activations (the ReLU outputs) are stored in bf16 - they are bf16 MFMA operands
+        # of the next conv and of its weight gradient anyway - which halves the HBM traffic that dominates the step
+        hidden_bf16 = compute == K.BF16 and bool(relu)
         if K.use_narrow_conv(weight.shape[1], weight.shape[0], k):       # 512 -> C: pointwise GEMM + tap shift-sum
             y = K.conv3x3_narrow(xh, weight, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1), mul_exp=float(f),
                                  relu=bool(relu), compute=compute)
         else:
             y = K.conv2d(xh, packed, weight.shape[0], k, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1),
-                         mul_exp=float(f), relu=bool(relu), compute=compute, out_dtype=K.F32)
+                         mul_exp=float(f), relu=bool(relu), compute=compute, out_dtype=K.BF16 if hidden_bf16 else K.F32)
         ctx.save_for_backward(xh, weight, mul, y)
         ctx.f, ctx.relu, ctx.k, ctx.compute = float(f), bool(relu), int(k), compute
         ctx.add_shape = add.shape
@@ -107,14 +110,17 @@ class ConvScaleFn(Function):
     @staticmethod
     def backward(ctx, dy):
         xh, weight, mul, y = ctx.saved_tensors
-        dc, dmul, dadd = K.scale_bwd(dy.contiguous(), y, mul.detach().reshape(-1), ctx.f, ctx.relu)
+        dc, dmul, dadd = K.scale_bwd(dy.contiguous(), y, mul.detach().reshape(-1), ctx.f, ctx.relu)   # dc in y's storage type
         dx = None
         if ctx.needs_input_grad[0]:
             wt = K.conv_flip_weights(weight.detach().contiguous())
             if K.use_narrow_conv(weight.shape[0], weight.shape[1], ctx.k):   # data gradient of C/2 -> 512: a 512 -> C/2 conv
                 dx = K.conv3x3_narrow(dc, wt, compute=ctx.compute)
             else:
-                dx = K.conv2d(dc, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute, out_dtype=K.F32)
+                dx = K.conv2d(dc, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute,
+                              out_dtype=K.BF16 if xh.dtype == torch.bfloat16 else K.F32)
+            if dx.dtype != xh.dtype:
+                dx = dx.to(xh.dtype)
         dw = K.conv_wgrad(xh, dc, ctx.k, compute=ctx.compute)
         return dx, dw, dadd.reshape(ctx.add_shape), dmul.view_as(mul), None, None, None, None, None
 

@@ -384,3 +384,26 @@ def test_conv_wgrad_bf16_on_channel_slice_not_multiple_of_4():
     assert any(e["label"].startswith("conv_wgrad_bf16") for e in K.stop_trace())
     assert tuple(dw.shape) == (512, 6, 3, 3)
     assert_close(dw, w.grad, 1e-2, "bf16 wgrad on a 6-of-12 channel slice")
+
+
+def test_mixed_dtype_scale_bwd_and_wgrad():
+    """bf16 storage of the hidden activations / gradients: the kernels must give what the fp32 kernels give on the same
+    (bf16-representable) values, up to the rounding of the bf16 dc output."""
+    c = 512
+    dy = rnd(2, 4, 4, c, seed=61).bfloat16()
+    y = torch.relu(rnd(2, 4, 4, c, seed=62)).bfloat16()
+    mul = rnd(c, seed=63, scale=0.2)
+    ref = K.scale_bwd(dy.float().to(DEV), y.float().to(DEV), mul.to(DEV), 1.0, True)
+    got = K.scale_bwd(dy.to(DEV), y.to(DEV), mul.to(DEV), 1.0, True)
+    assert got[0].dtype == torch.bfloat16
+    assert_close(got[0].float(), ref[0], 4e-3, "dc (bf16 storage)")
+    assert_close(got[1], ref[1], 1e-5, "dmul")
+    assert_close(got[2], ref[2], 1e-5, "dadd")
+    mixed = K.scale_bwd(dy.float().to(DEV), y.to(DEV), mul.to(DEV), 1.0, True)
+    assert mixed[0].dtype == torch.bfloat16
+    assert_close(mixed[0].float(), ref[0], 4e-3, "dc (fp32 dy, bf16 y)")
+    x = rnd(2, 8, 8, 512, seed=64).bfloat16().to(DEV)
+    d = rnd(2, 8, 8, 512, seed=65).bfloat16().to(DEV)
+    exact = K.conv_wgrad(x.float(), d.float(), 1)
+    for xx, dd in ((x, d), (x.float(), d), (x, d.float())):
+        assert_close(K.conv_wgrad(xx, dd, 1, compute=K.BF16), exact, 1e-5, f"wgrad {xx.dtype}/{dd.dtype}")
