@@ -145,11 +145,27 @@ def train_bench(args, rank, world, device, barrier):
 
     for _ in range(max(args.warmup, 1)):
         loss = train_step()
+    # One process, no collective inside the step: capture forward + backward + optimizer (~1600 kernel launches through the
+    # C ABI plus torch's glue) once as a hipGraph and replay it, so the host issues one call per step.
+    graphed = world == 1 and not args.no_graph
+    if graphed:
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = train_step()
+        run = graph.replay
+        run()
+        loss = static_loss
+    else:
+        def run():
+            nonlocal loss
+            loss = train_step()
     barrier()
-    log(f"training: timed region, loss {float(loss):.4f}, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+    log(f"training: timed region ({'hipGraph replay' if graphed else 'eager'}), loss {float(loss):.4f}, "
+        f"peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = train_step()
+        run()
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0, device)
     if rank == 0:
@@ -161,7 +177,7 @@ def train_bench(args, rank, world, device, barrier):
             "config": {"workload": f"Glow L={args.L} K={args.K} training step on 32x32x3, 5-bit, batch={args.batch}/GPU "
                                    "(BASELINE configs[2] shape; forward, bits/dim, backward, clip_grad_value_/norm_ 1, Adam lr 1e-4 - the synthetic trained-like weights diverge at the reference's 1e-3)",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "optimizer": "nfdp fused clip+Adam (flat buffers)",
+                       "optimizer": "nfdp fused clip+Adam (flat buffers)", "launch": "hipGraph replay" if graphed else "eager",
                        "gradient_allreduce": "bucketed, overlapped with backward" if world > 1 else "none"},
             "loss_bits_per_dim": round(float(loss), 6) if bool(torch.isfinite(loss)) else None,
             "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)

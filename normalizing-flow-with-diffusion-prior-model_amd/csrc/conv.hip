@@ -280,6 +280,127 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
     }
 }
 
+// ----------------------------------------------------------------------------- pointwise conv on bf16 activations
+// The 512->512 1x1 convs of the training path (forward and data gradient) and the 512 -> 9*C tap GEMMs read a bf16
+// activation tensor whose rows ARE the GEMM's K-contiguous operand rows: no gather, no conversion.  Both operands go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB = 8 rows x 128 B per wave instruction, no VGPRs), double
+// buffered: the DMA of K tile t+1 is issued before the MFMAs of tile t, one barrier per K tile.  The LDS image is
+// lane-linear, so the bank swizzle (16-byte chunk index ^ (row>>1)&7: the 16 rows of a ds_read_b128 lane group land on 16
+// distinct slots of the 256-byte bank row) is applied to the per-lane SOURCE address and again on the fragment read.
+// Roles are swapped against conv_kernel (A := weights, B := pixels) so a lane ends up with 4 consecutive output
+// channels of one pixel: 8- or 16-byte stores and float4 epilogue parameters.
+constexpr int PW_BM = 128, PW_BN = 128, PW_BK = 64;
+constexpr int PW_TILE_BYTES = PW_BM * PW_BK * 2;           // 16 KiB per operand per stage
+
+__global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvParams P) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];      // [2 stages][pixels 16 KiB | weights 16 KiB]
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int nt = slot % P.Nt;
+    const int mt = (slot / P.Nt) * 8 + xcd;
+    if (mt >= P.Mt) return;
+    const long m0 = (long)mt * PW_BM;
+    const int n0 = nt * PW_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int r16 = lane & 15, q = lane >> 4;
+    const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(P.x);
+    const __bf16* __restrict__ wg = reinterpret_cast<const __bf16*>(P.w);
+
+    // this lane's source rows for its wave's 4 pieces of each operand tile (piece = 8 rows x 128 B)
+    const __bf16* src_x[4];
+    const __bf16* src_w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);              // logical 16-byte chunk stored at this lane's slot
+        long px = m0 + row;
+        if (px >= P.npix) px = P.npix - 1;                         // tail rows: any valid address, results are not stored
+        src_x[i] = xg + px * P.x_ld + c * 8;
+        src_w[i] = wg + (size_t)(n0 + row) * P.Kpad + c * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * 2 * PW_TILE_BYTES + wave * 4 * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_x[i] + kt * PW_BK),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_w[i] + kt * PW_BK),
+                                             (__attribute__((address_space(3))) void*)(base + PW_TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+    f32x4 acc[4][4];                                               // [n tile][pixel tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes inside an operand tile) for k-step 0; k-step 1 flips chunk bit 2
+    int off_w[4], off_x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rw = wn * 64 + i * 16 + r16, rx = wm * 64 + i * 16 + r16;
+        off_w[i] = rw * 128 + ((q ^ ((rw >> 1) & 7)) << 4);
+        off_x[i] = rx * 128 + ((q ^ ((rx >> 1) & 7)) << 4);
+    }
+    const int nk = P.Kpad / PW_BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* xs = smem + cur * 2 * PW_TILE_BYTES;
+        const char* ws = xs + PW_TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8*>(ws + (off_w[i] ^ (ks << 6)));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8*>(xs + (off_x[j] ^ (ks << 6)));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                           // drains the DMA of tile kt+1 (vmcnt(0)) and frees buffer cur
+    }
+
+    // ---- epilogue: D[row = n = 4q + r][col = pixel = r16];  v = (acc + add[n]) * exp(f mul[n]); relu
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * q;
+        if (n >= P.Cout) continue;                                 // Cout % 4 == 0: the 4 channels are in or out together
+        float addv[4] = {0.f, 0.f, 0.f, 0.f}, mulv[4] = {1.f, 1.f, 1.f, 1.f};
+        if (P.add) { const float4 t = *reinterpret_cast<const float4*>(P.add + n); addv[0] = t.x; addv[1] = t.y; addv[2] = t.z; addv[3] = t.w; }
+        if (P.mul) {
+            const float4 t = *reinterpret_cast<const float4*>(P.mul + n);
+            mulv[0] = t.x; mulv[1] = t.y; mulv[2] = t.z; mulv[3] = t.w;
+            if (P.mul_exp != 0.f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mulv[r] = expf(__fmul_rn(mulv[r], P.mul_exp));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long px = m0 + wm * 64 + j * 16 + r16;
+            if (px >= P.npix) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[i][j][r];
+                if (P.add) v[r] = __fadd_rn(v[r], addv[r]);
+                if (P.mul) v[r] = __fmul_rn(v[r], mulv[r]);
+                if (P.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (P.y_bf16)
+                *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(P.y) + px * P.y_ld + n) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+            else
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + px * P.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // OIHW fp32 -> [Cout_pad][Kpad] in the compute dtype, k = (ky*KW+kx)*Cin+ci, zero padded
 template <bool BF16>
 __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int KH, int KW,
@@ -402,6 +523,24 @@ extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void
     // vector path: 4 consecutive k stay inside one tap and the 4-element load is naturally aligned
     const bool vec = (Cin % 4 == 0) && (x_ld % 4 == 0) && (((uintptr_t)x) % (4 * esz) == 0);
     hipStream_t s = as_stream(stream);
+    // pointwise conv on bf16 activations with a wide output: the LDS-DMA GEMM
+    const int y_esz = (y_dtype == NFDP_BF16) ? 2 : 4;
+    if (compute == NFDP_BF16 && x_dtype == NFDP_BF16 && KH == 1 && Cin % PW_BK == 0 && Cout > 64 && Cout % 4 == 0 && x_ld % 8 == 0 &&
+        ((uintptr_t)x % 16) == 0 && y_ld % 4 == 0 && ((uintptr_t)y % (4 * y_esz)) == 0 && (add == nullptr || (uintptr_t)add % 16 == 0) &&
+        (mul == nullptr || (uintptr_t)mul % 16 == 0) && npix >= 4 * PW_BM) {
+        P.Mt = (int)cdiv(npix, PW_BM);
+        P.Nt = cout_pad_for(Cout) / PW_BN;
+        const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      4 * PW_TILE_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(pw_gemm_bf16_kernel, dim3(grid), dim3(kThreads), 4 * PW_TILE_BYTES, s, P);
+        NFDP_CHECK_LAUNCH("conv2d (pointwise bf16 GEMM)");
+        return NFDP_OK;
+    }
     if (compute == NFDP_F32) {
         if (vec) launch_by_cout<false, false, true>(P, s);
         else launch_by_cout<false, false, false>(P, s);

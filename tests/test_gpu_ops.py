@@ -221,3 +221,30 @@ def test_invconv_logdets_multi_size_matches_fp64_slogdet():
         lad, _ = K.invconv_prepare(w.unsqueeze(0).contiguous(), want_inverse=False)
         assert abs(float(lad[0]) - float(v)) <= 2e-6
     assert torch.equal(K.invconv_logdets(dev).cpu().double(), got)            # deterministic
+
+
+@pytest.mark.parametrize("shape,cout,out_bf16", [((4, 16, 16, 512), 512, True), ((5, 11, 11, 512), 512, False),
+                                                  ((3, 16, 16, 512), 108, False), ((2, 16, 16, 128), 192, True)])
+def test_pointwise_bf16_gemm(shape, cout, out_bf16):
+    """1x1 conv on bf16 activations (LDS-DMA GEMM kernel): against an fp32 matmul of the same bf16-rounded operands with the
+    ActNorm-style epilogue; pixel counts that are not a multiple of the 128-pixel tile, Cout that is not a multiple of 128."""
+    b, h, w, cin = shape
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(shape, generator=g).bfloat16()
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5)
+    add = torch.randn(cout, generator=g) * 0.1
+    mul = torch.randn(cout, generator=g) * 0.1
+    ref = x.float().reshape(-1, cin) @ wt.reshape(cout, cin).bfloat16().float().t()
+    ref = torch.relu((ref + add) * torch.exp(3.0 * mul)).reshape(b, h, w, cout)
+    packed = K.conv_pack(wt.to(DEV), K.BF16)
+    got = K.conv2d(x.to(DEV), packed, cout, 1, add=add.to(DEV), mul=mul.to(DEV), mul_exp=3.0, relu=True, compute=K.BF16,
+                   out_dtype=K.BF16 if out_bf16 else K.F32)
+    assert got.dtype == (torch.bfloat16 if out_bf16 else torch.float32)
+    err = (got.float().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < (6e-3 if out_bf16 else 2e-5), err
+    # no epilogue, strided input view (a channel slice of a wider tensor)
+    wide = torch.randn(b, h, w, cin + 64, generator=g).bfloat16().to(DEV)
+    got2 = K.conv2d(wide[..., 64:], packed, cout, 1, compute=K.BF16)
+    ref2 = (wide[..., 64:].float().reshape(-1, cin) @ wt.reshape(cout, cin).bfloat16().float().t().to(DEV)).reshape(b, h, w, cout)
+    err2 = (got2 - ref2).abs().max().item() / ref2.abs().max().item()
+    assert err2 < 2e-5, err2
