@@ -435,9 +435,10 @@ class GaussianDiffusion(nn.Module):
         self._graphs = {}
 
     # ---- hipGraph-captured reverse step: eps = Unet(x, t) -> fused p_sample in place -> t -= 1, state on the device
-    def _step_inplace(self, xh: Tensor, tb: Tensor) -> None:
+    def _step_inplace(self, xh: Tensor, tb: Tensor, gen: Optional[torch.Generator] = None) -> None:
         eps = self.model.forward_nhwc(xh, tb)
-        K.p_sample(xh, eps, torch.randn_like(xh), tb, self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
+        noise = torch.randn_like(xh) if gen is None else torch.randn(xh.shape, device=xh.device, dtype=xh.dtype, generator=gen)
+        K.p_sample(xh, eps, noise, tb, self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
                    self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
                    want_x0=False, clip=True, out=xh)
         tb.sub_(1)
@@ -447,18 +448,24 @@ class GaussianDiffusion(nn.Module):
         if key not in self._graphs:
             xh = torch.zeros(shape_nhwc, device=device)
             tb = torch.zeros(shape_nhwc[0], device=device, dtype=torch.long)
+            # The step's noise comes from a generator of its own, registered with the graph: a replay writes the Philox
+            # offset into a device tensor that belongs to the GENERATOR, so graphs sharing the default generator and
+            # replayed on different streams (DiffusionPrior runs the latent parts concurrently) would overwrite each other's
+            # offsets.  p_sample_loop reseeds it from the default generator, so torch.manual_seed still fixes the samples.
+            gen = torch.Generator(device=device)
             warm = torch.cuda.Stream(device=device)           # warm-up off the default stream: packs weights, sets
             warm.wait_stream(torch.cuda.current_stream())     # kernel attributes, primes the allocator
             with torch.cuda.stream(warm):
                 for _ in range(2):
                     tb.fill_(1)
-                    self._step_inplace(xh, tb)
+                    self._step_inplace(xh, tb, gen)
             torch.cuda.current_stream().wait_stream(warm)
             g = torch.cuda.CUDAGraph()
+            g.register_generator_state(gen)
             tb.fill_(1)
             with torch.cuda.graph(g):
-                self._step_inplace(xh, tb)
-            self._graphs[key] = (g, xh, tb)
+                self._step_inplace(xh, tb, gen)
+            self._graphs[key] = (g, xh, tb, gen)
         return self._graphs[key]
 
     # ---- closed-form pieces
@@ -517,13 +524,12 @@ class GaussianDiffusion(nn.Module):
         device = self.betas.device
         b, c, h, w = shape
         if self.use_graph and x_T is None and noises is None and not return_all_timesteps and self.num_timesteps > 1:
-            g, xh, tb = self._captured_step((b, h, w, c), device)
-            xh.normal_()
-            tb.fill_(self.num_timesteps - 1)
-            for _ in range(self.num_timesteps - 1):           # t = T-1 .. 1 (the graph decrements t itself)
-                g.replay()
-            img, _ = self._p_sample_nhwc(xh, 0, None, False)   # t = 0: no noise
-            return self.unnormalize(K.as_nchw(img))
+            it = self.p_sample_loop_iter(shape)
+            try:
+                while True:
+                    next(it)
+            except StopIteration as done:
+                return done.value
         img = torch.randn((b, h, w, c), device=device) if x_T is None else K.to_nhwc(x_T.to(device)).contiguous()
         imgs = [img]
         for i, t in enumerate(reversed(range(0, self.num_timesteps))):
@@ -533,6 +539,32 @@ class GaussianDiffusion(nn.Module):
                 imgs.append(img)
         ret = K.as_nchw(img) if not return_all_timesteps else torch.stack([K.as_nchw(i) for i in imgs], dim=1)
         return self.unnormalize(ret)
+
+    def p_sample_loop_iter(self, shape):
+        """The captured-step loop as a generator: enqueues one timestep per next() on the CURRENT stream and returns the sample
+        through StopIteration.  DiffusionPrior drives one of these per latent part, each under its own stream, in round-robin,
+        so the parts' steps overlap on the GPU (a step is ~100 small kernels; one chain leaves most CUs idle)."""
+        with torch.no_grad():
+            device = self.betas.device
+            b, c, h, w = shape
+            g, xh, tb, gen = self._captured_step((b, h, w, c), device)
+            gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))       # from the default (CPU) generator: no device sync
+            xh.normal_(generator=gen)
+            tb.fill_(self.num_timesteps - 1)
+        for _ in range(self.num_timesteps - 1):               # t = T-1 .. 1 (the graph decrements t itself)
+            g.replay()
+            yield
+        with torch.no_grad():
+            img, _ = self._p_sample_nhwc(xh, 0, None, False)   # t = 0: no noise
+            return self.unnormalize(K.as_nchw(img))
+
+    def sample_iter(self, batch_size=16):
+        """Generator form of sample(): yields between timesteps where the loop can be interleaved with other chains (the
+        hipGraph path of p_sample_loop); the DDIM and eager loops run to completion inside the first next()."""
+        shape = (batch_size, self.channels, self.image_size, self.image_size)
+        if not self.is_ddim_sampling and self.use_graph and self.num_timesteps > 1:
+            return (yield from self.p_sample_loop_iter(shape))
+        return self.sample(batch_size)
 
     @torch.no_grad()
     def ddim_sample(self, shape, return_all_timesteps=False, x_T: Optional[Tensor] = None,

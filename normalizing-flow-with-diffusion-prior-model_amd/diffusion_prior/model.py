@@ -35,6 +35,9 @@ class DiffusionModel(nn.Module):
     def sample_latent(self, n_samples: int, return_all_timesteps: bool = False):
         return self.__diffusion.sample(batch_size=n_samples, return_all_timesteps=return_all_timesteps)
 
+    def sample_latent_iter(self, n_samples: int):
+        return self.__diffusion.sample_iter(batch_size=n_samples)
+
     def sample_latent_given_start(self, start):
         """(reference model.py:57-70)"""
         d = self.__diffusion
@@ -62,6 +65,8 @@ class DiffusionPrior(nn.Module):
                                                     channels=latent_channels[i])
                                      for i in range(self.latent_formater.get_num_latent_parts())])
         self.loss_type = self.priors[0].loss_type
+        self.concurrent_parts = True          # one HIP stream per latent part in the sampling loops (see _sample_parts)
+        self._part_streams = None
 
     def forward(self, latents: list) -> list:
         """List of per-part losses  (reference model.py:105-119)."""
@@ -71,15 +76,61 @@ class DiffusionPrior(nn.Module):
             losses.append(self.priors[i](processed_latents[i]))
         return losses
 
+    def _sample_parts(self, make) -> list:
+        """Runs one sampling chain per latent part; make(prior, idx) returns the chain as a generator that yields between
+        timesteps (or a plain result).  The chains are independent and each step is ~100 small kernels that leave most of the
+        256 CUs idle, so on a GPU every part gets its own HIP stream (its own hardware queue) and the host enqueues the
+        parts' timesteps in round-robin: the chains overlap (2x for the three MNIST/CIFAR parts).  Each chain draws its noise
+        from a generator of its own, seeded from the default generator in part order, so the samples are those of the
+        sequential loop (`concurrent_parts = False`) bit for bit."""
+        def drain(chain):
+            if not hasattr(chain, "__next__"):
+                return chain
+            try:
+                while True:
+                    next(chain)
+            except StopIteration as done:
+                return done.value
+
+        dev = next(self.priors[0].parameters()).device
+        if not (self.concurrent_parts and dev.type == "cuda" and len(self.priors) > 1) or torch.cuda.is_current_stream_capturing():
+            return [drain(make(prior, i)) for i, prior in enumerate(self.priors)]
+        cur = torch.cuda.current_stream(dev)
+        if self._part_streams is None or len(self._part_streams) != len(self.priors):
+            self._part_streams = [torch.cuda.Stream(device=dev) for _ in self.priors]
+        n = len(self.priors)
+        chains, outs, live = [None] * n, [None] * n, []
+        for i, prior in enumerate(self.priors):
+            self._part_streams[i].wait_stream(cur)
+            with torch.cuda.stream(self._part_streams[i]):
+                chains[i] = make(prior, i)
+                if hasattr(chains[i], "__next__"):
+                    live.append(i)
+                else:
+                    outs[i] = chains[i]
+        while live:
+            for i in list(live):
+                with torch.cuda.stream(self._part_streams[i]):
+                    try:
+                        next(chains[i])
+                    except StopIteration as done:
+                        outs[i] = done.value
+                        live.remove(i)
+        for side, out in zip(self._part_streams, outs):
+            cur.wait_stream(side)
+            if isinstance(out, torch.Tensor):
+                out.record_stream(cur)
+        return outs
+
     def sample_latents(self, n_samples: int, return_all_timesteps: bool = False) -> list:
         """(reference model.py:121-134)"""
         if not return_all_timesteps:
-            return self.latent_formater.postprocess([prior.sample_latent(n_samples, False) for prior in self.priors])
+            return self.latent_formater.postprocess(self._sample_parts(lambda prior, i: prior.sample_latent_iter(n_samples)))
         return [prior.sample_latent(n_samples, True) for prior in self.priors]
 
     @torch.no_grad()
     def sample_latents_given_start(self, latents: list) -> list:
-        return [prior.sample_latent_given_start(latents[idx]) for idx, prior in enumerate(self.priors)]
+        return self._sample_parts(lambda prior, idx: prior.sample_latent_given_start(latents[idx]))
 
     def evaluate_neg_log_likelihood(self, latents: list) -> list:
         neg_lls = []
