@@ -680,8 +680,9 @@ class GaussianDiffusion(nn.Module):
             raise NotImplementedError("self-conditioning is not on the hot path")
         return self._vb_term_nhwc(K.to_nhwc(x_start).contiguous(), K.to_nhwc(x_t).contiguous(), t.contiguous(), clip_denoised)
 
-    def _vb_step_inplace(self, x0h: Tensor, tb: Tensor, total: Tensor) -> None:
-        xth = K.q_sample(x0h, torch.randn_like(x0h), tb, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+    def _vb_step_inplace(self, x0h: Tensor, tb: Tensor, total: Tensor, gen: Optional[torch.Generator] = None) -> None:
+        noise = torch.randn_like(x0h) if gen is None else torch.randn(x0h.shape, device=x0h.device, dtype=x0h.dtype, generator=gen)
+        xth = K.q_sample(x0h, noise, tb, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
         self._vb_term_nhwc(x0h, xth, tb, True, total)
         tb.sub_(1)
 
@@ -691,19 +692,37 @@ class GaussianDiffusion(nn.Module):
             x0h = torch.zeros(shape_nhwc, device=device)
             tb = torch.zeros(shape_nhwc[0], device=device, dtype=torch.long)
             total = torch.zeros(shape_nhwc[0], device=device, dtype=torch.float64)
+            gen = torch.Generator(device=device)               # a generator per graph: see _captured_step
             warm = torch.cuda.Stream(device=device)
             warm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(warm):
                 for _ in range(2):
                     tb.fill_(1)
-                    self._vb_step_inplace(x0h, tb, total)
+                    self._vb_step_inplace(x0h, tb, total, gen)
             torch.cuda.current_stream().wait_stream(warm)
             g = torch.cuda.CUDAGraph()
+            g.register_generator_state(gen)
             tb.fill_(1)
             with torch.cuda.graph(g):
-                self._vb_step_inplace(x0h, tb, total)
-            self._graphs[key] = (g, x0h, tb, total)
+                self._vb_step_inplace(x0h, tb, total, gen)
+            self._graphs[key] = (g, x0h, tb, total, gen)
         return self._graphs[key]
+
+    def calc_neg_log_likelihood_iter(self, x_start):
+        """The captured variational-bound loop as a generator (one timestep per next(), the bound through StopIteration), so
+        DiffusionPrior can interleave the latent parts' loops on separate streams like the sampling chains."""
+        with torch.no_grad():
+            x0h = K.to_nhwc(x_start).contiguous()
+            g, x0s, tb, total, gen = self._captured_vb_step(tuple(x0h.shape), x0h.device)
+            gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
+            x0s.copy_(x0h)
+            total.zero_()
+            tb.fill_(self.num_timesteps - 1)
+        for _ in range(self.num_timesteps):
+            g.replay()
+            yield
+        with torch.no_grad():
+            return total.float() + self._prior_bpd(x_start)
 
     @torch.no_grad()
     def calc_neg_log_likelihood_loop(self, x_start, x_self_cond=None, clip_denoised=True,
@@ -715,20 +734,19 @@ class GaussianDiffusion(nn.Module):
         step, logical NCHW) replaces the randn_like draws."""
         if x_self_cond is not None:
             raise NotImplementedError("self-conditioning is not on the hot path")
+        if self.use_graph and noises is None:
+            it = self.calc_neg_log_likelihood_iter(x_start)
+            try:
+                while True:
+                    next(it)
+            except StopIteration as done:
+                return done.value
         x0h = K.to_nhwc(x_start).contiguous()
         b = x0h.shape[0]
-        if self.use_graph and noises is None:
-            g, x0s, tb, total = self._captured_vb_step(tuple(x0h.shape), x0h.device)
-            x0s.copy_(x0h)
-            total.zero_()
-            tb.fill_(self.num_timesteps - 1)
-            for _ in range(self.num_timesteps):
-                g.replay()
-        else:
-            total = torch.zeros(b, device=x0h.device, dtype=torch.float64)
-            for i, t in enumerate(reversed(range(self.num_timesteps))):
-                tb = torch.full((b,), t, device=x0h.device, dtype=torch.long)
-                nz = torch.randn_like(x0h) if noises is None else K.to_nhwc(noises[i].to(x0h.device)).contiguous()
-                xth = K.q_sample(x0h, nz, tb, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
-                self._vb_term_nhwc(x0h, xth, tb, True, total)
+        total = torch.zeros(b, device=x0h.device, dtype=torch.float64)
+        for i, t in enumerate(reversed(range(self.num_timesteps))):
+            tb = torch.full((b,), t, device=x0h.device, dtype=torch.long)
+            nz = torch.randn_like(x0h) if noises is None else K.to_nhwc(noises[i].to(x0h.device)).contiguous()
+            xth = K.q_sample(x0h, nz, tb, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
+            self._vb_term_nhwc(x0h, xth, tb, True, total)
         return total.float() + self._prior_bpd(x_start)

@@ -53,6 +53,12 @@ class DiffusionModel(nn.Module):
     def calc_neg_log_likelihood_loop(self, x):
         return self.__diffusion.calc_neg_log_likelihood_loop(x)
 
+    def calc_neg_log_likelihood_iter(self, x):
+        d = self.__diffusion
+        if d.use_graph and x.is_cuda:
+            return d.calc_neg_log_likelihood_iter(x)
+        return d.calc_neg_log_likelihood_loop(x)
+
 
 class DiffusionPrior(nn.Module):
     """Models the flow's prior with one diffusion model per latent part  (reference model.py:79-159)."""
@@ -133,12 +139,9 @@ class DiffusionPrior(nn.Module):
         return self._sample_parts(lambda prior, idx: prior.sample_latent_given_start(latents[idx]))
 
     def evaluate_neg_log_likelihood(self, latents: list) -> list:
-        neg_lls = []
         processed_latents = self.latent_formater.process_latents(latents)
-        for i in range(0, len(processed_latents)):
-            prior, latent = self.priors[i], processed_latents[i]
-            neg_lls.append(prior.calc_neg_log_likelihood_loop(latent) / np.prod(latent.shape[1:]))
-        return neg_lls
+        bounds = self._sample_parts(lambda prior, i: prior.calc_neg_log_likelihood_iter(processed_latents[i]))
+        return [bound / np.prod(latent.shape[1:]) for bound, latent in zip(bounds, processed_latents)]
 
     def interpolate_latents(self, latents1, latents2, lam):
         return [prior.interpolate_latent(latents1[idx], latents2[idx], lam) for idx, prior in enumerate(self.priors)]

@@ -79,6 +79,13 @@ def test_evaluate_neg_log_likelihood_and_bpd(vg):
     lat, _ = nf.transform(x - 0.5, torch.zeros(4, dtype=torch.float64, device=DEV))
     nlls = prior.evaluate_neg_log_likelihood(lat)
     assert len(nlls) == 2 and all(v.shape == (4,) and torch.isfinite(v).all() for v in nlls)
+    # the parts' loops interleaved on one stream each == the reference's part-after-part order, bit for bit
+    res = {}
+    for mode in (True, False):
+        prior.concurrent_parts = mode
+        torch.manual_seed(21)
+        res[mode] = [v.clone() for v in prior.evaluate_neg_log_likelihood(lat)]
+    assert all(torch.equal(a, b) for a, b in zip(res[True], res[False]))
     bpd = calculate_bpd_with_diff_prior(nf, prior, data_loader=batches, n_bits=5, n_bins=32.0, device=torch.device(DEV))
     bpd2 = calculate_bpd_with_diff_prior(nf, prior, data_loader=batches, n_bits=5, n_bins=32.0, device=torch.device(DEV),
                                          reference_accumulation=False)
