@@ -280,6 +280,160 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
     }
 }
 
+// ----------------------------------------------------------------------------- small fp32 convs: K split over the waves
+// The U-Net layers of the reverse-diffusion step (B*H*W of a few thousand pixels, K = 9*Cin up to 1728) fill the chip with one
+// 64x64 tile per CU, and conv_kernel then spends its time on the load -> LDS -> barrier -> MFMA round trip of each of its
+// K/32 tiles (24 us for 7.7 us of fp32 MFMA work).  Here every wave computes the WHOLE 64x64 tile over a quarter of the K
+// tiles: operands go global -> VGPR already in MFMA fragment shape (a lane's 8 consecutive k of one pixel / one output
+// channel = 32 contiguous bytes; the four q-lanes of a row cover a 128-byte line), double-buffered in registers, no LDS and
+// no barrier in the loop; the four partial tiles meet once in LDS and are summed in wave order (deterministic), then the
+// epilogue writes float4 rows.  Roles as in pw_gemm (A := weights) so a lane owns 4 consecutive output channels.
+// Needs Cin % 8 == 0 (8 consecutive k stay inside one tap), fp32 in and out.
+constexpr int SK_LD = 64 + 4;                                  // partial-tile row stride in floats
+#ifndef NFDP_SK_WAVES
+#define NFDP_SK_WAVES 8
+#endif
+#ifndef NFDP_SK_KL
+#define NFDP_SK_KL 4
+#endif
+constexpr int SK_WAVES = NFDP_SK_WAVES;                        // 8 = 2 waves per SIMD: one wave's load latency hides under the other's MFMAs
+constexpr int SK_KL = NFDP_SK_KL;                              // consecutive k per lane per stage (4 or 8): a stage is 4*SK_KL deep
+constexpr int SK_BK = 4 * SK_KL;
+constexpr int SK_THREADS = SK_WAVES * 64;
+constexpr int SK_LDS_BYTES = SK_WAVES * 64 * SK_LD * 4;
+
+__global__ void __launch_bounds__(SK_THREADS) conv_splitk_f32_kernel(const ConvParams P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* part = reinterpret_cast<float*>(smem);              // [SK_WAVES][64 pixels][SK_LD]
+    const int nt = blockIdx.x % P.Nt, mt = blockIdx.x / P.Nt;
+    const long m0 = (long)mt * 64;
+    const int n0 = nt * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, q = lane >> 4;
+    const float* __restrict__ xg = reinterpret_cast<const float*>(P.x);
+    const float* __restrict__ wg = reinterpret_cast<const float*>(P.w);
+    const int HW = P.H * P.W;
+
+    // this lane's 4 pixels (one per pixel tile) and 4 weight rows
+    int py[4], px[4];
+    long pbase[4];
+    bool pok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const long p = m0 + j * 16 + r16;
+        pok[j] = p < P.npix;
+        const long pc = pok[j] ? p : 0;
+        const long b = pc / HW;
+        const int r = (int)(pc - b * HW);
+        py[j] = r / P.W; px[j] = r - py[j] * P.W;
+        pbase[j] = b * HW;
+    }
+    const float* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wrow[i] = wg + (size_t)(n0 + i * 16 + r16) * P.Kpad + SK_KL * q;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Frags { float4 w[4][SK_KL / 4]; float4 x[4][SK_KL / 4]; };
+    auto load = [&](Frags& f, int kt) {
+        const int k0 = kt * SK_BK + SK_KL * q;
+        const int tap = k0 / P.Cin, ci = k0 - tap * P.Cin;
+        const int dy = tap / P.KW - P.pad, dx = tap - (tap / P.KW) * P.KW - P.pad;
+        const bool kok = k0 < P.K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int h = 0; h < SK_KL / 4; ++h) f.w[i][h] = *reinterpret_cast<const float4*>(wrow[i] + kt * SK_BK + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = py[j] + dy, xx = px[j] + dx;
+            const bool ok = kok && pok[j] && (unsigned)y < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
+            // always load (from a clamped, valid address) and mask the bits: a "load or zero" select makes hipcc branch
+            // around every dword and wait for each one
+            const float* src = xg + (pbase[j] + (ok ? y * P.W + xx : 0)) * P.x_ld + (ok ? ci : 0);
+            const unsigned msk = ok ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int h = 0; h < SK_KL / 4; ++h) {
+                const uint4 v = *reinterpret_cast<const uint4*>(src + 4 * h);
+                f.x[j][h] = __builtin_bit_cast(float4, make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk));
+            }
+        }
+    };
+    auto compute = [&](const Frags& f) {
+#pragma unroll
+        for (int kk = 0; kk < SK_KL; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = reinterpret_cast<const float*>(&f.w[i][0])[kk];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, reinterpret_cast<const float*>(&f.x[j][0])[kk], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    // K stages wave, wave+SK_WAVES, ...: two register sets, the loads of the next stage fly under the MFMAs of the current one
+    const int nk = P.Kpad / SK_BK;
+    Frags f0, f1;
+    int kt = wave;
+    if (kt < nk) load(f0, kt);
+    while (kt < nk) {
+        if (kt + SK_WAVES < nk) load(f1, kt + SK_WAVES);
+        compute(f0);
+        kt += SK_WAVES;
+        if (kt >= nk) break;
+        if (kt + SK_WAVES < nk) load(f0, kt + SK_WAVES);
+        compute(f1);
+        kt += SK_WAVES;
+    }
+
+    // ---- the partial tiles meet in LDS: D[row = n = 4q + r][col = pixel = r16]
+    float* mine = part + wave * 64 * SK_LD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(mine + (j * 16 + r16) * SK_LD + i * 16 + 4 * q) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 1024 / SK_THREADS; ++e) {
+        const int idx = tid + SK_THREADS * e;                      // 1024 float4 of the 64 x 64 tile
+        const int m = idx >> 4, n4 = (idx & 15) * 4;
+        const long p = m0 + m;
+        const int n = n0 + n4;
+        if (p >= P.npix || n >= P.Cout) continue;
+        float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
+#pragma unroll
+        for (int w = 1; w < SK_WAVES; ++w) {
+            const float4 t = *reinterpret_cast<const float4*>(part + (w * 64 + m) * SK_LD + n4);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (P.add) {
+            const float4 a4 = *reinterpret_cast<const float4*>(P.add + n);
+            o[0] = __fadd_rn(o[0], a4.x); o[1] = __fadd_rn(o[1], a4.y); o[2] = __fadd_rn(o[2], a4.z); o[3] = __fadd_rn(o[3], a4.w);
+        }
+        if (P.mul) {
+            const float4 m4 = *reinterpret_cast<const float4*>(P.mul + n);
+            float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (P.mul_exp != 0.f) mv[r] = expf(__fmul_rn(mv[r], P.mul_exp));
+                o[r] = __fmul_rn(o[r], mv[r]);
+            }
+        }
+        if (P.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+        }
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + p * P.y_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // ----------------------------------------------------------------------------- pointwise conv on bf16 activations
 // The 512->512 1x1 convs of the training path (forward and data gradient) and the 512 -> 9*C tap GEMMs read a bf16
 // activation tensor whose rows ARE the GEMM's K-contiguous operand rows: no gather, no conversion.  Both operands go
@@ -539,6 +693,22 @@ extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void
         }
         hipLaunchKernelGGL(pw_gemm_bf16_kernel, dim3(grid), dim3(kThreads), 4 * PW_TILE_BYTES, s, P);
         NFDP_CHECK_LAUNCH("conv2d (pointwise bf16 GEMM)");
+        return NFDP_OK;
+    }
+    // small fp32 problems with a long K: every wave takes a quarter of the K tiles of a 64 x 64 output tile
+    if (compute == NFDP_F32 && Cin % 8 == 0 && x_ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && Cout >= 64 && Cout % 4 == 0 &&
+        y_ld % 4 == 0 && ((uintptr_t)y % 16) == 0 && P.Kpad >= 8 * 32 && cdiv(npix, 64) * cdiv(Cout, 64) <= 1024 &&
+        (add == nullptr || (uintptr_t)add % 16 == 0) && (mul == nullptr || (uintptr_t)mul % 16 == 0)) {
+        P.Mt = (int)cdiv(npix, 64);
+        P.Nt = (int)cdiv(Cout, 64);
+        static bool sk_attr_set = false;
+        if (!sk_attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      SK_LDS_BYTES);
+            sk_attr_set = true;
+        }
+        hipLaunchKernelGGL(conv_splitk_f32_kernel, dim3(P.Mt * P.Nt), dim3(SK_THREADS), SK_LDS_BYTES, s, P);
+        NFDP_CHECK_LAUNCH("conv2d (split-K fp32)");
         return NFDP_OK;
     }
     if (compute == NFDP_F32) {

@@ -385,6 +385,9 @@ def conv2d(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, *, add=Non
         vec = cin % 4 == 0 and _ld(xh, "conv2d") % 4 == 0
         lbl = (f"conv_kernel<{'bf16' if compute == BF16 else 'f32'},x{'bf16' if x_dt == BF16 else 'f32'},"
                f"{'vec' if vec else 'scalar'},{256 if bn <= 48 else 128}x{bn}> k{k} {cin}->{cout} hw{h}")
+        if compute == F32 and cin % 8 == 0 and cout >= 64 and cout % 4 == 0 and cin * k * k >= 256 and \
+                -(-b * h * w // 64) * -(-cout // 64) <= 1024:
+            lbl = f"conv_splitk_f32 k{k} {cin}->{cout} hw{h}"
         if compute == BF16 and x_dt == BF16 and k == 1 and cin % 64 == 0 and cout > 64 and cout % 4 == 0 and b * h * w >= 512:
             lbl = f"pw_gemm_bf16 k1 {cin}->{cout} hw{h}"
     _call("nfdp_conv2d_nhwc", _ptr(xh), x_dt, _ld(xh, "conv2d"), _ptr(packed), _ptr(out), out_dtype, _ld(out, "conv2d"),

@@ -248,3 +248,26 @@ def test_pointwise_bf16_gemm(shape, cout, out_bf16):
     ref2 = (wide[..., 64:].float().reshape(-1, cin) @ wt.reshape(cout, cin).bfloat16().float().t().to(DEV)).reshape(b, h, w, cout)
     err2 = (got2 - ref2).abs().max().item() / ref2.abs().max().item()
     assert err2 < 2e-5, err2
+
+
+@pytest.mark.parametrize("shape,cout,k", [((3, 8, 8, 64), 64, 3), ((2, 6, 10, 40), 100, 3), ((2, 4, 4, 256), 128, 1),
+                                           ((1, 16, 16, 192), 128, 3)])
+def test_small_fp32_conv_split_k(shape, cout, k):
+    """Small fp32 convs (U-Net layers of the reverse step) take the wave-split-K kernel: against F.conv2d, with partial pixel
+    tiles, Cout not a multiple of 64, zero padding at the borders, and the (acc+add)*exp(f*mul) -> ReLU epilogue."""
+    import torch.nn.functional as F
+    b, h, w, cin = shape
+    g = torch.Generator().manual_seed(cin * k + cout)
+    x = torch.randn(shape, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    add = torch.randn(cout, generator=g) * 0.1
+    mul = torch.randn(cout, generator=g) * 0.1
+    conv = F.conv2d(x.permute(0, 3, 1, 2), wt, padding=k // 2).permute(0, 2, 3, 1)
+    packed = K.conv_pack(wt.to(DEV), K.F32)
+    got = K.conv2d(x.to(DEV), packed, cout, k)
+    assert_close(got.cpu(), conv, 2e-5, "plain")
+    got = K.conv2d(x.to(DEV), packed, cout, k, add=add.to(DEV), mul=mul.to(DEV), mul_exp=3.0, relu=True)
+    assert_close(got.cpu(), torch.relu((conv + add) * torch.exp(3.0 * mul)), 2e-5, "epilogue")
+    wide = torch.randn(b, h, w, cin + 8, generator=g)
+    got = K.conv2d(wide.to(DEV)[..., 8:], packed, cout, k)
+    assert_close(got.cpu(), F.conv2d(wide[..., 8:].permute(0, 3, 1, 2), wt, padding=k // 2).permute(0, 2, 3, 1), 2e-5, "strided view")
