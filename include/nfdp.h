@@ -50,6 +50,10 @@ int nfdp_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, 
 int nfdp_squeeze_nhwc_f32(const float* x, int x_ld, float* y, int B, int C, int H, int W, nfdp_stream_t stream);
 /* Squeeze.invert, transforms.py:238: y is [B,h,w,C4] (16-byte aligned) -> x [B,2h,2w,C4/4]. */
 int nfdp_unsqueeze_nhwc_f32(const float* y, float* x, int B, int C4, int h, int w, nfdp_stream_t stream);
+/* Explicit im2col of a narrow tensor for a 3x3 "same" conv (training path of the C/2 -> 512 convs, utils.py:67): x [B,H,W,C] fp32
+ * with pixel stride x_ld -> out [B*H*W][Kpad] bf16, out[p][tap*C + c] = x[p + shift(tap)][c] (zero outside the image and for
+ * columns >= 9C); Kpad >= 9C, Kpad % 8 == 0, out 16-byte aligned. */
+int nfdp_im2col3x3_bf16(const float* x, int x_ld, void* out, int B, int H, int W, int C, int Kpad, nfdp_stream_t stream);
 /* channel slice copy: dst[p, 0:n) = src[p, off:off+n) for npix pixels (Split / chunk / concat plumbing). */
 int nfdp_copy_channels_f32(const float* src, int src_ld, float* dst, int dst_ld, long npix, int n, nfdp_stream_t stream);
 

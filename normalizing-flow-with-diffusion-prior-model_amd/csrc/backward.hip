@@ -593,6 +593,117 @@ __global__ void __launch_bounds__(kBlock) wgrad_bf16_kernel(const WgradParams p)
             }
 }
 
+// The same GEMM for pointwise convs whose operands are BOTH stored in bf16 (the 512 -> 512 conv of the coupling network and the
+// im2col form of its input conv): no gather and no conversion, so both tiles go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: 1 KiB = 4 pixel rows x 128 channels per wave instruction, no VGPRs), 64 pixels per stage, double
+// buffered like pw_gemm_bf16_kernel (conv.hip).  The LDS image is lane-linear with 256-byte rows, so the bank swizzle that
+// makes the transposing reads conflict-free (16-byte chunk ^ ((row & 3) << 2 | (row >> 2) & 3)) is applied to the per-lane
+// SOURCE address and again on the read.  Requires whole 64-pixel stages (npix and the slice length multiples of 64).
+constexpr int WD_KC = 64;
+constexpr int WD_TILE_BYTES = WD_KC * WB_BM * 2;              // 16 KiB per operand per stage
+
+__device__ __forceinline__ int wd_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__global__ void __launch_bounds__(kBlock, 2) wgrad_bf16_dma_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char wd_smem[];   // [2 stages][dy tile 16 KiB | x tile 16 KiB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bid = blockIdx.x;
+    const int nb = bid % p.nblocks; bid /= p.nblocks;
+    const int mb = bid % p.mblocks;
+    const int ks = bid / p.mblocks;
+    const long p_begin = (long)ks * p.px_per_split;
+    const long p_end = (p_begin + p.px_per_split) < p.npix ? (p_begin + p.px_per_split) : p.npix;
+    const __bf16* __restrict__ dyg = reinterpret_cast<const __bf16*>(p.dy);
+    const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(p.x);
+
+    // this lane's source offsets for its wave's 4 pieces (4 pixel rows each) of each operand tile
+    long src_a[4], src_b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 4 + (lane >> 4);
+        const int ch = (lane & 15) ^ wd_swz(row);                  // logical 16-byte chunk (8 channels) stored at this lane's slot
+        int ca = mb * WB_BM + ch * 8, cb = nb * WB_BN + ch * 8;
+        if (ca > p.Cout - 8) ca = p.Cout - 8;                      // ragged last block: any valid address, those columns are dropped
+        if (cb > p.N - 8) cb = p.N - 8;
+        src_a[i] = (long)row * p.dy_ld + ca;
+        src_b[i] = (long)row * p.x_ld + cb;
+    }
+    auto stage = [&](int buf, long p0) {
+        char* base = wd_smem + buf * 2 * WD_TILE_BYTES + wave * 4 * 1024;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dyg + p0 * p.dy_ld + src_a[i]),
+                                             (__attribute__((address_space(3))) void*)(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xg + p0 * p.x_ld + src_b[i]),
+                                             (__attribute__((address_space(3))) void*)(base + WD_TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int c32 = lane & 31, g = lane >> 5;
+    // transposing-read gather addresses (bytes inside an operand tile) for pixel sub-block 0 of a 16-pixel k-step: lane 4q+p of a
+    // 16-lane group supplies row q, 8 bytes at channel 4p of its group's 16-channel half; the second read is 4 rows further
+    const int tq = (lane & 15) >> 2, tp = lane & 3, hh = (lane >> 4) & 1;
+    int off_a[2][2], off_b[2][2];                                  // [tile][r]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = 8 * g + 4 * r + tq;                     // + 16 * kstep: leaves wd_swz unchanged
+            const int cha = (wm * 64 + i * 32) / 8 + 2 * hh + (tp >> 1), chb = (wn * 64 + i * 32) / 8 + 2 * hh + (tp >> 1);
+            off_a[i][r] = row * 256 + ((cha ^ wd_swz(row)) << 4) + 8 * (tp & 1);
+            off_b[i][r] = row * 256 + ((chb ^ wd_swz(row)) << 4) + 8 * (tp & 1);
+        }
+    typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    auto frag = [&](const char* tile, const int (&off)[2], int kstep) -> bf16x8 {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + off[0] + kstep * 16 * 256));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + off[1] + kstep * 16 * 256));
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    stage(0, p_begin);
+    __syncthreads();
+    int cur = 0;
+    for (long p0 = p_begin; p0 < p_end; p0 += WD_KC) {
+        if (p0 + WD_KC < p_end) stage(cur ^ 1, p0 + WD_KC);
+        const char* at = wd_smem + cur * 2 * WD_TILE_BYTES;
+        const char* bt = at + WD_TILE_BYTES;
+#pragma unroll
+        for (int kstep = 0; kstep < WD_KC / 16; ++kstep) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = frag(at, off_a[i], kstep);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = frag(bt, off_b[j], kstep);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();                                           // drains the DMA of the next stage, frees buffer cur
+        cur ^= 1;
+    }
+    float* out = p.ws + (size_t)ks * p.Mpad * p.Npad;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb * WB_BM + wm * 64 + i * 32 + drow32(r, g);
+                const int n = nb * WB_BN + wn * 64 + j * 32 + c32;
+                out[(size_t)m * p.Npad + n] = acc[i][j][r];
+            }
+}
+
 // ----------------------------------------------------------------------------- tap shift-sum (narrow 3x3 convs)
 // A 3x3 conv with few output channels spends its time staging im2col rows.  Computed instead as a pointwise GEMM
 // T[p][tap*Co + co] = sum_ci x[p][ci] W[co][ci][tap] (a wide 1x1 conv: fast) followed by
@@ -806,8 +917,8 @@ static void wgrad_bf16_plan(int B, int H, int W, int Cin, int Cout, int k, Wgrad
     if (want < 1) want = 1;
     if (want > 256) want = 256;
     long per = cdiv(p->npix, want);
-    per = cdiv(per, WB_KC) * WB_KC;
-    if (per < 4 * WB_KC) per = 4 * WB_KC;
+    per = cdiv(per, 64) * 64;                              // whole stages of either kernel (32 / 64 pixels)
+    if (per < 128) per = 128;
     p->px_per_split = per;
     p->ksplit = (int)cdiv(p->npix, per);
 }
@@ -837,7 +948,17 @@ extern "C" int nfdp_conv_wgrad_bf16(const void* x, int x_dtype, int x_ld, const 
     p.x_ld = x_ld; p.dy_ld = dy_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.k = k;
     hipStream_t s = as_stream(stream);
     const dim3 grid(p.mblocks * p.nblocks * p.ksplit);
-    if (xb && db) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true>), grid, dim3(kBlock), 0, s, p);
+    const bool dma = xb && db && k == 1 && Cout >= 8 && Cin >= 8 && Cin % 8 == 0 && Cout % 8 == 0 && x_ld % 8 == 0 && dy_ld % 8 == 0 &&
+                     (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && p.npix % WD_KC == 0;
+    if (dma) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      4 * WD_TILE_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_bf16_dma_kernel, grid, dim3(kBlock), 4 * WD_TILE_BYTES, s, p);
+    } else if (xb && db) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true>), grid, dim3(kBlock), 0, s, p);
     else if (xb) hipLaunchKernelGGL((wgrad_bf16_kernel<true, false>), grid, dim3(kBlock), 0, s, p);
     else if (db) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true>), grid, dim3(kBlock), 0, s, p);
     else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false>), grid, dim3(kBlock), 0, s, p);

@@ -445,6 +445,7 @@ __global__ void __launch_bounds__(SK_THREADS) conv_splitk_f32_kernel(const ConvP
 // channels of one pixel: 8- or 16-byte stores and float4 epilogue parameters.
 constexpr int PW_BM = 128, PW_BN = 128, PW_BK = 64;
 constexpr int PW_TILE_BYTES = PW_BM * PW_BK * 2;           // 16 KiB per operand per stage
+constexpr int PW_LDS_BYTES = PW_BM * (PW_BN * 4 + 16);      // the staged fp32 output tile (66 KiB) >= the 4 operand buffers (64 KiB)
 
 __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvParams P) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [2 stages][pixels 16 KiB | weights 16 KiB]
@@ -520,14 +521,20 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
         __syncthreads();                                           // drains the DMA of tile kt+1 (vmcnt(0)) and frees buffer cur
     }
 
-    // ---- epilogue: D[row = n = 4q + r][col = pixel = r16];  v = (acc + add[n]) * exp(f mul[n]); relu
+    // ---- epilogue: D[row = n = 4q + r][col = pixel = r16];  v = (acc + add[n]) * exp(f mul[n]); relu.
+    // The finished tile goes through LDS (the stage buffers are free after the loop's last barrier) so that the global stores
+    // are 16 bytes per lane along full output rows: stored straight from the accumulators a lane owns 8 bytes of a row, a wave
+    // store touches 16 rows, and at K = 64 the kernel was bound by those stores (1.6 TB/s).
+    const int esz = P.y_bf16 ? 2 : 4;
+    const int pitch = PW_BN * esz + 16;                            // bytes per staged pixel row
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int n = n0 + wn * 64 + i * 16 + 4 * q;
-        if (n >= P.Cout) continue;                                 // Cout % 4 == 0: the 4 channels are in or out together
+        const int nl = wn * 64 + i * 16 + 4 * q;
+        const int n = n0 + nl;
+        const bool nok = n < P.Cout;                               // Cout % 4 == 0: the 4 channels are in or out together
         float addv[4] = {0.f, 0.f, 0.f, 0.f}, mulv[4] = {1.f, 1.f, 1.f, 1.f};
-        if (P.add) { const float4 t = *reinterpret_cast<const float4*>(P.add + n); addv[0] = t.x; addv[1] = t.y; addv[2] = t.z; addv[3] = t.w; }
-        if (P.mul) {
+        if (P.add && nok) { const float4 t = *reinterpret_cast<const float4*>(P.add + n); addv[0] = t.x; addv[1] = t.y; addv[2] = t.z; addv[3] = t.w; }
+        if (P.mul && nok) {
             const float4 t = *reinterpret_cast<const float4*>(P.mul + n);
             mulv[0] = t.x; mulv[1] = t.y; mulv[2] = t.z; mulv[3] = t.w;
             if (P.mul_exp != 0.f) {
@@ -537,8 +544,7 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const long px = m0 + wm * 64 + j * 16 + r16;
-            if (px >= P.npix) continue;
+            const int pl = wm * 64 + j * 16 + r16;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -547,10 +553,25 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
                 if (P.mul) v[r] = __fmul_rn(v[r], mulv[r]);
                 if (P.relu) v[r] = fmaxf(v[r], 0.f);
             }
-            if (P.y_bf16)
-                *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(P.y) + px * P.y_ld + n) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
-            else
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + px * P.y_ld + n) = make_float4(v[0], v[1], v[2], v[3]);
+            char* dst = smem + pl * pitch + nl * esz;
+            if (P.y_bf16) *reinterpret_cast<uint2*>(dst) = pack_bf16x4(make_float4(v[0], v[1], v[2], v[3]));
+            else *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    const int cpr = PW_BN * esz / 16;                              // 16-byte chunks per row: 16 (bf16) or 32 (fp32)
+    const int n_el = 16 / esz;                                     // channels per chunk
+    for (int idx = tid; idx < PW_BM * cpr; idx += kThreads) {
+        const int pl = idx / cpr, ch = idx - pl * cpr;
+        const long px = m0 + pl;
+        const int n = n0 + ch * n_el;
+        if (px >= P.npix || n >= P.Cout) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + pl * pitch + ch * 16);
+        char* dst = reinterpret_cast<char*>(P.y) + (px * P.y_ld + n) * esz;
+        if (n + n_el <= P.Cout) {
+            *reinterpret_cast<uint4*>(dst) = v;
+        } else {                                                   // last chunk of a Cout that is a multiple of 4 but not of 8
+            *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
         }
     }
 }
@@ -584,7 +605,9 @@ inline int cout_pad_for(int Cout) {
     const int bn = tile_n_for(Cout);
     return (int)(cdiv(Cout, bn) * bn);
 }
-inline int kpad_for(int Cin, int KH, int KW) { return (int)(cdiv((long)Cin * KH * KW, BK) * BK); }
+// K is padded to 64: whole 64-deep stages for pw_gemm_bf16_kernel, and the packed 3x3 weight [Cout_pad][Kpad] (k = tap*Cin + ci)
+// is then also the 1x1 weight that acts on nfdp_im2col3x3_bf16's rows
+inline int kpad_for(int Cin, int KH, int KW) { return (int)(cdiv((long)Cin * KH * KW, 2 * BK) * 2 * BK); }
 
 template <bool BF16, bool XBF16, bool VEC, int BM, int BN, int WAVES_M, int WAVES_N>
 void launch_cfg(ConvParams& P, hipStream_t s) {
@@ -680,7 +703,7 @@ extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void
     // pointwise conv on bf16 activations with a wide output: the LDS-DMA GEMM
     const int y_esz = (y_dtype == NFDP_BF16) ? 2 : 4;
     if (compute == NFDP_BF16 && x_dtype == NFDP_BF16 && KH == 1 && Cin % PW_BK == 0 && Cout > 64 && Cout % 4 == 0 && x_ld % 8 == 0 &&
-        ((uintptr_t)x % 16) == 0 && y_ld % 4 == 0 && ((uintptr_t)y % (4 * y_esz)) == 0 && (add == nullptr || (uintptr_t)add % 16 == 0) &&
+        ((uintptr_t)x % 16) == 0 && y_ld % (16 / y_esz) == 0 && ((uintptr_t)y % 16) == 0 && (add == nullptr || (uintptr_t)add % 16 == 0) &&
         (mul == nullptr || (uintptr_t)mul % 16 == 0) && npix >= 4 * PW_BM) {
         P.Mt = (int)cdiv(npix, PW_BM);
         P.Nt = cout_pad_for(Cout) / PW_BN;
@@ -688,10 +711,10 @@ extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      4 * PW_TILE_BYTES);
+                                      PW_LDS_BYTES);
             attr_set = true;
         }
-        hipLaunchKernelGGL(pw_gemm_bf16_kernel, dim3(grid), dim3(kThreads), 4 * PW_TILE_BYTES, s, P);
+        hipLaunchKernelGGL(pw_gemm_bf16_kernel, dim3(grid), dim3(kThreads), PW_LDS_BYTES, s, P);
         NFDP_CHECK_LAUNCH("conv2d (pointwise bf16 GEMM)");
         return NFDP_OK;
     }

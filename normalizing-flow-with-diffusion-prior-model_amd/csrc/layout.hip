@@ -124,6 +124,35 @@ __global__ void postprocess_kernel(const float* __restrict__ x, uint8_t* __restr
     }
 }
 
+
+// Explicit im2col of a NARROW NHWC tensor for a 3x3 "same" conv: out[p][tap*C + c] = bf16(x[p + shift(tap)][c]) (0 outside the
+// image), columns 9C..Kpad zero.  For the C/2 -> 512 input conv of the coupling network the 9C-wide matrix is a tenth of the
+// 512-channel tensors it meets, and it turns the conv and its weight gradient into plain GEMMs with K-contiguous rows.
+__global__ void im2col3x3_bf16_kernel(const float* __restrict__ x, int x_ld, int H, int W, int C, __bf16* __restrict__ out,
+                                      int Kpad, long nchunks) {
+    const int per = Kpad / 8, K = 9 * C;
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < nchunks; i += (long)gridDim.x * kBlock) {
+        const long p = i / per;
+        const int k0 = (int)(i - p * per) * 8;
+        const long b = p / ((long)H * W);
+        const int r = (int)(p - b * H * W);
+        const int y = r / W, xx = r - y * W;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            float f = 0.f;
+            if (k < K) {
+                const int tap = k / C, c = k - tap * C;
+                const int yy = y + tap / 3 - 1, xs = xx + tap % 3 - 1;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W) f = x[((b * H + yy) * W + xs) * (long)x_ld + c];
+            }
+            v[j] = (__bf16)f;
+        }
+        *reinterpret_cast<bf16x8*>(out + i * 8) = v;
+    }
+}
+
 }  // namespace
 
 #define LAUNCH_1D(kernel, total, ...)                                                              \
@@ -214,5 +243,17 @@ extern "C" int nfdp_postprocess_nhwc_to_u8_nchw(const float* x, uint8_t* u8, int
     if (total == 0) return NFDP_OK;
     LAUNCH_1D(postprocess_kernel, total, x, u8, total, C, H * W, n_bins);
     NFDP_CHECK_LAUNCH("postprocess");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_im2col3x3_bf16(const float* x, int x_ld, void* out, int B, int H, int W, int C, int Kpad, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && out, NFDP_EINVAL, "im2col3x3: null pointer");
+    NFDP_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && x_ld >= C && Kpad >= 9 * C && Kpad % 8 == 0, NFDP_ESHAPE,
+                 "im2col3x3: bad shape C=%d x_ld=%d Kpad=%d", C, x_ld, Kpad);
+    NFDP_REQUIRE(((uintptr_t)out & 15) == 0, NFDP_ESHAPE, "im2col3x3: out must be 16-byte aligned");
+    const long nchunks = (long)B * H * W * (Kpad / 8);
+    if (nchunks == 0) return NFDP_OK;
+    LAUNCH_1D(im2col3x3_bf16_kernel, nchunks, x, x_ld, H, W, C, reinterpret_cast<__bf16*>(out), Kpad, nchunks);
+    NFDP_CHECK_LAUNCH("im2col3x3");
     return NFDP_OK;
 }

@@ -370,6 +370,28 @@ def conv_pack(w_oihw: torch.Tensor, compute: int) -> torch.Tensor:
 _TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
 
 
+def use_im2col_conv(cin: int, cout: int, k: int, compute: int) -> bool:
+    """The narrow-input 3x3 convs of the training path (C/2 -> 512): explicit im2col (a matrix 9C wide, a tenth of the
+    512-channel tensors it meets) + plain K-contiguous GEMMs for the conv and its weight gradient."""
+    return compute == BF16 and k == 3 and 9 * cin <= 512 and cout > 64 and cout % 4 == 0
+
+
+def im2col_kpad(cin: int) -> int:
+    return -(-9 * cin // 64) * 64
+
+
+def im2col3x3(xh: torch.Tensor) -> torch.Tensor:
+    """xh [B,H,W,C] fp32 pixel-strided view -> [B,H,W,Kpad] bf16, columns (tap, c), zero padded (nfdp_im2col3x3_bf16).  Kpad is
+    the row pitch of conv_pack's layout for the 3x3 weight, so that packed weight is also the 1x1 weight for these rows."""
+    _need(xh, torch.float32, "im2col3x3")
+    b, h, w, c = xh.shape
+    kpad = im2col_kpad(c)
+    out = torch.empty((b, h, w, kpad), device=xh.device, dtype=torch.bfloat16)
+    _call("nfdp_im2col3x3_bf16", _ptr(xh), _ld(xh, "im2col3x3"), _ptr(out), b, h, w, c, kpad, _stream(), label="im2col3x3",
+          nbytes=float(b * h * w) * (c * 4 * 9 + kpad * 2))
+    return out
+
+
 def conv2d(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, *, add=None, mul=None, mul_exp: float = 0.0,
            relu: bool = False, compute: int = F32, out_dtype: int = F32, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """xh: [B,H,W,Cin] pixel-strided view (fp32 or bf16) -> [B,H,W,cout] (fp32 or bf16)."""

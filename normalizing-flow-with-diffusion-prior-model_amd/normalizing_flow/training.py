@@ -96,13 +96,20 @@ class ConvScaleFn(Function):
         # bf16 mode: the 512-channel hidden activations (the ReLU outputs) are stored in bf16 - they are bf16 MFMA operands
         # of the next conv and of its weight gradient anyway - which halves the HBM traffic that dominates the step
         hidden_bf16 = compute == K.BF16 and bool(relu)
+        xcol = None
         if K.use_narrow_conv(weight.shape[1], weight.shape[0], k):       # 512 -> C: pointwise GEMM + tap shift-sum
             y = K.conv3x3_narrow(xh, weight, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1), mul_exp=float(f),
                                  relu=bool(relu), compute=compute)
+        elif K.use_im2col_conv(weight.shape[1], weight.shape[0], k, compute):   # C/2 -> 512: explicit im2col + pointwise GEMM
+            xcol = K.im2col3x3(xh)                                        # (the packed 3x3 weight is the 1x1 weight for its rows)
+            y = K.conv2d(xcol, packed, weight.shape[0], 1, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1),
+                         mul_exp=float(f), relu=bool(relu), compute=compute, out_dtype=K.BF16 if hidden_bf16 else K.F32)
         else:
             y = K.conv2d(xh, packed, weight.shape[0], k, add=add.detach().reshape(-1), mul=mul.detach().reshape(-1),
                          mul_exp=float(f), relu=bool(relu), compute=compute, out_dtype=K.BF16 if hidden_bf16 else K.F32)
-        ctx.save_for_backward(xh, weight, mul, y)
+        ctx.save_for_backward(xh if xcol is None else xcol, weight, mul, y)
+        ctx.im2col = xcol is not None
+        ctx.x_dtype = xh.dtype
         ctx.f, ctx.relu, ctx.k, ctx.compute = float(f), bool(relu), int(k), compute
         ctx.add_shape = add.shape
         return y
@@ -116,12 +123,20 @@ class ConvScaleFn(Function):
             wt = K.conv_flip_weights(weight.detach().contiguous())
             if K.use_narrow_conv(weight.shape[0], weight.shape[1], ctx.k):   # data gradient of C/2 -> 512: a 512 -> C/2 conv
                 dx = K.conv3x3_narrow(dc, wt, compute=ctx.compute)
+            elif dc.dtype == torch.float32 and K.use_im2col_conv(weight.shape[0], weight.shape[1], ctx.k, ctx.compute):
+                # data gradient of the 512 -> C zero conv: a C -> 512 conv of the narrow dc, as im2col + pointwise GEMM
+                dx = K.conv2d(K.im2col3x3(dc), K.conv_pack(wt, ctx.compute), weight.shape[1], 1, compute=ctx.compute,
+                              out_dtype=K.BF16 if ctx.x_dtype == torch.bfloat16 else K.F32)
             else:
                 dx = K.conv2d(dc, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute,
-                              out_dtype=K.BF16 if xh.dtype == torch.bfloat16 else K.F32)
-            if dx.dtype != xh.dtype:
-                dx = dx.to(xh.dtype)
-        dw = K.conv_wgrad(xh, dc, ctx.k, compute=ctx.compute)
+                              out_dtype=K.BF16 if ctx.x_dtype == torch.bfloat16 else K.F32)
+            if dx.dtype != ctx.x_dtype:
+                dx = dx.to(ctx.x_dtype)
+        if ctx.im2col:                                                     # xh is the saved im2col matrix: a plain GEMM over pixels
+            o, i = weight.shape[:2]
+            dw = K.conv_wgrad(xh, dc, 1, compute=ctx.compute)[:, :9 * i, 0, 0].reshape(o, 3, 3, i).permute(0, 3, 1, 2).contiguous()
+        else:
+            dw = K.conv_wgrad(xh, dc, ctx.k, compute=ctx.compute)
         return dx, dw, dadd.reshape(ctx.add_shape), dmul.view_as(mul), None, None, None, None, None
 
 

