@@ -138,16 +138,17 @@ __global__ void im2col3x3_bf16_kernel(const float* __restrict__ x, int x_ld, int
         const int r = (int)(p - b * H * W);
         const int y = r / W, xx = r - y * W;
         bf16x8 v;
+        int tap = k0 / C, c = k0 - tap * C;                        // one division per thread, then walk (tap, c)
+        const float* row = x + ((b * H + y) * W + xx) * (long)x_ld;   // centre pixel
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j;
             float f = 0.f;
-            if (k < K) {
-                const int tap = k / C, c = k - tap * C;
-                const int yy = y + tap / 3 - 1, xs = xx + tap % 3 - 1;
-                if ((unsigned)yy < (unsigned)H && (unsigned)xs < (unsigned)W) f = x[((b * H + yy) * W + xs) * (long)x_ld + c];
+            if (k0 + j < K) {
+                const int dy = (tap * 11 >> 5) - 1, dx = tap - 3 * (tap * 11 >> 5) - 1;   // tap / 3, tap % 3 for tap < 9
+                if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(xx + dx) < (unsigned)W) f = row[(dy * W + dx) * (long)x_ld + c];
             }
             v[j] = (__bf16)f;
+            if (++c == C) { c = 0; ++tap; }
         }
         *reinterpret_cast<bf16x8*>(out + i * 8) = v;
     }
