@@ -183,6 +183,58 @@ def train_bench(args, rank, world, device, barrier):
             "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
 
 
+def inverse_bench(args, rank, world, device, barrier):
+    """BASELINE configs[1] is forward + INVERSE: times Glow.invert (reference glow.py:203-228) on the latents of the same
+    synthetic batch - all latents given (exact reconstruction) or only the last one (the Split layers sample from their learned
+    priors, temperature 0.7: the sampling path) - as a hipGraph replay like the forward leg."""
+    import nfdp_hip as KH
+    from nfdp_hip.dist import max_over_ranks
+    flow, prior, _, _ = build_models(args.L, args.K, args.compute, device)
+    _, _, u8_d, noise_d = make_batch(args.batch, rank, device)
+    with torch.no_grad():
+        xh = KH.preprocess_u8(u8_d, noise_d, 5)
+        ldj = torch.zeros(args.batch, dtype=torch.float64, device=device)
+        logp = torch.zeros(args.batch, dtype=torch.float64, device=device)
+        zs = [z.contiguous() for z in flow.transform_nhwc(xh, ldj, logp)]
+        lat = zs if not args.sample else [zs[-1]]
+        temp = 1.0 if not args.sample else 0.7
+
+        def inv():
+            return flow.invert_nhwc(lat, temperature=temp)
+
+        for _ in range(max(args.warmup, 2)):
+            out = inv()
+        rt = float((out - xh).abs().max() / xh.abs().max()) if not args.sample else None
+        graphed = not args.no_graph
+        if graphed:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = inv()
+            run = g.replay
+            run()
+        else:
+            run = inv
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0, device)
+        finite = bool(torch.isfinite(out).all())
+    if rank == 0:
+        what = "inverse (all latents given)" if not args.sample else "sampling inverse (last latent given, Split priors sampled, T=0.7)"
+        print(json.dumps({
+            "metric": f"images/sec, Glow L{args.L}K{args.K} 32x32x3 {'sample' if args.sample else 'inverse'}",
+            "value": round(args.batch * world * args.steps / elapsed, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.compute, "data": "synthetic",
+            "config": {"workload": f"Glow L={args.L} K={args.K} {what} on 32x32x3, batch={args.batch}/GPU (BASELINE configs[1] shape, "
+                                   "glow.py:203-228)", "batch_per_gpu": args.batch, "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay" if graphed else "eager"},
+            "round_trip_max_rel_err": rt, "finite": finite}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +245,8 @@ def main():
     ap.add_argument("--L", type=int, default=3)
     ap.add_argument("--K", type=int, default=16)
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--inverse", action="store_true", help="time Glow.invert on the batch's latents instead (configs[1] is forward+inverse)")
+    ap.add_argument("--sample", action="store_true", help="time the sampling inverse (only the last latent given, Split priors sampled at T=0.7)")
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE configs[2]: trainer.py:152-167 body, HIP training path in the "
                          "--compute mode (fp32 activations), fused clip+Adam, bucketed RCCL gradient all-reduce for N>1); not the headline metric")
@@ -229,6 +283,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.inverse or args.sample:
+        inverse_bench(args, rank, world, device, barrier)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.train:
         train_bench(args, rank, world, device, barrier)
         if world > 1:
