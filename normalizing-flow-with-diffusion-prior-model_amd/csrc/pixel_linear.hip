@@ -187,6 +187,14 @@ int launch_templated(const float* x, float* y, long npix, const float* w, const 
     const size_t lds = ((size_t)2 * kTilePx * (C + 1) + 2 * C) * sizeof(float);
     const long ntiles = cdiv(npix, kTilePx);
     const int grid = (int)(ntiles < 4096 ? ntiles : 4096);
+    if (lds > 65536) {                               // C = 192 (last level of a 5-level, 3-channel model): 99 KB, opted into once
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pixel_linear_kernel<C, MODE>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+    }
     hipLaunchKernelGGL((pixel_linear_kernel<C, MODE>), dim3(grid), dim3(kBlock), lds, s, x, y, npix, w, scale, bias, lad, hw,
                        cst);
     return NFDP_OK;
@@ -207,6 +215,11 @@ int dispatch(const char* what, const float* x, float* y, long npix, int C, const
         case 16: launch_templated<16, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
         case 24: launch_templated<24, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
         case 48: launch_templated<48, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        // deeper models (L = 4, 5: CelebA 128x128 is L = 5): C = 2^(l+2) * {1, 3}
+        case 32: launch_templated<32, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 64: launch_templated<64, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 96: launch_templated<96, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 192: launch_templated<192, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
         default: {
             NFDP_REQUIRE(x != y, NFDP_EINVAL, "%s: in-place needs a templated C (got %d)", what, C);
             NFDP_REQUIRE(cst == nullptr, NFDP_EUNSUPPORTED, "%s: fused log-det constants need a templated C (got %d)", what, C);

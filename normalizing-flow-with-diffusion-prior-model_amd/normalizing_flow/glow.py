@@ -216,12 +216,15 @@ class Glow(Transform):
         lads = None
         if ldj is not None:
             groups = [list(b.flows) for b in self.blocks] + [list(self.final_flows)]
-            allw = [f.invconv2d._w() for g in groups for f in g]
-            flat = K.invconv_logdets(allw)
+            small = [g for g in groups if g[0].invconv2d._w().shape[-1] <= 96]      # the one-launch LU holds a matrix in LDS
+            flat = K.invconv_logdets([f.invconv2d._w() for g in small for f in g]) if small else None
             lads, o = [], 0
             for g in groups:
-                lads.append(flat[o:o + len(g)])
-                o += len(g)
+                if g[0].invconv2d._w().shape[-1] <= 96:
+                    lads.append(flat[o:o + len(g)])
+                    o += len(g)
+                else:                          # C = 192 at the last level of a 5-level model: batched Gauss-Jordan, global workspace
+                    lads.append(_level_logdets(g))
         hws = []
         for i, block in enumerate(self.blocks):
             yh, z = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True)
