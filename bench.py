@@ -38,6 +38,8 @@ HBM_PEAK_GBS = 8000.0
 
 def build_models(L, K, compute, device, seed=1):
     from normalizing_flow import Glow, GaussianPrior
+    from normalizing_flow import glow as _glow
+    _glow.set_weight_term_cache(False)          # every timed step recomputes the 1x1-conv log-dets / inverses, as the reference does
     from tests.golden.synth import synth_tensor, DEEP
     flow = Glow(in_channel=3, L=L, K=K, compute=compute)
     prior = GaussianPrior(2 ** (L + 1) * 3)

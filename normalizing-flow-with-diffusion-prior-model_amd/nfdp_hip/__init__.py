@@ -317,10 +317,23 @@ def invconv_apply(xh, w, out=None):
     return out
 
 
+_WIDE_C = 96      # from here on the per-pixel CxC product runs on the exact-fp32 MFMA conv kernel (a lane of pixel_linear_kernel would
+                  # walk C/4 x C serial FMAs: 142 us for the 512 pixels of the C = 192 level of a 5-level model)
+
+
+def _mfma_1x1(xh, w, out):
+    c = xh.shape[-1]
+    y = conv2d(xh, conv_pack(w.detach().reshape(c, c, 1, 1), F32), c, 1, compute=F32)
+    out.copy_(y)
+    return out
+
+
 def actnorm_invconv_fwd(xh, scale, bias, w, out=None):
     _need(xh, torch.float32, "actnorm_invconv_fwd"); _dense(xh, "actnorm_invconv_fwd")
     out = torch.empty_like(xh) if out is None else out
     c = xh.shape[-1]
+    if c >= _WIDE_C and c % 8 == 0:
+        return _mfma_1x1(actnorm_fwd(xh, scale, bias), w, out)
     _call("nfdp_actnorm_invconv_fwd_f32", _ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(w),
           _stream(), label=f"pixel_linear_kernel<{c},pre_affine>", flops=2.0 * xh.numel() * c, nbytes=8.0 * xh.numel())
     return out
@@ -352,6 +365,9 @@ def invconv_actnorm_inv(yh, scale, bias, winv, out=None):
     _need(yh, torch.float32, "invconv_actnorm_inv"); _dense(yh, "invconv_actnorm_inv")
     out = torch.empty_like(yh) if out is None else out
     c = yh.shape[-1]
+    if c >= _WIDE_C and c % 8 == 0:
+        _mfma_1x1(yh, winv, out)
+        return actnorm_inv(out, scale, bias, out=out)
     _call("nfdp_invconv_actnorm_inv_f32", _ptr(yh), _ptr(out), yh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(winv),
           _stream(), label=f"pixel_linear_kernel<{c},post_affine>", flops=2.0 * yh.numel() * c, nbytes=8.0 * yh.numel())
     return out
@@ -891,16 +907,23 @@ def diffusion_loss_bwd(pred, target, t, p2w, grad_out, l1: bool):
     return dp
 
 
+def pack_taps(w_oihw: torch.Tensor, compute: int) -> torch.Tensor:
+    """Packed weight of the pointwise GEMM of conv3x3_narrow: rows [tap*Co + co], columns ci (weight-sized plumbing)."""
+    co, ci = w_oihw.shape[:2]
+    return conv_pack(w_oihw.detach().permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1).contiguous(), compute)
+
+
 def conv3x3_narrow(xh: torch.Tensor, w_oihw: torch.Tensor, *, add=None, mul=None, mul_exp: float = 0.0, relu: bool = False,
-                   compute: int = F32) -> torch.Tensor:
+                   compute: int = F32, packed_taps: Optional[torch.Tensor] = None) -> torch.Tensor:
     """3x3 'same' conv with Cin >> Cout as a pointwise GEMM to the 9*Cout tap contributions (one wide, fast 1x1 conv)
     followed by the tap shift-sum with the conv kernel's epilogue act((acc + add) * exp(mul_exp * mul))."""
     co, ci, k, _ = w_oihw.shape
     if k != 3:
         raise ValueError("conv3x3_narrow: 3x3 only")
     b, h, w, _ = xh.shape
-    wpt = w_oihw.detach().permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1).contiguous()        # [tap*Co + co][ci]: weight-sized plumbing
-    t = conv2d(xh, conv_pack(wpt, compute), 9 * co, 1, compute=compute, out_dtype=F32)
+    if packed_taps is None:
+        packed_taps = pack_taps(w_oihw, compute)
+    t = conv2d(xh, packed_taps, 9 * co, 1, compute=compute, out_dtype=F32)
     out = torch.empty((b, h, w, co), device=xh.device, dtype=torch.float32)
     _call("nfdp_tap_shift_sum_f32", _ptr(t), _ptr(out), b, h, w, co, _ptr(add), _ptr(mul), float(mul_exp), int(relu), _stream())
     return out
@@ -908,3 +931,8 @@ def conv3x3_narrow(xh: torch.Tensor, w_oihw: torch.Tensor, *, add=None, mul=None
 
 def use_narrow_conv(cin: int, cout: int, k: int) -> bool:
     return k == 3 and cout <= 64 and cin >= 4 * cout and cin >= 128
+
+
+def use_tap_conv(cin: int, cout: int, k: int, compute: int) -> bool:
+    """Inference form of the 512 -> C zero conv in bf16 mode (any C up to 192: the deeper levels of 4- and 5-level models)."""
+    return compute == BF16 and k == 3 and cout <= 192 and cin >= 2 * cout and cin >= 128 and cin % 64 == 0

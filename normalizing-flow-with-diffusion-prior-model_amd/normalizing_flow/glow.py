@@ -74,11 +74,47 @@ class StepFlow(Transform):
         return K.as_nchw(self.invert_nhwc_(K.to_nhwc(y).contiguous().clone()))
 
 
+# log|det W| and W^-1 depend only on the weights.  The reference recomputes them on every call (transforms.py:131, :144:
+# SURVEY Appendix A #4); with this switch on they are kept per level until a 1x1-conv weight changes (tensor version /
+# storage / optimizer epoch) - evaluation and sampling run many batches on fixed weights, and for a 5-level model the 16
+# Gauss-Jordans of the C = 192 level cost 12 ms, a third of a forward pass.  bench.py turns it off: every timed step
+# recomputes them, as the reference does.  Never read or filled while a stream is capturing.
+CACHE_WEIGHT_TERMS = True
+
+
+def set_weight_term_cache(on: bool) -> None:
+    global CACHE_WEIGHT_TERMS
+    CACHE_WEIGHT_TERMS = bool(on)
+
+
+def _cached_terms(flows: Sequence[StepFlow], what: str, compute):
+    use = CACHE_WEIGHT_TERMS and not torch.is_grad_enabled() and not (
+        torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+    if not use:
+        return compute()
+    key = (what, K.param_epoch()) + tuple((f.invconv2d._w().data_ptr(), f.invconv2d._w()._version) for f in flows)
+    slot = flows[0].__dict__.setdefault("_weight_terms", {})
+    hit = slot.get(what)
+    if hit is None or hit[0] != key:
+        hit = (key, compute())
+        slot[what] = hit
+    return hit[1]
+
+
 def _level_logdets(flows: Sequence[StepFlow]) -> Tensor:
     """log|det W| of all K flows of a level in ONE fp64 launch (the reference runs K slogdets, transforms.py:131)."""
-    w = torch.stack([f.invconv2d._w() for f in flows])                          # [K,C,C] gather (plumbing)
-    lads, _ = K.invconv_prepare(w, want_inverse=False)
-    return lads
+    def compute():
+        w = torch.stack([f.invconv2d._w() for f in flows])                      # [K,C,C] gather (plumbing)
+        return K.invconv_prepare(w, want_inverse=False)[0]
+    return _cached_terms(flows, "logdets", compute)
+
+
+def _level_inverses(flows: Sequence[StepFlow]) -> Tensor:
+    """W^-1 of all K flows of a level (fp64 Gauss-Jordan, one launch; the reference inverts per call, transforms.py:144)."""
+    def compute():
+        w = torch.stack([f.invconv2d._w() for f in flows])
+        return K.invconv_prepare(w, want_inverse=True)[1]
+    return _cached_terms(flows, "inverses", compute)
 
 
 # Flows per persistent launch: by default a whole level (the kernel takes up to 32 flows per launch and the ABI entry
@@ -130,8 +166,7 @@ def _side_stream(device) -> "torch.cuda.Stream":
 
 
 def _run_flows_inv(flows: Sequence[StepFlow], yh: Tensor) -> Tensor:
-    w = torch.stack([f.invconv2d._w() for f in flows])
-    _, winvs = K.invconv_prepare(w, want_inverse=True)
+    winvs = _level_inverses(flows)
     tabs = _level_tables(flows, yh)
     if tabs is not None:
         wl = [winvs[i] for i in range(len(flows))]
@@ -217,7 +252,8 @@ class Glow(Transform):
         if ldj is not None:
             groups = [list(b.flows) for b in self.blocks] + [list(self.final_flows)]
             small = [g for g in groups if g[0].invconv2d._w().shape[-1] <= 96]      # the one-launch LU holds a matrix in LDS
-            flat = K.invconv_logdets([f.invconv2d._w() for g in small for f in g]) if small else None
+            flat = _cached_terms([f for g in small for f in g], "logdets_all",
+                                 lambda: K.invconv_logdets([f.invconv2d._w() for g in small for f in g])) if small else None
             lads, o = [], 0
             for g in groups:
                 if g[0].invconv2d._w().shape[-1] <= 96:

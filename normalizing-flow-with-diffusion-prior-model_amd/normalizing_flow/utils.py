@@ -36,6 +36,15 @@ class _PackedCache:
         return self._packed
 
 
+    def get_taps(self, weight: Tensor, compute: int) -> Tensor:
+        """Packed [9*O, I] weight of the tap GEMM (K.conv3x3_narrow)."""
+        key = (weight.data_ptr(), weight._version, compute, weight.device, K.param_epoch())
+        if key != getattr(self, "_key_taps", None):
+            self._packed_taps = K.pack_taps(weight, compute)
+            self._key_taps = key
+        return self._packed_taps
+
+
 class _ConvWeights(nn.Module):
     """Parameter container with nn.Conv2d's names, shapes and default init (never calls a torch conv)."""
 
@@ -74,6 +83,11 @@ class ZeroConv2d(nn.Module):
 
     def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None) -> Tensor:
         c = K.compute_enum(compute)
+        if xh.dtype == torch.bfloat16 and K.use_tap_conv(self.in_channels, self.out_channels, self.filter_size, c):
+            # 512 -> C with C small: as an implicit GEMM the im2col staging dominates (10-70 TFLOP/s); computed instead as a
+            # pointwise GEMM to the 9*C tap contributions + tap shift-sum (the decomposition of the fused flow-step kernel)
+            return K.conv3x3_narrow(xh, self.weight, add=self.bias, mul=self.logs.view(-1), mul_exp=self.logscale_factor,
+                                    relu=False, compute=c, packed_taps=self._cache.get_taps(self.weight, c))
         return K.conv2d(xh, self._cache.get(self.weight, c), self.out_channels, self.filter_size, add=self.bias,
                         mul=self.logs.view(-1), mul_exp=self.logscale_factor, relu=False, compute=c, out_dtype=K.F32)
 
