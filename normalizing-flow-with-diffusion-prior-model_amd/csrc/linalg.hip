@@ -88,6 +88,116 @@ __global__ void __launch_bounds__(kBlock) gauss_jordan_kernel(const float* __res
 }
 
 
+// ---- 64 < C <= 192: the matrix in REGISTERS ---------------------------------------------------------------------------
+// An fp64 192 x 192 matrix is 295 KB - more than LDS - and the kernel above then works in a global workspace: three barriers
+// and a pass over [W | I] in L2 per step, 12.5 ms for the sixteen C = 192 matrices of a 5-level model (a third of its forward
+// pass).  Here one 1024-thread workgroup holds the matrix in registers, 2D-cyclic: thread (ti, tj) = (tid / 32, tid % 32) owns
+// the elements (ti + 32 a, tj + 32 b), NB x NB doubles.  IN-PLACE Gauss-Jordan inversion (no identity half) with implicit
+// partial pivoting: step k takes the unused row p with the largest |A[p][k]| (lowest p on ties), broadcasts row p and column k
+// through LDS, and every thread updates its own elements; the array then holds M with W^-1[k][p_j] = M[p_k][j].
+// (C <= 128: 32 x 32 threads; C <= 192: 16 x 32 threads with 12 x 6 elements each, 144 of the 256 registers of a wave.)
+// Rows / columns beyond C are padded with identity and never chosen.  Two barriers per step (LDS scratch double-buffered).
+template <int TI, int NBR, int NBC>       // TI x 32 threads; thread (ti, tj) owns rows ti + TI a (a < NBR), columns tj + 32 b (b < NBC)
+__global__ void __launch_bounds__(TI * 32) gauss_jordan_reg_kernel(const float* __restrict__ w, int C, float* __restrict__ logabsdet,
+                                                                   float* __restrict__ winv) {
+    constexpr int CP = 32 * NBC;
+    static_assert(TI * NBR == CP, "square padded matrix");
+    __shared__ double cand_v[2][TI];
+    __shared__ int cand_i[2][TI];
+    __shared__ double rowk[2][CP];
+    __shared__ double fcol[2][CP];
+    __shared__ int used[CP];
+    __shared__ int pivrow[CP];
+    __shared__ int kof[CP];
+    __shared__ double pivlog[CP];
+    const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
+    const float* wm = w + (size_t)blockIdx.x * C * C;
+    double a[NBR][NBC];
+#pragma unroll
+    for (int x = 0; x < NBR; ++x)
+#pragma unroll
+        for (int y = 0; y < NBC; ++y) {
+            const int i = ti + TI * x, j = tj + 32 * y;
+            a[x][y] = (i < C && j < C) ? (double)wm[i * C + j] : (i == j ? 1.0 : 0.0);
+        }
+    for (int i = tid; i < CP; i += TI * 32) used[i] = 0;
+    __syncthreads();
+    for (int k = 0; k < C; ++k) {
+        const int buf = k & 1, kb = k >> 5, kt = k & 31;
+        // 1. pivot candidates: the TI threads that own column k (tj == k % 32), each over its NBR rows
+        if (tj == kt) {
+            double best = -1.0;
+            int bi = 1 << 30;
+#pragma unroll
+            for (int x = 0; x < NBR; ++x) {
+                const int i = ti + TI * x;
+                double v = 0.0;
+#pragma unroll
+                for (int y = 0; y < NBC; ++y) if (y == kb) v = a[x][y];
+                fcol[buf][i] = v;                                   // column k, all rows (read in step 3)
+                v = fabs(v);
+                if (i < C && !used[i] && (v > best || (v == best && i < bi))) { best = v; bi = i; }
+            }
+            cand_v[buf][ti] = best;
+            cand_i[buf][ti] = bi;
+        }
+        __syncthreads();
+        double pb = -1.0;
+        int p = 1 << 30;
+#pragma unroll 8
+        for (int q = 0; q < TI; ++q) {
+            const double v = cand_v[buf][q];
+            const int i = cand_i[buf][q];
+            if (v > pb || (v == pb && i < p)) { pb = v; p = i; }
+        }
+        // 2. the owners of row p publish it
+        if (ti == p % TI) {
+            const int pxl = p / TI;
+#pragma unroll
+            for (int y = 0; y < NBC; ++y) {
+                double v = 0.0;
+#pragma unroll
+                for (int x = 0; x < NBR; ++x) if (x == pxl) v = a[x][y];
+                rowk[buf][tj + 32 * y] = v;
+            }
+        }
+        __syncthreads();
+        const double pv = rowk[buf][k];
+        const double inv = 1.0 / pv;
+        // 3. in-place update of this thread's elements
+#pragma unroll
+        for (int y = 0; y < NBC; ++y) {
+            const int j = tj + 32 * y;
+            const double r = (j == k) ? inv : rowk[buf][j] * inv;   // new pivot row element
+#pragma unroll
+            for (int x = 0; x < NBR; ++x) {
+                const int i = ti + TI * x;
+                const double f = fcol[buf][i];
+                if (i == p) a[x][y] = r;
+                else a[x][y] = ((j == k) ? 0.0 : a[x][y]) - f * r;
+            }
+        }
+        if (tid == 0) { used[p] = 1; pivrow[k] = p; kof[p] = k; pivlog[k] = log(fabs(pv)); }
+        // the next step writes the other LDS buffers; its first barrier orders this step's reads before step k+2's writes
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sum = 0.0;
+        for (int k = 0; k < C; ++k) sum += pivlog[k];               // step order: deterministic
+        logabsdet[blockIdx.x] = (float)sum;
+    }
+    if (winv) {
+        float* out = winv + (size_t)blockIdx.x * C * C;
+#pragma unroll
+        for (int x = 0; x < NBR; ++x)
+#pragma unroll
+            for (int y = 0; y < NBC; ++y) {
+                const int i = ti + TI * x, j = tj + 32 * y;
+                if (i < C && j < C) out[kof[i] * C + pivrow[j]] = (float)a[x][y];
+            }
+    }
+}
+
 // ---- log|det| only, matrices of DIFFERENT sizes in one launch (all 1x1 convolutions of a Glow forward pass) --------
 // LU with implicit partial pivoting on W alone (no identity half): step k picks the unused row with the largest
 // |A[r][k]| (lowest r on ties, as above), and every other unused row i gets A[i][j] -= (A[i][k] / pv) * A[p][j] for
@@ -286,6 +396,12 @@ extern "C" int nfdp_invconv_prepare_f32(const float* w, int n, int C, float* log
         const size_t lds = (size_t)C * 2 * C * sizeof(double) + red;
         hipLaunchKernelGGL((gauss_jordan_kernel<true>), dim3(n), dim3(kBlock), lds, as_stream(stream), w, C, logabsdet,
                            winv, nullptr);
+    } else if (C <= 96) {
+        hipLaunchKernelGGL((gauss_jordan_reg_kernel<32, 3, 3>), dim3(n), dim3(1024), 0, as_stream(stream), w, C, logabsdet, winv);
+    } else if (C <= 128) {
+        hipLaunchKernelGGL((gauss_jordan_reg_kernel<32, 4, 4>), dim3(n), dim3(1024), 0, as_stream(stream), w, C, logabsdet, winv);
+    } else if (C <= 192) {
+        hipLaunchKernelGGL((gauss_jordan_reg_kernel<16, 12, 6>), dim3(n), dim3(512), 0, as_stream(stream), w, C, logabsdet, winv);
     } else {
         NFDP_REQUIRE(ws, NFDP_EINVAL, "invconv_prepare: workspace required for C=%d", C);
         hipLaunchKernelGGL((gauss_jordan_kernel<false>), dim3(n), dim3(kBlock), red, as_stream(stream), w, C, logabsdet,

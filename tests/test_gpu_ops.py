@@ -271,3 +271,20 @@ def test_small_fp32_conv_split_k(shape, cout, k):
     wide = torch.randn(b, h, w, cin + 8, generator=g)
     got = K.conv2d(wide.to(DEV)[..., 8:], packed, cout, k)
     assert_close(got.cpu(), F.conv2d(wide[..., 8:].permute(0, 3, 1, 2), wt, padding=k // 2).permute(0, 2, 3, 1), 2e-5, "strided view")
+
+
+@pytest.mark.parametrize("c", [65, 72, 96, 100, 128, 160, 192, 200])
+def test_invconv_prepare_large_c(c):
+    """log|det W| and W^-1 for 64 < C: the register-resident in-place Gauss-Jordan (C <= 192) and the global-workspace kernel
+    beyond, against fp64 LAPACK; several matrices per launch, rows permuted so the implicit pivoting has work to do."""
+    g = torch.Generator().manual_seed(c)
+    q, _ = torch.linalg.qr(torch.randn(3, c, c, generator=g, dtype=torch.float64))
+    w = (q * torch.exp(0.3 * torch.randn(3, 1, c, generator=g, dtype=torch.float64)))[:, torch.randperm(c, generator=g)]
+    lad, winv = K.invconv_prepare(w.float().to(DEV), want_inverse=True)
+    w32 = w.float().double()
+    ref_lad = torch.linalg.slogdet(w32)[1]
+    assert float((lad.cpu().double() - ref_lad).abs().max()) < 1e-5 * max(1.0, float(ref_lad.abs().max()))
+    ref_inv = torch.linalg.inv(w32)
+    assert float((winv.cpu().double() - ref_inv).abs().max()) < 1e-5 * float(ref_inv.abs().max())
+    lad2, none = K.invconv_prepare(w.float().to(DEV), want_inverse=False)
+    assert none is None and torch.equal(lad2, lad)
