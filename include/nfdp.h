@@ -192,6 +192,11 @@ int nfdp_sinusoidal_emb_f32(const long* t, float* out, int B, int dim, nfdp_stre
 /* LinearAttention.forward :320-332 between to_qkv and to_out; qkv [B][n][3*heads*32] -> out [B][n][heads*32]. */
 int nfdp_linear_attention_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale,
                               nfdp_stream_t stream);
+/* The same for long sequences (n > 256: the 32x32 / 64x64 latent parts of the larger models): positions in chunks of 256 over
+ * the grid, two launches, chunk partials in ws (nfdp_linear_attention_ws_bytes; 0 when n <= 256: use the entry above). */
+size_t nfdp_linear_attention_ws_bytes(int B, int n, int heads);
+int nfdp_linear_attention_chunked_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale, void* ws,
+                                      nfdp_stream_t stream);
 /* Attention.forward :347-357 between to_qkv and to_out (softmax over keys), n <= 256 pixels. */
 int nfdp_attention_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale,
                        nfdp_stream_t stream);

@@ -286,6 +286,117 @@ __global__ void __launch_bounds__(kBlock) linear_attention_kernel(const float* _
     }
 }
 
+// ---- n > 256 positions (the 64x64 / 32x32 latent parts of the larger models): the positions are cut into chunks of 256 and
+// spread over blockIdx.y.  Pass 1 (one workgroup per (b, head, chunk), the chunk's k and v staged in LDS as above) produces
+// the chunk's column max m_c[d], sum_c[d] = sum_i exp(k - m_c) and the unnormalised context sum_i exp(k - m_c) v[e]; pass 2
+// recombines the chunks in chunk order (rescaling by exp(m_c - m): the usual streaming-softmax identity, deterministic) and
+// applies the context to its own 256 positions.  With one workgroup per (b, head) walking all n positions serially the 6x64x64
+// part of a 128x128 model spent 45 % of its reverse step here.
+constexpr int LA_CHUNK = 256;
+constexpr int LA_REC = 2 * DH + DH * DH;                        // floats per (b, head, chunk) record: m | s | ctx
+
+__global__ void __launch_bounds__(kBlock) linear_attention_partial_kernel(const float* __restrict__ qkv, float* __restrict__ ws, int n,
+                                                                         int heads) {
+    __shared__ float kmax[DH];
+    __shared__ float part[8][DH];
+    __shared__ float ksm[LA_CHUNK][DH + 1], vsm[LA_CHUNK][DH + 1];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, c = blockIdx.y;
+    const int HD = heads * DH, ld = 3 * HD;
+    const int i0 = c * LA_CHUNK;
+    const int nc = (n - i0) < LA_CHUNK ? (n - i0) : LA_CHUNK;
+    const float* base = qkv + ((long)b * n + i0) * ld;
+    const float* kp = base + HD + hd * DH;
+    const float* vp = base + 2 * HD + hd * DH;
+    const int d = threadIdx.x % DH, grp = threadIdx.x / DH;
+    for (int e = threadIdx.x; e < nc * DH; e += kBlock) {
+        const int i = e / DH, dd = e % DH;
+        ksm[i][dd] = kp[(long)i * ld + dd];
+        vsm[i][dd] = vp[(long)i * ld + dd];
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int i = grp; i < nc; i += 8) m = fmaxf(m, ksm[i][d]);
+    part[grp][d] = m;
+    __syncthreads();
+    if (threadIdx.x < DH) {
+        float mm = part[0][d];
+        for (int g = 1; g < 8; ++g) mm = fmaxf(mm, part[g][d]);
+        kmax[d] = mm;
+    }
+    __syncthreads();
+    const float km = kmax[d];
+    float s = 0.f;
+    for (int i = grp; i < nc; i += 8) s += expf(ksm[i][d] - km);
+    __syncthreads();
+    part[grp][d] = s;
+    __syncthreads();
+    float* rec = ws + ((size_t)blockIdx.x * gridDim.y + c) * LA_REC;
+    if (threadIdx.x < DH) {
+        float ss = 0.f;
+        for (int g = 0; g < 8; ++g) ss += part[g][d];
+        rec[d] = km;
+        rec[DH + d] = ss;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};                            // thread owns d and e in [4 grp, 4 grp + 4)
+    for (int i = 0; i < nc; ++i) {
+        const float pexp = expf(ksm[i][d] - km);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(pexp, vsm[i][4 * grp + j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rec[2 * DH + d * DH + 4 * grp + j] = acc[j];
+}
+
+__global__ void __launch_bounds__(kBlock) linear_attention_apply_kernel(const float* __restrict__ qkv, const float* __restrict__ ws,
+                                                                       float* __restrict__ out, int n, int heads, float scale) {
+    __shared__ float gm[DH], gs[DH], ctx[DH][DH + 1];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, c = blockIdx.y, nch = gridDim.y;
+    const int HD = heads * DH, qld = 3 * HD;
+    const float* recs = ws + (size_t)blockIdx.x * nch * LA_REC;
+    const int d = threadIdx.x % DH, grp = threadIdx.x / DH;
+    if (threadIdx.x < DH) {
+        float m = -INFINITY;
+        for (int q = 0; q < nch; ++q) m = fmaxf(m, recs[q * LA_REC + d]);
+        float ssum = 0.f;
+        for (int q = 0; q < nch; ++q) ssum += recs[q * LA_REC + DH + d] * expf(recs[q * LA_REC + d] - m);
+        gm[d] = m;
+        gs[d] = ssum;
+    }
+    __syncthreads();
+    {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < nch; ++q) {
+            const float r = expf(recs[q * LA_REC + d] - gm[d]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(recs[q * LA_REC + 2 * DH + d * DH + 4 * grp + j], r, acc[j]);
+        }
+        const float norm = 1.0f / (gs[d] * (float)n);               // softmax denominator and v / n
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ctx[d][4 * grp + j] = acc[j] * norm;
+    }
+    __syncthreads();
+    const int i = c * LA_CHUNK + threadIdx.x;
+    if (i < n) {
+        const float* qp = qkv + ((long)b * n + i) * qld + hd * DH;
+        float q[DH];
+        float mq = -INFINITY;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) { q[dd] = qp[dd]; mq = fmaxf(mq, q[dd]); }
+        float sq = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) { q[dd] = expf(q[dd] - mq); sq += q[dd]; }
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) q[dd] = __fmul_rn(q[dd] / sq, scale);
+        float* orow = out + ((long)b * n + i) * HD + hd * DH;
+        for (int e = 0; e < DH; ++e) {
+            float acc = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < DH; ++dd) acc = fmaf(ctx[dd][e], q[dd], acc);
+            orow[e] = acc;
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------- full attention core (:351-357), n <= 256
 // one workgroup per (b, head); K and V staged in LDS; thread i owns query i
 __global__ void __launch_bounds__(kBlock) attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n,
@@ -428,6 +539,27 @@ extern "C" int nfdp_linear_attention_f32(const float* qkv, float* out, int B, in
     }
     hipLaunchKernelGGL(linear_attention_kernel, dim3(B * heads), dim3(kBlock), la_lds, as_stream(stream), qkv, out, n, heads, scale);
     NFDP_CHECK_LAUNCH("linear_attention");
+    return NFDP_OK;
+}
+
+extern "C" size_t nfdp_linear_attention_ws_bytes(int B, int n, int heads) {
+    if (B <= 0 || n <= kBlock || heads <= 0) return 0;
+    return (size_t)B * heads * cdiv(n, LA_CHUNK) * LA_REC * sizeof(float);
+}
+
+extern "C" int nfdp_linear_attention_chunked_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale,
+                                                 void* ws, nfdp_stream_t stream) {
+    NFDP_REQUIRE(qkv && out && ws, NFDP_EINVAL, "linear_attention_chunked: null pointer");
+    NFDP_REQUIRE(B >= 0 && n > 0 && heads > 0, NFDP_ESHAPE, "linear_attention_chunked: bad shape");
+    NFDP_REQUIRE(dim_head == DH, NFDP_EUNSUPPORTED, "linear_attention_chunked: dim_head=%d (32 only)", dim_head);
+    if (B == 0) return NFDP_OK;
+    const int nch = (int)cdiv(n, LA_CHUNK);
+    NFDP_REQUIRE(nch <= 65535, NFDP_ESHAPE, "linear_attention_chunked: n=%d too long", n);
+    const dim3 grid(B * heads, nch);
+    hipLaunchKernelGGL(linear_attention_partial_kernel, grid, dim3(kBlock), 0, as_stream(stream), qkv, reinterpret_cast<float*>(ws), n, heads);
+    hipLaunchKernelGGL(linear_attention_apply_kernel, grid, dim3(kBlock), 0, as_stream(stream), qkv, reinterpret_cast<const float*>(ws), out,
+                       n, heads, scale);
+    NFDP_CHECK_LAUNCH("linear_attention_chunked");
     return NFDP_OK;
 }
 

@@ -624,6 +624,12 @@ def linear_attention(qkv: torch.Tensor, heads: int, dim_head: int, scale: float)
     _need(qkv, torch.float32, "linear_attention"); _dense(qkv, "linear_attention")
     b, h, w, _ = qkv.shape
     out = torch.empty((b, h, w, heads * dim_head), device=qkv.device, dtype=torch.float32)
+    nbytes = lib().nfdp_linear_attention_ws_bytes(b, h * w, heads)
+    if nbytes:                                                       # n > 256: chunked over the grid, two launches
+        ws = torch.empty(nbytes, device=qkv.device, dtype=torch.uint8)
+        _call("nfdp_linear_attention_chunked_f32", _ptr(qkv), _ptr(out), b, h * w, heads, dim_head, float(scale), _ptr(ws), _stream(),
+              label="linear_attention_chunked")
+        return out
     _call("nfdp_linear_attention_f32", _ptr(qkv), _ptr(out), b, h * w, heads, dim_head, float(scale), _stream(),
           label="linear_attention_kernel")
     return out

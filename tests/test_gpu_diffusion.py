@@ -166,3 +166,18 @@ def test_concurrent_part_streams_match_sequential_sampling():
     for other in outs[True]:
         for a, b in zip(outs[False][0], other):
             assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("hw,b", [(16, 3), (20, 2), (32, 2), (64, 1)])
+def test_linear_attention_core_long_sequences(hw, b):
+    """LinearAttention core (gaussian_diffusion.py:320-332) at n = 256 (one workgroup per head) and beyond (positions chunked over
+    the grid, streaming-softmax recombination; n = 400 has a ragged last chunk) against the plain formula."""
+    heads, d, n = 4, 32, hw * hw
+    g = torch.Generator().manual_seed(hw)
+    qkv = torch.randn(b, 3 * heads * d, hw, hw, generator=g) * 1.5
+    q, k, v = (t.reshape(b, heads, d, n) for t in qkv.chunk(3, dim=1))
+    ctx = torch.einsum("bhdn,bhen->bhde", k.softmax(dim=-1), v / n)
+    ref = torch.einsum("bhde,bhdn->bhen", ctx, q.softmax(dim=-2) * d ** -0.5).reshape(b, heads * d, hw, hw)
+    got = K.linear_attention(qkv.permute(0, 2, 3, 1).contiguous().to(DEV), heads, d, d ** -0.5)
+    err = float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
