@@ -197,7 +197,8 @@ int nfdp_linear_attention_f32(const float* qkv, float* out, int B, int n, int he
 size_t nfdp_linear_attention_ws_bytes(int B, int n, int heads);
 int nfdp_linear_attention_chunked_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale, void* ws,
                                       nfdp_stream_t stream);
-/* Attention.forward :347-357 between to_qkv and to_out (softmax over keys), n <= 256 pixels. */
+/* Attention.forward :347-357 between to_qkv and to_out (softmax over keys); n > 256 pixels: queries chunked over the grid, keys
+ * streamed through LDS. */
 int nfdp_attention_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale,
                        nfdp_stream_t stream);
 /* nn.Upsample(scale_factor=2, mode='nearest') :171;  x [B,H,W,C] -> y [B,2H,2W,C]. */

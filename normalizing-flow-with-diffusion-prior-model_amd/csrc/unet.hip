@@ -443,6 +443,60 @@ __global__ void __launch_bounds__(kBlock) attention_kernel(const float* __restri
     for (int dd = 0; dd < DH; ++dd) orow[dd] = o[dd] / den;
 }
 
+// n > 256: queries in chunks of 256 over blockIdx.y, keys / values streamed through LDS in chunks of 256, the same two passes
+// (row max, then exp(s - max) sums) so the arithmetic is that of the one-chunk kernel.
+__global__ void __launch_bounds__(kBlock) attention_long_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n,
+                                                               int heads, float scale) {
+    __shared__ float Ks[kBlock][DH + 1], Vs[kBlock][DH + 1];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int HD = heads * DH, ld = 3 * HD;
+    const float* base = qkv + (long)b * n * ld;
+    const int i = blockIdx.y * kBlock + threadIdx.x;
+    const bool active = i < n;
+    float q[DH];
+#pragma unroll
+    for (int dd = 0; dd < DH; ++dd) q[dd] = active ? __fmul_rn(base[(long)i * ld + hd * DH + dd], scale) : 0.f;
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < n; j0 += kBlock) {
+        const int nc = (n - j0) < kBlock ? (n - j0) : kBlock;
+        __syncthreads();
+        for (int e = threadIdx.x; e < nc * DH; e += kBlock) Ks[e / DH][e % DH] = base[(long)(j0 + e / DH) * ld + HD + hd * DH + e % DH];
+        __syncthreads();
+        for (int j = 0; j < nc; ++j) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < DH; ++dd) sdot = fmaf(q[dd], Ks[j][dd], sdot);
+            mx = fmaxf(mx, sdot);
+        }
+    }
+    float o[DH];
+#pragma unroll
+    for (int dd = 0; dd < DH; ++dd) o[dd] = 0.f;
+    float den = 0.f;
+    for (int j0 = 0; j0 < n; j0 += kBlock) {
+        const int nc = (n - j0) < kBlock ? (n - j0) : kBlock;
+        __syncthreads();
+        for (int e = threadIdx.x; e < nc * DH; e += kBlock) {
+            Ks[e / DH][e % DH] = base[(long)(j0 + e / DH) * ld + HD + hd * DH + e % DH];
+            Vs[e / DH][e % DH] = base[(long)(j0 + e / DH) * ld + 2 * HD + hd * DH + e % DH];
+        }
+        __syncthreads();
+        for (int j = 0; j < nc; ++j) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < DH; ++dd) sdot = fmaf(q[dd], Ks[j][dd], sdot);
+            const float p = expf(sdot - mx);
+            den += p;
+#pragma unroll
+            for (int dd = 0; dd < DH; ++dd) o[dd] = fmaf(p, Vs[j][dd], o[dd]);
+        }
+    }
+    if (!active) return;
+    float* orow = out + ((long)b * n + i) * HD + hd * DH;
+#pragma unroll
+    for (int dd = 0; dd < DH; ++dd) orow[dd] = o[dd] / den;
+}
+
 __global__ void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, long total, int C, int H, int W) {
     for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
         const int c = (int)(i % C);
@@ -568,8 +622,14 @@ extern "C" int nfdp_attention_f32(const float* qkv, float* out, int B, int n, in
     NFDP_REQUIRE(qkv && out, NFDP_EINVAL, "attention: null pointer");
     NFDP_REQUIRE(B >= 0 && n > 0 && heads > 0, NFDP_ESHAPE, "attention: bad shape");
     NFDP_REQUIRE(dim_head == DH, NFDP_EUNSUPPORTED, "attention: dim_head=%d (32 only)", dim_head);
-    NFDP_REQUIRE(n <= kBlock, NFDP_EUNSUPPORTED, "attention: n=%d pixels (<= 256 in this build)", n);
     if (B == 0) return NFDP_OK;
+    if (n > kBlock) {
+        NFDP_REQUIRE(cdiv(n, kBlock) <= 65535, NFDP_ESHAPE, "attention: n=%d too long", n);
+        hipLaunchKernelGGL(attention_long_kernel, dim3(B * heads, (int)cdiv(n, kBlock)), dim3(kBlock), 0, as_stream(stream), qkv, out, n,
+                           heads, scale);
+        NFDP_CHECK_LAUNCH("attention (long)");
+        return NFDP_OK;
+    }
     const size_t lds = (size_t)2 * n * (DH + 1) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {

@@ -181,3 +181,18 @@ def test_linear_attention_core_long_sequences(hw, b):
     got = K.linear_attention(qkv.permute(0, 2, 3, 1).contiguous().to(DEV), heads, d, d ** -0.5)
     err = float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max() / ref.abs().max())
     assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("hw,b", [(8, 3), (16, 2), (20, 2), (32, 1)])
+def test_full_attention_core_long_sequences(hw, b):
+    """Attention core (gaussian_diffusion.py:351-357) at n <= 256 (keys in LDS once) and beyond (queries chunked over the grid,
+    keys streamed) against the plain formula."""
+    heads, d, n = 4, 32, hw * hw
+    g = torch.Generator().manual_seed(100 + hw)
+    qkv = torch.randn(b, 3 * heads * d, hw, hw, generator=g)
+    q, k, v = (t.reshape(b, heads, d, n) for t in qkv.chunk(3, dim=1))
+    sim = torch.einsum("bhdi,bhdj->bhij", q * d ** -0.5, k)
+    ref = torch.einsum("bhij,bhdj->bhid", sim.softmax(dim=-1), v).permute(0, 1, 3, 2).reshape(b, heads * d, hw, hw)
+    got = K.attention(qkv.permute(0, 2, 3, 1).contiguous().to(DEV), heads, d, d ** -0.5)
+    err = float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
