@@ -124,7 +124,13 @@ class Conv2dActNorm(nn.Module):
             # data-dependent init (transforms.py:74-78) on the raw conv output, then the fused pass below
             raw = K.conv2d(xh, packed, cv.out_channels, self.filter_size, compute=c, out_dtype=K.F32)
             an.init_from(raw)
-        return K.conv2d(xh, packed, cv.out_channels, self.filter_size, add=an.bias.view(-1), mul=an.scale.view(-1),
+        k = self.filter_size
+        if xh.dtype == torch.float32 and xh.shape[0] * xh.shape[1] * xh.shape[2] >= 4096 and \
+                K.use_im2col_conv(cv.in_channels, cv.out_channels, k, c):
+            # C/2 -> 512 on a narrow fp32 tensor: explicit im2col (9C wide) + the LDS-DMA pointwise GEMM; the packed 3x3
+            # weight is the 1x1 weight for the im2col rows (same bf16 operands and summation order as the implicit GEMM)
+            xh, k = K.im2col3x3(xh), 1
+        return K.conv2d(xh, packed, cv.out_channels, k, add=an.bias.view(-1), mul=an.scale.view(-1),
                         mul_exp=1.0, relu=relu, compute=c, out_dtype=out_dtype)
 
     def forward(self, x: Tensor) -> Tensor:
