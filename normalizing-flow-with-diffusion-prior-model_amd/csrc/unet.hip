@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(kBlock) ws_standardize_kernel(const float* __r
 __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __restrict__ x, float* __restrict__ y, int HW,
                                                                int C, int groups, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
-                                                               const float* __restrict__ ss, int ss_ld, float eps) {
+                                                               const float* __restrict__ ss, int ss_ld, float eps, int lds_cached) {
     __shared__ double red[4];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups, n = HW * cpg;
@@ -89,6 +89,41 @@ __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __r
                 }
                 *reinterpret_cast<float4*>(y + base + (long)(e / q) * C + (e % q) * 4) = make_float4(o[0], o[1], o[2], o[3]);
             }
+        }
+        return;
+    }
+    // larger groups (the 64x64 / 32x32 latent parts of the larger models): the group is staged in LDS when it fits (one global
+    // read instead of three), float4 pieces, same fp64 statistics
+    extern __shared__ __attribute__((aligned(16))) float gsm[];
+    if (lds_cached && cpg % 4 == 0) {
+        const int q = cpg / 4, nv = HW * q;
+        float4* g4 = reinterpret_cast<float4*>(gsm);
+        double s1 = 0.0;
+        for (int e = threadIdx.x; e < nv; e += kBlock) {
+            const float4 v = *reinterpret_cast<const float4*>(x + base + (long)(e / q) * C + (e % q) * 4);
+            g4[e] = v;
+            s1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        }
+        const double mean_d = block_sum256(s1, red) / n;
+        double s2 = 0.0;
+        for (int e = threadIdx.x; e < nv; e += kBlock) {
+            const float4 v = g4[e];
+            const double d0 = v.x - mean_d, d1 = v.y - mean_d, d2 = v.z - mean_d, d3 = v.w - mean_d;
+            s2 += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        const double var_d = block_sum256(s2, red) / n;
+        const float m = (float)mean_d, r = (float)(1.0 / sqrt(var_d + (double)eps));
+        for (int e = threadIdx.x; e < nv; e += kBlock) {
+            const int c0 = g * cpg + (e % q) * 4;
+            const float4 v = g4[e];
+            float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[j], m), r), gamma[c0 + j]), beta[c0 + j]);
+                if (ss) t = __fadd_rn(__fmul_rn(t, __fadd_rn(ss[(long)b * ss_ld + c0 + j], 1.0f)), ss[(long)b * ss_ld + C + c0 + j]);
+                o[j] = t / (1.0f + expf(-t));
+            }
+            *reinterpret_cast<float4*>(y + base + (long)(e / q) * C + (e % q) * 4) = make_float4(o[0], o[1], o[2], o[3]);
         }
         return;
     }
@@ -530,8 +565,18 @@ extern "C" int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, 
     NFDP_REQUIRE(B >= 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, NFDP_ESHAPE, "groupnorm_silu: bad shape");
     if (B == 0) return NFDP_OK;
     NFDP_REQUIRE(!scale_shift || ss_ld >= 2 * C, NFDP_ESHAPE, "groupnorm_silu: ss_ld < 2C");
-    hipLaunchKernelGGL(groupnorm_silu_kernel, dim3(B * groups), dim3(kBlock), 0, as_stream(stream), x, y, HW, C, groups, gamma,
-                       beta, scale_shift, ss_ld, eps);
+    const long n = (long)HW * (C / groups);
+    constexpr long kGnLdsMax = 36 * 1024;                        // floats: 144 KiB of the 160 KiB LDS
+    const int lds_cached = n > 256 * 16 && n <= kGnLdsMax && (C / groups) % 4 == 0 && C % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
+                           ((uintptr_t)y & 15) == 0;
+    static bool gn_attr = false;
+    if (lds_cached && !gn_attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&groupnorm_silu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(kGnLdsMax * sizeof(float)));
+        gn_attr = true;
+    }
+    hipLaunchKernelGGL(groupnorm_silu_kernel, dim3(B * groups), dim3(kBlock), lds_cached ? (size_t)n * sizeof(float) : 0,
+                       as_stream(stream), x, y, HW, C, groups, gamma, beta, scale_shift, ss_ld, eps, lds_cached);
     NFDP_CHECK_LAUNCH("groupnorm_silu");
     return NFDP_OK;
 }

@@ -196,3 +196,20 @@ def test_full_attention_core_long_sequences(hw, b):
     got = K.attention(qkv.permute(0, 2, 3, 1).contiguous().to(DEV), heads, d, d ** -0.5)
     err = float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max() / ref.abs().max())
     assert err < 1e-5, err
+
+
+@pytest.mark.parametrize("hw,c,groups", [(8, 64, 8), (32, 64, 16), (64, 64, 16), (64, 192, 8), (48, 66, 3)])
+def test_groupnorm_silu_all_group_sizes(hw, c, groups):
+    """Block's GroupNorm -> (scale+1) x + shift -> SiLU (gaussian_diffusion.py:267-276) for groups that fit the registers, that
+    are staged in LDS (32x32 / 64x64 latent parts) and that take the three-pass global path (too large or odd widths)."""
+    import torch.nn.functional as F
+    b = 2
+    g = torch.Generator().manual_seed(hw + c)
+    x = torch.randn(b, c, hw, hw, generator=g) * 2.0 + 0.3
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    ss = torch.randn(b, 2 * c, generator=g) * 0.5
+    ref = F.group_norm(x, groups, gamma, beta, eps=1e-5)
+    ref = F.silu(ref * (ss[:, :c, None, None] + 1) + ss[:, c:, None, None])
+    got = K.groupnorm_silu(x.permute(0, 2, 3, 1).contiguous().to(DEV), groups, gamma.to(DEV), beta.to(DEV), ss.to(DEV), 1e-5)
+    err = float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
