@@ -180,6 +180,10 @@ int nfdp_ws_standardize_f32(const float* w, float* out, int Cout, int fan_in, fl
  * one [B][sum 2C] buffer). */
 int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
                             const float* beta, const float* scale_shift, int ss_ld, float eps, nfdp_stream_t stream);
+/* The same with ResnetBlock's residual add (:301) folded in: y = SiLU(...) + residual (residual [B,HW,C] or null). */
+int nfdp_groupnorm_silu_res_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
+                                const float* beta, const float* scale_shift, int ss_ld, float eps, const float* residual,
+                                nfdp_stream_t stream);
 /* LayerNorm.forward :205-209 (channel LayerNorm, gain only) + optional residual add (Residual :160-166). */
 int nfdp_chan_layernorm_f32(const float* x, float* y, long npix, int C, const float* gain, float eps,
                             const float* residual, nfdp_stream_t stream);

@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(kBlock) ws_standardize_kernel(const float* __r
 __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __restrict__ x, float* __restrict__ y, int HW,
                                                                int C, int groups, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
-                                                               const float* __restrict__ ss, int ss_ld, float eps, int lds_cached) {
+                                                               const float* __restrict__ ss, int ss_ld, float eps, int lds_cached,
+                                                               const float* __restrict__ res) {
     __shared__ double red[4];
     const int b = blockIdx.x / groups, g = blockIdx.x % groups;
     const int cpg = C / groups, n = HW * cpg;
@@ -87,7 +88,12 @@ __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __r
                     if (ss) t = __fadd_rn(__fmul_rn(t, __fadd_rn(ss[(long)b * ss_ld + c0 + j], 1.0f)), ss[(long)b * ss_ld + C + c0 + j]);
                     o[j] = t / (1.0f + expf(-t));
                 }
-                *reinterpret_cast<float4*>(y + base + (long)(e / q) * C + (e % q) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                const long off = base + (long)(e / q) * C + (e % q) * 4;
+                if (res) {                                         // ResnetBlock's  h + res_conv(x)  (:301), same fp32 add as a separate pass
+                    const float4 rv = *reinterpret_cast<const float4*>(res + off);
+                    o[0] = __fadd_rn(o[0], rv.x); o[1] = __fadd_rn(o[1], rv.y); o[2] = __fadd_rn(o[2], rv.z); o[3] = __fadd_rn(o[3], rv.w);
+                }
+                *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
         return;
@@ -123,7 +129,12 @@ __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __r
                 if (ss) t = __fadd_rn(__fmul_rn(t, __fadd_rn(ss[(long)b * ss_ld + c0 + j], 1.0f)), ss[(long)b * ss_ld + C + c0 + j]);
                 o[j] = t / (1.0f + expf(-t));
             }
-            *reinterpret_cast<float4*>(y + base + (long)(e / q) * C + (e % q) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            const long off = base + (long)(e / q) * C + (e % q) * 4;
+            if (res) {
+                const float4 rv = *reinterpret_cast<const float4*>(res + off);
+                o[0] = __fadd_rn(o[0], rv.x); o[1] = __fadd_rn(o[1], rv.y); o[2] = __fadd_rn(o[2], rv.z); o[3] = __fadd_rn(o[3], rv.w);
+            }
+            *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
         }
         return;
     }
@@ -142,7 +153,8 @@ __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __r
         const long idx = base + (long)(e / cpg) * C + (e % cpg);
         float v = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(x[idx], m), r), gamma[c]), beta[c]);
         if (ss) v = __fadd_rn(__fmul_rn(v, __fadd_rn(ss[(long)b * ss_ld + c], 1.0f)), ss[(long)b * ss_ld + C + c]);
-        y[idx] = v / (1.0f + expf(-v));                      // SiLU = v * sigmoid(v)
+        v = v / (1.0f + expf(-v));                           // SiLU = v * sigmoid(v)
+        y[idx] = res ? __fadd_rn(v, res[idx]) : v;
     }
 }
 
@@ -558,9 +570,19 @@ extern "C" int nfdp_ws_standardize_f32(const float* w, float* out, int Cout, int
     return NFDP_OK;
 }
 
+extern "C" int nfdp_groupnorm_silu_res_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
+                                           const float* beta, const float* scale_shift, int ss_ld, float eps,
+                                           const float* residual, nfdp_stream_t stream);
+
 extern "C" int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
                                        const float* beta, const float* scale_shift, int ss_ld, float eps,
                                        nfdp_stream_t stream) {
+    return nfdp_groupnorm_silu_res_f32(x, y, B, HW, C, groups, gamma, beta, scale_shift, ss_ld, eps, nullptr, stream);
+}
+
+extern "C" int nfdp_groupnorm_silu_res_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
+                                           const float* beta, const float* scale_shift, int ss_ld, float eps,
+                                           const float* residual, nfdp_stream_t stream) {
     NFDP_REQUIRE(x && y && gamma && beta, NFDP_EINVAL, "groupnorm_silu: null pointer");
     NFDP_REQUIRE(B >= 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, NFDP_ESHAPE, "groupnorm_silu: bad shape");
     if (B == 0) return NFDP_OK;
@@ -568,7 +590,7 @@ extern "C" int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, 
     const long n = (long)HW * (C / groups);
     constexpr long kGnLdsMax = 36 * 1024;                        // floats: 144 KiB of the 160 KiB LDS
     const int lds_cached = n > 256 * 16 && n <= kGnLdsMax && (C / groups) % 4 == 0 && C % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
-                           ((uintptr_t)y & 15) == 0;
+                           ((uintptr_t)y & 15) == 0 && ((uintptr_t)residual & 15) == 0;
     static bool gn_attr = false;
     if (lds_cached && !gn_attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&groupnorm_silu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -576,7 +598,7 @@ extern "C" int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, 
         gn_attr = true;
     }
     hipLaunchKernelGGL(groupnorm_silu_kernel, dim3(B * groups), dim3(kBlock), lds_cached ? (size_t)n * sizeof(float) : 0,
-                       as_stream(stream), x, y, HW, C, groups, gamma, beta, scale_shift, ss_ld, eps, lds_cached);
+                       as_stream(stream), x, y, HW, C, groups, gamma, beta, scale_shift, ss_ld, eps, lds_cached, residual);
     NFDP_CHECK_LAUNCH("groupnorm_silu");
     return NFDP_OK;
 }

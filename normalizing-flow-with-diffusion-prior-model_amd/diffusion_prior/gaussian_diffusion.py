@@ -154,9 +154,9 @@ class Block(nn.Module):
         self.norm = _GroupNormParams(groups, dim_out)
         self.act = _Marker("silu")
 
-    def forward_nhwc(self, xh, scale_shift=None, compute=None):
+    def forward_nhwc(self, xh, scale_shift=None, compute=None, residual=None):
         h = self.proj.forward_nhwc(xh, compute)
-        return K.groupnorm_silu(h, self.norm.num_groups, self.norm.weight, self.norm.bias, scale_shift, 1e-5)
+        return K.groupnorm_silu(h, self.norm.num_groups, self.norm.weight, self.norm.bias, scale_shift, 1e-5, residual)
 
 
 class ResnetBlock(nn.Module):
@@ -176,9 +176,8 @@ class ResnetBlock(nn.Module):
         if ss is None and exists(self.mlp) and exists(temb):
             ss = K.linear(temb, self.mlp[1].weight, self.mlp[1].bias, pre_act=1)
         h = self.block1.forward_nhwc(xh, ss, compute)
-        h = self.block2.forward_nhwc(h, None, compute)
         res = self.res_conv.forward_nhwc(xh, compute) if isinstance(self.res_conv, _Conv) else xh
-        return K.add(h, res.contiguous())
+        return self.block2.forward_nhwc(h, None, compute, residual=res.contiguous())   # h + res folded into block2's epilogue
 
 
 class LinearAttention(nn.Module):

@@ -581,16 +581,20 @@ def ws_standardize(w: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     return out
 
 
-def groupnorm_silu(xh: torch.Tensor, groups: int, gamma, beta, scale_shift: Optional[torch.Tensor], eps: float = 1e-5):
+def groupnorm_silu(xh: torch.Tensor, groups: int, gamma, beta, scale_shift: Optional[torch.Tensor], eps: float = 1e-5,
+                   residual: Optional[torch.Tensor] = None):
     _need(xh, torch.float32, "groupnorm_silu"); _dense(xh, "groupnorm_silu")
+    if residual is not None:
+        _need(residual, torch.float32, "groupnorm_silu residual"); _dense(residual, "groupnorm_silu residual")
+        assert residual.shape == xh.shape
     b, h, w, c = xh.shape
     y = torch.empty_like(xh)
     ss_ld = 0
     if scale_shift is not None:                       # [B, 2C] rows, possibly a column slice of a wider [B, sum] buffer
         assert scale_shift.shape == (b, 2 * c) and scale_shift.stride(1) == 1
         ss_ld = scale_shift.stride(0) if b > 1 else 2 * c
-    _call("nfdp_groupnorm_silu_f32", _ptr(xh), _ptr(y), b, h * w, c, groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift),
-          ss_ld, float(eps), _stream(), label="groupnorm_silu_kernel", nbytes=8.0 * xh.numel())
+    _call("nfdp_groupnorm_silu_res_f32", _ptr(xh), _ptr(y), b, h * w, c, groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift),
+          ss_ld, float(eps), _ptr(residual), _stream(), label="groupnorm_silu_kernel", nbytes=8.0 * xh.numel())
     return y
 
 
