@@ -232,3 +232,36 @@ def test_five_level_model_against_oracle(compute, tol):
     assert_close(ldj, ldj_o, tol, "ldj")
     assert_close(logp, logp_o, tol, "logp")
     assert_close(flow.invert(zs), x, 1e-3 if compute == "f32" else 5e-2, "round trip")
+
+
+@pytest.mark.parametrize("c,L,kf,size,b", [(1, 5, 1, 32, 3), (3, 4, 1, 64, 2), (1, 4, 2, 64, 2), (3, 2, 2, 16, 5), (1, 3, 2, 8, 4)])
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_model_geometries_against_oracle(c, L, kf, size, b, compute):
+    """Geometries beyond the two benchmarked models (1- and 3-channel data, 2 to 5 levels, 8x8 to 64x64 inputs, odd batches):
+    forward + NLL against the oracle, inverse round trip, and one backward pass through the HIP training path (finite
+    gradients for every parameter)."""
+    from normalizing_flow import Glow, GaussianPrior, calculate_loss
+    flow = Glow(in_channel=c, L=L, K=kf, compute=compute).to(DEV)
+    prior = GaussianPrior(2 ** (L + 1) * c).to(DEV)
+    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 3, DEEP)) for k, v in flow.state_dict().items()})
+    prior.load_state_dict({k: T(synth_tensor(k, v.shape, 3, DEEP)) for k, v in prior.state_dict().items()})
+    x = torch.rand(b, c, size, size, generator=torch.Generator().manual_seed(c * 100 + L)) - 0.5
+    tol = TOL if compute == "f32" else 2e-2
+    with torch.no_grad():
+        ldj, logp = z64(b), z64(b)
+        zs, _, _ = flow.transform(x.to(DEV), ldj, logp)
+        logp = logp + prior.compute_log_prob(zs[-1])
+        sd = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
+        psd = {k: v.detach().cpu() for k, v in prior.state_dict().items()}
+        zo, ldj_o, logp_o, _ = O.fwd_nll(x, sd, psd, L, kf)
+        for i, (a, r) in enumerate(zip(zs, zo)):
+            assert_close(a, r, tol, f"z{i}")
+        assert_close(ldj, ldj_o, tol, "ldj")
+        assert_close(logp, logp_o, tol, "logp")
+        assert_close(flow.invert(zs), x, 1e-3 if compute == "f32" else 2e-2, "round trip")
+    ldj, logp = z64(b), z64(b)
+    zs, ldj, logp = flow.transform(x.to(DEV), ldj, logp)
+    loss = calculate_loss(ldj + logp + prior.compute_log_prob(zs[-1]), 32.0, size * size * 3.0)
+    loss.backward()
+    for name, p in list(flow.named_parameters()) + list(prior.named_parameters()):
+        assert p.grad is None or torch.isfinite(p.grad).all(), name
