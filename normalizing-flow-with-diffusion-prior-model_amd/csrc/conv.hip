@@ -290,19 +290,27 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
 // epilogue writes float4 rows.  Roles as in pw_gemm (A := weights) so a lane owns 4 consecutive output channels.
 // Needs Cin % 8 == 0 (8 consecutive k stay inside one tap), fp32 in and out.
 constexpr int SK_LD = 64 + 4;                                  // partial-tile row stride in floats
-#ifndef NFDP_SK_WAVES
-#define NFDP_SK_WAVES 8
-#endif
-#ifndef NFDP_SK_KL
-#define NFDP_SK_KL 4
-#endif
-constexpr int SK_WAVES = NFDP_SK_WAVES;                        // 8 = 2 waves per SIMD: one wave's load latency hides under the other's MFMAs
-constexpr int SK_KL = NFDP_SK_KL;                              // consecutive k per lane per stage (4 or 8): a stage is 4*SK_KL deep
-constexpr int SK_BK = 4 * SK_KL;
-constexpr int SK_THREADS = SK_WAVES * 64;
-constexpr int SK_LDS_BYTES = SK_WAVES * 64 * SK_LD * 4;
 
-__global__ void __launch_bounds__(SK_THREADS) conv_splitk_f32_kernel(const ConvParams P) {
+// EMU: the fp32 products on the bf16 matrix cores.  v = h + m + l with h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)
+// represents an fp32 value exactly (3 x 8 significand bits), and a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + terms
+// below 2^-24 |a*b|: six v_mfma_f32_16x16x32_bf16 (16 cycles each, fp32 accumulation) replace eight v_mfma_f32_16x16x4_f32
+// (32 cycles each) per 32 k: 2.7x fewer matrix-pipe cycles at the accuracy of the fp32 FMA chain (measured against fp64 on
+// K = 576..4608 sums: 2e-7 relative, the chain itself 5e-7).  The splits are VALU work on the fragments already in registers.
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r1 = v[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;
+        h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+    }
+}
+
+template <int SK_WAVES, int SK_KL, bool EMU>       // waves per workgroup, consecutive k per lane per stage (a stage is 4*SK_KL deep)
+__global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const ConvParams P) {
+    constexpr int SK_BK = 4 * SK_KL, SK_THREADS = SK_WAVES * 64;
+    static_assert(!EMU || SK_KL == 8, "the bf16 MFMA takes 8 consecutive k per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* part = reinterpret_cast<float*>(smem);              // [SK_WAVES][64 pixels][SK_LD]
     const int nt = blockIdx.x % P.Nt, mt = blockIdx.x / P.Nt;
@@ -364,6 +372,29 @@ __global__ void __launch_bounds__(SK_THREADS) conv_splitk_f32_kernel(const ConvP
         }
     };
     auto compute = [&](const Frags& f) {
+        if constexpr (EMU) {
+            bf16x8 wh[4], wm[4], wl[4], xh[4], xm[4], xl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float wv[8] = {f.w[i][0].x, f.w[i][0].y, f.w[i][0].z, f.w[i][0].w, f.w[i][1].x, f.w[i][1].y, f.w[i][1].z, f.w[i][1].w};
+                const float xv[8] = {f.x[i][0].x, f.x[i][0].y, f.x[i][0].z, f.x[i][0].w, f.x[i][1].x, f.x[i][1].y, f.x[i][1].z, f.x[i][1].w};
+                split3(wv, wh[i], wm[i], wl[i]);
+                split3(xv, xh[i], xm[i], xl[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                      // smallest terms first
+                    f32x4 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[i], xm[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm[i], xh[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xm[j], c, 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xh[j], c, 0, 0, 0);
+                }
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < SK_KL; ++kk) {
 #pragma unroll
@@ -653,6 +684,14 @@ void launch_by_cout(ConvParams& P, hipStream_t s) {
 
 }  // namespace
 
+static int g_f32_products = 0;
+extern "C" int nfdp_set_f32_products(int mode) {
+    NFDP_REQUIRE(mode == 0 || mode == 1, NFDP_EINVAL, "set_f32_products: mode=%d (0 exact fp32 MFMA, 1 six bf16 MFMAs)", mode);
+    g_f32_products = mode;
+    return NFDP_OK;
+}
+extern "C" int nfdp_get_f32_products(void) { return g_f32_products; }
+
 extern "C" size_t nfdp_conv_packed_bytes(int Cout, int Cin, int KH, int KW, int compute) {
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
     return (size_t)cout_pad_for(Cout) * kpad_for(Cin, KH, KW) * (compute == NFDP_BF16 ? 2 : 4);
@@ -726,11 +765,16 @@ extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void
         P.Nt = (int)cdiv(Cout, 64);
         static bool sk_attr_set = false;
         if (!sk_attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      SK_LDS_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<8, 4, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * SK_LD * 4);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<4, 8, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
             sk_attr_set = true;
         }
-        hipLaunchKernelGGL(conv_splitk_f32_kernel, dim3(P.Mt * P.Nt), dim3(SK_THREADS), SK_LDS_BYTES, s, P);
+        if (g_f32_products == 1)      // fp32 products as six bf16 MFMAs (nfdp_set_f32_products)
+            hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true>), dim3(P.Mt * P.Nt), dim3(256), 4 * 64 * SK_LD * 4, s, P);
+        else
+            hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false>), dim3(P.Mt * P.Nt), dim3(512), 8 * 64 * SK_LD * 4, s, P);
         NFDP_CHECK_LAUNCH("conv2d (split-K fp32)");
         return NFDP_OK;
     }

@@ -109,6 +109,12 @@ _trace = None
 _param_epoch = 0
 
 
+def set_f32_products(mode: str) -> None:
+    """'exact' (v_mfma_f32_16x16x4_f32, default) | 'bf16x6' (three-way bf16 split of both operands, six bf16 MFMAs, fp32-chain
+    accuracy) for the small fp32 convs (nfdp_set_f32_products)."""
+    _check(lib().nfdp_set_f32_products({"exact": 0, "bf16x6": 1}[mode]))
+
+
 def param_epoch() -> int:
     return _param_epoch
 

@@ -288,3 +288,27 @@ def test_invconv_prepare_large_c(c):
     assert float((winv.cpu().double() - ref_inv).abs().max()) < 1e-5 * float(ref_inv.abs().max())
     lad2, none = K.invconv_prepare(w.float().to(DEV), want_inverse=False)
     assert none is None and torch.equal(lad2, lad)
+
+
+def test_f32_products_on_bf16_matrix_cores():
+    """nfdp_set_f32_products(1): fp32 operands split three ways into bf16 (exact), six bf16 MFMAs per product - as close to the
+    fp64 result as the exact fp32 MFMA chain (both a few 1e-7), incl. padding borders, ragged tiles and the epilogue."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 9, 7, 72, generator=g) * 3.0
+    wt = torch.randn(100, 72, 3, 3, generator=g) / 25.0
+    add, mul = torch.randn(100, generator=g) * 0.1, torch.randn(100, generator=g) * 0.1
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), padding=1).permute(0, 2, 3, 1)
+    ref_e = torch.relu((ref + add.double()) * torch.exp(3.0 * mul.double()))
+    packed = K.conv_pack(wt.to(DEV), K.F32)
+    errs = {}
+    try:
+        for mode in ("exact", "bf16x6"):
+            K.set_f32_products(mode)
+            got = K.conv2d(x.to(DEV), packed, 100, 3)
+            got_e = K.conv2d(x.to(DEV), packed, 100, 3, add=add.to(DEV), mul=mul.to(DEV), mul_exp=3.0, relu=True)
+            errs[mode] = max(float((got.cpu().double() - ref).abs().max() / ref.abs().max()),
+                             float((got_e.cpu().double() - ref_e).abs().max() / ref_e.abs().max()))
+    finally:
+        K.set_f32_products("exact")
+    assert errs["exact"] < 2e-6 and errs["bf16x6"] < 2e-6, errs
