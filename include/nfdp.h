@@ -230,6 +230,11 @@ int nfdp_p_sample_f32(const float* x, const float* eps_hat, const float* noise, 
 /* one ddim_sample iteration :749-773 with the step's scalars computed by the caller. */
 int nfdp_ddim_step_f32(const float* x, const float* eps_hat, const float* noise, float* out, long n, float sr,
                        float srm1, float sqrt_alpha_next, float c, float sigma, int last, nfdp_stream_t stream);
+/* The same with the step's scalars in a device table, row chosen by a device-side counter (one captured hipGraph serves every
+ * step): table [S][8] fp32 rows (sr, srm1, sqrt_alpha_next, c, sigma, last (0/1), time of this step, unused); step: int64 [1];
+ * t_next (nullable): int64 [B], receives the time of row step+1 for the next U-Net call.  noise must be valid (unused when last). */
+int nfdp_ddim_step_table_f32(const float* x, const float* eps_hat, const float* noise, float* out, long n, const float* table,
+                             const long* step, int S, long* t_next, int B, nfdp_stream_t stream);
 /* p_losses :855-859: out[0] = mean_b( mean_chw(|pred-target|^p) * p2_weight[t_b] ), p = 2 (l1=0) or 1 (l1=1);
  * per_sample_ws: B floats of workspace. */
 int nfdp_diffusion_loss_f32(const float* pred, const float* target, const long* t, const float* p2_weight, int B,

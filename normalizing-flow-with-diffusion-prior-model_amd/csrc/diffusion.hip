@@ -52,6 +52,31 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
     }
 }
 
+// The same step with its scalars read from a device table row selected by a device-side step counter, so that ONE captured
+// hipGraph serves every step of the loop: table[s] = (sr, srm1, sqrt_alpha_next, c, sigma, last, time); also writes the U-Net's
+// timestep of the NEXT step into t_next[b] (the graph then increments the counter).  In place (out == x) is fine.
+__global__ void ddim_step_table_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
+                                       float* __restrict__ out, long total, const float* __restrict__ table, const long* __restrict__ step,
+                                       int S, long* __restrict__ t_next, int B) {
+    const long sidx = step[0] < S ? step[0] : S - 1;
+    const float* row = table + sidx * 8;
+    const float sr = row[0], srm1 = row[1], sqrt_an = row[2], c = row[3], sigma = row[4];
+    const bool last = row[5] != 0.f;
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const float e = eps[i];
+        float x0 = __fsub_rn(__fmul_rn(sr, x[i]), __fmul_rn(srm1, e));
+        x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        float v = x0;
+        if (!last) v = __fadd_rn(__fadd_rn(__fmul_rn(x0, sqrt_an), __fmul_rn(c, e)), __fmul_rn(sigma, noise[i]));
+        out[i] = v;
+    }
+    if (t_next != nullptr && blockIdx.x == 0) {
+        const long nidx = sidx + 1 < S ? sidx + 1 : S - 1;
+        const long tn = (long)table[nidx * 8 + 6];
+        for (int b = threadIdx.x; b < B; b += kBlock) t_next[b] = tn;
+    }
+}
+
 // out[0] = mean_b( mean_chw(|pred-target|^p) * w[t_b] );  one workgroup per sample writes its term, then a finisher
 __global__ void __launch_bounds__(kBlock) loss_per_sample_kernel(const float* __restrict__ pred, const float* __restrict__ target,
                                                                 const long* __restrict__ t, const float* __restrict__ w,
@@ -196,6 +221,17 @@ extern "C" int nfdp_ddim_step_f32(const float* x, const float* eps_hat, const fl
     hipLaunchKernelGGL(ddim_step_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), x, eps_hat, noise, out, n,
                        sr, srm1, sqrt_alpha_next, c, sigma, last);
     NFDP_CHECK_LAUNCH("ddim_step");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_ddim_step_table_f32(const float* x, const float* eps_hat, const float* noise, float* out, long n,
+                                        const float* table, const long* step, int S, long* t_next, int B, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && eps_hat && noise && out && table && step, NFDP_EINVAL, "ddim_step_table: null pointer");
+    NFDP_REQUIRE(n >= 0 && S > 0 && B >= 0, NFDP_ESHAPE, "ddim_step_table: bad size");
+    if (n == 0) return NFDP_OK;
+    hipLaunchKernelGGL(ddim_step_table_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), x, eps_hat, noise, out,
+                       n, table, step, S, t_next, B);
+    NFDP_CHECK_LAUNCH("ddim_step_table");
     return NFDP_OK;
 }
 

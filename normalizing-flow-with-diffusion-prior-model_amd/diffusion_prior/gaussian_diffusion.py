@@ -559,16 +559,94 @@ class GaussianDiffusion(nn.Module):
 
     def sample_iter(self, batch_size=16):
         """Generator form of sample(): yields between timesteps where the loop can be interleaved with other chains (the
-        hipGraph path of p_sample_loop); the DDIM and eager loops run to completion inside the first next()."""
+        hipGraph paths of p_sample_loop and ddim_sample); the eager loops run to completion inside the first next()."""
         shape = (batch_size, self.channels, self.image_size, self.image_size)
         if not self.is_ddim_sampling and self.use_graph and self.num_timesteps > 1:
             return (yield from self.p_sample_loop_iter(shape))
+        if self.is_ddim_sampling and self.use_graph and self.betas.is_cuda:
+            return (yield from self.ddim_sample_iter(shape))
         return self.sample(batch_size)
+
+    # ---- DDIM (the reference's yaml default: sampling_timesteps = 100 < T): the same captured-step machinery
+    def _ddim_table(self, device):
+        """[S, 8] fp32 rows (sr, srm1, sqrt(alpha_next), c, sigma, last, time, 0): the per-step scalars of reference :749-773,
+        computed once on the host in fp32 from the schedule exactly as the eager loop below computes them."""
+        key = ("ddim_table", str(device), self.sampling_timesteps, float(self.ddim_sampling_eta))
+        if key not in self._graphs:
+            total, S, eta = self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+            times = list(reversed(torch.linspace(-1, total - 1, steps=S + 1).int().tolist()))
+            ac = self.alphas_cumprod.detach().cpu()
+            sr, srm1 = self.sqrt_recip_alphas_cumprod.detach().cpu(), self.sqrt_recipm1_alphas_cumprod.detach().cpu()
+            rows = []
+            for time, time_next in zip(times[:-1], times[1:]):
+                if time_next < 0:
+                    rows.append([float(sr[time]), float(srm1[time]), 0.0, 0.0, 0.0, 1.0, float(time), 0.0])
+                else:
+                    alpha, alpha_next = ac[time], ac[time_next]
+                    sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+                    cc = (1 - alpha_next - sigma ** 2).sqrt()
+                    rows.append([float(sr[time]), float(srm1[time]), float(alpha_next.sqrt()), float(cc), float(sigma), 0.0,
+                                 float(time), 0.0])
+            self._graphs[key] = torch.tensor(rows, dtype=torch.float32, device=device)
+        return self._graphs[key]
+
+    def _ddim_step_inplace(self, xh: Tensor, tb: Tensor, step: Tensor, table: Tensor, gen: torch.Generator) -> None:
+        eps = self.model.forward_nhwc(xh, tb)
+        noise = torch.randn(xh.shape, device=xh.device, dtype=xh.dtype, generator=gen)
+        K.ddim_step_table(xh, eps, noise, table, step, tb)           # x in place; tb <- time of the next step
+        step.add_(1)
+
+    def _captured_ddim_step(self, shape_nhwc, device):
+        key = ("ddim", tuple(shape_nhwc), str(device), self.sampling_timesteps, float(self.ddim_sampling_eta))
+        if key not in self._graphs:
+            table = self._ddim_table(device)
+            xh = torch.zeros(shape_nhwc, device=device)
+            tb = torch.zeros(shape_nhwc[0], device=device, dtype=torch.long)
+            step = torch.zeros(1, device=device, dtype=torch.long)
+            gen = torch.Generator(device=device)               # a generator per graph: see _captured_step
+            warm = torch.cuda.Stream(device=device)
+            warm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(warm):
+                for _ in range(2):
+                    step.zero_(); tb.fill_(int(table[0, 6].item()))
+                    self._ddim_step_inplace(xh, tb, step, table, gen)
+            torch.cuda.current_stream().wait_stream(warm)
+            g = torch.cuda.CUDAGraph()
+            g.register_generator_state(gen)
+            step.zero_()
+            with torch.cuda.graph(g):
+                self._ddim_step_inplace(xh, tb, step, table, gen)
+            self._graphs[key] = (g, xh, tb, step, gen, int(table[0, 6].item()))
+        return self._graphs[key]
+
+    def ddim_sample_iter(self, shape):
+        """The DDIM loop on the captured step as a generator (one sampling step per next(), the sample through StopIteration):
+        the U-Net's timestep and the step's scalars come from device tables indexed by a device-side counter."""
+        with torch.no_grad():
+            device = self.betas.device
+            b, c, h, w = shape
+            g, xh, tb, step, gen, t0 = self._captured_ddim_step((b, h, w, c), device)
+            gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
+            xh.normal_(generator=gen)
+            tb.fill_(t0)
+            step.zero_()
+        for _ in range(self.sampling_timesteps):
+            g.replay()
+            yield
+        with torch.no_grad():
+            return self.unnormalize(K.as_nchw(xh.clone()))
 
     @torch.no_grad()
     def ddim_sample(self, shape, return_all_timesteps=False, x_T: Optional[Tensor] = None,
                     noises: Optional[Sequence[Tensor]] = None):
         """(reference :735-777); the per-step scalars are computed in fp32 on the host from the schedule."""
+        if self.use_graph and x_T is None and noises is None and not return_all_timesteps and self.betas.is_cuda:
+            it = self.ddim_sample_iter(shape)
+            try:
+                while True:
+                    next(it)
+            except StopIteration as done:
+                return done.value
         device, total, S, eta = self.betas.device, self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
         times = torch.linspace(-1, total - 1, steps=S + 1)
         times = list(reversed(times.int().tolist()))

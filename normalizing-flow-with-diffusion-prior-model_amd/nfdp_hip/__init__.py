@@ -705,6 +705,12 @@ def ddim_step(x, eps_hat, noise, sr, srm1, sqrt_an, c, sigma, last: bool):
     return out
 
 
+def ddim_step_table(x, eps_hat, noise, table, step, t_next) -> None:
+    """In-place DDIM step with the scalars of row step[0] of `table` ([S,8] fp32); t_next [B] int64 gets the next step's time."""
+    _call("nfdp_ddim_step_table_f32", _ptr(x), _ptr(eps_hat), _ptr(noise), _ptr(x), x.numel(), _ptr(table), _ptr(step),
+          table.shape[0], _ptr(t_next), 0 if t_next is None else t_next.numel(), _stream())
+
+
 def diffusion_loss(pred, target, t, p2w, l1: bool) -> torch.Tensor:
     _dense(pred, "diffusion_loss"); _dense(target, "diffusion_loss")
     b = pred.shape[0]

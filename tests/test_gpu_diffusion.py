@@ -213,3 +213,25 @@ def test_groupnorm_silu_all_group_sizes(hw, c, groups):
     got = K.groupnorm_silu(x.permute(0, 2, 3, 1).contiguous().to(DEV), groups, gamma.to(DEV), beta.to(DEV), ss.to(DEV), 1e-5)
     err = float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max() / ref.abs().max())
     assert err < 1e-5, err
+
+
+@torch.no_grad()
+def test_ddim_captured_loop_matches_eager_loop(dg):
+    """ddim_sample on the captured step (scalars and timesteps from device tables, device-side step counter, per-graph Philox
+    generator) against the eager loop fed the very same noise: the generator is re-created here from the same seed draw."""
+    dd = make_diffusion(dg, timesteps=50, sampling_timesteps=7, ddim_sampling_eta=1.0)
+    assert dd.is_ddim_sampling
+    shape = (3, 2, 16, 16)
+    torch.manual_seed(123)
+    got = dd.ddim_sample(shape)                                   # captures on first use (the capture draws from its own generator)
+    torch.manual_seed(123)
+    got = dd.ddim_sample(shape)
+    torch.manual_seed(123)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    g2 = torch.Generator(device=DEV).manual_seed(seed)
+    x_T = torch.empty(3, 16, 16, 2, device=DEV).normal_(generator=g2)
+    noises = [torch.randn(3, 16, 16, 2, device=DEV, generator=g2) for _ in range(6)]
+    dd.use_graph = False
+    ref = dd.ddim_sample(shape, x_T=x_T.permute(0, 3, 1, 2), noises=[n.permute(0, 3, 1, 2) for n in noises])
+    assert torch.isfinite(got).all()
+    assert_close(got, ref, 1e-5, "captured vs eager DDIM")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """DiffusionPrior.sample_latents wall time (BASELINE configs[3] shape: MNIST latent parts 2x16x16 / 4x8x8 / 16x4x4, U-Net dim 64
 mults [1,2] groups 8, cosine schedule): the three per-part reverse chains one after the other vs one HIP stream per part.
-usage: python tools/bench_sampling.py [batch] [T]"""
+usage: python tools/bench_sampling.py [batch] [T] [S]   (S < T: DDIM with S sampling steps, the reference's yaml default is S = 100)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "normalizing-flow-with-diffusion-prior-model_amd")]
@@ -9,11 +9,12 @@ import torch
 from diffusion_prior import DiffusionPrior, IdentityFormater
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+S = int(sys.argv[3]) if len(sys.argv) > 3 else T
 fmt = IdentityFormater(3, 1, 32)
 shapes = fmt.get_input_shapes()
 with torch.no_grad():
     prior = DiffusionPrior(latent_formater=fmt, unet_kwargs=dict(dim=64, dim_mults=(1, 2), resnet_block_groups=8),
-                           diffusion_kwargs=dict(timesteps=T, sampling_timesteps=T, loss_type="l2", beta_schedule="cosine"),
+                           diffusion_kwargs=dict(timesteps=T, sampling_timesteps=S, loss_type="l2", beta_schedule="cosine"),
                            image_sizes=[int(s[1]) for s in shapes], latent_channels=[int(s[0]) for s in shapes])
     for mode in (False, True):
         prior.concurrent_parts = mode
@@ -24,5 +25,5 @@ with torch.no_grad():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert all(torch.isfinite(z).all() for z in zs)
-        print(f"B={B} T={T} {'one stream per part' if mode else 'sequential parts    '}: {dt:.3f} s per sample_latents "
-              f"= {dt / T * 1e3:.3f} ms per timestep (3 parts), {B / dt:.1f} latent sets/s", flush=True)
+        print(f"B={B} T={T} S={S} {'one stream per part' if mode else 'sequential parts    '}: {dt:.3f} s per sample_latents "
+              f"= {dt / S * 1e3:.3f} ms per sampling step (3 parts), {B / dt:.1f} latent sets/s", flush=True)
