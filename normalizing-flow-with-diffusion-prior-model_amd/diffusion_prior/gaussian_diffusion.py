@@ -539,22 +539,39 @@ class GaussianDiffusion(nn.Module):
         ret = K.as_nchw(img) if not return_all_timesteps else torch.stack([K.as_nchw(i) for i in imgs], dim=1)
         return self.unnormalize(ret)
 
-    def p_sample_loop_iter(self, shape):
+    def p_sample_loop_iter(self, shape, x_start_nhwc: Optional[Tensor] = None, t_first: Optional[int] = None):
         """The captured-step loop as a generator: enqueues one timestep per next() on the CURRENT stream and returns the sample
         through StopIteration.  DiffusionPrior drives one of these per latent part, each under its own stream, in round-robin,
-        so the parts' steps overlap on the GPU (a step is ~100 small kernels; one chain leaves most CUs idle)."""
+        so the parts' steps overlap on the GPU (a step is ~100 small kernels; one chain leaves most CUs idle).
+        x_start_nhwc / t_first: start from a given x_t at timestep t_first instead of pure noise at T-1 (the reverse halves of
+        sample_latent_given_start and interpolate)."""
+        t_first = self.num_timesteps - 1 if t_first is None else int(t_first)
         with torch.no_grad():
             device = self.betas.device
             b, c, h, w = shape
             g, xh, tb, gen = self._captured_step((b, h, w, c), device)
             gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))       # from the default (CPU) generator: no device sync
-            xh.normal_(generator=gen)
-            tb.fill_(self.num_timesteps - 1)
-        for _ in range(self.num_timesteps - 1):               # t = T-1 .. 1 (the graph decrements t itself)
+            if x_start_nhwc is None:
+                xh.normal_(generator=gen)
+            else:
+                xh.copy_(x_start_nhwc)
+            tb.fill_(t_first)
+        for _ in range(t_first):                              # t = t_first .. 1 (the graph decrements t itself)
             g.replay()
             yield
         with torch.no_grad():
             img, _ = self._p_sample_nhwc(xh, 0, None, False)   # t = 0: no noise
+            return self.unnormalize(K.as_nchw(img))
+
+    def reverse_from_iter(self, x_t: Tensor, t_first: int):
+        """Reverse chain from a given x_t (logical NCHW) at timestep t_first down to 0: the captured loop when available (a
+        generator, see p_sample_loop_iter), else the eager p_sample loop."""
+        if self.use_graph and x_t.is_cuda and t_first >= 1:
+            return (yield from self.p_sample_loop_iter(tuple(x_t.shape), K.to_nhwc(x_t).contiguous(), t_first))
+        with torch.no_grad():
+            img = K.to_nhwc(x_t).contiguous()
+            for i in reversed(range(0, t_first + 1)):
+                img, _ = self._p_sample_nhwc(img, i, None, False)
             return self.unnormalize(K.as_nchw(img))
 
     def sample_iter(self, batch_size=16):
@@ -690,10 +707,15 @@ class GaussianDiffusion(nn.Module):
         assert x1.shape == x2.shape
         tb = torch.full((b,), t, device=device, dtype=torch.long)
         xt1, xt2 = self.q_sample(x1, t=tb), self.q_sample(x2, t=tb)
-        img = K.to_nhwc((1 - lam) * xt1 + lam * xt2).contiguous()
-        for i in reversed(range(0, t)):
-            img, _ = self._p_sample_nhwc(img, i, None, False)
-        return K.as_nchw(img)
+        img = (1 - lam) * xt1 + lam * xt2
+        if t < 1:
+            return img
+        it = self.reverse_from_iter(img, t - 1)               # i = t-1 .. 0, as the reference's loop
+        try:
+            while True:
+                next(it)
+        except StopIteration as done:
+            return done.value
 
     def q_sample(self, x_start, t, noise=None):
         """(reference :806-812)"""

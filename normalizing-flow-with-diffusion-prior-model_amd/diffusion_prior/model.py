@@ -38,14 +38,21 @@ class DiffusionModel(nn.Module):
     def sample_latent_iter(self, n_samples: int):
         return self.__diffusion.sample_iter(batch_size=n_samples)
 
-    def sample_latent_given_start(self, start):
-        """(reference model.py:57-70)"""
+    def sample_latent_given_start_iter(self, start):
+        """(reference model.py:57-70) as a generator: noise the start to T-1, then the reverse chain on the captured step."""
         d = self.__diffusion
-        timesteps = torch.ones(start.size(0), dtype=torch.int64, device=start.device) * (d.num_timesteps - 1)
-        x_t = d.q_sample(start, timesteps, noise=None)
-        for t in reversed(range(0, d.num_timesteps)):
-            x_t, _ = d.p_sample(x_t, t, None)
-        return d.unnormalize(x_t)
+        with torch.no_grad():
+            timesteps = torch.ones(start.size(0), dtype=torch.int64, device=start.device) * (d.num_timesteps - 1)
+            x_t = d.q_sample(start, timesteps, noise=None)
+        return (yield from d.reverse_from_iter(x_t, d.num_timesteps - 1))
+
+    def sample_latent_given_start(self, start):
+        it = self.sample_latent_given_start_iter(start)
+        try:
+            while True:
+                next(it)
+        except StopIteration as done:
+            return done.value
 
     def interpolate_latent(self, latent_1, latent_2, lam):
         return self.__diffusion.interpolate(latent_1, latent_2, t=None, lam=lam)
@@ -136,7 +143,7 @@ class DiffusionPrior(nn.Module):
 
     @torch.no_grad()
     def sample_latents_given_start(self, latents: list) -> list:
-        return self._sample_parts(lambda prior, idx: prior.sample_latent_given_start(latents[idx]))
+        return self._sample_parts(lambda prior, idx: prior.sample_latent_given_start_iter(latents[idx]))
 
     def evaluate_neg_log_likelihood(self, latents: list) -> list:
         processed_latents = self.latent_formater.process_latents(latents)

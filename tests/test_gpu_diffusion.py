@@ -235,3 +235,32 @@ def test_ddim_captured_loop_matches_eager_loop(dg):
     ref = dd.ddim_sample(shape, x_T=x_T.permute(0, 3, 1, 2), noises=[n.permute(0, 3, 1, 2) for n in noises])
     assert torch.isfinite(got).all()
     assert_close(got, ref, 1e-5, "captured vs eager DDIM")
+
+
+@torch.no_grad()
+def test_interpolate_and_given_start_on_the_captured_chain(dg):
+    """GaussianDiffusion.interpolate (:785-804) and DiffusionModel.sample_latent_given_start (model.py:57-70): the reverse half on
+    the captured step equals the eager p_sample loop fed the same noise (the chain's generator is re-created from the seed draw)."""
+    d = make_diffusion(dg, timesteps=9)
+    shape = (2, 2, 16, 16)
+    g = torch.Generator().manual_seed(4)
+    x1, x2 = torch.randn(shape, generator=g).to(DEV), torch.randn(shape, generator=g).to(DEV)
+    d.interpolate(x1, x2, t=6, lam=0.3)                           # captures the step
+    outs = {}
+    for mode in (True, False):
+        d.use_graph = mode
+        torch.manual_seed(77)
+        if mode:
+            outs[mode] = d.interpolate(x1, x2, t=6, lam=0.3)
+        else:                                                      # the eager loop with the captured chain's noise
+            tb = torch.full((2,), 6, device=DEV, dtype=torch.long)
+            xt1, xt2 = d.q_sample(x1, t=tb), d.q_sample(x2, t=tb)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            g2 = torch.Generator(device=DEV).manual_seed(seed)
+            img = K.to_nhwc(0.7 * xt1 + 0.3 * xt2).contiguous()
+            for i in reversed(range(0, 6)):
+                nz = torch.randn(img.shape, device=DEV, generator=g2) if i > 0 else None
+                img, _ = d._p_sample_nhwc(img, i, nz, False)
+            outs[mode] = K.as_nchw(img)
+    assert torch.isfinite(outs[True]).all()
+    assert_close(outs[True], outs[False], 1e-5, "interpolate: captured vs eager chain")
