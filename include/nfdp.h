@@ -57,6 +57,11 @@ int nfdp_unsqueeze_nhwc_f32(const float* y, float* x, int B, int C4, int h, int 
  * K = 576..4608) at 2.7x fewer matrix-pipe cycles.  Process-wide switch (not per call); storage stays fp32. */
 int nfdp_set_f32_products(int mode);
 int nfdp_get_f32_products(void);
+/* The coupling network (coupling_network utils.py:72-90: conv3x3 -> ActNorm -> ReLU -> conv1x1 -> ActNorm -> ReLU -> the nine tap
+ * contributions of the ZeroConv2d) for images of ANY size, bf16 MFMA, hidden activations on chip: xcol = nfdp_im2col3x3_bf16 of the
+ * first C/2 channels ([npix][xcol_ld] bf16, xcol_ld >= 9*C/2 rounded up to 16), packed = nfdp_coupling_fused_pack image,
+ * T [npix][9*C] fp32 (n = tap*C + co) for nfdp_tap_shift_sum_f32 (add = bias, mul = logs, mul_exp = 3).  C in {4,8,16,12,24,48}. */
+int nfdp_coupling_mlp_bf16(const void* xcol, int xcol_ld, long npix, const void* packed, float* T, int C, nfdp_stream_t stream);
 /* Explicit im2col of a narrow tensor for a 3x3 "same" conv (training path of the C/2 -> 512 convs, utils.py:67): x [B,H,W,C] fp32
  * with pixel stride x_ld -> out [B*H*W][Kpad] bf16, out[p][tap*C + c] = x[p + shift(tap)][c] (zero outside the image and for
  * columns >= 9C); Kpad >= 9C, Kpad % 8 == 0, out 16-byte aligned. */

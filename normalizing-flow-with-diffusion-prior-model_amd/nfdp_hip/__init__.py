@@ -951,6 +951,25 @@ def conv3x3_narrow(xh: torch.Tensor, w_oihw: torch.Tensor, *, add=None, mul=None
     return out
 
 
+def coupling_mlp_supported(c: int, n_features: int) -> bool:
+    return n_features == 512 and lib().nfdp_coupling_fused_packed_bytes(c) != 0
+
+
+def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: torch.Tensor, logs: torch.Tensor,
+                       mul_exp: float) -> torch.Tensor:
+    """NN(x_a) of an affine coupling for any image size (bf16 mode): im2col of the C/2-channel half -> the per-pixel three-GEMM
+    chain with the hidden activations on chip (nfdp_coupling_mlp_bf16) -> tap shift-sum with the ZeroConv2d epilogue.
+    xh_a: [B,H,W,C/2] fp32 pixel-strided view; returns h = (log_s | t) [B,H,W,C] fp32."""
+    b, h, w, _ = xh_a.shape
+    xcol = im2col3x3(xh_a)
+    t = torch.empty((b, h, w, 9 * c), device=xh_a.device, dtype=torch.float32)
+    _call("nfdp_coupling_mlp_bf16", _ptr(xcol), xcol.shape[-1], b * h * w, _ptr(packed), _ptr(t), c, _stream(),
+          label=f"coupling_mlp<{c}> hw{h}", flops=2.0 * b * h * w * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c))
+    out = torch.empty((b, h, w, c), device=xh_a.device, dtype=torch.float32)
+    _call("nfdp_tap_shift_sum_f32", _ptr(t), _ptr(out), b, h, w, c, _ptr(bias), _ptr(logs), float(mul_exp), 0, _stream())
+    return out
+
+
 def use_narrow_conv(cin: int, cout: int, k: int) -> bool:
     return k == 3 and cout <= 64 and cin >= 4 * cout and cin >= 128
 

@@ -132,6 +132,17 @@ class AffineCoupling(Transform):
             return None
         return self.net.fused_packed()
 
+    def _net_nhwc(self, xh: Tensor) -> Tensor:
+        """NN(x_a) -> (log_s | t).  Images larger than the fused flow-step kernels' (which own whole 16x16 / 8x8 / 4x4 images) take
+        the tiled form in bf16 mode: explicit im2col -> per-pixel GEMM chain with the hidden activations on chip -> tap shift-sum;
+        otherwise the three convs one by one."""
+        b, hh, ww, c = xh.shape
+        if self.fused and K.compute_enum(self.compute) == K.BF16 and b * hh * ww >= 1024 and \
+                K.coupling_mlp_supported(c, self.n_features) and self.net.fused_ready():
+            zc = self.net[-1]
+            return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(), c, zc.bias, zc.logs.view(-1), zc.logscale_factor)
+        return self.net.forward_nhwc(xh[..., : c // 2], compute=self.compute)
+
     def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], ldj_const: Optional[Tensor] = None) -> Tensor:
         """In place on xh's second channel half.  ldj_const: device [2] fp32 added before the coupling sum."""
         packed = self._fused_pack(xh)
@@ -139,7 +150,7 @@ class AffineCoupling(Transform):
             K.coupling_fused(xh, packed, ldj, ldj_const, inverse=False)
             return xh
         c = xh.shape[-1]
-        h = self.net.forward_nhwc(xh[..., : c // 2], compute=self.compute)
+        h = self._net_nhwc(xh)
         K.coupling_fwd(xh, h, ldj, ldj_const)
         return xh
 
@@ -148,8 +159,7 @@ class AffineCoupling(Transform):
         if packed is not None:
             K.coupling_fused(yh, packed, None, None, inverse=True)
             return yh
-        c = yh.shape[-1]
-        h = self.net.forward_nhwc(yh[..., : c // 2], compute=self.compute)
+        h = self._net_nhwc(yh)
         K.coupling_inv(yh, h)
         return yh
 

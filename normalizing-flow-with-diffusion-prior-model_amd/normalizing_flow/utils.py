@@ -143,6 +143,9 @@ class CouplingNet(nn.Sequential):
     coupling epilogue into ONE launch.  Indexing/keys identical to the reference's nn.Sequential (net.0, net.2,
     net.4; ReLUs at 1 and 3)."""
 
+    def fused_ready(self) -> bool:
+        return self[0].actnorm.initialized() and self[2].actnorm.initialized()
+
     def fused_packed(self):
         """MFMA-register-image pack of all nine parameter tensors for nfdp_coupling_fused_bf16, rebuilt when any
         of them changes.  None while a hidden ActNorm still awaits its data-dependent init."""
