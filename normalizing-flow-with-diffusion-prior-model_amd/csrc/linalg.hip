@@ -150,6 +150,9 @@ __global__ void __launch_bounds__(TI * 32) gauss_jordan_reg_kernel(const float* 
             const int i = cand_i[buf][q];
             if (v > pb || (v == pb && i < p)) { pb = v; p = i; }
         }
+        // bookkeeping by one thread, BEFORE this step's second barrier: the next step's candidate search reads used[] right
+        // after it (written at the end of the step it raced with that search: a pivot row could be chosen twice)
+        if (tid == 0) { used[p] = 1; pivrow[k] = p; kof[p] = k; }
         // 2. the owners of row p publish it
         if (ti == p % TI) {
             const int pxl = p / TI;
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(TI * 32) gauss_jordan_reg_kernel(const float* 
                 else a[x][y] = ((j == k) ? 0.0 : a[x][y]) - f * r;
             }
         }
-        if (tid == 0) { used[p] = 1; pivrow[k] = p; kof[p] = k; pivlog[k] = log(fabs(pv)); }
+        if (tid == 0) pivlog[k] = log(fabs(pv));
         // the next step writes the other LDS buffers; its first barrier orders this step's reads before step k+2's writes
     }
     __syncthreads();
