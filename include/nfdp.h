@@ -132,6 +132,11 @@ int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed,
 int nfdp_coupling_fwd_f32(float* x, const float* h, int B, int HW, int C, double* ldj, const float* ldj_const,
                           nfdp_stream_t stream);
 int nfdp_coupling_inv_f32(float* y, const float* h, int B, int HW, int C, nfdp_stream_t stream);
+/* coupling_fwd for large images at small batch: the pixels of a sample spread over several workgroups, chunk sums of the log-det in
+ * ws (nfdp_coupling_chunked_ws_bytes; 0 = use nfdp_coupling_fwd_f32), added to ldj in chunk order by a second launch. */
+size_t nfdp_coupling_chunked_ws_bytes(int B, int HW, int C);
+int nfdp_coupling_fwd_chunked_f32(float* x, const float* h, int B, int HW, int C, double* ldj, const float* ldj_const, void* ws,
+                                  nfdp_stream_t stream);
 /* Fused coupling layer (bf16 MFMA, fp32 accumulate, fp32 flow state): the whole coupling network
  * (utils.py:83-89) and the coupling epilogue above in ONE launch; the 512-wide hidden activations stay in
  * registers, weights stream through LDS from a pre-packed MFMA register image.  x: [B,H,W,C] contiguous, updated in

@@ -61,6 +61,50 @@ __global__ void __launch_bounds__(kBlock) coupling_kernel(float* __restrict__ x,
     }
 }
 
+// Large images (64x64 ... levels of a 128x128 model): one workgroup per sample leaves most of the chip idle (B = 32), so the
+// pixels of a sample are cut into gridDim.y chunks; the chunk sums of log(s + 1e-6) go to part[b][chunk] and
+// coupling_ldj_finish_kernel adds them to ldj in chunk order (deterministic).
+template <bool INV>
+__global__ void __launch_bounds__(kBlock) coupling_chunk_kernel(float* __restrict__ x, const float* __restrict__ h, int HW, int C,
+                                                                double* __restrict__ part) {
+    __shared__ double red[kBlock / 64];
+    const int Ch = C >> 1;
+    const long base = (long)blockIdx.x * HW * C;
+    const int n = HW * Ch;
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int e0 = blockIdx.y * per, e1 = (e0 + per) < n ? (e0 + per) : n;
+    double acc = 0.0;
+    for (int e = e0 + threadIdx.x; e < e1; e += kBlock) {
+        const int p = e / Ch, c = e - p * Ch;
+        const long row = base + (long)p * C;
+        const float log_s = h[row + c];
+        const float t = h[row + Ch + c];
+        const float s = sigmoid_p2(log_s);
+        const float xb = x[row + Ch + c];
+        if (!INV) {
+            x[row + Ch + c] = __fmul_rn(__fadd_rn(xb, t), s);
+            acc += (double)logf(__fadd_rn(s, 1e-6f));
+        } else {
+            x[row + Ch + c] = __fsub_rn(__fdiv_rn(xb, __fadd_rn(s, 1e-6f)), t);
+        }
+    }
+    if (!INV && part) {
+        const double s = block_sum_d(acc, red);
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = s;
+    }
+}
+
+__global__ void coupling_ldj_finish_kernel(double* __restrict__ ldj, int B, const double* __restrict__ part, int nch,
+                                           const float* __restrict__ ldj_const) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int q = 0; q < nch; ++q) s += part[(size_t)b * nch + q];
+    double v = ldj[b];
+    if (ldj_const) v = (v + (double)ldj_const[0]) + (double)ldj_const[1];
+    ldj[b] = v + s;
+}
+
 // H_MODE 0: h [B,HW,2Cz]; 1: h [2Cz] broadcast
 template <int H_MODE>
 __global__ void __launch_bounds__(kBlock) gauss_logp_kernel(const float* __restrict__ z, int z_ld,
@@ -164,12 +208,44 @@ extern "C" int nfdp_coupling_fwd_f32(float* x, const float* h, int B, int HW, in
     return NFDP_OK;
 }
 
+static int coupling_chunks(int B, int HW, int C) {
+    const long n = (long)HW * (C / 2);
+    if (B <= 0 || n < 16384 || B >= 512) return 0;               // one workgroup per sample is fine
+    long want = 1024 / B, cap = n / 4096;                          // ~4 workgroups per CU, at least 4096 elements each
+    if (want > cap) want = cap;
+    return want < 2 ? 0 : (int)want;
+}
+
+extern "C" size_t nfdp_coupling_chunked_ws_bytes(int B, int HW, int C) {
+    const int nch = coupling_chunks(B, HW, C);
+    return nch ? (size_t)B * nch * sizeof(double) : 0;
+}
+
+extern "C" int nfdp_coupling_fwd_chunked_f32(float* x, const float* h, int B, int HW, int C, double* ldj, const float* ldj_const,
+                                             void* ws, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && h, NFDP_EINVAL, "coupling_fwd_chunked: null pointer");
+    NFDP_REQUIRE(B >= 0 && HW > 0 && C > 0 && C % 2 == 0, NFDP_ESHAPE, "coupling_fwd_chunked: bad shape");
+    const int nch = coupling_chunks(B, HW, C);
+    NFDP_REQUIRE(nch > 0 && (ws || !ldj), NFDP_EINVAL, "coupling_fwd_chunked: not a chunked geometry or missing workspace");
+    hipLaunchKernelGGL((coupling_chunk_kernel<false>), dim3(B, nch), dim3(kBlock), 0, as_stream(stream), x, h, HW, C,
+                       ldj ? reinterpret_cast<double*>(ws) : nullptr);
+    if (ldj)
+        hipLaunchKernelGGL(coupling_ldj_finish_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, as_stream(stream), ldj, B,
+                           reinterpret_cast<const double*>(ws), nch, ldj_const);
+    NFDP_CHECK_LAUNCH("coupling_fwd_chunked");
+    return NFDP_OK;
+}
+
 extern "C" int nfdp_coupling_inv_f32(float* y, const float* h, int B, int HW, int C, nfdp_stream_t stream) {
     NFDP_REQUIRE(y && h, NFDP_EINVAL, "coupling_inv: null pointer");
     NFDP_REQUIRE(B >= 0 && HW > 0 && C > 0, NFDP_ESHAPE, "coupling_inv: bad shape");
     NFDP_REQUIRE(C % 2 == 0, NFDP_ESHAPE, "coupling_inv: C=%d must be even", C);
     if (B == 0) return NFDP_OK;
-    hipLaunchKernelGGL((coupling_kernel<true>), dim3(B), dim3(kBlock), 0, as_stream(stream), y, h, HW, C, nullptr, nullptr);
+    const int nch = coupling_chunks(B, HW, C);
+    if (nch)
+        hipLaunchKernelGGL((coupling_chunk_kernel<true>), dim3(B, nch), dim3(kBlock), 0, as_stream(stream), y, h, HW, C, nullptr);
+    else
+        hipLaunchKernelGGL((coupling_kernel<true>), dim3(B), dim3(kBlock), 0, as_stream(stream), y, h, HW, C, nullptr, nullptr);
     NFDP_CHECK_LAUNCH("coupling_inv");
     return NFDP_OK;
 }

@@ -447,6 +447,12 @@ def coupling_fwd(xh, hh, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.
     b, h, w, c = xh.shape
     if ldj is not None:
         _need(ldj, torch.float64, "coupling_fwd ldj")
+    nbytes = lib().nfdp_coupling_chunked_ws_bytes(b, h * w, c)
+    if nbytes:                                           # large image, small batch: several workgroups per sample
+        ws = torch.empty(nbytes, device=xh.device, dtype=torch.uint8)
+        _call("nfdp_coupling_fwd_chunked_f32", _ptr(xh), _ptr(hh), b, h * w, c, _ptr(ldj), _ptr(ldj_const), _ptr(ws), _stream(),
+              label="coupling_kernel<fwd,chunked>", nbytes=4.0 * xh.numel() * 2)
+        return
     _call("nfdp_coupling_fwd_f32", _ptr(xh), _ptr(hh), b, h * w, c, _ptr(ldj), _ptr(ldj_const), _stream(),
           label="coupling_kernel<fwd>", nbytes=4.0 * xh.numel() * 2)
 

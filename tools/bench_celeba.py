@@ -55,6 +55,14 @@ with torch.no_grad():
     _glow.set_weight_term_cache(True)
     t = timeit(fwd)
     print(f"  with the weight-only terms kept until a weight changes (default): forward+NLL {t * 1e3:.2f} ms = {B / t:.0f} img/s", flush=True)
+    _glow.set_weight_term_cache(False)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        fwd()
+    t = timeit(gr.replay)
+    print(f"  forward+NLL replayed as one hipGraph (log-dets recomputed inside): {t * 1e3:.2f} ms = {B / t:.0f} img/s", flush=True)
+    _glow.set_weight_term_cache(True)
     lat = [z.contiguous() for z in zs]
     t = timeit(lambda: flow.invert_nhwc(lat))
     rec = flow.invert_nhwc(lat)
