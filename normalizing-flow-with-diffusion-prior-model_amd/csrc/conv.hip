@@ -24,6 +24,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int BK = 32;
+int g_f32_products = 0;          // nfdp_set_f32_products: 0 exact fp32 MFMA chain, 1 three-way bf16 split + six bf16 MFMAs
 
 struct ConvParams {
     const void* x;
@@ -44,8 +45,25 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
     return __builtin_bit_cast(uint2, h);
 }
 
-template <bool BF16, bool XBF16, bool VEC, int BM, int BN, int WAVES_M, int WAVES_N>
+// EMU: the fp32 products on the bf16 matrix cores.  v = h + m + l with h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)
+// represents an fp32 value exactly (3 x 8 significand bits), and a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + terms
+// below 2^-24 |a*b|: six v_mfma_f32_16x16x32_bf16 (16 cycles each, fp32 accumulation) replace eight v_mfma_f32_16x16x4_f32
+// (32 cycles each) per 32 k: 2.7x fewer matrix-pipe cycles at the accuracy of the fp32 FMA chain (measured against fp64 on
+// K = 576..4608 sums: 2e-7 relative, the chain itself 5e-7).  The splits are VALU work on the fragments already in registers.
+__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r1 = v[e] - (float)hh;
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;
+        h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
+    }
+}
+
+template <bool BF16, bool XBF16, bool VEC, int BM, int BN, int WAVES_M, int WAVES_N, bool EMU = false>
 __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
+    static_assert(!EMU || !BF16, "the split applies to fp32 operands");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
     static_assert(!XBF16 || BF16, "bf16 storage needs bf16 compute");
     constexpr int ROWB = BF16 ? 64 : 128;              // LDS bytes per 32-k row
@@ -230,13 +248,33 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
                     b[j][4 * h] = v.x; b[j][4 * h + 1] = v.y; b[j][4 * h + 2] = v.z; b[j][4 * h + 3] = v.w;
                 }
             }
+            if constexpr (EMU) {                                   // six bf16 MFMAs per 32 k instead of eight fp32 ones (split3)
+                bf16x8 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+                for (int i = 0; i < TM; ++i) split3(a[i], ah[i], am[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) split3(b[j], bh[j], bm[j], bl[j]);
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        auto c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bm[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am[i], bh[j], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bm[j], c, 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], c, 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][kk], b[j][kk], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -290,22 +328,6 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
 // epilogue writes float4 rows.  Roles as in pw_gemm (A := weights) so a lane owns 4 consecutive output channels.
 // Needs Cin % 8 == 0 (8 consecutive k stay inside one tap), fp32 in and out.
 constexpr int SK_LD = 64 + 4;                                  // partial-tile row stride in floats
-
-// EMU: the fp32 products on the bf16 matrix cores.  v = h + m + l with h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)
-// represents an fp32 value exactly (3 x 8 significand bits), and a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + terms
-// below 2^-24 |a*b|: six v_mfma_f32_16x16x32_bf16 (16 cycles each, fp32 accumulation) replace eight v_mfma_f32_16x16x4_f32
-// (32 cycles each) per 32 k: 2.7x fewer matrix-pipe cycles at the accuracy of the fp32 FMA chain (measured against fp64 on
-// K = 576..4608 sums: 2e-7 relative, the chain itself 5e-7).  The splits are VALU work on the fragments already in registers.
-__device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const __bf16 hh = (__bf16)v[e];
-        const float r1 = v[e] - (float)hh;
-        const __bf16 mm = (__bf16)r1;
-        const float r2 = r1 - (float)mm;
-        h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
-    }
-}
 
 template <int SK_WAVES, int SK_KL, bool EMU>       // waves per workgroup, consecutive k per lane per stage (a stage is 4*SK_KL deep)
 __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const ConvParams P) {
@@ -652,6 +674,18 @@ void launch_cfg(ConvParams& P, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
+    if constexpr (!BF16) {
+        if (g_f32_products == 1) {                       // fp32 products as six bf16 MFMAs (nfdp_set_f32_products)
+            static bool attr_set_e = false;
+            if (lds > 65536 && !attr_set_e) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BF16, XBF16, VEC, BM, BN, WAVES_M, WAVES_N, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set_e = true;
+            }
+            hipLaunchKernelGGL((conv_kernel<BF16, XBF16, VEC, BM, BN, WAVES_M, WAVES_N, true>), dim3(grid), dim3(kThreads), lds, s, P);
+            return;
+        }
+    }
     hipLaunchKernelGGL((conv_kernel<BF16, XBF16, VEC, BM, BN, WAVES_M, WAVES_N>), dim3(grid), dim3(kThreads), lds, s, P);
 }
 
@@ -662,6 +696,12 @@ void launch_cfg_small(ConvParams& P, hipStream_t s) {
     P.Nt = P.Cout / BN;                                   // Cout % 64 == 0: the packed rows (padded to 64/128) cover it
     const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
     const size_t lds = 2 * (size_t)(BM + BN) * (BF16 ? 64 : 128);
+    if constexpr (!BF16) {
+        if (g_f32_products == 1) {
+            hipLaunchKernelGGL((conv_kernel<BF16, XBF16, VEC, BM, BN, 2, 2, true>), dim3(grid), dim3(kThreads), lds, s, P);
+            return;
+        }
+    }
     hipLaunchKernelGGL((conv_kernel<BF16, XBF16, VEC, BM, BN, 2, 2>), dim3(grid), dim3(kThreads), lds, s, P);
 }
 
@@ -684,7 +724,6 @@ void launch_by_cout(ConvParams& P, hipStream_t s) {
 
 }  // namespace
 
-static int g_f32_products = 0;
 extern "C" int nfdp_set_f32_products(int mode) {
     NFDP_REQUIRE(mode == 0 || mode == 1, NFDP_EINVAL, "set_f32_products: mode=%d (0 exact fp32 MFMA, 1 six bf16 MFMAs)", mode);
     g_f32_products = mode;

@@ -313,6 +313,18 @@ def test_f32_products_on_bf16_matrix_cores():
     finally:
         K.set_f32_products("exact")
     assert errs["exact"] < 2e-6 and errs["bf16x6"] < 2e-6, errs
+    # the tiled conv kernel (short K: not the split-K path) takes the same switch
+    x2 = torch.randn(4, 16, 16, 12, generator=g)
+    w2 = torch.randn(96, 12, 3, 3, generator=g) / 10.0
+    ref2 = F.conv2d(x2.permute(0, 3, 1, 2).double(), w2.double(), padding=1).permute(0, 2, 3, 1)
+    p2 = K.conv_pack(w2.to(DEV), K.F32)
+    try:
+        for mode in ("exact", "bf16x6"):
+            K.set_f32_products(mode)
+            got2 = K.conv2d(x2.to(DEV), p2, 96, 3)
+            assert float((got2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 2e-6, mode
+    finally:
+        K.set_f32_products("exact")
 
 
 def test_coupling_chunked_matches_per_sample_kernel():

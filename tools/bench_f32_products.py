@@ -8,7 +8,8 @@ import torch
 import torch.nn.functional as F
 import nfdp_hip as K
 dev = "cuda"
-for (b, hw, cin, cout, k) in [(64, 16, 64, 64, 3), (64, 8, 128, 128, 3), (64, 8, 192, 128, 3), (16, 8, 512, 64, 3)]:
+for (b, hw, cin, cout, k) in [(64, 16, 64, 64, 3), (64, 8, 128, 128, 3), (64, 8, 192, 128, 3), (16, 8, 512, 64, 3),
+                              (32, 64, 64, 64, 3), (32, 64, 128, 64, 3), (512, 16, 512, 512, 1), (512, 16, 6, 512, 3)]:
     g = torch.Generator().manual_seed(cin)
     x = torch.randn(b, hw, hw, cin, generator=g)
     w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
