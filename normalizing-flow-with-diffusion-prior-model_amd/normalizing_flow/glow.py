@@ -78,7 +78,9 @@ class StepFlow(Transform):
 # SURVEY Appendix A #4); with this switch on they are kept per level until a 1x1-conv weight changes (tensor version /
 # storage / optimizer epoch) - evaluation and sampling run many batches on fixed weights, and for a 5-level model the 16
 # Gauss-Jordans of the C = 192 level cost 12 ms, a third of a forward pass.  bench.py turns it off: every timed step
-# recomputes them, as the reference does.  Never read or filled while a stream is capturing.
+# recomputes them, as the reference does.  Never read or filled while a stream is capturing.  Like the packed-weight caches the
+# key is (storage, tensor version, optimizer epoch): an in-place edit through `.data` (which has its own version counter) is
+# invisible to it - call nfdp_hip.bump_param_epoch() after such an edit, or switch the cache off.
 CACHE_WEIGHT_TERMS = True
 
 
