@@ -289,7 +289,11 @@ __global__ void __launch_bounds__(kBlock) linear_attention_kernel(const float* _
     __syncthreads();
     // 2. column sum of exp(k - max)
     float s = 0.f;
-    for (int i = grp; i < n; i += 8) s += expf(kp[(long)i * ld + d] - kmax[d]);
+    for (int i = grp; i < n; i += 8) {
+        const float ev = expf(kp[(long)i * ld + d] - kmax[d]);
+        if (staged) lsm[i * (DH + 1) + d] = ev;                     // keep exp(k - max) in place of k: step 3 needs it for every e
+        s += ev;
+    }
     part[grp][d] = s;
     __syncthreads();
     if (threadIdx.x < DH) {
@@ -304,7 +308,7 @@ __global__ void __launch_bounds__(kBlock) linear_attention_kernel(const float* _
         const float inv_n = 1.0f / (float)n;
         const float km = kmax[d], ks = ksum[d];
         for (int i = 0; i < n; ++i) {
-            const float p = expf(kp[(long)i * ld + d] - km) / ks;
+            const float p = (staged ? kp[(long)i * ld + d] : expf(kp[(long)i * ld + d] - km)) / ks;
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = fmaf(p, vp[(long)i * ld + 4 * grp + j] * inv_n, acc[j]);
         }
@@ -313,6 +317,36 @@ __global__ void __launch_bounds__(kBlock) linear_attention_kernel(const float* _
     }
     __syncthreads();
     // 4. per pixel: softmax over d of q, times scale, then out[e] = sum_d ctx[d][e] q[d]
+    if (staged) {
+        // k and v are done with: their LDS holds the q rows (coalesced load) and then the output rows (coalesced store); a thread
+        // walking its own 128-byte row of q / out in global memory touched 32 different lines per wave instruction
+        float* qs = lsm;
+        float* os = lsm + n * (DH + 1);
+        for (int e = threadIdx.x; e < n * DH; e += kBlock) qs[(e / DH) * (DH + 1) + e % DH] = qp[(long)(e / DH) * qld + e % DH];
+        __syncthreads();
+        const int i = threadIdx.x;
+        if (i < n) {
+            float q[DH];
+            float mq = -INFINITY;
+#pragma unroll
+            for (int dd = 0; dd < DH; ++dd) { q[dd] = qs[i * (DH + 1) + dd]; mq = fmaxf(mq, q[dd]); }
+            float sq = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < DH; ++dd) { q[dd] = expf(q[dd] - mq); sq += q[dd]; }
+#pragma unroll
+            for (int dd = 0; dd < DH; ++dd) q[dd] = __fmul_rn(q[dd] / sq, scale);
+            for (int e = 0; e < DH; ++e) {
+                float acc = 0.f;
+#pragma unroll
+                for (int dd = 0; dd < DH; ++dd) acc = fmaf(ctx[dd][e], q[dd], acc);
+                os[i * (DH + 1) + e] = acc;
+            }
+        }
+        __syncthreads();
+        float* obase = out + (long)b * n * HD + hd * DH;
+        for (int e = threadIdx.x; e < n * DH; e += kBlock) obase[(long)(e / DH) * HD + e % DH] = os[(e / DH) * (DH + 1) + e % DH];
+        return;
+    }
     for (int i = threadIdx.x; i < n; i += kBlock) {
         float q[DH];
         float mq = -INFINITY;
@@ -422,26 +456,34 @@ __global__ void __launch_bounds__(kBlock) linear_attention_apply_kernel(const fl
         for (int j = 0; j < 4; ++j) ctx[d][4 * grp + j] = acc[j] * norm;
     }
     __syncthreads();
-    const int i = c * LA_CHUNK + threadIdx.x;
-    if (i < n) {
-        const float* qp = qkv + ((long)b * n + i) * qld + hd * DH;
+    // this chunk's q rows in, output rows out: both through LDS so the global accesses are coalesced
+    __shared__ float qs[LA_CHUNK][DH + 1], os[LA_CHUNK][DH + 1];
+    const int i0 = c * LA_CHUNK;
+    const int nc = (n - i0) < LA_CHUNK ? (n - i0) : LA_CHUNK;
+    const float* qbase = qkv + ((long)b * n + i0) * qld + hd * DH;
+    for (int e = threadIdx.x; e < nc * DH; e += kBlock) qs[e / DH][e % DH] = qbase[(long)(e / DH) * qld + e % DH];
+    __syncthreads();
+    if (threadIdx.x < nc) {
+        const int i = threadIdx.x;
         float q[DH];
         float mq = -INFINITY;
 #pragma unroll
-        for (int dd = 0; dd < DH; ++dd) { q[dd] = qp[dd]; mq = fmaxf(mq, q[dd]); }
+        for (int dd = 0; dd < DH; ++dd) { q[dd] = qs[i][dd]; mq = fmaxf(mq, q[dd]); }
         float sq = 0.f;
 #pragma unroll
         for (int dd = 0; dd < DH; ++dd) { q[dd] = expf(q[dd] - mq); sq += q[dd]; }
 #pragma unroll
         for (int dd = 0; dd < DH; ++dd) q[dd] = __fmul_rn(q[dd] / sq, scale);
-        float* orow = out + ((long)b * n + i) * HD + hd * DH;
         for (int e = 0; e < DH; ++e) {
             float acc = 0.f;
 #pragma unroll
             for (int dd = 0; dd < DH; ++dd) acc = fmaf(ctx[dd][e], q[dd], acc);
-            orow[e] = acc;
+            os[i][e] = acc;
         }
     }
+    __syncthreads();
+    float* obase = out + ((long)b * n + i0) * HD + hd * DH;
+    for (int e = threadIdx.x; e < nc * DH; e += kBlock) obase[(long)(e / DH) * HD + e % DH] = os[e / DH][e % DH];
 }
 
 // ----------------------------------------------------------------------------- full attention core (:351-357), n <= 256
