@@ -118,21 +118,28 @@ class ConvScaleFn(Function):
     def backward(ctx, dy):
         xh, weight, mul, y = ctx.saved_tensors
         dc, dmul, dadd = K.scale_bwd(dy.contiguous(), y, mul.detach().reshape(-1), ctx.f, ctx.relu)   # dc in y's storage type
-        dx = None
+        dx, dc_col = None, None
         if ctx.needs_input_grad[0]:
             wt = K.conv_flip_weights(weight.detach().contiguous())
             if K.use_narrow_conv(weight.shape[0], weight.shape[1], ctx.k):   # data gradient of C/2 -> 512: a 512 -> C/2 conv
                 dx = K.conv3x3_narrow(dc, wt, compute=ctx.compute)
             elif dc.dtype == torch.float32 and K.use_im2col_conv(weight.shape[0], weight.shape[1], ctx.k, ctx.compute):
                 # data gradient of the 512 -> C zero conv: a C -> 512 conv of the narrow dc, as im2col + pointwise GEMM
-                dx = K.conv2d(K.im2col3x3(dc), K.conv_pack(wt, ctx.compute), weight.shape[1], 1, compute=ctx.compute,
+                dc_col = K.im2col3x3(dc)
+                dx = K.conv2d(dc_col, K.conv_pack(wt, ctx.compute), weight.shape[1], 1, compute=ctx.compute,
                               out_dtype=K.BF16 if ctx.x_dtype == torch.bfloat16 else K.F32)
             else:
                 dx = K.conv2d(dc, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute,
                               out_dtype=K.BF16 if ctx.x_dtype == torch.bfloat16 else K.F32)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
-        if ctx.im2col:                                                     # xh is the saved im2col matrix: a plain GEMM over pixels
+        if dc_col is not None and xh.dtype == torch.bfloat16:
+            # weight gradient of the zero conv from the same im2col matrix: G[i][tap*C + c] = sum_p x[p][i] dc[p + shift(tap)][c] is a
+            # plain GEMM over pixels of two bf16 tensors (LDS-DMA kernel, no gather), and dW[c][i][ky][kx] = G[i][2-ky][2-kx][c]
+            o, i = weight.shape[:2]
+            g = K.conv_wgrad(dc_col, xh, 1, compute=ctx.compute)[:, :9 * o, 0, 0]
+            dw = g.reshape(i, 3, 3, o).flip(1, 2).permute(3, 0, 1, 2).contiguous()
+        elif ctx.im2col:                                                   # xh is the saved im2col matrix: a plain GEMM over pixels
             o, i = weight.shape[:2]
             dw = K.conv_wgrad(xh, dc, 1, compute=ctx.compute)[:, :9 * i, 0, 0].reshape(o, 3, 3, i).permute(0, 3, 1, 2).contiguous()
         else:
