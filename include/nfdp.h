@@ -313,6 +313,12 @@ int nfdp_gauss_logp_bwd_f32(const float* z, int z_ld, const float* h, int h_mode
  * decay) on all n elements; step = 1-based iteration count.  The norm never leaves the device; norm_out (nullable)
  * receives it.  ws: nfdp_fused_adam_ws_bytes() bytes. */
 size_t nfdp_fused_adam_ws_bytes(void);
+/* The same with the learning rate and the step count on the device: hyper = double[2] {lr, steps taken so far}; the call increments
+ * hyper[1] first and derives the bias corrections from it in the kernel, so a captured hipGraph of a training step replays a
+ * correct Adam step every time (host-side scalars would freeze at their capture-time values). */
+int nfdp_fused_adam_step_dev_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm,
+                                 double* hyper, float beta1, float beta2, float eps, float weight_decay, int adamw, void* ws,
+                                 float* norm_out, nfdp_stream_t stream);
 int nfdp_fused_adam_step_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int adamw, long step, void* ws,
                              float* norm_out, nfdp_stream_t stream);

@@ -38,9 +38,17 @@ __global__ void __launch_bounds__(kBlock) adam_step_kernel(float* __restrict__ p
                                                           const double* __restrict__ partial, int n_partial, float max_norm,
                                                           float lr, float beta1, float beta2, float eps, float weight_decay,
                                                           int adamw, float bias_c1, float bias_c2_sqrt,
-                                                          float* __restrict__ norm_out) {
-    __shared__ float coef_s;
+                                                          float* __restrict__ norm_out, const double* __restrict__ hyper) {
+    __shared__ float coef_s, hyp_s[3];
     if (threadIdx.x == 0) {
+        if (hyper != nullptr) {                  // device-resident learning rate and step count: the launch is replayable in a hipGraph
+            const double step = hyper[1];
+            hyp_s[0] = (float)hyper[0];
+            hyp_s[1] = (float)(1.0 - pow((double)beta1, step));
+            hyp_s[2] = (float)sqrt(1.0 - pow((double)beta2, step));
+        } else {
+            hyp_s[0] = lr; hyp_s[1] = bias_c1; hyp_s[2] = bias_c2_sqrt;
+        }
         float coef = 1.0f;
         if (max_norm > 0.f && n_clip > 0) {
             double s = 0.0;
@@ -53,7 +61,9 @@ __global__ void __launch_bounds__(kBlock) adam_step_kernel(float* __restrict__ p
     }
     __syncthreads();
     const float coef = coef_s;
-    const float step_size = lr / bias_c1;
+    lr = hyp_s[0];
+    bias_c2_sqrt = hyp_s[2];
+    const float step_size = lr / hyp_s[1];
     for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
         float gi = g[i];
         if (i < n_clip && coef != 1.0f) {
@@ -74,17 +84,41 @@ __global__ void __launch_bounds__(kBlock) adam_step_kernel(float* __restrict__ p
     }
 }
 
+__global__ void adam_tick_kernel(double* __restrict__ hyper) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) hyper[1] += 1.0;
+}
+
 }  // namespace
 
 extern "C" size_t nfdp_fused_adam_ws_bytes(void) { return kMaxPartials * sizeof(double); }
 
+static int fused_adam_launch(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int adamw, long step, double* hyper, void* ws,
+                             float* norm_out, nfdp_stream_t stream);
+
 extern "C" int nfdp_fused_adam_step_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value,
                                         float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                                         int adamw, long step, void* ws, float* norm_out, nfdp_stream_t stream) {
+    NFDP_REQUIRE(step >= 1, NFDP_ESHAPE, "fused_adam_step: step=%ld", step);
+    return fused_adam_launch(p, g, m, v, n, n_clip, clip_value, max_norm, lr, beta1, beta2, eps, weight_decay, adamw, step, nullptr, ws,
+                             norm_out, stream);
+}
+
+extern "C" int nfdp_fused_adam_step_dev_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value,
+                                            float max_norm, double* hyper, float beta1, float beta2, float eps, float weight_decay,
+                                            int adamw, void* ws, float* norm_out, nfdp_stream_t stream) {
+    NFDP_REQUIRE(hyper, NFDP_EINVAL, "fused_adam_step_dev: null hyper");
+    return fused_adam_launch(p, g, m, v, n, n_clip, clip_value, max_norm, 0.f, beta1, beta2, eps, weight_decay, adamw, 1, hyper, ws,
+                             norm_out, stream);
+}
+
+static int fused_adam_launch(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int adamw, long step, double* hyper, void* ws,
+                             float* norm_out, nfdp_stream_t stream) {
     NFDP_REQUIRE(p && g && m && v && ws, NFDP_EINVAL, "fused_adam_step: null pointer");
-    NFDP_REQUIRE(n > 0 && n_clip >= 0 && n_clip <= n && step >= 1, NFDP_ESHAPE, "fused_adam_step: bad sizes n=%ld n_clip=%ld step=%ld",
-                 n, n_clip, step);
+    NFDP_REQUIRE(n > 0 && n_clip >= 0 && n_clip <= n, NFDP_ESHAPE, "fused_adam_step: bad sizes n=%ld n_clip=%ld", n, n_clip);
     hipStream_t s = as_stream(stream);
+    if (hyper) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, hyper);      // step count += 1 on the device
     double* partial = reinterpret_cast<double*>(ws);
     int nblk = 1;
     if (n_clip > 0 && (clip_value > 0.f || max_norm > 0.f)) {
@@ -97,7 +131,7 @@ extern "C" int nfdp_fused_adam_step_f32(float* p, float* g, float* m, float* v, 
     const float bias_c1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bias_c2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adam_step_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, p, g, m, v, n, n_clip, partial, nblk,
-                       max_norm, lr, beta1, beta2, eps, weight_decay, adamw, bias_c1, bias_c2_sqrt, norm_out);
+                       max_norm, lr, beta1, beta2, eps, weight_decay, adamw, bias_c1, bias_c2_sqrt, norm_out, hyper);
     NFDP_CHECK_LAUNCH("fused_adam_step");
     return NFDP_OK;
 }

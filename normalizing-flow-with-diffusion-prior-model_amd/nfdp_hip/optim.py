@@ -39,7 +39,11 @@ class FusedAdam:
         self.exp_avg_sq = torch.zeros(self.n, device=dev, dtype=torch.float32)
         self.grad_norm = torch.zeros(1, device=dev, dtype=torch.float32)
         self._ws = torch.empty(lib().nfdp_fused_adam_ws_bytes() if dev.type == "cuda" else 8192, device=dev, dtype=torch.uint8)
-        self.step_count = 0
+        # learning rate and step count live on the device ({lr, steps taken}): the launch reads them there, so a training step captured
+        # in a hipGraph replays a correct Adam step every time (host scalars would freeze at their capture-time values)
+        self._hyper = torch.tensor([float(lr), 0.0], device=dev, dtype=torch.float64)
+        self._lr_uploaded = float(lr)
+        self._host_steps = 0
         off = 0
         with torch.no_grad():
             for p in self.params:
@@ -63,19 +67,26 @@ class FusedAdam:
     def step(self) -> None:
         if not self.flat_param.is_cuda:
             raise RuntimeError("FusedAdam.step: the HIP path needs GPU tensors (no CPU fallback)")
-        self.step_count += 1
+        if float(self.lr) != self._lr_uploaded:                # a scheduler changed .lr on the host: one 8-byte copy on the stream
+            self._hyper[0:1].copy_(torch.tensor([float(self.lr)], dtype=torch.float64), non_blocking=True)
+            self._lr_uploaded = float(self.lr)
         b1, b2 = self.betas
-        _call("nfdp_fused_adam_step_f32", _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-              self.n, self.n_clip, float(self.clip_value or 0.0), float(self.max_norm or 0.0), float(self.lr), float(b1), float(b2),
-              float(self.eps), float(self.weight_decay), int(self.adamw), self.step_count, _ptr(self._ws), _ptr(self.grad_norm),
-              _stream())
+        _call("nfdp_fused_adam_step_dev_f32", _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+              self.n, self.n_clip, float(self.clip_value or 0.0), float(self.max_norm or 0.0), _ptr(self._hyper), float(b1), float(b2),
+              float(self.eps), float(self.weight_decay), int(self.adamw), _ptr(self._ws), _ptr(self.grad_norm), _stream())
+        self._host_steps += 1
         bump_param_epoch()          # parameters changed through an alias: invalidate the kernel-layout weight caches
+
+    @property
+    def step_count(self) -> int:
+        """Steps taken, read back from the device counter (graph replays advance it without passing through step())."""
+        return int(self._hyper[1].item())
 
     def state_dict(self):
         return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "lr": self.lr}
 
     def load_state_dict(self, sd) -> None:
-        self.step_count = int(sd["step"])
+        self._hyper[1] = float(int(sd["step"]))
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.lr = sd.get("lr", self.lr)

@@ -427,3 +427,52 @@ def test_im2col_form_of_the_narrow_input_conv():
         dw = K.conv_wgrad(col, dc, 1, compute=K.BF16)[:, :9 * c, 0, 0].reshape(512, 3, 3, c).permute(0, 3, 1, 2)
         dw_ref = K.conv_wgrad(x.bfloat16().float(), dc.float(), 3)
         assert_close(dw, dw_ref, 1e-5, f"weight gradient C={c}")
+
+
+def test_fused_adam_replayed_in_a_graph_takes_real_adam_steps():
+    """The optimizer's step count and learning rate live on the device, so a step captured in a hipGraph replays with the
+    right bias corrections (host-side scalars would freeze at capture time): 2 eager + 4 replayed steps == 6 eager steps,
+    against torch.optim.Adam as well; a learning-rate change between replays is picked up."""
+    from nfdp_hip.optim import FusedAdam
+    g = torch.Generator().manual_seed(9)
+    shapes = [(64, 7), (33,)]
+    mk = lambda: [torch.nn.Parameter((torch.randn(*s, generator=torch.Generator().manual_seed(1 + i)) * 0.5).to(DEV)) for i, s in enumerate(shapes)]
+    pa, pb, pr = mk(), mk(), mk()
+    grads = [[(torch.randn(*s, generator=g) * 0.3).to(DEV) for s in shapes] for _ in range(6)]
+    a, b = FusedAdam(pa, lr=1e-2, max_norm=1.0), FusedAdam(pb, lr=1e-2, max_norm=1.0)
+    ref = torch.optim.Adam(pr, lr=1e-2)
+
+    def set_grads(ps, gs):
+        for p, gr in zip(ps, gs):
+            p.grad.copy_(gr)
+
+    for t in range(6):                                             # all eager
+        if t == 4:
+            ref.param_groups[0]["lr"] = 5e-3
+            a.lr = 5e-3
+        set_grads(pa, grads[t]); a.step()
+        for p, gr in zip(pr, grads[t]):
+            p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(pr, 1.0)
+        ref.step()
+    static = [torch.zeros_like(x) for x in grads[0]]
+    for t in range(2):
+        set_grads(pb, grads[t]); b.step()
+    graph = torch.cuda.CUDAGraph()
+    for s_, gr in zip(static, grads[2]):
+        s_.copy_(gr)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):                                  # captured step t = 2 (runs once at capture? no: capture only records)
+        set_grads(pb, static); b.step()
+    for t in range(2, 6):
+        for s_, gr in zip(static, grads[t]):
+            s_.copy_(gr)
+        if t == 4:
+            b.lr = 5e-3
+            b._hyper[0:1].copy_(torch.tensor([5e-3], dtype=torch.float64))     # what step() does on an lr change, outside the graph
+            b._lr_uploaded = 5e-3
+        graph.replay()
+    assert a.step_count == 6 and b.step_count == 6
+    for x, y, r in zip(pa, pb, pr):
+        assert_close(y, x, 1e-6, "replayed vs eager FusedAdam")
+        assert_close(x, r, 3e-5, "FusedAdam vs torch Adam")
