@@ -193,7 +193,9 @@ def train_bench(args, rank, world, device, barrier):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             static_loss = train_step()
-        run = graph.replay
+        def run():
+            graph.replay()
+            KH.bump_param_epoch()          # the replay updated the parameters: eager code afterwards must rebuild its weight caches
         run()
         loss = static_loss
     else:

@@ -14,7 +14,11 @@ import torch
 class Graphed:
     """graphed = Graphed(fn, example_inputs);  out = graphed(*new_inputs)   (out aliases the captured output tensors)."""
 
-    def __init__(self, fn: Callable, example_inputs: Sequence[torch.Tensor], warmup: int = 2):
+    def __init__(self, fn: Callable, example_inputs: Sequence[torch.Tensor], warmup: int = 2, mutates_params: bool = False):
+        """mutates_params: the captured callable updates parameters on the device (an optimizer step).  Every replay then bumps the
+        parameter epoch so that kernel-layout weight caches used by eager code afterwards are rebuilt (torch's version counters do
+        not see a replayed update)."""
+        self._mutates = mutates_params
         if not torch.cuda.is_available():
             raise RuntimeError("Graphed needs the GPU (there is no CPU fallback)")
         self._static_in = [t.clone() for t in example_inputs]
@@ -38,4 +42,7 @@ class Graphed:
             if dst.data_ptr() != src.data_ptr():
                 dst.copy_(src, non_blocking=True)
         self._graph.replay()
+        if self._mutates:
+            from . import bump_param_epoch
+            bump_param_epoch()
         return self._out

@@ -476,3 +476,51 @@ def test_fused_adam_replayed_in_a_graph_takes_real_adam_steps():
     for x, y, r in zip(pa, pb, pr):
         assert_close(y, x, 1e-6, "replayed vs eager FusedAdam")
         assert_close(x, r, 3e-5, "FusedAdam vs torch Adam")
+
+
+def test_graphed_training_step_then_eager_eval_sees_the_new_weights():
+    """A training step replayed from a hipGraph changes the parameters behind torch's version counters; Graphed(mutates_params=True)
+    bumps the parameter epoch so the eager forward afterwards repacks its weights: its bits/dim equals a fresh model's with the
+    same parameter values."""
+    from nfdp_hip.graphs import Graphed
+    from nfdp_hip.optim import FusedAdam
+    from normalizing_flow import calculate_loss, initialize_with_zeros
+    from tests.golden.synth import DEEP
+    flow, prior, _, _ = build(3, 3, 1, 41)
+    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 41, DEEP)) for k, v in flow.state_dict().items()})
+    prior.load_state_dict({k: T(synth_tensor(k, v.shape, 42, DEEP)) for k, v in prior.state_dict().items()})
+    flow.set_compute("bf16")
+    flow.to(DEV); prior.to(DEV)
+    opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-3, clip_value=1, max_norm=1)
+    x = (T(synth_input("gx", (8, 3, 32, 32), 6)) * 0.4).to(DEV)
+
+    def bpd(xb):
+        ll, logp = initialize_with_zeros(2, xb.shape[0], torch.device(DEV))
+        latents, ll, logp = flow.transform(xb, ll, logp)
+        return calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0)
+
+    def train_step(xb):
+        loss = bpd(xb)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss.detach()
+
+    with torch.no_grad():
+        before = float(bpd(x))
+    graphed = Graphed(train_step, [x], warmup=1, mutates_params=True)
+    for _ in range(3):
+        graphed(x)
+    with torch.no_grad():
+        after = float(bpd(x))                                      # eager, through the weight caches
+        sd = {k: v.detach().clone() for k, v in flow.state_dict().items()}
+        psd = {k: v.detach().clone() for k, v in prior.state_dict().items()}
+    flow2, prior2, _, _ = build(3, 3, 1, 41)
+    flow2.load_state_dict(sd); prior2.load_state_dict(psd)
+    flow2.set_compute("bf16"); flow2.to(DEV); prior2.to(DEV)
+    with torch.no_grad():
+        ll, logp = initialize_with_zeros(2, 8, torch.device(DEV))
+        latents, ll, logp = flow2.transform(x, ll, logp)
+        fresh = float(calculate_loss(ll + logp + prior2.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0))
+    assert after < before, (before, after)
+    assert abs(after - fresh) < 1e-6 * abs(fresh), (after, fresh)
