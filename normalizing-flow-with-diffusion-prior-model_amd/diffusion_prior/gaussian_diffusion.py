@@ -433,6 +433,16 @@ class GaussianDiffusion(nn.Module):
         self.use_graph = True
         self._graphs = {}
 
+    def _drop_stale_graphs(self) -> None:
+        """A captured step reads the kernel-layout copies of the U-Net weights that existed at capture time.  When a weight has
+        changed since (training between two sampling calls, load_state_dict, FusedAdam's epoch) the captured graphs are dropped
+        and recaptured on next use; the schedule tables stay."""
+        stamp = (K.param_epoch(),) + tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        if stamp != getattr(self, "_graph_stamp", None):
+            for k in [k for k in self._graphs if k[0] in ("step", "ddim", "vb")]:
+                del self._graphs[k]
+            self._graph_stamp = stamp
+
     # ---- hipGraph-captured reverse step: eps = Unet(x, t) -> fused p_sample in place -> t -= 1, state on the device
     def _step_inplace(self, xh: Tensor, tb: Tensor, gen: Optional[torch.Generator] = None) -> None:
         eps = self.model.forward_nhwc(xh, tb)
@@ -443,7 +453,8 @@ class GaussianDiffusion(nn.Module):
         tb.sub_(1)
 
     def _captured_step(self, shape_nhwc, device):
-        key = (tuple(shape_nhwc), str(device))
+        key = ("step", tuple(shape_nhwc), str(device))
+        self._drop_stale_graphs()
         if key not in self._graphs:
             xh = torch.zeros(shape_nhwc, device=device)
             tb = torch.zeros(shape_nhwc[0], device=device, dtype=torch.long)
@@ -615,6 +626,7 @@ class GaussianDiffusion(nn.Module):
 
     def _captured_ddim_step(self, shape_nhwc, device):
         key = ("ddim", tuple(shape_nhwc), str(device), self.sampling_timesteps, float(self.ddim_sampling_eta))
+        self._drop_stale_graphs()
         if key not in self._graphs:
             table = self._ddim_table(device)
             xh = torch.zeros(shape_nhwc, device=device)
@@ -787,6 +799,7 @@ class GaussianDiffusion(nn.Module):
 
     def _captured_vb_step(self, shape_nhwc, device):
         key = ("vb", tuple(shape_nhwc), str(device))
+        self._drop_stale_graphs()
         if key not in self._graphs:
             x0h = torch.zeros(shape_nhwc, device=device)
             tb = torch.zeros(shape_nhwc[0], device=device, dtype=torch.long)

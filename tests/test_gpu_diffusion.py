@@ -105,7 +105,7 @@ def test_sampling_loops_golden(dg):
     assert_close(out, dg["ddim_out"], TOL, "ddim T=8 S=4")
     assert d8.use_graph
     s = d8.sample(batch_size=3)                                    # device RNG path, hipGraph-captured step
-    assert (3, 16, 16, 2) in [k[0] for k in d8._graphs]
+    assert ("step", (3, 16, 16, 2)) in [k[:2] for k in d8._graphs]
     d8.use_graph = False
     s2 = d8.sample(batch_size=3)                                   # eager loop
     assert s2.shape == s.shape and torch.isfinite(s2).all()
@@ -264,3 +264,29 @@ def test_interpolate_and_given_start_on_the_captured_chain(dg):
             outs[mode] = K.as_nchw(img)
     assert torch.isfinite(outs[True]).all()
     assert_close(outs[True], outs[False], 1e-5, "interpolate: captured vs eager chain")
+
+
+@torch.no_grad()
+def test_captured_sampling_graph_follows_weight_updates(dg):
+    """Sampling between training steps (diffusion_prior/trainer.py:181-182): the captured reverse step must not keep using the
+    weights it was captured with.  After an in-place weight update the same seed gives different samples, equal to those of the
+    eager loop with the new weights."""
+    d = make_diffusion(dg, timesteps=6)
+    shape = (2, 2, 16, 16)
+    torch.manual_seed(5)
+    d.sample(batch_size=2)                                        # capture
+    torch.manual_seed(5)
+    s_old = d.sample(batch_size=2)
+    for p in d.model.parameters():
+        p.mul_(1.05)                                              # what an optimizer step does (bumps the tensor versions)
+    torch.manual_seed(5)
+    s_new = d.sample(batch_size=2)
+    assert not torch.equal(s_old, s_new)
+    torch.manual_seed(5)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    g2 = torch.Generator(device=DEV).manual_seed(seed)
+    x_T = torch.empty(2, 16, 16, 2, device=DEV).normal_(generator=g2)
+    noises = [torch.randn(2, 16, 16, 2, device=DEV, generator=g2) for _ in range(5)]
+    d.use_graph = False
+    ref = d.p_sample_loop(shape, x_T=x_T.permute(0, 3, 1, 2), noises=[n.permute(0, 3, 1, 2) for n in noises] + [None])
+    assert_close(s_new, ref, 1e-5, "captured loop after a weight update vs eager loop")
