@@ -5,6 +5,10 @@ one by one from Python the host costs about as much time as the GPU spends compu
 (after warm-up runs on a side stream, as torch.cuda.graphs requires) and replays it with new inputs copied into the captured
 input tensors.  The callable must be free of host synchronisation and use only static shapes - which holds for
 Glow.transform / invert, GaussianPrior, the training step with nfdp_hip.optim.FusedAdam, and the diffusion steps.
+
+A captured graph reads the kernel-layout weight copies that existed at capture time.  An inference graph therefore has to be
+re-captured after the parameters change; a training-step graph re-packs its weights inside the graph (the warm-up step's
+optimizer update invalidates every cache, so the packing launches are recorded) and can be replayed indefinitely.
 """
 from typing import Callable, Sequence
 
