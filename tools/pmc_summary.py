@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc passes (one directory per pass) into per-kernel averages per launch.
 
-usage: python tools/pmc_summary.py OUT.json DIR [DIR...]
+usage: python tools/pmc_summary.py OUT.json DIR [DIR...]      (NFDP_PMC_KERNEL_RE: regex of the kernels to keep, default the fused
+flow-step kernels)
 Each DIR is the -d directory of one `rocprofv3 --pmc ... -- python3 tools/time_fused_level.py` pass (separate passes:
 FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 PMC slots').  HBM bytes per launch =
 2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B, same guide, 'HBM') + WRITE_SIZE; both counters are in KB.
@@ -21,7 +22,7 @@ for d in dirs:
                 per_dispatch[key] += float(r["Counter_Value"])     # a counter is reported per XCD/instance: sum them
                 names[r["Dispatch_Id"]] = r["Kernel_Name"]
         for (disp, ctr), v in per_dispatch.items():
-            m = re.search(r"coupling_fused\w*kernel<[^>]*>", names[disp])
+            m = re.search(os.environ.get("NFDP_PMC_KERNEL_RE", r"coupling_fused\w*kernel<[^>]*>"), names[disp])
             if not m:
                 continue
             a = acc[m.group(0)][ctr]
