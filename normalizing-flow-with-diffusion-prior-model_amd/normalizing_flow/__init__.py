@@ -21,43 +21,41 @@ from .utils import (init_optimizer, preprocess_batch, postprocess_batch, initial
 
 
 class NFBackbone(nn.Module):
-    """Frozen-or-trainable Glow used as the encoder/decoder of the diffusion prior
-    (reference normalizing_flow/__init__.py:16-106)."""
+    """The Glow that encodes images into latent parts (and decodes samples) for the diffusion prior; optionally frozen.
+    Same constructor arguments, attributes (`model`, `L`, `K`, `device`) and methods as reference normalizing_flow/__init__.py:16-106;
+    the flow runs on the HIP path (`compute`: 'f32' | 'bf16' | None = library default)."""
 
     def __init__(self, model_dir: str, in_channel: int, L: int, K: int, learn_prior_mean_logs: bool, freeze_flow: bool,
                  compute: Optional[str] = None):
         super().__init__()
-        self.L, self.K, self.learn_prior_mean_logs = L, K, learn_prior_mean_logs
-        self.model = Glow(in_channel=in_channel, L=L, K=K, learn_prior_mean_logs=learn_prior_mean_logs, compute=compute)
-        self.device = self.model.device
-        self.model.to(self.device)
-        self.freeze_flow = freeze_flow
-        if model_dir:
-            checkpoint = torch.load(model_dir, map_location=torch.device('cpu'))
-            self.model.load_state_dict(checkpoint["flow"])
-        for param in self.model.parameters():
-            param.requires_grad = not self.freeze_flow
+        flow = Glow(in_channel=in_channel, L=L, K=K, learn_prior_mean_logs=learn_prior_mean_logs, compute=compute)
+        self.model = flow.to(flow.device)
+        self.device, self.L, self.K = flow.device, L, K
+        self.learn_prior_mean_logs = learn_prior_mean_logs
+        self.freeze_flow = bool(freeze_flow)
+        if model_dir:                                         # checkpoint written by save_model(): {"flow": state_dict, ...}
+            state = torch.load(model_dir, map_location="cpu")["flow"]
+            flow.load_state_dict(state)
+        flow.requires_grad_(not self.freeze_flow)
 
-    def is_frozen(self):
+    def is_frozen(self) -> bool:
         return self.freeze_flow
 
-    def set_train_mode(self):
-        if not self.is_frozen():
-            self.train()
-        else:
-            self.eval()
+    def set_train_mode(self) -> None:
+        """train() only for a trainable backbone; a frozen one stays in eval mode (reference :58-64)."""
+        self.train(mode=not self.freeze_flow)
 
-    def set_eval_mode(self):
-        self.eval()
+    def set_eval_mode(self) -> None:
+        self.train(mode=False)
 
     def transform(self, x: Tensor, log_det_jac: Tensor) -> Tuple[list, Tensor]:
-        """Glow.transform with logp=None: the Split priors are skipped  (reference __init__.py:81)."""
-        parts_of_latent_variable, log_det_jac, _ = self.model.transform(x, log_det_jac, None)
-        return parts_of_latent_variable, log_det_jac
+        """Encode: Glow.transform with logp=None, i.e. the Split priors are not evaluated (reference :70-83)."""
+        latents, ldj, _unused = self.model.transform(x, log_det_jac, None)
+        return latents, ldj
 
     def invert(self, latents: list) -> Tensor:
         return self.model.invert(latents)
 
     @torch.no_grad()
     def sample(self, latents: list, postprocess_func=None) -> Tensor:
-        return self.model.sample(latents, postprocess_func)
+        return self.model.sample(latents, postprocess_func=postprocess_func)
