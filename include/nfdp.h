@@ -119,6 +119,12 @@ int nfdp_invconv_actnorm_inv_f32(const float* y, float* x, long npix, int C, con
 size_t nfdp_conv_packed_bytes(int Cout, int Cin, int KH, int KW, int compute);
 int nfdp_conv_pack_weights(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, int compute,
                            nfdp_stream_t stream);
+/* The packed forms the training path derives from a parameter, in one launch from the parameter itself: flip = 1 packs the
+ * data-gradient weight W'[i][o][ky][kx] = w[o][i][K-1-ky][K-1-kx]; taps = 1 packs the pointwise form of a KxK conv with few outputs
+ * (rows tap*Cout' + co', columns ci': the GEMM in front of nfdp_tap_shift_sum_f32).  Sizes: nfdp_conv_packed_bytes_ex. */
+size_t nfdp_conv_packed_bytes_ex(int Cout, int Cin, int KH, int KW, int compute, int flip, int taps);
+int nfdp_conv_pack_weights_ex(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, int compute, int flip, int taps,
+                              nfdp_stream_t stream);
 int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
                      int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
                      float mul_exp, int relu, int compute, nfdp_stream_t stream);

@@ -647,6 +647,28 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restric
     }
 }
 
+// The same packing for the weights the training path derives from a parameter, straight from the parameter (one launch instead of
+// flip / permute copies + pack):  flip: the data-gradient weight W'[o'][i'][ky][kx] = w[i'][o'][K-1-ky][K-1-kx] (Cout' = Cin,
+// Cin' = Cout);  taps: the pointwise form of a 3x3 conv with few outputs, rows n = tap*Cout' + co', columns ci' (conv3x3_narrow).
+template <bool BF16>
+__global__ void pack_weights_ex_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int KK, int flip,
+                                       int taps, int rows, int K, int Kpad, long total) {
+    const int Co = flip ? Cin : Cout, Ci = flip ? Cout : Cin;     // logical (primed) channel counts
+    for (long i = blockIdx.x * (long)kThreads + threadIdx.x; i < total; i += (long)gridDim.x * kThreads) {
+        const int k = (int)(i % Kpad);
+        const int n = (int)(i / Kpad);
+        float v = 0.f;
+        if (n < rows && k < K) {
+            int co, ci, tap;
+            if (taps) { tap = n / Co; co = n - tap * Co; ci = k; }
+            else { tap = k / Ci; ci = k - tap * Ci; co = n; }
+            v = flip ? w[((long)ci * Cin + co) * KK + (KK - 1 - tap)] : w[((long)co * Cin + ci) * KK + tap];
+        }
+        if (BF16) reinterpret_cast<__bf16*>(out)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(out)[i] = v;
+    }
+}
+
 inline int tile_n_for(int Cout) {
     if (Cout <= 16) return 16;
     if (Cout <= 32) return 32;
@@ -751,6 +773,32 @@ extern "C" int nfdp_conv_pack_weights(const float* w_oihw, void* w_packed, int C
         hipLaunchKernelGGL((pack_weights_kernel<false>), dim3(grid), dim3(kThreads), 0, as_stream(stream), w_oihw, w_packed,
                            Cout, Cin, KH, KW, K, Kpad, total);
     NFDP_CHECK_LAUNCH("conv_pack_weights");
+    return NFDP_OK;
+}
+
+extern "C" size_t nfdp_conv_packed_bytes_ex(int Cout, int Cin, int KH, int KW, int compute, int flip, int taps) {
+    if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
+    const int Co = flip ? Cin : Cout, Ci = flip ? Cout : Cin;
+    return taps ? nfdp_conv_packed_bytes(KH * KW * Co, Ci, 1, 1, compute) : nfdp_conv_packed_bytes(Co, Ci, KH, KW, compute);
+}
+
+extern "C" int nfdp_conv_pack_weights_ex(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, int compute, int flip,
+                                         int taps, nfdp_stream_t stream) {
+    NFDP_REQUIRE(w_oihw && w_packed, NFDP_EINVAL, "conv_pack_weights_ex: null pointer");
+    NFDP_REQUIRE(Cout > 0 && Cin > 0 && KH > 0 && KW == KH, NFDP_ESHAPE, "conv_pack_weights_ex: bad shape");
+    const int Co = flip ? Cin : Cout, Ci = flip ? Cout : Cin, KK = KH * KW;
+    const int rows = taps ? KK * Co : Co;
+    const int K = taps ? Ci : Ci * KK;
+    const int Kpad = taps ? kpad_for(Ci, 1, 1) : kpad_for(Ci, KH, KW);
+    const long total = (long)cout_pad_for(rows) * Kpad;
+    const int grid = stream_grid(total, kThreads);
+    if (compute == NFDP_BF16)
+        hipLaunchKernelGGL((pack_weights_ex_kernel<true>), dim3(grid), dim3(kThreads), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin,
+                           KK, flip, taps, rows, K, Kpad, total);
+    else
+        hipLaunchKernelGGL((pack_weights_ex_kernel<false>), dim3(grid), dim3(kThreads), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin,
+                           KK, flip, taps, rows, K, Kpad, total);
+    NFDP_CHECK_LAUNCH("conv_pack_weights_ex");
     return NFDP_OK;
 }
 

@@ -37,8 +37,8 @@ class ConvFn(Function):
         dy = dy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            wt = K.conv_flip_weights(weight.detach().contiguous())
-            dx = K.conv2d(dy, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute, out_dtype=K.F32)
+            dx = K.conv2d(dy, K.conv_pack_ex(weight.detach().contiguous(), ctx.compute, flip=True), weight.shape[1], ctx.k,
+                          compute=ctx.compute, out_dtype=K.F32)
         dw = K.conv_wgrad(xh, dy, ctx.k, compute=ctx.compute)
         db = K.scale_bwd(dy, want_dc=False)[2] if ctx.has_bias else None
         return dx, dw, db, None, None

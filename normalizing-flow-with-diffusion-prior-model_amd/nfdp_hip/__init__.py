@@ -935,19 +935,30 @@ def diffusion_loss_bwd(pred, target, t, p2w, grad_out, l1: bool):
     return dp
 
 
+def conv_pack_ex(w_oihw: torch.Tensor, compute: int, flip: bool = False, taps: bool = False) -> torch.Tensor:
+    """conv_pack of a derived weight in one launch from the parameter: flip = the data-gradient weight (flipped taps, channels
+    swapped), taps = the pointwise [tap*Co + co][ci] form of conv3x3_narrow (nfdp_conv_pack_weights_ex)."""
+    _need(w_oihw, torch.float32, "conv_pack_ex"); _dense(w_oihw, "conv_pack_ex")
+    co, ci, kh, kw = w_oihw.shape
+    nbytes = lib().nfdp_conv_packed_bytes_ex(co, ci, kh, kw, compute, int(flip), int(taps))
+    packed = torch.empty(nbytes, device=w_oihw.device, dtype=torch.uint8)
+    _call("nfdp_conv_pack_weights_ex", _ptr(w_oihw), _ptr(packed), co, ci, kh, kw, compute, int(flip), int(taps), _stream())
+    return packed
+
+
 def pack_taps(w_oihw: torch.Tensor, compute: int) -> torch.Tensor:
-    """Packed weight of the pointwise GEMM of conv3x3_narrow: rows [tap*Co + co], columns ci (weight-sized plumbing)."""
-    co, ci = w_oihw.shape[:2]
-    return conv_pack(w_oihw.detach().permute(2, 3, 0, 1).reshape(9 * co, ci, 1, 1).contiguous(), compute)
+    """Packed weight of the pointwise GEMM of conv3x3_narrow: rows [tap*Co + co], columns ci."""
+    return conv_pack_ex(w_oihw.detach().contiguous(), compute, taps=True)
 
 
 def conv3x3_narrow(xh: torch.Tensor, w_oihw: torch.Tensor, *, add=None, mul=None, mul_exp: float = 0.0, relu: bool = False,
-                   compute: int = F32, packed_taps: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   compute: int = F32, packed_taps: Optional[torch.Tensor] = None, co: Optional[int] = None) -> torch.Tensor:
     """3x3 'same' conv with Cin >> Cout as a pointwise GEMM to the 9*Cout tap contributions (one wide, fast 1x1 conv)
     followed by the tap shift-sum with the conv kernel's epilogue act((acc + add) * exp(mul_exp * mul))."""
-    co, ci, k, _ = w_oihw.shape
-    if k != 3:
-        raise ValueError("conv3x3_narrow: 3x3 only")
+    if w_oihw is not None:
+        co, ci, k, _ = w_oihw.shape
+        if k != 3:
+            raise ValueError("conv3x3_narrow: 3x3 only")
     b, h, w, _ = xh.shape
     if packed_taps is None:
         packed_taps = pack_taps(w_oihw, compute)

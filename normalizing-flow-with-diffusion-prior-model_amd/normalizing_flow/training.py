@@ -120,16 +120,17 @@ class ConvScaleFn(Function):
         dc, dmul, dadd = K.scale_bwd(dy.contiguous(), y, mul.detach().reshape(-1), ctx.f, ctx.relu)   # dc in y's storage type
         dx, dc_col = None, None
         if ctx.needs_input_grad[0]:
-            wt = K.conv_flip_weights(weight.detach().contiguous())
-            if K.use_narrow_conv(weight.shape[0], weight.shape[1], ctx.k):   # data gradient of C/2 -> 512: a 512 -> C/2 conv
-                dx = K.conv3x3_narrow(dc, wt, compute=ctx.compute)
+            wd = weight.detach().contiguous()           # the data-gradient weight (flipped taps, channels swapped) is packed straight
+            if K.use_narrow_conv(weight.shape[0], weight.shape[1], ctx.k):   # from the parameter.  C/2 -> 512: its data gradient is a 512 -> C/2 conv
+                dx = K.conv3x3_narrow(dc, None, compute=ctx.compute, co=weight.shape[1],
+                                      packed_taps=K.conv_pack_ex(wd, ctx.compute, flip=True, taps=True))
             elif dc.dtype == torch.float32 and K.use_im2col_conv(weight.shape[0], weight.shape[1], ctx.k, ctx.compute):
                 # data gradient of the 512 -> C zero conv: a C -> 512 conv of the narrow dc, as im2col + pointwise GEMM
                 dc_col = K.im2col3x3(dc)
-                dx = K.conv2d(dc_col, K.conv_pack(wt, ctx.compute), weight.shape[1], 1, compute=ctx.compute,
+                dx = K.conv2d(dc_col, K.conv_pack_ex(wd, ctx.compute, flip=True), weight.shape[1], 1, compute=ctx.compute,
                               out_dtype=K.BF16 if ctx.x_dtype == torch.bfloat16 else K.F32)
             else:
-                dx = K.conv2d(dc, K.conv_pack(wt, ctx.compute), weight.shape[1], ctx.k, compute=ctx.compute,
+                dx = K.conv2d(dc, K.conv_pack_ex(wd, ctx.compute, flip=True), weight.shape[1], ctx.k, compute=ctx.compute,
                               out_dtype=K.BF16 if ctx.x_dtype == torch.bfloat16 else K.F32)
             if dx.dtype != ctx.x_dtype:
                 dx = dx.to(ctx.x_dtype)
