@@ -12,9 +12,11 @@ bits/dim.  Weights: deterministic 'trained-like' synthetic weights (tests/golden
 is no network for checkpoints.  The 1x1-conv log|det| is recomputed every step (as the reference does); packed
 (kernel-layout) copies of the conv weights are rebuilt only when a parameter changes.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest share of step time, timed live with
-HIP events on the launch stream during extra profiled steps after the timed region; `cpu_baseline` is the CPU
-oracle (a torch-CPU restatement of the reference, kind "port") on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0).  `roofline` is for the kernel with the largest share of step time: found with HIP events
+around every launch of three extra eager steps after the timed region, then timed under the timed region's conditions (a
+hipGraph of back-to-back launches of that kernel, HIP events on the launch stream: `sustained_level_time`); `cpu_baseline`
+is the CPU oracle (a torch-CPU restatement of the reference, kind "port") on a bounded sample of the same workload.
+Other modes (not the headline): --inverse / --sample (Glow.invert, configs[1]), --train (training step, configs[2]).
 """
 import argparse
 import json
