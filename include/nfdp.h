@@ -313,6 +313,17 @@ int nfdp_coupling_bwd_f32(const float* x, const float* h, const float* dy, const
 int nfdp_gauss_logp_bwd_f32(const float* z, int z_ld, const float* h, int h_mode, const double* gl, int B, int HW, int Cz,
                             float* dz, float* dh, nfdp_stream_t stream);
 
+/* Data gradient of a pointwise conv fused with the scale/ReLU backward of the layer in front of it (the two hidden layers of the
+ * coupling network): dy = x W'^T stays in the accumulators; with the saved output y = relu((u + b) e^{f s}) of that layer (bf16) the
+ * epilogue writes dc = [y > 0] dy e^{f s} (bf16) and returns dmul = f sum [y > 0] dy y and dadd = sum dc, i.e. what
+ * nfdp_conv2d_nhwc + nfdp_scale_bwd produce in two passes with dy in memory.  x: [npix][x_ld] bf16, w_packed: nfdp_conv_pack_weights(_ex)
+ * of the data-gradient weight (1x1, Cin -> Cout), Cin % 64 == 0, Cout % 8 == 0, npix >= 512 (nfdp_pointwise_dgrad_masked_supported). */
+int nfdp_pointwise_dgrad_masked_supported(long npix, int Cin, int Cout);
+size_t nfdp_pointwise_dgrad_masked_ws_bytes(long npix, int Cout);
+int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const void* w_packed, const void* y_saved, int y_ld, const float* mul,
+                                     float f, long npix, int Cin, int Cout, void* dc, int dc_ld, float* dmul, float* dadd, void* ws,
+                                     nfdp_stream_t stream);
+
 /* Fused optimizer step on flat fp32 buffers (trainer.py:165-167 + utils.py:120-137): for the first n_clip elements
  * g = clamp(g, +-clip_value) (clip_grad_value_; <= 0: off) then g *= min(1, max_norm / (||g[:n_clip]||_2 + 1e-6))
  * (clip_grad_norm_; <= 0: off), then torch.optim.Adam (adamw=0: weight decay added to g) or AdamW (adamw=1: decoupled

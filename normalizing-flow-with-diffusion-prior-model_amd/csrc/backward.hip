@@ -809,6 +809,11 @@ extern "C" int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int 
     return NFDP_OK;
 }
 
+// used by the fused scale/ReLU backward epilogue of the pointwise GEMM (conv.hip): same partial layout [blk][2][C]
+void nfdp_internal_scale_bwd_finish(const double* part, int nblk, int C, float f, float* dmul, float* dadd, hipStream_t s) {
+    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 16)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
+}
+
 static int scale_bwd_blocks(long npix) {
     long g = cdiv(npix, 32);
     if (g > 512) g = 512;            // 2 workgroups per CU; every block costs 2 C doubles of partials the finish kernel re-reads

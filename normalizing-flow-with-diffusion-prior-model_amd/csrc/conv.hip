@@ -37,6 +37,9 @@ struct ConvParams {
     int H, W, Cin, Cout, KH, KW, pad;
     int K, Kpad, Mt, Nt, relu;
     float mul_exp;
+    const void* mask_y = nullptr;     // pw_gemm masked epilogue (fused scale/ReLU backward): the saved layer output, bf16
+    int mask_ld = 0;
+    double* part = nullptr;           // [Mt][2][Cout] partial sums of  g*y  and  dc
 };
 
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
@@ -500,6 +503,8 @@ constexpr int PW_BM = 128, PW_BN = 128, PW_BK = 64;
 constexpr int PW_TILE_BYTES = PW_BM * PW_BK * 2;           // 16 KiB per operand per stage
 constexpr int PW_LDS_BYTES = PW_BM * (PW_BN * 4 + 16);      // the staged fp32 output tile (66 KiB) >= the 4 operand buffers (64 KiB)
 
+// MASK: the epilogue is the scale/ReLU backward of the layer whose OUTPUT gradient this GEMM produces (see below).
+template <bool MASK>
 __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvParams P) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];      // [2 stages][pixels 16 KiB | weights 16 KiB]
     const int bid = blockIdx.x;
@@ -578,6 +583,67 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
     // The finished tile goes through LDS (the stage buffers are free after the loop's last barrier) so that the global stores
     // are 16 bytes per lane along full output rows: stored straight from the accumulators a lane owns 8 bytes of a row, a wave
     // store touches 16 rows, and at K = 64 the kernel was bound by those stores (1.6 TB/s).
+    if constexpr (MASK) {
+        // Fused scale/ReLU backward (what nfdp_scale_bwd does in a pass of its own): the accumulators are dy, the gradient w.r.t. the
+        // OUTPUT y = relu((u + b) e^{f s}) of the previous layer; with the saved y (bf16) this epilogue writes
+        // dc = [y > 0] dy e^{f s[n]} (bf16) - the operand of that layer's data- and weight-gradient GEMMs - and the tile's column sums
+        // of [y > 0] dy y and of dc (-> ds, db), so dy never goes to memory and y is read once.
+        constexpr int pitchF = PW_BN * 4 + 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float4*>(smem + (wm * 64 + j * 16 + r16) * pitchF + (wn * 64 + i * 16 + 4 * q) * 4) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        __syncthreads();
+        const int ch = tid & 15, rg = tid >> 4;                    // 8 channels n0 + 8 ch .., rows rg, rg + 16, ...
+        const int n = n0 + ch * 8;
+        const bool nok = n < P.Cout;                               // Cout % 8 == 0 (checked by the host)
+        float fac[8], s1[8], s2[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            fac[j] = (nok && P.mul) ? expf(__fmul_rn(P.mul[n + j], P.mul_exp)) : 1.0f;
+            s1[j] = 0.f; s2[j] = 0.f;
+        }
+        const __bf16* yb = reinterpret_cast<const __bf16*>(P.mask_y);
+        for (int pl = rg; pl < PW_BM; pl += 16) {
+            const long px = m0 + pl;
+            if (px < P.npix && nok) {
+                const float4 lo = *reinterpret_cast<const float4*>(smem + pl * pitchF + ch * 32);
+                const float4 hi = *reinterpret_cast<const float4*>(smem + pl * pitchF + ch * 32 + 16);
+                const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                const bf16x8 yv = *reinterpret_cast<const bf16x8*>(yb + px * P.mask_ld + n);
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float yj = (float)yv[j];
+                    const float g = yj > 0.f ? v[j] : 0.f;
+                    s1[j] = fmaf(g, yj, s1[j]);
+                    const float d = __fmul_rn(g, fac[j]);
+                    s2[j] += d;
+                    o[j] = (__bf16)d;
+                }
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<__bf16*>(P.y) + px * P.y_ld + n) = o;
+            }
+        }
+        __syncthreads();                                           // everyone is done with the staged tile: reuse it for the column sums
+        float* red = reinterpret_cast<float*>(smem);               // [16 row groups][128 columns][2]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            red[(rg * PW_BN + ch * 8 + j) * 2] = s1[j];
+            red[(rg * PW_BN + ch * 8 + j) * 2 + 1] = s2[j];
+        }
+        __syncthreads();
+        {
+            const int col = tid & (PW_BN - 1), which = tid >> 7;   // 256 threads = 128 columns x 2 sums
+            if (n0 + col < P.Cout) {
+                double acc2 = 0.0;
+                for (int g = 0; g < 16; ++g) acc2 += (double)red[(g * PW_BN + col) * 2 + which];      // fixed order
+                P.part[((size_t)mt * 2 + which) * P.Cout + n0 + col] = acc2;
+            }
+        }
+        return;
+    }
     const int esz = P.y_bf16 ? 2 : 4;
     const int pitch = PW_BN * esz + 16;                            // bytes per staged pixel row
 #pragma unroll
@@ -802,6 +868,47 @@ extern "C" int nfdp_conv_pack_weights_ex(const float* w_oihw, void* w_packed, in
     return NFDP_OK;
 }
 
+void nfdp_internal_scale_bwd_finish(const double* part, int nblk, int C, float f, float* dmul, float* dadd, hipStream_t s);   // backward.hip
+
+extern "C" int nfdp_pointwise_dgrad_masked_supported(long npix, int Cin, int Cout) {
+    return Cin % PW_BK == 0 && Cout > 64 && Cout % 8 == 0 && npix >= 4 * PW_BM;
+}
+
+extern "C" size_t nfdp_pointwise_dgrad_masked_ws_bytes(long npix, int Cout) {
+    return (size_t)cdiv(npix, PW_BM) * 2 * Cout * sizeof(double);
+}
+
+extern "C" int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const void* w_packed, const void* y_saved, int y_ld,
+                                                const float* mul, float f, long npix, int Cin, int Cout, void* dc, int dc_ld, float* dmul,
+                                                float* dadd, void* ws, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && w_packed && y_saved && dc && dmul && dadd && ws, NFDP_EINVAL, "pointwise_dgrad_masked: null pointer");
+    NFDP_REQUIRE(nfdp_pointwise_dgrad_masked_supported(npix, Cin, Cout), NFDP_EUNSUPPORTED,
+                 "pointwise_dgrad_masked: npix=%ld Cin=%d Cout=%d (Cin %% 64, Cout %% 8, npix >= 512)", npix, Cin, Cout);
+    NFDP_REQUIRE(x_ld >= Cin && x_ld % 8 == 0 && y_ld >= Cout && y_ld % 8 == 0 && dc_ld >= Cout && dc_ld % 8 == 0 &&
+                     (((uintptr_t)x | (uintptr_t)y_saved | (uintptr_t)dc) & 15) == 0, NFDP_ESHAPE,
+                 "pointwise_dgrad_masked: bf16 rows must be 16-byte aligned with strides that are multiples of 8");
+    ConvParams P;
+    P.x = x; P.w = w_packed; P.y = dc; P.add = nullptr; P.mul = mul; P.npix = npix;
+    P.x_ld = x_ld; P.y_ld = dc_ld; P.y_bf16 = 1;
+    P.H = 1; P.W = 1; P.Cin = Cin; P.Cout = Cout; P.KH = 1; P.KW = 1; P.pad = 0;
+    P.K = Cin; P.Kpad = kpad_for(Cin, 1, 1); P.relu = 1; P.mul_exp = f;
+    P.mask_y = y_saved; P.mask_ld = y_ld; P.part = reinterpret_cast<double*>(ws);
+    P.Mt = (int)cdiv(npix, PW_BM);
+    P.Nt = cout_pad_for(Cout) / PW_BN;
+    const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
+    hipStream_t s = as_stream(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  PW_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pw_gemm_bf16_kernel<true>, dim3(grid), dim3(kThreads), PW_LDS_BYTES, s, P);
+    nfdp_internal_scale_bwd_finish(P.part, P.Mt, Cout, f, dmul, dadd, s);
+    NFDP_CHECK_LAUNCH("pointwise_dgrad_masked");
+    return NFDP_OK;
+}
+
 extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
                                 int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
                                 float mul_exp, int relu, int compute, nfdp_stream_t stream) {
@@ -836,11 +943,11 @@ extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void
         const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       PW_LDS_BYTES);
             attr_set = true;
         }
-        hipLaunchKernelGGL(pw_gemm_bf16_kernel, dim3(grid), dim3(kThreads), PW_LDS_BYTES, s, P);
+        hipLaunchKernelGGL(pw_gemm_bf16_kernel<false>, dim3(grid), dim3(kThreads), PW_LDS_BYTES, s, P);
         NFDP_CHECK_LAUNCH("conv2d (pointwise bf16 GEMM)");
         return NFDP_OK;
     }

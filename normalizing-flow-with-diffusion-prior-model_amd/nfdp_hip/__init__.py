@@ -968,6 +968,26 @@ def conv3x3_narrow(xh: torch.Tensor, w_oihw: torch.Tensor, *, add=None, mul=None
     return out
 
 
+def pointwise_dgrad_masked_supported(npix: int, cin: int, cout: int) -> bool:
+    return bool(lib().nfdp_pointwise_dgrad_masked_supported(npix, cin, cout))
+
+
+def pointwise_dgrad_masked(xh: torch.Tensor, packed: torch.Tensor, y_saved: torch.Tensor, mul: torch.Tensor, f: float):
+    """Data gradient of a 1x1 conv (xh [B,H,W,Cin] bf16 times the packed data-gradient weight) fused with the scale/ReLU backward of
+    the layer whose saved output is y_saved [B,H,W,Cout] bf16: -> (dc bf16 [B,H,W,Cout], dmul [Cout], dadd [Cout])."""
+    _need(xh, torch.bfloat16, "pointwise_dgrad_masked"); _need(y_saved, torch.bfloat16, "pointwise_dgrad_masked")
+    b, h, w, cin = xh.shape
+    cout = y_saved.shape[-1]
+    dc = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.bfloat16)
+    dmul = torch.empty(cout, device=xh.device, dtype=torch.float32)
+    dadd = torch.empty(cout, device=xh.device, dtype=torch.float32)
+    ws = torch.empty(lib().nfdp_pointwise_dgrad_masked_ws_bytes(b * h * w, cout), device=xh.device, dtype=torch.uint8)
+    _call("nfdp_pointwise_dgrad_masked_bf16", _ptr(xh), _ld(xh, "pointwise_dgrad_masked"), _ptr(packed), _ptr(y_saved),
+          _ld(y_saved, "pointwise_dgrad_masked"), _ptr(mul), float(f), b * h * w, cin, cout, _ptr(dc), cout, _ptr(dmul), _ptr(dadd),
+          _ptr(ws), _stream(), label=f"pw_gemm_bf16<masked> k1 {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout)
+    return dc, dmul, dadd
+
+
 def coupling_mlp_supported(c: int, n_features: int) -> bool:
     return n_features == 512 and lib().nfdp_coupling_fused_packed_bytes(c) != 0
 

@@ -524,3 +524,25 @@ def test_graphed_training_step_then_eager_eval_sees_the_new_weights():
         fresh = float(calculate_loss(ll + logp + prior2.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0))
     assert after < before, (before, after)
     assert abs(after - fresh) < 1e-6 * abs(fresh), (after, fresh)
+
+
+@pytest.mark.parametrize("shape,cin", [((4, 16, 16), 512), ((5, 11, 11), 128), ((2, 16, 16), 64)])
+def test_pointwise_dgrad_with_fused_scale_relu_backward(shape, cin):
+    """The data-gradient GEMM whose epilogue is the scale/ReLU backward of the layer in front: against the two-pass form
+    (conv2d -> bf16 dy -> scale_bwd) on the same operands.  dc differs only by the bf16 rounding of dy the fused form skips;
+    the parameter sums agree to that rounding."""
+    b, h, w = shape
+    cout = 512
+    g = torch.Generator().manual_seed(cin)
+    x = (torch.randn(b, h, w, cin, generator=g) * 0.5).bfloat16().to(DEV)
+    wt = (torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5).to(DEV)
+    y = torch.relu(torch.randn(b, h, w, cout, generator=g)).bfloat16().to(DEV)
+    mul = (torch.randn(cout, generator=g) * 0.2).to(DEV)
+    packed = K.conv_pack(wt, K.BF16)
+    dy = K.conv2d(x, packed, cout, 1, compute=K.BF16, out_dtype=K.F32)                  # unrounded dy for the reference
+    dc_ref, dmul_ref, dadd_ref = K.scale_bwd(dy, y.float(), mul, 1.0, True)
+    dc, dmul, dadd = K.pointwise_dgrad_masked(x, packed, y, mul, 1.0)
+    assert dc.dtype == torch.bfloat16
+    assert_close(dc.float(), dc_ref, 4e-3, "dc")
+    assert_close(dmul, dmul_ref, 2e-5, "dmul")
+    assert_close(dadd, dadd_ref, 2e-5, "dadd")
