@@ -382,16 +382,17 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_vec_kernel(const TDY* __rest
     }
 }
 
-// One workgroup per 16 channels: 16 lanes of partials per channel (lane g takes blocks g, g+16, ...), combined in lane
-// order.  (With one thread per channel the whole partial buffer - MBs for C = 512 - went through C/256 = 2 CUs.)
+// One workgroup per 8 channels: 32 lanes of partials per channel (lane g takes blocks g, g+32, ...), combined in lane order.
+// (With one thread per channel the whole partial buffer - MBs for C = 512 - went through C/256 = 2 CUs; the fused GEMM epilogue
+// writes one partial row per 128 pixels, 8 MB at level 0, so the reads are spread over C/8 = 64 workgroups.)
 __global__ void __launch_bounds__(kBlock) scale_bwd_finish_kernel(const double* __restrict__ part, int nblk, int C, float f,
                                                                  float* __restrict__ dmul, float* __restrict__ dadd) {
-    __shared__ double red[2][16][16];
-    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double red[2][32][8];
+    const int cl = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
     double a = 0.0, b = 0.0;
     if (c < C)
-        for (int q = g; q < nblk; q += 16) {
+        for (int q = g; q < nblk; q += 32) {
             a += part[((size_t)q * 2 + 0) * C + c];
             b += part[((size_t)q * 2 + 1) * C + c];
         }
@@ -400,7 +401,7 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_finish_kernel(const double* 
     __syncthreads();
     if (g == 0 && c < C) {
         double sa = 0.0, sb = 0.0;
-        for (int t = 0; t < 16; ++t) { sa += red[0][t][cl]; sb += red[1][t][cl]; }
+        for (int t = 0; t < 32; ++t) { sa += red[0][t][cl]; sb += red[1][t][cl]; }
         if (dmul) dmul[c] = (float)(sa * (double)f);
         if (dadd) dadd[c] = (float)sb;
     }
@@ -811,7 +812,7 @@ extern "C" int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int 
 
 // used by the fused scale/ReLU backward epilogue of the pointwise GEMM (conv.hip): same partial layout [blk][2][C]
 void nfdp_internal_scale_bwd_finish(const double* part, int nblk, int C, float f, float* dmul, float* dadd, hipStream_t s) {
-    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 16)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
+    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
 }
 
 static int scale_bwd_blocks(long npix) {
@@ -871,7 +872,7 @@ extern "C" int nfdp_scale_bwd(const void* dy, int dy_dtype, int dy_ld, const voi
                            dy_dtype, y_dtype, dc_dtype);
             return NFDP_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 16)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
+    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
     NFDP_CHECK_LAUNCH("scale_bwd");
     return NFDP_OK;
 }
