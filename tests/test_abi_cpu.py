@@ -45,7 +45,7 @@ def test_argument_validation_without_gpu():
     assert l.nfdp_coupling_fwd_f32(p, p, 0, 4, 4, None, None, None) == 0
 
 
-@pytest.mark.parametrize("tag", ["M", "N"])
+@pytest.mark.parametrize("tag", ["M", "N", "D"])
 def test_state_dict_keys_match_reference(tag):
     from normalizing_flow import Glow, GaussianPrior
     m = meta_of(load_golden(f"glow_{tag}.npz"))

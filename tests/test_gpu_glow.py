@@ -28,7 +28,7 @@ def build(m, compute="f32"):
     return flow, prior
 
 
-@pytest.mark.parametrize("tag", ["M", "N"])
+@pytest.mark.parametrize("tag", ["M", "N", "D"])
 @torch.no_grad()
 def test_glow_forward_nll_golden(tag):
     from normalizing_flow import calculate_loss
@@ -53,7 +53,7 @@ def test_glow_forward_nll_golden(tag):
     assert none is None and all(torch.equal(a, b) for a, b in zip(zs, zs2))
 
 
-@pytest.mark.parametrize("tag", ["M", "N"])
+@pytest.mark.parametrize("tag", ["M", "N", "D"])
 @torch.no_grad()
 def test_glow_inverse_and_sampling_golden(tag):
     from normalizing_flow import postprocess_batch

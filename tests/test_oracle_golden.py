@@ -103,7 +103,7 @@ def test_pre_post_bpd(ops):
         O.output_shapes(3, 3, 30 // 2 * 2 + 1)
 
 
-@pytest.mark.parametrize("tag", ["M", "N"])
+@pytest.mark.parametrize("tag", ["M", "N", "D"])
 def test_glow_composite(tag):
     g = load_golden(f"glow_{tag}.npz")
     m = meta_of(g)

@@ -378,6 +378,7 @@ if __name__ == "__main__":
     if "glow" in which:
         gen_glow("M", 1, 3, 4, 4, 1)      # BASELINE configs[0] shape (MNIST 1x32x32, L3 K4)
         gen_glow("N", 3, 3, 2, 2, 2)      # north-star shape with reduced K
+        gen_glow("D", 3, 5, 1, 2, 3)      # CelebA depth (BASELINE configs[4]: L = 5 -> C up to 192) on 32x32 inputs
     if "init" in which:
         gen_glow_init()
     if "diffusion" in which:
