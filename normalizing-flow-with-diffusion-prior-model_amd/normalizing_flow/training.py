@@ -149,24 +149,59 @@ class ConvScaleFn(Function):
 
 
 class CouplingFn(Function):
-    """(x_a | x_b), (log_s | t) -> (x_a | (x_b + t) * sigmoid(log_s + 2)), per-sample sum log(s + 1e-6)
-    (reference transforms.py:179-185)."""
+    """(x_a | x_b), (log_s | t), ldj -> (x_a | (x_b + t) * sigmoid(log_s + 2)), ldj + per-sample sum log(s + 1e-6)
+    (reference transforms.py:179-185).  The running log-det goes through the node (the kernel adds into its fp64 copy), so the
+    chain of flows costs no separate add launch; ldj=None returns the per-sample increment alone."""
 
     @staticmethod
-    def forward(ctx, xh, hh):
+    def forward(ctx, xh, hh, ldj):
         xh, hh = xh.contiguous(), hh.contiguous()
         y = xh.clone()
-        inc = torch.zeros(xh.shape[0], device=xh.device, dtype=torch.float64)
-        K.coupling_fwd(y, hh, inc, None)
+        if ldj is None:
+            acc = torch.zeros(xh.shape[0], device=xh.device, dtype=torch.float64)
+        else:
+            acc = ldj.to(torch.float64, copy=True)
+        K.coupling_fwd(y, hh, acc, None)
         ctx.save_for_backward(xh, hh)
-        return y, inc
+        ctx.ldj_dtype = None if ldj is None else ldj.dtype
+        return y, acc
 
     @staticmethod
-    def backward(ctx, dy, dinc):
+    def backward(ctx, dy, dacc):
         xh, hh = ctx.saved_tensors
         if dy is None:
             dy = torch.zeros_like(xh)
-        return K.coupling_bwd(xh, hh, dy.contiguous(), None if dinc is None else dinc.contiguous())
+        dx, dh = K.coupling_bwd(xh, hh, dy.contiguous(), None if dacc is None else dacc.contiguous())
+        dldj = None
+        if ctx.ldj_dtype is not None and dacc is not None:
+            dldj = dacc if dacc.dtype == ctx.ldj_dtype else dacc.to(ctx.ldj_dtype)
+        return dx, dh, dldj
+
+
+class LevelLogdetFn(Function):
+    """hw * sum over the flows of a level of (sum(actnorm.scale) + log|det W|) as ONE node (reference transforms.py:82, :131-133,
+    added per flow there): one batched fp64 Gauss-Jordan for the log-dets and inverses, one product for all dW = g hw W^-T.
+    Per flow the same terms cost ~14 scalar-sized launches forward + backward (sum, two products, three adds, their reductions)."""
+
+    @staticmethod
+    def forward(ctx, hw, n, *params):
+        ws, scales = params[:n], params[n:]
+        c = ws[0].shape[0]
+        w = torch.stack([x.detach().reshape(c, c) for x in ws])
+        lads, winvs = K.invconv_prepare(w, want_inverse=True)
+        ssum = torch.cat([x.detach().reshape(-1) for x in scales]).sum(dtype=torch.float64)
+        ctx.save_for_backward(winvs)
+        ctx.hw, ctx.n = float(hw), n
+        ctx.wshape, ctx.sshape = ws[0].shape, scales[0].shape
+        return ((lads.sum(dtype=torch.float64) + ssum) * float(hw)).reshape(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (winvs,) = ctx.saved_tensors
+        gh = (g.reshape(()) * ctx.hw).to(torch.float32)
+        dw = (gh * winvs.transpose(1, 2)).contiguous()
+        ds = gh.expand(ctx.sshape)
+        return (None, None) + tuple(dw[i].view(ctx.wshape) for i in range(ctx.n)) + (ds,) * ctx.n
 
 
 class GaussLogpFn(Function):
@@ -294,7 +329,8 @@ def coupling_net(net, xa: Tensor, compute: Optional[str] = None) -> Tensor:
 
 
 def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None) -> Tuple[Tensor, Optional[Tensor]]:
-    """actnorm -> invconv -> affine coupling (reference glow.py:44-49), differentiable."""
+    """actnorm -> invconv -> affine coupling (reference glow.py:44-49), differentiable.  pre="level": the weight-only log-det terms of
+    this flow (actnorm scale sum, log|det W|) are added once per level by the caller (LevelLogdetFn)."""
     an, ic, cp = flow.actnorm, flow.invconv2d, flow.affcoupling
     hw = xh.shape[1] * xh.shape[2]
     if not an.initialized():
@@ -303,10 +339,28 @@ def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None) -> Tuple[Tensor
     y = ActNormFn.apply(xh, an.scale, an.bias)
     y = InvConvFn.apply(y, ic.weight)
     c = y.shape[-1]
-    y, inc = CouplingFn.apply(y, coupling_net(cp.net, y[..., : c // 2], cp.compute))
-    if ldj is not None:
+    h = coupling_net(cp.net, y[..., : c // 2], cp.compute)
+    if ldj is None:
+        y, _ = CouplingFn.apply(y, h, None)
+    elif isinstance(pre, str):
+        y, ldj = CouplingFn.apply(y, h, ldj)
+    else:
+        y, inc = CouplingFn.apply(y, h, None)
         ldj = ldj + hw * an.scale.sum() + hw * LogAbsDetFn.apply(ic.weight, pre) + inc
     return y, ldj
+
+
+def _level_flows(flows, yh: Tensor, ldj: Optional[Tensor]):
+    """All flows of a level; with a log-det accumulator the weight-only terms are one LevelLogdetFn node for the level."""
+    if ldj is None:
+        for flow in flows:
+            yh, _ = step_flow(flow, yh, None)
+        return yh, None
+    hw = yh.shape[1] * yh.shape[2]
+    for flow in flows:
+        yh, ldj = step_flow(flow, yh, ldj, "level")      # data-dependent ActNorm init (if any) happens in here, before the scales are read
+    term = LevelLogdetFn.apply(hw, len(flows), *[f.invconv2d.weight for f in flows], *[f.actnorm.scale for f in flows])
+    return yh, ldj + term
 
 
 def split(mod, xh: Tensor, logp: Optional[Tensor]):
@@ -322,28 +376,15 @@ def split(mod, xh: Tensor, logp: Optional[Tensor]):
     return yv, zv.contiguous(), logp
 
 
-def _level_logdets(flows):
-    """(lad [1], W^-1) of every flow of a level from ONE batched fp64 Gauss-Jordan launch (weights only)."""
-    w = torch.stack([f.invconv2d.weight.detach().reshape(f.invconv2d.weight.shape[0], -1) for f in flows]).contiguous()
-    lads, winvs = K.invconv_prepare(w, want_inverse=True)
-    return [(lads[i:i + 1], winvs[i]) for i in range(len(flows))]
-
-
 def glow_transform(glow, x: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor]):
     """Glow.transform with a gradient graph (reference glow.py:172-201): -> (latent parts NCHW views, ldj, logp)."""
     yh = K.to_nhwc(x)
     zs = []
     for block in glow.blocks:
-        yh = SqueezeFn.apply(yh)
-        pre = _level_logdets(block.flows) if ldj is not None else [None] * len(block.flows)
-        for flow, pr in zip(block.flows, pre):
-            yh, ldj = step_flow(flow, yh, ldj, pr)
+        yh, ldj = _level_flows(block.flows, SqueezeFn.apply(yh), ldj)
         yh, z, logp = split(block.split, yh, logp)
         zs.append(K.as_nchw(z))
-    yh = SqueezeFn.apply(yh)
-    pre = _level_logdets(glow.final_flows) if ldj is not None else [None] * len(glow.final_flows)
-    for flow, pr in zip(glow.final_flows, pre):
-        yh, ldj = step_flow(flow, yh, ldj, pr)
+    yh, ldj = _level_flows(glow.final_flows, SqueezeFn.apply(yh), ldj)
     zs.append(K.as_nchw(yh))
     return zs, ldj, logp
 

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Where do the small launches of one training step come from?  One eager step (Glow L3 K16, B=512, bf16) under torch.profiler with
+Python stacks: device kernels grouped by the aten op and the innermost frame of this repo that issued them."""
+import os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "normalizing-flow-with-diffusion-prior-model_amd")]
+import torch
+import bench
+import nfdp_hip as KH
+from nfdp_hip.optim import FusedAdam
+from normalizing_flow import calculate_loss, initialize_with_zeros
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+dev = torch.device("cuda", 0)
+flow, prior, _, _ = bench.build_models(3, 16, "bf16", dev)
+flow.train(); prior.train()
+opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-4, clip_value=1.0, max_norm=1.0)
+_, _, u8_d, noise_d = bench.make_batch(B, 0, dev)
+
+
+def train_step():
+    x = KH.as_nchw(KH.preprocess_u8(u8_d, noise_d, 5))
+    ll, logp = initialize_with_zeros(2, B, dev)
+    latents, ll, logp = flow.transform(x, ll, logp)
+    logp = logp + prior.compute_log_prob(latents[-1])
+    loss = calculate_loss(ll + logp, 32.0, 3 * 32 * 32)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return loss.detach()
+
+
+for _ in range(3):
+    train_step()
+torch.cuda.synchronize()
+from torch.profiler import profile, ProfilerActivity
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    train_step()
+    torch.cuda.synchronize()
+
+agg = collections.defaultdict(lambda: [0, 0.0])
+for ev in prof.events():
+    if ev.device_type != torch.autograd.DeviceType.CPU or not ev.kernels:
+        continue
+    if not ev.name.startswith("aten::"):
+        continue
+    where = "?"
+    for fr in ev.stack:
+        if "normalizing-flow-with-diffusion-prior-model_amd" in fr or "bench.py" in fr or "trace_train_ops" in fr:
+            where = fr.split("normalizing-flow-with-diffusion-prior-model_amd/")[-1]
+            break
+    a = agg[(ev.name, where)]
+    a[0] += len(ev.kernels)
+    a[1] += sum(k.duration for k in ev.kernels)
+tot = sum(v[0] for v in agg.values())
+print(f"{tot} device launches issued by aten ops")
+for (name, where), v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:70]:
+    print(f"{v[0]:5d}  {v[1] / 1e3:7.3f} ms  {name:28s} {where}")
