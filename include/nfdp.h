@@ -284,6 +284,17 @@ int nfdp_conv_wgrad_bf16_supported(int Cin, int Cout);
 size_t nfdp_conv_wgrad_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int k);
 int nfdp_conv_wgrad_bf16(const void* x, int x_dtype, int x_ld, const void* dy, int dy_dtype, int dy_ld, int B, int H, int W,
                          int Cin, int Cout, int k, float* dw, void* ws, nfdp_stream_t stream);
+/* Gradient accumulation in the reducing launch (what autograd's AccumulateGrad does with one more elementwise launch per parameter,
+ * ~640 per training step of Glow L3 K16): accumulate != 0 adds the result to dw instead of storing it.  out_form selects where the
+ * reduced GEMM lands, for the convs the training path runs as plain GEMMs over im2col rows (k must be 1 for forms 1, 2):
+ *   0: dw[Cout][Cin][k][k] of the conv itself (as above);
+ *   1: x = nfdp_im2col3x3_bf16 rows of an out_c-channel tensor (9*out_c <= Cin): the 3x3 weight gradient dw[Cout][out_c][3][3];
+ *   2: x = im2col rows of the out_c-channel OUTPUT gradient of a 3x3 conv and dy = that conv's input: dw[out_c][Cout][3][3] with the
+ *      taps mirrored (ZeroConv2d's weight gradient from the im2col matrix of its output gradient). */
+int nfdp_conv_wgrad_f32_ex(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout, int k,
+                           float* dw, void* ws, int out_form, int out_c, int accumulate, nfdp_stream_t stream);
+int nfdp_conv_wgrad_bf16_ex(const void* x, int x_dtype, int x_ld, const void* dy, int dy_dtype, int dy_ld, int B, int H, int W,
+                            int Cin, int Cout, int k, float* dw, void* ws, int out_form, int out_c, int accumulate, nfdp_stream_t stream);
 /* wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: nfdp_conv2d_nhwc on pack(wt) is the data gradient of the conv with w. */
 int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int I, int k, nfdp_stream_t stream);
 /* Second half of a narrow 3x3 'same' conv computed as a pointwise GEMM to tap contributions T [B,H,W,9*Co] (column
@@ -303,6 +314,10 @@ int nfdp_scale_bwd(const void* dy, int dy_dtype, int dy_ld, const void* y, int y
                    long npix, int C, void* dc, int dc_dtype, int dc_ld, float* dmul, float* dadd, void* ws, nfdp_stream_t stream);
 int nfdp_scale_bwd_f32(const float* dy, int dy_ld, const float* y, int y_ld, const float* mul, float f, int relu, long npix,
                        int C, float* dc, int dc_ld, float* dmul, float* dadd, void* ws, nfdp_stream_t stream);
+/* accumulate != 0: dmul / dadd are added to (the parameters' .grad in place) instead of stored. */
+int nfdp_scale_bwd_ex(const void* dy, int dy_dtype, int dy_ld, const void* y, int y_dtype, int y_ld, const float* mul, float f, int relu,
+                      long npix, int C, void* dc, int dc_dtype, int dc_ld, float* dmul, float* dadd, void* ws, int accumulate,
+                      nfdp_stream_t stream);
 /* Backward of AffineCoupling.transform (transforms.py:179-185).  x: tensor before the coupling [B,HW,C] dense,
  * h = (log_s | t) network output, dy: gradient w.r.t. the output, gl (nullable): fp64 [B] gradient w.r.t. the
  * per-sample log-det increment.  dx, dh: [B,HW,C] dense. */
@@ -323,6 +338,9 @@ size_t nfdp_pointwise_dgrad_masked_ws_bytes(long npix, int Cout);
 int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const void* w_packed, const void* y_saved, int y_ld, const float* mul,
                                      float f, long npix, int Cin, int Cout, void* dc, int dc_ld, float* dmul, float* dadd, void* ws,
                                      nfdp_stream_t stream);
+int nfdp_pointwise_dgrad_masked_bf16_ex(const void* x, int x_ld, const void* w_packed, const void* y_saved, int y_ld, const float* mul,
+                                        float f, long npix, int Cin, int Cout, void* dc, int dc_ld, float* dmul, float* dadd, void* ws,
+                                        int accumulate, nfdp_stream_t stream);
 
 /* Fused optimizer step on flat fp32 buffers (trainer.py:165-167 + utils.py:120-137): for the first n_clip elements
  * g = clamp(g, +-clip_value) (clip_grad_value_; <= 0: off) then g *= min(1, max_norm / (||g[:n_clip]||_2 + 1e-6))

@@ -114,29 +114,45 @@ __global__ void __launch_bounds__(64) wgrad_kernel(const WgradParams p) {
             }
 }
 
-// dw[o][ci][ky][kx] (OIHW) = sum over the pixel slices.  256/LPO outputs x LPO lanes per workgroup: lane g sums slices g,
-// g+LPO, ... and the lane sums are combined in lane order (fixed order -> deterministic; a tiny CxC output with 2048
-// slices would otherwise be one workgroup walking them serially).  LPO = 64 for the tiny outputs, 8 otherwise.
+// Where a reduced element (m = dy channel, n = (tap, x channel) column of the padded [Mpad][Npad] slices) lands in dw, and whether
+// it is added to what is there (gradient accumulation straight into the parameter's .grad):
+//   dst = m*sm + (n % D)*sd + (n / D)*st + off   for m < Cout, n < N.
+// form 0: dw[o][ci][ky][kx] (OIHW) of the conv itself.  form 1 (k = 1, x = im2col rows of a c-channel tensor): the 3x3 weight
+// dw[o][c][3][3].  form 2 (k = 1, x = im2col rows of the c-channel OUTPUT gradient, dy = the conv's input): dw[c][Cout][3][3] with the
+// taps mirrored (the zero conv's weight gradient from the im2col matrix of its output gradient).
+struct WgradOut { int D, N; long sm, sd, st, off; int acc; };
+
+static bool wgrad_out_map(int form, int c, int Cout, int Cin, int k, int acc, WgradOut* o) {
+    o->acc = acc;
+    if (form == 0) { o->D = Cin; o->N = k * k * Cin; o->sm = (long)Cin * k * k; o->sd = k * k; o->st = 1; o->off = 0; return true; }
+    if (k != 1 || c <= 0 || 9 * c > Cin) return false;
+    o->D = c; o->N = 9 * c;
+    if (form == 1) { o->sm = 9L * c; o->sd = 9; o->st = 1; o->off = 0; return true; }
+    if (form == 2) { o->sm = 9; o->sd = 9L * Cout; o->st = -1; o->off = 8; return true; }
+    return false;
+}
+
+__device__ __forceinline__ void wgrad_put(float* __restrict__ dw, const WgradOut& o, int m, int n, float v) {
+    float* d = dw + (m * o.sm + (n % o.D) * o.sd + (n / o.D) * o.st + o.off);
+    *d = o.acc ? *d + v : v;
+}
+
+// Sum over the pixel slices.  256/LPO outputs x LPO lanes per workgroup: lane g sums slices g, g+LPO, ... and the lane sums are
+// combined in lane order (fixed order -> deterministic; a tiny CxC output with 2048 slices would otherwise be one workgroup walking
+// them serially).  LPO = 64 for the tiny outputs, 8 otherwise.
 template <int LPO>
 __global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ksplit,
-                                                             int Mpad, int Npad, int Cout, int Cin, int k) {
+                                                             int Mpad, int Npad, int Cout, WgradOut o) {
     constexpr int OPW = kBlock / LPO;
     __shared__ float red[LPO][OPW];
-    const long total = (long)Cout * Cin * k * k;
+    const long total = (long)Cout * o.N;
     const int el = threadIdx.x % OPW, g = threadIdx.x / OPW;
     for (long i0 = (long)blockIdx.x * OPW; i0 < total; i0 += (long)gridDim.x * OPW) {
         const long i = i0 + el;
+        const int m = (int)(i / o.N), n = (int)(i % o.N);
         float s = 0.f;
-        if (i < total) {
-            const int kx = (int)(i % k);
-            long r = i / k;
-            const int ky = (int)(r % k);
-            r /= k;
-            const int ci = (int)(r % Cin);
-            const int o = (int)(r / Cin);
-            const int n = (ky * k + kx) * Cin + ci;
-            for (int q = g; q < ksplit; q += LPO) s += ws[((size_t)q * Mpad + o) * Npad + n];
-        }
+        if (i < total)
+            for (int q = g; q < ksplit; q += LPO) s += ws[((size_t)q * Mpad + m) * Npad + n];
         __syncthreads();
         red[g][el] = s;
         __syncthreads();
@@ -144,7 +160,7 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __res
             float t = 0.f;
 #pragma unroll
             for (int j = 0; j < LPO; ++j) t += red[j][el];
-            dw[i] = t;
+            wgrad_put(dw, o, m, n, t);
         }
     }
 }
@@ -152,7 +168,7 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_kernel(const float* __res
 // The same sum for the larger outputs, walking the padded [Mpad][Npad] slices as they lie in memory: a wave reads 1 KB
 // contiguous per slice (float4 per lane), the 4 waves take slices w, w+4, ... and are combined in wave order.
 __global__ void __launch_bounds__(kBlock) wgrad_reduce_vec_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ksplit,
-                                                                 int Mpad, int Npad, int Cout, int Cin, int k) {
+                                                                 int Mpad, int Npad, int Cout, WgradOut o) {
     __shared__ float4 red[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long slice = (long)Mpad * Npad;
@@ -169,26 +185,21 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_vec_kernel(const float* _
         float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 4; ++w) { t[0] += red[w][lane].x; t[1] += red[w][lane].y; t[2] += red[w][lane].z; t[3] += red[w][lane].w; }
-        const int m = (int)(e0 / Npad), n0 = (int)(e0 % Npad), N = k * k * Cin;
+        const int m = (int)(e0 / Npad), n0 = (int)(e0 % Npad);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + j;
-            if (m < Cout && n < N) dw[((size_t)m * Cin + n % Cin) * (k * k) + n / Cin] = t[j];
-        }
+        for (int j = 0; j < 4; ++j)
+            if (m < Cout && n0 + j < o.N) wgrad_put(dw, o, m, n0 + j, t[j]);
     }
 }
 
-static void launch_wgrad_reduce(const float* ws, float* dw, int ksplit, int Mpad, int Npad, int Cout, int Cin, int k, hipStream_t s) {
-    const long slice = (long)Mpad * Npad;
+static void launch_wgrad_reduce(const float* ws, float* dw, int ksplit, int Mpad, int Npad, int Cout, const WgradOut& o, hipStream_t s) {
+    const long slice = (long)Mpad * Npad, total = (long)Cout * o.N;
     if (slice >= 16384 && Npad % 4 == 0)
-        hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((int)cdiv(slice, 256)), dim3(kBlock), 0, s, ws, dw, ksplit, Mpad, Npad, Cout,
-                           Cin, k);
-    else if ((long)Cout * Cin * k * k <= 4096 && ksplit >= 256)
-        hipLaunchKernelGGL((wgrad_reduce_kernel<64>), dim3(stream_grid((long)Cout * Cin * k * k, 4)), dim3(kBlock), 0, s, ws, dw, ksplit,
-                           Mpad, Npad, Cout, Cin, k);
+        hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((int)cdiv(slice, 256)), dim3(kBlock), 0, s, ws, dw, ksplit, Mpad, Npad, Cout, o);
+    else if (total <= 4096 && ksplit >= 256)
+        hipLaunchKernelGGL((wgrad_reduce_kernel<64>), dim3(stream_grid(total, 4)), dim3(kBlock), 0, s, ws, dw, ksplit, Mpad, Npad, Cout, o);
     else
-        hipLaunchKernelGGL((wgrad_reduce_kernel<8>), dim3(stream_grid((long)Cout * Cin * k * k, 32)), dim3(kBlock), 0, s, ws, dw, ksplit,
-                           Mpad, Npad, Cout, Cin, k);
+        hipLaunchKernelGGL((wgrad_reduce_kernel<8>), dim3(stream_grid(total, 32)), dim3(kBlock), 0, s, ws, dw, ksplit, Mpad, Npad, Cout, o);
 }
 
 // wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: the forward conv kernel on wt is the data gradient of conv(., w)
@@ -386,7 +397,7 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_vec_kernel(const TDY* __rest
 // (With one thread per channel the whole partial buffer - MBs for C = 512 - went through C/256 = 2 CUs; the fused GEMM epilogue
 // writes one partial row per 128 pixels, 8 MB at level 0, so the reads are spread over C/8 = 64 workgroups.)
 __global__ void __launch_bounds__(kBlock) scale_bwd_finish_kernel(const double* __restrict__ part, int nblk, int C, float f,
-                                                                 float* __restrict__ dmul, float* __restrict__ dadd) {
+                                                                 float* __restrict__ dmul, float* __restrict__ dadd, int acc) {
     __shared__ double red[2][32][8];
     const int cl = threadIdx.x & 7, g = threadIdx.x >> 3;
     const int c = blockIdx.x * 8 + cl;
@@ -402,8 +413,8 @@ __global__ void __launch_bounds__(kBlock) scale_bwd_finish_kernel(const double* 
     if (g == 0 && c < C) {
         double sa = 0.0, sb = 0.0;
         for (int t = 0; t < 32; ++t) { sa += red[0][t][cl]; sb += red[1][t][cl]; }
-        if (dmul) dmul[c] = (float)(sa * (double)f);
-        if (dadd) dadd[c] = (float)sb;
+        if (dmul) dmul[c] = (float)(sa * (double)f) + (acc ? dmul[c] : 0.f);       // acc: add to the parameter's .grad in place
+        if (dadd) dadd[c] = (float)sb + (acc ? dadd[c] : 0.f);
     }
 }
 
@@ -774,9 +785,12 @@ extern "C" size_t nfdp_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cou
     return (size_t)p.ksplit * p.Mpad * p.Npad * sizeof(float);
 }
 
-extern "C" int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout,
-                                   int k, float* dw, void* ws, nfdp_stream_t stream) {
+extern "C" int nfdp_conv_wgrad_f32_ex(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout,
+                                      int k, float* dw, void* ws, int out_form, int out_c, int accumulate, nfdp_stream_t stream) {
     NFDP_REQUIRE(x && dy && dw && ws, NFDP_EINVAL, "conv_wgrad: null pointer");
+    WgradOut om;
+    NFDP_REQUIRE(wgrad_out_map(out_form, out_c, Cout, Cin, k, accumulate, &om), NFDP_ESHAPE,
+                 "conv_wgrad: output form %d needs k = 1 and 9*out_c <= Cin (k=%d out_c=%d Cin=%d)", out_form, k, out_c, Cin);
     NFDP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 7 && (k & 1), NFDP_ESHAPE,
                  "conv_wgrad: bad shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d", B, H, W, Cin, Cout, k);
     NFDP_REQUIRE(x_ld >= Cin && dy_ld >= Cout, NFDP_ESHAPE, "conv_wgrad: pixel stride smaller than the channel count");
@@ -796,9 +810,14 @@ extern "C" int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, in
     else if (MT == 1 && NT == 4) launch_wgrad<1, 4>(p, s);
     else if (MT == 1 && NT == 2) launch_wgrad<1, 2>(p, s);
     else launch_wgrad<1, 1>(p, s);
-    launch_wgrad_reduce(p.ws, dw, p.ksplit, p.Mpad, p.Npad, Cout, Cin, k, s);
+    launch_wgrad_reduce(p.ws, dw, p.ksplit, p.Mpad, p.Npad, Cout, om, s);
     NFDP_CHECK_LAUNCH("conv_wgrad");
     return NFDP_OK;
+}
+
+extern "C" int nfdp_conv_wgrad_f32(const float* x, int x_ld, const float* dy, int dy_ld, int B, int H, int W, int Cin, int Cout,
+                                   int k, float* dw, void* ws, nfdp_stream_t stream) {
+    return nfdp_conv_wgrad_f32_ex(x, x_ld, dy, dy_ld, B, H, W, Cin, Cout, k, dw, ws, 0, 0, 0, stream);
 }
 
 extern "C" int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int I, int k, nfdp_stream_t stream) {
@@ -811,8 +830,8 @@ extern "C" int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int 
 }
 
 // used by the fused scale/ReLU backward epilogue of the pointwise GEMM (conv.hip): same partial layout [blk][2][C]
-void nfdp_internal_scale_bwd_finish(const double* part, int nblk, int C, float f, float* dmul, float* dadd, hipStream_t s) {
-    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
+void nfdp_internal_scale_bwd_finish(const double* part, int nblk, int C, float f, float* dmul, float* dadd, int acc, hipStream_t s) {
+    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd, acc);
 }
 
 static int scale_bwd_blocks(long npix) {
@@ -852,9 +871,9 @@ static void launch_scale_bwd(const void* dy, int dy_ld, const void* y, int y_ld,
                            C, c, dc_ld, part, rows);
 }
 
-extern "C" int nfdp_scale_bwd(const void* dy, int dy_dtype, int dy_ld, const void* y, int y_dtype, int y_ld, const float* mul,
-                              float f, int relu, long npix, int C, void* dc, int dc_dtype, int dc_ld, float* dmul, float* dadd,
-                              void* ws, nfdp_stream_t stream) {
+extern "C" int nfdp_scale_bwd_ex(const void* dy, int dy_dtype, int dy_ld, const void* y, int y_dtype, int y_ld, const float* mul,
+                                 float f, int relu, long npix, int C, void* dc, int dc_dtype, int dc_ld, float* dmul, float* dadd,
+                                 void* ws, int accumulate, nfdp_stream_t stream) {
     NFDP_REQUIRE(dy && ws, NFDP_EINVAL, "scale_bwd: null pointer");
     NFDP_REQUIRE(npix > 0 && C > 0 && C <= 4096 && dy_ld >= C, NFDP_ESHAPE, "scale_bwd: bad shape npix=%ld C=%d", npix, C);
     NFDP_REQUIRE((y == nullptr || y_ld >= C) && (dc == nullptr || dc_ld >= C), NFDP_ESHAPE, "scale_bwd: bad pixel stride");
@@ -872,9 +891,15 @@ extern "C" int nfdp_scale_bwd(const void* dy, int dy_dtype, int dy_ld, const voi
                            dy_dtype, y_dtype, dc_dtype);
             return NFDP_EUNSUPPORTED;
     }
-    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd);
+    hipLaunchKernelGGL(scale_bwd_finish_kernel, dim3((int)cdiv(C, 8)), dim3(kBlock), 0, s, part, nblk, C, f, dmul, dadd, accumulate);
     NFDP_CHECK_LAUNCH("scale_bwd");
     return NFDP_OK;
+}
+
+extern "C" int nfdp_scale_bwd(const void* dy, int dy_dtype, int dy_ld, const void* y, int y_dtype, int y_ld, const float* mul,
+                              float f, int relu, long npix, int C, void* dc, int dc_dtype, int dc_ld, float* dmul, float* dadd,
+                              void* ws, nfdp_stream_t stream) {
+    return nfdp_scale_bwd_ex(dy, dy_dtype, dy_ld, y, y_dtype, y_ld, mul, f, relu, npix, C, dc, dc_dtype, dc_ld, dmul, dadd, ws, 0, stream);
 }
 
 extern "C" int nfdp_scale_bwd_f32(const float* dy, int dy_ld, const float* y, int y_ld, const float* mul, float f, int relu,
@@ -937,9 +962,13 @@ extern "C" size_t nfdp_conv_wgrad_bf16_ws_bytes(int B, int H, int W, int Cin, in
     return (size_t)p.ksplit * p.Mpad * p.Npad * sizeof(float);
 }
 
-extern "C" int nfdp_conv_wgrad_bf16(const void* x, int x_dtype, int x_ld, const void* dy, int dy_dtype, int dy_ld, int B, int H, int W,
-                                    int Cin, int Cout, int k, float* dw, void* ws, nfdp_stream_t stream) {
+extern "C" int nfdp_conv_wgrad_bf16_ex(const void* x, int x_dtype, int x_ld, const void* dy, int dy_dtype, int dy_ld, int B, int H, int W,
+                                       int Cin, int Cout, int k, float* dw, void* ws, int out_form, int out_c, int accumulate,
+                                       nfdp_stream_t stream) {
     NFDP_REQUIRE(x && dy && dw && ws, NFDP_EINVAL, "conv_wgrad_bf16: null pointer");
+    WgradOut om;
+    NFDP_REQUIRE(wgrad_out_map(out_form, out_c, Cout, Cin, k, accumulate, &om), NFDP_ESHAPE,
+                 "conv_wgrad_bf16: output form %d needs k = 1 and 9*out_c <= Cin (k=%d out_c=%d Cin=%d)", out_form, k, out_c, Cin);
     NFDP_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && k >= 1 && k <= 7 && (k & 1), NFDP_ESHAPE,
                  "conv_wgrad_bf16: bad shape B=%d H=%d W=%d Cin=%d Cout=%d k=%d", B, H, W, Cin, Cout, k);
     NFDP_REQUIRE(nfdp_conv_wgrad_bf16_supported(Cin, Cout), NFDP_EUNSUPPORTED,
@@ -968,9 +997,14 @@ extern "C" int nfdp_conv_wgrad_bf16(const void* x, int x_dtype, int x_ld, const 
     else if (xb) hipLaunchKernelGGL((wgrad_bf16_kernel<true, false>), grid, dim3(kBlock), 0, s, p);
     else if (db) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true>), grid, dim3(kBlock), 0, s, p);
     else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false>), grid, dim3(kBlock), 0, s, p);
-    launch_wgrad_reduce(p.ws, dw, p.ksplit, p.Mpad, p.Npad, Cout, Cin, k, s);
+    launch_wgrad_reduce(p.ws, dw, p.ksplit, p.Mpad, p.Npad, Cout, om, s);
     NFDP_CHECK_LAUNCH("conv_wgrad_bf16");
     return NFDP_OK;
+}
+
+extern "C" int nfdp_conv_wgrad_bf16(const void* x, int x_dtype, int x_ld, const void* dy, int dy_dtype, int dy_ld, int B, int H, int W,
+                                    int Cin, int Cout, int k, float* dw, void* ws, nfdp_stream_t stream) {
+    return nfdp_conv_wgrad_bf16_ex(x, x_dtype, x_ld, dy, dy_dtype, dy_ld, B, H, W, Cin, Cout, k, dw, ws, 0, 0, 0, stream);
 }
 
 extern "C" int nfdp_tap_shift_sum_f32(const float* T, float* out, int B, int H, int W, int Co, const float* add, const float* mul,

@@ -868,7 +868,7 @@ extern "C" int nfdp_conv_pack_weights_ex(const float* w_oihw, void* w_packed, in
     return NFDP_OK;
 }
 
-void nfdp_internal_scale_bwd_finish(const double* part, int nblk, int C, float f, float* dmul, float* dadd, hipStream_t s);   // backward.hip
+void nfdp_internal_scale_bwd_finish(const double* part, int nblk, int C, float f, float* dmul, float* dadd, int acc, hipStream_t s);   // backward.hip
 
 extern "C" int nfdp_pointwise_dgrad_masked_supported(long npix, int Cin, int Cout) {
     return Cin % PW_BK == 0 && Cout > 64 && Cout % 8 == 0 && npix >= 4 * PW_BM;
@@ -878,9 +878,9 @@ extern "C" size_t nfdp_pointwise_dgrad_masked_ws_bytes(long npix, int Cout) {
     return (size_t)cdiv(npix, PW_BM) * 2 * Cout * sizeof(double);
 }
 
-extern "C" int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const void* w_packed, const void* y_saved, int y_ld,
-                                                const float* mul, float f, long npix, int Cin, int Cout, void* dc, int dc_ld, float* dmul,
-                                                float* dadd, void* ws, nfdp_stream_t stream) {
+extern "C" int nfdp_pointwise_dgrad_masked_bf16_ex(const void* x, int x_ld, const void* w_packed, const void* y_saved, int y_ld,
+                                                   const float* mul, float f, long npix, int Cin, int Cout, void* dc, int dc_ld,
+                                                   float* dmul, float* dadd, void* ws, int accumulate, nfdp_stream_t stream) {
     NFDP_REQUIRE(x && w_packed && y_saved && dc && dmul && dadd && ws, NFDP_EINVAL, "pointwise_dgrad_masked: null pointer");
     NFDP_REQUIRE(nfdp_pointwise_dgrad_masked_supported(npix, Cin, Cout), NFDP_EUNSUPPORTED,
                  "pointwise_dgrad_masked: npix=%ld Cin=%d Cout=%d (Cin %% 64, Cout %% 8, npix >= 512)", npix, Cin, Cout);
@@ -904,9 +904,16 @@ extern "C" int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const v
         attr_set = true;
     }
     hipLaunchKernelGGL(pw_gemm_bf16_kernel<true>, dim3(grid), dim3(kThreads), PW_LDS_BYTES, s, P);
-    nfdp_internal_scale_bwd_finish(P.part, P.Mt, Cout, f, dmul, dadd, s);
+    nfdp_internal_scale_bwd_finish(P.part, P.Mt, Cout, f, dmul, dadd, accumulate, s);
     NFDP_CHECK_LAUNCH("pointwise_dgrad_masked");
     return NFDP_OK;
+}
+
+extern "C" int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const void* w_packed, const void* y_saved, int y_ld,
+                                                const float* mul, float f, long npix, int Cin, int Cout, void* dc, int dc_ld, float* dmul,
+                                                float* dadd, void* ws, nfdp_stream_t stream) {
+    return nfdp_pointwise_dgrad_masked_bf16_ex(x, x_ld, w_packed, y_saved, y_ld, mul, f, npix, Cin, Cout, dc, dc_ld, dmul, dadd, ws, 0,
+                                               stream);
 }
 
 extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,

@@ -757,10 +757,13 @@ def _dt(t: torch.Tensor) -> int:
     return BF16 if t.dtype == torch.bfloat16 else F32
 
 
-def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int, compute: int = F32) -> torch.Tensor:
+def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int, compute: int = F32, out: Optional[torch.Tensor] = None,
+               accumulate: bool = False, form: int = 0, form_c: int = 0) -> torch.Tensor:
     """-> dw [Cout,Cin,k,k] fp32 of a stride-1 'same' conv; xh, dyh pixel-strided NHWC, fp32 (or bf16 with compute=BF16).
     compute=BF16 runs the bf16-MFMA kernel where its alignment rules allow (channel counts and pixel strides multiples of 4),
-    else the exact-fp32 one."""
+    else the exact-fp32 one.  out (dense fp32, e.g. the parameter's .grad) receives the result, added to its contents when
+    accumulate; form 1 / 2 (k = 1, xh = im2col rows of a form_c-channel tensor) store the 3x3 weight gradient [Cout,form_c,3,3] /
+    the mirrored [form_c,Cout,3,3] of the zero conv directly (nfdp_conv_wgrad_bf16_ex)."""
     for a in (xh, dyh):
         if not a.is_cuda:
             raise NfdpError("conv_wgrad: the HIP path needs GPU tensors (no CPU fallback)")
@@ -770,29 +773,40 @@ def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int, compute: int = F32) 
     cout = dyh.shape[-1]
     if tuple(dyh.shape[:3]) != (b, h, w):
         raise ValueError(f"conv_wgrad: shape mismatch {tuple(xh.shape)} / {tuple(dyh.shape)}")
-    if compute == BF16 and k > 1 and cout * 4 <= cin and cin % 4 == 0 and cout % 4 == 0 and cout * k * k <= 512:
+    plain = out is None and form == 0
+    if plain and compute == BF16 and k > 1 and cout * 4 <= cin and cin % 4 == 0 and cout % 4 == 0 and cout * k * k <= 512:
         # narrow output (ZeroConv2d 512 -> C): gather the k*k taps over the NARROW tensor instead, so the wide one is read
         # once instead of k*k times:  dW[o][i][ky][kx] = W'[i][o][k-1-ky][k-1-kx]  with  W' = wgrad(x := dy, dy := x)
         return conv_flip_weights(conv_wgrad(dyh, xh, k, compute=compute))
-    if compute == BF16 and cin % 4 != 0 and cout % 4 == 0 and _ld(xh, "conv_wgrad") >= (cin + 3) // 4 * 4:
+    if plain and compute == BF16 and cin % 4 != 0 and cout % 4 == 0 and _ld(xh, "conv_wgrad") >= (cin + 3) // 4 * 4:
         # x is a channel slice (x_a = first C/2 channels, C/2 = 6) of a wider pixel row: run the bf16 kernel on the slice
         # rounded up to a multiple of 4 channels (valid memory of the same row) and drop the extra input columns
         c4 = (cin + 3) // 4 * 4
         wide = xh.as_strided((b, h, w, c4), xh.stride())
         return conv_wgrad(wide, dyh, k, compute=compute)[:, :cin].contiguous()
-    dw = torch.empty((cout, cin, k, k), device=xh.device, dtype=torch.float32)
+    shape = {0: (cout, cin, k, k), 1: (cout, form_c, 3, 3), 2: (form_c, cout, 3, 3)}[form]
+    if out is None:
+        dw = torch.empty(shape, device=xh.device, dtype=torch.float32)
+        accumulate = False
+    else:
+        _need(out, torch.float32, "conv_wgrad out"); _dense(out, "conv_wgrad out")
+        if tuple(out.shape) != shape:
+            raise ValueError(f"conv_wgrad: out has shape {tuple(out.shape)}, expected {shape}")
+        dw = out
     if compute == BF16 and cin % 4 == 0 and cout % 4 == 0:
         xl, dl = _ld(xh, "conv_wgrad"), _ld(dyh, "conv_wgrad")
         if xl % 4 == 0 and dl % 4 == 0 and xh.data_ptr() % 16 == 0 and dyh.data_ptr() % 16 == 0:
             ws = torch.empty(lib().nfdp_conv_wgrad_bf16_ws_bytes(b, h, w, cin, cout, k), device=xh.device, dtype=torch.uint8)
-            _call("nfdp_conv_wgrad_bf16", _ptr(xh), _dt(xh), xl, _ptr(dyh), _dt(dyh), dl, b, h, w, cin, cout, k, _ptr(dw), _ptr(ws),
-                  _stream(), label=f"conv_wgrad_bf16 k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout * k * k)
+            _call("nfdp_conv_wgrad_bf16_ex", _ptr(xh), _dt(xh), xl, _ptr(dyh), _dt(dyh), dl, b, h, w, cin, cout, k, _ptr(dw), _ptr(ws),
+                  int(form), int(form_c), int(accumulate), _stream(), label=f"conv_wgrad_bf16 k{k} {cin}->{cout} hw{h}",
+                  flops=2.0 * b * h * w * cin * cout * k * k)
             return dw
     if xh.dtype != torch.float32 or dyh.dtype != torch.float32:          # exact-fp32 kernel: fp32 operands only
         xh, dyh = xh.float(), dyh.float()
     ws = torch.empty(lib().nfdp_conv_wgrad_ws_bytes(b, h, w, cin, cout, k), device=xh.device, dtype=torch.uint8)
-    _call("nfdp_conv_wgrad_f32", _ptr(xh), _ld(xh, "conv_wgrad"), _ptr(dyh), _ld(dyh, "conv_wgrad"), b, h, w, cin, cout, k,
-          _ptr(dw), _ptr(ws), _stream(), label=f"conv_wgrad k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout * k * k)
+    _call("nfdp_conv_wgrad_f32_ex", _ptr(xh), _ld(xh, "conv_wgrad"), _ptr(dyh), _ld(dyh, "conv_wgrad"), b, h, w, cin, cout, k,
+          _ptr(dw), _ptr(ws), int(form), int(form_c), int(accumulate), _stream(), label=f"conv_wgrad k{k} {cin}->{cout} hw{h}",
+          flops=2.0 * b * h * w * cin * cout * k * k)
     return dw
 
 
@@ -804,9 +818,11 @@ def conv_flip_weights(w_oihw: torch.Tensor) -> torch.Tensor:
     return wt
 
 
-def scale_bwd(dyh, yh=None, mul=None, f: float = 1.0, relu: bool = False, want_dc: bool = True, dc_dtype=None):
+def scale_bwd(dyh, yh=None, mul=None, f: float = 1.0, relu: bool = False, want_dc: bool = True, dc_dtype=None,
+              grads_out=None):
     """Backward of y = act((u + add) * exp(f*mul)) -> (dc or None, dmul [C] or None, dadd [C]).  dyh / yh fp32 or bf16;
-    dc_dtype (torch dtype, default: dyh's... fp32 unless yh is bf16) selects the storage of dc."""
+    dc_dtype (torch dtype, default: dyh's... fp32 unless yh is bf16) selects the storage of dc.  grads_out = (dmul_acc, dadd_acc):
+    dense fp32 [C]-sized tensors (the parameters' .grad) the two sums are ADDED to in the finishing launch."""
     if dyh.dtype not in (torch.float32, torch.bfloat16) or not dyh.is_cuda:
         raise NfdpError("scale_bwd: expected an fp32 or bf16 GPU tensor")
     c = dyh.shape[-1]
@@ -815,12 +831,19 @@ def scale_bwd(dyh, yh=None, mul=None, f: float = 1.0, relu: bool = False, want_d
     if dc_dtype is None:
         dc_dtype = torch.bfloat16 if (yh is not None and yh.dtype == torch.bfloat16) else torch.float32
     dc = torch.empty(dyh.shape, device=dev, dtype=dc_dtype) if want_dc else None
-    dmul = torch.empty(c, device=dev, dtype=torch.float32) if yh is not None else None
-    dadd = torch.empty(c, device=dev, dtype=torch.float32)
+    if grads_out is not None:
+        dmul, dadd = grads_out
+        for g in (dmul, dadd):
+            _need(g, torch.float32, "scale_bwd grads_out"); _dense(g, "scale_bwd grads_out")
+            if g.numel() != c:
+                raise ValueError(f"scale_bwd: grads_out tensors must hold {c} elements")
+    else:
+        dmul = torch.empty(c, device=dev, dtype=torch.float32) if yh is not None else None
+        dadd = torch.empty(c, device=dev, dtype=torch.float32)
     ws = torch.empty(lib().nfdp_scale_bwd_ws_bytes(npix, c), device=dev, dtype=torch.uint8)
-    _call("nfdp_scale_bwd", _ptr(dyh), _dt(dyh), _ld4(dyh), _ptr(yh), _dt(yh) if yh is not None else F32,
+    _call("nfdp_scale_bwd_ex", _ptr(dyh), _dt(dyh), _ld4(dyh), _ptr(yh), _dt(yh) if yh is not None else F32,
           _ld4(yh) if yh is not None else c, _ptr(mul), float(f), int(relu), npix, c, _ptr(dc), _dt(dc) if dc is not None else F32, c,
-          _ptr(dmul), _ptr(dadd), _ptr(ws), _stream())
+          _ptr(dmul), _ptr(dadd), _ptr(ws), int(grads_out is not None), _stream())
     return dc, dmul, dadd
 
 
@@ -972,19 +995,28 @@ def pointwise_dgrad_masked_supported(npix: int, cin: int, cout: int) -> bool:
     return bool(lib().nfdp_pointwise_dgrad_masked_supported(npix, cin, cout))
 
 
-def pointwise_dgrad_masked(xh: torch.Tensor, packed: torch.Tensor, y_saved: torch.Tensor, mul: torch.Tensor, f: float):
+def pointwise_dgrad_masked(xh: torch.Tensor, packed: torch.Tensor, y_saved: torch.Tensor, mul: torch.Tensor, f: float, grads_out=None):
     """Data gradient of a 1x1 conv (xh [B,H,W,Cin] bf16 times the packed data-gradient weight) fused with the scale/ReLU backward of
-    the layer whose saved output is y_saved [B,H,W,Cout] bf16: -> (dc bf16 [B,H,W,Cout], dmul [Cout], dadd [Cout])."""
+    the layer whose saved output is y_saved [B,H,W,Cout] bf16: -> (dc bf16 [B,H,W,Cout], dmul [Cout], dadd [Cout]).
+    grads_out = (dmul_acc, dadd_acc): the sums are added to these dense fp32 tensors (the parameters' .grad) instead."""
     _need(xh, torch.bfloat16, "pointwise_dgrad_masked"); _need(y_saved, torch.bfloat16, "pointwise_dgrad_masked")
     b, h, w, cin = xh.shape
     cout = y_saved.shape[-1]
     dc = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.bfloat16)
-    dmul = torch.empty(cout, device=xh.device, dtype=torch.float32)
-    dadd = torch.empty(cout, device=xh.device, dtype=torch.float32)
+    if grads_out is not None:
+        dmul, dadd = grads_out
+        for g in (dmul, dadd):
+            _need(g, torch.float32, "pointwise_dgrad_masked grads_out"); _dense(g, "pointwise_dgrad_masked grads_out")
+            if g.numel() != cout:
+                raise ValueError(f"pointwise_dgrad_masked: grads_out tensors must hold {cout} elements")
+    else:
+        dmul = torch.empty(cout, device=xh.device, dtype=torch.float32)
+        dadd = torch.empty(cout, device=xh.device, dtype=torch.float32)
     ws = torch.empty(lib().nfdp_pointwise_dgrad_masked_ws_bytes(b * h * w, cout), device=xh.device, dtype=torch.uint8)
-    _call("nfdp_pointwise_dgrad_masked_bf16", _ptr(xh), _ld(xh, "pointwise_dgrad_masked"), _ptr(packed), _ptr(y_saved),
+    _call("nfdp_pointwise_dgrad_masked_bf16_ex", _ptr(xh), _ld(xh, "pointwise_dgrad_masked"), _ptr(packed), _ptr(y_saved),
           _ld(y_saved, "pointwise_dgrad_masked"), _ptr(mul), float(f), b * h * w, cin, cout, _ptr(dc), cout, _ptr(dmul), _ptr(dadd),
-          _ptr(ws), _stream(), label=f"pw_gemm_bf16<masked> k1 {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * cout)
+          _ptr(ws), int(grads_out is not None), _stream(), label=f"pw_gemm_bf16<masked> k1 {cin}->{cout} hw{h}",
+          flops=2.0 * b * h * w * cin * cout)
     return dc, dmul, dadd
 
 

@@ -24,6 +24,32 @@ def grad_needed(module: torch.nn.Module) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
 
+# Parameter gradients straight into .grad: where a parameter already holds a dense fp32 .grad (FusedAdam's views into its flat gradient
+# buffer, or grads kept by zero_grad(set_to_none=False)) the launch that finishes a parameter gradient ADDS it there and the node returns
+# None for it, instead of handing autograd a temporary that AccumulateGrad adds with one more elementwise launch per parameter (~640 per
+# step of Glow L3 K16, plus the flip / permute copies that brought the GEMM results into OIHW order).  Not taken for a parameter with
+# tensor hooks or post-accumulate-grad hooks (a gradient reducer must see the accumulation), nor when .grad is None - so
+# torch.autograd.grad() on parameters that hold a .grad needs DIRECT_PARAM_GRADS = False.
+DIRECT_PARAM_GRADS = True
+
+
+def _slot(p):
+    if not DIRECT_PARAM_GRADS or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
+        return None
+    g = p.grad
+    if g is None or g.dtype != torch.float32 or g.shape != p.shape or not g.is_contiguous() or not g.is_cuda:
+        return None
+    if p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+        return None
+    return g
+
+
+def _slots(*params):
+    """The .grad tensors of all params, or None unless every one of them can be accumulated into directly."""
+    gs = [_slot(p) for p in params]
+    return None if any(g is None for g in gs) else gs
+
+
 # ----------------------------------------------------------------------------- Functions
 class ActNormFn(Function):
     """y = exp(scale) * (x + bias)   (reference transforms.py:80)."""
@@ -32,11 +58,16 @@ class ActNormFn(Function):
     def forward(ctx, xh, scale, bias):
         y = K.actnorm_fwd(xh.contiguous(), scale.detach().reshape(-1), bias.detach().reshape(-1))
         ctx.save_for_backward(y, scale)
+        ctx.params = (scale, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         y, scale = ctx.saved_tensors
+        gs = _slots(*ctx.params)
+        if gs is not None:
+            dx, _, _ = K.scale_bwd(dy.contiguous(), y, scale.detach().reshape(-1), 1.0, False, grads_out=(gs[0].view(-1), gs[1].view(-1)))
+            return dx, None, None
         dx, dscale, dbias = K.scale_bwd(dy.contiguous(), y, scale.detach().reshape(-1), 1.0, False)
         return dx, dscale.view_as(scale), dbias.view_as(scale)
 
@@ -50,6 +81,7 @@ class InvConvFn(Function):
         xh = xh.contiguous()
         y = K.invconv_apply(xh, weight.detach().reshape(c, c).contiguous())
         ctx.save_for_backward(xh, weight)
+        ctx.params = (weight,)
         return y
 
     @staticmethod
@@ -58,6 +90,10 @@ class InvConvFn(Function):
         c = weight.shape[0]
         dy = dy.contiguous()
         dx = K.invconv_apply(dy, weight.detach().reshape(c, c).t().contiguous())   # W^T dy (transpose: weight-sized glue)
+        gs = _slots(*ctx.params)
+        if gs is not None and weight.dim() == 4:
+            K.conv_wgrad(xh, dy, 1, out=gs[0], accumulate=True)
+            return dx, None
         dw = K.conv_wgrad(xh, dy, 1)
         return dx, dw.view_as(weight)
 
@@ -193,15 +229,22 @@ class LevelLogdetFn(Function):
         ctx.save_for_backward(winvs)
         ctx.hw, ctx.n = float(hw), n
         ctx.wshape, ctx.sshape = ws[0].shape, scales[0].shape
+        ctx.params = params
         return ((lads.sum(dtype=torch.float64) + ssum) * float(hw)).reshape(1)
 
     @staticmethod
     def backward(ctx, g):
         (winvs,) = ctx.saved_tensors
+        n = ctx.n
         gh = (g.reshape(()) * ctx.hw).to(torch.float32)
         dw = (gh * winvs.transpose(1, 2)).contiguous()
-        ds = gh.expand(ctx.sshape)
-        return (None, None) + tuple(dw[i].view(ctx.wshape) for i in range(ctx.n)) + (ds,) * ctx.n
+        dws = [dw[i].view(ctx.wshape) for i in range(n)]
+        gs = _slots(*ctx.params)
+        if gs is not None:                                         # two multi-tensor launches instead of 2n accumulations
+            torch._foreach_add_(gs[:n], dws)
+            torch._foreach_add_(gs[n:], [gh.expand(ctx.sshape).contiguous()] * n)
+            return (None,) * (2 + 2 * n)
+        return (None, None) + tuple(dws) + (gh.expand(ctx.sshape),) * n
 
 
 class GaussLogpFn(Function):
@@ -274,6 +317,7 @@ class CouplingNetFn(Function):
         h = K.conv3x3_narrow(y2, None, add=b3.detach().reshape(-1), mul=l3.detach().reshape(-1), mul_exp=float(f3), relu=False,
                              compute=c, packed_taps=p3t, co=w3.shape[0])
         ctx.save_for_backward(xcol, y1, y2, h, w1, s1, w2, s2, w3, l3)
+        ctx.params = (w1, b1, s1, w2, b2, s2, w3, b3, l3)
         ctx.f3 = float(f3)
         ctx.shapes = (b1.shape, s1.shape, b2.shape, s2.shape, b3.shape, l3.shape)
         return h
@@ -283,23 +327,36 @@ class CouplingNetFn(Function):
         xcol, y1, y2, h, w1, s1, w2, s2, w3, l3 = ctx.saved_tensors
         c = K.BF16
         co, hid = w3.shape[0], w3.shape[1]
+        gs = _slots(*ctx.params)                                   # parameter gradients added straight into .grad (see DIRECT_PARAM_GRADS)
+        if gs is not None:
+            gw1, gb1, gs1, gw2, gb2, gs2, gw3, gb3, gl3 = gs
+            flat = lambda a, b: (a.view(-1), b.view(-1))
+        direct = gs is not None
+        o1, i1 = w1.shape[:2]
         # zero conv: h = (u3 + b3) e^{3 l3}
-        dc3, dl3, db3 = K.scale_bwd(dh.contiguous(), h, l3.detach().reshape(-1), ctx.f3, False)
+        dc3, dl3, db3 = K.scale_bwd(dh.contiguous(), h, l3.detach().reshape(-1), ctx.f3, False, grads_out=flat(gl3, gb3) if direct else None)
         dc3_col = K.im2col3x3(dc3)
-        g = K.conv_wgrad(dc3_col, y2, 1, compute=c)[:, :9 * co, 0, 0]                   # dW3 from the same im2col matrix
-        dw3 = g.reshape(hid, 3, 3, co).flip(1, 2).permute(3, 0, 1, 2).contiguous()
+        if direct:                                                  # dW3 from the same im2col matrix, stored mirrored into OIHW by the reduce
+            K.conv_wgrad(dc3_col, y2, 1, compute=c, out=gw3, accumulate=True, form=2, form_c=co)
+        else:
+            g = K.conv_wgrad(dc3_col, y2, 1, compute=c)[:, :9 * co, 0, 0]
+            dw3 = g.reshape(hid, 3, 3, co).flip(1, 2).permute(3, 0, 1, 2).contiguous()
         # hidden layer 2: its output gradient is the C -> 512 conv of dc3; its scale/ReLU backward rides in that GEMM's epilogue
         dc2, ds2, db2 = K.pointwise_dgrad_masked(dc3_col, K.conv_pack_ex(w3.detach().contiguous(), c, flip=True), y2,
-                                                 s2.detach().reshape(-1), 1.0)
-        dw2 = K.conv_wgrad(y1, dc2, 1, compute=c)
+                                                 s2.detach().reshape(-1), 1.0, grads_out=flat(gs2, gb2) if direct else None)
+        dw2 = K.conv_wgrad(y1, dc2, 1, compute=c, out=gw2 if direct else None, accumulate=direct)
         # hidden layer 1: output gradient = dc2 W2 (1x1), same fusion
         dc1, ds1, db1 = K.pointwise_dgrad_masked(dc2, K.conv_pack_ex(w2.detach().contiguous(), c, flip=True), y1,
-                                                 s1.detach().reshape(-1), 1.0)
-        o1, i1 = w1.shape[:2]
-        dw1 = K.conv_wgrad(xcol, dc1, 1, compute=c)[:, :9 * i1, 0, 0].reshape(o1, 3, 3, i1).permute(0, 3, 1, 2).contiguous()
+                                                 s1.detach().reshape(-1), 1.0, grads_out=flat(gs1, gb1) if direct else None)
+        if direct:
+            K.conv_wgrad(xcol, dc1, 1, compute=c, out=gw1, accumulate=True, form=1, form_c=i1)
+        else:
+            dw1 = K.conv_wgrad(xcol, dc1, 1, compute=c)[:, :9 * i1, 0, 0].reshape(o1, 3, 3, i1).permute(0, 3, 1, 2).contiguous()
         dxa = None
         if ctx.needs_input_grad[0]:                                 # 512 -> C/2 data gradient: tap GEMM + shift-sum
             dxa = K.conv3x3_narrow(dc1, None, compute=c, co=i1, packed_taps=K.conv_pack_ex(w1.detach().contiguous(), c, flip=True, taps=True))
+        if direct:
+            return (dxa,) + (None,) * 11
         sb1, ss1, sb2, ss2, sb3, sl3 = ctx.shapes
         return (dxa, dw1, db1.reshape(sb1), ds1.reshape(ss1), dw2, db2.reshape(sb2), ds2.reshape(ss2), dw3, db3.reshape(sb3),
                 dl3.reshape(sl3), None, None)

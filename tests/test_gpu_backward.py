@@ -546,3 +546,54 @@ def test_pointwise_dgrad_with_fused_scale_relu_backward(shape, cin):
     assert_close(dc.float(), dc_ref, 4e-3, "dc")
     assert_close(dmul, dmul_ref, 2e-5, "dmul")
     assert_close(dadd, dadd_ref, 2e-5, "dadd")
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+def test_parameter_gradients_added_straight_into_grad(compute):
+    """training.DIRECT_PARAM_GRADS: with a dense .grad in place (FusedAdam's flat-buffer views) the finishing launches of the backward
+    kernels add the parameter gradients there and the nodes return None - same numbers, bit for bit, as the gradients autograd
+    accumulates from returned tensors (incl. the im2col-form weight gradients stored into OIHW by the reduce), a second backward
+    doubles them, and a parameter with a post-accumulate hook (a gradient reducer) keeps the autograd route."""
+    from normalizing_flow import calculate_loss, initialize_with_zeros, training
+    from tests.golden.synth import DEEP
+    B = 8
+    flow, prior, _, _ = build(3, 3, 2, 41)
+    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 41, DEEP)) for k, v in flow.state_dict().items()})
+    prior.load_state_dict({k: T(synth_tensor(k, v.shape, 42, DEEP)) for k, v in prior.state_dict().items()})
+    flow.set_compute(compute)
+    x = (T(synth_input("train_x", (B, 3, 32, 32), 6)) * 0.4).to(DEV)
+    params = list(flow.parameters()) + list(prior.parameters())
+
+    def backward():
+        ll, logp = initialize_with_zeros(2, B, torch.device(DEV))
+        latents, ll, logp = flow.transform(x, ll, logp)
+        loss = calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0)
+        loss.backward()
+        return loss.detach()
+
+    backward()                                                        # data-dependent init out of the way; .grad = None so far
+    def run(direct, times=1):
+        training.DIRECT_PARAM_GRADS = direct
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        K.start_trace()
+        for _ in range(times):
+            backward()
+        n_launch = len(K.stop_trace())
+        return [p.grad.clone() for p in params], n_launch
+    try:
+        ref, _ = run(False)
+        got, _ = run(True)
+        for (name, _), a, b in zip(list(flow.named_parameters()) + list(prior.named_parameters()), got, ref):
+            assert torch.equal(a, b), (name, float((a - b).abs().max()))
+        twice, _ = run(True, times=2)
+        for a, b in zip(twice, ref):
+            assert_close(a, 2 * b, 1e-6, "two backward passes accumulate")
+        seen = []
+        w = flow.blocks[0].flows[0].affcoupling.net[2].conv.weight
+        h = w.register_post_accumulate_grad_hook(lambda p: seen.append(p.grad.clone()))
+        hooked, _ = run(True)
+        h.remove()
+        assert len(seen) == 1 and all(torch.equal(a, b) for a, b in zip(hooked, ref))
+    finally:
+        training.DIRECT_PARAM_GRADS = True
