@@ -73,29 +73,32 @@ class ActNormFn(Function):
 
 
 class InvConvFn(Function):
-    """y = conv2d(x, W) with W [C,C,1,1]   (reference transforms.py:132)."""
+    """y = conv2d(x, W) with W [C,C,1,1]   (reference transforms.py:132).  wt: W^T [C,C] for the data gradient, from the level's
+    one batched transpose (else transposed here)."""
 
     @staticmethod
-    def forward(ctx, xh, weight):
+    def forward(ctx, xh, weight, wt=None):
         c = weight.shape[0]
         xh = xh.contiguous()
         y = K.invconv_apply(xh, weight.detach().reshape(c, c).contiguous())
-        ctx.save_for_backward(xh, weight)
+        ctx.save_for_backward(xh, weight, wt)
         ctx.params = (weight,)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xh, weight = ctx.saved_tensors
+        xh, weight, wt = ctx.saved_tensors
         c = weight.shape[0]
         dy = dy.contiguous()
-        dx = K.invconv_apply(dy, weight.detach().reshape(c, c).t().contiguous())   # W^T dy (transpose: weight-sized glue)
+        if wt is None:
+            wt = weight.detach().reshape(c, c).t().contiguous()
+        dx = K.invconv_apply(dy, wt)                                # W^T dy
         gs = _slots(*ctx.params)
         if gs is not None and weight.dim() == 4:
             K.conv_wgrad(xh, dy, 1, out=gs[0], accumulate=True)
-            return dx, None
+            return dx, None, None
         dw = K.conv_wgrad(xh, dy, 1)
-        return dx, dw.view_as(weight)
+        return dx, dw.view_as(weight), None
 
 
 class LogAbsDetFn(Function):
@@ -184,22 +187,38 @@ class ConvScaleFn(Function):
         return dx, dw, dadd.reshape(ctx.add_shape), dmul.view_as(mul), None, None, None, None, None
 
 
+def _coupling_forward(ctx, xh, hh, ldj, own_ldj):
+    """Shared by CouplingFn / CouplingStepFn: y = coupling(x, h) out of place, log-det into the fp64 accumulator (ldj itself when
+    the caller owns it - a fresh fp64 tensor of this graph, marked dirty - else a copy)."""
+    y = xh.clone()
+    if ldj is None:
+        acc = torch.zeros(xh.shape[0], device=xh.device, dtype=torch.float64)
+    elif own_ldj and ldj.dtype == torch.float64 and ldj.is_contiguous():
+        acc = ldj
+        ctx.mark_dirty(ldj)
+    else:
+        acc = ldj.to(torch.float64, copy=True)
+    K.coupling_fwd(y, hh, acc, None)
+    ctx.ldj_dtype = None if ldj is None else ldj.dtype
+    return y, acc
+
+
+def _ldj_grad(ctx, dacc):
+    if ctx.ldj_dtype is None or dacc is None:
+        return None
+    return dacc if dacc.dtype == ctx.ldj_dtype else dacc.to(ctx.ldj_dtype)
+
+
 class CouplingFn(Function):
     """(x_a | x_b), (log_s | t), ldj -> (x_a | (x_b + t) * sigmoid(log_s + 2)), ldj + per-sample sum log(s + 1e-6)
-    (reference transforms.py:179-185).  The running log-det goes through the node (the kernel adds into its fp64 copy), so the
-    chain of flows costs no separate add launch; ldj=None returns the per-sample increment alone."""
+    (reference transforms.py:179-185).  The running log-det goes through the node (the kernel adds into it), so the chain of flows
+    costs no separate add launch; ldj=None returns the per-sample increment alone."""
 
     @staticmethod
-    def forward(ctx, xh, hh, ldj):
+    def forward(ctx, xh, hh, ldj, own_ldj=False):
         xh, hh = xh.contiguous(), hh.contiguous()
-        y = xh.clone()
-        if ldj is None:
-            acc = torch.zeros(xh.shape[0], device=xh.device, dtype=torch.float64)
-        else:
-            acc = ldj.to(torch.float64, copy=True)
-        K.coupling_fwd(y, hh, acc, None)
+        y, acc = _coupling_forward(ctx, xh, hh, ldj, own_ldj)
         ctx.save_for_backward(xh, hh)
-        ctx.ldj_dtype = None if ldj is None else ldj.dtype
         return y, acc
 
     @staticmethod
@@ -208,10 +227,7 @@ class CouplingFn(Function):
         if dy is None:
             dy = torch.zeros_like(xh)
         dx, dh = K.coupling_bwd(xh, hh, dy.contiguous(), None if dacc is None else dacc.contiguous())
-        dldj = None
-        if ctx.ldj_dtype is not None and dacc is not None:
-            dldj = dacc if dacc.dtype == ctx.ldj_dtype else dacc.to(ctx.ldj_dtype)
-        return dx, dh, dldj
+        return dx, dh, _ldj_grad(ctx, dacc), None
 
 
 class LevelLogdetFn(Function):
@@ -298,68 +314,88 @@ def _zero_conv(mod, xh: Tensor, c: int) -> Tensor:
                              mod._cache.get(mod.weight, c), mod.filter_size, c)
 
 
-class CouplingNetFn(Function):
-    """The whole coupling network (utils.py:72-90) as ONE autograd node for the bf16 training mode: the same forward launches as
-    three ConvScaleFn nodes (im2col + pointwise GEMM, pointwise GEMM, tap GEMM + shift-sum; hidden activations saved in bf16),
-    and a backward in which the scale/ReLU backward of the two hidden layers runs in the EPILOGUE of the GEMM that produces their
-    output gradient (nfdp_pointwise_dgrad_masked_bf16): dy1 and dy2 never go to memory and y1, y2 are read once there - separately
-    that pass moved 0.4 GB per hidden layer and flow at level 0 (96 launches, 3.8 ms per step)."""
+def _net_forward(xa, w1, b1, s1, w2, b2, s2, w3, b3, l3, f3, packs):
+    """The coupling network (utils.py:72-90) in bf16 training mode: im2col + pointwise GEMM, pointwise GEMM, tap GEMM + shift-sum; the
+    hidden activations stay in bf16.  -> h and what the backward needs."""
+    c = K.BF16
+    p1, p2, p3t = packs                                        # packed w1 (3x3 = im2col form), w2 (1x1), tap form of w3
+    xcol = K.im2col3x3(xa)
+    y1 = K.conv2d(xcol, p1, w1.shape[0], 1, add=b1.detach().reshape(-1), mul=s1.detach().reshape(-1), mul_exp=1.0, relu=True,
+                  compute=c, out_dtype=K.BF16)
+    y2 = K.conv2d(y1, p2, w2.shape[0], 1, add=b2.detach().reshape(-1), mul=s2.detach().reshape(-1), mul_exp=1.0, relu=True,
+                  compute=c, out_dtype=K.BF16)
+    h = K.conv3x3_narrow(y2, None, add=b3.detach().reshape(-1), mul=l3.detach().reshape(-1), mul_exp=float(f3), relu=False,
+                         compute=c, packed_taps=p3t, co=w3.shape[0])
+    return h, (xcol, y1, y2)
+
+
+def _net_backward(dh, h, xcol, y1, y2, params, f3, need_dxa):
+    """-> (dxa or None, the nine parameter gradients in `params` order or None when they went straight into .grad).  The scale/ReLU
+    backward of the two hidden layers runs in the EPILOGUE of the GEMM that produces their output gradient
+    (nfdp_pointwise_dgrad_masked_bf16): dy1 and dy2 never go to memory and y1, y2 are read once there - separately that pass moved
+    0.4 GB per hidden layer and flow at level 0 (96 launches, 3.8 ms per step)."""
+    w1, b1, s1, w2, b2, s2, w3, b3, l3 = params
+    c = K.BF16
+    co, hid = w3.shape[0], w3.shape[1]
+    o1, i1 = w1.shape[:2]
+    gs = _slots(*params)                                       # parameter gradients added straight into .grad (see DIRECT_PARAM_GRADS)
+    direct = gs is not None
+    if direct:
+        gw1, gb1, gs1, gw2, gb2, gs2, gw3, gb3, gl3 = gs
+    flat = lambda a, b: (a.view(-1), b.view(-1))
+    # zero conv: h = (u3 + b3) e^{3 l3}
+    dc3, dl3, db3 = K.scale_bwd(dh.contiguous(), h, l3.detach().reshape(-1), f3, False, grads_out=flat(gl3, gb3) if direct else None)
+    dc3_col = K.im2col3x3(dc3)
+    if direct:                                                  # dW3 from the same im2col matrix, stored mirrored into OIHW by the reduce
+        K.conv_wgrad(dc3_col, y2, 1, compute=c, out=gw3, accumulate=True, form=2, form_c=co)
+    else:
+        g = K.conv_wgrad(dc3_col, y2, 1, compute=c)[:, :9 * co, 0, 0]
+        dw3 = g.reshape(hid, 3, 3, co).flip(1, 2).permute(3, 0, 1, 2).contiguous()
+    # hidden layer 2: its output gradient is the C -> 512 conv of dc3; its scale/ReLU backward rides in that GEMM's epilogue
+    dc2, ds2, db2 = K.pointwise_dgrad_masked(dc3_col, K.conv_pack_ex(w3.detach().contiguous(), c, flip=True), y2,
+                                             s2.detach().reshape(-1), 1.0, grads_out=flat(gs2, gb2) if direct else None)
+    dw2 = K.conv_wgrad(y1, dc2, 1, compute=c, out=gw2 if direct else None, accumulate=direct)
+    # hidden layer 1: output gradient = dc2 W2 (1x1), same fusion
+    dc1, ds1, db1 = K.pointwise_dgrad_masked(dc2, K.conv_pack_ex(w2.detach().contiguous(), c, flip=True), y1,
+                                             s1.detach().reshape(-1), 1.0, grads_out=flat(gs1, gb1) if direct else None)
+    if direct:
+        K.conv_wgrad(xcol, dc1, 1, compute=c, out=gw1, accumulate=True, form=1, form_c=i1)
+    else:
+        dw1 = K.conv_wgrad(xcol, dc1, 1, compute=c)[:, :9 * i1, 0, 0].reshape(o1, 3, 3, i1).permute(0, 3, 1, 2).contiguous()
+    dxa = None
+    if need_dxa:                                                # 512 -> C/2 data gradient: tap GEMM + shift-sum
+        dxa = K.conv3x3_narrow(dc1, None, compute=c, co=i1, packed_taps=K.conv_pack_ex(w1.detach().contiguous(), c, flip=True, taps=True))
+    if direct:
+        return dxa, None
+    return dxa, (dw1, db1.view_as(b1), ds1.view_as(s1), dw2, db2.view_as(b2), ds2.view_as(s2), dw3, db3.view_as(b3), dl3.view_as(l3))
+
+
+class CouplingStepFn(Function):
+    """The affine coupling of a flow step as ONE autograd node for the bf16 training mode (reference transforms.py:170-186 with the
+    network of utils.py:72-90): h = NN(x_a), (x_a | (x_b + t) s), ldj + sum log s.  One node instead of network + slice + coupling
+    nodes: the data gradient of the network is added into the first half of the coupling's dx in place, where autograd's slice backward
+    costs a zero fill, a copy and an add of full-size tensors per flow."""
 
     @staticmethod
-    def forward(ctx, xa, w1, b1, s1, w2, b2, s2, w3, b3, l3, f3, packs):
-        c = K.BF16
-        p1, p2, p3t = packs                                        # packed w1 (3x3 = im2col form), w2 (1x1), tap form of w3
-        xcol = K.im2col3x3(xa)
-        y1 = K.conv2d(xcol, p1, w1.shape[0], 1, add=b1.detach().reshape(-1), mul=s1.detach().reshape(-1), mul_exp=1.0, relu=True,
-                      compute=c, out_dtype=K.BF16)
-        y2 = K.conv2d(y1, p2, w2.shape[0], 1, add=b2.detach().reshape(-1), mul=s2.detach().reshape(-1), mul_exp=1.0, relu=True,
-                      compute=c, out_dtype=K.BF16)
-        h = K.conv3x3_narrow(y2, None, add=b3.detach().reshape(-1), mul=l3.detach().reshape(-1), mul_exp=float(f3), relu=False,
-                             compute=c, packed_taps=p3t, co=w3.shape[0])
-        ctx.save_for_backward(xcol, y1, y2, h, w1, s1, w2, s2, w3, l3)
-        ctx.params = (w1, b1, s1, w2, b2, s2, w3, b3, l3)
-        ctx.f3 = float(f3)
-        ctx.shapes = (b1.shape, s1.shape, b2.shape, s2.shape, b3.shape, l3.shape)
-        return h
+    def forward(ctx, xh, ldj, own_ldj, f3, packs, *params):
+        xh = xh.contiguous()
+        c = xh.shape[-1]
+        h, (xcol, y1, y2) = _net_forward(xh[..., : c // 2], *params, f3, packs)
+        y, acc = _coupling_forward(ctx, xh, h, ldj, own_ldj)
+        ctx.save_for_backward(xh, h, xcol, y1, y2)
+        ctx.params, ctx.f3 = params, float(f3)
+        return y, acc
 
     @staticmethod
-    def backward(ctx, dh):
-        xcol, y1, y2, h, w1, s1, w2, s2, w3, l3 = ctx.saved_tensors
-        c = K.BF16
-        co, hid = w3.shape[0], w3.shape[1]
-        gs = _slots(*ctx.params)                                   # parameter gradients added straight into .grad (see DIRECT_PARAM_GRADS)
-        if gs is not None:
-            gw1, gb1, gs1, gw2, gb2, gs2, gw3, gb3, gl3 = gs
-            flat = lambda a, b: (a.view(-1), b.view(-1))
-        direct = gs is not None
-        o1, i1 = w1.shape[:2]
-        # zero conv: h = (u3 + b3) e^{3 l3}
-        dc3, dl3, db3 = K.scale_bwd(dh.contiguous(), h, l3.detach().reshape(-1), ctx.f3, False, grads_out=flat(gl3, gb3) if direct else None)
-        dc3_col = K.im2col3x3(dc3)
-        if direct:                                                  # dW3 from the same im2col matrix, stored mirrored into OIHW by the reduce
-            K.conv_wgrad(dc3_col, y2, 1, compute=c, out=gw3, accumulate=True, form=2, form_c=co)
-        else:
-            g = K.conv_wgrad(dc3_col, y2, 1, compute=c)[:, :9 * co, 0, 0]
-            dw3 = g.reshape(hid, 3, 3, co).flip(1, 2).permute(3, 0, 1, 2).contiguous()
-        # hidden layer 2: its output gradient is the C -> 512 conv of dc3; its scale/ReLU backward rides in that GEMM's epilogue
-        dc2, ds2, db2 = K.pointwise_dgrad_masked(dc3_col, K.conv_pack_ex(w3.detach().contiguous(), c, flip=True), y2,
-                                                 s2.detach().reshape(-1), 1.0, grads_out=flat(gs2, gb2) if direct else None)
-        dw2 = K.conv_wgrad(y1, dc2, 1, compute=c, out=gw2 if direct else None, accumulate=direct)
-        # hidden layer 1: output gradient = dc2 W2 (1x1), same fusion
-        dc1, ds1, db1 = K.pointwise_dgrad_masked(dc2, K.conv_pack_ex(w2.detach().contiguous(), c, flip=True), y1,
-                                                 s1.detach().reshape(-1), 1.0, grads_out=flat(gs1, gb1) if direct else None)
-        if direct:
-            K.conv_wgrad(xcol, dc1, 1, compute=c, out=gw1, accumulate=True, form=1, form_c=i1)
-        else:
-            dw1 = K.conv_wgrad(xcol, dc1, 1, compute=c)[:, :9 * i1, 0, 0].reshape(o1, 3, 3, i1).permute(0, 3, 1, 2).contiguous()
-        dxa = None
-        if ctx.needs_input_grad[0]:                                 # 512 -> C/2 data gradient: tap GEMM + shift-sum
-            dxa = K.conv3x3_narrow(dc1, None, compute=c, co=i1, packed_taps=K.conv_pack_ex(w1.detach().contiguous(), c, flip=True, taps=True))
-        if direct:
-            return (dxa,) + (None,) * 11
-        sb1, ss1, sb2, ss2, sb3, sl3 = ctx.shapes
-        return (dxa, dw1, db1.reshape(sb1), ds1.reshape(ss1), dw2, db2.reshape(sb2), ds2.reshape(ss2), dw3, db3.reshape(sb3),
-                dl3.reshape(sl3), None, None)
+    def backward(ctx, dy, dacc):
+        xh, h, xcol, y1, y2 = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(xh)
+        dx, dh = K.coupling_bwd(xh, h, dy.contiguous(), None if dacc is None else dacc.contiguous())
+        dxa, grads = _net_backward(dh, h, xcol, y1, y2, ctx.params, ctx.f3, ctx.needs_input_grad[0])
+        if dxa is not None:
+            dx[..., : dxa.shape[-1]] += dxa
+        return (dx, _ldj_grad(ctx, dacc), None, None, None) + (grads if grads is not None else (None,) * 9)
 
 
 def _fused_net_ok(net, xa: Tensor, c: int) -> bool:
@@ -376,46 +412,55 @@ def _fused_net_ok(net, xa: Tensor, c: int) -> bool:
 
 
 def coupling_net(net, xa: Tensor, compute: Optional[str] = None) -> Tensor:
+    """The coupling network as three conv nodes (any mode, any size)."""
     c = K.compute_enum(compute)
-    if _fused_net_ok(net, xa, c):
-        c1, c2, zc = net[0], net[2], net[4]
-        packs = (c1.conv.packed(c), c2.conv.packed(c), zc._cache.get_taps(zc.weight, c))
-        return CouplingNetFn.apply(xa, c1.conv.weight, c1.actnorm.bias, c1.actnorm.scale, c2.conv.weight, c2.actnorm.bias,
-                                   c2.actnorm.scale, zc.weight, zc.bias, zc.logs, zc.logscale_factor, packs)
     return _zero_conv(net[4], _conv_actnorm_relu(net[2], _conv_actnorm_relu(net[0], xa, c), c), c)
 
 
-def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None) -> Tuple[Tensor, Optional[Tensor]]:
+def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None, wt: Optional[Tensor] = None, own_ldj: bool = False):
     """actnorm -> invconv -> affine coupling (reference glow.py:44-49), differentiable.  pre="level": the weight-only log-det terms of
-    this flow (actnorm scale sum, log|det W|) are added once per level by the caller (LevelLogdetFn)."""
+    this flow (actnorm scale sum, log|det W|) are added once per level by the caller (LevelLogdetFn); wt: W^T of the 1x1 conv;
+    own_ldj: ldj is a tensor of this graph the coupling node may add into in place."""
     an, ic, cp = flow.actnorm, flow.invconv2d, flow.affcoupling
     hw = xh.shape[1] * xh.shape[2]
     if not an.initialized():
         with torch.no_grad():
             an.init_from(xh.detach().contiguous())
     y = ActNormFn.apply(xh, an.scale, an.bias)
-    y = InvConvFn.apply(y, ic.weight)
+    y = InvConvFn.apply(y, ic.weight, wt)
     c = y.shape[-1]
-    h = coupling_net(cp.net, y[..., : c // 2], cp.compute)
-    if ldj is None:
-        y, _ = CouplingFn.apply(y, h, None)
-    elif isinstance(pre, str):
-        y, ldj = CouplingFn.apply(y, h, ldj)
+    level = isinstance(pre, str)
+    net = cp.net
+    if _fused_net_ok(net, y[..., : c // 2], K.compute_enum(cp.compute)):
+        c1, c2, zc = net[0], net[2], net[4]
+        cc = K.BF16
+        packs = (c1.conv.packed(cc), c2.conv.packed(cc), zc._cache.get_taps(zc.weight, cc))
+        y, inc = CouplingStepFn.apply(y, ldj if level else None, own_ldj and level, zc.logscale_factor, packs, c1.conv.weight,
+                                      c1.actnorm.bias, c1.actnorm.scale, c2.conv.weight, c2.actnorm.bias, c2.actnorm.scale, zc.weight,
+                                      zc.bias, zc.logs)
     else:
-        y, inc = CouplingFn.apply(y, h, None)
-        ldj = ldj + hw * an.scale.sum() + hw * LogAbsDetFn.apply(ic.weight, pre) + inc
-    return y, ldj
+        h = coupling_net(net, y[..., : c // 2], cp.compute)
+        y, inc = CouplingFn.apply(y, h, ldj if level else None, own_ldj and level)
+    if ldj is None:
+        return y, None
+    if level:
+        return y, inc
+    return y, ldj + hw * an.scale.sum() + hw * LogAbsDetFn.apply(ic.weight, pre) + inc
 
 
 def _level_flows(flows, yh: Tensor, ldj: Optional[Tensor]):
-    """All flows of a level; with a log-det accumulator the weight-only terms are one LevelLogdetFn node for the level."""
+    """All flows of a level; with a log-det accumulator the weight-only terms are one LevelLogdetFn node for the level, the transposed
+    1x1 weights (data gradient) come from one batched transpose, and the per-sample terms are added into one fp64 tensor in place."""
+    c = yh.shape[-1]
+    wts = torch.stack([f.invconv2d.weight.detach().reshape(c, c) for f in flows]).transpose(1, 2).contiguous()
     if ldj is None:
-        for flow in flows:
-            yh, _ = step_flow(flow, yh, None)
+        for i, flow in enumerate(flows):
+            yh, _ = step_flow(flow, yh, None, wt=wts[i])
         return yh, None
     hw = yh.shape[1] * yh.shape[2]
-    for flow in flows:
-        yh, ldj = step_flow(flow, yh, ldj, "level")      # data-dependent ActNorm init (if any) happens in here, before the scales are read
+    ldj = ldj.to(torch.float64, copy=True)                        # this graph's own accumulator from here on
+    for i, flow in enumerate(flows):
+        yh, ldj = step_flow(flow, yh, ldj, "level", wts[i], True)  # data-dependent ActNorm init (if any) happens in here, before the scales are read
     term = LevelLogdetFn.apply(hw, len(flows), *[f.invconv2d.weight for f in flows], *[f.actnorm.scale for f in flows])
     return yh, ldj + term
 
