@@ -34,6 +34,7 @@ extern "C" {
 
 #define NFDP_F32 0
 #define NFDP_BF16 1
+#define NFDP_PACK_JOB_WORDS 12 /* int64 words of one nfdp_conv_pack_weights_batch job */
 
 typedef void* nfdp_stream_t;
 
@@ -327,6 +328,13 @@ int nfdp_coupling_bwd_f32(const float* x, const float* h, const float* dy, const
  * dh [B,HW,2Cz] dense per element for both h modes (mode 1 callers sum it over pixels with nfdp_scale_bwd_f32). */
 int nfdp_gauss_logp_bwd_f32(const float* z, int z_ld, const float* h, int h_mode, const double* gl, int B, int HW, int Cz,
                             float* dz, float* dh, nfdp_stream_t stream);
+
+/* Batched nfdp_conv_pack_weights_ex: one launch for every derived weight layout of a training step (forward, data-gradient and tap
+ * forms of the coupling networks' convs: ~290 separate launches per step of Glow L3 K16 otherwise).  jobs_dev: n jobs of
+ * NFDP_PACK_JOB_WORDS int64 words each in DEVICE memory, each filled on the host by nfdp_conv_pack_job (same arguments and packed
+ * layout as nfdp_conv_pack_weights_ex; w_packed: nfdp_conv_packed_bytes_ex bytes); max_total: the largest job[10] (element count). */
+int nfdp_conv_pack_job(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, int flip, int taps, long* job);
+int nfdp_conv_pack_weights_batch(const long* jobs_dev, int n, long max_total, int compute, nfdp_stream_t stream);
 
 /* Data gradient of a pointwise conv fused with the scale/ReLU backward of the layer in front of it (the two hidden layers of the
  * coupling network): dy = x W'^T stays in the accumulators; with the saved output y = relu((u + b) e^{f s}) of that layer (bf16) the

@@ -969,6 +969,44 @@ def conv_pack_ex(w_oihw: torch.Tensor, compute: int, flip: bool = False, taps: b
     return packed
 
 
+class PackBatch:
+    """Kernel-layout copies of many conv weights refreshed by ONE launch (nfdp_conv_pack_weights_batch).  specs: [(weight OIHW fp32
+    parameter, flip, taps)]; .views[i] is the packed tensor of specs[i] (same bytes as conv_pack_ex), valid after run().  The views
+    live in one buffer and the job table on the device, so a captured training step replays the launch unchanged; matches() tells
+    whether the parameters still live where the table points."""
+
+    def __init__(self, specs, compute: int):
+        import numpy as np
+        if not specs:
+            raise ValueError("PackBatch: no weights")
+        self.compute = compute
+        dev = specs[0][0].device
+        sizes, offs, total = [], [], 0
+        for w, flip, taps in specs:
+            _need(w, torch.float32, "PackBatch"); _dense(w, "PackBatch")
+            co, ci, kh, kw = w.shape
+            n = lib().nfdp_conv_packed_bytes_ex(co, ci, kh, kw, compute, int(flip), int(taps))
+            sizes.append(n); offs.append(total)
+            total += -(-n // 256) * 256
+        self.buf = torch.empty(total, device=dev, dtype=torch.uint8)
+        self.views = [self.buf[o:o + n] for o, n in zip(offs, sizes)]
+        jobs = np.zeros((len(specs), 12), dtype=np.int64)
+        for i, ((w, flip, taps), v) in enumerate(zip(specs, self.views)):
+            co, ci, kh, kw = w.shape
+            _check(lib().nfdp_conv_pack_job(_ptr(w), _ptr(v), co, ci, kh, kw, int(flip), int(taps), jobs[i].ctypes.data))
+        self.max_total = int(jobs[:, 10].max())
+        self.jobs = torch.from_numpy(jobs).to(dev)
+        self._key = tuple(w.data_ptr() for w, _, _ in specs)
+        self._weights = [w for w, _, _ in specs]
+
+    def matches(self) -> bool:
+        return self._key == tuple(w.data_ptr() for w in self._weights)
+
+    def run(self) -> None:
+        _call("nfdp_conv_pack_weights_batch", _ptr(self.jobs), self.jobs.shape[0], self.max_total, self.compute, _stream(),
+              label=f"pack_weights_batch x{self.jobs.shape[0]}")
+
+
 def pack_taps(w_oihw: torch.Tensor, compute: int) -> torch.Tensor:
     """Packed weight of the pointwise GEMM of conv3x3_narrow: rows [tap*Co + co], columns ci."""
     return conv_pack_ex(w_oihw.detach().contiguous(), compute, taps=True)

@@ -329,7 +329,7 @@ def _net_forward(xa, w1, b1, s1, w2, b2, s2, w3, b3, l3, f3, packs):
     return h, (xcol, y1, y2)
 
 
-def _net_backward(dh, h, xcol, y1, y2, params, f3, need_dxa):
+def _net_backward(dh, h, xcol, y1, y2, params, f3, need_dxa, bpacks=None):
     """-> (dxa or None, the nine parameter gradients in `params` order or None when they went straight into .grad).  The scale/ReLU
     backward of the two hidden layers runs in the EPILOGUE of the GEMM that produces their output gradient
     (nfdp_pointwise_dgrad_masked_bf16): dy1 and dy2 never go to memory and y1, y2 are read once there - separately that pass moved
@@ -338,6 +338,9 @@ def _net_backward(dh, h, xcol, y1, y2, params, f3, need_dxa):
     c = K.BF16
     co, hid = w3.shape[0], w3.shape[1]
     o1, i1 = w1.shape[:2]
+    if bpacks is None:                                         # data-gradient layouts: from the step's batched packing, else packed here
+        bpacks = (K.conv_pack_ex(w3.detach().contiguous(), c, flip=True), K.conv_pack_ex(w2.detach().contiguous(), c, flip=True),
+                  K.conv_pack_ex(w1.detach().contiguous(), c, flip=True, taps=True) if need_dxa else None)
     gs = _slots(*params)                                       # parameter gradients added straight into .grad (see DIRECT_PARAM_GRADS)
     direct = gs is not None
     if direct:
@@ -352,11 +355,11 @@ def _net_backward(dh, h, xcol, y1, y2, params, f3, need_dxa):
         g = K.conv_wgrad(dc3_col, y2, 1, compute=c)[:, :9 * co, 0, 0]
         dw3 = g.reshape(hid, 3, 3, co).flip(1, 2).permute(3, 0, 1, 2).contiguous()
     # hidden layer 2: its output gradient is the C -> 512 conv of dc3; its scale/ReLU backward rides in that GEMM's epilogue
-    dc2, ds2, db2 = K.pointwise_dgrad_masked(dc3_col, K.conv_pack_ex(w3.detach().contiguous(), c, flip=True), y2,
+    dc2, ds2, db2 = K.pointwise_dgrad_masked(dc3_col, bpacks[0], y2,
                                              s2.detach().reshape(-1), 1.0, grads_out=flat(gs2, gb2) if direct else None)
     dw2 = K.conv_wgrad(y1, dc2, 1, compute=c, out=gw2 if direct else None, accumulate=direct)
     # hidden layer 1: output gradient = dc2 W2 (1x1), same fusion
-    dc1, ds1, db1 = K.pointwise_dgrad_masked(dc2, K.conv_pack_ex(w2.detach().contiguous(), c, flip=True), y1,
+    dc1, ds1, db1 = K.pointwise_dgrad_masked(dc2, bpacks[1], y1,
                                              s1.detach().reshape(-1), 1.0, grads_out=flat(gs1, gb1) if direct else None)
     if direct:
         K.conv_wgrad(xcol, dc1, 1, compute=c, out=gw1, accumulate=True, form=1, form_c=i1)
@@ -364,7 +367,7 @@ def _net_backward(dh, h, xcol, y1, y2, params, f3, need_dxa):
         dw1 = K.conv_wgrad(xcol, dc1, 1, compute=c)[:, :9 * i1, 0, 0].reshape(o1, 3, 3, i1).permute(0, 3, 1, 2).contiguous()
     dxa = None
     if need_dxa:                                                # 512 -> C/2 data gradient: tap GEMM + shift-sum
-        dxa = K.conv3x3_narrow(dc1, None, compute=c, co=i1, packed_taps=K.conv_pack_ex(w1.detach().contiguous(), c, flip=True, taps=True))
+        dxa = K.conv3x3_narrow(dc1, None, compute=c, co=i1, packed_taps=bpacks[2])
     if direct:
         return dxa, None
     return dxa, (dw1, db1.view_as(b1), ds1.view_as(s1), dw2, db2.view_as(b2), ds2.view_as(s2), dw3, db3.view_as(b3), dl3.view_as(l3))
@@ -377,13 +380,13 @@ class CouplingStepFn(Function):
     costs a zero fill, a copy and an add of full-size tensors per flow."""
 
     @staticmethod
-    def forward(ctx, xh, ldj, own_ldj, f3, packs, *params):
+    def forward(ctx, xh, ldj, own_ldj, f3, packs, bpacks, *params):
         xh = xh.contiguous()
         c = xh.shape[-1]
         h, (xcol, y1, y2) = _net_forward(xh[..., : c // 2], *params, f3, packs)
         y, acc = _coupling_forward(ctx, xh, h, ldj, own_ldj)
         ctx.save_for_backward(xh, h, xcol, y1, y2)
-        ctx.params, ctx.f3 = params, float(f3)
+        ctx.params, ctx.f3, ctx.bpacks = params, float(f3), bpacks
         return y, acc
 
     @staticmethod
@@ -392,10 +395,18 @@ class CouplingStepFn(Function):
         if dy is None:
             dy = torch.zeros_like(xh)
         dx, dh = K.coupling_bwd(xh, h, dy.contiguous(), None if dacc is None else dacc.contiguous())
-        dxa, grads = _net_backward(dh, h, xcol, y1, y2, ctx.params, ctx.f3, ctx.needs_input_grad[0])
+        dxa, grads = _net_backward(dh, h, xcol, y1, y2, ctx.params, ctx.f3, ctx.needs_input_grad[0], ctx.bpacks)
         if dxa is not None:
             dx[..., : dxa.shape[-1]] += dxa
-        return (dx, _ldj_grad(ctx, dacc), None, None, None) + (grads if grads is not None else (None,) * 9)
+        return (dx, _ldj_grad(ctx, dacc), None, None, None, None) + (grads if grads is not None else (None,) * 9)
+
+
+def _fused_net_shapes_ok(net) -> bool:
+    c1, c2, zc = net[0], net[2], net[4]
+    hid, c = c1.conv.out_channels, K.BF16
+    return (c1.filter_size == 3 and c2.filter_size == 1 and zc.filter_size == 3
+            and K.use_im2col_conv(c1.conv.in_channels, hid, 3, c) and K.use_im2col_conv(zc.out_channels, hid, 3, c)
+            and K.use_narrow_conv(hid, zc.out_channels, 3) and K.use_narrow_conv(hid, c1.conv.in_channels, 3))
 
 
 def _fused_net_ok(net, xa: Tensor, c: int) -> bool:
@@ -404,11 +415,46 @@ def _fused_net_ok(net, xa: Tensor, c: int) -> bool:
     c1, c2, zc = net[0], net[2], net[4]
     npix = xa.shape[0] * xa.shape[1] * xa.shape[2]
     hid = c1.conv.out_channels
-    return (c1.actnorm.initialized() and c2.actnorm.initialized() and c1.filter_size == 3 and c2.filter_size == 1 and zc.filter_size == 3
-            and K.use_im2col_conv(c1.conv.in_channels, hid, 3, c) and K.use_im2col_conv(zc.out_channels, hid, 3, c)
-            and K.use_narrow_conv(hid, zc.out_channels, 3) and K.use_narrow_conv(hid, c1.conv.in_channels, 3)
+    return (c1.actnorm.initialized() and c2.actnorm.initialized() and _fused_net_shapes_ok(net)
             and K.pointwise_dgrad_masked_supported(npix, K.im2col_kpad(zc.out_channels), hid)
             and K.pointwise_dgrad_masked_supported(npix, hid, hid))
+
+
+class _StepPacks:
+    """The six kernel layouts per coupling network the bf16 training step needs (w1 im2col form, w2, w3 tap form; data-gradient
+    forms of w3, w2 and the tap form of w1's), for all flows of a model, refreshed by one launch per step (K.PackBatch) instead of six
+    launches per flow."""
+
+    def __init__(self, flows):
+        specs, self.index = [], {}
+        for f in flows:
+            net = f.affcoupling.net
+            if K.compute_enum(f.affcoupling.compute) != K.BF16 or not _fused_net_shapes_ok(net):
+                continue
+            w1, w2, w3 = net[0].conv.weight, net[2].conv.weight, net[4].weight
+            self.index[id(f)] = len(specs)
+            specs += [(w1, False, False), (w2, False, False), (w3, False, True), (w3, True, False), (w2, True, False), (w1, True, True)]
+        self.batch = K.PackBatch(specs, K.BF16) if specs else None        # the Parameters themselves: matches() follows re-pointed .data
+
+    def refresh(self) -> None:
+        if self.batch is not None:
+            self.batch.run()
+
+    def get(self, flow):
+        i = self.index.get(id(flow))
+        return None if i is None else self.batch.views[i:i + 6]
+
+
+def _step_packs(glow):
+    flows = [f for b in glow.blocks for f in b.flows] + list(glow.final_flows)
+    sp = getattr(glow, "_step_packs", None)
+    key = tuple(id(f) for f in flows) + tuple(f.affcoupling.compute for f in flows)
+    if sp is None or sp.key != key or (sp.batch is not None and not sp.batch.matches()):
+        sp = _StepPacks(flows)
+        sp.key = key
+        object.__setattr__(glow, "_step_packs", sp)
+    sp.refresh()
+    return sp
 
 
 def coupling_net(net, xa: Tensor, compute: Optional[str] = None) -> Tensor:
@@ -417,10 +463,10 @@ def coupling_net(net, xa: Tensor, compute: Optional[str] = None) -> Tensor:
     return _zero_conv(net[4], _conv_actnorm_relu(net[2], _conv_actnorm_relu(net[0], xa, c), c), c)
 
 
-def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None, wt: Optional[Tensor] = None, own_ldj: bool = False):
+def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None, wt: Optional[Tensor] = None, own_ldj: bool = False, six=None):
     """actnorm -> invconv -> affine coupling (reference glow.py:44-49), differentiable.  pre="level": the weight-only log-det terms of
     this flow (actnorm scale sum, log|det W|) are added once per level by the caller (LevelLogdetFn); wt: W^T of the 1x1 conv;
-    own_ldj: ldj is a tensor of this graph the coupling node may add into in place."""
+    own_ldj: ldj is a tensor of this graph the coupling node may add into in place; six: the flow's layouts from _StepPacks."""
     an, ic, cp = flow.actnorm, flow.invconv2d, flow.affcoupling
     hw = xh.shape[1] * xh.shape[2]
     if not an.initialized():
@@ -434,8 +480,11 @@ def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None, wt: Optional[Te
     if _fused_net_ok(net, y[..., : c // 2], K.compute_enum(cp.compute)):
         c1, c2, zc = net[0], net[2], net[4]
         cc = K.BF16
-        packs = (c1.conv.packed(cc), c2.conv.packed(cc), zc._cache.get_taps(zc.weight, cc))
-        y, inc = CouplingStepFn.apply(y, ldj if level else None, own_ldj and level, zc.logscale_factor, packs, c1.conv.weight,
+        if six is not None:                                        # this step's batched packing (forward + data-gradient layouts)
+            packs, bpacks = tuple(six[:3]), tuple(six[3:])
+        else:
+            packs, bpacks = (c1.conv.packed(cc), c2.conv.packed(cc), zc._cache.get_taps(zc.weight, cc)), None
+        y, inc = CouplingStepFn.apply(y, ldj if level else None, own_ldj and level, zc.logscale_factor, packs, bpacks, c1.conv.weight,
                                       c1.actnorm.bias, c1.actnorm.scale, c2.conv.weight, c2.actnorm.bias, c2.actnorm.scale, zc.weight,
                                       zc.bias, zc.logs)
     else:
@@ -448,19 +497,19 @@ def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None, wt: Optional[Te
     return y, ldj + hw * an.scale.sum() + hw * LogAbsDetFn.apply(ic.weight, pre) + inc
 
 
-def _level_flows(flows, yh: Tensor, ldj: Optional[Tensor]):
+def _level_flows(flows, yh: Tensor, ldj: Optional[Tensor], sp=None):
     """All flows of a level; with a log-det accumulator the weight-only terms are one LevelLogdetFn node for the level, the transposed
     1x1 weights (data gradient) come from one batched transpose, and the per-sample terms are added into one fp64 tensor in place."""
     c = yh.shape[-1]
     wts = torch.stack([f.invconv2d.weight.detach().reshape(c, c) for f in flows]).transpose(1, 2).contiguous()
     if ldj is None:
         for i, flow in enumerate(flows):
-            yh, _ = step_flow(flow, yh, None, wt=wts[i])
+            yh, _ = step_flow(flow, yh, None, wt=wts[i], six=sp.get(flow) if sp else None)
         return yh, None
     hw = yh.shape[1] * yh.shape[2]
     ldj = ldj.to(torch.float64, copy=True)                        # this graph's own accumulator from here on
     for i, flow in enumerate(flows):
-        yh, ldj = step_flow(flow, yh, ldj, "level", wts[i], True)  # data-dependent ActNorm init (if any) happens in here, before the scales are read
+        yh, ldj = step_flow(flow, yh, ldj, "level", wts[i], True, sp.get(flow) if sp else None)  # data-dependent ActNorm init (if any) happens in here, before the scales are read
     term = LevelLogdetFn.apply(hw, len(flows), *[f.invconv2d.weight for f in flows], *[f.actnorm.scale for f in flows])
     return yh, ldj + term
 
@@ -482,11 +531,12 @@ def glow_transform(glow, x: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor
     """Glow.transform with a gradient graph (reference glow.py:172-201): -> (latent parts NCHW views, ldj, logp)."""
     yh = K.to_nhwc(x)
     zs = []
+    sp = _step_packs(glow)                                       # one launch: every weight layout this step's forward and backward read
     for block in glow.blocks:
-        yh, ldj = _level_flows(block.flows, SqueezeFn.apply(yh), ldj)
+        yh, ldj = _level_flows(block.flows, SqueezeFn.apply(yh), ldj, sp)
         yh, z, logp = split(block.split, yh, logp)
         zs.append(K.as_nchw(z))
-    yh, ldj = _level_flows(glow.final_flows, SqueezeFn.apply(yh), ldj)
+    yh, ldj = _level_flows(glow.final_flows, SqueezeFn.apply(yh), ldj, sp)
     zs.append(K.as_nchw(yh))
     return zs, ldj, logp
 

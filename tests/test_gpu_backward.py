@@ -597,3 +597,27 @@ def test_parameter_gradients_added_straight_into_grad(compute):
         assert len(seen) == 1 and all(torch.equal(a, b) for a, b in zip(hooked, ref))
     finally:
         training.DIRECT_PARAM_GRADS = True
+
+
+def test_batched_weight_packing_matches_the_single_launches():
+    """nfdp_conv_pack_weights_batch: all derived layouts of a step in one launch, byte for byte what conv_pack / conv_pack_ex give;
+    a second run() picks up changed weights (the job table points at the parameters' storage)."""
+    ws = [torch.nn.Parameter(rnd(512, 6, 3, 3, seed=1).to(DEV)), torch.nn.Parameter(rnd(512, 512, 1, 1, seed=2).to(DEV)),
+          torch.nn.Parameter(rnd(12, 512, 3, 3, seed=3).to(DEV)), torch.nn.Parameter(rnd(48, 512, 3, 3, seed=4).to(DEV))]
+    specs = [(ws[0], False, False), (ws[1], False, False), (ws[2], False, True), (ws[2], True, False), (ws[1], True, False),
+             (ws[0], True, True), (ws[3], False, True), (ws[3], True, False)]
+    for compute in (K.BF16, K.F32):
+        pb = K.PackBatch(specs, compute)
+        for rnd_no in range(2):
+            pb.run()
+            for (w, flip, taps), v in zip(specs, pb.views):
+                ref = K.conv_pack_ex(w.detach(), compute, flip=flip, taps=taps)
+                assert v.numel() == ref.numel() and torch.equal(v, ref), (tuple(w.shape), flip, taps, compute)
+                if not flip and not taps:
+                    assert torch.equal(v, K.conv_pack(w.detach(), compute))
+            with torch.no_grad():
+                for w in ws:
+                    w.mul_(-0.5)
+        assert pb.matches()
+        ws[0].data = ws[0].data.clone()
+        assert not pb.matches()
