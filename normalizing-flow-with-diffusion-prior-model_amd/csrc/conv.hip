@@ -557,11 +557,26 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
         off_x[i] = rx * 128 + ((q ^ ((rx >> 1) & 7)) << 4);
     }
     const int nk = P.Kpad / PW_BK;
+    // MASK: the saved y this thread's epilogue rows need (8 x 16 bytes) is fetched under the last two K tiles, not after them
+    bf16x8 ypre[MASK ? 8 : 1];
+    const int e_ch = tid & 15, e_rg = tid >> 4;                   // epilogue role: 8 channels n0 + 8 e_ch .., rows e_rg, e_rg + 16, ...
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        if constexpr (MASK) {
+            if (kt == (nk >= 2 ? nk - 2 : 0)) {
+                const __bf16* yb = reinterpret_cast<const __bf16*>(P.mask_y);
+                const int n = n0 + e_ch * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    long px = m0 + e_rg + 16 * e;
+                    if (px >= P.npix) px = P.npix - 1;             // clamped: loaded, never used
+                    ypre[e] = *reinterpret_cast<const bf16x8*>(yb + px * P.mask_ld + (n < P.Cout ? n : 0));
+                }
+            }
+        }
         const char* xs = smem + cur * 2 * PW_TILE_BYTES;
         const char* ws = xs + PW_TILE_BYTES;
 #pragma unroll
@@ -605,14 +620,15 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
             fac[j] = (nok && P.mul) ? expf(__fmul_rn(P.mul[n + j], P.mul_exp)) : 1.0f;
             s1[j] = 0.f; s2[j] = 0.f;
         }
-        const __bf16* yb = reinterpret_cast<const __bf16*>(P.mask_y);
-        for (int pl = rg; pl < PW_BM; pl += 16) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int pl = rg + 16 * e;
             const long px = m0 + pl;
             if (px < P.npix && nok) {
                 const float4 lo = *reinterpret_cast<const float4*>(smem + pl * pitchF + ch * 32);
                 const float4 hi = *reinterpret_cast<const float4*>(smem + pl * pitchF + ch * 32 + 16);
                 const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-                const bf16x8 yv = *reinterpret_cast<const bf16x8*>(yb + px * P.mask_ld + n);
+                const bf16x8 yv = ypre[e];
                 bf16x8 o;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
