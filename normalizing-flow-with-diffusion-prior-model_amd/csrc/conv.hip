@@ -560,6 +560,23 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
     // MASK: the saved y this thread's epilogue rows need (8 x 16 bytes) is fetched under the last two K tiles, not after them
     bf16x8 ypre[MASK ? 8 : 1];
     const int e_ch = tid & 15, e_rg = tid >> 4;                   // epilogue role: 8 channels n0 + 8 e_ch .., rows e_rg, e_rg + 16, ...
+    // per-channel epilogue parameters, requested before the first tile so their latency is not paid after the last one (a K = 64
+    // GEMM is one tile long: its workgroups live a few microseconds)
+    float4 addq[MASK ? 1 : 4], mulq[MASK ? 2 : 4];
+    if constexpr (MASK) {
+        const int n = n0 + e_ch * 8;
+        const bool ok = n < P.Cout && P.mul;
+        mulq[0] = ok ? *reinterpret_cast<const float4*>(P.mul + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        mulq[1] = ok ? *reinterpret_cast<const float4*>(P.mul + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + 4 * q;
+            const bool nok = n < P.Cout;
+            addq[i] = (P.add && nok) ? *reinterpret_cast<const float4*>(P.add + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            mulq[i] = (P.mul && nok) ? *reinterpret_cast<const float4*>(P.mul + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     stage(0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
@@ -615,9 +632,10 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
         const int n = n0 + ch * 8;
         const bool nok = n < P.Cout;                               // Cout % 8 == 0 (checked by the host)
         float fac[8], s1[8], s2[8];
+        const float mraw[8] = {mulq[0].x, mulq[0].y, mulq[0].z, mulq[0].w, mulq[1].x, mulq[1].y, mulq[1].z, mulq[1].w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            fac[j] = (nok && P.mul) ? expf(__fmul_rn(P.mul[n + j], P.mul_exp)) : 1.0f;
+            fac[j] = (nok && P.mul) ? expf(__fmul_rn(mraw[j], P.mul_exp)) : 1.0f;
             s1[j] = 0.f; s2[j] = 0.f;
         }
 #pragma unroll
@@ -668,9 +686,9 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
         const int n = n0 + nl;
         const bool nok = n < P.Cout;                               // Cout % 4 == 0: the 4 channels are in or out together
         float addv[4] = {0.f, 0.f, 0.f, 0.f}, mulv[4] = {1.f, 1.f, 1.f, 1.f};
-        if (P.add && nok) { const float4 t = *reinterpret_cast<const float4*>(P.add + n); addv[0] = t.x; addv[1] = t.y; addv[2] = t.z; addv[3] = t.w; }
+        if (P.add && nok) { const float4 t = addq[MASK ? 0 : i]; addv[0] = t.x; addv[1] = t.y; addv[2] = t.z; addv[3] = t.w; }
         if (P.mul && nok) {
-            const float4 t = *reinterpret_cast<const float4*>(P.mul + n);
+            const float4 t = mulq[MASK ? 0 : i];
             mulv[0] = t.x; mulv[1] = t.y; mulv[2] = t.z; mulv[3] = t.w;
             if (P.mul_exp != 0.f) {
 #pragma unroll
