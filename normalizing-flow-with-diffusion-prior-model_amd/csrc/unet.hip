@@ -367,6 +367,152 @@ __global__ void __launch_bounds__(kBlock) linear_attention_kernel(const float* _
     }
 }
 
+// The same core for n <= 256 positions with every global access batched: a thread issues all of its (up to 8) 16-byte loads of a
+// staging pass before it touches LDS, where the loops above wait out one load latency per element (32 dependent round trips per
+// pass at n = 256: ~46 us per launch at 16x16, a tenth of the reverse step of a 2x16x16 part); the softmax denominators are applied
+// once to the 32x32 context instead of to every term, and the context is read as broadcast float4.
+__global__ void __launch_bounds__(kBlock) linear_attention_staged_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                        int n, int heads, float scale) {
+    __shared__ float kmax[DH], ksum[DH];
+    __shared__ __attribute__((aligned(16))) float ctx4[DH][DH];
+    __shared__ float part[8][DH];
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    constexpr int LP = DH + 1;                                       // LDS row pitch (conflict-free column walks)
+    float* ksm = lsm;
+    float* vsm = lsm + n * LP;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+    const int HD = heads * DH, ld = 3 * HD;
+    const float* base = qkv + (long)b * n * ld;
+    const float* qp = base + hd * DH;
+    const float* kp = base + HD + hd * DH;
+    const float* vp = base + 2 * HD + hd * DH;
+    const int tid = threadIdx.x;
+    const int r = tid >> 3, c4 = (tid & 7) * 4;                       // staging role: rows r, r + 32, ..; floats c4 .. c4+3
+    const int d = tid % DH, grp = tid / DH;
+    {
+        float4 kv[8], vv[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = r + 32 * it;
+            if (i < n) {
+                kv[it] = *reinterpret_cast<const float4*>(kp + (long)i * ld + c4);
+                vv[it] = *reinterpret_cast<const float4*>(vp + (long)i * ld + c4);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = r + 32 * it;
+            if (i < n) {
+                float* kd = ksm + i * LP + c4;
+                float* vd = vsm + i * LP + c4;
+                kd[0] = kv[it].x; kd[1] = kv[it].y; kd[2] = kv[it].z; kd[3] = kv[it].w;
+                vd[0] = vv[it].x; vd[1] = vv[it].y; vd[2] = vv[it].z; vd[3] = vv[it].w;
+            }
+        }
+    }
+    // q rows: requested now, used in step 4 (their latency hides under steps 1-3)
+    float4 qv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int i = r + 32 * it;
+        if (i < n) qv[it] = *reinterpret_cast<const float4*>(qp + (long)i * ld + c4);
+    }
+    __syncthreads();
+    // 1. column max of k over n
+    float m = -INFINITY;
+    for (int i = grp; i < n; i += 8) m = fmaxf(m, ksm[i * LP + d]);
+    part[grp][d] = m;
+    __syncthreads();
+    if (tid < DH) {
+        float mm = part[0][d];
+        for (int g = 1; g < 8; ++g) mm = fmaxf(mm, part[g][d]);
+        kmax[d] = mm;
+    }
+    __syncthreads();
+    // 2. exp(k - max) in place, column sums
+    float s = 0.f;
+    {
+        const float km = kmax[d];
+        for (int i = grp; i < n; i += 8) {
+            const float ev = expf(ksm[i * LP + d] - km);
+            ksm[i * LP + d] = ev;
+            s += ev;
+        }
+    }
+    __syncthreads();                                                  // part[] was read by the threads < DH above
+    part[grp][d] = s;
+    __syncthreads();
+    if (tid < DH) {
+        float ss = 0.f;
+        for (int g = 0; g < 8; ++g) ss += part[g][d];
+        ksum[d] = ss;
+    }
+    __syncthreads();
+    // 3. ctx[d][e] = (sum_i exp(k - max)[i][d] v[i][e]) / (ksum[d] n); thread owns d and e in [4 grp, 4 grp + 4)
+    {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < n; ++i) {
+            const float p = ksm[i * LP + d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(p, vsm[i * LP + 4 * grp + j], acc[j]);
+        }
+        const float f = 1.0f / (ksum[d] * (float)n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ctx4[d][4 * grp + j] = acc[j] * f;
+    }
+    __syncthreads();                                                  // k, v are done with: their LDS takes the q rows, then the output rows
+    float* qs = ksm;
+    float* os = vsm;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int i = r + 32 * it;
+        if (i < n) {
+            float* qd = qs + i * LP + c4;
+            qd[0] = qv[it].x; qd[1] = qv[it].y; qd[2] = qv[it].z; qd[3] = qv[it].w;
+        }
+    }
+    __syncthreads();
+    // 4. per position: softmax over d of q, times scale, then out[e] = sum_d ctx[d][e] q[d]
+    if (tid < n) {
+        const int i = tid;
+        float q[DH];
+        float mq = -INFINITY;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) { q[dd] = qs[i * LP + dd]; mq = fmaxf(mq, q[dd]); }
+        float sq = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) { q[dd] = expf(q[dd] - mq); sq += q[dd]; }
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) q[dd] = __fmul_rn(q[dd] / sq, scale);
+        float acc[DH];
+#pragma unroll
+        for (int e = 0; e < DH; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DH; ++dd) {
+#pragma unroll
+            for (int e4 = 0; e4 < DH / 4; ++e4) {
+                const float4 c = *reinterpret_cast<const float4*>(&ctx4[dd][4 * e4]);      // same address in every lane: broadcast
+                acc[4 * e4 + 0] = fmaf(c.x, q[dd], acc[4 * e4 + 0]);
+                acc[4 * e4 + 1] = fmaf(c.y, q[dd], acc[4 * e4 + 1]);
+                acc[4 * e4 + 2] = fmaf(c.z, q[dd], acc[4 * e4 + 2]);
+                acc[4 * e4 + 3] = fmaf(c.w, q[dd], acc[4 * e4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < DH; ++e) os[i * LP + e] = acc[e];
+    }
+    __syncthreads();
+    float* obase = out + (long)b * n * HD + hd * DH;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int i = r + 32 * it;
+        if (i < n) {
+            const float* od = os + i * LP + c4;
+            *reinterpret_cast<float4*>(obase + (long)i * HD + c4) = make_float4(od[0], od[1], od[2], od[3]);
+        }
+    }
+}
+
 // ---- n > 256 positions (the 64x64 / 32x32 latent parts of the larger models): the positions are cut into chunks of 256 and
 // spread over blockIdx.y.  Pass 1 (one workgroup per (b, head, chunk), the chunk's k and v staged in LDS as above) produces
 // the chunk's column max m_c[d], sum_c[d] = sum_i exp(k - m_c) and the unnormalised context sum_i exp(k - m_c) v[e]; pass 2
@@ -700,7 +846,18 @@ extern "C" int nfdp_linear_attention_f32(const float* qkv, float* out, int B, in
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBlock * (DH + 1) * (int)sizeof(float));
         la_attr = true;
     }
-    hipLaunchKernelGGL(linear_attention_kernel, dim3(B * heads), dim3(kBlock), la_lds, as_stream(stream), qkv, out, n, heads, scale);
+    if (n <= kBlock && (((uintptr_t)qkv | (uintptr_t)out) & 15) == 0) {
+        static bool las_attr = false;
+        if (!las_attr) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_attention_staged_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBlock * (DH + 1) * (int)sizeof(float));
+            las_attr = true;
+        }
+        hipLaunchKernelGGL(linear_attention_staged_kernel, dim3(B * heads), dim3(kBlock), la_lds, as_stream(stream), qkv, out, n, heads,
+                           scale);
+    } else {
+        hipLaunchKernelGGL(linear_attention_kernel, dim3(B * heads), dim3(kBlock), la_lds, as_stream(stream), qkv, out, n, heads, scale);
+    }
     NFDP_CHECK_LAUNCH("linear_attention");
     return NFDP_OK;
 }
