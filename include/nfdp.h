@@ -69,6 +69,10 @@ int nfdp_coupling_mlp_bf16(const void* xcol, int xcol_ld, long npix, const void*
 int nfdp_im2col3x3_bf16(const float* x, int x_ld, void* out, int B, int H, int W, int C, int Kpad, nfdp_stream_t stream);
 /* channel slice copy: dst[p, 0:n) = src[p, off:off+n) for npix pixels (Split / chunk / concat plumbing). */
 int nfdp_copy_channels_f32(const float* src, int src_ld, float* dst, int dst_ld, long npix, int n, nfdp_stream_t stream);
+/* torch.cat((a, b), dim=1) of the U-Net's skip connections (denoising_diffusion_pytorch.py:478-486) for pixel-strided NHWC tensors:
+ * out[p][0:ca] = a[p], out[p][ca:ca+cb] = b[p], one launch. */
+int nfdp_concat_channels_f32(const float* a, int a_ld, int ca, const float* b, int b_ld, int cb, float* out, int out_ld, long npix,
+                             nfdp_stream_t stream);
 
 /* ---------------------------------------------------------------- ActNorm (transforms.py:56-94) */
 /* Data-dependent init, transforms.py:74-78: scale[c] = -log(std_unbiased + 1e-6), bias[c] = -mean over

@@ -214,6 +214,41 @@ extern "C" int nfdp_copy_channels_f32(const float* src, int src_ld, float* dst, 
     return NFDP_OK;
 }
 
+// torch.cat((a, b), dim=channel) of two pixel-strided NHWC tensors in one launch (the U-Net's skip connections,
+// denoising_diffusion_pytorch.py:478-486): float4 per thread when all channel counts, strides and pointers allow.
+template <bool VEC>
+__global__ void concat_channels_kernel(const float* __restrict__ a, int a_ld, int ca, const float* __restrict__ b, int b_ld, int cb,
+                                       float* __restrict__ out, int out_ld, long total) {
+    constexpr int V = VEC ? 4 : 1;
+    const int c = (ca + cb) / V;
+    for (long e = blockIdx.x * (long)kBlock + threadIdx.x; e < total; e += (long)gridDim.x * kBlock) {
+        const long p = e / c;
+        const int j = (int)(e - p * c) * V;
+        const float* src = j < ca ? a + p * a_ld + j : b + p * b_ld + (j - ca);
+        float* dst = out + p * out_ld + j;
+        if (VEC) *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+        else *dst = *src;
+    }
+}
+
+extern "C" int nfdp_concat_channels_f32(const float* a, int a_ld, int ca, const float* b, int b_ld, int cb, float* out, int out_ld,
+                                        long npix, nfdp_stream_t stream) {
+    NFDP_REQUIRE(a && b && out, NFDP_EINVAL, "concat_channels: null pointer");
+    NFDP_REQUIRE(npix >= 0 && ca > 0 && cb > 0 && a_ld >= ca && b_ld >= cb && out_ld >= ca + cb, NFDP_ESHAPE,
+                 "concat_channels: bad shape");
+    if (npix == 0) return NFDP_OK;
+    const bool vec = ((ca | cb | a_ld | b_ld | out_ld) & 3) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0;
+    if (vec) {
+        const long total = npix * ((ca + cb) / 4);
+        LAUNCH_1D(concat_channels_kernel<true>, total, a, a_ld, ca, b, b_ld, cb, out, out_ld, total);
+    } else {
+        const long total = npix * (ca + cb);
+        LAUNCH_1D(concat_channels_kernel<false>, total, a, a_ld, ca, b, b_ld, cb, out, out_ld, total);
+    }
+    NFDP_CHECK_LAUNCH("concat_channels");
+    return NFDP_OK;
+}
+
 extern "C" int nfdp_preprocess_u8_nchw_to_nhwc_f32(const uint8_t* u8, const float* noise_nchw, float* y, int B, int C,
                                                    int H, int W, int n_bits, nfdp_stream_t stream) {
     NFDP_REQUIRE(u8 && y, NFDP_EINVAL, "preprocess: null pointer");

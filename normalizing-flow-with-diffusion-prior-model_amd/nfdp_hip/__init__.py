@@ -675,12 +675,15 @@ def add(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """torch.cat((a, b), dim=channel) for NHWC tensors, as two strided channel copies."""
+    """torch.cat((a, b), dim=channel) for NHWC tensors, one launch."""
     bb, h, w, ca = a.shape
     cb = b.shape[-1]
+    _need(a, torch.float32, "concat_channels"); _need(b, torch.float32, "concat_channels")
+    if tuple(b.shape[:3]) != (bb, h, w):
+        raise ValueError(f"concat_channels: shape mismatch {tuple(a.shape)} / {tuple(b.shape)}")
     out = torch.empty((bb, h, w, ca + cb), device=a.device, dtype=torch.float32)
-    copy_channels(a, out[..., :ca])
-    copy_channels(b, out[..., ca:])
+    _call("nfdp_concat_channels_f32", _ptr(a), _ld(a, "concat_channels"), ca, _ptr(b), _ld(b, "concat_channels"), cb, _ptr(out), ca + cb,
+          bb * h * w, _stream(), label="concat_channels", nbytes=8.0 * out.numel())
     return out
 
 
