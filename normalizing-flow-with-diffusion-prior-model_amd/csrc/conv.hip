@@ -332,14 +332,18 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
 // Needs Cin % 8 == 0 (8 consecutive k stay inside one tap), fp32 in and out.
 constexpr int SK_LD = 64 + 4;                                  // partial-tile row stride in floats
 
-template <int SK_WAVES, int SK_KL, bool EMU>       // waves per workgroup, consecutive k per lane per stage (a stage is 4*SK_KL deep)
+// PT: 16-pixel tiles per workgroup (4 = the 64 x 64 tile; 2 / 1 when 64-pixel tiles would leave CUs without a workgroup: the 8x8 and
+// 4x4 levels of a B = 64 reverse step have 4096 / 1024 pixels - every wave's MFMA chain, the critical path of the launch, shrinks
+// with PT while the weight fragments are re-read from L2)
+template <int SK_WAVES, int SK_KL, bool EMU, int PT = 4>       // waves per workgroup, consecutive k per lane per stage (a stage is 4*SK_KL deep)
 __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const ConvParams P) {
     constexpr int SK_BK = 4 * SK_KL, SK_THREADS = SK_WAVES * 64;
     static_assert(!EMU || SK_KL == 8, "the bf16 MFMA takes 8 consecutive k per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* part = reinterpret_cast<float*>(smem);              // [SK_WAVES][64 pixels][SK_LD]
+    constexpr int MT = 16 * PT;                                // pixels per workgroup
+    float* part = reinterpret_cast<float*>(smem);              // [SK_WAVES][MT pixels][SK_LD]
     const int nt = blockIdx.x % P.Nt, mt = blockIdx.x / P.Nt;
-    const long m0 = (long)mt * 64;
+    const long m0 = (long)mt * MT;
     const int n0 = nt * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
@@ -347,12 +351,12 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
     const float* __restrict__ wg = reinterpret_cast<const float*>(P.w);
     const int HW = P.H * P.W;
 
-    // this lane's 4 pixels (one per pixel tile) and 4 weight rows
-    int py[4], px[4];
-    long pbase[4];
-    bool pok[4];
+    // this lane's PT pixels (one per pixel tile) and 4 weight rows
+    int py[PT], px[PT];
+    long pbase[PT];
+    bool pok[PT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < PT; ++j) {
         const long p = m0 + j * 16 + r16;
         pok[j] = p < P.npix;
         const long pc = pok[j] ? p : 0;
@@ -365,13 +369,13 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
 #pragma unroll
     for (int i = 0; i < 4; ++i) wrow[i] = wg + (size_t)(n0 + i * 16 + r16) * P.Kpad + SK_KL * q;
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][PT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    struct Frags { float4 w[4][SK_KL / 4]; float4 x[4][SK_KL / 4]; };
+    struct Frags { float4 w[4][SK_KL / 4]; float4 x[PT][SK_KL / 4]; };
     auto load = [&](Frags& f, int kt) {
         const int k0 = kt * SK_BK + SK_KL * q;
         const int tap = k0 / P.Cin, ci = k0 - tap * P.Cin;
@@ -382,7 +386,7 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
 #pragma unroll
             for (int h = 0; h < SK_KL / 4; ++h) f.w[i][h] = *reinterpret_cast<const float4*>(wrow[i] + kt * SK_BK + 4 * h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PT; ++j) {
             const int y = py[j] + dy, xx = px[j] + dx;
             const bool ok = kok && pok[j] && (unsigned)y < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
             // always load (from a clamped, valid address) and mask the bits: a "load or zero" select makes hipcc branch
@@ -398,18 +402,21 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
     };
     auto compute = [&](const Frags& f) {
         if constexpr (EMU) {
-            bf16x8 wh[4], wm[4], wl[4], xh[4], xm[4], xl[4];
+            bf16x8 wh[4], wm[4], wl[4], xh[PT], xm[PT], xl[PT];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float wv[8] = {f.w[i][0].x, f.w[i][0].y, f.w[i][0].z, f.w[i][0].w, f.w[i][1].x, f.w[i][1].y, f.w[i][1].z, f.w[i][1].w};
-                const float xv[8] = {f.x[i][0].x, f.x[i][0].y, f.x[i][0].z, f.x[i][0].w, f.x[i][1].x, f.x[i][1].y, f.x[i][1].z, f.x[i][1].w};
                 split3(wv, wh[i], wm[i], wl[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < PT; ++i) {
+                const float xv[8] = {f.x[i][0].x, f.x[i][0].y, f.x[i][0].z, f.x[i][0].w, f.x[i][1].x, f.x[i][1].y, f.x[i][1].z, f.x[i][1].w};
                 split3(xv, xh[i], xm[i], xl[i]);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {                      // smallest terms first
+                for (int j = 0; j < PT; ++j) {                     // smallest terms first
                     f32x4 c = acc[i][j];
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[i], xh[j], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[i], xl[j], c, 0, 0, 0);
@@ -426,7 +433,7 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
             for (int i = 0; i < 4; ++i) {
                 const float a = reinterpret_cast<const float*>(&f.w[i][0])[kk];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < PT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, reinterpret_cast<const float*>(&f.x[j][0])[kk], acc[i][j], 0, 0, 0);
             }
         }
@@ -447,17 +454,19 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
     }
 
     // ---- the partial tiles meet in LDS: D[row = n = 4q + r][col = pixel = r16]
-    float* mine = part + wave * 64 * SK_LD;
+    float* mine = part + wave * MT * SK_LD;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < PT; ++j)
             *reinterpret_cast<float4*>(mine + (j * 16 + r16) * SK_LD + i * 16 + 4 * q) =
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     __syncthreads();
+    constexpr int NF4 = MT * 16;                                   // float4 of the MT x 64 tile
 #pragma unroll
-    for (int e = 0; e < 1024 / SK_THREADS; ++e) {
-        const int idx = tid + SK_THREADS * e;                      // 1024 float4 of the 64 x 64 tile
+    for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
+        const int idx = tid + SK_THREADS * e;
+        if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
         const int m = idx >> 4, n4 = (idx & 15) * 4;
         const long p = m0 + m;
         const int n = n0 + n4;
@@ -465,7 +474,7 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
         float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
 #pragma unroll
         for (int w = 1; w < SK_WAVES; ++w) {
-            const float4 t = *reinterpret_cast<const float4*>(part + (w * 64 + m) * SK_LD + n4);
+            const float4 t = *reinterpret_cast<const float4*>(part + (w * MT + m) * SK_LD + n4);
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
         float o[4] = {v.x, v.y, v.z, v.w};
@@ -1052,20 +1061,29 @@ extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void
     if (compute == NFDP_F32 && Cin % 8 == 0 && x_ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && Cout >= 64 && Cout % 4 == 0 &&
         y_ld % 4 == 0 && ((uintptr_t)y % 16) == 0 && P.Kpad >= 8 * 32 && cdiv(npix, 64) * cdiv(Cout, 64) <= 1024 &&
         (add == nullptr || (uintptr_t)add % 16 == 0) && (mul == nullptr || (uintptr_t)mul % 16 == 0)) {
-        P.Mt = (int)cdiv(npix, 64);
         P.Nt = (int)cdiv(Cout, 64);
+        // pixel tiles per workgroup: 64-pixel tiles unless they leave CUs without a workgroup (then 32 or 16 pixels)
+        const long t64 = cdiv(npix, 64) * P.Nt;
+        const int pt = t64 >= 256 ? 4 : (2 * t64 >= 256 ? 2 : 1);
+        P.Mt = (int)cdiv(npix, 16 * pt);
+        const dim3 grid(P.Mt * P.Nt);
         static bool sk_attr_set = false;
         if (!sk_attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<8, 4, false>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<8, 4, false, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * SK_LD * 4);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<4, 8, true>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<4, 8, true, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
             sk_attr_set = true;
         }
-        if (g_f32_products == 1)      // fp32 products as six bf16 MFMAs (nfdp_set_f32_products)
-            hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true>), dim3(P.Mt * P.Nt), dim3(256), 4 * 64 * SK_LD * 4, s, P);
-        else
-            hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false>), dim3(P.Mt * P.Nt), dim3(512), 8 * 64 * SK_LD * 4, s, P);
+        if (g_f32_products == 1) {    // fp32 products as six bf16 MFMAs (nfdp_set_f32_products)
+            if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 4>), grid, dim3(256), 4 * 64 * SK_LD * 4, s, P);
+            else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 2>), grid, dim3(256), 4 * 32 * SK_LD * 4, s, P);
+            else hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 1>), grid, dim3(256), 4 * 16 * SK_LD * 4, s, P);
+        } else {
+            if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false, 4>), grid, dim3(512), 8 * 64 * SK_LD * 4, s, P);
+            else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false, 2>), grid, dim3(512), 8 * 32 * SK_LD * 4, s, P);
+            else hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false, 1>), grid, dim3(512), 8 * 16 * SK_LD * 4, s, P);
+        }
         NFDP_CHECK_LAUNCH("conv2d (split-K fp32)");
         return NFDP_OK;
     }
