@@ -65,6 +65,27 @@ __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __r
                 s1 += (double)v[k].x + (double)v[k].y + (double)v[k].z + (double)v[k].w;
             }
         }
+        // everything else the output pass reads is requested now, so its latency hides under the two block reductions: this
+        // thread's 4 channels are the same for every k when q divides the block size (q = cpg/4 is 1, 2 or 4 for the models here)
+        const bool same_c = (kBlock % q) == 0;
+        const int cp = g * cpg + (threadIdx.x % q) * 4;
+        float4 gpre = make_float4(0.f, 0.f, 0.f, 0.f), bpre = gpre, sspre = gpre, shpre = gpre, rpre[RC / 4];
+        if (same_c) {
+            gpre = *reinterpret_cast<const float4*>(gamma + cp);
+            bpre = *reinterpret_cast<const float4*>(beta + cp);
+            if (ss) {
+                const float* sr = ss + (long)b * ss_ld;
+                sspre = make_float4(sr[cp], sr[cp + 1], sr[cp + 2], sr[cp + 3]);
+                shpre = make_float4(sr[C + cp], sr[C + cp + 1], sr[C + cp + 2], sr[C + cp + 3]);
+            }
+        }
+        if (res) {
+#pragma unroll
+            for (int k = 0; k < RC / 4; ++k) {
+                const int e = threadIdx.x + k * kBlock;
+                rpre[k] = e < nv ? *reinterpret_cast<const float4*>(res + base + (long)(e / q) * C + (e % q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         const double mean_d = block_sum256(s1, red) / n;
         double s2 = 0.0;
 #pragma unroll
@@ -82,15 +103,21 @@ __global__ void __launch_bounds__(kBlock) groupnorm_silu_kernel(const float* __r
             if (e < nv) {
                 const int c0 = g * cpg + (e % q) * 4;
                 float o[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+                const float gq[4] = {gpre.x, gpre.y, gpre.z, gpre.w}, bq[4] = {bpre.x, bpre.y, bpre.z, bpre.w};
+                const float sq[4] = {sspre.x, sspre.y, sspre.z, sspre.w}, hq[4] = {shpre.x, shpre.y, shpre.z, shpre.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[j], m), r), gamma[c0 + j]), beta[c0 + j]);
-                    if (ss) t = __fadd_rn(__fmul_rn(t, __fadd_rn(ss[(long)b * ss_ld + c0 + j], 1.0f)), ss[(long)b * ss_ld + C + c0 + j]);
+                    const float ga = same_c ? gq[j] : gamma[c0 + j], be = same_c ? bq[j] : beta[c0 + j];
+                    float t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[j], m), r), ga), be);
+                    if (ss) {
+                        const float sc = same_c ? sq[j] : ss[(long)b * ss_ld + c0 + j], sh = same_c ? hq[j] : ss[(long)b * ss_ld + C + c0 + j];
+                        t = __fadd_rn(__fmul_rn(t, __fadd_rn(sc, 1.0f)), sh);
+                    }
                     o[j] = t / (1.0f + expf(-t));
                 }
                 const long off = base + (long)(e / q) * C + (e % q) * 4;
                 if (res) {                                         // ResnetBlock's  h + res_conv(x)  (:301), same fp32 add as a separate pass
-                    const float4 rv = *reinterpret_cast<const float4*>(res + off);
+                    const float4 rv = rpre[k];
                     o[0] = __fadd_rn(o[0], rv.x); o[1] = __fadd_rn(o[1], rv.y); o[2] = __fadd_rn(o[2], rv.z); o[3] = __fadd_rn(o[3], rv.w);
                 }
                 *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
@@ -197,15 +224,49 @@ __global__ void __launch_bounds__(kBlock) linear_kernel(const float* __restrict_
     float* xs = lsm;                   // [LIN_TB][IP]
     float* ws = lsm + LIN_TB * IP;     // [LIN_TO][IP]
     const int o0 = blockIdx.x * LIN_TO, b0 = blockIdx.y * LIN_TB;
-    for (int e = threadIdx.x; e < LIN_TB * I; e += kBlock) {
-        const int r = e / I, i = e % I;
-        float v = (b0 + r < B) ? in[(long)(b0 + r) * I + i] : 0.f;
-        if (pre == 1) v = v / (1.0f + expf(-v));
-        xs[r * IP + i] = v;
-    }
-    for (int e = threadIdx.x; e < LIN_TO * I; e += kBlock) {
-        const int r = e / I, i = e % I;
-        ws[r * IP + i] = (o0 + r < O) ? w[(long)(o0 + r) * I + i] : 0.f;
+    if ((I & 3) == 0 && (((uintptr_t)in | (uintptr_t)w) & 15) == 0) {
+        // 16-byte loads, eight in flight per thread before LDS is touched (an element-wise staging loop waits out one load
+        // latency per element: 64 dependent round trips for I = 256 made this 37 us for a [64 x 256] x [256 x 256] product)
+        const int I4 = I >> 2;
+        auto stage = [&](const float* __restrict__ src, int row0, int rows, int nrows, float* dst, bool act) {
+            const int total = nrows * I4;
+            for (int base = threadIdx.x; base < total; base += kBlock * 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + u * kBlock;
+                    const int r = e / I4, c = e - r * I4;
+                    v[u] = (e < total && row0 + r < rows) ? *reinterpret_cast<const float4*>(src + (long)(row0 + r) * I + 4 * c)
+                                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = base + u * kBlock;
+                    if (e >= total) continue;
+                    const int r = e / I4, c = e - r * I4;
+                    float t[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    if (act) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] = t[j] / (1.0f + expf(-t[j]));
+                    }
+                    float* d = dst + r * IP + 4 * c;
+                    d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3];
+                }
+            }
+        };
+        stage(in, b0, B, LIN_TB, xs, pre == 1);
+        stage(w, o0, O, LIN_TO, ws, false);
+    } else {
+        for (int e = threadIdx.x; e < LIN_TB * I; e += kBlock) {
+            const int r = e / I, i = e % I;
+            float v = (b0 + r < B) ? in[(long)(b0 + r) * I + i] : 0.f;
+            if (pre == 1) v = v / (1.0f + expf(-v));
+            xs[r * IP + i] = v;
+        }
+        for (int e = threadIdx.x; e < LIN_TO * I; e += kBlock) {
+            const int r = e / I, i = e % I;
+            ws[r * IP + i] = (o0 + r < O) ? w[(long)(o0 + r) * I + i] : 0.f;
+        }
     }
     __syncthreads();
     const int bl = threadIdx.x % LIN_TB, og = threadIdx.x / LIN_TB;      // og in 0..3 -> outputs 4og..4og+3
