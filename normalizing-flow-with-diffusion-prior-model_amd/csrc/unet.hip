@@ -191,6 +191,46 @@ __global__ void __launch_bounds__(kBlock) chan_layernorm_kernel(const float* __r
                                                                long npix, int C, const float* __restrict__ gain, float eps,
                                                                const float* __restrict__ residual) {
     const int lane = threadIdx.x & 63;
+    if (C <= 256) {
+        // the row lives in registers (one global read) and the gain / residual are requested with it, before the two reductions
+        float gv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gv[k] = lane + 64 * k < C ? gain[lane + 64 * k] : 0.f;
+        for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < npix; p += (long)gridDim.x * 4) {
+            const float* xr = x + p * C;
+            float xv[4], rv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = lane + 64 * k;
+                xv[k] = c < C ? xr[c] : 0.f;
+                rv[k] = (residual && c < C) ? residual[p * C + c] : 0.f;
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lane + 64 * k < C) s += (double)xv[k];
+            const double mean = wave_sum_d(s) / C;
+            double q = 0.0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (lane + 64 * k < C) {
+                    const double d = (double)xv[k] - mean;
+                    q += d * d;
+                }
+            const double var = wave_sum_d(q) / C;
+            const float m = (float)mean, r = rsqrtf(__fadd_rn((float)var, eps));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = lane + 64 * k;
+                if (c < C) {
+                    float v = __fmul_rn(__fmul_rn(__fsub_rn(xv[k], m), r), gv[k]);
+                    if (residual) v = __fadd_rn(v, rv[k]);
+                    y[p * C + c] = v;
+                }
+            }
+        }
+        return;
+    }
     for (long p = (long)blockIdx.x * 4 + (threadIdx.x >> 6); p < npix; p += (long)gridDim.x * 4) {
         const float* xr = x + p * C;
         double s = 0.0;
