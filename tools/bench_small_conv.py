@@ -7,8 +7,8 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "normalizing-flow-with-diffusion-prior-
 import torch
 import nfdp_hip as K
 dev = "cuda"
-for (b, hw, cin, cout, k) in [(16, 16, 64, 64, 3), (64, 16, 64, 64, 3), (256, 16, 64, 64, 3), (1024, 16, 64, 64, 3),
-                              (64, 8, 128, 128, 3), (64, 8, 192, 128, 3), (64, 16, 128, 64, 1)]:
+for (b, hw, cin, cout, k) in [(16, 16, 64, 64, 3), (64, 16, 64, 64, 3), (128, 16, 64, 64, 3), (256, 16, 64, 64, 3), (1024, 16, 64, 64, 3),
+                              (64, 16, 128, 64, 3), (64, 8, 64, 64, 3), (64, 8, 128, 128, 3), (64, 8, 192, 128, 3), (64, 4, 128, 128, 3), (64, 16, 128, 64, 1)]:
     x = torch.randn(b, hw, hw, cin, device=dev)
     w = torch.randn(cout, cin, k, k, device=dev) * 0.05
     packed = K.conv_pack(w, K.F32)
