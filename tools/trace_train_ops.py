@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Where do the small launches of one training step come from?  One eager step (Glow L3 K16, B=512, bf16) under torch.profiler with
-Python stacks: device kernels grouped by the aten op and the innermost frame of this repo that issued them."""
+"""How many device launches of one training step come from torch's own ops (autograd glue: AccumulateGrad adds, copies, fills, scalar
+arithmetic) rather than from the C ABI?  One eager step (Glow L3 K16, B=512, bf16) under torch.profiler, device kernels grouped by the
+aten op that issued them.  (1835 at the 32.3 ms state of the step, 212 after the launch-count work described in DESIGN.md.)"""
 import os, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "normalizing-flow-with-diffusion-prior-model_amd")]
@@ -34,7 +35,7 @@ for _ in range(3):
     train_step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     train_step()
     torch.cuda.synchronize()
 
@@ -44,11 +45,7 @@ for ev in prof.events():
         continue
     if not ev.name.startswith("aten::"):
         continue
-    where = "?"
-    for fr in ev.stack:
-        if "normalizing-flow-with-diffusion-prior-model_amd" in fr or "bench.py" in fr or "trace_train_ops" in fr:
-            where = fr.split("normalizing-flow-with-diffusion-prior-model_amd/")[-1]
-            break
+    where = ""
     a = agg[(ev.name, where)]
     a[0] += len(ev.kernels)
     a[1] += sum(k.duration for k in ev.kernels)
