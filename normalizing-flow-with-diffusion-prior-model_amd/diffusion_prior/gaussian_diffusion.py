@@ -23,6 +23,7 @@ import torch
 from torch import nn, Tensor
 
 import nfdp_hip as K
+from normalizing_flow.base import _EpochOnApply
 
 ModelPrediction = namedtuple('ModelPrediction', ['pred_noise', 'pred_x_start'])
 
@@ -219,7 +220,7 @@ def _attn_block_nhwc(res: Residual, xh: Tensor, compute=None) -> Tensor:
 
 
 # ----------------------------------------------------------------------------- model (:363-490)
-class Unet(nn.Module):
+class Unet(_EpochOnApply, nn.Module):
     def __init__(self, dim, init_dim=None, out_dim=None, dim_mults=(1, 2, 4, 8), channels=3, self_condition=False,
                  resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
                  random_fourier_features=False, learned_sinusoidal_dim=16, compute: Optional[str] = None):
@@ -373,7 +374,7 @@ def sigmoid_beta_schedule(timesteps, start=-3, end=3, tau=1, clamp_min=1e-5):
 
 
 # ----------------------------------------------------------------------------- GaussianDiffusion (:540-867)
-class GaussianDiffusion(nn.Module):
+class GaussianDiffusion(_EpochOnApply, nn.Module):
     def __init__(self, model, *, image_size, timesteps=1000, sampling_timesteps=None, loss_type='l1',
                  objective='pred_noise', beta_schedule='sigmoid', schedule_fn_kwargs=dict(), p2_loss_weight_gamma=0.,
                  p2_loss_weight_k=1, ddim_sampling_eta=0., auto_normalize=True):

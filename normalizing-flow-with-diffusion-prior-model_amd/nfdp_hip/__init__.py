@@ -156,12 +156,25 @@ def _stream() -> int:
 _empty_scratch: Dict[str, torch.Tensor] = {}
 
 
+def _same_device(t) -> None:
+    """Every launch goes to the CURRENT device's current stream (_stream()): a tensor of another GPU would be read / written by
+    a kernel queued on the wrong device, with no stream ordering against the work that produced it.  One process per GPU:
+    torch.cuda.set_device(LOCAL_RANK) (normalizing_flow.base.default_device() does it when LOCAL_RANK is set), or
+    `with torch.cuda.device(t.device)` around the call.  Checked for every pointer handed to the C ABI."""
+    cur = torch.cuda.current_device()
+    if t.device.index is not None and t.device.index != cur:
+        raise NfdpError(f"tensor is on cuda:{t.device.index} but the current device is cuda:{cur}: kernels are queued on the current "
+                        f"device's stream - call torch.cuda.set_device({t.device.index}) (one process per GPU) first")
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     """Device address for the C ABI.  Empty tensors (an empty shard of a ragged data-parallel split) have a null data pointer,
     which the ABI rejects as a missing argument; they get the address of a small per-device scratch instead - every entry
     point returns before touching memory when a size is 0."""
     if t is None:
         return None
+    if t.is_cuda:
+        _same_device(t)
     if t.numel() == 0 and t.is_cuda:
         key = str(t.device)
         if key not in _empty_scratch:

@@ -18,9 +18,20 @@ from . import _call, _ptr, _stream, lib, bump_param_epoch
 
 
 class FusedAdam:
+    """weight_decay=None takes torch's default for the optimizer the reference's init_optimizer would build (utils.py:120-137):
+    0 for 'adam', 0.01 for 'adamw'.
+
+    direct_grads: "auto" | True | False - whether the backward launches may add parameter gradients straight into the flat gradient
+    buffer, bypassing autograd's AccumulateGrad nodes (normalizing_flow.training._slot).  Anything hanging on those nodes then never
+    runs - torch's DistributedDataParallel reducer does (its hooks live in C++ and cannot be detected) - so "auto" enables it only when
+    no process group with more than one rank exists at construction; pass True under data parallelism only with a reducer that works
+    on the flat buffer after backward (nfdp_hip.dist.FlatGradAllReduce), False with torch DDP even at world size 1."""
+
     def __init__(self, clipped: Iterable[torch.nn.Parameter], unclipped: Iterable[torch.nn.Parameter] = (), lr: float = 1e-3,
-                 betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0, adamw: bool = False,
-                 clip_value: Optional[float] = None, max_norm: Optional[float] = None):
+                 betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: Optional[float] = None, adamw: bool = False,
+                 clip_value: Optional[float] = None, max_norm: Optional[float] = None, direct_grads="auto"):
+        if weight_decay is None:
+            weight_decay = 0.01 if adamw else 0.0
         self.clipped = [p for p in clipped if p.requires_grad]
         self.unclipped = [p for p in unclipped if p.requires_grad]
         self.params = self.clipped + self.unclipped
@@ -52,6 +63,12 @@ class FusedAdam:
                 p.data = self.flat_param[off:off + k].view(p.shape)         # the parameter now lives in the flat buffer
                 p.grad = self.flat_grad[off:off + k].view(p.shape)          # autograd accumulates into this view in place
                 off += k
+        if direct_grads == "auto":
+            import torch.distributed as dist
+            direct_grads = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        self.direct_grads = bool(direct_grads)
+        for p in self.params:
+            p._nfdp_direct_grad = self.direct_grads
 
     def zero_grad(self, set_to_none: bool = False) -> None:
         """One memset; the .grad views are kept (set_to_none is accepted for signature compatibility and ignored)."""
@@ -82,11 +99,82 @@ class FusedAdam:
         """Steps taken, read back from the device counter (graph replays advance it without passing through step())."""
         return int(self._hyper[1].item())
 
+    def _param_group(self):
+        b1, b2 = self.betas
+        return {"lr": self.lr, "betas": (b1, b2), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False, "maximize": False,
+                "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": bool(self.adamw),
+                "params": list(range(len(self.params)))}
+
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "lr": self.lr}
+        """torch.optim.Adam / AdamW layout ({"state": {i: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]}, parameter i =
+        i-th of clipped + unclipped) so the reference's checkpoints (prior.py:102-115: "optimizer": optim.state_dict()) and
+        `optimizer.load_state_dict` (normalizing_flow/trainer.py:115) interchange with it.  Before the first step the state is
+        empty, like torch's."""
+        n_steps = self.step_count
+        state = {}
+        if n_steps > 0:
+            off = 0
+            for i, p in enumerate(self.params):
+                k = p.numel()
+                state[i] = {"step": torch.tensor(float(n_steps)),
+                            "exp_avg": self.exp_avg[off:off + k].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + k].view(p.shape).clone()}
+                off += k
+        return {"state": state, "param_groups": [self._param_group()]}
 
     def load_state_dict(self, sd) -> None:
-        self._hyper[1] = float(int(sd["step"]))
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.lr = sd.get("lr", self.lr)
+        """Accepts torch's Adam/AdamW layout (any number of param groups; the moments are matched by parameter index; the learning
+        rate, betas, eps and weight decay of the FIRST group apply - one flat launch has one set of hyper-parameters) and the flat
+        layout earlier versions of this class wrote ({"step", "exp_avg", "exp_avg_sq", "lr"})."""
+        if "param_groups" not in sd:                                       # legacy flat layout
+            self._hyper[1] = float(int(sd["step"]))
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.lr = sd.get("lr", self.lr)
+            return
+        ids = [i for g in sd["param_groups"] for i in g["params"]]
+        if len(ids) != len(self.params):
+            raise ValueError(f"FusedAdam.load_state_dict: checkpoint has {len(ids)} parameters, this optimizer {len(self.params)}")
+        state, steps, off = sd["state"], set(), 0
+        with torch.no_grad():
+            for i, p in zip(ids, self.params):
+                k = p.numel()
+                st = state.get(i)
+                if st is None:                                             # parameter never stepped (torch keeps no state for it)
+                    self.exp_avg[off:off + k].zero_()
+                    self.exp_avg_sq[off:off + k].zero_()
+                else:
+                    if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                        raise ValueError(f"FusedAdam.load_state_dict: parameter {i} has shape {tuple(p.shape)}, "
+                                         f"checkpoint {tuple(st['exp_avg'].shape)}")
+                    self.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    self.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(int(float(st["step"])))
+                off += k
+        if len(steps) > 1:
+            raise ValueError(f"FusedAdam.load_state_dict: parameters carry different step counts {sorted(steps)}; "
+                             "one flat launch has one bias correction")
+        self._hyper[1] = float(steps.pop() if steps else 0)
+        g0 = sd["param_groups"][0]
+        self.lr = float(g0.get("lr", self.lr))
+        self.betas = tuple(g0.get("betas", self.betas))
+        self.eps = float(g0.get("eps", self.eps))
+        self.weight_decay = float(g0.get("weight_decay", self.weight_decay))
+
+    @property
+    def param_groups(self):
+        """Read/write view for schedulers that set `group["lr"]` (normalizing_flow/trainer.py:119-120): assignments are picked up by
+        the next step()."""
+        return [_Group(self)]
+
+
+class _Group(dict):
+    def __init__(self, opt):
+        super().__init__(opt._param_group())
+        self["params"] = opt.params
+        self._opt = opt
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        if k == "lr" and hasattr(self, "_opt"):
+            self._opt.lr = float(v)

@@ -1,7 +1,7 @@
 """Base classes of the flow API — mirrors the reference's normalizing_flow/base.py:9-83.
 
-Differences that matter on MI355X: the device is `cuda:LOCAL_RANK` (one process per GPU) instead of the
-reference's process-wide "cuda"; modules can be constructed on a CPU-only host (state-dict work), but every
+Differences that matter on MI355X: the device is `cuda:LOCAL_RANK` (one process per GPU, made current on first use)
+instead of the reference's process-wide "cuda"; modules can be constructed on a CPU-only host (state-dict work), but every
 compute method needs the GPU + the HIP library and raises otherwise.
 """
 import os
@@ -14,9 +14,20 @@ from torch import Tensor
 
 
 def default_device() -> torch.device:
-    if torch.cuda.is_available():
-        return torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
-    return torch.device("cpu")
+    """The reference captures a process-wide "cuda" (= the current device) at import (base.py:18).  Here: one process per
+    GPU.  Under a launcher (LOCAL_RANK set) the rank's GPU is made the CURRENT device the first time a module is built, so a
+    reference-style script that never calls torch.cuda.set_device() still gets its tensors and its kernel launches on the
+    same GPU (the C ABI queues on the current device's stream and nfdp_hip refuses tensors of any other device).  Without a
+    launcher it is whatever device is current, like the reference."""
+    if not torch.cuda.is_available():
+        return torch.device("cpu")
+    lr = os.environ.get("LOCAL_RANK")
+    if lr is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    idx = int(lr) % max(torch.cuda.device_count(), 1)
+    if torch.cuda.current_device() != idx:
+        torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)
 
 
 def acc_in(t: Optional[Tensor]) -> Optional[Tensor]:
@@ -33,7 +44,18 @@ def acc_out(orig: Optional[Tensor], work: Optional[Tensor]) -> Optional[Tensor]:
     return orig
 
 
-class Transform(nn.Module, ABC):
+class _EpochOnApply:
+    """Module._apply (.to / .cuda / .float ...) re-creates or rewrites parameter storage: the kernel-layout weight caches are
+    keyed on (storage address, tensor version, parameter epoch), so bump the epoch and let them rebuild."""
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        import nfdp_hip
+        nfdp_hip.bump_param_epoch()
+        return out
+
+
+class Transform(_EpochOnApply, nn.Module, ABC):
     """Invertible transformation f: x -> y  (reference base.py:9-46)."""
 
     def __init__(self):
@@ -49,7 +71,7 @@ class Transform(nn.Module, ABC):
         ...
 
 
-class Prior(nn.Module, ABC):
+class Prior(_EpochOnApply, nn.Module, ABC):
     """Prior distribution  (reference base.py:49-83)."""
 
     def __init__(self):

@@ -24,17 +24,29 @@ def grad_needed(module: torch.nn.Module) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters())
 
 
-# Parameter gradients straight into .grad: where a parameter already holds a dense fp32 .grad (FusedAdam's views into its flat gradient
-# buffer, or grads kept by zero_grad(set_to_none=False)) the launch that finishes a parameter gradient ADDS it there and the node returns
-# None for it, instead of handing autograd a temporary that AccumulateGrad adds with one more elementwise launch per parameter (~640 per
-# step of Glow L3 K16, plus the flip / permute copies that brought the GEMM results into OIHW order).  Not taken for a parameter with
-# tensor hooks or post-accumulate-grad hooks (a gradient reducer must see the accumulation), nor when .grad is None - so
-# torch.autograd.grad() on parameters that hold a .grad needs DIRECT_PARAM_GRADS = False.
+# Parameter gradients straight into .grad: where a parameter already holds a dense fp32 .grad the launch that finishes a parameter
+# gradient ADDS it there and the node returns None for it, instead of handing autograd a temporary that AccumulateGrad adds with one
+# more elementwise launch per parameter (~640 per step of Glow L3 K16, plus the flip / permute copies that brought the GEMM results
+# into OIHW order).  Because the node returns None, the parameter's AccumulateGrad node never runs - and neither does anything hanging
+# on it.  Hooks registered from Python (tensor hooks, post-accumulate-grad hooks: nfdp_hip.dist.BucketedGradAllReduce) are visible and
+# switch the parameter back to the ordinary path, but torch's DistributedDataParallel registers its reducer hooks in C++ on the
+# AccumulateGrad node, where they cannot be seen.  The path is therefore OPT-IN per parameter: only the owner of the gradient buffer
+# marks a parameter (`enable_direct_grads`; nfdp_hip.optim.FusedAdam(direct_grads=...) does, and by default only when no process group
+# with more than one rank exists), stating that no external reducer depends on AccumulateGrad.  DIRECT_PARAM_GRADS = False switches it
+# off globally (torch.autograd.grad() on parameters that hold a .grad needs that).
 DIRECT_PARAM_GRADS = True
+
+
+def enable_direct_grads(params, on: bool = True) -> None:
+    """Mark parameters whose gradients the backward launches may add straight into their dense .grad (see above)."""
+    for p in params:
+        p._nfdp_direct_grad = bool(on)
 
 
 def _slot(p):
     if not DIRECT_PARAM_GRADS or not isinstance(p, torch.nn.Parameter) or not p.requires_grad:
+        return None
+    if not getattr(p, "_nfdp_direct_grad", False):
         return None
     g = p.grad
     if g is None or g.dtype != torch.float32 or g.shape != p.shape or not g.is_contiguous() or not g.is_cuda:

@@ -38,23 +38,32 @@ class ActNorm(Transform):
         self.scale = nn.Parameter(torch.zeros(size=(in_channels, 1, 1), device=self.device))
         self.bias = nn.Parameter(torch.zeros(size=(in_channels, 1, 1), device=self.device))
         self.register_buffer("is_initialized", torch.tensor(0, dtype=torch.uint8, device=self.device))
-        self._init_cache: Optional[bool] = None      # host mirror of the flag: the reference syncs (.item()) every call
+        # host mirror of the flag (the reference syncs with .item() on every call): (buffer identity, buffer version, value).
+        # copy_/fill_ on the buffer, load_state_dict, .to() and re-assigning the attribute all change the key; a write through
+        # `.is_initialized.data` does not (it has its own version counter) - call reset_init_cache() after one.
+        self._init_cache = None
+
+    def reset_init_cache(self) -> None:
+        self._init_cache = None
 
     def _load_from_state_dict(self, *args, **kwargs):
         self._init_cache = None
         return super()._load_from_state_dict(*args, **kwargs)
 
     def initialized(self) -> bool:
-        if self._init_cache is None:
-            self._init_cache = bool(self.is_initialized.item() != 0)   # one sync per (re)load, not per call
-        return self._init_cache
+        buf = self.is_initialized
+        key = (id(buf), buf.data_ptr(), buf._version)
+        if self._init_cache is None or self._init_cache[0] != key:
+            self._init_cache = (key, bool(buf.item() != 0))           # one sync per (re)load, not per call
+        return self._init_cache[1]
 
     @torch.no_grad()
     def init_from(self, xh: Tensor) -> None:
         """scale = -log(std+1e-6), bias = -mean over (B,H,W)  (reference transforms.py:74-78)."""
         K.actnorm_init(xh, self.scale.view(-1), self.bias.view(-1))
         self.is_initialized.fill_(1)
-        self._init_cache = True
+        buf = self.is_initialized
+        self._init_cache = ((id(buf), buf.data_ptr(), buf._version), True)
 
     def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor]) -> Tensor:
         if not self.initialized():

@@ -90,3 +90,111 @@ def test_no_oracle_import_in_product():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(d, f)).read()
                 assert "oracle" not in src.lower() or f == "build.py", f"{f} mentions the oracle"
+
+
+def test_tensor_of_another_device_is_refused(monkeypatch):
+    """Every launch goes to the CURRENT device's stream: a pointer of a tensor that lives on another GPU must raise (a rank
+    that never called torch.cuda.set_device would otherwise queue kernels on device 0 against memory of device N)."""
+    class Dev:
+        def __init__(self, i): self.index, self.type = i, "cuda"
+        def __str__(self): return f"cuda:{self.index}"
+
+    class FakeTensor:
+        is_cuda = True
+        def __init__(self, i): self.device = Dev(i)
+        def numel(self): return 4
+        def data_ptr(self): return 0x1000
+
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    assert nfdp_hip._ptr(FakeTensor(0)) == 0x1000
+    with pytest.raises(nfdp_hip.NfdpError, match="current device is cuda:0"):
+        nfdp_hip._ptr(FakeTensor(1))
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 1)
+    assert nfdp_hip._ptr(FakeTensor(1)) == 0x1000
+
+
+def test_default_device_makes_the_ranks_gpu_current(monkeypatch):
+    """Under a launcher (LOCAL_RANK set) building a module selects the rank's GPU as the current device, like the reference's
+    process-wide "cuda" but per process; without one it is the current device."""
+    from normalizing_flow import base
+    calls = []
+    state = {"cur": 0}
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: state["cur"])
+    monkeypatch.setattr(torch.cuda, "set_device", lambda i: (calls.append(i), state.update(cur=i)))
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert base.default_device() == torch.device("cuda", 3) and calls == [3]
+    assert base.default_device() == torch.device("cuda", 3) and calls == [3]       # already current: not set again
+    monkeypatch.delenv("LOCAL_RANK")
+    state["cur"] = 5
+    assert base.default_device() == torch.device("cuda", 5) and calls == [3]
+
+
+def test_fused_adam_state_dict_is_torch_adam_layout():
+    """FusedAdam.state_dict()/load_state_dict() interchange with torch.optim.Adam's (the reference checkpoints hold
+    optim.state_dict(), prior.py:113, and resume with optimizer.load_state_dict, trainer.py:115)."""
+    from nfdp_hip.optim import FusedAdam
+    torch.manual_seed(0)
+    mk = lambda: [torch.nn.Parameter(torch.randn(4, 3, 1, 1)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
+    pt, pf = mk(), mk()
+    ref = torch.optim.Adam(pt, lr=3e-4)
+    assert ref.state_dict()["state"] == {} and FusedAdam(mk()).state_dict()["state"] == {}
+    for _ in range(3):
+        for p in pt:
+            p.grad = torch.randn_like(p)
+        ref.step()
+    sd = ref.state_dict()
+    opt = FusedAdam(clipped=pf[:2], unclipped=pf[2:], lr=1e-3)
+    opt.load_state_dict(sd)
+    assert opt.lr == 3e-4 and opt.step_count == 3
+    back = opt.state_dict()
+    assert set(back) == {"state", "param_groups"} and set(back["state"]) == {0, 1, 2}
+    for i in range(3):
+        assert float(back["state"][i]["step"]) == 3.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert back["state"][i][k].shape == sd["state"][i][k].shape
+            assert torch.equal(back["state"][i][k], sd["state"][i][k])
+    g = back["param_groups"][0]
+    assert g["params"] == [0, 1, 2] and g["lr"] == 3e-4 and tuple(g["betas"]) == (0.9, 0.999) and g["weight_decay"] == 0.0
+    fresh = torch.optim.Adam(mk(), lr=1.0)
+    fresh.load_state_dict(back)                                       # torch accepts what FusedAdam wrote
+    assert fresh.state_dict()["param_groups"][0]["lr"] == 3e-4
+    assert torch.equal(fresh.state_dict()["state"][1]["exp_avg"], sd["state"][1]["exp_avg"])
+    # the reference's resume loop (trainer.py:119-120) sets the learning rate through param_groups
+    for group in opt.param_groups:
+        group["lr"] = 5e-5
+    assert opt.lr == 5e-5
+    # defaults of the optimizers init_optimizer builds (utils.py:131-134): Adam 0, AdamW 0.01
+    assert FusedAdam(mk()).weight_decay == 0.0 and FusedAdam(mk(), adamw=True).weight_decay == 0.01
+    # legacy flat layout still loads
+    opt.load_state_dict({"step": 7, "exp_avg": torch.zeros(opt.n), "exp_avg_sq": torch.ones(opt.n), "lr": 1e-3})
+    assert opt.step_count == 7 and opt.lr == 1e-3
+    with pytest.raises(ValueError):
+        opt.load_state_dict(torch.optim.Adam(mk()[:2]).state_dict())
+
+
+def test_actnorm_init_mirror_follows_the_buffer():
+    """The host mirror of ActNorm.is_initialized is keyed on the buffer (identity, storage, version): fill_/copy_, load_state_dict
+    and re-assigning the buffer are all seen without a reset call."""
+    from normalizing_flow.transforms import ActNorm
+    a = ActNorm(4)
+    assert a.initialized() is False
+    a.is_initialized.fill_(1)
+    assert a.initialized() is True
+    a.is_initialized = torch.tensor(0, dtype=torch.uint8)
+    assert a.initialized() is False
+    sd = a.state_dict()
+    sd["is_initialized"] = torch.tensor(1, dtype=torch.uint8)
+    a.load_state_dict(sd)
+    assert a.initialized() is True
+    a.is_initialized.data.zero_()                                     # invisible to version counters: documented reset
+    a.reset_init_cache()
+    assert a.initialized() is False
+
+
+def test_module_apply_bumps_the_parameter_epoch():
+    from normalizing_flow.transforms import ActNorm
+    e0 = nfdp_hip.param_epoch()
+    ActNorm(4).float()
+    assert nfdp_hip.param_epoch() > e0

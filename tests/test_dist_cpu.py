@@ -100,8 +100,26 @@ def _grad_worker(rank, world, port, out):
     ((model(x) - y) ** 2).mean().backward()                         # equal shards: mean of shard means = global mean
     ref = [p.grad.clone() for p in model.parameters()]
     err = max(float((a - b).abs().max()) for a, b in zip(mine, ref))
+    # two backward passes before one finish() (gradient accumulation): buckets launched by the first pass are reduced again
+    for p in params:
+        p.grad = None
+    ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
+    ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
+    red.finish()
+    err2 = max(float((p.grad - 2 * b).abs().max()) for p, b in zip(model.parameters(), ref))
+    # FlatGradAllReduce: in place on FusedAdam's flat gradient buffer, no hooks
+    red.remove()
+    from nfdp_hip.optim import FusedAdam
+    from nfdp_hip.dist import FlatGradAllReduce
+    opt = FusedAdam(model.parameters(), lr=1e-3, direct_grads=True)
+    flat = FlatGradAllReduce(opt, bucket_bytes=256)
+    opt.zero_grad()
+    ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
+    flat.finish()
+    err3 = max(float((p.grad - b).abs().max()) for p, b in zip(model.parameters(), ref))
+    auto = FusedAdam([torch.nn.Parameter(torch.ones(2))]).direct_grads      # "auto" under a 2-rank group: off
     if rank == 0:
-        out.put(err)
+        out.put((err, err2, err3, auto))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -113,8 +131,9 @@ def test_world2_gloo_bucketed_gradient_allreduce():
     procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    err = q.get(timeout=120)
+    err, err2, err3, auto = q.get(timeout=120)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert err <= 1e-6
+    assert err <= 1e-6 and err2 <= 2e-6 and err3 <= 1e-6
+    assert auto is False

@@ -572,6 +572,7 @@ def test_parameter_gradients_added_straight_into_grad(compute):
         return loss.detach()
 
     backward()                                                        # data-dependent init out of the way; .grad = None so far
+    training.enable_direct_grads(params)                              # opt-in: what FusedAdam(direct_grads=True) does
     def run(direct, times=1):
         training.DIRECT_PARAM_GRADS = direct
         for p in params:
@@ -595,6 +596,16 @@ def test_parameter_gradients_added_straight_into_grad(compute):
         hooked, _ = run(True)
         h.remove()
         assert len(seen) == 1 and all(torch.equal(a, b) for a, b in zip(hooked, ref))
+        # unmarked parameters (the default: an external reducer such as torch DDP may hang on AccumulateGrad) keep the autograd
+        # route: every parameter's AccumulateGrad node runs
+        training.enable_direct_grads(params, False)
+        fired = []
+        accs = [p.view_as(p).grad_fn.next_functions[0][0] for p in params]
+        hs = [a.register_hook(lambda *_: fired.append(1)) for a in accs]   # node-level hooks, like DDP's (invisible to _slot)
+        unmarked, _ = run(True)
+        for h in hs:
+            h.remove()
+        assert len(fired) == len(params) and all(torch.equal(a, b) for a, b in zip(unmarked, ref))
     finally:
         training.DIRECT_PARAM_GRADS = True
 
