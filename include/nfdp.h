@@ -161,6 +161,12 @@ size_t nfdp_coupling_fused_packed_bytes(int C);
 int nfdp_coupling_fused_pack(const float* w1, const float* scale1, const float* bias1, const float* w2,
                              const float* scale2, const float* bias2, const float* w3, const float* bias3,
                              const float* logs3, void* packed, int C, nfdp_stream_t stream);
+/* fold_scales != 0: as nfdp_coupling_fused_pack (inference images: exp(scale) of each hidden ActNorm folded into the next GEMM's
+ * weights).  fold_scales == 0: the image nfdp_level_fused_train_bf16 takes - plain weights, the kernel's epilogues compute
+ * (acc + bias) * exp(scale), the hidden activation the backward pass reads (utils.py:67-69). */
+int nfdp_coupling_fused_pack_ex(const float* w1, const float* scale1, const float* bias1, const float* w2,
+                                const float* scale2, const float* bias2, const float* w3, const float* bias3,
+                                const float* logs3, void* packed, int C, int fold_scales, nfdp_stream_t stream);
 int nfdp_coupling_fused_bf16(float* x, const void* packed, int B, int H, int W, int C, double* ldj,
                              const float* ldj_const, int inverse, nfdp_stream_t stream);
 /* One whole flow step in one launch (StepFlow.transform / invert, glow.py:46-48, :60-62): the flow head
@@ -179,6 +185,22 @@ int nfdp_stepflow_fused_bf16(float* x, const void* packed, int B, int H, int W, 
 int nfdp_level_fused_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
                           const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
                           int inverse, nfdp_stream_t stream);
+/* The same launch as the FORWARD of a training step (normalizing_flow/trainer.py:155: flow.transform under autograd): besides
+ * updating x in place it writes, for every flow i of the level, what the backward pass reads instead of recomputing or keeping the
+ * per-op intermediates of an unfused forward -
+ *   xpre [n_flows][B][H*W][C] fp32   flow-state tile entering the flow (input of ActNorm, transforms.py:80)
+ *   ypost[n_flows][B][H*W][C] fp32   after ActNorm + 1x1 conv: the coupling layer's input (transforms.py:179)
+ *   hout [n_flows][B][H*W][C] fp32   output of the coupling network's ZeroConv2d = (log_s | t) (utils.py:43-44)
+ *   y1, y2 [n_flows][Bpad][H*W][512] bf16   the two hidden activations after ActNorm + ReLU (utils.py:83-87), natural channel order;
+ *          Bpad = B rounded up to a multiple of nfdp_level_fused_train_group(H, W, C) (whole workgroups: rows of the images past
+ *          B are written with unspecified values)
+ * - straight from the registers / LDS tile of the fused kernel; `packed` images must be built with fold_scales = 0 (hidden stores are issued between the MFMAs of the last GEMM and
+ * counted in the weight ring's vmcnt waits).  ldj[b] += sum over the flows of sum log(s+1e-6) ONLY: the weight-only terms
+ * (H*W*sum(scale), H*W*log|det W|) belong to the caller's autograd graph.  n_flows <= 32.  Forward only. */
+int nfdp_level_fused_train_group(int H, int W, int C);
+int nfdp_level_fused_train_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
+                                const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
+                                float* xpre, float* ypost, float* hout, void* y1, void* y2, nfdp_stream_t stream);
 /* ldj[b] += (double)(hw * (float)sum(v[0..n_sum)))  (fp32 product): the standalone ActNorm / InvConv2d log-det terms. */
 int nfdp_ldj_add_scaled_f32(double* ldj, int B, const float* v, int n_sum, float hw, nfdp_stream_t stream);
 /* out2[0] = hw*sum(scale[0..C)) (transforms.py:81), out2[1] = hw*logabsdet[0] (transforms.py:131), fp32: the two

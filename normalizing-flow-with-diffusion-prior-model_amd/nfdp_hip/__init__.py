@@ -480,13 +480,16 @@ def coupling_fused_supported(h: int, w: int, c: int, n_features: int) -> bool:
     return bool(lib().nfdp_coupling_fused_supported(h, w, c, n_features))
 
 
-def coupling_fused_pack(w1, s1, b1, w2, s2, b2, w3, b3, l3) -> torch.Tensor:
+def coupling_fused_pack(w1, s1, b1, w2, s2, b2, w3, b3, l3, fold: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fold=True: the inference image (hidden ActNorm scales folded into the next GEMM's weights); fold=False: the image of the
+    training forward (level_fused_train).  `out`: re-use an existing image buffer."""
     c = w3.shape[0]
-    packed = torch.empty(lib().nfdp_coupling_fused_packed_bytes(c), device=w1.device, dtype=torch.uint8)
+    nbytes = lib().nfdp_coupling_fused_packed_bytes(c)
+    packed = out if out is not None and out.numel() == nbytes else torch.empty(nbytes, device=w1.device, dtype=torch.uint8)
     for t in (w1, s1, b1, w2, s2, b2, w3, b3, l3):
         _need(t, torch.float32, "coupling_fused_pack"); _dense(t, "coupling_fused_pack")
-    _call("nfdp_coupling_fused_pack", _ptr(w1), _ptr(s1), _ptr(b1), _ptr(w2), _ptr(s2), _ptr(b2), _ptr(w3), _ptr(b3),
-          _ptr(l3), _ptr(packed), c, _stream())
+    _call("nfdp_coupling_fused_pack_ex", _ptr(w1), _ptr(s1), _ptr(b1), _ptr(w2), _ptr(s2), _ptr(b2), _ptr(w3), _ptr(b3),
+          _ptr(l3), _ptr(packed), c, int(fold), _stream())
     return packed
 
 
@@ -534,6 +537,36 @@ def level_fused(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torc
     _call("nfdp_level_fused_bf16", _ptr(xh), b, h, wd, c, n, tab(packed), tab(scales), tab(biases), tab(ws), _ptr(ldj),
           int(inverse), _stream(), label=f"level_fused<{c},{wd}> x{n} {'inv' if inverse else 'fwd'}", flops=flops,
           nbytes=8.0 * xh.numel())
+
+
+def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torch.Tensor]):
+    """Training forward of a whole Glow level in ONE persistent launch (nfdp_level_fused_train_bf16): xh [B,H,W,C] is updated in
+    place; ldj[b] += the flows' per-sample coupling log-dets only.  -> (xpre, ypost, hout [n,B,H,W,C] fp32; y1, y2
+    [n,Bpad,H,W,512] bf16): per flow the tile before / after the flow head, the zero conv's output and the two hidden activations."""
+    _need(xh, torch.float32, "level_fused_train"); _dense(xh, "level_fused_train")
+    b, h, wd, c = xh.shape
+    n = len(packed)
+    if not (len(scales) == len(biases) == len(ws) == n):
+        raise ValueError("level_fused_train: pointer tables of different lengths")
+    if ldj is not None:
+        _need(ldj, torch.float64, "level_fused_train ldj")
+    grp = lib().nfdp_level_fused_train_group(h, wd, c)
+    if grp <= 0:
+        raise NfdpError(f"level_fused_train: unsupported geometry {h}x{wd}x{c}")
+    bpad = (b + grp - 1) // grp * grp
+    dev = xh.device
+    xpre = torch.empty((n, b, h, wd, c), device=dev, dtype=torch.float32)
+    ypost = torch.empty((n, b, h, wd, c), device=dev, dtype=torch.float32)
+    hout = torch.empty((n, b, h, wd, c), device=dev, dtype=torch.float32)
+    y1 = torch.empty((n, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
+    y2 = torch.empty((n, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
+    tab = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    ch = c // 2
+    flops = n * 2.0 * b * h * wd * (9 * ch * 512 + 512 * 512 + 9 * 512 * c + c * c)
+    _call("nfdp_level_fused_train_bf16", _ptr(xh), b, h, wd, c, n, tab(packed), tab(scales), tab(biases), tab(ws), _ptr(ldj),
+          _ptr(xpre), _ptr(ypost), _ptr(hout), _ptr(y1), _ptr(y2), _stream(), label=f"level_fused_train<{c},{wd}> x{n}", flops=flops,
+          nbytes=8.0 * xh.numel() + 12.0 * n * xh.numel() + 2048.0 * n * bpad * h * wd)
+    return xpre, ypost, hout, y1, y2
 
 
 def ldj_add_scaled(ldj: torch.Tensor, v: torch.Tensor, n_sum: int, hw: float):

@@ -329,7 +329,8 @@ def test_glow_training_in_bf16_mode_tracks_the_fp32_gradients():
     loss = calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0)
     loss.backward()
     labels = [e["label"] for e in K.stop_trace()]
-    assert any(lb.startswith("conv_wgrad_bf16") for lb in labels) and any("conv_kernel<bf16" in lb for lb in labels)
+    assert any(lb.startswith("conv_wgrad_bf16") for lb in labels)
+    assert any("conv_kernel<bf16" in lb or lb.startswith("level_fused_train") for lb in labels)
     assert_close(loss, bpd_ref.detach(), 2e-3, "bits/dim (bf16 coupling networks)")
 
     def fro(a, b):
@@ -632,3 +633,54 @@ def test_batched_weight_packing_matches_the_single_launches():
         assert pb.matches()
         ws[0].data = ws[0].data.clone()
         assert not pb.matches()
+
+
+@pytest.mark.parametrize("B,direct", [(8, False), (3, True), (37, False)])
+def test_fused_level_training_forward_matches_the_per_flow_nodes(B, direct):
+    """training.FUSED_TRAIN_FORWARD: the forward of every Glow level is ONE persistent launch (nfdp_level_fused_train_bf16) that
+    writes out what the backward needs; the per-flow autograd nodes (im2col + three GEMMs + coupling per flow) are the yardstick.
+    Same rounding points (bf16 MFMA inputs, fp32 accumulation and flow state), different summation order inside the GEMMs: latents,
+    bits/dim and every parameter gradient agree to bf16 round-off; ragged batches exercise the padded rows of the saved hidden
+    activations (8x8 / 4x4 levels own 2 / 8 images per workgroup)."""
+    from normalizing_flow import calculate_loss, initialize_with_zeros, training
+    from tests.golden.synth import DEEP
+    flow, prior, _, _ = build(3, 3, 2, 51)
+    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 51, DEEP)) for k, v in flow.state_dict().items()})
+    prior.load_state_dict({k: T(synth_tensor(k, v.shape, 52, DEEP)) for k, v in prior.state_dict().items()})
+    flow.set_compute("bf16")
+    x = (T(synth_input("train_x", (B, 3, 32, 32), 8)) * 0.4).to(DEV)
+    params = list(flow.parameters()) + list(prior.parameters())
+    names = [n for n, _ in flow.named_parameters()] + [n for n, _ in prior.named_parameters()]
+    if direct:
+        training.enable_direct_grads(params)
+
+    def run(fused):
+        training.FUSED_TRAIN_FORWARD = fused
+        for p in params:
+            p.grad = torch.zeros_like(p) if direct else None
+        ll, logp = initialize_with_zeros(2, B, torch.device(DEV))
+        K.start_trace()
+        latents, ll, logp = flow.transform(x, ll, logp)
+        loss = calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0)
+        loss.backward()
+        labels = [e["label"] for e in K.stop_trace()]
+        return [z.detach().clone() for z in latents], loss.detach().clone(), [p.grad.clone() for p in params], labels
+    try:
+        z0, l0, g0, lab0 = run(False)
+        z1, l1, g1, lab1 = run(True)
+        z2, l2, g2, _ = run(True)
+    finally:
+        training.FUSED_TRAIN_FORWARD = True
+        training.enable_direct_grads(params, False)
+    n_fused = sum(B * hw >= 512 for hw in (256, 64, 16))             # the fused-epilogue data-gradient GEMM of the backward needs 512 pixels
+    assert sum(lb.startswith("level_fused_train") for lb in lab1) == n_fused and not any(lb.startswith("level_fused_train") for lb in lab0)
+    assert len(lab1) < len(lab0)
+    for a, b in zip(z1, z0):
+        assert_close(a, b, 2e-2, "latents")                          # bf16 hidden activations: 8-bit mantissa
+    assert_close(l1, l0, 1e-4, "bits/dim")
+    fro = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    errs = {n: fro(a, b) for n, a, b in zip(names, g1, g0) if float(b.abs().max()) > 0}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print("fused vs per-flow training forward: median rel Frobenius err", float(np.median(list(errs.values()))), "worst", worst)
+    assert worst[1] <= 5e-2 and float(np.median(list(errs.values()))) <= 5e-3, worst
+    assert torch.equal(l1, l2) and all(torch.equal(a, b) for a, b in zip(g1, g2))      # deterministic
