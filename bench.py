@@ -177,7 +177,7 @@ def train_bench(args, rank, world, device, barrier):
     reducer = FlatGradAllReduce(opt) if world > 1 else None
     n_pixel = 32 * 32 * 3.0
 
-    def train_step():
+    def fwd_bwd():
         x = KH.as_nchw(KH.preprocess_u8(u8_d, noise_d, 5))
         ll, logp = initialize_with_zeros(2, args.batch, device)
         latents, ll, logp = flow.transform(x, ll, logp)
@@ -185,17 +185,23 @@ def train_bench(args, rank, world, device, barrier):
         loss = calculate_loss(ll + logp, 32.0, n_pixel)
         opt.zero_grad()
         loss.backward()
+        return loss.detach()
+
+    def train_step():
+        loss = fwd_bwd()
         if reducer is not None:
             reducer.finish()                   # averaged gradients before the clips: single-process semantics
         opt.step()                             # clip_grad_value_(1) + clip_grad_norm_(1) + Adam, two launches
-        return loss.detach()
+        return loss
 
     for _ in range(max(args.warmup, 1)):
         loss = train_step()
-    # One process, no collective inside the step: capture forward + backward + optimizer (~1600 kernel launches through the
-    # C ABI plus torch's glue) once as a hipGraph and replay it, so the host issues one call per step.
-    graphed = world == 1 and not args.no_graph
-    if graphed:
+    # The step is ~1400 kernel launches through the C ABI plus torch's glue: captured once as hipGraphs and replayed, so the host
+    # issues one call per step (eager launching takes ~37 ms of host time for 24 ms of kernels).  One process: the whole step is one
+    # graph.  Several ranks: forward + backward is one graph, the optimizer another, and the RCCL all-reduce of the flat gradient
+    # buffer runs between the two replays, outside any capture.
+    graphed = not args.no_graph
+    if graphed and world == 1:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
@@ -203,6 +209,20 @@ def train_bench(args, rank, world, device, barrier):
         def run():
             graph.replay()
             KH.bump_param_epoch()          # the replay updated the parameters: eager code afterwards must rebuild its weight caches
+        run()
+        loss = static_loss
+    elif graphed:
+        torch.cuda.synchronize()
+        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fb):
+            static_loss = fwd_bwd()
+        with torch.cuda.graph(g_opt):
+            opt.step()
+        def run():
+            g_fb.replay()
+            reducer.finish()
+            g_opt.replay()
+            KH.bump_param_epoch()
         run()
         loss = static_loss
     else:
@@ -226,7 +246,8 @@ def train_bench(args, rank, world, device, barrier):
             "config": {"workload": f"Glow L={args.L} K={args.K} training step on 32x32x3, 5-bit, batch={args.batch}/GPU "
                                    "(BASELINE configs[2] shape; forward, bits/dim, backward, clip_grad_value_/norm_ 1, Adam lr 1e-4 - the synthetic trained-like weights diverge at the reference's 1e-3)",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "optimizer": "nfdp fused clip+Adam (flat buffers)", "launch": "hipGraph replay" if graphed else "eager",
+                       "optimizer": "nfdp fused clip+Adam (flat buffers)",
+                       "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (forward+backward | all-reduce | optimizer)") if graphed else "eager",
                        "gradient_allreduce": "in place on the flat gradient buffer, 32 MiB slices, after backward" if world > 1 else "none"},
             "loss_bits_per_dim": round(float(loss), 6) if bool(torch.isfinite(loss)) else None,
             "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)

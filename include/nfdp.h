@@ -191,9 +191,10 @@ int nfdp_level_fused_bf16(float* x, int B, int H, int W, int C, int n_flows, con
  *   xpre [n_flows][B][H*W][C] fp32   flow-state tile entering the flow (input of ActNorm, transforms.py:80)
  *   ypost[n_flows][B][H*W][C] fp32   after ActNorm + 1x1 conv: the coupling layer's input (transforms.py:179)
  *   hout [n_flows][B][H*W][C] fp32   output of the coupling network's ZeroConv2d = (log_s | t) (utils.py:43-44)
- *   y1, y2 [n_flows][Bpad][H*W][512] bf16   the two hidden activations after ActNorm + ReLU (utils.py:83-87), natural channel order;
- *          Bpad = B rounded up to a multiple of nfdp_level_fused_train_group(H, W, C) (whole workgroups: rows of the images past
- *          B are written with unspecified values)
+ *   y1, y2 [n_flows][Bpad * H*W pixels x 512] bf16   the two hidden activations after ActNorm + ReLU (utils.py:83-87) in the BLOCKED
+ *          layout: 32-pixel tiles of [hidden block 16][k-step 2][half 2][pixel 32][8 channels], channel = 32 hb + 16 s + 8 g + e (the
+ *          MFMA B-fragment image: every store is one contiguous KiB); Bpad = B rounded up to a multiple of
+ *          nfdp_level_fused_train_group(H, W, C) (whole workgroups: tiles of the images past B hold unspecified finite values)
  * - straight from the registers / LDS tile of the fused kernel; `packed` images must be built with fold_scales = 0 (hidden stores are issued between the MFMAs of the last GEMM and
  * counted in the weight ring's vmcnt waits).  ldj[b] += sum over the flows of sum log(s+1e-6) ONLY: the weight-only terms
  * (H*W*sum(scale), H*W*log|det W|) belong to the caller's autograd graph.  n_flows <= 32.  Forward only. */
@@ -201,6 +202,18 @@ int nfdp_level_fused_train_group(int H, int W, int C);
 int nfdp_level_fused_train_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
                                 const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
                                 float* xpre, float* ypost, float* hout, void* y1, void* y2, nfdp_stream_t stream);
+/* Backward of the coupling network's data path in one launch (autograd of utils.py:83-89 w.r.t. its input, training step
+ * normalizing_flow/trainer.py:164): dc3 [B][H*W][C] fp32 = gradient at the ZeroConv2d's raw conv output (after its scale backward);
+ * y1, y2 = the hidden activations saved by nfdp_level_fused_train_bf16 (blocked layout, Bpad images).  Writes dc2, dc1 (same layout as
+ * y2, y1: gradients at the two hidden convs' raw outputs, i.e. after the ReLU mask and the ActNorm scale) for the weight-gradient
+ * GEMMs, and ADDS the data gradient of the network's input into dx[..., 0:C/2] (dx [B][H*W][C] fp32).  `packed`
+ * (nfdp_coupling_bwd_fused_packed_bytes(C) bytes): nfdp_coupling_bwd_fused_pack of w1 [512,C/2,3,3], scale1 [512], w2 [512,512,1,1],
+ * scale2 [512], w3 [C,512,3,3].  Geometries: those of nfdp_coupling_fused_supported; others return NFDP_EUNSUPPORTED. */
+size_t nfdp_coupling_bwd_fused_packed_bytes(int C);
+int nfdp_coupling_bwd_fused_pack(const float* w1, const float* scale1, const float* w2, const float* scale2, const float* w3,
+                                 void* packed, int C, nfdp_stream_t stream);
+int nfdp_coupling_bwd_fused_bf16(const float* dc3, float* dx, const void* packed, const void* y1, const void* y2, void* dc1,
+                                 void* dc2, int B, int H, int W, int C, nfdp_stream_t stream);
 /* ldj[b] += (double)(hw * (float)sum(v[0..n_sum)))  (fp32 product): the standalone ActNorm / InvConv2d log-det terms. */
 int nfdp_ldj_add_scaled_f32(double* ldj, int B, const float* v, int n_sum, float hw, nfdp_stream_t stream);
 /* out2[0] = hw*sum(scale[0..C)) (transforms.py:81), out2[1] = hw*logabsdet[0] (transforms.py:131), fp32: the two
@@ -322,6 +335,19 @@ int nfdp_conv_wgrad_f32_ex(const float* x, int x_ld, const float* dy, int dy_ld,
                            float* dw, void* ws, int out_form, int out_c, int accumulate, nfdp_stream_t stream);
 int nfdp_conv_wgrad_bf16_ex(const void* x, int x_dtype, int x_ld, const void* dy, int dy_dtype, int dy_ld, int B, int H, int W,
                             int Cin, int Cout, int k, float* dw, void* ws, int out_form, int out_c, int accumulate, nfdp_stream_t stream);
+/* The weight gradient of a 1x1 conv on bf16 operands (x [npix][Cin], dy [npix][Cout], rows 16-byte aligned, npix a multiple of 64) for
+ * a layer y = act((conv(x, W) + bias) * exp(scale)) whose dy is the gradient at the conv's RAW output (mask and scale already applied):
+ * besides dW (out_form 0: [Cout][Cin]; 1: x = im2col rows, dW stored as [Cout][out_c][3][3]) it yields the layer's ActNorm gradients
+ * from the same GEMM, with no further pass over the activations (Conv2dActNorm backward, utils.py:67-69):
+ *   dbias[m]  (+)= sum_p dy[p][m]                                   (ones-fragment MFMAs inside the GEMM)
+ *   dscale[m] (+)= sum_n W[m][n] dW[m][n] + bias[m] * dbias_term     (= sum_p dy_out * y; identity in DESIGN.md)
+ * w: the layer's weight in the layout dW is stored in; accumulate != 0 adds into dw / dscale / dbias.  w == NULL: dW only (any out_form).
+ * layout bit 0 / bit 1: x / dy is a 512-channel tensor in the BLOCKED layout of the fused flow-step kernels (32-pixel tiles of
+ * [hidden block 16][k-step 2][half 2][pixel 32][8 channels]; what nfdp_level_fused_train_bf16 and nfdp_coupling_bwd_fused_bf16
+ * write) instead of [pixel][channel] rows.  ws: nfdp_conv_wgrad_bf16_ws_bytes(1, 1, npix, Cin, Cout, 1) bytes. */
+int nfdp_conv_wgrad_bf16_affine(const void* x, int x_ld, const void* dy, int dy_ld, long npix, int Cin, int Cout, float* dw, void* ws,
+                                int out_form, int out_c, int accumulate, int layout, const float* w, const float* bias, float* dscale,
+                                float* dbias, nfdp_stream_t stream);
 /* wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: nfdp_conv2d_nhwc on pack(wt) is the data gradient of the conv with w. */
 int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int I, int k, nfdp_stream_t stream);
 /* Second half of a narrow 3x3 'same' conv computed as a pointwise GEMM to tap contributions T [B,H,W,9*Co] (column

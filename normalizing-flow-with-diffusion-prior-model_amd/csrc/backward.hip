@@ -30,6 +30,8 @@ struct WgradParams {
     const void* x;       // [B,H,W,Cin] pixel stride x_ld   (fp32; the bf16 kernel also takes bf16)
     const void* dy;      // [B,H,W,Cout] pixel stride dy_ld
     float* ws;           // [ksplit][Mpad][Npad] partial sums
+    int a_blocked = 0, b_blocked = 0;   // wgrad_bf16_dma_kernel: dy / x is a 512-channel tensor in the fused kernels' blocked layout
+    float* ws_db = nullptr;   // optional [ksplit][Mpad]: per-slice column sums of dy (wgrad_bf16_dma_kernel, n-block 0)
     int x_ld, dy_ld, B, H, W, Cin, Cout, k, N;   // N = k*k*Cin
     int mblocks, nblocks, ksplit, Mpad, Npad;
     long npix, px_per_split;
@@ -200,6 +202,84 @@ static void launch_wgrad_reduce(const float* ws, float* dw, int ksplit, int Mpad
         hipLaunchKernelGGL((wgrad_reduce_kernel<64>), dim3(stream_grid(total, 4)), dim3(kBlock), 0, s, ws, dw, ksplit, Mpad, Npad, Cout, o);
     else
         hipLaunchKernelGGL((wgrad_reduce_kernel<8>), dim3(stream_grid(total, 32)), dim3(kBlock), 0, s, ws, dw, ksplit, Mpad, Npad, Cout, o);
+}
+
+// The slice sum for a layer y = act((conv(x, W) + b) * exp(s)) whose raw-output gradient dc is the GEMM's dy operand, one workgroup per
+// output row m (= channel): besides dW[m][:] it yields the layer's ActNorm gradients without another pass over the activations -
+//   db[m] = sum_p dc[p][m]                        (column sums from wgrad_bf16_dma_kernel's ones-fragment MFMAs, ws_db)
+//   ds[m] = sum_p dy*y = sum_p dc[p][m] (u[p][m] + b[m]) = sum_n W[m][n] dW[m][n] + b[m] db[m]      (u = conv output = W x)
+// Fixed summation order (slices in order per thread, LDS tree over the threads): deterministic.
+__device__ __forceinline__ float wgrad_get(const float* __restrict__ w, const WgradOut& o, int m, int n) {
+    return w[m * o.sm + (n % o.D) * o.sd + (n / o.D) * o.st + o.off];
+}
+
+__global__ void __launch_bounds__(kBlock) wgrad_reduce_rows_kernel(const float* __restrict__ ws, const float* __restrict__ ws_db,
+                                                                  float* __restrict__ dw, int ksplit, int Mpad, int Npad, WgradOut o,
+                                                                  const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  float* __restrict__ dscale, float* __restrict__ dbias) {
+    // one workgroup per output row; the 4 waves take slices w, w+4, ... (4 loads in flight per lane), combined in wave order
+    constexpr int MAXJ = 3;                                        // Npad <= 768: float4 columns lane, lane + 64, lane + 128
+    __shared__ float4 red[4][MAXJ][64];
+    __shared__ float dots[64];
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long slice = (long)Mpad * Npad;
+    const int nj = (Npad / 4 + 63) / 64;
+    float4 acc[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* row = ws + (size_t)m * Npad;
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int n0 = (lane + 64 * j) * 4;
+        if (j < nj && n0 < Npad) {
+            int q = wave;
+            for (; q + 12 < ksplit; q += 16) {
+                const float4 v0 = *reinterpret_cast<const float4*>(row + (size_t)q * slice + n0);
+                const float4 v1 = *reinterpret_cast<const float4*>(row + (size_t)(q + 4) * slice + n0);
+                const float4 v2 = *reinterpret_cast<const float4*>(row + (size_t)(q + 8) * slice + n0);
+                const float4 v3 = *reinterpret_cast<const float4*>(row + (size_t)(q + 12) * slice + n0);
+                acc[j].x += v0.x; acc[j].y += v0.y; acc[j].z += v0.z; acc[j].w += v0.w;
+                acc[j].x += v1.x; acc[j].y += v1.y; acc[j].z += v1.z; acc[j].w += v1.w;
+                acc[j].x += v2.x; acc[j].y += v2.y; acc[j].z += v2.z; acc[j].w += v2.w;
+                acc[j].x += v3.x; acc[j].y += v3.y; acc[j].z += v3.z; acc[j].w += v3.w;
+            }
+            for (; q < ksplit; q += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(row + (size_t)q * slice + n0);
+                acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
+            }
+        }
+        red[wave][j][lane] = acc[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXJ; ++j) {
+            const int n0 = (lane + 64 * j) * 4;
+            if (j < nj && n0 < Npad) {
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) { t[0] += red[wv][j][lane].x; t[1] += red[wv][j][lane].y; t[2] += red[wv][j][lane].z; t[3] += red[wv][j][lane].w; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n0 + e < o.N) {
+                        dot = fmaf(wgrad_get(w, o, m, n0 + e), t[e], dot);
+                        wgrad_put(dw, o, m, n0 + e, t[e]);
+                    }
+            }
+        }
+        dots[lane] = dot;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float d = 0.f;
+        for (int l = 0; l < 64; ++l) d += dots[l];
+        float db = 0.f;
+        for (int q = 0; q < ksplit; ++q) db += ws_db[(size_t)q * Mpad + m];
+        const float ds = fmaf(bias[m], db, d);
+        dscale[m] = o.acc ? dscale[m] + ds : ds;
+        dbias[m] = o.acc ? dbias[m] + db : db;
+    }
 }
 
 // wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: the forward conv kernel on wt is the data gradient of conv(., w)
@@ -638,8 +718,12 @@ __global__ void __launch_bounds__(kBlock, 2) wgrad_bf16_dma_kernel(const WgradPa
         int ca = mb * WB_BM + ch * 8, cb = nb * WB_BN + ch * 8;
         if (ca > p.Cout - 8) ca = p.Cout - 8;                      // ragged last block: any valid address, those columns are dropped
         if (cb > p.N - 8) cb = p.N - 8;
-        src_a[i] = (long)row * p.dy_ld + ca;
-        src_b[i] = (long)row * p.x_ld + cb;
+        // blocked operand (32-pixel tiles of [hb][s][g][pixel][8 channels], 512 channels): the 16-byte unit of (pixel, 8-channel group
+        // c8) sits at tile*16384 + (c8/4)*1024 + ((c8/2)%2)*512 + (c8%2)*256 + (pixel%32)*8 elements; a stage's 64 pixels are two whole
+        // tiles, so the per-stage advance p0 * 512 is the same expression as for [pixel][512] rows
+        auto blk = [](int row_, int c) { const int c8 = c >> 3; return (long)(row_ >> 5) * 16384 + (c8 >> 2) * 1024 + ((c8 >> 1) & 1) * 512 + (c8 & 1) * 256 + (row_ & 31) * 8; };
+        src_a[i] = p.a_blocked ? blk(row, ca) : (long)row * p.dy_ld + ca;
+        src_b[i] = p.b_blocked ? blk(row, cb) : (long)row * p.x_ld + cb;
     }
     auto stage = [&](int buf, long p0) {
         char* base = wd_smem + buf * 2 * WD_TILE_BYTES + wave * 4 * 1024;
@@ -681,6 +765,18 @@ __global__ void __launch_bounds__(kBlock, 2) wgrad_bf16_dma_kernel(const WgradPa
         return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
+    // optional column sums of dy (the bias gradient of the layer whose output gradient dy is): one extra MFMA per A fragment against
+    // an all-ones B fragment, in the waves that own n-block 0's first column tile (every column of the result is the sum over pixels)
+    const bool do_db = p.ws_db != nullptr && nb == 0 && wn == 0;
+    f32x16 acc_db[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_db[i][r] = 0.f;
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
     stage(0, p_begin);
     __syncthreads();
     int cur = 0;
@@ -699,9 +795,20 @@ __global__ void __launch_bounds__(kBlock, 2) wgrad_bf16_dma_kernel(const WgradPa
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (do_db) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) acc_db[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], ones, acc_db[i], 0, 0, 0);
+            }
         }
         __syncthreads();                                           // drains the DMA of the next stage, frees buffer cur
         cur ^= 1;
+    }
+    if (do_db && (lane & 31) == 0) {
+        float* dbo = p.ws_db + (size_t)ks * p.Mpad;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dbo[mb * WB_BM + wm * 64 + i * 32 + drow32(r, lane >> 5)] = acc_db[i][r];
     }
     float* out = p.ws + (size_t)ks * p.Mpad * p.Npad;
 #pragma unroll
@@ -959,7 +1066,46 @@ extern "C" int nfdp_conv_wgrad_bf16_supported(int Cin, int Cout) { return Cin % 
 extern "C" size_t nfdp_conv_wgrad_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int k) {
     WgradParams p;
     wgrad_bf16_plan(B, H, W, Cin, Cout, k, &p);
-    return (size_t)p.ksplit * p.Mpad * p.Npad * sizeof(float);
+    return (size_t)p.ksplit * p.Mpad * (p.Npad + 1) * sizeof(float);          // + the per-slice column sums of the _affine entry
+}
+
+extern "C" int nfdp_conv_wgrad_bf16_affine(const void* x, int x_ld, const void* dy, int dy_ld, long npix, int Cin, int Cout, float* dw,
+                                           void* ws, int out_form, int out_c, int accumulate, int layout, const float* w,
+                                           const float* bias, float* dscale, float* dbias, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && dy && dw && ws, NFDP_EINVAL, "conv_wgrad_bf16_affine: null pointer");
+    const bool affine = w != nullptr;
+    NFDP_REQUIRE(!affine || (bias && dscale && dbias), NFDP_EINVAL, "conv_wgrad_bf16_affine: w given without bias / dscale / dbias");
+    WgradOut om;
+    NFDP_REQUIRE(wgrad_out_map(out_form, out_c, Cout, Cin, 1, accumulate, &om) && !(affine && out_form == 2), NFDP_ESHAPE,
+                 "conv_wgrad_bf16_affine: output form %d (out_c=%d Cin=%d; form 2 has no ActNorm gradients)", out_form, out_c, Cin);
+    NFDP_REQUIRE(!affine || Cin <= 768, NFDP_EUNSUPPORTED, "conv_wgrad_bf16_affine: Cin=%d (at most 768)", Cin);
+    NFDP_REQUIRE(!(layout & 1) || (Cin == 512 && x_ld == 512), NFDP_ESHAPE, "conv_wgrad_bf16_affine: a blocked x has 512 channels");
+    NFDP_REQUIRE(!(layout & 2) || (Cout == 512 && dy_ld == 512), NFDP_ESHAPE, "conv_wgrad_bf16_affine: a blocked dy has 512 channels");
+    NFDP_REQUIRE(npix > 0 && npix % WD_KC == 0 && npix < (1L << 31) && Cin >= 8 && Cout >= 8 && Cin % 8 == 0 && Cout % 8 == 0 && x_ld >= Cin &&
+                     dy_ld >= Cout && x_ld % 8 == 0 && dy_ld % 8 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
+                 NFDP_EUNSUPPORTED, "conv_wgrad_bf16_affine: bf16 operands, 16-byte aligned rows, channels multiples of 8, pixels a multiple of %d",
+                 WD_KC);
+    WgradParams p;
+    wgrad_bf16_plan(1, 1, (int)npix, Cin, Cout, 1, &p);
+    p.x = x; p.dy = dy; p.ws = reinterpret_cast<float*>(ws);
+    p.ws_db = affine ? p.ws + (size_t)p.ksplit * p.Mpad * p.Npad : nullptr;
+    p.b_blocked = layout & 1; p.a_blocked = (layout >> 1) & 1;
+    p.x_ld = x_ld; p.dy_ld = dy_ld; p.B = 1; p.H = 1; p.W = (int)npix; p.Cin = Cin; p.Cout = Cout; p.k = 1;
+    hipStream_t s = as_stream(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  4 * WD_TILE_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_bf16_dma_kernel, dim3(p.mblocks * p.nblocks * p.ksplit), dim3(kBlock), 4 * WD_TILE_BYTES, s, p);
+    if (affine)
+        hipLaunchKernelGGL(wgrad_reduce_rows_kernel, dim3(Cout), dim3(kBlock), 0, s, p.ws, p.ws_db, dw, p.ksplit, p.Mpad, p.Npad, om, w,
+                           bias, dscale, dbias);
+    else
+        launch_wgrad_reduce(p.ws, dw, p.ksplit, p.Mpad, p.Npad, Cout, om, s);
+    NFDP_CHECK_LAUNCH("conv_wgrad_bf16_affine");
+    return NFDP_OK;
 }
 
 extern "C" int nfdp_conv_wgrad_bf16_ex(const void* x, int x_dtype, int x_ld, const void* dy, int dy_dtype, int dy_ld, int B, int H, int W,
@@ -979,7 +1125,7 @@ extern "C" int nfdp_conv_wgrad_bf16_ex(const void* x, int x_dtype, int x_ld, con
                  NFDP_ESHAPE, "conv_wgrad_bf16: operands must be aligned to 4 elements with pixel strides that are multiples of 4");
     WgradParams p;
     wgrad_bf16_plan(B, H, W, Cin, Cout, k, &p);
-    p.x = x; p.dy = dy; p.ws = reinterpret_cast<float*>(ws);
+    p.x = x; p.dy = dy; p.ws = reinterpret_cast<float*>(ws); p.ws_db = nullptr;
     p.x_ld = x_ld; p.dy_ld = dy_ld; p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.k = k;
     hipStream_t s = as_stream(stream);
     const dim3 grid(p.mblocks * p.nblocks * p.ksplit);

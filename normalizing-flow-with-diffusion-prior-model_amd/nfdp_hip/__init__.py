@@ -415,13 +415,18 @@ def im2col_kpad(cin: int) -> int:
     return -(-9 * cin // 64) * 64
 
 
-def im2col3x3(xh: torch.Tensor) -> torch.Tensor:
+def im2col3x3(xh: torch.Tensor, pad_batch: int = 0) -> torch.Tensor:
     """xh [B,H,W,C] fp32 pixel-strided view -> [B,H,W,Kpad] bf16, columns (tap, c), zero padded (nfdp_im2col3x3_bf16).  Kpad is
-    the row pitch of conv_pack's layout for the 3x3 weight, so that packed weight is also the 1x1 weight for these rows."""
+    the row pitch of conv_pack's layout for the 3x3 weight, so that packed weight is also the 1x1 weight for these rows.
+    pad_batch > B: the result has pad_batch images, the extra ones all zero (operands of GEMMs over whole workgroups' pixels)."""
     _need(xh, torch.float32, "im2col3x3")
     b, h, w, c = xh.shape
     kpad = im2col_kpad(c)
-    out = torch.empty((b, h, w, kpad), device=xh.device, dtype=torch.bfloat16)
+    if pad_batch > b:
+        out = torch.empty((pad_batch, h, w, kpad), device=xh.device, dtype=torch.bfloat16)
+        out[b:].zero_()
+    else:
+        out = torch.empty((b, h, w, kpad), device=xh.device, dtype=torch.bfloat16)
     _call("nfdp_im2col3x3_bf16", _ptr(xh), _ld(xh, "im2col3x3"), _ptr(out), b, h, w, c, kpad, _stream(), label="im2col3x3",
           nbytes=float(b * h * w) * (c * 4 * 9 + kpad * 2))
     return out
@@ -542,7 +547,8 @@ def level_fused(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torc
 def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torch.Tensor]):
     """Training forward of a whole Glow level in ONE persistent launch (nfdp_level_fused_train_bf16): xh [B,H,W,C] is updated in
     place; ldj[b] += the flows' per-sample coupling log-dets only.  -> (xpre, ypost, hout [n,B,H,W,C] fp32; y1, y2
-    [n,Bpad,H,W,512] bf16): per flow the tile before / after the flow head, the zero conv's output and the two hidden activations."""
+    [n,Bpad,H,W,512] bf16): per flow the tile before / after the flow head, the zero conv's output and the two hidden activations -
+    y1 / y2 in the fused kernels' BLOCKED layout (blocked_to_rows), not [pixel][512] rows."""
     _need(xh, torch.float32, "level_fused_train"); _dense(xh, "level_fused_train")
     b, h, wd, c = xh.shape
     n = len(packed)
@@ -567,6 +573,46 @@ def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optiona
           _ptr(xpre), _ptr(ypost), _ptr(hout), _ptr(y1), _ptr(y2), _stream(), label=f"level_fused_train<{c},{wd}> x{n}", flops=flops,
           nbytes=8.0 * xh.numel() + 12.0 * n * xh.numel() + 2048.0 * n * bpad * h * wd)
     return xpre, ypost, hout, y1, y2
+
+
+def coupling_bwd_fused_supported(h: int, w: int, c: int, n_features: int) -> bool:
+    return coupling_fused_supported(h, w, c, n_features) and lib().nfdp_coupling_bwd_fused_packed_bytes(c) > 0
+
+
+def coupling_bwd_fused_pack(w1, s1, w2, s2, w3, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight image of the reverse coupling network (nfdp_coupling_bwd_fused_pack): w1 [512,C/2,3,3], s1 [512], w2 [512,512,1,1],
+    s2 [512], w3 [C,512,3,3]."""
+    c = w3.shape[0]
+    nbytes = lib().nfdp_coupling_bwd_fused_packed_bytes(c)
+    if nbytes == 0:
+        raise NfdpError(f"coupling_bwd_fused_pack: unsupported C={c}")
+    packed = out if out is not None and out.numel() == nbytes else torch.empty(nbytes, device=w1.device, dtype=torch.uint8)
+    for t in (w1, s1, w2, s2, w3):
+        _need(t, torch.float32, "coupling_bwd_fused_pack"); _dense(t, "coupling_bwd_fused_pack")
+    _call("nfdp_coupling_bwd_fused_pack", _ptr(w1), _ptr(s1), _ptr(w2), _ptr(s2), _ptr(w3), _ptr(packed), c, _stream())
+    return packed
+
+
+def coupling_bwd_fused(dc3: torch.Tensor, dx: torch.Tensor, packed: torch.Tensor, y1: torch.Tensor, y2: torch.Tensor):
+    """The coupling network's data-gradient chain in one launch (nfdp_coupling_bwd_fused_bf16).  dc3 [B,H,W,C] fp32 (gradient at the
+    zero conv's raw output); y1, y2 [Bpad,H,W,512] bf16 as saved by level_fused_train (BLOCKED layout, Bpad >= B: whole workgroups);
+    dx [B,H,W,C] fp32: its first C/2 channels receive += the network's input gradient.  -> (dc1, dc2), shaped and laid out like y1."""
+    _need(dc3, torch.float32, "coupling_bwd_fused"); _dense(dc3, "coupling_bwd_fused")
+    _need(dx, torch.float32, "coupling_bwd_fused dx"); _dense(dx, "coupling_bwd_fused dx")
+    _need(y1, torch.bfloat16, "coupling_bwd_fused y1"); _dense(y1, "coupling_bwd_fused y1")
+    _need(y2, torch.bfloat16, "coupling_bwd_fused y2"); _dense(y2, "coupling_bwd_fused y2")
+    b, h, w, c = dc3.shape
+    grp = lib().nfdp_level_fused_train_group(h, w, c)
+    bpad = (b + grp - 1) // grp * grp if grp > 0 else b
+    if tuple(dx.shape) != (b, h, w, c) or tuple(y1.shape) != (bpad, h, w, 512) or tuple(y2.shape) != (bpad, h, w, 512):
+        raise ValueError(f"coupling_bwd_fused: shapes dc3 {tuple(dc3.shape)} dx {tuple(dx.shape)} y1 {tuple(y1.shape)} y2 {tuple(y2.shape)}")
+    dc1 = torch.empty_like(y1)
+    dc2 = torch.empty_like(y2)
+    ch = c // 2
+    flops = 2.0 * b * h * w * (9 * c * 512 + 512 * 512 + 9 * 512 * ch)
+    _call("nfdp_coupling_bwd_fused_bf16", _ptr(dc3), _ptr(dx), _ptr(packed), _ptr(y1), _ptr(y2), _ptr(dc1), _ptr(dc2), b, h, w, c,
+          _stream(), label=f"coupling_bwd_fused<{c},{w}>", flops=flops, nbytes=4096.0 * bpad * h * w)
+    return dc1, dc2
 
 
 def ldj_add_scaled(ldj: torch.Tensor, v: torch.Tensor, n_sum: int, hw: float):
@@ -857,6 +903,58 @@ def conv_wgrad(xh: torch.Tensor, dyh: torch.Tensor, k: int, compute: int = F32, 
           _ptr(dw), _ptr(ws), int(form), int(form_c), int(accumulate), _stream(), label=f"conv_wgrad k{k} {cin}->{cout} hw{h}",
           flops=2.0 * b * h * w * cin * cout * k * k)
     return dw
+
+
+def blocked_to_rows(t: torch.Tensor) -> torch.Tensor:
+    """[..., 512] bf16 tensor in the fused kernels' blocked layout (32-pixel tiles of [hb 16][s 2][g 2][pixel 32][8]) -> ordinary
+    [pixel][512] rows, same shape.  torch indexing only (tests / debugging; nothing on the product path needs it)."""
+    n = t.numel() // 512
+    return t.reshape(n // 32, 16, 2, 2, 32, 8).permute(0, 4, 1, 2, 3, 5).reshape(t.shape).contiguous()
+
+
+def rows_to_blocked(t: torch.Tensor) -> torch.Tensor:
+    n = t.numel() // 512
+    return t.reshape(n // 32, 32, 16, 2, 2, 8).permute(0, 2, 3, 4, 1, 5).reshape(t.shape).contiguous()
+
+
+def conv_wgrad_blocked(xh: torch.Tensor, dyh: torch.Tensor, dw: torch.Tensor, accumulate: bool, form: int = 0, form_c: int = 0,
+                       x_blocked: bool = False, dy_blocked: bool = False) -> None:
+    """Plain dW of a 1x1 conv on bf16 operands, either of which may be a 512-channel tensor in the blocked layout
+    (nfdp_conv_wgrad_bf16_affine without the ActNorm outputs)."""
+    _need(xh, torch.bfloat16, "conv_wgrad_blocked"); _need(dyh, torch.bfloat16, "conv_wgrad_blocked")
+    _dense(xh, "conv_wgrad_blocked"); _dense(dyh, "conv_wgrad_blocked"); _need(dw, torch.float32, "conv_wgrad_blocked dw"); _dense(dw, "dw")
+    cin, cout = xh.shape[-1], dyh.shape[-1]
+    npix = xh.numel() // cin
+    shape = {0: (cout, cin, 1, 1), 1: (cout, form_c, 3, 3), 2: (form_c, cout, 3, 3)}[form]
+    if dyh.numel() // cout != npix or tuple(dw.shape) != shape:
+        raise ValueError(f"conv_wgrad_blocked: shapes {tuple(xh.shape)} / {tuple(dyh.shape)} / dw {tuple(dw.shape)} (expected {shape})")
+    ws = torch.empty(lib().nfdp_conv_wgrad_bf16_ws_bytes(1, 1, npix, cin, cout, 1), device=xh.device, dtype=torch.uint8)
+    _call("nfdp_conv_wgrad_bf16_affine", _ptr(xh), cin, _ptr(dyh), cout, npix, cin, cout, _ptr(dw), _ptr(ws), int(form), int(form_c),
+          int(accumulate), int(x_blocked) | (int(dy_blocked) << 1), None, None, None, None, _stream(),
+          label=f"conv_wgrad_bf16_blocked {cin}->{cout}", flops=2.0 * npix * cin * cout)
+
+
+def conv_wgrad_affine(xh: torch.Tensor, dyh: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, dw: torch.Tensor,
+                      dscale: torch.Tensor, dbias: torch.Tensor, accumulate: bool, form: int = 0, form_c: int = 0,
+                      x_blocked: bool = False, dy_blocked: bool = False) -> None:
+    """dW, dscale, dbias of a Conv2dActNorm layer from ONE GEMM over pixels (nfdp_conv_wgrad_bf16_affine): xh [..., Cin] bf16 (the layer's
+    input, or its im2col rows with form=1), dyh [..., Cout] bf16 = gradient at the conv's raw output; weight / bias: the layer's
+    parameters; dw / dscale / dbias: dense fp32 outputs (added to when accumulate)."""
+    _need(xh, torch.bfloat16, "conv_wgrad_affine"); _need(dyh, torch.bfloat16, "conv_wgrad_affine")
+    _dense(xh, "conv_wgrad_affine"); _dense(dyh, "conv_wgrad_affine")
+    for t in (weight, bias, dw, dscale, dbias):
+        _need(t, torch.float32, "conv_wgrad_affine"); _dense(t, "conv_wgrad_affine")
+    cin, cout = xh.shape[-1], dyh.shape[-1]
+    npix = xh.numel() // cin
+    if dyh.numel() // cout != npix:
+        raise ValueError(f"conv_wgrad_affine: shape mismatch {tuple(xh.shape)} / {tuple(dyh.shape)}")
+    shape = {0: (cout, cin, 1, 1), 1: (cout, form_c, 3, 3)}[form]
+    if tuple(dw.shape) != shape or tuple(weight.shape) != shape or dscale.numel() != cout or dbias.numel() != cout or bias.numel() != cout:
+        raise ValueError(f"conv_wgrad_affine: dw {tuple(dw.shape)} / weight {tuple(weight.shape)}, expected {shape}")
+    ws = torch.empty(lib().nfdp_conv_wgrad_bf16_ws_bytes(1, 1, npix, cin, cout, 1), device=xh.device, dtype=torch.uint8)
+    _call("nfdp_conv_wgrad_bf16_affine", _ptr(xh), cin, _ptr(dyh), cout, npix, cin, cout, _ptr(dw), _ptr(ws), int(form), int(form_c),
+          int(accumulate), int(x_blocked) | (int(dy_blocked) << 1), _ptr(weight), _ptr(bias), _ptr(dscale), _ptr(dbias), _stream(),
+          label=f"conv_wgrad_bf16_affine {cin}->{cout}", flops=2.0 * npix * cin * cout)
 
 
 def conv_flip_weights(w_oihw: torch.Tensor) -> torch.Tensor:

@@ -56,6 +56,75 @@ def _slot(p):
     return g
 
 
+# Weight-gradient GEMMs on a side stream.  The backward of a flow is a chain of data-gradient launches, each waiting for the one before
+# (coupling -> zero conv -> hidden layer 2 -> hidden layer 1 -> input conv -> 1x1 conv -> ActNorm -> next flow); at the 8x8 / 4x4
+# levels most of them sit at their ~5-14 us launch floor with the chip nearly idle.  The weight-gradient GEMMs and their split-K
+# reduces only produce parameter gradients - nothing later in the chain reads them - so they are forked onto a second HIP stream
+# (behind everything enqueued so far) and joined once per level / node; under a captured step they become parallel branches of the
+# hipGraph.  Tensors they read are kept referenced until the join, so the caching allocator cannot hand their memory to a
+# main-stream launch while the side stream still reads it.
+WGRAD_SIDE_STREAM = True
+_side_streams = {}
+_side_keep = []
+
+
+_side_jobs = []
+
+
+def _defer_side(fn, *tensors) -> None:
+    """Queue a weight-gradient launch for the side stream (run by _flush_side at the end of the flow: ONE fork per flow - every fork
+    and join is a cross-queue dependency in the captured graph); without the side stream it runs at once."""
+    if not WGRAD_SIDE_STREAM:
+        fn()
+    else:
+        _side_jobs.append((fn, tensors))
+
+
+def _flush_side() -> None:
+    if _side_jobs:
+        jobs = list(_side_jobs)
+        _side_jobs.clear()
+        with _OnSide(*[t for _, ts in jobs for t in ts]):
+            for fn, _ in jobs:
+                fn()
+
+
+class _OnSide:
+    """`with _OnSide(t0, t1, ...):` - launches inside go to the side stream, ordered after the main stream's work so far."""
+
+    def __init__(self, *tensors):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if not WGRAD_SIDE_STREAM:
+            return self
+        dev = torch.cuda.current_device()
+        side = _side_streams.get(dev)
+        if side is None:
+            side = _side_streams[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        _side_keep.append(self.tensors)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def _join_side() -> None:
+    """The main stream waits for the side stream's weight gradients (before anything may read them: autograd's accumulation of
+    returned gradients, the optimizer, a gradient all-reduce)."""
+    if _side_keep:
+        side = _side_streams.get(torch.cuda.current_device())
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        _side_keep.clear()
+
+
 def _slots(*params):
     """The .grad tensors of all params, or None unless every one of them can be accumulated into directly."""
     gs = [_slot(p) for p in params]
@@ -362,19 +431,23 @@ def _net_backward(dh, h, xcol, y1, y2, params, f3, need_dxa, bpacks=None):
     dc3, dl3, db3 = K.scale_bwd(dh.contiguous(), h, l3.detach().reshape(-1), f3, False, grads_out=flat(gl3, gb3) if direct else None)
     dc3_col = K.im2col3x3(dc3)
     if direct:                                                  # dW3 from the same im2col matrix, stored mirrored into OIHW by the reduce
-        K.conv_wgrad(dc3_col, y2, 1, compute=c, out=gw3, accumulate=True, form=2, form_c=co)
+        _defer_side(lambda: K.conv_wgrad(dc3_col, y2, 1, compute=c, out=gw3, accumulate=True, form=2, form_c=co), dc3_col, y2)
     else:
         g = K.conv_wgrad(dc3_col, y2, 1, compute=c)[:, :9 * co, 0, 0]
         dw3 = g.reshape(hid, 3, 3, co).flip(1, 2).permute(3, 0, 1, 2).contiguous()
     # hidden layer 2: its output gradient is the C -> 512 conv of dc3; its scale/ReLU backward rides in that GEMM's epilogue
     dc2, ds2, db2 = K.pointwise_dgrad_masked(dc3_col, bpacks[0], y2,
                                              s2.detach().reshape(-1), 1.0, grads_out=flat(gs2, gb2) if direct else None)
-    dw2 = K.conv_wgrad(y1, dc2, 1, compute=c, out=gw2 if direct else None, accumulate=direct)
+    if direct:
+        _defer_side(lambda: K.conv_wgrad(y1, dc2, 1, compute=c, out=gw2, accumulate=True), y1, dc2)
+        dw2 = None
+    else:
+        dw2 = K.conv_wgrad(y1, dc2, 1, compute=c)
     # hidden layer 1: output gradient = dc2 W2 (1x1), same fusion
     dc1, ds1, db1 = K.pointwise_dgrad_masked(dc2, bpacks[1], y1,
                                              s1.detach().reshape(-1), 1.0, grads_out=flat(gs1, gb1) if direct else None)
     if direct:
-        K.conv_wgrad(xcol, dc1, 1, compute=c, out=gw1, accumulate=True, form=1, form_c=i1)
+        _defer_side(lambda: K.conv_wgrad(xcol, dc1, 1, compute=c, out=gw1, accumulate=True, form=1, form_c=i1), xcol, dc1)
     else:
         dw1 = K.conv_wgrad(xcol, dc1, 1, compute=c)[:, :9 * i1, 0, 0].reshape(o1, 3, 3, i1).permute(0, 3, 1, 2).contiguous()
     dxa = None
@@ -410,6 +483,8 @@ class CouplingStepFn(Function):
         dxa, grads = _net_backward(dh, h, xcol, y1, y2, ctx.params, ctx.f3, ctx.needs_input_grad[0], ctx.bpacks)
         if dxa is not None:
             dx[..., : dxa.shape[-1]] += dxa
+        _flush_side()
+        _join_side()
         return (dx, _ldj_grad(ctx, dacc), None, None, None, None) + (grads if grads is not None else (None,) * 9)
 
 
@@ -513,6 +588,51 @@ def step_flow(flow, xh: Tensor, ldj: Optional[Tensor], pre=None, wt: Optional[Te
 FUSED_TRAIN_FORWARD = True          # bf16 mode, 32x32-model geometries: the level's forward is ONE persistent launch (see LevelFusedFn)
 
 
+FUSED_TRAIN_BACKWARD = True         # ... and the data-gradient chain of each coupling network one launch (nfdp_coupling_bwd_fused_bf16)
+
+
+def _net_backward_fused(dh, dx, ypost, h, y1, y2, params, f3, net):
+    """Backward of one coupling network on the fused kernels.  dh: gradient at the zero conv's output h; dx [B,H,W,C]: the coupling's
+    input gradient, whose first half receives += the network's input gradient; y1, y2: saved hidden activations ([Bpad,H,W,512]
+    bf16).  One launch for the data path (coupling_bwd_fused: zero conv^T -> mask/scale -> 1x1^T -> mask/scale -> input conv^T, hidden
+    gradients written once), three GEMMs over pixels for the parameters - the two hidden layers' ActNorm gradients come out of their
+    weight-gradient GEMMs (conv_wgrad_affine).  -> the nine parameter gradients in `params` order, or None when they went into .grad."""
+    w1, b1, s1, w2, b2, s2, w3, b3, l3 = params
+    c = K.BF16
+    co, hid = w3.shape[0], w3.shape[1]
+    o1, i1 = w1.shape[:2]
+    bpad = y1.shape[0]
+    gs = _slots(*params)
+    direct = gs is not None
+    if direct:
+        gw1, gb1, gs1, gw2, gb2, gs2, gw3, gb3, gl3 = gs
+    flat = lambda a, b: (a.view(-1), b.view(-1))
+    # zero conv: h = (u3 + b3) e^{3 l3}
+    dc3, dl3, db3 = K.scale_bwd(dh.contiguous(), h, l3.detach().reshape(-1), f3, False, grads_out=flat(gl3, gb3) if direct else None)
+    packed = K.coupling_bwd_fused_pack(w1.detach(), s1.detach().reshape(-1), w2.detach(), s2.detach().reshape(-1), w3.detach(),
+                                       out=getattr(net, "_fused_bwd", None) if net is not None else None)
+    if net is not None:
+        object.__setattr__(net, "_fused_bwd", packed)
+    dc1, dc2 = K.coupling_bwd_fused(dc3, dx, packed, y1, y2)
+    dc3_col = K.im2col3x3(dc3, pad_batch=bpad)
+    xcol = K.im2col3x3(ypost[..., : ypost.shape[-1] // 2], pad_batch=bpad)
+    if direct:
+        _defer_side(lambda: K.conv_wgrad_blocked(dc3_col, y2, gw3, True, form=2, form_c=co, dy_blocked=True), dc3_col, y2)
+        _defer_side(lambda: K.conv_wgrad_affine(y1, dc2, w2.detach(), b2.detach().reshape(-1), gw2, gs2.view(-1), gb2.view(-1), True,
+                                                x_blocked=True, dy_blocked=True), y1, dc2)
+        _defer_side(lambda: K.conv_wgrad_affine(xcol, dc1, w1.detach(), b1.detach().reshape(-1), gw1, gs1.view(-1), gb1.view(-1), True,
+                                                form=1, form_c=i1, dy_blocked=True), xcol, dc1)
+        return None
+    dw3 = torch.empty_like(w3)
+    K.conv_wgrad_blocked(dc3_col, y2, dw3, False, form=2, form_c=co, dy_blocked=True)
+    dw2, ds2, db2 = torch.empty_like(w2), torch.empty(hid, device=w2.device), torch.empty(hid, device=w2.device)
+    K.conv_wgrad_affine(y1, dc2, w2.detach(), b2.detach().reshape(-1), dw2, ds2, db2, False, x_blocked=True, dy_blocked=True)
+    dw1, ds1, db1 = torch.empty_like(w1), torch.empty(o1, device=w1.device), torch.empty(o1, device=w1.device)
+    K.conv_wgrad_affine(xcol, dc1, w1.detach().contiguous(), b1.detach().reshape(-1), dw1, ds1, db1, False, form=1, form_c=i1,
+                        dy_blocked=True)
+    return (dw1, db1.view_as(b1), ds1.view_as(s1), dw2, db2.view_as(b2), ds2.view_as(s2), dw3, db3.view_as(b3), dl3.view_as(l3))
+
+
 class LevelFusedFn(Function):
     """All K flow steps of a Glow level (reference glow.py:107-109: actnorm -> invconv -> affine coupling, K times) as ONE autograd
     node whose forward is ONE persistent launch of the fused flow-step kernel (nfdp_level_fused_train_bf16): the flow state stays in
@@ -529,7 +649,7 @@ class LevelFusedFn(Function):
 
     @staticmethod
     def forward(ctx, xh, ldj, meta, *params):
-        packed, wts, bpacks, f3 = meta
+        packed, wts, bpacks, f3 = meta[:4]
         n = len(packed)
         c = xh.shape[-1]
         y = xh.contiguous().clone()
@@ -541,6 +661,7 @@ class LevelFusedFn(Function):
         xpre, ypost, hout, y1, y2 = K.level_fused_train(y, packed, scales, biases, ws, acc)
         ctx.save_for_backward(xpre, ypost, hout, y1, y2, wts)
         ctx.params, ctx.bpacks, ctx.f3, ctx.n = params, bpacks, float(f3), n
+        ctx.nets = meta[4] if len(meta) > 4 else [None] * n
         ctx.ldj_dtype = None if ldj is None else ldj.dtype
         return y, acc
 
@@ -560,18 +681,17 @@ class LevelFusedFn(Function):
             net = params[P * i + 3: P * i + 12]
             # affine coupling + network
             dx, dh = K.coupling_bwd(ypost[i], hout[i], dy, dacc_c)
-            xcol = K.im2col3x3(ypost[i][..., : c // 2])
-            dxa, g9 = _net_backward(dh, hout[i], xcol, y1[i][:b], y2[i][:b], net, ctx.f3, True, ctx.bpacks[i])
-            dx[..., : c // 2] += dxa
+            g9 = _net_backward_fused(dh, dx, ypost[i], hout[i], y1[i], y2[i], net, ctx.f3, ctx.nets[i])
             # 1x1 conv (transforms.py:132): y = W a, with a = actnorm(xpre) recomputed (one elementwise launch)
             a = K.actnorm_fwd(xpre[i], scale.detach().reshape(-1), bias.detach().reshape(-1))
             da = K.invconv_apply(dx, wts[i])
             gw = _slots(weight)
             if gw is not None and weight.dim() == 4:
-                K.conv_wgrad(a, dx, 1, out=gw[0], accumulate=True)
+                _defer_side(lambda a=a, dx=dx, g=gw[0]: K.conv_wgrad(a, dx, 1, out=g, accumulate=True), a, dx)
                 dw = None
             else:
                 dw = K.conv_wgrad(a, dx, 1).view_as(weight)
+            _flush_side()                                            # one fork per flow: its four weight gradients
             # ActNorm (transforms.py:80)
             gsb = _slots(scale, bias)
             if gsb is not None:
@@ -583,6 +703,7 @@ class LevelFusedFn(Function):
             grads[P * i: P * i + 3] = [dsc, dbi, dw]
             if g9 is not None:
                 grads[P * i + 3: P * i + 12] = list(g9)
+        _join_side()
         dl = None
         if ctx.ldj_dtype is not None and dacc is not None:
             dl = dacc if dacc.dtype == ctx.ldj_dtype else dacc.to(ctx.ldj_dtype)
@@ -593,13 +714,22 @@ def _level_fused_ok(flows, yh: Tensor) -> bool:
     if not FUSED_TRAIN_FORWARD or yh.dtype != torch.float32 or len(flows) > 32:
         return False
     b, h, w, c = yh.shape
+    hid = flows[0].affcoupling.net[0].conv.out_channels
+    if not K.coupling_fused_supported(h, w, c, hid):
+        return False
+    if not (FUSED_TRAIN_BACKWARD and K.coupling_bwd_fused_supported(h, w, c, hid)):
+        return False            # the saved activations are in the fused kernels' blocked layout: only the fused backward reads it
+    bwd_fused = True
     for f in flows:
         cp = f.affcoupling
+        net = cp.net
         if K.compute_enum(cp.compute) != K.BF16 or not f.actnorm.initialized():
             return False
-        if not _fused_net_ok(cp.net, yh[..., : c // 2], K.BF16):
+        if not (net[0].actnorm.initialized() and net[2].actnorm.initialized()):
             return False
-    return K.coupling_fused_supported(h, w, c, flows[0].affcoupling.net[0].conv.out_channels)
+        if not bwd_fused and not _fused_net_ok(net, yh[..., : c // 2], K.BF16):     # the per-op backward has its own shape limits
+            return False
+    return True
 
 
 def _level_fused(flows, yh: Tensor, ldj: Optional[Tensor], sp, wts: Tensor):
@@ -613,7 +743,7 @@ def _level_fused(flows, yh: Tensor, ldj: Optional[Tensor], sp, wts: Tensor):
         params += [f.actnorm.scale, f.actnorm.bias, f.invconv2d.weight, c1.conv.weight, c1.actnorm.bias, c1.actnorm.scale,
                    c2.conv.weight, c2.actnorm.bias, c2.actnorm.scale, zc.weight, zc.bias, zc.logs]
     f3 = flows[0].affcoupling.net[4].logscale_factor
-    return LevelFusedFn.apply(yh, ldj, (packed, wts, bpacks, f3), *params)
+    return LevelFusedFn.apply(yh, ldj, (packed, wts, bpacks, f3, [f.affcoupling.net for f in flows]), *params)
 
 
 def _level_flows(flows, yh: Tensor, ldj: Optional[Tensor], sp=None):

@@ -672,7 +672,7 @@ def test_fused_level_training_forward_matches_the_per_flow_nodes(B, direct):
     finally:
         training.FUSED_TRAIN_FORWARD = True
         training.enable_direct_grads(params, False)
-    n_fused = sum(B * hw >= 512 for hw in (256, 64, 16))             # the fused-epilogue data-gradient GEMM of the backward needs 512 pixels
+    n_fused = 3
     assert sum(lb.startswith("level_fused_train") for lb in lab1) == n_fused and not any(lb.startswith("level_fused_train") for lb in lab0)
     assert len(lab1) < len(lab0)
     for a, b in zip(z1, z0):
@@ -684,3 +684,107 @@ def test_fused_level_training_forward_matches_the_per_flow_nodes(B, direct):
     print("fused vs per-flow training forward: median rel Frobenius err", float(np.median(list(errs.values()))), "worst", worst)
     assert worst[1] <= 5e-2 and float(np.median(list(errs.values()))) <= 5e-3, worst
     assert torch.equal(l1, l2) and all(torch.equal(a, b) for a, b in zip(g1, g2))      # deterministic
+
+
+@pytest.mark.parametrize("hw,c,B", [(16, 12, 3), (8, 24, 5), (4, 48, 11), (16, 12, 1), (16, 4, 2), (8, 8, 3), (4, 16, 9)])
+def test_fused_reverse_coupling_network(hw, c, B):
+    """nfdp_coupling_bwd_fused_bf16: the data-gradient chain of a coupling network (zero conv^T -> mask/scale -> 1x1^T -> mask/scale ->
+    input conv^T) in one launch, against torch's transposed convolutions on the same bf16-rounded operands: the two hidden gradients
+    (bf16, the forward's [pixel][512] layout, rows of absent images in the padded tail stay zero) and the input gradient added
+    into dx[..., :C/2].  Ragged batches: the 8x8 / 4x4 kernels own 2 / 8 images per workgroup."""
+    ch = c // 2
+    bf = lambda t: t.to(torch.bfloat16).float()
+    w1, w2, w3 = rnd(512, ch, 3, 3, seed=1, scale=0.05), rnd(512, 512, 1, 1, seed=2, scale=0.05), rnd(c, 512, 3, 3, seed=3, scale=0.05)
+    s1, s2 = rnd(512, seed=4, scale=0.2), rnd(512, seed=5, scale=0.2)
+    dc3 = rnd(B, c, hw, hw, seed=6)
+    y1 = bf(torch.relu(rnd(B, 512, hw, hw, seed=7)))
+    y2 = bf(torch.relu(rnd(B, 512, hw, hw, seed=8)))
+    dx0 = rnd(B, c, hw, hw, seed=9)
+    # reference (fp32 math on bf16-rounded GEMM operands, fp32 accumulation)
+    dy2 = F.conv_transpose2d(bf(dc3), bf(w3), padding=1)
+    dc2 = bf((y2 > 0) * dy2 * torch.exp(s2).view(1, -1, 1, 1))
+    dy1 = F.conv_transpose2d(dc2, bf(w2))
+    dc1 = bf((y1 > 0) * dy1 * torch.exp(s1).view(1, -1, 1, 1))
+    dxa = F.conv_transpose2d(dc1, bf(w1), padding=1)
+    grp = {16: 1, 8: 2, 4: 8}[hw]
+    bpad = (B + grp - 1) // grp * grp
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    def padded(t):                                                 # saved activations: padded to whole workgroups, blocked layout
+        out = torch.zeros(bpad, hw, hw, 512, dtype=torch.bfloat16)
+        out[:B] = nhwc(t).to(torch.bfloat16)
+        return K.rows_to_blocked(out).to(DEV)
+    packed = K.coupling_bwd_fused_pack(w1.to(DEV), s1.to(DEV), w2.to(DEV), s2.to(DEV), w3.to(DEV))
+    dx = nhwc(dx0).to(DEV)
+    g1b, g2b = K.coupling_bwd_fused(nhwc(dc3).to(DEV), dx, packed, padded(y1), padded(y2))
+    assert g1b.dtype == torch.bfloat16 and tuple(g1b.shape) == (bpad, hw, hw, 512)
+    g1, g2 = K.blocked_to_rows(g1b), K.blocked_to_rows(g2b)          # the gradients come back in the same blocked layout
+    assert_close(g2[:B].float(), nhwc(dc2), 2e-2, "dc2")
+    assert_close(g1[:B].float(), nhwc(dc1), 2e-2, "dc1")
+    want = nhwc(dx0).clone()
+    want[..., :ch] += nhwc(dxa)
+    assert_close(dx, want, 2e-2, "dx")
+    assert torch.equal(dx[..., ch:].cpu(), nhwc(dx0)[..., ch:])
+    assert float(g1[B:].float().abs().max() if bpad > B else 0.0) == 0.0 and float(g2[B:].float().abs().max() if bpad > B else 0.0) == 0.0
+    # ReLU mask exactly: where the saved activation is zero the gradient is zero
+    assert float(g2[:B].float()[nhwc(y2) == 0].abs().max()) == 0.0
+    # determinism
+    dx_b = nhwc(dx0).to(DEV)
+    h1, h2 = K.coupling_bwd_fused(nhwc(dc3).to(DEV), dx_b, packed, padded(y1), padded(y2))
+    assert torch.equal(h1, g1b) and torch.equal(h2, g2b) and torch.equal(dx_b, dx)
+
+
+@pytest.mark.parametrize("npix,cin,cout,form_c", [(1024, 512, 512, 0), (640, 64, 512, 6), (2048, 128, 512, 12), (128, 512, 512, 0)])
+def test_weight_gradient_gemm_with_actnorm_gradients(npix, cin, cout, form_c):
+    """nfdp_conv_wgrad_bf16_affine: dW of a Conv2dActNorm layer and, from the same GEMM, its ActNorm gradients - dbias as column sums
+    of the raw-output gradient (ones-fragment MFMAs), dscale through  sum_p dy*y = sum_n W[m][n] dW[m][n] + b[m] db[m]  - against
+    autograd of y = relu((x W^T + b) e^s) on the same bf16 operands; accumulation into existing gradients; im2col form (form_c > 0:
+    x rows are (tap, channel) columns padded to 64 / 128, dW stored as [Cout, form_c, 3, 3])."""
+    bf = lambda t: t.to(torch.bfloat16).float()
+    k_real = 9 * form_c if form_c else cin
+    x = bf(rnd(npix, cin, seed=1))
+    if form_c:
+        x[:, k_real:] = 0.0
+    w = rnd(cout, k_real, seed=2, scale=0.05)
+    b = rnd(cout, seed=3, scale=0.3)
+    s_ = rnd(cout, seed=4, scale=0.2)
+    wq = bf(w).requires_grad_()
+    bq, sq = b.clone().requires_grad_(), s_.clone().requires_grad_()
+    u = x[:, :k_real] @ wq.t()
+    y = torch.relu((u + bq) * torch.exp(sq))
+    dy = rnd(npix, cout, seed=5)
+    dc = bf((y > 0) * dy * torch.exp(sq).detach())                         # what the fused backward kernel writes (bf16)
+    # autograd with the bf16-rounded dc as the upstream gradient at the raw conv output
+    (u * dc).sum().backward(inputs=[wq], retain_graph=True)
+    dw_ref = wq.grad
+    db_ref = dc.sum(0)
+    ds_ref = (dc * (u.detach() + b)).sum(0)
+    if form_c:
+        w_param = w.view(cout, 3, 3, form_c).permute(0, 3, 1, 2).contiguous()      # columns are (tap, channel); parameter is OIHW
+        dw_want = dw_ref.view(cout, 3, 3, form_c).permute(0, 3, 1, 2).contiguous()
+    else:
+        w_param, dw_want = w.view(cout, cin, 1, 1), dw_ref.view(cout, cin, 1, 1)
+    dw = torch.full(w_param.shape, 0.5, device=DEV)
+    dsc, dbi = torch.full((cout,), -1.0, device=DEV), torch.full((cout,), 2.0, device=DEV)
+    args = (x.to(torch.bfloat16).to(DEV), dc.to(torch.bfloat16).to(DEV), bf(w_param).to(DEV).contiguous(), b.to(DEV))
+    K.conv_wgrad_affine(*args, dw, dsc, dbi, accumulate=True, form=1 if form_c else 0, form_c=form_c)
+    assert_close(dw - 0.5, dw_want, 2e-3, "dW (accumulated)")
+    assert_close(dbi - 2.0, db_ref, 2e-3, "dbias")
+    assert_close(dsc + 1.0, ds_ref, 5e-3, "dscale")
+    dw2, dsc2, dbi2 = torch.empty_like(dw), torch.empty_like(dsc), torch.empty_like(dbi)
+    K.conv_wgrad_affine(*args, dw2, dsc2, dbi2, accumulate=False, form=1 if form_c else 0, form_c=form_c)
+    assert_close(dw2, dw_want, 2e-3, "dW")
+    assert_close(dsc2, ds_ref, 5e-3, "dscale (stored)")
+    dw3, dsc3, dbi3 = torch.empty_like(dw), torch.empty_like(dsc), torch.empty_like(dbi)
+    K.conv_wgrad_affine(*args, dw3, dsc3, dbi3, accumulate=False, form=1 if form_c else 0, form_c=form_c)
+    assert torch.equal(dw2, dw3) and torch.equal(dsc2, dsc3) and torch.equal(dbi2, dbi3)
+    # 512-channel operands in the fused kernels' blocked layout: same numbers, bit for bit (only the source addresses differ)
+    xb = K.rows_to_blocked(args[0]) if cin == 512 else args[0]
+    dyb = K.rows_to_blocked(args[1])
+    dw4, dsc4, dbi4 = torch.empty_like(dw), torch.empty_like(dsc), torch.empty_like(dbi)
+    K.conv_wgrad_affine(xb, dyb, args[2], args[3], dw4, dsc4, dbi4, accumulate=False, form=1 if form_c else 0, form_c=form_c,
+                        x_blocked=cin == 512, dy_blocked=True)
+    assert torch.equal(dw2, dw4) and torch.equal(dsc2, dsc4) and torch.equal(dbi2, dbi4)
+    if not form_c:
+        dw5 = torch.empty_like(dw)
+        K.conv_wgrad_blocked(xb, dyb, dw5, False, x_blocked=True, dy_blocked=True)
+        assert_close(dw5, dw_want, 2e-3, "plain dW on blocked operands")
