@@ -195,25 +195,29 @@ int nfdp_level_fused_bf16(float* x, int B, int H, int W, int C, int n_flows, con
  *          layout: 32-pixel tiles of [hidden block 16][k-step 2][half 2][pixel 32][8 channels], channel = 32 hb + 16 s + 8 g + e (the
  *          MFMA B-fragment image: every store is one contiguous KiB); Bpad = B rounded up to a multiple of
  *          nfdp_level_fused_train_group(H, W, C) (whole workgroups: tiles of the images past B hold unspecified finite values)
+ *   xcol [n_flows][Bpad][H*W][nfdp_coupling_fused_im2col_cols(C, 0)] bf16   im2col rows of the coupling network's input x_a, columns
+ *          k = tap * C/2 + ci (zero beyond 9 C/2): the x operand of the first conv's weight-gradient GEMM
  * - straight from the registers / LDS tile of the fused kernel; `packed` images must be built with fold_scales = 0 (hidden stores are issued between the MFMAs of the last GEMM and
  * counted in the weight ring's vmcnt waits).  ldj[b] += sum over the flows of sum log(s+1e-6) ONLY: the weight-only terms
  * (H*W*sum(scale), H*W*log|det W|) belong to the caller's autograd graph.  n_flows <= 32.  Forward only. */
 int nfdp_level_fused_train_group(int H, int W, int C);
+int nfdp_coupling_fused_im2col_cols(int C, int backward);
 int nfdp_level_fused_train_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
                                 const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
-                                float* xpre, float* ypost, float* hout, void* y1, void* y2, nfdp_stream_t stream);
+                                float* xpre, float* ypost, float* hout, void* y1, void* y2, void* xcol, nfdp_stream_t stream);
 /* Backward of the coupling network's data path in one launch (autograd of utils.py:83-89 w.r.t. its input, training step
  * normalizing_flow/trainer.py:164): dc3 [B][H*W][C] fp32 = gradient at the ZeroConv2d's raw conv output (after its scale backward);
  * y1, y2 = the hidden activations saved by nfdp_level_fused_train_bf16 (blocked layout, Bpad images).  Writes dc2, dc1 (same layout as
  * y2, y1: gradients at the two hidden convs' raw outputs, i.e. after the ReLU mask and the ActNorm scale) for the weight-gradient
- * GEMMs, and ADDS the data gradient of the network's input into dx[..., 0:C/2] (dx [B][H*W][C] fp32).  `packed`
+ * GEMMs, dc3col ([Bpad][H*W][nfdp_coupling_fused_im2col_cols(C, 1)] bf16: im2col rows of dc3, the x operand of the zero conv's
+ * weight-gradient GEMM), and ADDS the data gradient of the network's input into dx[..., 0:C/2] (dx [B][H*W][C] fp32).  `packed`
  * (nfdp_coupling_bwd_fused_packed_bytes(C) bytes): nfdp_coupling_bwd_fused_pack of w1 [512,C/2,3,3], scale1 [512], w2 [512,512,1,1],
  * scale2 [512], w3 [C,512,3,3].  Geometries: those of nfdp_coupling_fused_supported; others return NFDP_EUNSUPPORTED. */
 size_t nfdp_coupling_bwd_fused_packed_bytes(int C);
 int nfdp_coupling_bwd_fused_pack(const float* w1, const float* scale1, const float* w2, const float* scale2, const float* w3,
                                  void* packed, int C, nfdp_stream_t stream);
 int nfdp_coupling_bwd_fused_bf16(const float* dc3, float* dx, const void* packed, const void* y1, const void* y2, void* dc1,
-                                 void* dc2, int B, int H, int W, int C, nfdp_stream_t stream);
+                                 void* dc2, void* dc3col, int B, int H, int W, int C, nfdp_stream_t stream);
 /* ldj[b] += (double)(hw * (float)sum(v[0..n_sum)))  (fp32 product): the standalone ActNorm / InvConv2d log-det terms. */
 int nfdp_ldj_add_scaled_f32(double* ldj, int B, const float* v, int n_sum, float hw, nfdp_stream_t stream);
 /* out2[0] = hw*sum(scale[0..C)) (transforms.py:81), out2[1] = hw*logabsdet[0] (transforms.py:131), fp32: the two

@@ -547,8 +547,9 @@ def level_fused(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torc
 def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torch.Tensor]):
     """Training forward of a whole Glow level in ONE persistent launch (nfdp_level_fused_train_bf16): xh [B,H,W,C] is updated in
     place; ldj[b] += the flows' per-sample coupling log-dets only.  -> (xpre, ypost, hout [n,B,H,W,C] fp32; y1, y2
-    [n,Bpad,H,W,512] bf16): per flow the tile before / after the flow head, the zero conv's output and the two hidden activations -
-    y1 / y2 in the fused kernels' BLOCKED layout (blocked_to_rows), not [pixel][512] rows."""
+    [n,Bpad,H,W,512] bf16; xcol [n,Bpad,H,W,cols] bf16): per flow the tile before / after the flow head, the zero conv's output, the
+    two hidden activations - y1 / y2 in the fused kernels' BLOCKED layout (blocked_to_rows), not [pixel][512] rows - and the im2col
+    rows of the coupling network's input."""
     _need(xh, torch.float32, "level_fused_train"); _dense(xh, "level_fused_train")
     b, h, wd, c = xh.shape
     n = len(packed)
@@ -566,13 +567,14 @@ def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optiona
     hout = torch.empty((n, b, h, wd, c), device=dev, dtype=torch.float32)
     y1 = torch.empty((n, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
     y2 = torch.empty((n, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
+    xcol = torch.empty((n, bpad, h, wd, lib().nfdp_coupling_fused_im2col_cols(c, 0)), device=dev, dtype=torch.bfloat16)
     tab = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
     ch = c // 2
     flops = n * 2.0 * b * h * wd * (9 * ch * 512 + 512 * 512 + 9 * 512 * c + c * c)
     _call("nfdp_level_fused_train_bf16", _ptr(xh), b, h, wd, c, n, tab(packed), tab(scales), tab(biases), tab(ws), _ptr(ldj),
-          _ptr(xpre), _ptr(ypost), _ptr(hout), _ptr(y1), _ptr(y2), _stream(), label=f"level_fused_train<{c},{wd}> x{n}", flops=flops,
-          nbytes=8.0 * xh.numel() + 12.0 * n * xh.numel() + 2048.0 * n * bpad * h * wd)
-    return xpre, ypost, hout, y1, y2
+          _ptr(xpre), _ptr(ypost), _ptr(hout), _ptr(y1), _ptr(y2), _ptr(xcol), _stream(), label=f"level_fused_train<{c},{wd}> x{n}",
+          flops=flops, nbytes=8.0 * xh.numel() + 12.0 * n * xh.numel() + 2048.0 * n * bpad * h * wd)
+    return xpre, ypost, hout, y1, y2, xcol
 
 
 def coupling_bwd_fused_supported(h: int, w: int, c: int, n_features: int) -> bool:
@@ -596,7 +598,8 @@ def coupling_bwd_fused_pack(w1, s1, w2, s2, w3, out: Optional[torch.Tensor] = No
 def coupling_bwd_fused(dc3: torch.Tensor, dx: torch.Tensor, packed: torch.Tensor, y1: torch.Tensor, y2: torch.Tensor):
     """The coupling network's data-gradient chain in one launch (nfdp_coupling_bwd_fused_bf16).  dc3 [B,H,W,C] fp32 (gradient at the
     zero conv's raw output); y1, y2 [Bpad,H,W,512] bf16 as saved by level_fused_train (BLOCKED layout, Bpad >= B: whole workgroups);
-    dx [B,H,W,C] fp32: its first C/2 channels receive += the network's input gradient.  -> (dc1, dc2), shaped and laid out like y1."""
+    dx [B,H,W,C] fp32: its first C/2 channels receive += the network's input gradient.  -> (dc1, dc2: shaped and laid out like y1;
+    dc3col [Bpad,H,W,cols] bf16: im2col rows of dc3, ordinary rows)."""
     _need(dc3, torch.float32, "coupling_bwd_fused"); _dense(dc3, "coupling_bwd_fused")
     _need(dx, torch.float32, "coupling_bwd_fused dx"); _dense(dx, "coupling_bwd_fused dx")
     _need(y1, torch.bfloat16, "coupling_bwd_fused y1"); _dense(y1, "coupling_bwd_fused y1")
@@ -608,11 +611,12 @@ def coupling_bwd_fused(dc3: torch.Tensor, dx: torch.Tensor, packed: torch.Tensor
         raise ValueError(f"coupling_bwd_fused: shapes dc3 {tuple(dc3.shape)} dx {tuple(dx.shape)} y1 {tuple(y1.shape)} y2 {tuple(y2.shape)}")
     dc1 = torch.empty_like(y1)
     dc2 = torch.empty_like(y2)
+    dc3col = torch.empty((bpad, h, w, lib().nfdp_coupling_fused_im2col_cols(c, 1)), device=dc3.device, dtype=torch.bfloat16)
     ch = c // 2
     flops = 2.0 * b * h * w * (9 * c * 512 + 512 * 512 + 9 * 512 * ch)
-    _call("nfdp_coupling_bwd_fused_bf16", _ptr(dc3), _ptr(dx), _ptr(packed), _ptr(y1), _ptr(y2), _ptr(dc1), _ptr(dc2), b, h, w, c,
-          _stream(), label=f"coupling_bwd_fused<{c},{w}>", flops=flops, nbytes=4096.0 * bpad * h * w)
-    return dc1, dc2
+    _call("nfdp_coupling_bwd_fused_bf16", _ptr(dc3), _ptr(dx), _ptr(packed), _ptr(y1), _ptr(y2), _ptr(dc1), _ptr(dc2), _ptr(dc3col), b, h,
+          w, c, _stream(), label=f"coupling_bwd_fused<{c},{w}>", flops=flops, nbytes=4096.0 * bpad * h * w)
+    return dc1, dc2, dc3col
 
 
 def ldj_add_scaled(ldj: torch.Tensor, v: torch.Tensor, n_sum: int, hw: float):

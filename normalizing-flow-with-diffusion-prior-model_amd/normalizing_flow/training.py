@@ -591,7 +591,7 @@ FUSED_TRAIN_FORWARD = True          # bf16 mode, 32x32-model geometries: the lev
 FUSED_TRAIN_BACKWARD = True         # ... and the data-gradient chain of each coupling network one launch (nfdp_coupling_bwd_fused_bf16)
 
 
-def _net_backward_fused(dh, dx, ypost, h, y1, y2, params, f3, net):
+def _net_backward_fused(dh, dx, xcol, h, y1, y2, params, f3, net):
     """Backward of one coupling network on the fused kernels.  dh: gradient at the zero conv's output h; dx [B,H,W,C]: the coupling's
     input gradient, whose first half receives += the network's input gradient; y1, y2: saved hidden activations ([Bpad,H,W,512]
     bf16).  One launch for the data path (coupling_bwd_fused: zero conv^T -> mask/scale -> 1x1^T -> mask/scale -> input conv^T, hidden
@@ -613,9 +613,7 @@ def _net_backward_fused(dh, dx, ypost, h, y1, y2, params, f3, net):
                                        out=getattr(net, "_fused_bwd", None) if net is not None else None)
     if net is not None:
         object.__setattr__(net, "_fused_bwd", packed)
-    dc1, dc2 = K.coupling_bwd_fused(dc3, dx, packed, y1, y2)
-    dc3_col = K.im2col3x3(dc3, pad_batch=bpad)
-    xcol = K.im2col3x3(ypost[..., : ypost.shape[-1] // 2], pad_batch=bpad)
+    dc1, dc2, dc3_col = K.coupling_bwd_fused(dc3, dx, packed, y1, y2)
     if direct:
         _defer_side(lambda: K.conv_wgrad_blocked(dc3_col, y2, gw3, True, form=2, form_c=co, dy_blocked=True), dc3_col, y2)
         _defer_side(lambda: K.conv_wgrad_affine(y1, dc2, w2.detach(), b2.detach().reshape(-1), gw2, gs2.view(-1), gb2.view(-1), True,
@@ -658,8 +656,8 @@ class LevelFusedFn(Function):
         scales = [params[P * i].detach().reshape(-1) for i in range(n)]
         biases = [params[P * i + 1].detach().reshape(-1) for i in range(n)]
         ws = [params[P * i + 2].detach().reshape(c, c) for i in range(n)]
-        xpre, ypost, hout, y1, y2 = K.level_fused_train(y, packed, scales, biases, ws, acc)
-        ctx.save_for_backward(xpre, ypost, hout, y1, y2, wts)
+        xpre, ypost, hout, y1, y2, xcol = K.level_fused_train(y, packed, scales, biases, ws, acc)
+        ctx.save_for_backward(xpre, ypost, hout, y1, y2, wts, xcol)
         ctx.params, ctx.bpacks, ctx.f3, ctx.n = params, bpacks, float(f3), n
         ctx.nets = meta[4] if len(meta) > 4 else [None] * n
         ctx.ldj_dtype = None if ldj is None else ldj.dtype
@@ -667,7 +665,7 @@ class LevelFusedFn(Function):
 
     @staticmethod
     def backward(ctx, dy, dacc):
-        xpre, ypost, hout, y1, y2, wts = ctx.saved_tensors
+        xpre, ypost, hout, y1, y2, wts, xcol = ctx.saved_tensors
         n, P, params = ctx.n, LevelFusedFn.NP, ctx.params
         b = ypost.shape[1]
         c = ypost.shape[-1]
@@ -681,7 +679,7 @@ class LevelFusedFn(Function):
             net = params[P * i + 3: P * i + 12]
             # affine coupling + network
             dx, dh = K.coupling_bwd(ypost[i], hout[i], dy, dacc_c)
-            g9 = _net_backward_fused(dh, dx, ypost[i], hout[i], y1[i], y2[i], net, ctx.f3, ctx.nets[i])
+            g9 = _net_backward_fused(dh, dx, xcol[i], hout[i], y1[i], y2[i], net, ctx.f3, ctx.nets[i])
             # 1x1 conv (transforms.py:132): y = W a, with a = actnorm(xpre) recomputed (one elementwise launch)
             a = K.actnorm_fwd(xpre[i], scale.detach().reshape(-1), bias.detach().reshape(-1))
             da = K.invconv_apply(dx, wts[i])

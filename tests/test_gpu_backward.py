@@ -715,9 +715,15 @@ def test_fused_reverse_coupling_network(hw, c, B):
         return K.rows_to_blocked(out).to(DEV)
     packed = K.coupling_bwd_fused_pack(w1.to(DEV), s1.to(DEV), w2.to(DEV), s2.to(DEV), w3.to(DEV))
     dx = nhwc(dx0).to(DEV)
-    g1b, g2b = K.coupling_bwd_fused(nhwc(dc3).to(DEV), dx, packed, padded(y1), padded(y2))
+    g1b, g2b, colb = K.coupling_bwd_fused(nhwc(dc3).to(DEV), dx, packed, padded(y1), padded(y2))
     assert g1b.dtype == torch.bfloat16 and tuple(g1b.shape) == (bpad, hw, hw, 512)
     g1, g2 = K.blocked_to_rows(g1b), K.blocked_to_rows(g2b)          # the gradients come back in the same blocked layout
+    # im2col rows of dc3 (x operand of the zero conv's weight-gradient GEMM): the standalone kernel's columns, zero tail images
+    ref_col = K.im2col3x3(nhwc(dc3).to(DEV))
+    ncol = colb.shape[-1]
+    assert ncol == 16 * ((9 * c + 15) // 16) and tuple(colb.shape[:3]) == (bpad, hw, hw)
+    assert torch.equal(colb[:B, ..., : 9 * c], ref_col[..., : 9 * c]) and float(colb[:B, ..., 9 * c:].float().abs().max() if ncol > 9 * c else 0.0) == 0.0
+    assert float(colb[B:].float().abs().max() if bpad > B else 0.0) == 0.0
     assert_close(g2[:B].float(), nhwc(dc2), 2e-2, "dc2")
     assert_close(g1[:B].float(), nhwc(dc1), 2e-2, "dc1")
     want = nhwc(dx0).clone()
@@ -729,7 +735,7 @@ def test_fused_reverse_coupling_network(hw, c, B):
     assert float(g2[:B].float()[nhwc(y2) == 0].abs().max()) == 0.0
     # determinism
     dx_b = nhwc(dx0).to(DEV)
-    h1, h2 = K.coupling_bwd_fused(nhwc(dc3).to(DEV), dx_b, packed, padded(y1), padded(y2))
+    h1, h2, _ = K.coupling_bwd_fused(nhwc(dc3).to(DEV), dx_b, packed, padded(y1), padded(y2))
     assert torch.equal(h1, g1b) and torch.equal(h2, g2b) and torch.equal(dx_b, dx)
 
 

@@ -46,3 +46,35 @@ with torch.no_grad():
         gb = 2 * len(flows) * B * hw * hw * 512 * 2 / 1e9
         print(f"level {hw}x{hw}x{c}: inference {t_inf - t_clone:8.1f} us   training {t_tr - t_clone:8.1f} us   "
               f"(+{gb:.2f} GB hidden stores -> {gb / ((t_tr - t_clone) * 1e-6) / 1e3:.2f} TB/s if it were the only cost)", flush=True)
+
+    # the reverse coupling network (one flow) and the three weight-gradient GEMMs of a flow, in isolation
+    for flows, (hw, c) in zip(levels, shapes):
+        f = flows[0]
+        net = f.affcoupling.net
+        w1, s1, b1 = net[0].conv.weight, net[0].actnorm.scale.view(-1), net[0].actnorm.bias.view(-1)
+        w2, s2, b2 = net[2].conv.weight, net[2].actnorm.scale.view(-1), net[2].actnorm.bias.view(-1)
+        w3 = net[4].weight
+        packed = K.coupling_bwd_fused_pack(w1, s1, w2, s2, w3)
+        grp = {16: 1, 8: 2, 4: 8}[hw]
+        bpad = (B + grp - 1) // grp * grp
+        y1 = torch.relu(torch.randn(bpad, hw, hw, 512, device=dev)).to(torch.bfloat16)
+        y2 = torch.relu(torch.randn(bpad, hw, hw, 512, device=dev)).to(torch.bfloat16)
+        dc3 = torch.randn(B, hw, hw, c, device=dev)
+        dx = torch.zeros(B, hw, hw, c, device=dev)
+        out = []
+        def bwd():
+            out.clear(); out.extend(K.coupling_bwd_fused(dc3, dx, packed, y1, y2))
+        t_b = timed(bwd)
+        dc1, dc2, _ = out
+        gw2, gs, gb = torch.zeros_like(w2), torch.zeros(512, device=dev), torch.zeros(512, device=dev)
+        t_w2 = timed(lambda: K.conv_wgrad_affine(y1, dc2, w2, b2, gw2, gs, gb, True, x_blocked=True, dy_blocked=True))
+        xcol = K.im2col3x3(torch.randn(B, hw, hw, c // 2, device=dev), pad_batch=bpad)
+        gw1 = torch.zeros_like(w1)
+        t_w1 = timed(lambda: K.conv_wgrad_affine(xcol, dc1, w1, b1, gw1, gs, gb, True, form=1, form_c=c // 2, dy_blocked=True))
+        dcol = K.im2col3x3(dc3, pad_batch=bpad)
+        gw3 = torch.zeros_like(w3)
+        t_w3 = timed(lambda: K.conv_wgrad_blocked(dcol, y2, gw3, True, form=2, form_c=c, dy_blocked=True))
+        npx = B * hw * hw
+        fl = 2.0 * npx * (9 * c * 512 + 512 * 512 + 9 * 512 * (c // 2))
+        print(f"level {hw}x{hw}x{c}: reverse network {t_b:7.1f} us ({fl / t_b / 1e6:6.0f} TFLOP/s, {4 * bpad * hw * hw * 1024 / t_b / 1e6:5.2f} TB/s hidden traffic)   "
+              f"dW2 {t_w2:6.1f} us ({2.0 * npx * 512 * 512 / t_w2 / 1e6:4.0f} TFLOP/s)  dW1 {t_w1:6.1f} us  dW3 {t_w3:6.1f} us", flush=True)
