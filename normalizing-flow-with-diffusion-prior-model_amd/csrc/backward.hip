@@ -527,6 +527,231 @@ __global__ void coupling_bwd_kernel(const float* __restrict__ x, const float* __
     }
 }
 
+// ----------------------------------------------------------------------------- link between two flow steps of the backward pass
+// Between the reverse coupling network of flow i and that of flow i-1 the backward pass runs, per pixel, the flow head of i backwards
+// (1x1 conv, ActNorm: transforms.py:132, :80) and the affine coupling of i-1 backwards (transforms.py:179-185) with the scale
+// backward of its ZeroConv2d (utils.py:43-44) - seven launches at their floor in the per-op path (ActNorm recompute, W^T product,
+// two scale backwards + two finishes, coupling backward).  Here: one launch, one thread per pixel with its C-channel rows in registers,
+//   a   = e^s (xpre + b)                 (ActNorm output of flow i: written out for the 1x1 conv's weight gradient)
+//   da  = W^T dx_in,   dy = da e^s       (dy = dx_in when there is no head: first call of a level; `wt` is W itself, row-major)
+//   part: sum da a (-> dscale), sum da e^s (-> dbias)
+//   coupling of i-1 on (ypost, hout, dy, gl) as coupling_bwd_kernel -> dx_out, dh;  dc3 = dh e^{f logs3}
+//   part: sum dh hout (-> dlogs3 / f), sum dc3 (-> dbias3)                            (no coupling: dx_out = dy, last call of a level)
+// and per-workgroup column sums in fp64 (fixed order: deterministic), reduced for all calls of a level by ONE finish launch.
+struct LinkParams {
+    const float* dx_in; const float* xpre; const float* wt; const float* scale; const float* bias; float* a_out;
+    const float* ypost; const float* hout; const double* gl; const float* logs3; float f3;
+    float* dx_out; float* dc3_out; double* part;
+    long npix; int HW;
+};
+
+template <int C>
+__global__ void __launch_bounds__(kBlock) flow_link_bwd_kernel(const LinkParams p) {
+    constexpr int Ch = C / 2, TS = C + 1;
+    __shared__ __attribute__((aligned(16))) float wt_s[C * C];
+    __shared__ float es_s[C], bs_s[C], fac_s[C];
+    __shared__ float tile[kBlock * TS];
+    const int tid = threadIdx.x;
+    const long px = (long)blockIdx.x * kBlock + tid;
+    const bool live = px < p.npix;
+    const bool head = p.xpre != nullptr, cpl = p.ypost != nullptr;
+    if (head) {
+        for (int i = tid; i < C * C; i += kBlock) wt_s[i] = p.wt[i];
+        for (int c = tid; c < C; c += kBlock) { es_s[c] = expf(p.scale[c]); bs_s[c] = p.bias[c]; }
+    }
+    if (cpl)
+        for (int c = tid; c < C; c += kBlock) fac_s[c] = expf(__fmul_rn(p.f3, p.logs3[c]));
+    __syncthreads();
+    // column sums over the workgroup's 256 pixels, one quantity at a time through a [256][C+1] tile (odd row stride: conflict-free)
+    double* out = p.part + (size_t)blockIdx.x * 4 * C;
+    auto colsum = [&](int q, const float (&v)[C]) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < C; ++c) tile[tid * TS + c] = live ? v[c] : 0.f;
+        __syncthreads();
+        if (tid < C) {
+            double sum = 0.0;
+            for (int r = 0; r < kBlock; ++r) sum += (double)tile[r * TS + tid];
+            out[q * C + tid] = sum;
+        }
+    };
+    float dy[C];
+    if (head) {
+        // da = W^T dx_in: the thread's dx row goes through its own LDS tile row so the product can walk the input channels with a
+        // run-time index (a fully unrolled C x C product keeps every weight live: 8 KB of scratch per lane at C = 48)
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) v = *reinterpret_cast<const float4*>(p.dx_in + px * C + c);
+            float* d = tile + tid * TS + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        float da[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) da[c] = 0.f;
+#pragma unroll 2
+        for (int k = 0; k < C; ++k) {
+            const float xv = tile[tid * TS + k];
+            const float* wr = wt_s + k * C;                       // W[k][:] (row-major 1x1 weight): broadcast float4 reads
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wr + c);
+                da[c] = fmaf(w4.x, xv, da[c]); da[c + 1] = fmaf(w4.y, xv, da[c + 1]);
+                da[c + 2] = fmaf(w4.z, xv, da[c + 2]); da[c + 3] = fmaf(w4.w, xv, da[c + 3]);
+            }
+        }
+        float q0[C];
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) xv = *reinterpret_cast<const float4*>(p.xpre + px * C + c);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            float av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float es = es_s[c + j];
+                av[j] = __fmul_rn(es, __fadd_rn(xs[j], bs_s[c + j]));
+                dy[c + j] = __fmul_rn(da[c + j], es);
+                q0[c + j] = __fmul_rn(da[c + j], av[j]);
+            }
+            if (live && p.a_out) *reinterpret_cast<float4*>(p.a_out + px * C + c) = make_float4(av[0], av[1], av[2], av[3]);
+        }
+        colsum(0, q0);
+        colsum(1, dy);
+    } else {
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) v = *reinterpret_cast<const float4*>(p.dx_in + px * C + c);
+            dy[c] = v.x; dy[c + 1] = v.y; dy[c + 2] = v.z; dy[c + 3] = v.w;
+        }
+        if (tid < C) { out[tid] = 0.0; out[C + tid] = 0.0; }
+    }
+    if (cpl) {
+        const float g = (p.gl && live) ? (float)p.gl[px / p.HW] : 0.f;
+        float xb[Ch], hv[C];
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) v = *reinterpret_cast<const float4*>(p.hout + px * C + c);
+            hv[c] = v.x; hv[c + 1] = v.y; hv[c + 2] = v.z; hv[c + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < Ch; c += (Ch % 4 == 0 ? 4 : 2)) {
+            if constexpr (Ch % 4 == 0) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) v = *reinterpret_cast<const float4*>(p.ypost + px * C + Ch + c);
+                xb[c] = v.x; xb[c + 1] = v.y; xb[c + 2] = v.z; xb[c + 3] = v.w;
+            } else {
+                float2 v = make_float2(0.f, 0.f);
+                if (live) v = *reinterpret_cast<const float2*>(p.ypost + px * C + Ch + c);
+                xb[c] = v.x; xb[c + 1] = v.y;
+            }
+        }
+        float q2[C], dc3[C];
+#pragma unroll
+        for (int c = 0; c < Ch; ++c) {
+            const float sg = sigmoid_p2(hv[c]);
+            const float t = hv[Ch + c];
+            const float dyb = dy[Ch + c];
+            const float dt = __fmul_rn(dyb, sg);
+            const float ds = __fadd_rn(__fmul_rn(dyb, __fadd_rn(xb[c], t)), __fdiv_rn(g, __fadd_rn(sg, 1e-6f)));
+            const float dls = __fmul_rn(__fmul_rn(ds, sg), __fsub_rn(1.0f, sg));
+            dy[Ch + c] = dt;                                   // dy now holds dx_out = (dy_a | dy_b s)
+            dc3[c] = __fmul_rn(dls, fac_s[c]);
+            dc3[Ch + c] = __fmul_rn(dt, fac_s[Ch + c]);
+            q2[c] = __fmul_rn(dls, hv[c]);
+            q2[Ch + c] = __fmul_rn(dt, hv[Ch + c]);
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                *reinterpret_cast<float4*>(p.dx_out + px * C + c) = make_float4(dy[c], dy[c + 1], dy[c + 2], dy[c + 3]);
+                *reinterpret_cast<float4*>(p.dc3_out + px * C + c) = make_float4(dc3[c], dc3[c + 1], dc3[c + 2], dc3[c + 3]);
+            }
+        }
+        colsum(2, q2);
+        colsum(3, dc3);
+    } else {
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < C; c += 4)
+                *reinterpret_cast<float4*>(p.dx_out + px * C + c) = make_float4(dy[c], dy[c + 1], dy[c + 2], dy[c + 3]);
+        }
+        if (tid < C) { out[2 * C + tid] = 0.0; out[3 * C + tid] = 0.0; }
+    }
+}
+
+// One launch for a whole level: call k's partials [nblk][4][C] -> the four gradients it feeds (pointers may be null).
+constexpr int kMaxLinkCalls = 33;
+struct LinkFinish {
+    float* dscale[kMaxLinkCalls]; float* dbias[kMaxLinkCalls]; float* dlogs3[kMaxLinkCalls]; float* dbias3[kMaxLinkCalls];
+    int n, nblk, C, acc; float f3;
+};
+__global__ void __launch_bounds__(kBlock) flow_link_finish_kernel(const double* __restrict__ part, const LinkFinish f) {
+    __shared__ double red[kBlock];
+    const int call = blockIdx.x / 4, q = blockIdx.x % 4, tid = threadIdx.x;
+    float* dst = q == 0 ? f.dscale[call] : (q == 1 ? f.dbias[call] : (q == 2 ? f.dlogs3[call] : f.dbias3[call]));
+    if (dst == nullptr) return;
+    const double* src = part + ((size_t)call * f.nblk * 4 + q) * f.C;
+    const int G = kBlock / 64;                              // 4 groups of 64 threads: channel = tid % 64, blocks g, g+4, ...
+    const int c = tid & 63, g = tid >> 6;
+    double sum = 0.0;
+    if (c < f.C)
+        for (int b = g; b < f.nblk; b += G) sum += src[(size_t)b * 4 * f.C + c];
+    red[tid] = sum;
+    __syncthreads();
+    if (g == 0 && c < f.C) {
+        double t = 0.0;
+        for (int k = 0; k < G; ++k) t += red[k * 64 + c];
+        const float v = (float)(q == 2 ? t * (double)f.f3 : t);
+        dst[c] = f.acc ? dst[c] + v : v;
+    }
+}
+
+extern "C" size_t nfdp_flow_link_bwd_part_bytes(long npix, int C) { return (size_t)cdiv(npix, kBlock) * 4 * C * sizeof(double); }
+
+extern "C" int nfdp_flow_link_bwd_f32(const float* dx_in, const float* xpre, const float* wt, const float* scale, const float* bias,
+                                      float* a_out, const float* ypost, const float* hout, const double* gl, const float* logs3, float f3,
+                                      float* dx_out, float* dc3_out, void* part, long npix, int HW, int C, nfdp_stream_t stream) {
+    NFDP_REQUIRE(dx_in && dx_out && part, NFDP_EINVAL, "flow_link_bwd: null pointer");
+    NFDP_REQUIRE(!xpre || (wt && scale && bias), NFDP_EINVAL, "flow_link_bwd: head given without wt / scale / bias");
+    NFDP_REQUIRE(!ypost || (hout && logs3 && dc3_out), NFDP_EINVAL, "flow_link_bwd: coupling given without hout / logs3 / dc3_out");
+    NFDP_REQUIRE(xpre || ypost, NFDP_EINVAL, "flow_link_bwd: neither a head nor a coupling");
+    NFDP_REQUIRE(npix >= 0 && HW > 0, NFDP_ESHAPE, "flow_link_bwd: bad shape");
+    NFDP_REQUIRE((((uintptr_t)dx_in | (uintptr_t)xpre | (uintptr_t)a_out | (uintptr_t)ypost | (uintptr_t)hout | (uintptr_t)dx_out |
+                   (uintptr_t)dc3_out) & 15) == 0, NFDP_ESHAPE, "flow_link_bwd: tensors must be 16-byte aligned");
+    if (npix == 0) return NFDP_OK;
+    LinkParams p{dx_in, xpre, wt, scale, bias, a_out, ypost, hout, gl, logs3, f3, dx_out, dc3_out, reinterpret_cast<double*>(part), npix, HW};
+    const dim3 grid((unsigned)cdiv(npix, kBlock));
+    hipStream_t s = as_stream(stream);
+    switch (C) {
+        case 4: hipLaunchKernelGGL(flow_link_bwd_kernel<4>, grid, dim3(kBlock), 0, s, p); break;
+        case 8: hipLaunchKernelGGL(flow_link_bwd_kernel<8>, grid, dim3(kBlock), 0, s, p); break;
+        case 16: hipLaunchKernelGGL(flow_link_bwd_kernel<16>, grid, dim3(kBlock), 0, s, p); break;
+        case 12: hipLaunchKernelGGL(flow_link_bwd_kernel<12>, grid, dim3(kBlock), 0, s, p); break;
+        case 24: hipLaunchKernelGGL(flow_link_bwd_kernel<24>, grid, dim3(kBlock), 0, s, p); break;
+        case 48: hipLaunchKernelGGL(flow_link_bwd_kernel<48>, grid, dim3(kBlock), 0, s, p); break;
+        default: nfdp_set_error("flow_link_bwd: unsupported C=%d", C); return NFDP_EUNSUPPORTED;
+    }
+    NFDP_CHECK_LAUNCH("flow_link_bwd");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_flow_link_finish_f32(const void* part, int n_calls, long npix, int C, float f3, float* const* dscale,
+                                         float* const* dbias, float* const* dlogs3, float* const* dbias3, int accumulate,
+                                         nfdp_stream_t stream) {
+    NFDP_REQUIRE(part && dscale && dbias && dlogs3 && dbias3, NFDP_EINVAL, "flow_link_finish: null pointer");
+    NFDP_REQUIRE(n_calls >= 0 && n_calls <= kMaxLinkCalls && C > 0 && C <= 64 && npix >= 0, NFDP_ESHAPE, "flow_link_finish: bad shape");
+    if (n_calls == 0 || npix == 0) return NFDP_OK;
+    LinkFinish f;
+    for (int i = 0; i < n_calls; ++i) { f.dscale[i] = dscale[i]; f.dbias[i] = dbias[i]; f.dlogs3[i] = dlogs3[i]; f.dbias3[i] = dbias3[i]; }
+    f.n = n_calls; f.nblk = (int)cdiv(npix, kBlock); f.C = C; f.acc = accumulate; f.f3 = f3;
+    hipLaunchKernelGGL(flow_link_finish_kernel, dim3(4 * n_calls), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const double*>(part), f);
+    NFDP_CHECK_LAUNCH("flow_link_finish");
+    return NFDP_OK;
+}
+
 // ----------------------------------------------------------------------------- Gaussian log-density backward
 // dz = gl (-(z-m) e^{-2 ls});  dmean = -dz;  dlogs = gl (-1 + (z-m)^2 e^{-2 ls});  dh is always per element [B,HW,2Cz]
 template <int H_MODE>

@@ -1018,6 +1018,57 @@ def coupling_bwd(xh, hh, dyh, gl: Optional[torch.Tensor]):
     return dx, dh
 
 
+def flow_link_bwd(dx_in: torch.Tensor, part: torch.Tensor, *, head=None, coupling=None, want_a: bool = True):
+    """One launch between two reverse coupling networks of the backward pass (nfdp_flow_link_bwd_f32).  dx_in [B,H,W,C] fp32;
+    head = (xpre, w [C,C] = the 1x1 weight, scale [C], bias [C]) of flow i; coupling = (ypost, hout, gl fp64 [B] or None, logs3 [C], f3) of
+    flow i-1; part: this call's fp64 partial buffer (flow_link_part).  -> (dx_out, dc3 or None, a or None)."""
+    _need(dx_in, torch.float32, "flow_link_bwd"); _dense(dx_in, "flow_link_bwd")
+    b, h, w, c = dx_in.shape
+    npix = b * h * w
+    dx_out = torch.empty_like(dx_in)
+    xpre = wt = scale = bias = a = None
+    if head is not None:
+        xpre, wt, scale, bias = head
+        for t in (xpre, wt, scale, bias):
+            _need(t, torch.float32, "flow_link_bwd head"); _dense(t, "flow_link_bwd head")
+        a = torch.empty_like(dx_in) if want_a else None
+    ypost = hout = gl = logs3 = dc3 = None
+    f3 = 0.0
+    if coupling is not None:
+        ypost, hout, gl, logs3, f3 = coupling
+        for t in (ypost, hout, logs3):
+            _need(t, torch.float32, "flow_link_bwd coupling"); _dense(t, "flow_link_bwd coupling")
+        if gl is not None:
+            _need(gl, torch.float64, "flow_link_bwd gl")
+        dc3 = torch.empty_like(dx_in)
+    _call("nfdp_flow_link_bwd_f32", _ptr(dx_in), _ptr(xpre), _ptr(wt), _ptr(scale), _ptr(bias), _ptr(a), _ptr(ypost), _ptr(hout), _ptr(gl),
+          _ptr(logs3), float(f3), _ptr(dx_out), _ptr(dc3), _ptr(part), npix, h * w, c, _stream(), label=f"flow_link_bwd<{c}>",
+          nbytes=4.0 * npix * c * 6)
+    return dx_out, dc3, a
+
+
+def flow_link_part(n_calls: int, npix: int, c: int, device) -> torch.Tensor:
+    """fp64 partial buffer for n_calls flow_link_bwd launches of a level: [n_calls, blocks, 4, C]."""
+    per = lib().nfdp_flow_link_bwd_part_bytes(npix, c) // 8
+    return torch.empty((n_calls, per), device=device, dtype=torch.float64)
+
+
+def flow_link_finish(part: torch.Tensor, npix: int, c: int, f3: float, dscale, dbias, dlogs3, dbias3, accumulate: bool) -> None:
+    """Reduce the partials of all link calls of a level in one launch; the four lists hold one fp32 [C] tensor or None per call."""
+    n = part.shape[0]
+    tab = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    for ts in (dscale, dbias, dlogs3, dbias3):
+        if len(ts) != n:
+            raise ValueError("flow_link_finish: one entry per call")
+        for t in ts:
+            if t is not None:
+                _need(t, torch.float32, "flow_link_finish"); _dense(t, "flow_link_finish")
+                if t.numel() != c:
+                    raise ValueError("flow_link_finish: outputs are [C]")
+    _call("nfdp_flow_link_finish_f32", _ptr(part), n, npix, c, float(f3), tab(dscale), tab(dbias), tab(dlogs3), tab(dbias3),
+          int(accumulate), _stream(), label="flow_link_finish")
+
+
 def gauss_logp_bwd(zh, h, h_mode: int, gl: torch.Tensor):
     _need(gl, torch.float64, "gauss_logp_bwd")
     b, hh, ww, cz = zh.shape

@@ -591,30 +591,26 @@ FUSED_TRAIN_FORWARD = True          # bf16 mode, 32x32-model geometries: the lev
 FUSED_TRAIN_BACKWARD = True         # ... and the data-gradient chain of each coupling network one launch (nfdp_coupling_bwd_fused_bf16)
 
 
-def _net_backward_fused(dh, dx, xcol, h, y1, y2, params, f3, net):
-    """Backward of one coupling network on the fused kernels.  dh: gradient at the zero conv's output h; dx [B,H,W,C]: the coupling's
-    input gradient, whose first half receives += the network's input gradient; y1, y2: saved hidden activations ([Bpad,H,W,512]
-    bf16).  One launch for the data path (coupling_bwd_fused: zero conv^T -> mask/scale -> 1x1^T -> mask/scale -> input conv^T, hidden
-    gradients written once), three GEMMs over pixels for the parameters - the two hidden layers' ActNorm gradients come out of their
-    weight-gradient GEMMs (conv_wgrad_affine).  -> the nine parameter gradients in `params` order, or None when they went into .grad."""
+def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net):
+    """Backward of one coupling network on the fused kernels, from the gradient dc3 at the zero conv's raw output (the link kernel has
+    applied its scale backward).  dx [B,H,W,C]: the coupling's input gradient, whose first half receives += the network's input
+    gradient; xcol: saved im2col rows of the network's input; y1, y2: saved hidden activations (blocked layout, [Bpad,H,W,512] bf16).
+    One launch for the data path (coupling_bwd_fused: zero conv^T -> mask/scale -> 1x1^T -> mask/scale -> input conv^T, hidden
+    gradients written once, im2col rows of dc3 on the side), three GEMMs over pixels for the parameters - the two hidden layers'
+    ActNorm gradients come out of their weight-gradient GEMMs (conv_wgrad_affine).  -> gradients of (w1, b1, s1, w2, b2, s2, w3) in
+    that order, or None when they went straight into .grad."""
     w1, b1, s1, w2, b2, s2, w3, b3, l3 = params
-    c = K.BF16
     co, hid = w3.shape[0], w3.shape[1]
     o1, i1 = w1.shape[:2]
-    bpad = y1.shape[0]
-    gs = _slots(*params)
+    gs = _slots(w1, b1, s1, w2, b2, s2, w3)
     direct = gs is not None
-    if direct:
-        gw1, gb1, gs1, gw2, gb2, gs2, gw3, gb3, gl3 = gs
-    flat = lambda a, b: (a.view(-1), b.view(-1))
-    # zero conv: h = (u3 + b3) e^{3 l3}
-    dc3, dl3, db3 = K.scale_bwd(dh.contiguous(), h, l3.detach().reshape(-1), f3, False, grads_out=flat(gl3, gb3) if direct else None)
     packed = K.coupling_bwd_fused_pack(w1.detach(), s1.detach().reshape(-1), w2.detach(), s2.detach().reshape(-1), w3.detach(),
                                        out=getattr(net, "_fused_bwd", None) if net is not None else None)
     if net is not None:
         object.__setattr__(net, "_fused_bwd", packed)
     dc1, dc2, dc3_col = K.coupling_bwd_fused(dc3, dx, packed, y1, y2)
     if direct:
+        gw1, gb1, gs1, gw2, gb2, gs2, gw3 = gs
         _defer_side(lambda: K.conv_wgrad_blocked(dc3_col, y2, gw3, True, form=2, form_c=co, dy_blocked=True), dc3_col, y2)
         _defer_side(lambda: K.conv_wgrad_affine(y1, dc2, w2.detach(), b2.detach().reshape(-1), gw2, gs2.view(-1), gb2.view(-1), True,
                                                 x_blocked=True, dy_blocked=True), y1, dc2)
@@ -628,7 +624,7 @@ def _net_backward_fused(dh, dx, xcol, h, y1, y2, params, f3, net):
     dw1, ds1, db1 = torch.empty_like(w1), torch.empty(o1, device=w1.device), torch.empty(o1, device=w1.device)
     K.conv_wgrad_affine(xcol, dc1, w1.detach().contiguous(), b1.detach().reshape(-1), dw1, ds1, db1, False, form=1, form_c=i1,
                         dy_blocked=True)
-    return (dw1, db1.view_as(b1), ds1.view_as(s1), dw2, db2.view_as(b2), ds2.view_as(s2), dw3, db3.view_as(b3), dl3.view_as(l3))
+    return (dw1, db1.view_as(b1), ds1.view_as(s1), dw2, db2.view_as(b2), ds2.view_as(s2), dw3)
 
 
 class LevelFusedFn(Function):
@@ -667,22 +663,30 @@ class LevelFusedFn(Function):
     def backward(ctx, dy, dacc):
         xpre, ypost, hout, y1, y2, wts, xcol = ctx.saved_tensors
         n, P, params = ctx.n, LevelFusedFn.NP, ctx.params
-        b = ypost.shape[1]
-        c = ypost.shape[-1]
+        bsz, hh, ww, c = ypost.shape[1:]
+        npix = bsz * hh * ww
         if dy is None:
             dy = torch.zeros_like(ypost[0])
         dy = dy.contiguous()
-        dacc_c = None if dacc is None else dacc.contiguous()
+        gl = None if dacc is None else dacc.contiguous()
+        f3 = ctx.f3
         grads = [None] * (P * n)
+        # The chain per flow, last flow first:  [link: head of flow i+1 backwards + coupling of flow i backwards] -> reverse coupling
+        # network of flow i (one launch) -> ...; the weight gradients of flow i go to the side stream.  Call k of the link kernel
+        # (k = 0: coupling of the last flow only; k = n: head of the first flow only) leaves per-workgroup partial sums of the four
+        # small parameter gradients it touches; ONE finish launch per level reduces them all.
+        part = K.flow_link_part(n + 1, npix, c, ypost.device)
+        l3 = lambda i: params[P * i + 11].detach().reshape(-1)
+        dx, dc3, _ = K.flow_link_bwd(dy, part[0], coupling=(ypost[n - 1], hout[n - 1], gl, l3(n - 1), f3))
+        direct_small = []
         for i in reversed(range(n)):
             scale, bias, weight = params[P * i: P * i + 3]
             net = params[P * i + 3: P * i + 12]
-            # affine coupling + network
-            dx, dh = K.coupling_bwd(ypost[i], hout[i], dy, dacc_c)
-            g9 = _net_backward_fused(dh, dx, xcol[i], hout[i], y1[i], y2[i], net, ctx.f3, ctx.nets[i])
-            # 1x1 conv (transforms.py:132): y = W a, with a = actnorm(xpre) recomputed (one elementwise launch)
-            a = K.actnorm_fwd(xpre[i], scale.detach().reshape(-1), bias.detach().reshape(-1))
-            da = K.invconv_apply(dx, wts[i])
+            g9 = _net_backward_fused(dc3, dx, xcol[i], y1[i], y2[i], net, ctx.nets[i])          # dx[..., :c/2] += network input gradient
+            head = (xpre[i], weight.detach().reshape(c, c), scale.detach().reshape(-1), bias.detach().reshape(-1))
+            cpl = (ypost[i - 1], hout[i - 1], gl, l3(i - 1), f3) if i > 0 else None
+            dx_next, dc3, a = K.flow_link_bwd(dx, part[n - i], head=head, coupling=cpl)
+            # 1x1 conv weight gradient dW = sum_p dx (x) a  (transforms.py:132), off the critical path
             gw = _slots(weight)
             if gw is not None and weight.dim() == 4:
                 _defer_side(lambda a=a, dx=dx, g=gw[0]: K.conv_wgrad(a, dx, 1, out=g, accumulate=True), a, dx)
@@ -690,22 +694,38 @@ class LevelFusedFn(Function):
             else:
                 dw = K.conv_wgrad(a, dx, 1).view_as(weight)
             _flush_side()                                            # one fork per flow: its four weight gradients
-            # ActNorm (transforms.py:80)
-            gsb = _slots(scale, bias)
-            if gsb is not None:
-                dy, _, _ = K.scale_bwd(da, a, scale.detach().reshape(-1), 1.0, False, grads_out=(gsb[0].view(-1), gsb[1].view(-1)))
-                dsc = dbi = None
-            else:
-                dy, dsc, dbi = K.scale_bwd(da, a, scale.detach().reshape(-1), 1.0, False)
-                dsc, dbi = dsc.view_as(scale), dbi.view_as(bias)
-            grads[P * i: P * i + 3] = [dsc, dbi, dw]
+            grads[P * i + 2] = dw
             if g9 is not None:
-                grads[P * i + 3: P * i + 12] = list(g9)
+                grads[P * i + 3: P * i + 10] = list(g9)
+            dx = dx_next
+        # small parameter gradients: call k feeds ActNorm (scale, bias) of flow n-k (k >= 1) and the zero conv (logs, bias) of flow n-1-k
+        small = []
+        for k in range(n + 1):
+            hf, cf = n - k, n - 1 - k
+            small.append(((params[P * hf], params[P * hf + 1]) if k >= 1 else (None, None)) +
+                         ((params[P * cf + 11], params[P * cf + 10]) if cf >= 0 else (None, None)))
+        flat = [t for tup in small for t in tup if t is not None]
+        gs = _slots(*flat)
+        if gs is not None:
+            it = iter(gs)
+            outs = [[None if t is None else next(it).view(-1) for t in tup] for tup in small]
+            acc = True
+        else:
+            outs = [[None if t is None else torch.empty(t.numel(), device=t.device, dtype=torch.float32) for t in tup] for tup in small]
+            acc = False
+        K.flow_link_finish(part, npix, c, f3, [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs], acc)
+        if not acc:
+            for k, (tup, o) in enumerate(zip(small, outs)):
+                hf, cf = n - k, n - 1 - k
+                if k >= 1:
+                    grads[P * hf], grads[P * hf + 1] = o[0].view_as(tup[0]), o[1].view_as(tup[1])
+                if cf >= 0:
+                    grads[P * cf + 11], grads[P * cf + 10] = o[2].view_as(tup[2]), o[3].view_as(tup[3])
         _join_side()
         dl = None
         if ctx.ldj_dtype is not None and dacc is not None:
             dl = dacc if dacc.dtype == ctx.ldj_dtype else dacc.to(ctx.ldj_dtype)
-        return (dy, dl, None) + tuple(grads)
+        return (dx, dl, None) + tuple(grads)
 
 
 def _level_fused_ok(flows, yh: Tensor) -> bool:

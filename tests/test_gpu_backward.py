@@ -794,3 +794,44 @@ def test_weight_gradient_gemm_with_actnorm_gradients(npix, cin, cout, form_c):
         dw5 = torch.empty_like(dw)
         K.conv_wgrad_blocked(xb, dyb, dw5, False, x_blocked=True, dy_blocked=True)
         assert_close(dw5, dw_want, 2e-3, "plain dW on blocked operands")
+
+
+@pytest.mark.parametrize("c,hw,B", [(12, 16, 3), (24, 8, 5), (48, 4, 21), (4, 16, 2), (16, 4, 7)])
+def test_flow_link_backward_kernel(c, hw, B):
+    """nfdp_flow_link_bwd_f32 + nfdp_flow_link_finish_f32: flow head backwards + previous flow's coupling backwards + zero-conv scale
+    backward in one launch, against the per-op kernels it replaces (ActNorm recompute, W^T product, two scale backwards, coupling
+    backward): all three call shapes of a level (coupling only / both / head only), accumulate and store modes."""
+    ch = c // 2
+    T4 = lambda seed, s=1.0: rnd(B, hw, hw, c, seed=seed, scale=s).to(DEV)
+    dx_in, xpre, ypost, hout = T4(1), T4(2), T4(3), T4(4, 0.5)
+    w = (torch.linalg.qr(rnd(c, c, seed=5))[0] + 0.05 * rnd(c, c, seed=6)).contiguous().to(DEV)
+    scale, bias, l3 = rnd(c, seed=7, scale=0.2).to(DEV), rnd(c, seed=8, scale=0.3).to(DEV), rnd(c, seed=9, scale=0.1).to(DEV)
+    gl = rnd(B, seed=10).double().to(DEV)
+    f3 = 3.0
+    npix = B * hw * hw
+    # per-op reference
+    a = K.actnorm_fwd(xpre, scale, bias)
+    da = K.invconv_apply(dx_in, w.t().contiguous())
+    dy, dscale, dbias = K.scale_bwd(da, a, scale, 1.0, False)
+    dxo, dh = K.coupling_bwd(ypost, hout, dy, gl)
+    dc3, dl3, db3 = K.scale_bwd(dh, hout, l3, f3, False)
+    dxo_c, dh_c = K.coupling_bwd(ypost, hout, dx_in, gl)             # coupling only: dy = dx_in
+    dc3_c, dl3_c, db3_c = K.scale_bwd(dh_c, hout, l3, f3, False)
+    part = K.flow_link_part(3, npix, c, DEV)
+    o0 = K.flow_link_bwd(dx_in, part[0], coupling=(ypost, hout, gl, l3, f3))
+    o1 = K.flow_link_bwd(dx_in, part[1], head=(xpre, w, scale, bias), coupling=(ypost, hout, gl, l3, f3))
+    o2 = K.flow_link_bwd(dx_in, part[2], head=(xpre, w, scale, bias))
+    assert o0[2] is None and o2[1] is None
+    assert_close(o0[0], dxo_c, 1e-6, "coupling only: dx"); assert_close(o0[1], dc3_c, 1e-6, "coupling only: dc3")
+    assert_close(o1[0], dxo, 1e-5, "both: dx"); assert_close(o1[1], dc3, 1e-5, "both: dc3"); assert_close(o1[2], a, 1e-6, "both: a")
+    assert_close(o2[0], dy, 1e-5, "head only: dy"); assert_close(o2[2], a, 1e-6, "head only: a")
+    z = lambda v=0.0: torch.full((c,), v, device=DEV)
+    ds_, db_, dl_, d3_ = [None, z(), z()], [None, z(), z()], [z(), z(), None], [z(), z(), None]
+    K.flow_link_finish(part, npix, c, f3, ds_, db_, dl_, d3_, accumulate=False)
+    assert_close(dl_[0], dl3_c, 2e-5, "dlogs3 (coupling only)"); assert_close(d3_[0], db3_c, 2e-5, "dbias3 (coupling only)")
+    assert_close(ds_[1], dscale, 2e-5, "dscale"); assert_close(db_[1], dbias, 2e-5, "dbias")
+    assert_close(dl_[1], dl3, 2e-5, "dlogs3"); assert_close(d3_[1], db3, 2e-5, "dbias3")
+    assert_close(ds_[2], dscale, 2e-5, "dscale (head only)")
+    acc = [z(1.0), z(2.0)]
+    K.flow_link_finish(part, npix, c, f3, [None, acc[0], None], [None, None, None], [None, None, None], [None, acc[1], None], accumulate=True)
+    assert_close(acc[0] - 1.0, dscale, 2e-5, "accumulated dscale"); assert_close(acc[1] - 2.0, db3, 2e-5, "accumulated dbias3")
