@@ -925,10 +925,20 @@ __global__ void __launch_bounds__(kBlock, 2) wgrad_bf16_dma_kernel(const WgradPa
     extern __shared__ __attribute__((aligned(1024))) char wd_smem[];   // [2 stages][dy tile 16 KiB | x tile 16 KiB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int bid = blockIdx.x;
-    const int nb = bid % p.nblocks; bid /= p.nblocks;
-    const int mb = bid % p.mblocks;
-    const int ks = bid / p.mblocks;
+    // Workgroup -> (pixel slice, output tile).  The mblocks x nblocks tiles of one pixel slice read the same operand rows (each A tile
+    // nblocks times, each B tile mblocks times): they belong on ONE XCD, whose L2 then serves the re-reads.  Workgroups go to XCDs
+    // round-robin (blockIdx % 8), so with the plain order the 16 tiles of a slice of the 512 x 512 gradient sat on all 8 XCDs and every
+    // XCD fetched its own copies from the Infinity Cache / HBM (3x the unique bytes; the kernel spent 63 % of its wave cycles waiting).
+    int bid = blockIdx.x, nb, mb, ks;
+    if (p.ksplit % 8 == 0) {
+        const int tiles = p.mblocks * p.nblocks, j = bid >> 3, t = j % tiles;
+        ks = (bid & 7) + 8 * (j / tiles);
+        mb = t / p.nblocks; nb = t % p.nblocks;
+    } else {
+        nb = bid % p.nblocks; bid /= p.nblocks;
+        mb = bid % p.mblocks;
+        ks = bid / p.mblocks;
+    }
     const long p_begin = (long)ks * p.px_per_split;
     const long p_end = (p_begin + p.px_per_split) < p.npix ? (p_begin + p.px_per_split) : p.npix;
     const __bf16* __restrict__ dyg = reinterpret_cast<const __bf16*>(p.dy);
