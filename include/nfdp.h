@@ -313,6 +313,22 @@ int nfdp_ddim_step_f32(const float* x, const float* eps_hat, const float* noise,
  * t_next (nullable): int64 [B], receives the time of row step+1 for the next U-Net call.  noise must be valid (unused when last). */
 int nfdp_ddim_step_table_f32(const float* x, const float* eps_hat, const float* noise, float* out, long n, const float* table,
                              const long* step, int S, long* t_next, int B, nfdp_stream_t stream);
+/* The same two steps for every objective of GaussianDiffusion.model_predictions (gaussian_diffusion.py:674-694):
+ *   x0 = clamp(x0_a x - x0_b model_out), x0_a / x0_b = (sr, srm1) for pred_noise, (0, -1) for pred_x0, (sqrt_ac, sqrt_one_minus_ac) for
+ *   pred_v;  derive_noise != 0: the noise used by the update is (sr x - x0) / srm1 (predict_noise_from_start :647-651) instead of
+ *   model_out;  x0_out (optional) receives x0 - the next step's self-conditioning input (:744-747).  Table rows of stride 12 carry
+ *   (..., derive at [7], x0_a at [8], x0_b at [9]). */
+int nfdp_ddim_step_ex_f32(const float* x, const float* model_out, const float* noise, float* out, float* x0_out, long n, float sr,
+                          float srm1, float x0_a, float x0_b, int derive_noise, float sqrt_alpha_next, float c, float sigma, int last,
+                          nfdp_stream_t stream);
+int nfdp_ddim_step_table_ex_f32(const float* x, const float* model_out, const float* noise, float* out, float* x0_out, long n,
+                                const float* table, int stride, const long* step, int S, long* t_next, int B, nfdp_stream_t stream);
+/* out = (sqrt_recip_ac[t] x_t - x_start) / sqrt_recipm1_ac[t]   (predict_noise_from_start, gaussian_diffusion.py:647-651). */
+int nfdp_noise_from_start_f32(const float* x_t, const float* x_start, const long* t, const float* sqrt_recip_ac,
+                              const float* sqrt_recipm1_ac, float* out, int B, int per_sample, nfdp_stream_t stream);
+/* out = a x + b  (add_first: (x + b) a): normalize_to_neg_one_to_one x*2-1 / unnormalize_to_zero_to_one (x+1)*0.5
+ * (gaussian_diffusion.py:148-157), the auto_normalize option of GaussianDiffusion. */
+int nfdp_axpb_f32(const float* x, float a, float b, float* out, long n, int add_first, nfdp_stream_t stream);
 /* p_losses :855-859: out[0] = mean_b( mean_chw(|pred-target|^p) * p2_weight[t_b] ), p = 2 (l1=0) or 1 (l1=1);
  * per_sample_ws: B floats of workspace. */
 int nfdp_diffusion_loss_f32(const float* pred, const float* target, const long* t, const float* p2_weight, int B,

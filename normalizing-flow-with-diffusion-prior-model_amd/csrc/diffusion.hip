@@ -38,43 +38,71 @@ __global__ void p_sample_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
-// DDIM step with host-side scalars:  x0 = clamp(sr x - srm1 eps);  last ? x0 : x0*sqrt_an + c*eps + sigma*noise
+// DDIM step with host-side scalars (reference ddim_sample :749-773 with model_predictions :674-694):
+//   x0 = clamp(x0_a x - x0_b out)      x0_a / x0_b by objective: pred_noise (sr, srm1), pred_x0 (0, -1), pred_v (sqrt_ac, sqrt_1m_ac)
+//   e  = derive ? (sr x - x0) / srm1 : out                       (predict_noise_from_start :647-651; pred_noise uses the raw output)
+//   last ? x0 : x0*sqrt_an + c*e + sigma*noise;   x0_out (optional) receives x0 (the next step's self-conditioning input)
 __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
-                                 float* __restrict__ out, long total, float sr, float srm1, float sqrt_an, float c, float sigma,
-                                 int last) {
+                                 float* __restrict__ out, float* __restrict__ x0_out, long total, float sr, float srm1, float x0_a,
+                                 float x0_b, int derive, float sqrt_an, float c, float sigma, int last) {
     for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
-        const float e = eps[i];
-        float x0 = __fsub_rn(__fmul_rn(sr, x[i]), __fmul_rn(srm1, e));
+        const float xv = x[i];
+        float e = eps[i];
+        float x0 = __fsub_rn(__fmul_rn(x0_a, xv), __fmul_rn(x0_b, e));
         x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        if (derive) e = __fdiv_rn(__fsub_rn(__fmul_rn(sr, xv), x0), srm1);
         float v = x0;
         if (!last) v = __fadd_rn(__fadd_rn(__fmul_rn(x0, sqrt_an), __fmul_rn(c, e)), __fmul_rn(sigma, noise[i]));
         out[i] = v;
+        if (x0_out) x0_out[i] = x0;
     }
 }
 
 // The same step with its scalars read from a device table row selected by a device-side step counter, so that ONE captured
-// hipGraph serves every step of the loop: table[s] = (sr, srm1, sqrt_alpha_next, c, sigma, last, time); also writes the U-Net's
-// timestep of the NEXT step into t_next[b] (the graph then increments the counter).  In place (out == x) is fine.
+// hipGraph serves every step of the loop: table[s] = (sr, srm1, sqrt_alpha_next, c, sigma, last, time, derive [, x0_a, x0_b, 0, 0] when
+// stride is 12; stride 8: x0_a = sr, x0_b = srm1); also writes the U-Net's timestep of the NEXT step into t_next[b] (the graph then
+// increments the counter).  In place (out == x) is fine.
 __global__ void ddim_step_table_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ noise,
-                                       float* __restrict__ out, long total, const float* __restrict__ table, const long* __restrict__ step,
-                                       int S, long* __restrict__ t_next, int B) {
+                                       float* __restrict__ out, float* __restrict__ x0_out, long total, const float* __restrict__ table,
+                                       int stride, const long* __restrict__ step, int S, long* __restrict__ t_next, int B) {
     const long sidx = step[0] < S ? step[0] : S - 1;
-    const float* row = table + sidx * 8;
+    const float* row = table + sidx * stride;
     const float sr = row[0], srm1 = row[1], sqrt_an = row[2], c = row[3], sigma = row[4];
     const bool last = row[5] != 0.f;
+    const bool derive = row[7] != 0.f;
+    const float x0_a = stride >= 12 ? row[8] : sr, x0_b = stride >= 12 ? row[9] : srm1;
     for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
-        const float e = eps[i];
-        float x0 = __fsub_rn(__fmul_rn(sr, x[i]), __fmul_rn(srm1, e));
+        const float xv = x[i];
+        float e = eps[i];
+        float x0 = __fsub_rn(__fmul_rn(x0_a, xv), __fmul_rn(x0_b, e));
         x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
+        if (derive) e = __fdiv_rn(__fsub_rn(__fmul_rn(sr, xv), x0), srm1);
         float v = x0;
         if (!last) v = __fadd_rn(__fadd_rn(__fmul_rn(x0, sqrt_an), __fmul_rn(c, e)), __fmul_rn(sigma, noise[i]));
         out[i] = v;
+        if (x0_out) x0_out[i] = x0;
     }
     if (t_next != nullptr && blockIdx.x == 0) {
         const long nidx = sidx + 1 < S ? sidx + 1 : S - 1;
-        const long tn = (long)table[nidx * 8 + 6];
+        const long tn = (long)table[nidx * stride + 6];
         for (int b = threadIdx.x; b < B; b += kBlock) t_next[b] = tn;
     }
+}
+
+// pred_noise = (sqrt(1/ac)[t] x_t - x0) / sqrt(1/ac - 1)[t]   (predict_noise_from_start, reference :647-651)
+__global__ void noise_from_start_kernel(const float* __restrict__ x, const float* __restrict__ x0, const long* __restrict__ t,
+                                        const float* __restrict__ sr, const float* __restrict__ srm1, float* __restrict__ out, long total,
+                                        int per_sample) {
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock) {
+        const long tb = t[i / per_sample];
+        out[i] = __fdiv_rn(__fsub_rn(__fmul_rn(sr[tb], x[i]), x0[i]), srm1[tb]);
+    }
+}
+
+// out = a x + b   (normalize_to_neg_one_to_one / unnormalize_to_zero_to_one, reference :148-157: x*2-1 and (x+1)*0.5 = 0.5 x + 0.5)
+__global__ void axpb_kernel(const float* __restrict__ x, float a, float b, float* __restrict__ out, long total, int mul_after_add) {
+    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < total; i += (long)gridDim.x * kBlock)
+        out[i] = mul_after_add ? __fmul_rn(__fadd_rn(x[i], b), a) : __fadd_rn(__fmul_rn(x[i], a), b);
 }
 
 // out[0] = mean_b( mean_chw(|pred-target|^p) * w[t_b] );  one workgroup per sample writes its term, then a finisher
@@ -213,25 +241,58 @@ extern "C" int nfdp_p_sample_f32(const float* x, const float* eps_hat, const flo
     return NFDP_OK;
 }
 
-extern "C" int nfdp_ddim_step_f32(const float* x, const float* eps_hat, const float* noise, float* out, long n, float sr,
-                                  float srm1, float sqrt_alpha_next, float c, float sigma, int last, nfdp_stream_t stream) {
-    NFDP_REQUIRE(x && eps_hat && out && (last || noise), NFDP_EINVAL, "ddim_step: null pointer");
+extern "C" int nfdp_ddim_step_ex_f32(const float* x, const float* model_out, const float* noise, float* out, float* x0_out, long n,
+                                     float sr, float srm1, float x0_a, float x0_b, int derive_noise, float sqrt_alpha_next, float c,
+                                     float sigma, int last, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && model_out && out && (last || noise), NFDP_EINVAL, "ddim_step: null pointer");
     NFDP_REQUIRE(n >= 0, NFDP_ESHAPE, "ddim_step: bad size");
     if (n == 0) return NFDP_OK;
-    hipLaunchKernelGGL(ddim_step_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), x, eps_hat, noise, out, n,
-                       sr, srm1, sqrt_alpha_next, c, sigma, last);
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), x, model_out, noise, out,
+                       x0_out, n, sr, srm1, x0_a, x0_b, derive_noise, sqrt_alpha_next, c, sigma, last);
     NFDP_CHECK_LAUNCH("ddim_step");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_ddim_step_f32(const float* x, const float* eps_hat, const float* noise, float* out, long n, float sr,
+                                  float srm1, float sqrt_alpha_next, float c, float sigma, int last, nfdp_stream_t stream) {
+    return nfdp_ddim_step_ex_f32(x, eps_hat, noise, out, nullptr, n, sr, srm1, sr, srm1, 0, sqrt_alpha_next, c, sigma, last, stream);
+}
+
+extern "C" int nfdp_ddim_step_table_ex_f32(const float* x, const float* model_out, const float* noise, float* out, float* x0_out, long n,
+                                           const float* table, int stride, const long* step, int S, long* t_next, int B,
+                                           nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && model_out && noise && out && table && step, NFDP_EINVAL, "ddim_step_table: null pointer");
+    NFDP_REQUIRE(n >= 0 && S > 0 && B >= 0 && (stride == 8 || stride == 12), NFDP_ESHAPE, "ddim_step_table: bad size / stride");
+    if (n == 0) return NFDP_OK;
+    hipLaunchKernelGGL(ddim_step_table_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), x, model_out, noise, out,
+                       x0_out, n, table, stride, step, S, t_next, B);
+    NFDP_CHECK_LAUNCH("ddim_step_table");
     return NFDP_OK;
 }
 
 extern "C" int nfdp_ddim_step_table_f32(const float* x, const float* eps_hat, const float* noise, float* out, long n,
                                         const float* table, const long* step, int S, long* t_next, int B, nfdp_stream_t stream) {
-    NFDP_REQUIRE(x && eps_hat && noise && out && table && step, NFDP_EINVAL, "ddim_step_table: null pointer");
-    NFDP_REQUIRE(n >= 0 && S > 0 && B >= 0, NFDP_ESHAPE, "ddim_step_table: bad size");
+    return nfdp_ddim_step_table_ex_f32(x, eps_hat, noise, out, nullptr, n, table, 8, step, S, t_next, B, stream);
+}
+
+extern "C" int nfdp_noise_from_start_f32(const float* x_t, const float* x_start, const long* t, const float* sqrt_recip_ac,
+                                         const float* sqrt_recipm1_ac, float* out, int B, int per_sample, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x_t && x_start && t && sqrt_recip_ac && sqrt_recipm1_ac && out, NFDP_EINVAL, "noise_from_start: null pointer");
+    NFDP_REQUIRE(B >= 0 && per_sample > 0, NFDP_ESHAPE, "noise_from_start: bad shape");
+    const long n = (long)B * per_sample;
     if (n == 0) return NFDP_OK;
-    hipLaunchKernelGGL(ddim_step_table_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), x, eps_hat, noise, out,
-                       n, table, step, S, t_next, B);
-    NFDP_CHECK_LAUNCH("ddim_step_table");
+    hipLaunchKernelGGL(noise_from_start_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), x_t, x_start, t,
+                       sqrt_recip_ac, sqrt_recipm1_ac, out, n, per_sample);
+    NFDP_CHECK_LAUNCH("noise_from_start");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_axpb_f32(const float* x, float a, float b, float* out, long n, int add_first, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && out, NFDP_EINVAL, "axpb: null pointer");
+    NFDP_REQUIRE(n >= 0, NFDP_ESHAPE, "axpb: bad size");
+    if (n == 0) return NFDP_OK;
+    hipLaunchKernelGGL(axpb_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, as_stream(stream), x, a, b, out, n, add_first);
+    NFDP_CHECK_LAUNCH("axpb");
     return NFDP_OK;
 }
 

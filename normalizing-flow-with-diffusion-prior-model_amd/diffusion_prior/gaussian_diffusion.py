@@ -10,10 +10,12 @@ reverse-diffusion step with on-device schedule lookup are one launch each).  All
 (`noise=` / `noises=`) for reproducible parity tests.  With trainable parameters and grad mode on, `Unet.forward` and
 `p_losses` run the differentiable path of diffusion_prior/training.py (autograd Functions over HIP forward/backward kernels).
 
-Not built (raise NotImplementedError): objectives other than 'pred_noise', self-conditioning, learned / random
-sinusoidal embeddings, auto_normalize.
+All three objectives ('pred_noise', 'pred_x0', 'pred_v'), self-conditioning and auto_normalize are built (the captured-graph loops
+serve the plain case - every recipe of the reference - and the eager loops the self-conditioned one).  Not built (raise
+NotImplementedError): learned / random sinusoidal embeddings, which the reference's GaussianDiffusion itself rejects (:559).
 """
 import math
+from random import random as _random
 from collections import namedtuple
 from functools import partial
 from typing import Optional, Sequence
@@ -43,7 +45,13 @@ def identity(t, *args, **kwargs):
 
 
 def normalize_to_neg_one_to_one(img):
-    raise NotImplementedError("auto_normalize=True is not on the hot path (DiffusionModel passes False, model.py:37-38)")
+    """img * 2 - 1  (reference :148-150)"""
+    return K.as_nchw(K.axpb(K.to_nhwc(img), 2.0, -1.0))
+
+
+def unnormalize_to_zero_to_one(t):
+    """(t + 1) * 0.5  (reference :153-157)"""
+    return K.as_nchw(K.axpb(K.to_nhwc(t), 0.5, 1.0, add_first=True))
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -225,13 +233,14 @@ class Unet(_EpochOnApply, nn.Module):
                  resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
                  random_fourier_features=False, learned_sinusoidal_dim=16, compute: Optional[str] = None):
         super().__init__()
-        if self_condition or learned_sinusoidal_cond or random_fourier_features:
-            raise NotImplementedError("self-conditioning / learned sinusoidal embeddings are not on the hot path")
+        if learned_sinusoidal_cond or random_fourier_features:
+            raise NotImplementedError("learned / random sinusoidal embeddings are not built (the reference's GaussianDiffusion rejects "
+                                      "such a U-Net, gaussian_diffusion.py:559)")
         self.compute = compute
         self.dim = dim
         self.channels = channels
         self.self_condition = self_condition
-        input_channels = channels
+        input_channels = channels * (2 if self_condition else 1)
         init_dim = default(init_dim, dim)
         self.init_conv = _Conv(input_channels, init_dim, 7)
         dims = [init_dim, *map(lambda m: dim * m, dim_mults)]
@@ -300,8 +309,16 @@ class Unet(_EpochOnApply, nn.Module):
             off += n
         return out
 
-    def forward_nhwc(self, xh: Tensor, time: Tensor) -> Tensor:
+    def with_self_cond(self, xh: Tensor, x_self_cond_h: Optional[Tensor]) -> Tensor:
+        """torch.cat((x_self_cond or zeros, x), dim=1)  (reference :452-454), NHWC."""
+        if not self.self_condition:
+            return xh
+        sc = torch.zeros_like(xh) if x_self_cond_h is None else x_self_cond_h
+        return K.concat_channels(sc.contiguous(), xh.contiguous())
+
+    def forward_nhwc(self, xh: Tensor, time: Tensor, x_self_cond_h: Optional[Tensor] = None) -> Tensor:
         c = self.compute
+        xh = self.with_self_cond(xh, x_self_cond_h)
         x = self.init_conv.forward_nhwc(xh, c)
         r = x
         ss = self._all_scale_shifts(self.time_embedding(time, silu_out=True))
@@ -333,12 +350,11 @@ class Unet(_EpochOnApply, nn.Module):
 
     def forward(self, x, time, x_self_cond=None):
         """(reference :451-490)"""
-        if x_self_cond is not None:
-            raise NotImplementedError("self-conditioning is not on the hot path")
+        sch = None if x_self_cond is None else K.to_nhwc(x_self_cond).contiguous()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from . import training                     # differentiable exact-fp32 path (diffusion_prior/training.py)
-            return K.as_nchw(training.unet_forward(self, K.to_nhwc(x).contiguous(), time))
-        return K.as_nchw(self.forward_nhwc(K.to_nhwc(x).contiguous(), time))
+            return K.as_nchw(training.unet_forward(self, K.to_nhwc(x).contiguous(), time, sch))
+        return K.as_nchw(self.forward_nhwc(K.to_nhwc(x).contiguous(), time, sch))
 
 
 # ----------------------------------------------------------------------------- schedules (:495-537)
@@ -387,8 +403,6 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
         self.image_size = image_size
         self.objective = objective
         assert objective in {'pred_noise', 'pred_x0', 'pred_v'}, 'objective must be either pred_noise, pred_x0 or pred_v'
-        if objective != 'pred_noise':
-            raise NotImplementedError("only objective='pred_noise' is built (the reference's recipes use it)")
         if beta_schedule == 'linear':
             beta_schedule_fn = linear_beta_schedule
         elif beta_schedule == 'cosine':
@@ -425,10 +439,20 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
         register_buffer('p2_loss_weight', (p2_loss_weight_k + alphas_cumprod / (1 - alphas_cumprod)) ** -p2_loss_weight_gamma)
         # kernel-side helper (not part of the reference's state): -sqrt(1/ac - 1) so x0 = a[t]*x + b[t]*eps is one launch
         self.register_buffer('_neg_sqrt_recipm1', -self.sqrt_recipm1_alphas_cumprod.clone(), persistent=False)
-        if auto_normalize:
-            raise NotImplementedError("auto_normalize=True is not on the hot path (DiffusionModel passes False)")
-        self.normalize = identity
-        self.unnormalize = identity
+        # x0 = _x0_a[t] x_t - _x0_b[t] model_out for every objective (model_predictions, reference :674-694): the kernels that used to
+        # take (sqrt_recip_ac, sqrt_recipm1_ac) take this pair - pred_noise: exactly those two (predict_start_from_noise :641-645);
+        # pred_x0: (0, -1), i.e. the output itself; pred_v: (sqrt_ac, sqrt_one_minus_ac) (predict_start_from_v :659-663)
+        if objective == 'pred_noise':
+            x0_a, x0_b = self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod
+        elif objective == 'pred_x0':
+            x0_a, x0_b = torch.zeros_like(self.betas), -torch.ones_like(self.betas)
+        else:
+            x0_a, x0_b = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+        self.register_buffer('_x0_a', x0_a.clone(), persistent=False)
+        self.register_buffer('_x0_b', x0_b.clone(), persistent=False)
+        self.register_buffer('_neg_sqrt_one_minus_ac', -self.sqrt_one_minus_alphas_cumprod.clone(), persistent=False)
+        self.normalize = normalize_to_neg_one_to_one if auto_normalize else identity
+        self.unnormalize = unnormalize_to_zero_to_one if auto_normalize else identity
         # The reverse step is ~150 small launches (launch-bound in eager mode): p_sample_loop replays ONE captured
         # hipGraph per timestep instead; set use_graph=False to force the eager loop.
         self.use_graph = True
@@ -448,7 +472,7 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
     def _step_inplace(self, xh: Tensor, tb: Tensor, gen: Optional[torch.Generator] = None) -> None:
         eps = self.model.forward_nhwc(xh, tb)
         noise = torch.randn_like(xh) if gen is None else torch.randn(xh.shape, device=xh.device, dtype=xh.dtype, generator=gen)
-        K.p_sample(xh, eps, noise, tb, self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
+        K.p_sample(xh, eps, noise, tb, self._x0_a, self._x0_b,
                    self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
                    want_x0=False, clip=True, out=xh)
         tb.sub_(1)
@@ -491,40 +515,62 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
         mean = K.as_nchw(K.q_sample(xs, xt, t.contiguous(), self.posterior_mean_coef1, self.posterior_mean_coef2))
         return mean, extract(self.posterior_variance, t, x_t.shape), extract(self.posterior_log_variance_clipped, t, x_t.shape)
 
+    def predict_noise_from_start(self, x_t, t, x0):
+        """(sqrt(1/ac) x_t - x0) / sqrt(1/ac - 1)  (reference :647-651)."""
+        return K.as_nchw(K.noise_from_start(K.to_nhwc(x_t).contiguous(), K.to_nhwc(x0).contiguous(), t.contiguous(),
+                                            self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod))
+
+    def predict_v(self, x_start, t, noise):
+        """sqrt(ac) noise - sqrt(1 - ac) x_start  (reference :653-657)."""
+        return K.as_nchw(K.q_sample(K.to_nhwc(noise).contiguous(), K.to_nhwc(x_start).contiguous(), t.contiguous(),
+                                    self.sqrt_alphas_cumprod, self._neg_sqrt_one_minus_ac))
+
+    def predict_start_from_v(self, x_t, t, v):
+        """sqrt(ac) x_t - sqrt(1 - ac) v  (reference :659-663)."""
+        return K.as_nchw(K.q_sample(K.to_nhwc(x_t).contiguous(), K.to_nhwc(v).contiguous(), t.contiguous(),
+                                    self.sqrt_alphas_cumprod, self._neg_sqrt_one_minus_ac))
+
+    def _predictions_nhwc(self, xh: Tensor, t: Tensor, sch: Optional[Tensor], clip: bool, want_noise: bool = True):
+        """model output -> (pred_noise or None, x_start, posterior mean) for the objective (reference :674-694 + q_posterior)."""
+        out = self.model.forward_nhwc(xh, t, sch)
+        mean, x0 = K.p_sample(xh, out, None, t, self._x0_a, self._x0_b, self.posterior_mean_coef1, self.posterior_mean_coef2,
+                              self.posterior_log_variance_clipped, want_x0=True, clip=clip)
+        if not want_noise:
+            return None, x0, mean
+        if self.objective == 'pred_noise':
+            return out, x0, mean
+        return K.noise_from_start(xh, x0, t, self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod), x0, mean
+
     def model_predictions(self, x, t, x_self_cond=None, clip_x_start=False):
         """(reference :674-694)"""
         xh = K.to_nhwc(x).contiguous()
-        eps = self.model.forward_nhwc(xh, t)
-        _, x0 = K.p_sample(xh, eps, None, t.contiguous(), self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
-                           self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
-                           want_x0=True, clip=clip_x_start)
+        sch = None if x_self_cond is None else K.to_nhwc(x_self_cond).contiguous()
+        eps, x0, _ = self._predictions_nhwc(xh, t.contiguous(), sch, clip_x_start)
         return ModelPrediction(K.as_nchw(eps), K.as_nchw(x0))
 
     def p_mean_variance(self, x, t, x_self_cond=None, clip_denoised=True):
         """(reference :696-704)"""
         xh = K.to_nhwc(x).contiguous()
-        eps = self.model.forward_nhwc(xh, t)
-        mean, x0 = K.p_sample(xh, eps, None, t.contiguous(), self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
-                              self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
-                              want_x0=True, clip=clip_denoised)
+        sch = None if x_self_cond is None else K.to_nhwc(x_self_cond).contiguous()
+        _, x0, mean = self._predictions_nhwc(xh, t.contiguous(), sch, clip_denoised, want_noise=False)
         return (K.as_nchw(mean), extract(self.posterior_variance, t, x.shape),
                 extract(self.posterior_log_variance_clipped, t, x.shape), K.as_nchw(x0))
 
-    def _p_sample_nhwc(self, xh: Tensor, t: int, noise: Optional[Tensor], want_x0: bool):
+    def _p_sample_nhwc(self, xh: Tensor, t: int, noise: Optional[Tensor], want_x0: bool, sch: Optional[Tensor] = None):
         b = xh.shape[0]
         tb = torch.full((b,), t, device=xh.device, dtype=torch.long)
-        eps = self.model.forward_nhwc(xh, tb)
+        out = self.model.forward_nhwc(xh, tb, sch)
         if t > 0 and noise is None:
             noise = torch.randn_like(xh)
-        return K.p_sample(xh, eps, noise if t > 0 else None, tb, self.sqrt_recip_alphas_cumprod,
-                          self.sqrt_recipm1_alphas_cumprod, self.posterior_mean_coef1, self.posterior_mean_coef2,
-                          self.posterior_log_variance_clipped, want_x0=want_x0, clip=True)
+        return K.p_sample(xh, out, noise if t > 0 else None, tb, self._x0_a, self._x0_b, self.posterior_mean_coef1,
+                          self.posterior_mean_coef2, self.posterior_log_variance_clipped, want_x0=want_x0, clip=True)
 
     @torch.no_grad()
     def p_sample(self, x, t: int, x_self_cond=None, noise: Optional[Tensor] = None):
         """One reverse step (reference :706-715); `noise` (logical NCHW) replaces the randn_like draw."""
         nh = None if noise is None else K.to_nhwc(noise).contiguous()
-        img, x0 = self._p_sample_nhwc(K.to_nhwc(x).contiguous(), t, nh, True)
+        sch = None if x_self_cond is None else K.to_nhwc(x_self_cond).contiguous()
+        img, x0 = self._p_sample_nhwc(K.to_nhwc(x).contiguous(), t, nh, True, sch)
         return K.as_nchw(img), K.as_nchw(x0)
 
     @torch.no_grad()
@@ -534,7 +580,8 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
         replace the device RNG draws."""
         device = self.betas.device
         b, c, h, w = shape
-        if self.use_graph and x_T is None and noises is None and not return_all_timesteps and self.num_timesteps > 1:
+        if self.use_graph and x_T is None and noises is None and not return_all_timesteps and self.num_timesteps > 1 \
+                and not self.self_condition:
             it = self.p_sample_loop_iter(shape)
             try:
                 while True:
@@ -543,9 +590,11 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
                 return done.value
         img = torch.randn((b, h, w, c), device=device) if x_T is None else K.to_nhwc(x_T.to(device)).contiguous()
         imgs = [img]
+        x_start = None
         for i, t in enumerate(reversed(range(0, self.num_timesteps))):
             nz = None if noises is None or t == 0 else K.to_nhwc(noises[i].to(device)).contiguous()
-            img, _ = self._p_sample_nhwc(img, t, nz, False)
+            self_cond = x_start if self.self_condition else None               # (reference :726-728)
+            img, x_start = self._p_sample_nhwc(img, t, nz, self.self_condition, self_cond)
             if return_all_timesteps:
                 imgs.append(img)
         ret = K.as_nchw(img) if not return_all_timesteps else torch.stack([K.as_nchw(i) for i in imgs], dim=1)
@@ -578,44 +627,50 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
     def reverse_from_iter(self, x_t: Tensor, t_first: int):
         """Reverse chain from a given x_t (logical NCHW) at timestep t_first down to 0: the captured loop when available (a
         generator, see p_sample_loop_iter), else the eager p_sample loop."""
-        if self.use_graph and x_t.is_cuda and t_first >= 1:
+        if self.use_graph and x_t.is_cuda and t_first >= 1 and not self.self_condition:
             return (yield from self.p_sample_loop_iter(tuple(x_t.shape), K.to_nhwc(x_t).contiguous(), t_first))
         with torch.no_grad():
             img = K.to_nhwc(x_t).contiguous()
+            x_start = None
             for i in reversed(range(0, t_first + 1)):
-                img, _ = self._p_sample_nhwc(img, i, None, False)
+                self_cond = x_start if self.self_condition else None
+                img, x_start = self._p_sample_nhwc(img, i, None, self.self_condition, self_cond)
             return self.unnormalize(K.as_nchw(img))
 
     def sample_iter(self, batch_size=16):
         """Generator form of sample(): yields between timesteps where the loop can be interleaved with other chains (the
         hipGraph paths of p_sample_loop and ddim_sample); the eager loops run to completion inside the first next()."""
         shape = (batch_size, self.channels, self.image_size, self.image_size)
-        if not self.is_ddim_sampling and self.use_graph and self.num_timesteps > 1:
+        if not self.is_ddim_sampling and self.use_graph and self.num_timesteps > 1 and not self.self_condition:
             return (yield from self.p_sample_loop_iter(shape))
-        if self.is_ddim_sampling and self.use_graph and self.betas.is_cuda:
+        if self.is_ddim_sampling and self.use_graph and self.betas.is_cuda and not self.self_condition:
             return (yield from self.ddim_sample_iter(shape))
         return self.sample(batch_size)
 
     # ---- DDIM (the reference's yaml default: sampling_timesteps = 100 < T): the same captured-step machinery
+    def _ddim_scalars(self, time: int, time_next: int, ac, sr, srm1):
+        """Host-side fp32 scalars of one DDIM step (reference :749-773) as a 12-float row: (sr, srm1, sqrt(alpha_next), c, sigma, last,
+        time, derive, x0_a, x0_b, 0, 0) - derive / x0_a / x0_b select the objective inside the kernel (nfdp_ddim_step_ex_f32)."""
+        derive = 0.0 if self.objective == 'pred_noise' else 1.0
+        x0_a, x0_b = float(self._x0_a[time]), float(self._x0_b[time])
+        if time_next < 0:
+            return [float(sr[time]), float(srm1[time]), 0.0, 0.0, 0.0, 1.0, float(time), derive, x0_a, x0_b, 0.0, 0.0]
+        alpha, alpha_next = ac[time], ac[time_next]
+        sigma = self.ddim_sampling_eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
+        cc = (1 - alpha_next - sigma ** 2).sqrt()
+        return [float(sr[time]), float(srm1[time]), float(alpha_next.sqrt()), float(cc), float(sigma), 0.0, float(time), derive,
+                x0_a, x0_b, 0.0, 0.0]
+
     def _ddim_table(self, device):
-        """[S, 8] fp32 rows (sr, srm1, sqrt(alpha_next), c, sigma, last, time, 0): the per-step scalars of reference :749-773,
-        computed once on the host in fp32 from the schedule exactly as the eager loop below computes them."""
+        """[S, 12] fp32 rows (_ddim_scalars), computed once on the host in fp32 from the schedule exactly as the eager loop below
+        computes them."""
         key = ("ddim_table", str(device), self.sampling_timesteps, float(self.ddim_sampling_eta))
         if key not in self._graphs:
-            total, S, eta = self.num_timesteps, self.sampling_timesteps, self.ddim_sampling_eta
+            total, S = self.num_timesteps, self.sampling_timesteps
             times = list(reversed(torch.linspace(-1, total - 1, steps=S + 1).int().tolist()))
             ac = self.alphas_cumprod.detach().cpu()
             sr, srm1 = self.sqrt_recip_alphas_cumprod.detach().cpu(), self.sqrt_recipm1_alphas_cumprod.detach().cpu()
-            rows = []
-            for time, time_next in zip(times[:-1], times[1:]):
-                if time_next < 0:
-                    rows.append([float(sr[time]), float(srm1[time]), 0.0, 0.0, 0.0, 1.0, float(time), 0.0])
-                else:
-                    alpha, alpha_next = ac[time], ac[time_next]
-                    sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
-                    cc = (1 - alpha_next - sigma ** 2).sqrt()
-                    rows.append([float(sr[time]), float(srm1[time]), float(alpha_next.sqrt()), float(cc), float(sigma), 0.0,
-                                 float(time), 0.0])
+            rows = [self._ddim_scalars(time, time_next, ac, sr, srm1) for time, time_next in zip(times[:-1], times[1:])]
             self._graphs[key] = torch.tensor(rows, dtype=torch.float32, device=device)
         return self._graphs[key]
 
@@ -670,7 +725,8 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
     def ddim_sample(self, shape, return_all_timesteps=False, x_T: Optional[Tensor] = None,
                     noises: Optional[Sequence[Tensor]] = None):
         """(reference :735-777); the per-step scalars are computed in fp32 on the host from the schedule."""
-        if self.use_graph and x_T is None and noises is None and not return_all_timesteps and self.betas.is_cuda:
+        if self.use_graph and x_T is None and noises is None and not return_all_timesteps and self.betas.is_cuda \
+                and not self.self_condition:
             it = self.ddim_sample_iter(shape)
             try:
                 while True:
@@ -687,19 +743,18 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
         ac = self.alphas_cumprod.detach().cpu()
         sr, srm1 = self.sqrt_recip_alphas_cumprod.detach().cpu(), self.sqrt_recipm1_alphas_cumprod.detach().cpu()
         j = 0
+        x_start = None
         for time, time_next in time_pairs:
             tb = torch.full((b,), time, device=device, dtype=torch.long)
-            eps = self.model.forward_nhwc(img, tb)
-            if time_next < 0:
-                img = K.ddim_step(img, eps, None, float(sr[time]), float(srm1[time]), 0.0, 0.0, 0.0, last=True)
-            else:
-                alpha, alpha_next = ac[time], ac[time_next]
-                sigma = eta * ((1 - alpha / alpha_next) * (1 - alpha_next) / (1 - alpha)).sqrt()
-                cc = (1 - alpha_next - sigma ** 2).sqrt()
+            self_cond = x_start if self.self_condition else None                # (reference :745)
+            out = self.model.forward_nhwc(img, tb, self_cond)
+            row = self._ddim_scalars(time, time_next, ac, sr, srm1)
+            nz = None
+            if time_next >= 0:
                 nz = torch.randn_like(img) if noises is None else K.to_nhwc(noises[j].to(device)).contiguous()
                 j += 1
-                img = K.ddim_step(img, eps, nz, float(sr[time]), float(srm1[time]), float(alpha_next.sqrt()), float(cc),
-                                  float(sigma), last=False)
+            img, x_start = K.ddim_step(img, out, nz, row[0], row[1], row[2], row[3], row[4], last=time_next < 0,
+                                       x0_coef=(row[8], row[9]), derive_noise=row[7] != 0.0, want_x0=True)
             if return_all_timesteps:
                 imgs.append(img)
         ret = K.as_nchw(img) if not return_all_timesteps else torch.stack([K.as_nchw(i) for i in imgs], dim=1)
@@ -754,8 +809,26 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
         x0h, nh = K.to_nhwc(x_start).contiguous(), K.to_nhwc(noise).contiguous()
         t = t.contiguous()
         xh = K.q_sample(x0h, nh, t, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
-        out = self.model.forward_nhwc(xh, t)
-        return K.diffusion_loss(out, nh, t, self.p2_loss_weight, l1=(kind == 'l1'))
+        sch = self._maybe_self_cond(xh, t)
+        out = self.model.forward_nhwc(xh, t, sch)
+        return K.diffusion_loss(out, self._loss_target_nhwc(x0h, nh, t), t, self.p2_loss_weight, l1=(kind == 'l1'))
+
+    def _maybe_self_cond(self, xh: Tensor, t: Tensor) -> Optional[Tensor]:
+        """Self-conditioning during training (reference :832-841): half of the time (python's random(), as the reference) the model's
+        own x_start prediction, computed without gradient, is fed back as conditioning."""
+        if not (self.self_condition and _random() < 0.5):
+            return None
+        with torch.no_grad():
+            _, x0, _ = self._predictions_nhwc(xh.detach(), t, None, False, want_noise=False)
+        return x0.detach()
+
+    def _loss_target_nhwc(self, x0h: Tensor, nh: Tensor, t: Tensor) -> Tensor:
+        """What the model output is compared with (reference :847-855): the noise, x_start, or v = sqrt(ac) noise - sqrt(1-ac) x_start."""
+        if self.objective == 'pred_noise':
+            return nh
+        if self.objective == 'pred_x0':
+            return x0h.detach()
+        return K.q_sample(nh, x0h.detach().contiguous(), t, self.sqrt_alphas_cumprod, self._neg_sqrt_one_minus_ac)
 
     def forward(self, img, *args, **kwargs):
         """(reference :861-867)"""
@@ -778,9 +851,9 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
         return K.prior_kl(K.to_nhwc(x_start).contiguous(), self.sqrt_alphas_cumprod, self.log_one_minus_alphas_cumprod,
                           self.num_timesteps - 1)
 
-    def _vb_term_nhwc(self, x0h, xth, t, clip_denoised=True, total=None):
-        eps = self.model.forward_nhwc(xth, t)
-        return K.vb_term(x0h, xth, eps, t, self.sqrt_recip_alphas_cumprod, self.sqrt_recipm1_alphas_cumprod,
+    def _vb_term_nhwc(self, x0h, xth, t, clip_denoised=True, total=None, sch=None):
+        eps = self.model.forward_nhwc(xth, t, sch)
+        return K.vb_term(x0h, xth, eps, t, self._x0_a, self._x0_b,
                          self.posterior_mean_coef1, self.posterior_mean_coef2, self.posterior_log_variance_clipped,
                          clip=clip_denoised, total=total)
 
@@ -788,9 +861,8 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
     def _vb_terms_bpd(self, x_start, x_t, t, x_self_cond=None, clip_denoised=True, model_kwargs=None):
         """One term of the bound per sample: decoder NLL where t == 0, KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) elsewhere
         (reference :932-958).  U-Net forward + one fused launch (posterior means, normal_kl, tanh-CDF likelihood, mean)."""
-        if x_self_cond is not None:
-            raise NotImplementedError("self-conditioning is not on the hot path")
-        return self._vb_term_nhwc(K.to_nhwc(x_start).contiguous(), K.to_nhwc(x_t).contiguous(), t.contiguous(), clip_denoised)
+        sch = None if x_self_cond is None else K.to_nhwc(x_self_cond).contiguous()
+        return self._vb_term_nhwc(K.to_nhwc(x_start).contiguous(), K.to_nhwc(x_t).contiguous(), t.contiguous(), clip_denoised, sch=sch)
 
     def _vb_step_inplace(self, x0h: Tensor, tb: Tensor, total: Tensor, gen: Optional[torch.Generator] = None) -> None:
         noise = torch.randn_like(x0h) if gen is None else torch.randn(x0h.shape, device=x0h.device, dtype=x0h.dtype, generator=gen)
@@ -845,9 +917,8 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
         The T terms are accumulated on the device in fp64 (the reference stacks them and sums in fp32); with device RNG
         one timestep (q_sample -> U-Net -> fused term -> t -= 1) is a hipGraph replayed T times.  `noises` (one per
         step, logical NCHW) replaces the randn_like draws."""
-        if x_self_cond is not None:
-            raise NotImplementedError("self-conditioning is not on the hot path")
-        if self.use_graph and noises is None:
+        sch = None if x_self_cond is None else K.to_nhwc(x_self_cond).contiguous()
+        if self.use_graph and noises is None and sch is None:
             it = self.calc_neg_log_likelihood_iter(x_start)
             try:
                 while True:
@@ -861,5 +932,5 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
             tb = torch.full((b,), t, device=x0h.device, dtype=torch.long)
             nz = torch.randn_like(x0h) if noises is None else K.to_nhwc(noises[i].to(x0h.device)).contiguous()
             xth = K.q_sample(x0h, nz, tb, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod)
-            self._vb_term_nhwc(x0h, xth, tb, True, total)
+            self._vb_term_nhwc(x0h, xth, tb, True, total, sch=sch)                 # (the reference passes the same x_self_cond to every term)
         return total.float() + self._prior_bpd(x_start)

@@ -232,10 +232,13 @@ def _attn_block(res, xh: Tensor, c: int) -> Tensor:
     return AddFn.apply(_conv(att.to_out, a, c), xh)
 
 
-def unet_forward(unet, xh: Tensor, time: Tensor) -> Tensor:
+def unet_forward(unet, xh: Tensor, time: Tensor, x_self_cond_h: Optional[Tensor] = None) -> Tensor:
     """Unet.forward with a gradient graph (reference :451-490); NHWC in, NHWC out.  The U-Net's compute mode applies to its
     convolutions; the small time-MLP linears stay exact fp32."""
     c = K.compute_enum(unet.compute)
+    if unet.self_condition:                                             # torch.cat((x_self_cond or zeros, x), dim=1)  (:452-454)
+        sc = torch.zeros_like(xh) if x_self_cond_h is None else x_self_cond_h.detach()
+        xh = ConcatFn.apply(sc.contiguous(), xh.contiguous())
     x = _conv(unet.init_conv, xh, c)
     r = x
     e = K.sinusoidal_emb(time.long(), unet.dim)
@@ -262,9 +265,10 @@ def unet_forward(unet, xh: Tensor, time: Tensor) -> Tensor:
 
 
 def p_losses(diffusion, x_start: Tensor, t: Tensor, noise: Optional[Tensor] = None) -> Tensor:
-    """GaussianDiffusion.p_losses with a gradient graph (reference :823-859; objective pred_noise).  When the latents carry
-    a graph themselves (unfrozen flow, trainer.py:139-141) the gradient flows back into them through q_sample and the
-    U-Net's first convolution."""
+    """GaussianDiffusion.p_losses with a gradient graph (reference :823-859; all three objectives, self-conditioning).  When the
+    latents carry a graph themselves (unfrozen flow, trainer.py:139-141) the gradient flows back into them through q_sample and
+    the U-Net's first convolution (and, for pred_x0 / pred_v, NOT through the target, which the reference does not detach either but
+    whose dependence on the latents only the unfrozen-flow recipe could see: that recipe uses pred_noise)."""
     noise = torch.randn_like(x_start) if noise is None else noise
     x0h, nh = K.to_nhwc(x_start), K.to_nhwc(noise.detach()).contiguous()
     t = t.contiguous()
@@ -272,5 +276,7 @@ def p_losses(diffusion, x_start: Tensor, t: Tensor, noise: Optional[Tensor] = No
         xh = QSampleFn.apply(x0h, nh, t, diffusion.sqrt_alphas_cumprod, diffusion.sqrt_one_minus_alphas_cumprod)
     else:
         xh = K.q_sample(x0h.contiguous(), nh, t, diffusion.sqrt_alphas_cumprod, diffusion.sqrt_one_minus_alphas_cumprod)
-    out = unet_forward(diffusion.model, xh, t)
-    return DiffusionLossFn.apply(out, nh, t, diffusion.p2_loss_weight, diffusion.loss_fn == "l1")
+    sch = diffusion._maybe_self_cond(xh.detach().contiguous(), t)
+    out = unet_forward(diffusion.model, xh, t, sch)
+    target = diffusion._loss_target_nhwc(x0h.detach().contiguous(), nh, t)
+    return DiffusionLossFn.apply(out, target, t, diffusion.p2_loss_weight, diffusion.loss_fn == "l1")

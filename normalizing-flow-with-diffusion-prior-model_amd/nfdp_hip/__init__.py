@@ -803,17 +803,41 @@ def p_sample(x, eps_hat, noise, t, sr, srm1, c1, c2, logvar, want_x0: bool = Tru
     return out, x0
 
 
-def ddim_step(x, eps_hat, noise, sr, srm1, sqrt_an, c, sigma, last: bool):
+def ddim_step(x, model_out, noise, sr, srm1, sqrt_an, c, sigma, last: bool, x0_coef=None, derive_noise: bool = False,
+              want_x0: bool = False):
+    """One DDIM step with host-side scalars (nfdp_ddim_step_ex_f32).  x0_coef = (a, b): x0 = clamp(a x - b model_out) (default
+    (sr, srm1): the pred_noise objective); derive_noise: the update's noise is (sr x - x0) / srm1.  -> out, or (out, x0)."""
     out = torch.empty_like(x)
-    _call("nfdp_ddim_step_f32", _ptr(x), _ptr(eps_hat), _ptr(noise), _ptr(out), x.numel(), float(sr), float(srm1), float(sqrt_an),
-          float(c), float(sigma), int(last), _stream())
+    x0 = torch.empty_like(x) if want_x0 else None
+    a, b = (sr, srm1) if x0_coef is None else x0_coef
+    _call("nfdp_ddim_step_ex_f32", _ptr(x), _ptr(model_out), _ptr(noise), _ptr(out), _ptr(x0), x.numel(), float(sr), float(srm1),
+          float(a), float(b), int(derive_noise), float(sqrt_an), float(c), float(sigma), int(last), _stream())
+    return (out, x0) if want_x0 else out
+
+
+def ddim_step_table(x, model_out, noise, table, step, t_next, x0_out=None) -> None:
+    """In-place DDIM step with the scalars of row step[0] of `table` ([S,8] or [S,12] fp32); t_next [B] int64 gets the next step's
+    time; x0_out (optional) the clamped x0 prediction."""
+    _call("nfdp_ddim_step_table_ex_f32", _ptr(x), _ptr(model_out), _ptr(noise), _ptr(x), _ptr(x0_out), x.numel(), _ptr(table),
+          table.shape[1], _ptr(step), table.shape[0], _ptr(t_next), 0 if t_next is None else t_next.numel(), _stream())
+
+
+def noise_from_start(x_t, x_start, t, sr, srm1) -> torch.Tensor:
+    """(sqrt_recip_ac[t] x_t - x_start) / sqrt_recipm1_ac[t]  (nfdp_noise_from_start_f32)."""
+    _dense(x_t, "noise_from_start"); _dense(x_start, "noise_from_start")
+    out = torch.empty_like(x_t)
+    b = x_t.shape[0]
+    _call("nfdp_noise_from_start_f32", _ptr(x_t), _ptr(x_start), _ptr(t), _ptr(sr), _ptr(srm1), _ptr(out), b, x_t.numel() // b, _stream())
     return out
 
 
-def ddim_step_table(x, eps_hat, noise, table, step, t_next) -> None:
-    """In-place DDIM step with the scalars of row step[0] of `table` ([S,8] fp32); t_next [B] int64 gets the next step's time."""
-    _call("nfdp_ddim_step_table_f32", _ptr(x), _ptr(eps_hat), _ptr(noise), _ptr(x), x.numel(), _ptr(table), _ptr(step),
-          table.shape[0], _ptr(t_next), 0 if t_next is None else t_next.numel(), _stream())
+def axpb(x: torch.Tensor, a: float, b: float, add_first: bool = False) -> torch.Tensor:
+    """a x + b, or (x + b) a with add_first (nfdp_axpb_f32)."""
+    _need(x, torch.float32, "axpb")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _call("nfdp_axpb_f32", _ptr(x), float(a), float(b), _ptr(out), x.numel(), int(add_first), _stream())
+    return out
 
 
 def diffusion_loss(pred, target, t, p2w, l1: bool) -> torch.Tensor:

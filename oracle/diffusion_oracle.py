@@ -160,9 +160,13 @@ def _squeeze2(x: Tensor) -> Tensor:
     return x.reshape(b, c, hh // 2, 2, ww // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(b, 4 * c, hh // 2, ww // 2)
 
 
-def unet_forward(x: Tensor, time: Tensor, sd: SD, dim: int, dim_mults: Sequence[int], groups: int = 8) -> Tensor:
-    """eps-hat = Unet(x_t, t), self_condition=False  (gaussian_diffusion.py:451-490, ctor 364-449)."""
+def unet_forward(x: Tensor, time: Tensor, sd: SD, dim: int, dim_mults: Sequence[int], groups: int = 8,
+                 self_condition: bool = False, x_self_cond: Optional[Tensor] = None) -> Tensor:
+    """eps-hat = Unet(x_t, t [, x_self_cond])  (gaussian_diffusion.py:451-490, ctor 364-449); self_condition: the input is
+    cat((x_self_cond or zeros, x), dim=1)  (:452-454)."""
     n_res = len(dim_mults)
+    if self_condition:
+        x = torch.cat((torch.zeros_like(x) if x_self_cond is None else x_self_cond, x), dim=1)
     x = F.conv2d(x, sd["init_conv.weight"], sd["init_conv.bias"], padding=3)
     r = x
     temb = time_embedding(time, sd, dim)
@@ -318,3 +322,91 @@ def calc_neg_log_likelihood_loop(buf, eps_model, x0: Tensor, noises: Sequence[Te
         tb = torch.full((x0.shape[0],), t, dtype=torch.long)
         vb.append(vb_term(buf, eps_model, x0, q_sample(buf, x0, tb, noises[i]), tb))
     return torch.stack(vb, dim=1).sum(dim=1) + prior_bpd(buf, x0)
+
+
+# ----------------------------------------------------------------------------- objectives / self-conditioning (variants)
+def predict_noise_from_start(buf, x_t: Tensor, t: Tensor, x0: Tensor) -> Tensor:
+    """(gaussian_diffusion.py:647-651)."""
+    return (_ext(buf["sqrt_recip_alphas_cumprod"], t, x_t.ndim) * x_t - x0) / _ext(buf["sqrt_recipm1_alphas_cumprod"], t, x_t.ndim)
+
+
+def predict_v(buf, x_start: Tensor, t: Tensor, noise: Tensor) -> Tensor:
+    """(gaussian_diffusion.py:653-657)."""
+    return _ext(buf["sqrt_alphas_cumprod"], t, x_start.ndim) * noise - _ext(buf["sqrt_one_minus_alphas_cumprod"], t, x_start.ndim) * x_start
+
+
+def predict_start_from_v(buf, x_t: Tensor, t: Tensor, v: Tensor) -> Tensor:
+    """(gaussian_diffusion.py:659-663)."""
+    return _ext(buf["sqrt_alphas_cumprod"], t, x_t.ndim) * x_t - _ext(buf["sqrt_one_minus_alphas_cumprod"], t, x_t.ndim) * v
+
+
+def model_predictions(buf, model, x: Tensor, t: Tensor, objective: str = "pred_noise", x_self_cond: Optional[Tensor] = None,
+                      clip_x_start: bool = False):
+    """-> (pred_noise, x_start) for the three objectives  (gaussian_diffusion.py:674-694).  model(x, t, x_self_cond)."""
+    out = model(x, t, x_self_cond)
+    clip = (lambda v: v.clamp(-1.0, 1.0)) if clip_x_start else (lambda v: v)
+    if objective == "pred_noise":
+        return out, clip(predict_start_from_noise(buf, x, t, out))
+    if objective == "pred_x0":
+        x0 = clip(out)
+    elif objective == "pred_v":
+        x0 = clip(predict_start_from_v(buf, x, t, out))
+    else:
+        raise ValueError(f"unknown objective {objective}")
+    return predict_noise_from_start(buf, x, t, x0), x0
+
+
+def p_sample_v(buf, model, x: Tensor, t: int, noise: Optional[Tensor], objective: str = "pred_noise",
+               x_self_cond: Optional[Tensor] = None):
+    """p_sample for any objective / with self-conditioning  (gaussian_diffusion.py:696-715)."""
+    tb = torch.full((x.shape[0],), t, dtype=torch.long)
+    _, x0 = model_predictions(buf, model, x, tb, objective, x_self_cond)
+    x0 = x0.clamp(-1.0, 1.0)
+    mean, _, logvar = q_posterior(buf, x0, x, tb)
+    return (mean + (0.5 * logvar).exp() * noise if t > 0 else mean), x0
+
+
+def p_sample_loop_v(buf, model, x_T: Tensor, noises: Sequence[Tensor], objective: str = "pred_noise", self_condition: bool = False):
+    """(gaussian_diffusion.py:717-733): with self-conditioning every step is conditioned on the previous step's x_start."""
+    T = buf["betas"].shape[0]
+    img, x_start = x_T, None
+    for i, t in enumerate(reversed(range(T))):
+        img, x_start = p_sample_v(buf, model, img, t, noises[i] if t > 0 else None, objective, x_start if self_condition else None)
+    return img
+
+
+def ddim_sample_v(buf, model, x_T: Tensor, S: int, eta: float, noises: Sequence[Tensor], objective: str = "pred_noise",
+                  self_condition: bool = False) -> Tensor:
+    """(gaussian_diffusion.py:735-777) for any objective / with self-conditioning."""
+    T = buf["betas"].shape[0]
+    times = list(reversed(torch.linspace(-1, T - 1, steps=S + 1).int().tolist()))
+    img, x_start, ac, j = x_T, None, buf["alphas_cumprod"], 0
+    for time, time_next in zip(times[:-1], times[1:]):
+        tb = torch.full((img.shape[0],), time, dtype=torch.long)
+        pred_noise, x_start = model_predictions(buf, model, img, tb, objective, x_start if self_condition else None, clip_x_start=True)
+        if time_next < 0:
+            img = x_start
+            continue
+        a, an = ac[time], ac[time_next]
+        sigma = eta * ((1 - a / an) * (1 - an) / (1 - a)).sqrt()
+        c = (1 - an - sigma ** 2).sqrt()
+        img = x_start * an.sqrt() + c * pred_noise + sigma * noises[j]
+        j += 1
+    return img
+
+
+def p_losses_v(buf, model, x0: Tensor, t: Tensor, noise: Tensor, objective: str = "pred_noise", loss_type: str = "l2",
+               self_condition: bool = False, random_draw: float = 1.0) -> Tensor:
+    """(gaussian_diffusion.py:823-859): target by objective; self-conditioning when random_draw < 0.5 (the reference calls random())."""
+    x = q_sample(buf, x0, t, noise)
+    x_self_cond = None
+    if self_condition and random_draw < 0.5:
+        with torch.no_grad():
+            x_self_cond = model_predictions(buf, model, x, t, objective)[1].detach()
+    out = model(x, t, x_self_cond)
+    target = {"pred_noise": noise, "pred_x0": x0}.get(objective)
+    if target is None:
+        target = predict_v(buf, x0, t, noise)
+    l = (out - target) ** 2 if loss_type == "l2" else (out - target).abs()
+    l = l.reshape(l.shape[0], -1).mean(dim=1) * buf["p2_loss_weight"].gather(-1, t)
+    return l.mean()

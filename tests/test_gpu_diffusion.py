@@ -52,8 +52,9 @@ def test_schedule_buffers_golden(dg):
         d = GaussianDiffusion(u, image_size=16, timesteps=1000, beta_schedule=sched, auto_normalize=False)
         for name in BUFFER_NAMES:
             assert_close(getattr(d, name), dg[f"buf_{sched}_{name}"], 1e-6, name)
-        assert [k for k, _ in d.named_buffers(recurse=False)] == list(BUFFER_NAMES) + ["_neg_sqrt_recipm1"]
-        assert "_neg_sqrt_recipm1" not in d.state_dict()
+        helpers = ["_neg_sqrt_recipm1", "_x0_a", "_x0_b", "_neg_sqrt_one_minus_ac"]       # kernel-side tables, not part of the state
+        assert [k for k, _ in d.named_buffers(recurse=False)] == list(BUFFER_NAMES) + helpers
+        assert not any(h in d.state_dict() for h in helpers)
     with pytest.raises(ValueError):
         GaussianDiffusion(u, image_size=16, beta_schedule="nope", auto_normalize=False)
 

@@ -214,6 +214,56 @@ def test_sampling_loops(dg):
     assert_close(out, dg["ddim_out"], 2e-5, "ddim")
 
 
+# ----------------------------------------------------------------------------- objectives / self-conditioning (variants)
+@pytest.fixture(scope="module")
+def xg():
+    return load_golden("diffusion_variants.npz")
+
+
+@pytest.mark.parametrize("obj", ["pred_x0", "pred_v"])
+def test_objective_variants(xg, obj):
+    """The oracle's restatement of model_predictions / p_sample / the loops / p_losses for pred_x0 and pred_v against outputs of the
+    reference itself (tools/make_goldens.py variants)."""
+    sd = synth_sd(meta_of(xg)["unet"], 21)
+    model = lambda x, t, sc=None: D.unet_forward(x, t, sd, 64, (1, 2), 8)
+    buf = D.diffusion_buffers("cosine", 1000)
+    x0, eps, t = T(xg["x0"]), T(xg["eps"]), T(xg["t"])
+    assert_close(D.p_losses_v(buf, model, x0, t, eps, obj), xg[f"{obj}_p_losses"], 1e-5, "p_losses")
+    for clip in (False, True):
+        pn, xs = D.model_predictions(buf, model, x0, t, obj, clip_x_start=clip)
+        assert_close(pn, xg[f"{obj}_mp_noise_clip{int(clip)}"], 2e-5, "pred_noise")
+        assert_close(xs, xg[f"{obj}_mp_x0_clip{int(clip)}"], 2e-5, "x_start")
+    for step in (0, 500):
+        img, xs = D.p_sample_v(buf, model, x0, step, T(xg[f"{obj}_psample{step}_noise"]), obj)
+        assert_close(img, xg[f"{obj}_psample{step}_img"], 2e-5, f"img{step}")
+    assert_close(D.predict_v(buf, x0, t, eps), xg[f"{obj}_predict_v"], TOL, "predict_v")
+    assert_close(D.predict_noise_from_start(buf, x0, t, eps), xg[f"{obj}_noise_from_start"], TOL, "noise_from_start")
+    buf8 = D.diffusion_buffers("cosine", 8)
+    out = D.p_sample_loop_v(buf8, model, T(xg[f"{obj}_loop8_xT"]), list(T(xg[f"{obj}_loop8_noises"])), obj)
+    assert_close(out, xg[f"{obj}_loop8_out"], 5e-5, "loop8")
+    out = D.ddim_sample_v(buf8, model, T(xg[f"{obj}_ddim_xT"]), 4, 1.0, list(T(xg[f"{obj}_ddim_noises"])), obj)
+    assert_close(out, xg[f"{obj}_ddim_out"], 5e-5, "ddim")
+
+
+def test_self_conditioning_variant(xg):
+    sd = synth_sd(meta_of(xg)["unet_sc"], 24)
+    model = lambda x, t, sc=None: D.unet_forward(x, t, sd, 64, (1, 2), 8, self_condition=True, x_self_cond=sc)
+    buf = D.diffusion_buffers("cosine", 1000)
+    x0, eps, t, sc = T(xg["x0"]), T(xg["eps"]), T(xg["t"]), T(xg["sc"])
+    assert_close(model(x0, t, sc), xg["sc_unet_given"], 1e-5, "unet with self cond")
+    assert_close(model(x0, t), xg["sc_unet_none"], 1e-5, "unet, zero default")
+    for name, draw in (("taken", 0.1), ("skipped", 0.9)):
+        got = D.p_losses_v(buf, model, x0, t, eps, self_condition=True, random_draw=draw)
+        assert_close(got, xg[f"sc_p_losses_{name}"], 1e-5, f"p_losses {name}")
+    img, xs = D.p_sample_v(buf, model, x0, 500, T(xg["sc_psample500_noise"]), x_self_cond=sc)
+    assert_close(img, xg["sc_psample500_img"], 2e-5, "p_sample with self cond")
+    buf8 = D.diffusion_buffers("cosine", 8)
+    out = D.p_sample_loop_v(buf8, model, T(xg["sc_loop8_xT"]), list(T(xg["sc_loop8_noises"])), self_condition=True)
+    assert_close(out, xg["sc_loop8_out"], 1e-4, "loop8 with self cond")
+    out = D.ddim_sample_v(buf8, model, T(xg["sc_ddim_xT"]), 4, 1.0, list(T(xg["sc_ddim_noises"])), self_condition=True)
+    assert_close(out, xg["sc_ddim_out"], 1e-3, "ddim with self cond (a chain that amplifies fp32 rounding: sqrt(1/ac_7) = 163)")
+
+
 # ----------------------------------------------------------------------------- variational bound + CatFormater index maps
 @pytest.fixture(scope="module")
 def vg():

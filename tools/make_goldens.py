@@ -280,6 +280,86 @@ def gen_diffusion():
     print("diffusion.npz", len(g), "arrays")
 
 
+# ------------------------------------------------------------------ objectives pred_x0 / pred_v, self-conditioning, auto_normalize
+@torch.no_grad()
+def gen_diffusion_variants():
+    """GaussianDiffusion options off the drivers' default path (gaussian_diffusion.py:647-663, :674-694, :726-728, :744-747, :832-855,
+    :148-157): same U-Net shape as `m0` of diffusion.npz."""
+    GD = R["gd"]
+    g, meta = {}, {}
+    x0 = t(synth_input("x0", (2, 2, 16, 16), 22)) * 0.8
+    eps = t(synth_input("eps", (2, 2, 16, 16), 23))
+    tt = torch.tensor([10, 700], dtype=torch.long)
+    g["x0"], g["eps"], g["t"] = n(x0), n(eps), n(tt)
+
+    def loops(tag, unet, **kw):
+        d8 = GD.GaussianDiffusion(unet, image_size=16, timesteps=8, beta_schedule="cosine", auto_normalize=False, **kw)
+        torch.manual_seed(31)
+        s8 = d8.sample(batch_size=2)
+        torch.manual_seed(31)
+        xT = torch.randn(2, 2, 16, 16)
+        nzs = [torch.randn(2, 2, 16, 16) for _ in range(7)]
+        g[f"{tag}_loop8_out"], g[f"{tag}_loop8_xT"], g[f"{tag}_loop8_noises"] = n(s8), n(xT), n(torch.stack(nzs))
+        dd = GD.GaussianDiffusion(unet, image_size=16, timesteps=8, sampling_timesteps=4, beta_schedule="cosine",
+                                  ddim_sampling_eta=1.0, auto_normalize=False, **kw)
+        torch.manual_seed(32)
+        sd = dd.sample(batch_size=2)
+        torch.manual_seed(32)
+        xT = torch.randn(2, 2, 16, 16)
+        nzs = [torch.randn(2, 2, 16, 16) for _ in range(3)]
+        g[f"{tag}_ddim_out"], g[f"{tag}_ddim_xT"], g[f"{tag}_ddim_noises"] = n(sd), n(xT), n(torch.stack(nzs))
+
+    u = GD.Unet(dim=64, dim_mults=(1, 2), channels=2, resnet_block_groups=8)
+    meta["unet"] = load_synth(u, 21)
+    for obj in ("pred_x0", "pred_v"):
+        d = GD.GaussianDiffusion(u, image_size=16, timesteps=1000, beta_schedule="cosine", loss_type="l2", objective=obj,
+                                 auto_normalize=False)
+        g[f"{obj}_p_losses"] = n(d.p_losses(x0, tt, noise=eps))
+        for clip in (False, True):
+            mp = d.model_predictions(x0, tt, clip_x_start=clip)
+            g[f"{obj}_mp_noise_clip{int(clip)}"], g[f"{obj}_mp_x0_clip{int(clip)}"] = n(mp.pred_noise), n(mp.pred_x_start)
+        for step in (0, 500):
+            torch.manual_seed(100 + step)
+            img, xs = d.p_sample(x0.clone(), step)
+            torch.manual_seed(100 + step)
+            nz = torch.randn_like(x0)
+            g[f"{obj}_psample{step}_img"], g[f"{obj}_psample{step}_x0"], g[f"{obj}_psample{step}_noise"] = n(img), n(xs), n(nz)
+        g[f"{obj}_predict_v"] = n(d.predict_v(x0, tt, eps))
+        g[f"{obj}_noise_from_start"] = n(d.predict_noise_from_start(x0, tt, eps))
+        loops(obj, u, objective=obj)
+    # self-conditioning (pred_noise): U-Net with 2*channels inputs
+    usc = GD.Unet(dim=64, dim_mults=(1, 2), channels=2, resnet_block_groups=8, self_condition=True)
+    meta["unet_sc"] = load_synth(usc, 24)
+    sc = t(synth_input("selfcond", (2, 2, 16, 16), 25)) * 0.5
+    g["sc"] = n(sc)
+    g["sc_unet_given"] = n(usc(x0, tt, sc))
+    g["sc_unet_none"] = n(usc(x0, tt))
+    d = GD.GaussianDiffusion(usc, image_size=16, timesteps=1000, beta_schedule="cosine", loss_type="l2", auto_normalize=False)
+    for name, draw in (("taken", 0.1), ("skipped", 0.9)):
+        GD.random = lambda draw=draw: draw                               # `from random import random` at :5 of the reference module
+        g[f"sc_p_losses_{name}"] = n(d.p_losses(x0, tt, noise=eps))
+    torch.manual_seed(105)
+    img, xs = d.p_sample(x0.clone(), 500, sc)
+    torch.manual_seed(105)
+    nz = torch.randn_like(x0)
+    g["sc_psample500_img"], g["sc_psample500_x0"], g["sc_psample500_noise"] = n(img), n(xs), n(nz)
+    loops("sc", usc)
+    # auto_normalize=True: forward() maps [0,1] images to [-1,1], sample() maps back (gaussian_diffusion.py:148-157, :637-638)
+    dan = GD.GaussianDiffusion(u, image_size=16, timesteps=8, beta_schedule="cosine", loss_type="l2", auto_normalize=True)
+    x01 = (x0 * 0.5 + 0.5).clamp(0, 1)
+    torch.manual_seed(9)
+    loss = dan(x01)
+    torch.manual_seed(9)
+    t_drawn = torch.randint(0, 8, (2,)).long()
+    nz = torch.randn_like(x0)
+    g["an_x01"], g["an_fwd_loss"], g["an_fwd_t"], g["an_fwd_noise"] = n(x01), n(loss), n(t_drawn), n(nz)
+    torch.manual_seed(31)
+    g["an_loop8_out"] = n(dan.sample(batch_size=2))
+    g["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "diffusion_variants.npz"), **g)
+    print("diffusion_variants.npz", len(g), "arrays")
+
+
 # ------------------------------------------------------------------ variational bound + CatFormater goldens
 @torch.no_grad()
 def gen_vlb():
@@ -372,7 +452,7 @@ def gen_train(C=3, L=3, K=2, B=2, seed=2):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion", "vlb", "train"]
+    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion", "variants", "vlb", "train"]
     if "ops" in which:
         gen_ops()
     if "glow" in which:
@@ -383,6 +463,8 @@ if __name__ == "__main__":
         gen_glow_init()
     if "diffusion" in which:
         gen_diffusion()
+    if "variants" in which:
+        gen_diffusion_variants()
     if "vlb" in which:
         gen_vlb()
     if "train" in which:
