@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""In-kernel shader clock of the level-0 fused flow-step launch (16 flows, B=512) on random data.
+Needs the diagnostic build:  tools/build_variant.sh clk -DNFDP_FUSED_STAMPS -DNFDP_FUSED_CLOCK
+then  NFDP_LIB_PATH=.../libnfdp_hip_clk.so python tools/kernel_clock.py
+clock = d(s_memtime) / d(s_memrealtime) x 100 MHz per workgroup, after ~2 s of back-to-back launches (the chip settles)."""
+import os, sys, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "normalizing-flow-with-diffusion-prior-model_amd")]
+import numpy as np, torch
+import nfdp_hip as K
+from tests.golden.synth import synth_tensor, DEEP
+from normalizing_flow import StepFlow
+from normalizing_flow.glow import _level_tables
+
+B = int(os.environ.get("NFDP_B", "512"))
+dev = torch.device("cuda", 0)
+lib = ctypes.CDLL(K.LIB_PATH)
+for c, hw, fn in [(12, 16, "nfdp_debug_read_stamps_v")]:
+    with torch.no_grad():
+        flows = []
+        for f in range(16):
+            m = StepFlow(c, 512, compute="bf16")
+            m.load_state_dict({k: torch.from_numpy(np.array(synth_tensor(f"flows.{f}." + k, v.shape, 1, DEEP)))
+                               for k, v in m.state_dict().items()})
+            flows.append(m.to(dev))
+        x0 = torch.rand(B, hw, hw, c, device=dev) - 0.5
+        x = x0.clone()
+        ldj = torch.zeros(B, dtype=torch.float64, device=dev)
+        packed, scales, biases = _level_tables(flows, x)
+        ws = [f.invconv2d._w() for f in flows]
+        n = int(os.environ.get("NFDP_LAUNCHES", "1600"))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(n):
+            if i == n - 20:
+                e0.record()
+            x.copy_(x0)
+            K.level_fused(x, packed, scales, biases, ws, ldj, inverse=False)
+        e1.record()
+        torch.cuda.synchronize()
+        buf = (ctypes.c_ulonglong * (512 * 16))()
+        f = getattr(lib, fn)
+        f.argtypes = [ctypes.c_void_p]
+        assert f(ctypes.addressof(buf)) == 0
+        a = np.frombuffer(buf, dtype=np.uint64).reshape(512, 16).astype(np.int64)
+        if os.environ.get("NFDP_PHASES"):       # full -DNFDP_FUSED_STAMPS build: stamps 1..7 are those of the LAST flow of the launch
+            names = ["head", "im2col", "GEMM1", "GEMM2/3", "tap sums", "coupling+ldj"]
+            d = np.diff(a[:, [9, 2, 3, 4, 5, 6, 7]], axis=1)
+            print("   last flow, cycles per phase (median over workgroups): " +
+                  ", ".join(f"{n} {np.median(d[:, i]):.0f}" for i, n in enumerate(names)) + f"; flow {np.median(a[:, 7] - a[:, 9]):.0f}", flush=True)
+            continue
+        cyc = a[:, 8] - a[:, 0]
+        rt = a[:, 12] - a[:, 4]
+        clk = cyc / rt * 0.1            # GHz
+        print(f"C={c} hw={hw} B={B}: launch+copy {e0.elapsed_time(e1) / 20 * 1e3:.1f} us; per workgroup: cycles median {np.median(cyc):.0f}, "
+              f"time median {np.median(rt) * 10:.0f} ns, clock median {np.median(clk):.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f})", flush=True)
