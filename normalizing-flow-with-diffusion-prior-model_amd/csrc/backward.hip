@@ -176,11 +176,20 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_vec_kernel(const float* _
     const long slice = (long)Mpad * Npad;
     const long e0 = ((long)blockIdx.x * 64 + lane) * 4;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e0 < slice)
-        for (int q = wave; q < ksplit; q += 4) {
+    if (e0 < slice) {
+        int q = wave;
+        for (; q + 28 < ksplit; q += 32) {                        // 8 loads in flight per lane
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(ws + (size_t)(q + 4 * u) * slice + e0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; q < ksplit; q += 4) {
             const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)q * slice + e0);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
+    }
     red[wave][lane] = s;
     __syncthreads();
     if (wave == 0 && e0 < slice) {
@@ -217,68 +226,59 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_rows_kernel(const float* 
                                                                   float* __restrict__ dw, int ksplit, int Mpad, int Npad, WgradOut o,
                                                                   const float* __restrict__ w, const float* __restrict__ bias,
                                                                   float* __restrict__ dscale, float* __restrict__ dbias) {
-    // one workgroup per output row; the 4 waves take slices w, w+4, ... (4 loads in flight per lane), combined in wave order
-    constexpr int MAXJ = 3;                                        // Npad <= 768: float4 columns lane, lane + 64, lane + 128
-    __shared__ float4 red[4][MAXJ][64];
-    __shared__ float dots[64];
-    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // One workgroup per output row.  Thread t owns float4 column t % (Npad/4) and the slices sg, sg + ng, ... (sg = t / (Npad/4), ng =
+    // 256 / (Npad/4) slice groups), 8 loads in flight per thread: the kernel streams ksplit * Npad floats per row and is otherwise
+    // latency-bound (the first version, 4 loads in flight per lane and a serial bias-gradient loop, took 27-40 us per launch).
+    __shared__ float4 red[kBlock];
+    __shared__ float sdot[kBlock], sdb[kBlock];
+    const int m = blockIdx.x, t = threadIdx.x;
+    const int nc4 = Npad / 4, ng = kBlock / nc4 > 0 ? kBlock / nc4 : 1;
+    const int c = t % nc4, sg = t / nc4;
     const long slice = (long)Mpad * Npad;
-    const int nj = (Npad / 4 + 63) / 64;
-    float4 acc[MAXJ];
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sg < ng && t < ng * nc4) {
+        const float* col = ws + (size_t)m * Npad + 4 * c;
+        int q = sg;
+        for (; q + 7 * ng < ksplit; q += 8 * ng) {
+            float4 v[8];
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float* row = ws + (size_t)m * Npad;
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(col + (size_t)(q + u * ng) * slice);
 #pragma unroll
-    for (int j = 0; j < MAXJ; ++j) {
-        const int n0 = (lane + 64 * j) * 4;
-        if (j < nj && n0 < Npad) {
-            int q = wave;
-            for (; q + 12 < ksplit; q += 16) {
-                const float4 v0 = *reinterpret_cast<const float4*>(row + (size_t)q * slice + n0);
-                const float4 v1 = *reinterpret_cast<const float4*>(row + (size_t)(q + 4) * slice + n0);
-                const float4 v2 = *reinterpret_cast<const float4*>(row + (size_t)(q + 8) * slice + n0);
-                const float4 v3 = *reinterpret_cast<const float4*>(row + (size_t)(q + 12) * slice + n0);
-                acc[j].x += v0.x; acc[j].y += v0.y; acc[j].z += v0.z; acc[j].w += v0.w;
-                acc[j].x += v1.x; acc[j].y += v1.y; acc[j].z += v1.z; acc[j].w += v1.w;
-                acc[j].x += v2.x; acc[j].y += v2.y; acc[j].z += v2.z; acc[j].w += v2.w;
-                acc[j].x += v3.x; acc[j].y += v3.y; acc[j].z += v3.z; acc[j].w += v3.w;
-            }
-            for (; q < ksplit; q += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(row + (size_t)q * slice + n0);
-                acc[j].x += v.x; acc[j].y += v.y; acc[j].z += v.z; acc[j].w += v.w;
-            }
+            for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
         }
-        red[wave][j][lane] = acc[j];
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float dot = 0.f;
-#pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int n0 = (lane + 64 * j) * 4;
-            if (j < nj && n0 < Npad) {
-                float t[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int wv = 0; wv < 4; ++wv) { t[0] += red[wv][j][lane].x; t[1] += red[wv][j][lane].y; t[2] += red[wv][j][lane].z; t[3] += red[wv][j][lane].w; }
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (n0 + e < o.N) {
-                        dot = fmaf(wgrad_get(w, o, m, n0 + e), t[e], dot);
-                        wgrad_put(dw, o, m, n0 + e, t[e]);
-                    }
-            }
+        for (; q < ksplit; q += ng) {
+            const float4 v = *reinterpret_cast<const float4*>(col + (size_t)q * slice);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        dots[lane] = dot;
     }
+    red[t] = a;
+    float db = 0.f;
+    for (int q = t; q < ksplit; q += kBlock) db += ws_db[(size_t)q * Mpad + m];
+    sdb[t] = db;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float d = 0.f;
-        for (int l = 0; l < 64; ++l) d += dots[l];
-        float db = 0.f;
-        for (int q = 0; q < ksplit; ++q) db += ws_db[(size_t)q * Mpad + m];
-        const float ds = fmaf(bias[m], db, d);
+    float dot = 0.f;
+    if (t < nc4) {
+        float4 s4 = red[t];
+        for (int gq = 1; gq < ng; ++gq) { const float4 v = red[t + gq * nc4]; s4.x += v.x; s4.y += v.y; s4.z += v.z; s4.w += v.w; }
+        const float tv[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * t + e < o.N) {
+                dot = fmaf(wgrad_get(w, o, m, 4 * t + e), tv[e], dot);
+                wgrad_put(dw, o, m, 4 * t + e, tv[e]);
+            }
+    }
+    sdot[t] = dot;
+    __syncthreads();
+    for (int sft = kBlock / 2; sft > 0; sft >>= 1) {              // fixed tree: deterministic
+        if (t < sft) { sdot[t] += sdot[t + sft]; sdb[t] += sdb[t + sft]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const float dbt = sdb[0];
+        const float ds = fmaf(bias[m], dbt, sdot[0]);
         dscale[m] = o.acc ? dscale[m] + ds : ds;
-        dbias[m] = o.acc ? dbias[m] + db : db;
+        dbias[m] = o.acc ? dbias[m] + dbt : dbt;
     }
 }
 
@@ -1058,6 +1058,237 @@ __global__ void __launch_bounds__(kBlock, 2) wgrad_bf16_dma_kernel(const WgradPa
             }
 }
 
+// The wide form of that GEMM for the coupling network's 512-channel gradients (dy has 512 channels: every weight gradient of the network,
+// 48 x 3 launches per training step).  wgrad_bf16_dma_kernel's 128 x 128 workgroup tiles (64 x 64 per wave) read one LDS fragment per
+// MFMA - the LDS peak - and every operand tile 4 times from L2; measured 10 % MFMA-busy, 63 % of the wave cycles waiting.  Here a
+// workgroup of 8 waves (two per SIMD, so one wave's DMA issue and waits sit under the other's MFMAs) owns 256 (dy channels) x TN (x
+// channels, TN = 256 or 128) outputs: a wave's 128 x TN/4 tile takes 4 + TN/128 fragments per 4 * TN/128 MFMAs, and every operand row is
+// read by 2 (not 4) workgroups.  Pixels arrive 32 per stage by LDS-DMA through a 4-slot ring (3 stages in flight, counted vmcnt + one raw
+// barrier per stage).  The price is more pixel slices (256 CUs / 2..4 tiles) for the reduce kernel to sum.
+constexpr int W2_KC = 32;                  // pixels per stage
+#ifndef NFDP_W2_NS
+#define NFDP_W2_NS 4
+#endif
+constexpr int W2_NS = NFDP_W2_NS, W2_DEPTH = W2_NS - 1;     // ring slots / stages in flight
+constexpr int W2_THREADS = 512;
+constexpr int W2_BM = 256;
+template <int TN> constexpr int w2_slot_bytes() { return W2_KC * (W2_BM + TN) * 2; }
+
+template <int N>
+__device__ __forceinline__ void w2_wait_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int TN>
+__global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const WgradParams p) {
+    static_assert(TN == 256 || TN == 128, "x tile");
+    extern __shared__ __attribute__((aligned(1024))) char w2_smem[];   // [W2_NS][dy tile 32 x 512 B | x tile 32 x 2*TN B]
+    constexpr int SLOT = w2_slot_bytes<TN>(), A_BYTES = W2_KC * W2_BM * 2, PB = TN * 2;
+    constexpr int NBP = TN == 256 ? 2 : 1;             // this wave's x pieces per stage (dy: always 2)
+    constexpr int PPS = 2 + NBP;                       // LDS-DMA pieces per wave and stage
+    constexpr int NJ = TN / 128;                       // 32-column tiles of a wave (its 128 x TN/4 outputs: 4 x NJ MFMA tiles)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    // workgroup -> (pixel slice, output tile): the tiles of one slice on one XCD (blockIdx % 8), whose L2 serves the second read of each row
+    int bid = blockIdx.x, nb, mb, ks;
+    if (p.ksplit % 8 == 0) {
+        const int tiles = p.mblocks * p.nblocks, j = bid >> 3, t = j % tiles;
+        ks = (bid & 7) + 8 * (j / tiles);
+        mb = t / p.nblocks; nb = t % p.nblocks;
+    } else {
+        nb = bid % p.nblocks; bid /= p.nblocks;
+        mb = bid % p.mblocks;
+        ks = bid / p.mblocks;
+    }
+    const long p_begin = (long)ks * p.px_per_split;
+    const long p_end = (p_begin + p.px_per_split) < p.npix ? (p_begin + p.px_per_split) : p.npix;
+    const int nstage = (int)((p_end - p_begin) / W2_KC);
+    const __bf16* __restrict__ dyg = reinterpret_cast<const __bf16*>(p.dy);
+    const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(p.x);
+
+    // A blocked operand (32-pixel tiles of [hb][s][g][pixel][8 channels] = [64 chunks of 8 channels][32 pixels][16 B], 512 channels; a
+    // stage is one tile) keeps that chunk-major order in LDS: its 256-channel half is 16 KiB of consecutive bytes, so a DMA piece is two
+    // whole chunks = 1 KiB of consecutive global bytes.  (Gathering it into pixel rows, as wgrad_bf16_dma_kernel does, makes every wave
+    // instruction touch 32 cache lines for 1 KiB: the texture path, not HBM or the matrix cores, then bounds the kernel - 136 us for the
+    // level-0 512 x 512 gradient against 42 us of HBM time.)  Inside a chunk pixel p sits at slot p ^ ((chunk & 3) << 2): the four chunks a
+    // transposing read covers then fall into four different 64-byte bank groups.
+    long src_a[2], src_b[NBP];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (p.a_blocked) {
+            const int chunk = 2 * (2 * wave + i) + (lane >> 5), px = (lane & 31) ^ ((chunk & 3) << 2);
+            src_a[i] = (long)(mb * 32 + chunk) * 256 + px * 8;
+        } else {                                       // pixel rows: a piece = 2 rows of 256 channels (32 chunks of 16 B)
+            const int row = 4 * wave + 2 * i + (lane >> 5);
+            const int ch = (lane & 31) ^ wd_swz(row);
+            src_a[i] = (long)row * p.dy_ld + mb * W2_BM + ch * 8;      // Cout == 512: always inside
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NBP; ++i) {
+        if (p.b_blocked) {                             // (TN == 256: a blocked x has 512 channels)
+            const int chunk = 2 * (NBP * wave + i) + (lane >> 5), px = (lane & 31) ^ ((chunk & 3) << 2);
+            src_b[i] = (long)(nb * 32 + chunk) * 256 + px * 8;
+        } else {
+            int row, ch;
+            if (TN == 256) { row = 4 * wave + 2 * i + (lane >> 5); ch = (lane & 31) ^ wd_swz(row); }
+            else { row = 4 * wave + (lane >> 4); ch = (lane & 15) ^ wd_swz(row); }      // a piece = 4 pixel rows of 128 channels
+            int cb = nb * TN + ch * 8;
+            if (cb > p.N - 8) cb = p.N - 8;            // ragged last block: any valid address, those columns are dropped
+            src_b[i] = (long)row * p.x_ld + cb;
+        }
+    }
+    auto stage = [&](int slot, long p0) {
+        char* base = w2_smem + slot * SLOT;
+#if defined(NFDP_W2_ABLATE) && NFDP_W2_ABLATE == 2     // timing-only build: the matrix work without the operand stream
+        return;
+#endif
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dyg + p0 * p.dy_ld + src_a[i]),
+                                             (__attribute__((address_space(3))) void*)(base + (2 * wave + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NBP; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xg + p0 * p.x_ld + src_b[i]),
+                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + (NBP * wave + i) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[4][NJ], acc_db;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc_db[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j][r] = 0.f;
+    }
+    const int c32 = lane & 31, g = lane >> 5;
+    // transposing-read gather addresses inside an operand tile (see wgrad_bf16_dma_kernel; row pitch 512 B for dy, 2*TN B for x)
+    const int tq = (lane & 15) >> 2, tp = lane & 3, hh = (lane >> 4) & 1;
+    int off_a[4][2], off_b[NJ][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = 8 * g + 4 * r + tq;                         // + 16 * kstep: leaves both swizzles unchanged
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int cha = (wm * 128 + i * 32) / 8 + 2 * hh + (tp >> 1);
+            off_a[i][r] = p.a_blocked ? cha * 512 + ((row ^ ((cha & 3) << 2)) << 4) + 8 * (tp & 1)
+                                      : row * (W2_BM * 2) + ((cha ^ wd_swz(row)) << 4) + 8 * (tp & 1);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int chb = (wn * (TN / 4) + j * 32) / 8 + 2 * hh + (tp >> 1);
+            off_b[j][r] = A_BYTES + (p.b_blocked ? chb * 512 + ((row ^ ((chb & 3) << 2)) << 4) + 8 * (tp & 1)
+                                                 : row * PB + ((chb ^ wd_swz(row)) << 4) + 8 * (tp & 1));
+        }
+    }
+    const int ka = p.a_blocked ? 256 : 16 * W2_BM * 2, kb = p.b_blocked ? 256 : 16 * PB;   // bytes per 16-pixel k-step
+    // The transposing reads are hand-issued (asm volatile) with hand-counted waits: a compiler-visible LDS read makes hipcc drain the
+    // in-flight LDS-DMA first (s_waitcnt vmcnt(0): possible alias), which would serialise every stage's fetch with its MFMAs.
+    // optional column sums of dy (the layer's bias gradient): in n-block 0 wave (wm, wn) also reads dy fragment wn of its row half and
+    // multiplies it by an all-ones B fragment, so the four waves of a row half cover its four fragments with one extra MFMA per k-step
+    const bool do_db = p.ws_db != nullptr && nb == 0;
+    int off_d[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = 8 * g + 4 * r + tq;
+        const int cha = (wm * 128 + wn * 32) / 8 + 2 * hh + (tp >> 1);
+        off_d[r] = p.a_blocked ? cha * 512 + ((row ^ ((cha & 3) << 2)) << 4) + 8 * (tp & 1)
+                               : row * (W2_BM * 2) + ((cha ^ wd_swz(row)) << 4) + 8 * (tp & 1);
+    }
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+    const unsigned smem0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)w2_smem;
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    struct Frags { s16x4 a[4][2], b[NJ][2], d[2]; };
+    auto issue = [&](Frags& f, unsigned tile, int kstep) __attribute__((always_inline)) {
+        const unsigned oa = tile + kstep * ka, ob = tile + kstep * kb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.a[i][r]) : "v"(oa + off_a[i][r]));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.b[j][r]) : "v"(ob + off_b[j][r]));
+        if (do_db) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.d[r]) : "v"(oa + off_d[r]));
+        }
+    };
+    // all of f's reads are back once at most N younger LDS reads are outstanding (LDS returns in order)
+    auto arrived = [&](Frags& f, auto nc) __attribute__((always_inline)) {
+        constexpr int N = decltype(nc)::value;
+        if (do_db) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.d[0]), "+v"(f.d[1]) : "i"(N));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.a[i][0]), "+v"(f.a[i][1]) : "i"(N));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.b[j][0]), "+v"(f.b[j][1]) : "i"(N));
+    };
+    auto cat = [](const s16x4& lo, const s16x4& hi) -> bf16x8 {
+        return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+        bf16x8 bfr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) bfr[j] = cat(f.b[j][0], f.b[j][1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 af = cat(f.a[i][0], f.a[i][1]);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (do_db) acc_db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat(f.d[0], f.d[1]), ones, acc_db, 0, 0, 0);
+    };
+    constexpr int NRD = 2 * (4 + NJ);                  // LDS reads per k-step (+2 with the column sums)
+
+#pragma unroll
+    for (int s0 = 0; s0 < W2_DEPTH; ++s0)
+        if (s0 < nstage) stage(s0, p_begin + (long)s0 * W2_KC);
+    for (int it = 0; it < nstage; ++it) {
+        // this wave's pieces of stage `it` have landed once only the younger stages' pieces are outstanding; after the barrier every
+        // wave's have, and every wave is done reading stage it-1, whose slot takes stage it+DEPTH
+        const int younger = (nstage - 1 - it) < (W2_DEPTH - 1) ? (nstage - 1 - it) : (W2_DEPTH - 1);
+        if (W2_DEPTH >= 4 && younger == 3) w2_wait_barrier<3 * PPS>();
+        else if (W2_DEPTH >= 3 && younger == 2) w2_wait_barrier<2 * PPS>();
+        else if (younger == 1) w2_wait_barrier<PPS>();
+        else w2_wait_barrier<0>();
+        if (it + W2_DEPTH < nstage) stage((it + W2_DEPTH) % W2_NS, p_begin + (long)(it + W2_DEPTH) * W2_KC);
+        const unsigned tile = smem0 + (it % W2_NS) * SLOT;
+#if defined(NFDP_W2_ABLATE) && NFDP_W2_ABLATE == 1     // timing-only build: the operand stream without the matrix work
+        continue;
+#endif
+        static_assert(W2_KC == 32, "two k-steps per stage: both sets of fragments are requested up front");
+        Frags f0, f1;
+        issue(f0, tile, 0);
+        issue(f1, tile, 1);
+        if (do_db) arrived(f0, std::integral_constant<int, NRD + 2>{});
+        else arrived(f0, std::integral_constant<int, NRD>{});
+        mma(f0);
+        arrived(f1, std::integral_constant<int, 0>{});
+        mma(f1);
+    }
+    if (do_db && c32 == 0) {
+        float* dbo = p.ws_db + (size_t)ks * p.Mpad;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dbo[mb * W2_BM + wm * 128 + wn * 32 + drow32(r, g)] = acc_db[r];
+    }
+    float* out = p.ws + (size_t)ks * p.Mpad * p.Npad;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb * W2_BM + wm * 128 + i * 32 + drow32(r, g);
+                const int n = nb * TN + wn * (TN / 4) + j * 32 + c32;
+                out[(size_t)m * p.Npad + n] = acc[i][j][r];
+            }
+}
+
 // ----------------------------------------------------------------------------- tap shift-sum (narrow 3x3 convs)
 // A 3x3 conv with few output channels spends its time staging im2col rows.  Computed instead as a pointwise GEMM
 // T[p][tap*Co + co] = sum_ci x[p][ci] W[co][ci][tap] (a wide 1x1 conv: fast) followed by
@@ -1296,12 +1527,63 @@ static void wgrad_bf16_plan(int B, int H, int W, int Cin, int Cout, int k, Wgrad
     p->ksplit = (int)cdiv(p->npix, per);
 }
 
+// The wide kernel's plan: dy has exactly 512 channels (two 256-row tiles), x up to 512 columns in tiles of 256 (128 when N <= 128);
+// one workgroup per CU, so 256 / tiles pixel slices of whole 32-pixel stages.
+static bool wgrad_wide_ok(long npix, int N, int Cout, int k) {
+    static const bool off = [] { const char* e = getenv("NFDP_WGRAD_WIDE"); return e && e[0] == '0'; }();   // A/B measurements
+    return !off && k == 1 && Cout == 512 && N >= 8 && N <= 512 && N % 8 == 0 && npix % W2_KC == 0 && npix >= 2 * W2_KC;
+}
+static int wgrad_wide_tn(int N) { return N > 128 ? 256 : 128; }
+static void wgrad_wide_plan(long npix, int N, WgradParams* p) {
+    const int tn = wgrad_wide_tn(N);
+    p->N = N;
+    p->mblocks = 2;
+    p->nblocks = (int)cdiv(N, tn);
+    p->Mpad = 512;
+    p->Npad = p->nblocks * tn;
+    p->npix = npix;
+    long want = 256 / ((long)p->mblocks * p->nblocks);
+    static const int want_env = [] { const char* e = getenv("NFDP_WGRAD_SLICES"); return e ? atoi(e) : 0; }();   // sweeps
+    if (want_env > 0) want = want_env;
+    long per = cdiv(cdiv(npix, want), W2_KC) * W2_KC;
+    if (per < 2 * W2_KC) per = 2 * W2_KC;
+    p->px_per_split = per;
+    p->ksplit = (int)cdiv(npix, per);
+}
+static void launch_wgrad_wide(const WgradParams& p, hipStream_t s) {
+    const dim3 grid(p.mblocks * p.nblocks * p.ksplit);
+    if (wgrad_wide_tn(p.N) == 256) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_wide_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      W2_NS * w2_slot_bytes<256>());
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_bf16_wide_kernel<256>, grid, dim3(W2_THREADS), W2_NS * w2_slot_bytes<256>(), s, p);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_wide_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      W2_NS * w2_slot_bytes<128>());
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_bf16_wide_kernel<128>, grid, dim3(W2_THREADS), W2_NS * w2_slot_bytes<128>(), s, p);
+    }
+}
+
 extern "C" int nfdp_conv_wgrad_bf16_supported(int Cin, int Cout) { return Cin % 4 == 0 && Cout % 4 == 0; }
 
 extern "C" size_t nfdp_conv_wgrad_bf16_ws_bytes(int B, int H, int W, int Cin, int Cout, int k) {
     WgradParams p;
     wgrad_bf16_plan(B, H, W, Cin, Cout, k, &p);
-    return (size_t)p.ksplit * p.Mpad * (p.Npad + 1) * sizeof(float);          // + the per-slice column sums of the _affine entry
+    size_t bytes = (size_t)p.ksplit * p.Mpad * (p.Npad + 1) * sizeof(float);  // + the per-slice column sums of the _affine entry
+    if (wgrad_wide_ok((long)B * H * W, k * k * Cin, Cout, k)) {               // whichever kernel the launch picks
+        WgradParams q;
+        wgrad_wide_plan((long)B * H * W, Cin, &q);
+        const size_t wide = (size_t)q.ksplit * q.Mpad * (q.Npad + 1) * sizeof(float);
+        if (wide > bytes) bytes = wide;
+    }
+    return bytes;
 }
 
 extern "C" int nfdp_conv_wgrad_bf16_affine(const void* x, int x_ld, const void* dy, int dy_ld, long npix, int Cin, int Cout, float* dw,
@@ -1321,19 +1603,25 @@ extern "C" int nfdp_conv_wgrad_bf16_affine(const void* x, int x_ld, const void* 
                  NFDP_EUNSUPPORTED, "conv_wgrad_bf16_affine: bf16 operands, 16-byte aligned rows, channels multiples of 8, pixels a multiple of %d",
                  WD_KC);
     WgradParams p;
-    wgrad_bf16_plan(1, 1, (int)npix, Cin, Cout, 1, &p);
+    const bool wide = wgrad_wide_ok(npix, Cin, Cout, 1);
+    if (wide) wgrad_wide_plan(npix, Cin, &p);
+    else wgrad_bf16_plan(1, 1, (int)npix, Cin, Cout, 1, &p);
     p.x = x; p.dy = dy; p.ws = reinterpret_cast<float*>(ws);
     p.ws_db = affine ? p.ws + (size_t)p.ksplit * p.Mpad * p.Npad : nullptr;
     p.b_blocked = layout & 1; p.a_blocked = (layout >> 1) & 1;
     p.x_ld = x_ld; p.dy_ld = dy_ld; p.B = 1; p.H = 1; p.W = (int)npix; p.Cin = Cin; p.Cout = Cout; p.k = 1;
     hipStream_t s = as_stream(stream);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  4 * WD_TILE_BYTES);
-        attr_set = true;
+    if (wide) {
+        launch_wgrad_wide(p, s);
+    } else {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      4 * WD_TILE_BYTES);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(wgrad_bf16_dma_kernel, dim3(p.mblocks * p.nblocks * p.ksplit), dim3(kBlock), 4 * WD_TILE_BYTES, s, p);
     }
-    hipLaunchKernelGGL(wgrad_bf16_dma_kernel, dim3(p.mblocks * p.nblocks * p.ksplit), dim3(kBlock), 4 * WD_TILE_BYTES, s, p);
     if (affine)
         hipLaunchKernelGGL(wgrad_reduce_rows_kernel, dim3(Cout), dim3(kBlock), 0, s, p.ws, p.ws_db, dw, p.ksplit, p.Mpad, p.Npad, om, w,
                            bias, dscale, dbias);
