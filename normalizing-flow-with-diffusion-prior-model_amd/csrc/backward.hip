@@ -1081,7 +1081,7 @@ __device__ __forceinline__ void w2_wait_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int TN>
+template <int TN, bool ABLK, bool BBLK>          // ABLK / BBLK: dy / x in the blocked layout
 __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const WgradParams p) {
     static_assert(TN == 256 || TN == 128, "x tile");
     extern __shared__ __attribute__((aligned(1024))) char w2_smem[];   // [W2_NS][dy tile 32 x 512 B | x tile 32 x 2*TN B]
@@ -1117,7 +1117,7 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
     long src_a[2], src_b[NBP];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        if (p.a_blocked) {
+        if (ABLK) {
             const int chunk = 2 * (2 * wave + i) + (lane >> 5), px = (lane & 31) ^ ((chunk & 3) << 2);
             src_a[i] = (long)(mb * 32 + chunk) * 256 + px * 8;
         } else {                                       // pixel rows: a piece = 2 rows of 256 channels (32 chunks of 16 B)
@@ -1128,7 +1128,7 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
     }
 #pragma unroll
     for (int i = 0; i < NBP; ++i) {
-        if (p.b_blocked) {                             // (TN == 256: a blocked x has 512 channels)
+        if (BBLK) {                                    // (TN == 256: a blocked x has 512 channels)
             const int chunk = 2 * (NBP * wave + i) + (lane >> 5), px = (lane & 31) ^ ((chunk & 3) << 2);
             src_b[i] = (long)(nb * 32 + chunk) * 256 + px * 8;
         } else {
@@ -1174,17 +1174,17 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int cha = (wm * 128 + i * 32) / 8 + 2 * hh + (tp >> 1);
-            off_a[i][r] = p.a_blocked ? cha * 512 + ((row ^ ((cha & 3) << 2)) << 4) + 8 * (tp & 1)
+            off_a[i][r] = ABLK ? cha * 512 + ((row ^ ((cha & 3) << 2)) << 4) + 8 * (tp & 1)
                                       : row * (W2_BM * 2) + ((cha ^ wd_swz(row)) << 4) + 8 * (tp & 1);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int chb = (wn * (TN / 4) + j * 32) / 8 + 2 * hh + (tp >> 1);
-            off_b[j][r] = A_BYTES + (p.b_blocked ? chb * 512 + ((row ^ ((chb & 3) << 2)) << 4) + 8 * (tp & 1)
-                                                 : row * PB + ((chb ^ wd_swz(row)) << 4) + 8 * (tp & 1));
+            off_b[j][r] = BBLK ? chb * 512 + ((row ^ ((chb & 3) << 2)) << 4) + 8 * (tp & 1)
+                               : row * PB + ((chb ^ wd_swz(row)) << 4) + 8 * (tp & 1);
         }
     }
-    const int ka = p.a_blocked ? 256 : 16 * W2_BM * 2, kb = p.b_blocked ? 256 : 16 * PB;   // bytes per 16-pixel k-step
+    constexpr int KA = ABLK ? 256 : 16 * W2_BM * 2, KB = BBLK ? 256 : 16 * PB;   // bytes per 16-pixel k-step
     // The transposing reads are hand-issued (asm volatile) with hand-counted waits: a compiler-visible LDS read makes hipcc drain the
     // in-flight LDS-DMA first (s_waitcnt vmcnt(0): possible alias), which would serialise every stage's fetch with its MFMAs.
     // optional column sums of dy (the layer's bias gradient): in n-block 0 wave (wm, wn) also reads dy fragment wn of its row half and
@@ -1195,7 +1195,7 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
     for (int r = 0; r < 2; ++r) {
         const int row = 8 * g + 4 * r + tq;
         const int cha = (wm * 128 + wn * 32) / 8 + 2 * hh + (tp >> 1);
-        off_d[r] = p.a_blocked ? cha * 512 + ((row ^ ((cha & 3) << 2)) << 4) + 8 * (tp & 1)
+        off_d[r] = ABLK ? cha * 512 + ((row ^ ((cha & 3) << 2)) << 4) + 8 * (tp & 1)
                                : row * (W2_BM * 2) + ((cha ^ wd_swz(row)) << 4) + 8 * (tp & 1);
     }
     bf16x8 ones;
@@ -1204,25 +1204,30 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
     const unsigned smem0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)w2_smem;
     typedef short s16x8 __attribute__((ext_vector_type(8)));
     struct Frags { s16x4 a[4][2], b[NJ][2], d[2]; };
-    auto issue = [&](Frags& f, unsigned tile, int kstep) __attribute__((always_inline)) {
-        const unsigned oa = tile + kstep * ka, ob = tile + kstep * kb;
+    // request the fragments of k-step KS of the stage in ring slot `tile` (one address add per read and stage; the k-step and the x
+    // tile's offset are immediates)
+    auto issue = [&](Frags& f, unsigned tile, auto ksc, auto dbc) __attribute__((always_inline)) {
+        constexpr int KS = decltype(ksc)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.a[i][r]) : "v"(oa + off_a[i][r]));
+            for (int r = 0; r < 2; ++r)
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.a[i][r]) : "v"(tile + off_a[i][r]), "i"(KS * KA));
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 2; ++r) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.b[j][r]) : "v"(ob + off_b[j][r]));
-        if (do_db) {
-#pragma unroll
-            for (int r = 0; r < 2; ++r) asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.d[r]) : "v"(oa + off_d[r]));
+            for (int r = 0; r < 2; ++r)
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.b[j][r]) : "v"(tile + off_b[j][r]), "i"(A_BYTES + KS * KB));
+        const unsigned ad0 = tile + off_d[0], ad1 = tile + off_d[1];     // (named outside the constexpr branch: clang rejects the capture inside)
+        if constexpr (decltype(dbc)::value) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.d[0]) : "v"(ad0), "i"(KS * KA));
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.d[1]) : "v"(ad1), "i"(KS * KA));
         }
     };
     // all of f's reads are back once at most N younger LDS reads are outstanding (LDS returns in order)
-    auto arrived = [&](Frags& f, auto nc) __attribute__((always_inline)) {
+    auto arrived = [&](Frags& f, auto nc, auto dbc) __attribute__((always_inline)) {
         constexpr int N = decltype(nc)::value;
-        if (do_db) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.d[0]), "+v"(f.d[1]) : "i"(N));
+        if constexpr (decltype(dbc)::value) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.d[0]), "+v"(f.d[1]) : "i"(N));
 #pragma unroll
         for (int i = 0; i < 4; ++i) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.a[i][0]), "+v"(f.a[i][1]) : "i"(N));
 #pragma unroll
@@ -1231,7 +1236,7 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
     auto cat = [](const s16x4& lo, const s16x4& hi) -> bf16x8 {
         return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
-    auto mma = [&](const Frags& f) __attribute__((always_inline)) {
+    auto mma = [&](const Frags& f, auto dbc) __attribute__((always_inline)) {
         bf16x8 bfr[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) bfr[j] = cat(f.b[j][0], f.b[j][1]);
@@ -1241,36 +1246,56 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
 #pragma unroll
             for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (do_db) acc_db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat(f.d[0], f.d[1]), ones, acc_db, 0, 0, 0);
+        if constexpr (decltype(dbc)::value) acc_db = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cat(f.d[0], f.d[1]), ones, acc_db, 0, 0, 0);
     };
-    constexpr int NRD = 2 * (4 + NJ);                  // LDS reads per k-step (+2 with the column sums)
 
-#pragma unroll
-    for (int s0 = 0; s0 < W2_DEPTH; ++s0)
-        if (s0 < nstage) stage(s0, p_begin + (long)s0 * W2_KC);
-    for (int it = 0; it < nstage; ++it) {
-        // this wave's pieces of stage `it` have landed once only the younger stages' pieces are outstanding; after the barrier every
-        // wave's have, and every wave is done reading stage it-1, whose slot takes stage it+DEPTH
-        const int younger = (nstage - 1 - it) < (W2_DEPTH - 1) ? (nstage - 1 - it) : (W2_DEPTH - 1);
-        if (W2_DEPTH >= 4 && younger == 3) w2_wait_barrier<3 * PPS>();
-        else if (W2_DEPTH >= 3 && younger == 2) w2_wait_barrier<2 * PPS>();
-        else if (younger == 1) w2_wait_barrier<PPS>();
-        else w2_wait_barrier<0>();
-        if (it + W2_DEPTH < nstage) stage((it + W2_DEPTH) % W2_NS, p_begin + (long)(it + W2_DEPTH) * W2_KC);
-        const unsigned tile = smem0 + (it % W2_NS) * SLOT;
-#if defined(NFDP_W2_ABLATE) && NFDP_W2_ABLATE == 1     // timing-only build: the operand stream without the matrix work
-        continue;
-#endif
-        static_assert(W2_KC == 32, "two k-steps per stage: both sets of fragments are requested up front");
+    // Software pipeline over the stages (two 16-pixel k-steps each): the fragments of the NEXT k-step are requested before the MFMAs of
+    // the current one, across the stage boundary too - the barrier that publishes stage it+1 (and frees the slot of stage it-1 for stage
+    // it+3) sits between the two k-steps of stage it, so no LDS latency and no barrier skew is exposed in front of an MFMA group.
+    static_assert(W2_KC == 32 && W2_NS == 4, "pipeline written for two k-steps per stage and a 4-slot ring");
+    auto run = [&](auto dbc) __attribute__((always_inline)) {
+        constexpr int NR = 2 * (4 + NJ) + (decltype(dbc)::value ? 2 : 0);        // LDS reads per k-step
+        constexpr std::integral_constant<int, 0> k0{};
+        constexpr std::integral_constant<int, 1> k1{};
         Frags f0, f1;
-        issue(f0, tile, 0);
-        issue(f1, tile, 1);
-        if (do_db) arrived(f0, std::integral_constant<int, NRD + 2>{});
-        else arrived(f0, std::integral_constant<int, NRD>{});
-        mma(f0);
-        arrived(f1, std::integral_constant<int, 0>{});
-        mma(f1);
-    }
+        if (nstage >= 3) w2_wait_barrier<2 * PPS>();
+        else if (nstage == 2) w2_wait_barrier<PPS>();
+        else w2_wait_barrier<0>();
+#if !(defined(NFDP_W2_ABLATE) && NFDP_W2_ABLATE == 1)
+        issue(f0, smem0, k0, dbc);
+#endif
+        for (int it = 0; it < nstage; ++it) {
+            const unsigned tile = smem0 + (it % W2_NS) * SLOT;
+#if !(defined(NFDP_W2_ABLATE) && NFDP_W2_ABLATE == 1)     // (== 1: timing-only build, the operand stream without the matrix work)
+            issue(f1, tile, k1, dbc);
+            arrived(f0, std::integral_constant<int, NR>{}, dbc);
+            mma(f0, dbc);
+#endif
+            if (it + 1 < nstage) {
+                // this wave's pieces of stage it+1 have landed once only stage it+2's are outstanding; after the barrier every wave's
+                // have, and every wave is past its reads of stage it-1
+                if (it + 2 < nstage) w2_wait_barrier<PPS>();
+                else w2_wait_barrier<0>();
+                if (it + 3 < nstage) stage((it + 3) % W2_NS, p_begin + (long)(it + 3) * W2_KC);
+#if !(defined(NFDP_W2_ABLATE) && NFDP_W2_ABLATE == 1)
+                issue(f0, smem0 + ((it + 1) % W2_NS) * SLOT, k0, dbc);
+                arrived(f1, std::integral_constant<int, NR>{}, dbc);
+#endif
+            } else {
+#if !(defined(NFDP_W2_ABLATE) && NFDP_W2_ABLATE == 1)
+                arrived(f1, std::integral_constant<int, 0>{}, dbc);
+#endif
+            }
+#if !(defined(NFDP_W2_ABLATE) && NFDP_W2_ABLATE == 1)
+            mma(f1, dbc);
+#endif
+        }
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < 3; ++s0)
+        if (s0 < nstage) stage(s0, p_begin + (long)s0 * W2_KC);
+    if (do_db) run(std::true_type{});
+    else run(std::false_type{});
     if (do_db && c32 == 0) {
         float* dbo = p.ws_db + (size_t)ks * p.Mpad;
 #pragma unroll
@@ -1544,30 +1569,34 @@ static void wgrad_wide_plan(long npix, int N, WgradParams* p) {
     p->npix = npix;
     long want = 256 / ((long)p->mblocks * p->nblocks);
     static const int want_env = [] { const char* e = getenv("NFDP_WGRAD_SLICES"); return e ? atoi(e) : 0; }();   // sweeps
+    if (want > npix / (8 * W2_KC)) want = npix / (8 * W2_KC);     // at least 8 stages per slice: below that the partial tiles cost more than they spread
+    if (want < 1) want = 1;
     if (want_env > 0) want = want_env;
     long per = cdiv(cdiv(npix, want), W2_KC) * W2_KC;
     if (per < 2 * W2_KC) per = 2 * W2_KC;
     p->px_per_split = per;
     p->ksplit = (int)cdiv(npix, per);
 }
+template <int TN, bool ABLK, bool BBLK>
+static void launch_wgrad_wide_t(const WgradParams& p, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_wide_kernel<TN, ABLK, BBLK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, W2_NS * w2_slot_bytes<TN>());
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wgrad_bf16_wide_kernel<TN, ABLK, BBLK>), dim3(p.mblocks * p.nblocks * p.ksplit), dim3(W2_THREADS),
+                       W2_NS * w2_slot_bytes<TN>(), s, p);
+}
 static void launch_wgrad_wide(const WgradParams& p, hipStream_t s) {
-    const dim3 grid(p.mblocks * p.nblocks * p.ksplit);
     if (wgrad_wide_tn(p.N) == 256) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_wide_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      W2_NS * w2_slot_bytes<256>());
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(wgrad_bf16_wide_kernel<256>, grid, dim3(W2_THREADS), W2_NS * w2_slot_bytes<256>(), s, p);
-    } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_wide_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      W2_NS * w2_slot_bytes<128>());
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(wgrad_bf16_wide_kernel<128>, grid, dim3(W2_THREADS), W2_NS * w2_slot_bytes<128>(), s, p);
+        if (p.a_blocked && p.b_blocked) launch_wgrad_wide_t<256, true, true>(p, s);
+        else if (p.a_blocked) launch_wgrad_wide_t<256, true, false>(p, s);
+        else if (p.b_blocked) launch_wgrad_wide_t<256, false, true>(p, s);
+        else launch_wgrad_wide_t<256, false, false>(p, s);
+    } else {                                           // (a blocked x has 512 channels: never here)
+        if (p.a_blocked) launch_wgrad_wide_t<128, true, false>(p, s);
+        else launch_wgrad_wide_t<128, false, false>(p, s);
     }
 }
 
