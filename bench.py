@@ -442,14 +442,14 @@ def main():
             # HBM traffic of the same kernel/shape from a separate rocprofv3 --pmc pass (committed summary):
             # FETCH_SIZE doubled for wide coalesced reads on gfx950 (MI355X_MICROARCH.md §HBM) + WRITE_SIZE, per launch
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_a_pmc_summary.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_d_pmc_summary.json")))
                 key = {"level_fused<12,16>": "coupling_fused_kernel<12, 16, 2, false, false>",
                        "level_fused<24,8>": "coupling_fused_rs2_kernel<24, 8, 4, false>",
                        "level_fused<48,4>": "coupling_fused_rs_kernel<48, 4, false>"}.get(lbl.split(" ")[0])
                 if key and args.batch == 512:
                     roofline["traffic"] = int(pmc[key]["hbm_bytes_per_launch"])
                     roofline["traffic_note"] = ("bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2: gfx950 tallies 128-B reads at 64 B) + "
-                                                "WRITE_SIZE in separate passes, profiles/r02_a_pmc_summary.json (tools/profile_round.sh)")
+                                                "WRITE_SIZE in separate passes, profiles/r02_d_pmc_summary.json (tools/profile_round.sh)")
             except (OSError, KeyError, ValueError):
                 pass
             roofline.update({"kernel": lbl, "avg_launch_us": round(avg_s * 1e6, 2),
