@@ -386,6 +386,18 @@ int nfdp_conv_wgrad_bf16_ex(const void* x, int x_dtype, int x_ld, const void* dy
 int nfdp_conv_wgrad_bf16_affine(const void* x, int x_ld, const void* dy, int dy_ld, long npix, int Cin, int Cout, float* dw, void* ws,
                                 int out_form, int out_c, int accumulate, int layout, const float* w, const float* bias, float* dscale,
                                 float* dbias, nfdp_stream_t stream);
+/* The weight gradients of ONE flow's coupling network (utils.py:72-90; autograd of trainer.py:163-164) as one GEMM launch and one
+ * reduce launch: n_gemm (1..3) problems nfdp_conv_wgrad_bf16_affine would run one by one, over the same npix pixels (a multiple of 32)
+ * and each with a 512-channel BLOCKED dy.  Per problem q: x[q] ([npix][x_ld[q]] bf16 rows, or BLOCKED when x_blocked[q]: then
+ * cin[q] == x_ld[q] == 512), cin[q] (multiple of 8, at most 512), dw[q] / out_form[q] / out_c[q] as in nfdp_conv_wgrad_bf16_affine,
+ * w[q] / bias[q] / dscale[q] / dbias[q]: the layer's ActNorm parameters and gradients (w[q] == NULL: dW only, any out_form).
+ * The pixel slices are dealt to the problems in proportion to their cost, so they finish together on one chip-wide grid.
+ * ws: nfdp_coupling_wgrad3_ws_bytes(npix, cin, n_gemm) bytes (0: unsupported shapes). */
+size_t nfdp_coupling_wgrad3_ws_bytes(long npix, const int* cin, int n_gemm);
+int nfdp_coupling_wgrad3_bf16(const void* const* x, const int* x_ld, const int* x_blocked, const void* const* dy, const int* cin,
+                              float* const* dw, const int* out_form, const int* out_c, const float* const* w, const float* const* bias,
+                              float* const* dscale, float* const* dbias, int n_gemm, long npix, void* ws, int accumulate,
+                              nfdp_stream_t stream);
 /* wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: nfdp_conv2d_nhwc on pack(wt) is the data gradient of the conv with w. */
 int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int I, int k, nfdp_stream_t stream);
 /* Second half of a narrow 3x3 'same' conv computed as a pointwise GEMM to tap contributions T [B,H,W,9*Co] (column

@@ -222,16 +222,14 @@ __device__ __forceinline__ float wgrad_get(const float* __restrict__ w, const Wg
     return w[m * o.sm + (n % o.D) * o.sd + (n / o.D) * o.st + o.off];
 }
 
-__global__ void __launch_bounds__(kBlock) wgrad_reduce_rows_kernel(const float* __restrict__ ws, const float* __restrict__ ws_db,
-                                                                  float* __restrict__ dw, int ksplit, int Mpad, int Npad, WgradOut o,
-                                                                  const float* __restrict__ w, const float* __restrict__ bias,
-                                                                  float* __restrict__ dscale, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_reduce_row(const float* __restrict__ ws, const float* __restrict__ ws_db, float* __restrict__ dw,
+                                                 int ksplit, int Mpad, int Npad, const WgradOut& o, const float* __restrict__ w,
+                                                 const float* __restrict__ bias, float* __restrict__ dscale, float* __restrict__ dbias,
+                                                 int m, float4* red, float* sdot, float* sdb) {
     // One workgroup per output row.  Thread t owns float4 column t % (Npad/4) and the slices sg, sg + ng, ... (sg = t / (Npad/4), ng =
     // 256 / (Npad/4) slice groups), 8 loads in flight per thread: the kernel streams ksplit * Npad floats per row and is otherwise
     // latency-bound (the first version, 4 loads in flight per lane and a serial bias-gradient loop, took 27-40 us per launch).
-    __shared__ float4 red[kBlock];
-    __shared__ float sdot[kBlock], sdb[kBlock];
-    const int m = blockIdx.x, t = threadIdx.x;
+    const int t = threadIdx.x;
     const int nc4 = Npad / 4, ng = kBlock / nc4 > 0 ? kBlock / nc4 : 1;
     const int c = t % nc4, sg = t / nc4;
     const long slice = (long)Mpad * Npad;
@@ -252,8 +250,10 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_rows_kernel(const float* 
         }
     }
     red[t] = a;
+    const bool affine = w != nullptr;                     // (uniform)
     float db = 0.f;
-    for (int q = t; q < ksplit; q += kBlock) db += ws_db[(size_t)q * Mpad + m];
+    if (affine)
+        for (int q = t; q < ksplit; q += kBlock) db += ws_db[(size_t)q * Mpad + m];
     sdb[t] = db;
     __syncthreads();
     float dot = 0.f;
@@ -264,10 +264,11 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_rows_kernel(const float* 
 #pragma unroll
         for (int e = 0; e < 4; ++e)
             if (4 * t + e < o.N) {
-                dot = fmaf(wgrad_get(w, o, m, 4 * t + e), tv[e], dot);
+                if (affine) dot = fmaf(wgrad_get(w, o, m, 4 * t + e), tv[e], dot);
                 wgrad_put(dw, o, m, 4 * t + e, tv[e]);
             }
     }
+    if (!affine) return;
     sdot[t] = dot;
     __syncthreads();
     for (int sft = kBlock / 2; sft > 0; sft >>= 1) {              // fixed tree: deterministic
@@ -280,6 +281,15 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_rows_kernel(const float* 
         dscale[m] = o.acc ? dscale[m] + ds : ds;
         dbias[m] = o.acc ? dbias[m] + dbt : dbt;
     }
+}
+
+__global__ void __launch_bounds__(kBlock) wgrad_reduce_rows_kernel(const float* __restrict__ ws, const float* __restrict__ ws_db,
+                                                                  float* __restrict__ dw, int ksplit, int Mpad, int Npad, WgradOut o,
+                                                                  const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  float* __restrict__ dscale, float* __restrict__ dbias) {
+    __shared__ float4 red[kBlock];
+    __shared__ float sdot[kBlock], sdb[kBlock];
+    wgrad_reduce_row(ws, ws_db, dw, ksplit, Mpad, Npad, o, w, bias, dscale, dbias, blockIdx.x, red, sdot, sdb);
 }
 
 // wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: the forward conv kernel on wt is the data gradient of conv(., w)
@@ -1082,9 +1092,9 @@ __device__ __forceinline__ void w2_wait_barrier() {
 }
 
 template <int TN, bool ABLK, bool BBLK>          // ABLK / BBLK: dy / x in the blocked layout
-__global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const WgradParams p) {
+__device__ __forceinline__ void wgrad_wide_body(const WgradParams& p, int bid, char* w2_smem) {
     static_assert(TN == 256 || TN == 128, "x tile");
-    extern __shared__ __attribute__((aligned(1024))) char w2_smem[];   // [W2_NS][dy tile 32 x 512 B | x tile 32 x 2*TN B]
+    // w2_smem: [W2_NS][dy tile 32 x 512 B | x tile 32 x 2*TN B]
     constexpr int SLOT = w2_slot_bytes<TN>(), A_BYTES = W2_KC * W2_BM * 2, PB = TN * 2;
     constexpr int NBP = TN == 256 ? 2 : 1;             // this wave's x pieces per stage (dy: always 2)
     constexpr int PPS = 2 + NBP;                       // LDS-DMA pieces per wave and stage
@@ -1092,7 +1102,7 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     // workgroup -> (pixel slice, output tile): the tiles of one slice on one XCD (blockIdx % 8), whose L2 serves the second read of each row
-    int bid = blockIdx.x, nb, mb, ks;
+    int nb, mb, ks;
     if (p.ksplit % 8 == 0) {
         const int tiles = p.mblocks * p.nblocks, j = bid >> 3, t = j % tiles;
         ks = (bid & 7) + 8 * (j / tiles);
@@ -1104,7 +1114,7 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
     }
     const long p_begin = (long)ks * p.px_per_split;
     const long p_end = (p_begin + p.px_per_split) < p.npix ? (p_begin + p.px_per_split) : p.npix;
-    const int nstage = (int)((p_end - p_begin) / W2_KC);
+    const int nstage = p_end > p_begin ? (int)((p_end - p_begin) / W2_KC) : 0;   // (an empty last slice still writes its zero tile)
     const __bf16* __restrict__ dyg = reinterpret_cast<const __bf16*>(p.dy);
     const __bf16* __restrict__ xg = reinterpret_cast<const __bf16*>(p.x);
 
@@ -1294,8 +1304,10 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
 #pragma unroll
     for (int s0 = 0; s0 < 3; ++s0)
         if (s0 < nstage) stage(s0, p_begin + (long)s0 * W2_KC);
-    if (do_db) run(std::true_type{});
-    else run(std::false_type{});
+    if (nstage > 0) {
+        if (do_db) run(std::true_type{});
+        else run(std::false_type{});
+    }
     if (do_db && c32 == 0) {
         float* dbo = p.ws_db + (size_t)ks * p.Mpad;
 #pragma unroll
@@ -1312,6 +1324,50 @@ __global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const Wg
                 const int n = nb * TN + wn * (TN / 4) + j * 32 + c32;
                 out[(size_t)m * p.Npad + n] = acc[i][j][r];
             }
+}
+
+template <int TN, bool ABLK, bool BBLK>
+__global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_wide_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char w2_dyn_smem[];
+    wgrad_wide_body<TN, ABLK, BBLK>(p, blockIdx.x, w2_dyn_smem);
+}
+
+// The weight gradients of one flow's coupling network as ONE launch: up to three GEMMs over the same pixels (dW2: y1 x dc2; dW1: im2col
+// rows x dc1; dW3: im2col rows of dc3 x y2), each with its own slice count, workgroups dealt to the GEMMs in order (the 256 x 256 tiles
+// first: they take longest).  One launch per GEMM gave each 256 / tiles slices; together the 8 tiles of a level-0 flow share the chip,
+// the slices are 1.5-2.7 x longer, and the fp32 partial tiles the reduce has to re-read shrink accordingly.
+struct WgradMulti {
+    WgradParams p[3];
+    int first[4];        // first workgroup of each GEMM (multiples of 8: the XCD mapping of the body reads the low bits)
+    int kind[3];         // 0: <256, blocked, blocked>  1: <256, blocked, rows>  2: <128, blocked, rows>
+    int n;
+};
+__global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_multi_kernel(const WgradMulti m) {
+    extern __shared__ __attribute__((aligned(1024))) char w2_dyn_smem[];
+    const int b = blockIdx.x;
+    const int q = (m.n > 2 && b >= m.first[2]) ? 2 : ((m.n > 1 && b >= m.first[1]) ? 1 : 0);
+    const int bid = b - m.first[q];
+    if (bid >= m.p[q].mblocks * m.p[q].nblocks * m.p[q].ksplit) return;      // padding up to the next multiple of 8 workgroups
+    if (m.kind[q] == 0) wgrad_wide_body<256, true, true>(m.p[q], bid, w2_dyn_smem);
+    else if (m.kind[q] == 1) wgrad_wide_body<256, true, false>(m.p[q], bid, w2_dyn_smem);
+    else wgrad_wide_body<128, true, false>(m.p[q], bid, w2_dyn_smem);
+}
+
+// The slice sums of those GEMMs in one launch: one workgroup per output row of every GEMM (wgrad_reduce_rows_kernel's work; a GEMM
+// without ActNorm parameters - the zero conv's - has w == nullptr and only writes dW).
+struct ReduceMulti {
+    const float* ws[3]; const float* ws_db[3]; float* dw[3];
+    const float* w[3]; const float* bias[3]; float* dscale[3]; float* dbias[3];
+    WgradOut o[3];
+    int ksplit[3], Npad[3];
+    int n;
+};
+__global__ void __launch_bounds__(kBlock) wgrad_reduce_multi_kernel(const ReduceMulti r) {
+    __shared__ float4 red[kBlock];
+    __shared__ float sdot[kBlock], sdb[kBlock];
+    const int q = blockIdx.x / 512, m = blockIdx.x % 512;
+    wgrad_reduce_row(r.ws[q], r.ws_db[q], r.dw[q], r.ksplit[q], 512, r.Npad[q], r.o[q], r.w[q], r.bias[q], r.dscale[q], r.dbias[q], m, red,
+                     sdot, sdb);
 }
 
 // ----------------------------------------------------------------------------- tap shift-sum (narrow 3x3 convs)
@@ -1627,9 +1683,9 @@ extern "C" int nfdp_conv_wgrad_bf16_affine(const void* x, int x_ld, const void* 
     NFDP_REQUIRE(!affine || Cin <= 768, NFDP_EUNSUPPORTED, "conv_wgrad_bf16_affine: Cin=%d (at most 768)", Cin);
     NFDP_REQUIRE(!(layout & 1) || (Cin == 512 && x_ld == 512), NFDP_ESHAPE, "conv_wgrad_bf16_affine: a blocked x has 512 channels");
     NFDP_REQUIRE(!(layout & 2) || (Cout == 512 && dy_ld == 512), NFDP_ESHAPE, "conv_wgrad_bf16_affine: a blocked dy has 512 channels");
-    NFDP_REQUIRE(npix > 0 && npix % WD_KC == 0 && npix < (1L << 31) && Cin >= 8 && Cout >= 8 && Cin % 8 == 0 && Cout % 8 == 0 && x_ld >= Cin &&
+    NFDP_REQUIRE(npix > 0 && (npix % WD_KC == 0 || wgrad_wide_ok(npix, Cin, Cout, 1)) && npix < (1L << 31) && Cin >= 8 && Cout >= 8 && Cin % 8 == 0 && Cout % 8 == 0 && x_ld >= Cin &&
                      dy_ld >= Cout && x_ld % 8 == 0 && dy_ld % 8 == 0 && (((uintptr_t)x | (uintptr_t)dy) & 15) == 0,
-                 NFDP_EUNSUPPORTED, "conv_wgrad_bf16_affine: bf16 operands, 16-byte aligned rows, channels multiples of 8, pixels a multiple of %d",
+                 NFDP_EUNSUPPORTED, "conv_wgrad_bf16_affine: bf16 operands, 16-byte aligned rows, channels multiples of 8, pixels a multiple of %d (32 with 512 dy channels)",
                  WD_KC);
     WgradParams p;
     const bool wide = wgrad_wide_ok(npix, Cin, Cout, 1);
@@ -1657,6 +1713,97 @@ extern "C" int nfdp_conv_wgrad_bf16_affine(const void* x, int x_ld, const void* 
     else
         launch_wgrad_reduce(p.ws, dw, p.ksplit, p.Mpad, p.Npad, Cout, om, s);
     NFDP_CHECK_LAUNCH("conv_wgrad_bf16_affine");
+    return NFDP_OK;
+}
+
+// ---- the weight gradients of one flow's coupling network in one GEMM launch + one reduce launch (see wgrad_bf16_multi_kernel)
+static bool wgrad3_plan(long npix, const int* cin, int n, WgradParams* p) {
+    if (n < 1 || n > 3) return false;
+    double denom = 0.0;
+    double cost[3];
+    for (int q = 0; q < n; ++q) {
+        if (!wgrad_wide_ok(npix, cin[q], 512, 1)) return false;
+        const int tn = wgrad_wide_tn(cin[q]);
+        cost[q] = tn == 256 ? 0.87 : 0.6;                  // measured us per 32-pixel stage of a workgroup
+        denom += 2.0 * (double)cdiv(cin[q], tn) * cost[q];
+    }
+    const long cap = npix / (8 * W2_KC);                   // at least 8 stages per slice
+    for (int q = 0; q < n; ++q) {
+        const int tn = wgrad_wide_tn(cin[q]);
+        long want = (long)(256.0 / denom * cost[q]) / 8 * 8;   // slices in proportion to the stage cost: the GEMMs finish together
+        if (want < 8) want = 8;
+        if (want > cap) want = cap >= 8 ? cap / 8 * 8 : (cap > 0 ? cap : 1);
+        p[q].N = cin[q];
+        p[q].mblocks = 2;
+        p[q].nblocks = (int)cdiv(cin[q], tn);
+        p[q].Mpad = 512;
+        p[q].Npad = p[q].nblocks * tn;
+        p[q].npix = npix;
+        long per = cdiv(cdiv(npix, want), W2_KC) * W2_KC;
+        if (per < 2 * W2_KC) per = 2 * W2_KC;
+        p[q].px_per_split = per;
+        p[q].ksplit = (int)cdiv(npix, per);
+    }
+    return true;
+}
+
+extern "C" size_t nfdp_coupling_wgrad3_ws_bytes(long npix, const int* cin, int n_gemm) {
+    WgradParams p[3];
+    if (!cin || !wgrad3_plan(npix, cin, n_gemm, p)) return 0;
+    size_t bytes = 0;
+    for (int q = 0; q < n_gemm; ++q) bytes += (size_t)p[q].ksplit * 512 * (p[q].Npad + 1) * sizeof(float);
+    return bytes;
+}
+
+extern "C" int nfdp_coupling_wgrad3_bf16(const void* const* x, const int* x_ld, const int* x_blocked, const void* const* dy, const int* cin,
+                                         float* const* dw, const int* out_form, const int* out_c, const float* const* w,
+                                         const float* const* bias, float* const* dscale, float* const* dbias, int n_gemm, long npix,
+                                         void* ws, int accumulate, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && x_ld && x_blocked && dy && cin && dw && out_form && out_c && w && bias && dscale && dbias && ws, NFDP_EINVAL,
+                 "coupling_wgrad3: null pointer");
+    WgradMulti m;
+    NFDP_REQUIRE(wgrad3_plan(npix, cin, n_gemm, m.p), NFDP_EUNSUPPORTED,
+                 "coupling_wgrad3: 1..3 GEMMs over a multiple of %d pixels, x channels multiples of 8 up to 512", W2_KC);
+    ReduceMulti r;
+    m.n = r.n = n_gemm;
+    float* wsf = reinterpret_cast<float*>(ws);
+    int blocks = 0;
+    for (int q = 0; q < n_gemm; ++q) {
+        WgradParams& p = m.p[q];
+        NFDP_REQUIRE(x[q] && dy[q] && dw[q], NFDP_EINVAL, "coupling_wgrad3: null pointer in GEMM %d", q);
+        const bool affine = w[q] != nullptr;
+        NFDP_REQUIRE(!affine || (bias[q] && dscale[q] && dbias[q]), NFDP_EINVAL, "coupling_wgrad3: w given without bias / dscale / dbias");
+        NFDP_REQUIRE(wgrad_out_map(out_form[q], out_c[q], 512, cin[q], 1, accumulate, &r.o[q]) && !(affine && out_form[q] == 2), NFDP_ESHAPE,
+                     "coupling_wgrad3: output form %d of GEMM %d (out_c=%d Cin=%d)", out_form[q], q, out_c[q], cin[q]);
+        NFDP_REQUIRE(!x_blocked[q] || (cin[q] == 512 && x_ld[q] == 512), NFDP_ESHAPE, "coupling_wgrad3: a blocked x has 512 channels");
+        NFDP_REQUIRE(x_ld[q] >= cin[q] && x_ld[q] % 8 == 0 && (((uintptr_t)x[q] | (uintptr_t)dy[q]) & 15) == 0, NFDP_ESHAPE,
+                     "coupling_wgrad3: 16-byte aligned bf16 rows");
+        p.x = x[q]; p.dy = dy[q];
+        p.ws = wsf;
+        wsf += (size_t)p.ksplit * 512 * p.Npad;
+        p.ws_db = affine ? wsf : nullptr;
+        wsf += (size_t)p.ksplit * 512;
+        p.a_blocked = 1; p.b_blocked = x_blocked[q] ? 1 : 0;
+        p.x_ld = x_ld[q]; p.dy_ld = 512; p.B = 1; p.H = 1; p.W = (int)npix; p.Cin = cin[q]; p.Cout = 512; p.k = 1;
+        m.kind[q] = x_blocked[q] ? 0 : (wgrad_wide_tn(cin[q]) == 256 ? 1 : 2);
+        m.first[q] = blocks;
+        blocks += p.mblocks * p.nblocks * p.ksplit;
+        blocks = (blocks + 7) & ~7;                                   // the next GEMM starts on XCD 0 again
+        r.ws[q] = p.ws; r.ws_db[q] = p.ws_db; r.dw[q] = dw[q]; r.w[q] = w[q]; r.bias[q] = bias[q]; r.dscale[q] = dscale[q]; r.dbias[q] = dbias[q];
+        r.ksplit[q] = p.ksplit; r.Npad[q] = p.Npad;
+    }
+    m.first[n_gemm] = blocks;
+    for (int q = n_gemm; q < 3; ++q) { m.kind[q] = 0; m.first[q + 1] = blocks; }
+    hipStream_t s = as_stream(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  W2_NS * w2_slot_bytes<256>());
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_bf16_multi_kernel, dim3(blocks), dim3(W2_THREADS), W2_NS * w2_slot_bytes<256>(), s, m);
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(512 * n_gemm), dim3(kBlock), 0, s, r);
+    NFDP_CHECK_LAUNCH("coupling_wgrad3");
     return NFDP_OK;
 }
 

@@ -985,6 +985,50 @@ def conv_wgrad_affine(xh: torch.Tensor, dyh: torch.Tensor, weight: torch.Tensor,
           label=f"conv_wgrad_bf16_affine {cin}->{cout}", flops=2.0 * npix * cin * cout)
 
 
+def coupling_wgrad3(problems, accumulate: bool = True) -> None:
+    """The weight gradients of one flow's coupling network in one GEMM launch + one reduce launch (nfdp_coupling_wgrad3_bf16).
+    problems: 1..3 dicts with keys x (bf16 rows [..., Cin] or a BLOCKED 512-channel tensor when x_blocked), dy (BLOCKED [..., 512] bf16),
+    dw (fp32, dense), form / form_c (as conv_wgrad_affine), optional weight / bias / dscale / dbias (the layer's ActNorm: all or none),
+    x_blocked."""
+    n = len(problems)
+    if not 1 <= n <= 3:
+        raise ValueError("coupling_wgrad3: 1..3 problems")
+    npix = None
+    for pr in problems:
+        xh, dyh = pr["x"], pr["dy"]
+        _need(xh, torch.bfloat16, "coupling_wgrad3"); _need(dyh, torch.bfloat16, "coupling_wgrad3")
+        _dense(xh, "coupling_wgrad3"); _dense(dyh, "coupling_wgrad3")
+        if dyh.shape[-1] != 512:
+            raise ValueError("coupling_wgrad3: dy must have 512 channels")
+        cin = xh.shape[-1]
+        if npix is None:
+            npix = dyh.numel() // 512
+        if dyh.numel() // 512 != npix or xh.numel() // cin != npix:
+            raise ValueError(f"coupling_wgrad3: pixel counts differ ({tuple(xh.shape)} / {tuple(dyh.shape)})")
+        form, form_c = int(pr.get("form", 0)), int(pr.get("form_c", 0))
+        shape = {0: (512, cin, 1, 1), 1: (512, form_c, 3, 3), 2: (form_c, 512, 3, 3)}[form]
+        aff = [pr.get(k) for k in ("weight", "bias", "dscale", "dbias")]
+        if any(t is None for t in aff) != all(t is None for t in aff):
+            raise ValueError("coupling_wgrad3: weight / bias / dscale / dbias go together")
+        for t in [pr["dw"]] + [t for t in aff if t is not None]:
+            _need(t, torch.float32, "coupling_wgrad3"); _dense(t, "coupling_wgrad3")
+        if tuple(pr["dw"].shape) != shape or (aff[0] is not None and tuple(aff[0].shape) != shape):
+            raise ValueError(f"coupling_wgrad3: dw {tuple(pr['dw'].shape)}, expected {shape}")
+    ints = lambda vs: (ctypes.c_int * n)(*[int(v) for v in vs])
+    tab = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else _ptr(t) for t in ts])
+    cins = ints(pr["x"].shape[-1] for pr in problems)
+    nbytes = lib().nfdp_coupling_wgrad3_ws_bytes(npix, cins, n)
+    if nbytes == 0:
+        raise NfdpError(f"coupling_wgrad3: unsupported shapes (npix={npix}, cin={[pr['x'].shape[-1] for pr in problems]})")
+    ws = torch.empty(nbytes, device=problems[0]["x"].device, dtype=torch.uint8)
+    _call("nfdp_coupling_wgrad3_bf16", tab(pr["x"] for pr in problems), ints(pr["x"].shape[-1] for pr in problems),
+          ints(bool(pr.get("x_blocked", False)) for pr in problems), tab(pr["dy"] for pr in problems), cins,
+          tab(pr["dw"] for pr in problems), ints(pr.get("form", 0) for pr in problems), ints(pr.get("form_c", 0) for pr in problems),
+          tab(pr.get("weight") for pr in problems), tab(pr.get("bias") for pr in problems), tab(pr.get("dscale") for pr in problems),
+          tab(pr.get("dbias") for pr in problems), n, npix, _ptr(ws), int(accumulate), _stream(),
+          label=f"coupling_wgrad3 x{n}", flops=sum(2.0 * npix * 512 * pr["x"].shape[-1] for pr in problems))
+
+
 def conv_flip_weights(w_oihw: torch.Tensor) -> torch.Tensor:
     _need(w_oihw, torch.float32, "conv_flip_weights"); _dense(w_oihw, "conv_flip_weights")
     o, i, k, _ = w_oihw.shape

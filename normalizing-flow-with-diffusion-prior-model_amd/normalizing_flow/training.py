@@ -11,6 +11,7 @@ path"); autograd only strings them together.  What stays in torch is glue of par
 Layout: NHWC fp32 activations like the inference path, parameters in the reference's layouts; nothing is updated in
 place (autograd needs the inputs), so this path is selected only when gradients are required.
 """
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -589,6 +590,9 @@ FUSED_TRAIN_FORWARD = True          # bf16 mode, 32x32-model geometries: the lev
 
 
 FUSED_TRAIN_BACKWARD = True         # ... and the data-gradient chain of each coupling network one launch (nfdp_coupling_bwd_fused_bf16)
+# the three weight gradients of a coupling network as one GEMM launch + one reduce launch (nfdp_coupling_wgrad3_bf16); False: one
+# conv_wgrad_affine / conv_wgrad_blocked call per gradient (A/B measurements, tests)
+WGRAD_ONE_LAUNCH = os.environ.get("NFDP_WGRAD_ONE_LAUNCH", "1") != "0"
 
 
 def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net):
@@ -609,21 +613,35 @@ def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net):
     if net is not None:
         object.__setattr__(net, "_fused_bwd", packed)
     dc1, dc2, dc3_col = K.coupling_bwd_fused(dc3, dx, packed, y1, y2)
+    def problems(gw1, gb1, gs1, gw2, gb2, gs2, gw3):
+        # the three weight gradients as ONE GEMM launch + one reduce (coupling_wgrad3): the 512 x 512 one first, it takes longest
+        return [dict(x=y1, dy=dc2, dw=gw2, x_blocked=True, weight=w2.detach(), bias=b2.detach().reshape(-1), dscale=gs2.view(-1),
+                     dbias=gb2.view(-1)),
+                dict(x=xcol, dy=dc1, dw=gw1, form=1, form_c=i1, weight=w1.detach().contiguous(), bias=b1.detach().reshape(-1),
+                     dscale=gs1.view(-1), dbias=gb1.view(-1)),
+                dict(x=dc3_col, dy=y2, dw=gw3, form=2, form_c=co)]
     if direct:
-        gw1, gb1, gs1, gw2, gb2, gs2, gw3 = gs
-        _defer_side(lambda: K.conv_wgrad_blocked(dc3_col, y2, gw3, True, form=2, form_c=co, dy_blocked=True), dc3_col, y2)
-        _defer_side(lambda: K.conv_wgrad_affine(y1, dc2, w2.detach(), b2.detach().reshape(-1), gw2, gs2.view(-1), gb2.view(-1), True,
-                                                x_blocked=True, dy_blocked=True), y1, dc2)
-        _defer_side(lambda: K.conv_wgrad_affine(xcol, dc1, w1.detach(), b1.detach().reshape(-1), gw1, gs1.view(-1), gb1.view(-1), True,
-                                                form=1, form_c=i1, dy_blocked=True), xcol, dc1)
+        pr = problems(*gs)
+        if WGRAD_ONE_LAUNCH:
+            _defer_side(lambda: K.coupling_wgrad3(pr, True), dc3_col, y2, y1, dc2, xcol, dc1)
+        else:
+            gw1, gb1, gs1, gw2, gb2, gs2, gw3 = gs
+            _defer_side(lambda: K.conv_wgrad_blocked(dc3_col, y2, gw3, True, form=2, form_c=co, dy_blocked=True), dc3_col, y2)
+            _defer_side(lambda: K.conv_wgrad_affine(y1, dc2, w2.detach(), b2.detach().reshape(-1), gw2, gs2.view(-1), gb2.view(-1), True,
+                                                    x_blocked=True, dy_blocked=True), y1, dc2)
+            _defer_side(lambda: K.conv_wgrad_affine(xcol, dc1, w1.detach(), b1.detach().reshape(-1), gw1, gs1.view(-1), gb1.view(-1), True,
+                                                    form=1, form_c=i1, dy_blocked=True), xcol, dc1)
         return None
     dw3 = torch.empty_like(w3)
-    K.conv_wgrad_blocked(dc3_col, y2, dw3, False, form=2, form_c=co, dy_blocked=True)
     dw2, ds2, db2 = torch.empty_like(w2), torch.empty(hid, device=w2.device), torch.empty(hid, device=w2.device)
-    K.conv_wgrad_affine(y1, dc2, w2.detach(), b2.detach().reshape(-1), dw2, ds2, db2, False, x_blocked=True, dy_blocked=True)
     dw1, ds1, db1 = torch.empty_like(w1), torch.empty(o1, device=w1.device), torch.empty(o1, device=w1.device)
-    K.conv_wgrad_affine(xcol, dc1, w1.detach().contiguous(), b1.detach().reshape(-1), dw1, ds1, db1, False, form=1, form_c=i1,
-                        dy_blocked=True)
+    if WGRAD_ONE_LAUNCH:
+        K.coupling_wgrad3(problems(dw1, db1, ds1, dw2, db2, ds2, dw3), False)
+    else:
+        K.conv_wgrad_blocked(dc3_col, y2, dw3, False, form=2, form_c=co, dy_blocked=True)
+        K.conv_wgrad_affine(y1, dc2, w2.detach(), b2.detach().reshape(-1), dw2, ds2, db2, False, x_blocked=True, dy_blocked=True)
+        K.conv_wgrad_affine(xcol, dc1, w1.detach().contiguous(), b1.detach().reshape(-1), dw1, ds1, db1, False, form=1, form_c=i1,
+                            dy_blocked=True)
     return (dw1, db1.view_as(b1), ds1.view_as(s1), dw2, db2.view_as(b2), ds2.view_as(s2), dw3)
 
 

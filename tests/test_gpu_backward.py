@@ -796,6 +796,58 @@ def test_weight_gradient_gemm_with_actnorm_gradients(npix, cin, cout, form_c):
         assert_close(dw5, dw_want, 2e-3, "plain dW on blocked operands")
 
 
+@pytest.mark.parametrize("npix,c", [(2048, 12), (512, 48), (96, 24), (8192, 4)])
+def test_weight_gradients_of_a_flow_in_one_launch(npix, c):
+    """nfdp_coupling_wgrad3_bf16: the three weight gradients of a coupling network (512 x 512 on blocked operands with ActNorm
+    gradients, the input conv's on im2col rows with ActNorm gradients, the zero conv's in the transposed form) as one GEMM launch and
+    one reduce launch, against the per-gradient entry points on the same operands (different pixel slices: fp32 summation order
+    differs), store and accumulate modes, and with one or two problems only."""
+    bf = lambda t: t.to(torch.bfloat16)
+    ch = c // 2
+    k1, k3 = 16 * ((9 * ch + 15) // 16), 16 * ((9 * c + 15) // 16)
+    y1 = K.rows_to_blocked(bf(torch.relu(rnd(npix, 512, seed=1))).to(DEV))
+    y2 = K.rows_to_blocked(bf(torch.relu(rnd(npix, 512, seed=2))).to(DEV))
+    dc1 = K.rows_to_blocked(bf(rnd(npix, 512, seed=3)).to(DEV))
+    dc2 = K.rows_to_blocked(bf(rnd(npix, 512, seed=4)).to(DEV))
+    xcol = rnd(npix, k1, seed=5); xcol[:, 9 * ch:] = 0.0
+    dcol = rnd(npix, k3, seed=6); dcol[:, 9 * c:] = 0.0
+    xcol, dcol = bf(xcol).to(DEV), bf(dcol).to(DEV)
+    w1, b1 = rnd(512, ch, 3, 3, seed=7, scale=0.05).to(DEV), rnd(512, seed=8, scale=0.3).to(DEV)
+    w2, b2 = rnd(512, 512, 1, 1, seed=9, scale=0.05).to(DEV), rnd(512, seed=10, scale=0.3).to(DEV)
+    z = lambda *shape: torch.zeros(*shape, device=DEV)
+    # the per-gradient entry points
+    gw1, gs1, gb1, gw2, gs2, gb2, gw3 = z(512, ch, 3, 3), z(512), z(512), z(512, 512, 1, 1), z(512), z(512), z(c, 512, 3, 3)
+    K.conv_wgrad_affine(y1, dc2, w2, b2, gw2, gs2, gb2, False, x_blocked=True, dy_blocked=True)
+    K.conv_wgrad_affine(xcol, dc1, w1, b1, gw1, gs1, gb1, False, form=1, form_c=ch, dy_blocked=True)
+    K.conv_wgrad_blocked(dcol, y2, gw3, False, form=2, form_c=c, dy_blocked=True)
+
+    def problems(hw1, hs1, hb1, hw2, hs2, hb2, hw3):
+        return [dict(x=y1, dy=dc2, dw=hw2, x_blocked=True, weight=w2, bias=b2, dscale=hs2, dbias=hb2),
+                dict(x=xcol, dy=dc1, dw=hw1, form=1, form_c=ch, weight=w1, bias=b1, dscale=hs1, dbias=hb1),
+                dict(x=dcol, dy=y2, dw=hw3, form=2, form_c=c)]
+    out = [torch.full_like(t, 0.25) for t in (gw1, gs1, gb1, gw2, gs2, gb2, gw3)]
+    K.coupling_wgrad3(problems(*out), accumulate=True)
+    for got, want, what in zip(out, (gw1, gs1, gb1, gw2, gs2, gb2, gw3), ("dW1", "dscale1", "dbias1", "dW2", "dscale2", "dbias2", "dW3")):
+        assert_close(got - 0.25, want, 2e-4, f"{what} (accumulated)")
+    out2 = [torch.empty_like(t) for t in out]
+    K.coupling_wgrad3(problems(*out2), accumulate=False)
+    out3 = [torch.empty_like(t) for t in out]
+    K.coupling_wgrad3(problems(*out3), accumulate=False)
+    for a, b_, want in zip(out2, out3, (gw1, gs1, gb1, gw2, gs2, gb2, gw3)):
+        assert torch.equal(a, b_)                                               # fixed summation order: run-to-run identical
+        assert_close(a, want, 2e-4, "stored")
+    one = torch.empty_like(gw3)
+    K.coupling_wgrad3([dict(x=dcol, dy=y2, dw=one, form=2, form_c=c)], accumulate=False)
+    assert_close(one, gw3, 2e-4, "a single problem")
+    two = [torch.empty_like(gw2), torch.empty_like(gs2), torch.empty_like(gb2), torch.empty_like(gw3)]
+    K.coupling_wgrad3([dict(x=y1, dy=dc2, dw=two[0], x_blocked=True, weight=w2, bias=b2, dscale=two[1], dbias=two[2]),
+                       dict(x=dcol, dy=y2, dw=two[3], form=2, form_c=c)], accumulate=False)
+    for got, want in zip(two, (gw2, gs2, gb2, gw3)):
+        assert_close(got, want, 2e-4, "two problems")
+    with pytest.raises(Exception):
+        K.coupling_wgrad3([dict(x=xcol[:-1], dy=dc1, dw=gw1, form=1, form_c=ch)])
+
+
 @pytest.mark.parametrize("c,hw,B", [(12, 16, 3), (24, 8, 5), (48, 4, 21), (4, 16, 2), (16, 4, 7)])
 def test_flow_link_backward_kernel(c, hw, B):
     """nfdp_flow_link_bwd_f32 + nfdp_flow_link_finish_f32: flow head backwards + previous flow's coupling backwards + zero-conv scale
