@@ -226,16 +226,18 @@ int nfdp_coupling_bwd_fused_bf16(const float* dc3, float* dx, const void* packed
  *   coupling (ypost != NULL): on (ypost, hout = (log_s | t), dy, gl[b] = gradient of the per-sample log-det, optional):
  *                           dx_out = (dy_a | dy_b s),  dh = (ds s (1-s) | dy_b s) with ds = dy_b (x_b + t) + gl / (s + 1e-6),
  *                           dc3_out = dh e^{f3 logs3}            (no coupling: dx_out = dy)
- *   part ([ceil(npix/256)][4][C] fp64, nfdp_flow_link_bwd_part_bytes): per-workgroup sums of da a, da e^scale, dh hout, dc3.
+ *   part (nfdp_flow_link_bwd_part_bytes: [ceil(npix/256)][4][C] fp64, then [ceil(npix/256)][C*C] fp32): per-workgroup sums of da a,
+ *                           da e^scale, dh hout, dc3 and - head calls - the workgroup's partial of the 1x1 conv's weight gradient
+ *                           dW[k][c] = sum_p dx_in[p][k] a[p][c] (transforms.py:132; exact-fp32 MFMA).
  * nfdp_flow_link_finish_f32 reduces the partials of n_calls calls (laid out back to back) in one launch: for call k
- * dscale[k] (+)= sum da a,  dbias[k] (+)= sum da e^scale,  dlogs3[k] (+)= f3 sum dh hout,  dbias3[k] (+)= sum dc3  (HOST arrays of
- * n_calls device pointers, entries may be NULL).  C in {4, 8, 12, 16, 24, 48}; n_calls <= 33. */
+ * dscale[k] (+)= sum da a,  dbias[k] (+)= sum da e^scale,  dlogs3[k] (+)= f3 sum dh hout,  dbias3[k] (+)= sum dc3,  dw[k] ([C][C]) (+)= dW
+ * (HOST arrays of n_calls device pointers, entries may be NULL).  C in {4, 8, 12, 16, 24, 48}; n_calls <= 33. */
 size_t nfdp_flow_link_bwd_part_bytes(long npix, int C);
 int nfdp_flow_link_bwd_f32(const float* dx_in, const float* xpre, const float* w, const float* scale, const float* bias, float* a_out,
                            const float* ypost, const float* hout, const double* gl, const float* logs3, float f3, float* dx_out,
                            float* dc3_out, void* part, long npix, int HW, int C, nfdp_stream_t stream);
 int nfdp_flow_link_finish_f32(const void* part, int n_calls, long npix, int C, float f3, float* const* dscale, float* const* dbias,
-                              float* const* dlogs3, float* const* dbias3, int accumulate, nfdp_stream_t stream);
+                              float* const* dlogs3, float* const* dbias3, float* const* dw, int accumulate, nfdp_stream_t stream);
 /* ldj[b] += (double)(hw * (float)sum(v[0..n_sum)))  (fp32 product): the standalone ActNorm / InvConv2d log-det terms. */
 int nfdp_ldj_add_scaled_f32(double* ldj, int B, const float* v, int n_sum, float hw, nfdp_stream_t stream);
 /* out2[0] = hw*sum(scale[0..C)) (transforms.py:81), out2[1] = hw*logabsdet[0] (transforms.py:131), fp32: the two

@@ -553,6 +553,7 @@ struct LinkParams {
     const float* ypost; const float* hout; const double* gl; const float* logs3; float f3;
     float* dx_out; float* dc3_out; double* part;
     long npix; int HW;
+    float* part_w;       // [blocks][C*C] fp32: per-workgroup partial of the 1x1 conv's weight gradient (head calls), or null
 };
 
 template <int C>
@@ -560,7 +561,9 @@ __global__ void __launch_bounds__(kBlock) flow_link_bwd_kernel(const LinkParams 
     constexpr int Ch = C / 2, TS = C + 1;
     __shared__ __attribute__((aligned(16))) float wt_s[C * C];
     __shared__ float es_s[C], bs_s[C], fac_s[C];
-    __shared__ float tile[kBlock * TS];
+    extern __shared__ __attribute__((aligned(16))) float link_dyn[];       // tile [256][C+1] | tile2 [256][C+1] (ActNorm output rows)
+    float* tile = link_dyn;
+    float* tile2 = link_dyn + kBlock * TS;
     const int tid = threadIdx.x;
     const long px = (long)blockIdx.x * kBlock + tid;
     const bool live = px < p.npix;
@@ -623,8 +626,56 @@ __global__ void __launch_bounds__(kBlock) flow_link_bwd_kernel(const LinkParams 
                 av[j] = __fmul_rn(es, __fadd_rn(xs[j], bs_s[c + j]));
                 dy[c + j] = __fmul_rn(da[c + j], es);
                 q0[c + j] = __fmul_rn(da[c + j], av[j]);
+                tile2[tid * TS + c + j] = av[j];
             }
             if (live && p.a_out) *reinterpret_cast<float4*>(p.a_out + px * C + c) = make_float4(av[0], av[1], av[2], av[3]);
+        }
+        if (p.part_w) {
+            // The 1x1 conv's weight gradient dW[k][c] = sum_p dx_in[p][k] a[p][c] (transforms.py:132) of this workgroup's 256 pixels on
+            // the exact-fp32 matrix cores: both row sets are in LDS (tile: dx_in, zero rows for absent pixels; tile2: a), a wave takes
+            // 64 pixels, 2 per v_mfma_f32_32x32x2_f32 (lane = channel, lane half = pixel: consecutive LDS words per half-wave).  The
+            // four wave partials are summed through LDS; nfdp_flow_link_finish_f32 sums the workgroups in fp64.  (Before: a separate
+            // split-K GEMM + reduce per flow on the side stream, 96 launches and 2.2 ms of kernel time per step.)
+            constexpr int MT = (C + 31) / 32;
+            __syncthreads();
+            const int lane = tid & 63, wave = tid >> 6, m0 = lane & 31, kk = lane >> 5;
+            f32x16 accw[MT][MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accw[i][j][r] = 0.f;
+#pragma unroll 4
+            for (int st = 0; st < 32; ++st) {
+                const int prow = (64 * wave + 2 * st + kk) * TS;
+                float av_[MT], bv_[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+                    const int chn = 32 * i + m0;
+                    av_[i] = chn < C ? tile[prow + chn] : 0.f;
+                    bv_[i] = chn < C ? tile2[prow + chn] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], accw[i][j], 0, 0, 0);
+            }
+            __syncthreads();                                       // every wave is done reading the two tiles
+            float* redw = tile;                                    // [4 waves][C*C] (fits: 4 C^2 <= 256 (C+1) for C <= 48)
+            static_assert(4 * C * C <= 2 * kBlock * TS, "wave partials alias the tiles");
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 32 * i + drow32(r, kk), col = 32 * j + m0;
+                        if (row < C && col < C) redw[wave * C * C + row * C + col] = accw[i][j][r];
+                    }
+            __syncthreads();
+            float* pw = p.part_w + (size_t)blockIdx.x * C * C;
+            for (int e = tid; e < C * C; e += kBlock) pw[e] = (redw[e] + redw[C * C + e]) + (redw[2 * C * C + e] + redw[3 * C * C + e]);
         }
         colsum(0, q0);
         colsum(1, dy);
@@ -696,14 +747,36 @@ __global__ void __launch_bounds__(kBlock) flow_link_bwd_kernel(const LinkParams 
 constexpr int kMaxLinkCalls = 33;
 struct LinkFinish {
     float* dscale[kMaxLinkCalls]; float* dbias[kMaxLinkCalls]; float* dlogs3[kMaxLinkCalls]; float* dbias3[kMaxLinkCalls];
+    float* dw[kMaxLinkCalls];
     int n, nblk, C, acc; float f3;
+    long call_doubles;   // doubles between the partial buffers of consecutive calls
+    int wblocks;         // workgroups per call for the 1x1 conv's weight gradient: ceil(C*C / 64)
 };
 __global__ void __launch_bounds__(kBlock) flow_link_finish_kernel(const double* __restrict__ part, const LinkFinish f) {
     __shared__ double red[kBlock];
-    const int call = blockIdx.x / 4, q = blockIdx.x % 4, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= 4 * f.n) {
+        // dW[e] (+)= sum over the workgroups' fp32 partials (behind the call's fp64 column sums), 64 elements x 4 groups per workgroup
+        const int wb = blockIdx.x - 4 * f.n, call = wb / f.wblocks, e = (wb % f.wblocks) * 64 + (tid & 63), g = tid >> 6;
+        float* dst = f.dw[call];
+        if (dst == nullptr) return;
+        const float* src = reinterpret_cast<const float*>(part + (size_t)call * f.call_doubles + (size_t)f.nblk * 4 * f.C);
+        const int cc = f.C * f.C;
+        double sum = 0.0;
+        if (e < cc)
+            for (int b = g; b < f.nblk; b += 4) sum += (double)src[(size_t)b * cc + e];
+        red[tid] = sum;
+        __syncthreads();
+        if (g == 0 && e < cc) {
+            const float v = (float)((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
+            dst[e] = f.acc ? dst[e] + v : v;
+        }
+        return;
+    }
+    const int call = blockIdx.x / 4, q = blockIdx.x % 4;
     float* dst = q == 0 ? f.dscale[call] : (q == 1 ? f.dbias[call] : (q == 2 ? f.dlogs3[call] : f.dbias3[call]));
     if (dst == nullptr) return;
-    const double* src = part + ((size_t)call * f.nblk * 4 + q) * f.C;
+    const double* src = part + (size_t)call * f.call_doubles + (size_t)q * f.C;
     const int G = kBlock / 64;                              // 4 groups of 64 threads: channel = tid % 64, blocks g, g+4, ...
     const int c = tid & 63, g = tid >> 6;
     double sum = 0.0;
@@ -719,7 +792,22 @@ __global__ void __launch_bounds__(kBlock) flow_link_finish_kernel(const double* 
     }
 }
 
-extern "C" size_t nfdp_flow_link_bwd_part_bytes(long npix, int C) { return (size_t)cdiv(npix, kBlock) * 4 * C * sizeof(double); }
+// per call: [blocks][4][C] fp64 column sums, then [blocks][C*C] fp32 partials of the 1x1 conv's weight gradient (rounded up to 8 bytes)
+template <int C>
+static void launch_flow_link(dim3 grid, hipStream_t s, const LinkParams& p) {
+    constexpr int kDyn = 2 * kBlock * (C + 1) * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_link_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(flow_link_bwd_kernel<C>, grid, dim3(kBlock), kDyn, s, p);
+}
+
+extern "C" size_t nfdp_flow_link_bwd_part_bytes(long npix, int C) {
+    const size_t nblk = (size_t)cdiv(npix, kBlock);
+    return nblk * 4 * C * sizeof(double) + ((nblk * C * C * sizeof(float) + 7) & ~(size_t)7);
+}
 
 extern "C" int nfdp_flow_link_bwd_f32(const float* dx_in, const float* xpre, const float* wt, const float* scale, const float* bias,
                                       float* a_out, const float* ypost, const float* hout, const double* gl, const float* logs3, float f3,
@@ -732,16 +820,18 @@ extern "C" int nfdp_flow_link_bwd_f32(const float* dx_in, const float* xpre, con
     NFDP_REQUIRE((((uintptr_t)dx_in | (uintptr_t)xpre | (uintptr_t)a_out | (uintptr_t)ypost | (uintptr_t)hout | (uintptr_t)dx_out |
                    (uintptr_t)dc3_out) & 15) == 0, NFDP_ESHAPE, "flow_link_bwd: tensors must be 16-byte aligned");
     if (npix == 0) return NFDP_OK;
-    LinkParams p{dx_in, xpre, wt, scale, bias, a_out, ypost, hout, gl, logs3, f3, dx_out, dc3_out, reinterpret_cast<double*>(part), npix, HW};
+    LinkParams p{dx_in, xpre, wt, scale, bias, a_out, ypost, hout, gl, logs3, f3, dx_out, dc3_out, reinterpret_cast<double*>(part), npix, HW,
+                 nullptr};
     const dim3 grid((unsigned)cdiv(npix, kBlock));
+    if (xpre) p.part_w = reinterpret_cast<float*>(p.part + (size_t)grid.x * 4 * C);
     hipStream_t s = as_stream(stream);
     switch (C) {
-        case 4: hipLaunchKernelGGL(flow_link_bwd_kernel<4>, grid, dim3(kBlock), 0, s, p); break;
-        case 8: hipLaunchKernelGGL(flow_link_bwd_kernel<8>, grid, dim3(kBlock), 0, s, p); break;
-        case 16: hipLaunchKernelGGL(flow_link_bwd_kernel<16>, grid, dim3(kBlock), 0, s, p); break;
-        case 12: hipLaunchKernelGGL(flow_link_bwd_kernel<12>, grid, dim3(kBlock), 0, s, p); break;
-        case 24: hipLaunchKernelGGL(flow_link_bwd_kernel<24>, grid, dim3(kBlock), 0, s, p); break;
-        case 48: hipLaunchKernelGGL(flow_link_bwd_kernel<48>, grid, dim3(kBlock), 0, s, p); break;
+        case 4: launch_flow_link<4>(grid, s, p); break;
+        case 8: launch_flow_link<8>(grid, s, p); break;
+        case 16: launch_flow_link<16>(grid, s, p); break;
+        case 12: launch_flow_link<12>(grid, s, p); break;
+        case 24: launch_flow_link<24>(grid, s, p); break;
+        case 48: launch_flow_link<48>(grid, s, p); break;
         default: nfdp_set_error("flow_link_bwd: unsupported C=%d", C); return NFDP_EUNSUPPORTED;
     }
     NFDP_CHECK_LAUNCH("flow_link_bwd");
@@ -749,15 +839,22 @@ extern "C" int nfdp_flow_link_bwd_f32(const float* dx_in, const float* xpre, con
 }
 
 extern "C" int nfdp_flow_link_finish_f32(const void* part, int n_calls, long npix, int C, float f3, float* const* dscale,
-                                         float* const* dbias, float* const* dlogs3, float* const* dbias3, int accumulate,
-                                         nfdp_stream_t stream) {
-    NFDP_REQUIRE(part && dscale && dbias && dlogs3 && dbias3, NFDP_EINVAL, "flow_link_finish: null pointer");
+                                         float* const* dbias, float* const* dlogs3, float* const* dbias3, float* const* dw,
+                                         int accumulate, nfdp_stream_t stream) {
+    NFDP_REQUIRE(part && dscale && dbias && dlogs3 && dbias3 && dw, NFDP_EINVAL, "flow_link_finish: null pointer");
     NFDP_REQUIRE(n_calls >= 0 && n_calls <= kMaxLinkCalls && C > 0 && C <= 64 && npix >= 0, NFDP_ESHAPE, "flow_link_finish: bad shape");
     if (n_calls == 0 || npix == 0) return NFDP_OK;
     LinkFinish f;
-    for (int i = 0; i < n_calls; ++i) { f.dscale[i] = dscale[i]; f.dbias[i] = dbias[i]; f.dlogs3[i] = dlogs3[i]; f.dbias3[i] = dbias3[i]; }
+    bool any_dw = false;
+    for (int i = 0; i < n_calls; ++i) {
+        f.dscale[i] = dscale[i]; f.dbias[i] = dbias[i]; f.dlogs3[i] = dlogs3[i]; f.dbias3[i] = dbias3[i]; f.dw[i] = dw[i];
+        any_dw = any_dw || dw[i] != nullptr;
+    }
     f.n = n_calls; f.nblk = (int)cdiv(npix, kBlock); f.C = C; f.acc = accumulate; f.f3 = f3;
-    hipLaunchKernelGGL(flow_link_finish_kernel, dim3(4 * n_calls), dim3(kBlock), 0, as_stream(stream), reinterpret_cast<const double*>(part), f);
+    f.call_doubles = (long)(nfdp_flow_link_bwd_part_bytes(npix, C) / sizeof(double));
+    f.wblocks = (C * C + 63) / 64;
+    hipLaunchKernelGGL(flow_link_finish_kernel, dim3(4 * n_calls + (any_dw ? n_calls * f.wblocks : 0)), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const double*>(part), f);
     NFDP_CHECK_LAUNCH("flow_link_finish");
     return NFDP_OK;
 }

@@ -1116,15 +1116,25 @@ def flow_link_bwd(dx_in: torch.Tensor, part: torch.Tensor, *, head=None, couplin
 
 
 def flow_link_part(n_calls: int, npix: int, c: int, device) -> torch.Tensor:
-    """fp64 partial buffer for n_calls flow_link_bwd launches of a level: [n_calls, blocks, 4, C]."""
+    """Partial buffer for n_calls flow_link_bwd launches of a level: per call [blocks, 4, C] fp64 + [blocks, C*C] fp32."""
     per = lib().nfdp_flow_link_bwd_part_bytes(npix, c) // 8
     return torch.empty((n_calls, per), device=device, dtype=torch.float64)
 
 
-def flow_link_finish(part: torch.Tensor, npix: int, c: int, f3: float, dscale, dbias, dlogs3, dbias3, accumulate: bool) -> None:
-    """Reduce the partials of all link calls of a level in one launch; the four lists hold one fp32 [C] tensor or None per call."""
+def flow_link_finish(part: torch.Tensor, npix: int, c: int, f3: float, dscale, dbias, dlogs3, dbias3, accumulate: bool, dw=None) -> None:
+    """Reduce the partials of all link calls of a level in one launch; the four lists hold one fp32 [C] tensor or None per call, dw one
+    dense fp32 tensor of C*C elements (the 1x1 conv's weight gradient of the call's head) or None."""
     n = part.shape[0]
     tab = lambda ts: (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in ts])
+    if dw is None:
+        dw = [None] * n
+    if len(dw) != n:
+        raise ValueError("flow_link_finish: one entry per call")
+    for t in dw:
+        if t is not None:
+            _need(t, torch.float32, "flow_link_finish"); _dense(t, "flow_link_finish")
+            if t.numel() != c * c:
+                raise ValueError("flow_link_finish: dw entries are [C, C]")
     for ts in (dscale, dbias, dlogs3, dbias3):
         if len(ts) != n:
             raise ValueError("flow_link_finish: one entry per call")
@@ -1133,7 +1143,7 @@ def flow_link_finish(part: torch.Tensor, npix: int, c: int, f3: float, dscale, d
                 _need(t, torch.float32, "flow_link_finish"); _dense(t, "flow_link_finish")
                 if t.numel() != c:
                     raise ValueError("flow_link_finish: outputs are [C]")
-    _call("nfdp_flow_link_finish_f32", _ptr(part), n, npix, c, float(f3), tab(dscale), tab(dbias), tab(dlogs3), tab(dbias3),
+    _call("nfdp_flow_link_finish_f32", _ptr(part), n, npix, c, float(f3), tab(dscale), tab(dbias), tab(dlogs3), tab(dbias3), tab(dw),
           int(accumulate), _stream(), label="flow_link_finish")
 
 

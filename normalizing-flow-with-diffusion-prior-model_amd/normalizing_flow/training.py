@@ -703,16 +703,9 @@ class LevelFusedFn(Function):
             g9 = _net_backward_fused(dc3, dx, xcol[i], y1[i], y2[i], net, ctx.nets[i])          # dx[..., :c/2] += network input gradient
             head = (xpre[i], weight.detach().reshape(c, c), scale.detach().reshape(-1), bias.detach().reshape(-1))
             cpl = (ypost[i - 1], hout[i - 1], gl, l3(i - 1), f3) if i > 0 else None
-            dx_next, dc3, a = K.flow_link_bwd(dx, part[n - i], head=head, coupling=cpl)
-            # 1x1 conv weight gradient dW = sum_p dx (x) a  (transforms.py:132), off the critical path
-            gw = _slots(weight)
-            if gw is not None and weight.dim() == 4:
-                _defer_side(lambda a=a, dx=dx, g=gw[0]: K.conv_wgrad(a, dx, 1, out=g, accumulate=True), a, dx)
-                dw = None
-            else:
-                dw = K.conv_wgrad(a, dx, 1).view_as(weight)
-            _flush_side()                                            # one fork per flow: its four weight gradients
-            grads[P * i + 2] = dw
+            # (the 1x1 conv's weight gradient dW = sum_p dx (x) a, transforms.py:132, is left in the call's partial buffer too)
+            dx_next, dc3, _ = K.flow_link_bwd(dx, part[n - i], head=head, coupling=cpl, want_a=False)
+            _flush_side()                                            # one fork per flow: the coupling network's weight gradients
             if g9 is not None:
                 grads[P * i + 3: P * i + 10] = list(g9)
             dx = dx_next
@@ -721,7 +714,8 @@ class LevelFusedFn(Function):
         for k in range(n + 1):
             hf, cf = n - k, n - 1 - k
             small.append(((params[P * hf], params[P * hf + 1]) if k >= 1 else (None, None)) +
-                         ((params[P * cf + 11], params[P * cf + 10]) if cf >= 0 else (None, None)))
+                         ((params[P * cf + 11], params[P * cf + 10]) if cf >= 0 else (None, None)) +
+                         ((params[P * hf + 2],) if k >= 1 else (None,)))
         flat = [t for tup in small for t in tup if t is not None]
         gs = _slots(*flat)
         if gs is not None:
@@ -731,12 +725,14 @@ class LevelFusedFn(Function):
         else:
             outs = [[None if t is None else torch.empty(t.numel(), device=t.device, dtype=torch.float32) for t in tup] for tup in small]
             acc = False
-        K.flow_link_finish(part, npix, c, f3, [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs], acc)
+        K.flow_link_finish(part, npix, c, f3, [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs], acc,
+                           dw=[o[4] for o in outs])
         if not acc:
             for k, (tup, o) in enumerate(zip(small, outs)):
                 hf, cf = n - k, n - 1 - k
                 if k >= 1:
                     grads[P * hf], grads[P * hf + 1] = o[0].view_as(tup[0]), o[1].view_as(tup[1])
+                    grads[P * hf + 2] = o[4].view_as(tup[4])
                 if cf >= 0:
                     grads[P * cf + 11], grads[P * cf + 10] = o[2].view_as(tup[2]), o[3].view_as(tup[3])
         _join_side()

@@ -887,3 +887,12 @@ def test_flow_link_backward_kernel(c, hw, B):
     acc = [z(1.0), z(2.0)]
     K.flow_link_finish(part, npix, c, f3, [None, acc[0], None], [None, None, None], [None, None, None], [None, acc[1], None], accumulate=True)
     assert_close(acc[0] - 1.0, dscale, 2e-5, "accumulated dscale"); assert_close(acc[1] - 2.0, db3, 2e-5, "accumulated dbias3")
+    # the 1x1 conv's weight gradient dW[k][c] = sum_p dx_in[p][k] a[p][c] (transforms.py:132) out of the head calls' partial buffers
+    dw_ref = (dx_in.reshape(npix, c).double().t() @ a.reshape(npix, c).double()).float()
+    dws = [None, torch.empty(c, c, 1, 1, device=DEV), torch.full((c, c), 0.5, device=DEV)]
+    none3 = [None, None, None]
+    K.flow_link_finish(part, npix, c, f3, none3, none3, none3, none3, accumulate=False, dw=[None, dws[1], None])
+    K.flow_link_finish(part, npix, c, f3, none3, none3, none3, none3, accumulate=True, dw=[None, None, dws[2]])
+    assert_close(dws[1].view(c, c), dw_ref, 1e-5, "1x1 conv dW (both)")
+    assert_close(dws[2] - 0.5, dw_ref, 1e-5, "1x1 conv dW (head only, accumulated)")
+    assert_close(K.conv_wgrad(a, dx_in, 1).view(c, c), dw_ref, 1e-5, "the split-K GEMM it replaces")
