@@ -280,6 +280,11 @@ int nfdp_linear_f32(const float* in, const float* w, const float* bias, float* o
                     int post_act, nfdp_stream_t stream);
 /* SinusoidalPosEmb.forward :231-237; t is int64 [B]. */
 int nfdp_sinusoidal_emb_f32(const long* t, float* out, int B, int dim, nfdp_stream_t stream);
+/* RandomOrLearnedSinusoidalPosEmb.forward (gaussian_diffusion.py:240-255): out [B][2*half + 1] = [t | sin(2 pi t w_j) | cos(2 pi t w_j)],
+ * w [half] the module's `weights`; _bwd: dw[j] (+)= d loss / d w_j from dout [B][2*half + 1] (learned variant; the random one is frozen). */
+int nfdp_learned_sinusoidal_emb_f32(const long* t, const float* w, float* out, int B, int half, nfdp_stream_t stream);
+int nfdp_learned_sinusoidal_bwd_f32(const long* t, const float* w, const float* dout, float* dw, int B, int half, int accumulate,
+                                    nfdp_stream_t stream);
 /* LinearAttention.forward :320-332 between to_qkv and to_out; qkv [B][n][3*heads*32] -> out [B][n][heads*32]. */
 int nfdp_linear_attention_f32(const float* qkv, float* out, int B, int n, int heads, int dim_head, float scale,
                               nfdp_stream_t stream);

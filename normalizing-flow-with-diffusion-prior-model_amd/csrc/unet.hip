@@ -345,6 +345,34 @@ __global__ void sinusoidal_kernel(const long* __restrict__ t, float* __restrict_
     out[(long)b * dim + half + j] = cosf(a);
 }
 
+// random / learned sinusoidal embedding (RandomOrLearnedSinusoidalPosEmb, :240-255): out[b] = [t | sin(a_j) | cos(a_j)] with
+// a_j = ((t w_j) 2) pi in fp32 (the reference's `x * weights * 2 * math.pi`, left to right), row length 2*half + 1
+__global__ void learned_sinusoidal_kernel(const long* __restrict__ t, const float* __restrict__ w, float* __restrict__ out, int B, int half) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= B * half) return;
+    const int b = idx / half, j = idx % half;
+    const float tv = (float)t[b];
+    const float a = __fmul_rn(__fmul_rn(__fmul_rn(tv, w[j]), 2.0f), 3.14159265358979323846f);
+    float* row = out + (long)b * (2 * half + 1);
+    if (j == 0) row[0] = tv;
+    row[1 + j] = sinf(a);
+    row[1 + half + j] = cosf(a);
+}
+// its weight gradient: dw[j] (+)= sum_b 2 pi t_b (g_sin[b][j] cos a - g_cos[b][j] sin a); one thread per frequency, samples in order
+__global__ void learned_sinusoidal_bwd_kernel(const long* __restrict__ t, const float* __restrict__ w, const float* __restrict__ dout,
+                                              float* __restrict__ dw, int B, int half, int accumulate) {
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= half) return;
+    double sum = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float tv = (float)t[b];
+        const float a = __fmul_rn(__fmul_rn(__fmul_rn(tv, w[j]), 2.0f), 3.14159265358979323846f);
+        const float* g = dout + (long)b * (2 * half + 1);
+        sum += (double)(g[1 + j] * cosf(a) - g[1 + half + j] * sinf(a)) * (double)tv * 6.283185307179586;
+    }
+    dw[j] = accumulate ? dw[j] + (float)sum : (float)sum;
+}
+
 // ----------------------------------------------------------------------------- linear attention core (:320-332)
 // qkv: [B][n][3*H*32] (q | k | v, head-major inside each third); out: [B][n][H*32].  One workgroup per (b, head):
 //   q <- softmax_d(q) * scale,  k <- softmax_n(k),  v <- v/n,  ctx[d][e] = sum_n k[d][n] v[e][n],
@@ -921,6 +949,26 @@ extern "C" int nfdp_linear_f32(const float* in, const float* w, const float* bia
     hipLaunchKernelGGL(linear_kernel, dim3((int)cdiv(O, LIN_TO), (int)cdiv(B, LIN_TB)), dim3(kBlock), lds, as_stream(stream), in, w,
                        bias, out, B, I, O, O, pre_act, post_act);
     NFDP_CHECK_LAUNCH("linear");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_learned_sinusoidal_emb_f32(const long* t, const float* w, float* out, int B, int half, nfdp_stream_t stream) {
+    NFDP_REQUIRE(t && w && out, NFDP_EINVAL, "learned_sinusoidal_emb: null pointer");
+    NFDP_REQUIRE(B >= 0 && half >= 1, NFDP_ESHAPE, "learned_sinusoidal_emb: bad shape");
+    if (B == 0) return NFDP_OK;
+    hipLaunchKernelGGL(learned_sinusoidal_kernel, dim3((int)cdiv((long)B * half, kBlock)), dim3(kBlock), 0, as_stream(stream), t, w, out, B,
+                       half);
+    NFDP_CHECK_LAUNCH("learned_sinusoidal_emb");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_learned_sinusoidal_bwd_f32(const long* t, const float* w, const float* dout, float* dw, int B, int half,
+                                               int accumulate, nfdp_stream_t stream) {
+    NFDP_REQUIRE(t && w && dout && dw, NFDP_EINVAL, "learned_sinusoidal_bwd: null pointer");
+    NFDP_REQUIRE(B >= 0 && half >= 1, NFDP_ESHAPE, "learned_sinusoidal_bwd: bad shape");
+    hipLaunchKernelGGL(learned_sinusoidal_bwd_kernel, dim3((int)cdiv((long)half, kBlock)), dim3(kBlock), 0, as_stream(stream), t, w, dout, dw,
+                       B, half, accumulate);
+    NFDP_CHECK_LAUNCH("learned_sinusoidal_bwd");
     return NFDP_OK;
 }
 

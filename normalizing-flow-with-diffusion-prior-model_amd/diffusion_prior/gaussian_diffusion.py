@@ -11,8 +11,8 @@ reverse-diffusion step with on-device schedule lookup are one launch each).  All
 `p_losses` run the differentiable path of diffusion_prior/training.py (autograd Functions over HIP forward/backward kernels).
 
 All three objectives ('pred_noise', 'pred_x0', 'pred_v'), self-conditioning and auto_normalize are built (the captured-graph loops
-serve the plain case - every recipe of the reference - and the eager loops the self-conditioned one).  Not built (raise
-NotImplementedError): learned / random sinusoidal embeddings, which the reference's GaussianDiffusion itself rejects (:559).
+serve the plain case - every recipe of the reference - and the eager loops the self-conditioned one).  The U-Net also takes the
+learned / random sinusoidal time embeddings (:240-255); GaussianDiffusion rejects such a U-Net exactly as the reference does (:559).
 """
 import math
 from random import random as _random
@@ -154,6 +154,18 @@ class SinusoidalPosEmb(nn.Module):
         self.dim = dim
 
 
+class RandomOrLearnedSinusoidalPosEmb(nn.Module):
+    """[t | sin(2 pi t w) | cos(2 pi t w)] with random (frozen) or learned frequencies w  (reference :240-255; same parameter name)."""
+
+    def __init__(self, dim, is_random=False):
+        super().__init__()
+        assert (dim % 2) == 0
+        self.weights = nn.Parameter(torch.randn(dim // 2), requires_grad=not is_random)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return K.learned_sinusoidal_emb(x.long(), self.weights.detach())
+
+
 class Block(nn.Module):
     """WS-conv3x3 -> GroupNorm -> x*(scale+1)+shift -> SiLU  (reference :260-276)."""
 
@@ -233,9 +245,6 @@ class Unet(_EpochOnApply, nn.Module):
                  resnet_block_groups=8, learned_variance=False, learned_sinusoidal_cond=False,
                  random_fourier_features=False, learned_sinusoidal_dim=16, compute: Optional[str] = None):
         super().__init__()
-        if learned_sinusoidal_cond or random_fourier_features:
-            raise NotImplementedError("learned / random sinusoidal embeddings are not built (the reference's GaussianDiffusion rejects "
-                                      "such a U-Net, gaussian_diffusion.py:559)")
         self.compute = compute
         self.dim = dim
         self.channels = channels
@@ -247,8 +256,12 @@ class Unet(_EpochOnApply, nn.Module):
         in_out = list(zip(dims[:-1], dims[1:]))
         block_klass = partial(ResnetBlock, groups=resnet_block_groups)
         time_dim = dim * 4
-        self.random_or_learned_sinusoidal_cond = False
-        self.time_mlp = nn.Sequential(SinusoidalPosEmb(dim), _Linear(dim, time_dim), _Marker("gelu"), _Linear(time_dim, time_dim))
+        self.random_or_learned_sinusoidal_cond = learned_sinusoidal_cond or random_fourier_features
+        if self.random_or_learned_sinusoidal_cond:                           # (reference :398-405)
+            sinu_pos_emb, fourier_dim = RandomOrLearnedSinusoidalPosEmb(learned_sinusoidal_dim, random_fourier_features), learned_sinusoidal_dim + 1
+        else:
+            sinu_pos_emb, fourier_dim = SinusoidalPosEmb(dim), dim
+        self.time_mlp = nn.Sequential(sinu_pos_emb, _Linear(fourier_dim, time_dim), _Marker("gelu"), _Linear(time_dim, time_dim))
         self.downs = nn.ModuleList([])
         self.ups = nn.ModuleList([])
         num_resolutions = len(in_out)
@@ -280,7 +293,10 @@ class Unet(_EpochOnApply, nn.Module):
     def time_embedding(self, time: Tensor, silu_out: bool = False) -> Tensor:
         """sinusoidal -> Linear -> GELU -> Linear  (reference :407-412); silu_out additionally applies the SiLU every
         ResnetBlock.mlp starts with (:282-283), once for all of them."""
-        e = K.sinusoidal_emb(time.long(), self.dim)
+        if self.random_or_learned_sinusoidal_cond:
+            e = K.learned_sinusoidal_emb(time.long(), self.time_mlp[0].weights.detach())
+        else:
+            e = K.sinusoidal_emb(time.long(), self.dim)
         e = K.linear(e, self.time_mlp[1].weight, self.time_mlp[1].bias, post_act=1)
         return K.linear(e, self.time_mlp[3].weight, self.time_mlp[3].bias, post_act=2 if silu_out else 0)
 

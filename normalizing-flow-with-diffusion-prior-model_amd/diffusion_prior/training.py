@@ -199,6 +199,22 @@ def _conv(mod, xh: Tensor, c: int = K.F32) -> Tensor:
     return ConvFn.apply(xh, w, mod.bias, mod.k, c)
 
 
+class LearnedSinusoidalFn(Function):
+    """RandomOrLearnedSinusoidalPosEmb (reference :240-255) with the gradient of its learned frequencies."""
+
+    @staticmethod
+    def forward(ctx, weights, time):
+        ctx.save_for_backward(weights, time)
+        return K.learned_sinusoidal_emb(time, weights.detach())
+
+    @staticmethod
+    def backward(ctx, dout):
+        weights, time = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None
+        return K.learned_sinusoidal_bwd(time, weights.detach(), dout.contiguous()), None
+
+
 def _linear(mod, x: Tensor) -> Tensor:
     """nn.Linear on [B, I] as a 1x1 convolution of a [B,1,1,I] image (same kernels, same gradients)."""
     b = x.shape[0]
@@ -241,7 +257,10 @@ def unet_forward(unet, xh: Tensor, time: Tensor, x_self_cond_h: Optional[Tensor]
         xh = ConcatFn.apply(sc.contiguous(), xh.contiguous())
     x = _conv(unet.init_conv, xh, c)
     r = x
-    e = K.sinusoidal_emb(time.long(), unet.dim)
+    if unet.random_or_learned_sinusoidal_cond:
+        e = LearnedSinusoidalFn.apply(unet.time_mlp[0].weights, time.long())
+    else:
+        e = K.sinusoidal_emb(time.long(), unet.dim)
     e = ActFn.apply(_linear(unet.time_mlp[1], e), K.GELU)
     t_act = ActFn.apply(_linear(unet.time_mlp[3], e), K.SILU)            # the SiLU every ResnetBlock.mlp starts with
     hs = []

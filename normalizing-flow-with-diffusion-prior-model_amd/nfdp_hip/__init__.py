@@ -732,6 +732,29 @@ def sinusoidal_emb(t: torch.Tensor, dim: int) -> torch.Tensor:
     return out
 
 
+def learned_sinusoidal_emb(t: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    """RandomOrLearnedSinusoidalPosEmb.forward: t int64 [B], weights fp32 [half] -> [B, 2*half + 1]."""
+    _need(t, torch.int64, "learned_sinusoidal_emb"); _need(weights, torch.float32, "learned_sinusoidal_emb"); _dense(weights, "learned_sinusoidal_emb")
+    half = weights.numel()
+    out = torch.empty((t.numel(), 2 * half + 1), device=t.device, dtype=torch.float32)
+    _call("nfdp_learned_sinusoidal_emb_f32", _ptr(t.contiguous()), _ptr(weights), _ptr(out), t.numel(), half, _stream())
+    return out
+
+
+def learned_sinusoidal_bwd(t: torch.Tensor, weights: torch.Tensor, dout: torch.Tensor, dw: Optional[torch.Tensor] = None,
+                           accumulate: bool = False) -> torch.Tensor:
+    """Gradient of learned_sinusoidal_emb with respect to `weights` (dout [B, 2*half + 1])."""
+    _need(t, torch.int64, "learned_sinusoidal_bwd"); _need(dout, torch.float32, "learned_sinusoidal_bwd"); _dense(dout, "learned_sinusoidal_bwd")
+    half = weights.numel()
+    if dout.shape[-1] != 2 * half + 1 or dout.numel() != t.numel() * (2 * half + 1):
+        raise ValueError("learned_sinusoidal_bwd: dout must be [B, 2*half + 1]")
+    if dw is None:
+        dw, accumulate = torch.empty(half, device=t.device, dtype=torch.float32), False
+    _call("nfdp_learned_sinusoidal_bwd_f32", _ptr(t.contiguous()), _ptr(weights), _ptr(dout), _ptr(dw), t.numel(), half, int(accumulate),
+          _stream())
+    return dw
+
+
 def linear_attention(qkv: torch.Tensor, heads: int, dim_head: int, scale: float) -> torch.Tensor:
     _need(qkv, torch.float32, "linear_attention"); _dense(qkv, "linear_attention")
     b, h, w, _ = qkv.shape

@@ -146,6 +146,12 @@ def full_attention(x: Tensor, sd: SD, p: str, heads: int = 4) -> Tensor:
 
 def time_embedding(t: Tensor, sd: SD, dim: int) -> Tensor:
     """sinusoidal(dim) -> Linear -> GELU(exact) -> Linear  (gaussian_diffusion.py:231-237, 407-412)."""
+    if "time_mlp.0.weights" in sd:            # RandomOrLearnedSinusoidalPosEmb (gaussian_diffusion.py:240-255)
+        x = t[:, None]
+        freqs = x * sd["time_mlp.0.weights"][None, :] * 2 * math.pi
+        e = torch.cat((x, torch.cat((freqs.sin(), freqs.cos()), dim=-1)), dim=-1)
+        e = F.linear(e, sd["time_mlp.1.weight"], sd["time_mlp.1.bias"])
+        return F.linear(F.gelu(e), sd["time_mlp.3.weight"], sd["time_mlp.3.bias"])
     half = dim // 2
     f = math.log(10000) / (half - 1)
     f = torch.exp(torch.arange(half) * -f)

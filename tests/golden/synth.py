@@ -62,6 +62,8 @@ def synth_tensor(key: str, shape, seed: int, profile: dict = GOLDEN) -> np.ndarr
             else:
                 std = 1.0 / np.sqrt(fan_in)
             v = std * g
+    elif leaf == "weights":                       # RandomOrLearnedSinusoidalPosEmb frequencies (cycles per timestep)
+        v = 0.01 * g
     else:
         raise KeyError(f"no synth rule for {key}")
     return v.astype(np.float32)

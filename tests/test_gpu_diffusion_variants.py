@@ -117,3 +117,33 @@ def test_auto_normalize_golden(vg):
     s = d.sample(batch_size=2)
     assert s.shape == (2, 2, 16, 16) and torch.isfinite(s).all()
     assert float(s.min()) >= -1e-6 and float(s.max()) <= 1 + 1e-6      # the last step clamps x_start to [-1,1] before unnormalize
+
+
+# ----------------------------------------------------------------------------- random / learned sinusoidal time embeddings
+@pytest.mark.parametrize("tag", ["learned", "random"])
+def test_unet_with_learned_or_random_time_embedding(tag):
+    """Unet(learned_sinusoidal_cond=True) / Unet(random_fourier_features=True) (gaussian_diffusion.py:240-255, :398-405): embedding and
+    U-Net output against the reference (tests/golden/unet_embeddings.npz); the learned frequencies' gradient (and two other parameters'
+    through the same graph) against the reference's autograd; GaussianDiffusion rejects such a U-Net as the reference does (:559)."""
+    from diffusion_prior import Unet, GaussianDiffusion
+    eg = load_golden("unet_embeddings.npz")
+    kw = dict(learned_sinusoidal_cond=True) if tag == "learned" else dict(random_fourier_features=True)
+    u = Unet(dim=64, dim_mults=(1, 2), channels=2, resnet_block_groups=8, learned_sinusoidal_dim=16, **kw)
+    u.load_state_dict(synth_sd(meta_of(eg)[tag], 26), strict=True)
+    u = u.to(DEV)
+    assert u.time_mlp[0].weights.requires_grad == bool(int(eg[f"{tag}_requires_grad"]))
+    x0, eps, t = T(eg["x0"]).to(DEV), T(eg["eps"]).to(DEV), T(eg["t"]).to(DEV)
+    with torch.no_grad():
+        assert_close(u.time_mlp[0](t), eg[f"{tag}_emb"], 1e-5, "embedding")
+        assert_close(u(x0, t), eg[f"{tag}_out"], TOL, "U-Net output (inference path)")
+    out = u(x0, t)                                                  # grad mode: the differentiable path
+    assert_close(out, eg[f"{tag}_out"], TOL, "U-Net output (training path)")
+    (out * eps).sum().backward()
+    if tag == "learned":
+        assert_close(u.time_mlp[0].weights.grad, eg["learned_grad_weights"], 2e-3, "d loss / d frequencies")
+        assert_close(u.time_mlp[1].weight.grad, eg["learned_grad_lin1"], 2e-3, "d loss / d time_mlp.1.weight")
+        assert_close(u.init_conv.weight.grad, eg["learned_grad_init_conv"], 2e-3, "d loss / d init_conv.weight")
+    else:
+        assert u.time_mlp[0].weights.grad is None
+    with pytest.raises(AssertionError):
+        GaussianDiffusion(u, image_size=16, timesteps=8)

@@ -344,3 +344,14 @@ def test_oracle_autograd_matches_reference_training_gradients():
             assert psd[k].grad is None or float(psd[k].grad.abs().max()) == 0.0
         else:
             close_summary(psd[k].grad, ref, 2e-5, f"prior grad {k}")
+
+
+# ----------------------------------------------------------------------------- random / learned sinusoidal time embeddings
+@pytest.mark.parametrize("tag", ["learned", "random"])
+def test_unet_with_learned_or_random_time_embedding(tag):
+    """The oracle's U-Net with RandomOrLearnedSinusoidalPosEmb (gaussian_diffusion.py:240-255) against the reference's outputs
+    (tools/make_goldens.py embeddings)."""
+    eg = load_golden("unet_embeddings.npz")
+    sd = synth_sd(meta_of(eg)[tag], 26)
+    out = D.unet_forward(T(eg["x0"]), T(eg["t"]), sd, 64, (1, 2), 8)
+    assert_close(out, eg[f"{tag}_out"], 2e-5, f"unet with {tag} embedding")

@@ -361,6 +361,32 @@ def gen_diffusion_variants():
 
 
 # ------------------------------------------------------------------ variational bound + CatFormater goldens
+def gen_unet_embeddings():
+    """U-Nets with random / learned sinusoidal time embeddings (gaussian_diffusion.py:240-255, :398-405): forward outputs, and for the
+    learned variant the gradient of its frequencies and of the first time-MLP linear under loss = sum(out * eps)."""
+    GD = R["gd"]
+    g, meta = {}, {}
+    x0 = t(synth_input("x0", (2, 2, 16, 16), 22)) * 0.8
+    eps = t(synth_input("eps", (2, 2, 16, 16), 23))
+    tt = torch.tensor([10, 700], dtype=torch.long)
+    g["x0"], g["eps"], g["t"] = n(x0), n(eps), n(tt)
+    for tag, kw in (("learned", dict(learned_sinusoidal_cond=True)), ("random", dict(random_fourier_features=True))):
+        u = GD.Unet(dim=64, dim_mults=(1, 2), channels=2, resnet_block_groups=8, learned_sinusoidal_dim=16, **kw)
+        meta[tag] = load_synth(u, 26)
+        out = u(x0, tt)
+        g[f"{tag}_out"] = n(out)
+        g[f"{tag}_emb"] = n(u.time_mlp[0](tt))
+        g[f"{tag}_requires_grad"] = np.array(int(u.time_mlp[0].weights.requires_grad))
+        if u.time_mlp[0].weights.requires_grad:
+            (out * eps).sum().backward()
+            g[f"{tag}_grad_weights"] = n(u.time_mlp[0].weights.grad)
+            g[f"{tag}_grad_lin1"] = n(u.time_mlp[1].weight.grad)
+            g[f"{tag}_grad_init_conv"] = n(u.init_conv.weight.grad)
+    g["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "unet_embeddings.npz"), **g)
+    print("unet_embeddings.npz", len(g), "arrays")
+
+
 @torch.no_grad()
 def gen_vlb():
     GD, FM = R["gd"], R["formaters"]
@@ -452,7 +478,7 @@ def gen_train(C=3, L=3, K=2, B=2, seed=2):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion", "variants", "vlb", "train"]
+    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion", "variants", "embeddings", "vlb", "train"]
     if "ops" in which:
         gen_ops()
     if "glow" in which:
@@ -465,6 +491,8 @@ if __name__ == "__main__":
         gen_diffusion()
     if "variants" in which:
         gen_diffusion_variants()
+    if "embeddings" in which:
+        gen_unet_embeddings()
     if "vlb" in which:
         gen_vlb()
     if "train" in which:
