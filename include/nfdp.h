@@ -214,6 +214,11 @@ int nfdp_level_fused_train_bf16(float* x, int B, int H, int W, int C, int n_flow
  * (nfdp_coupling_bwd_fused_packed_bytes(C) bytes): nfdp_coupling_bwd_fused_pack of w1 [512,C/2,3,3], scale1 [512], w2 [512,512,1,1],
  * scale2 [512], w3 [C,512,3,3].  Geometries: those of nfdp_coupling_fused_supported; others return NFDP_EUNSUPPORTED. */
 size_t nfdp_coupling_bwd_fused_packed_bytes(int C);
+/* The same images for n (<= 32) networks in one launch: params = HOST array of 9 * n (forward: w1, scale1, bias1, w2, scale2, bias2, w3,
+ * bias3, logs3 per network) or 5 * n (reverse: w1, scale1, w2, scale2, w3) device pointers, packed = HOST array of n output buffers.
+ * A training step re-packs every network of a level (its weights have just changed): one launch per level instead of one per flow. */
+int nfdp_coupling_fused_pack_batch(const float* const* params, void* const* packed, int n, int C, int fold_scales, nfdp_stream_t stream);
+int nfdp_coupling_bwd_fused_pack_batch(const float* const* params, void* const* packed, int n, int C, nfdp_stream_t stream);
 int nfdp_coupling_bwd_fused_pack(const float* w1, const float* scale1, const float* w2, const float* scale2, const float* w3,
                                  void* packed, int C, nfdp_stream_t stream);
 int nfdp_coupling_bwd_fused_bf16(const float* dc3, float* dx, const void* packed, const void* y1, const void* y2, void* dc1,

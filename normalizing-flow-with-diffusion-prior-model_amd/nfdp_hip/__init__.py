@@ -498,6 +498,48 @@ def coupling_fused_pack(w1, s1, b1, w2, s2, b2, w3, b3, l3, fold: bool = True, o
     return packed
 
 
+def _pack_batch(entry: str, per_net: int, nets, outs, c: int, nbytes: int, *extra) -> list:
+    n = len(nets)
+    if n == 0:
+        return []
+    dev = nets[0][0].device
+    if outs is None:
+        outs = [None] * n
+    outs = [o if o is not None and o.numel() == nbytes else torch.empty(nbytes, device=dev, dtype=torch.uint8) for o in outs]
+    flat = []
+    for ts in nets:
+        if len(ts) != per_net:
+            raise ValueError(f"{entry}: {per_net} tensors per network")
+        for t in ts:
+            _need(t, torch.float32, entry); _dense(t, entry)
+            flat.append(_ptr(t))
+    for i in range(0, n, 32):                                        # (the launch takes up to 32 networks)
+        m = min(32, n - i)
+        _call(entry, (ctypes.c_void_p * (per_net * m))(*flat[per_net * i: per_net * (i + m)]),
+              (ctypes.c_void_p * m)(*[_ptr(o) for o in outs[i: i + m]]), m, c, *extra, _stream())
+    return outs
+
+
+def coupling_fused_pack_batch(nets, fold: bool = True, outs=None) -> list:
+    """coupling_fused_pack for several networks of one geometry in one launch: nets = [(w1, s1, b1, w2, s2, b2, w3, b3, l3), ...];
+    outs: optional list of image buffers to re-use (None entries are allocated).  -> the images."""
+    if not nets:
+        return []
+    c = nets[0][6].shape[0]
+    return _pack_batch("nfdp_coupling_fused_pack_batch", 9, nets, outs, c, lib().nfdp_coupling_fused_packed_bytes(c), int(fold))
+
+
+def coupling_bwd_fused_pack_batch(nets, outs=None) -> list:
+    """coupling_bwd_fused_pack for several networks in one launch: nets = [(w1, s1, w2, s2, w3), ...]."""
+    if not nets:
+        return []
+    c = nets[0][4].shape[0]
+    nbytes = lib().nfdp_coupling_bwd_fused_packed_bytes(c)
+    if nbytes == 0:
+        raise NfdpError(f"coupling_bwd_fused_pack_batch: unsupported C={c}")
+    return _pack_batch("nfdp_coupling_bwd_fused_pack_batch", 5, nets, outs, c, nbytes)
+
+
 def coupling_fused(xh: torch.Tensor, packed: torch.Tensor, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.Tensor],
                    inverse: bool) -> None:
     """In place on xh [B,H,W,C]: the whole coupling layer (network + affine + log-det) in one launch (bf16 MFMA)."""

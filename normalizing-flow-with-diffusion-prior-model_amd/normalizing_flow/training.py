@@ -595,7 +595,7 @@ FUSED_TRAIN_BACKWARD = True         # ... and the data-gradient chain of each co
 WGRAD_ONE_LAUNCH = os.environ.get("NFDP_WGRAD_ONE_LAUNCH", "1") != "0"
 
 
-def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net):
+def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net, packed=None):
     """Backward of one coupling network on the fused kernels, from the gradient dc3 at the zero conv's raw output (the link kernel has
     applied its scale backward).  dx [B,H,W,C]: the coupling's input gradient, whose first half receives += the network's input
     gradient; xcol: saved im2col rows of the network's input; y1, y2: saved hidden activations (blocked layout, [Bpad,H,W,512] bf16).
@@ -608,10 +608,11 @@ def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net):
     o1, i1 = w1.shape[:2]
     gs = _slots(w1, b1, s1, w2, b2, s2, w3)
     direct = gs is not None
-    packed = K.coupling_bwd_fused_pack(w1.detach(), s1.detach().reshape(-1), w2.detach(), s2.detach().reshape(-1), w3.detach(),
-                                       out=getattr(net, "_fused_bwd", None) if net is not None else None)
-    if net is not None:
-        object.__setattr__(net, "_fused_bwd", packed)
+    if packed is None:                                     # (LevelFusedFn packs the whole level's images in one launch)
+        packed = K.coupling_bwd_fused_pack(w1.detach(), s1.detach().reshape(-1), w2.detach(), s2.detach().reshape(-1), w3.detach(),
+                                           out=getattr(net, "_fused_bwd", None) if net is not None else None)
+        if net is not None:
+            object.__setattr__(net, "_fused_bwd", packed)
     dc1, dc2, dc3_col = K.coupling_bwd_fused(dc3, dx, packed, y1, y2)
     def problems(gw1, gb1, gs1, gw2, gb2, gs2, gw3):
         # the three weight gradients as ONE GEMM launch + one reduce (coupling_wgrad3): the 512 x 512 one first, it takes longest
@@ -697,10 +698,17 @@ class LevelFusedFn(Function):
         l3 = lambda i: params[P * i + 11].detach().reshape(-1)
         dx, dc3, _ = K.flow_link_bwd(dy, part[0], coupling=(ypost[n - 1], hout[n - 1], gl, l3(n - 1), f3))
         direct_small = []
+        # the reverse images of the level's networks in one launch (weights are fixed during the backward pass)
+        bw = [(params[P * i + 3].detach(), params[P * i + 5].detach().reshape(-1), params[P * i + 6].detach(),
+               params[P * i + 8].detach().reshape(-1), params[P * i + 9].detach()) for i in range(n)]
+        rev = K.coupling_bwd_fused_pack_batch(bw, outs=[getattr(nt, "_fused_bwd", None) if nt is not None else None for nt in ctx.nets])
+        for nt, img in zip(ctx.nets, rev):
+            if nt is not None:
+                object.__setattr__(nt, "_fused_bwd", img)
         for i in reversed(range(n)):
             scale, bias, weight = params[P * i: P * i + 3]
             net = params[P * i + 3: P * i + 12]
-            g9 = _net_backward_fused(dc3, dx, xcol[i], y1[i], y2[i], net, ctx.nets[i])          # dx[..., :c/2] += network input gradient
+            g9 = _net_backward_fused(dc3, dx, xcol[i], y1[i], y2[i], net, ctx.nets[i], packed=rev[i])   # dx[..., :c/2] += network input gradient
             head = (xpre[i], weight.detach().reshape(c, c), scale.detach().reshape(-1), bias.detach().reshape(-1))
             cpl = (ypost[i - 1], hout[i - 1], gl, l3(i - 1), f3) if i > 0 else None
             # (the 1x1 conv's weight gradient dW = sum_p dx (x) a, transforms.py:132, is left in the call's partial buffer too)
@@ -766,10 +774,19 @@ def _level_fused_ok(flows, yh: Tensor) -> bool:
 
 def _level_fused(flows, yh: Tensor, ldj: Optional[Tensor], sp, wts: Tensor):
     packed, bpacks, params = [], [], []
+    nets = [f.affcoupling.net for f in flows]
+    # training images of the level's networks: the stale ones (all of them after an optimizer step) re-packed in ONE launch
+    keys = [n_.fused_train_key() for n_ in nets]
+    stale = [i for i, n_ in enumerate(nets) if getattr(n_, "_fused_train_key", None) != keys[i]]
+    if stale:
+        outs = K.coupling_fused_pack_batch([nets[i].fused_pack_tensors() for i in stale], fold=False,
+                                           outs=[getattr(nets[i], "_fused_train", None) for i in stale])
+        for i, o in zip(stale, outs):
+            nets[i]._fused_train, nets[i]._fused_train_key = o, keys[i]
     for f in flows:
         net = f.affcoupling.net
         c1, c2, zc = net[0], net[2], net[4]
-        packed.append(net.fused_packed_train())
+        packed.append(net._fused_train)
         six = sp.get(f) if sp else None
         bpacks.append(tuple(six[3:]) if six is not None else None)
         params += [f.actnorm.scale, f.actnorm.bias, f.invconv2d.weight, c1.conv.weight, c1.actnorm.bias, c1.actnorm.scale,

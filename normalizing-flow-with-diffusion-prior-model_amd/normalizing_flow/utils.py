@@ -160,16 +160,25 @@ class CouplingNet(nn.Sequential):
             self._fused_key = key
         return self._fused
 
+    def _pack_params(self):
+        c1, c2, zc = self[0], self[2], self[4]
+        return (c1.conv.weight, c1.actnorm.scale, c1.actnorm.bias, c2.conv.weight, c2.actnorm.scale, c2.actnorm.bias,
+                zc.weight, zc.bias, zc.logs)
+
+    def fused_pack_tensors(self):
+        """The nine tensors the packers read, detached (vectors flattened)."""
+        return tuple(t.detach().reshape(-1) if t.dim() != 4 else t.detach() for t in self._pack_params())
+
+    def fused_train_key(self):
+        return tuple((t.data_ptr(), t._version) for t in self._pack_params()) + (K.param_epoch(),)
+
     def fused_packed_train(self):
         """The image of the training forward (nfdp_level_fused_train_bf16: plain weights, scales applied in the epilogues), rebuilt
-        into the same buffer when a parameter changes - every step while training."""
-        c1, c2, zc = self[0], self[2], self[4]
-        ts = (c1.conv.weight, c1.actnorm.scale, c1.actnorm.bias, c2.conv.weight, c2.actnorm.scale, c2.actnorm.bias,
-              zc.weight, zc.bias, zc.logs)
-        key = tuple((t.data_ptr(), t._version) for t in ts) + (K.param_epoch(),)
+        into the same buffer when a parameter changes - every step while training (a whole level's images in one launch:
+        training._level_fused)."""
+        key = self.fused_train_key()
         if getattr(self, "_fused_train_key", None) != key:
-            self._fused_train = K.coupling_fused_pack(*[t.detach().reshape(-1) if t.dim() != 4 else t.detach() for t in ts], fold=False,
-                                                      out=getattr(self, "_fused_train", None))
+            self._fused_train = K.coupling_fused_pack(*self.fused_pack_tensors(), fold=False, out=getattr(self, "_fused_train", None))
             self._fused_train_key = key
         return self._fused_train
 
