@@ -231,7 +231,7 @@ int nfdp_coupling_bwd_fused_bf16(const float* dc3, float* dx, const void* packed
  *   coupling (ypost != NULL): on (ypost, hout = (log_s | t), dy, gl[b] = gradient of the per-sample log-det, optional):
  *                           dx_out = (dy_a | dy_b s),  dh = (ds s (1-s) | dy_b s) with ds = dy_b (x_b + t) + gl / (s + 1e-6),
  *                           dc3_out = dh e^{f3 logs3}            (no coupling: dx_out = dy)
- *   part (nfdp_flow_link_bwd_part_bytes: [ceil(npix/256)][4][C] fp64, then [ceil(npix/256)][C*C] fp32): per-workgroup sums of da a,
+ *   part (nfdp_flow_link_bwd_part_bytes: [workgroups][4][C] fp64, then [workgroups][C*C] fp32; 256 or 64 pixels per workgroup): per-workgroup sums of da a,
  *                           da e^scale, dh hout, dc3 and - head calls - the workgroup's partial of the 1x1 conv's weight gradient
  *                           dW[k][c] = sum_p dx_in[p][k] a[p][c] (transforms.py:132; exact-fp32 MFMA).
  * nfdp_flow_link_finish_f32 reduces the partials of n_calls calls (laid out back to back) in one launch: for call k

@@ -556,24 +556,27 @@ struct LinkParams {
     float* part_w;       // [blocks][C*C] fp32: per-workgroup partial of the 1x1 conv's weight gradient (head calls), or null
 };
 
-template <int C>
-__global__ void __launch_bounds__(kBlock) flow_link_bwd_kernel(const LinkParams p) {
+// LB pixels (threads) per workgroup: 64 (one wave) - with 256 the 8x8 / 4x4 levels of a B = 512 step have 128 / 32 workgroups, most of
+// the chip idle, and a workgroup's serial parts (the C x C product per pixel, the column sums over its rows, the weight-gradient MFMAs)
+// set the launch time: 23 / 32 us against 17 / 25 us.
+template <int C, int LB>
+__global__ void __launch_bounds__(LB) flow_link_bwd_kernel(const LinkParams p) {
     constexpr int Ch = C / 2, TS = C + 1;
     __shared__ __attribute__((aligned(16))) float wt_s[C * C];
     __shared__ float es_s[C], bs_s[C], fac_s[C];
     extern __shared__ __attribute__((aligned(16))) float link_dyn[];       // tile [256][C+1] | tile2 [256][C+1] (ActNorm output rows)
     float* tile = link_dyn;
-    float* tile2 = link_dyn + kBlock * TS;
+    float* tile2 = link_dyn + LB * TS;
     const int tid = threadIdx.x;
-    const long px = (long)blockIdx.x * kBlock + tid;
+    const long px = (long)blockIdx.x * LB + tid;
     const bool live = px < p.npix;
     const bool head = p.xpre != nullptr, cpl = p.ypost != nullptr;
     if (head) {
-        for (int i = tid; i < C * C; i += kBlock) wt_s[i] = p.wt[i];
-        for (int c = tid; c < C; c += kBlock) { es_s[c] = expf(p.scale[c]); bs_s[c] = p.bias[c]; }
+        for (int i = tid; i < C * C; i += LB) wt_s[i] = p.wt[i];
+        for (int c = tid; c < C; c += LB) { es_s[c] = expf(p.scale[c]); bs_s[c] = p.bias[c]; }
     }
     if (cpl)
-        for (int c = tid; c < C; c += kBlock) fac_s[c] = expf(__fmul_rn(p.f3, p.logs3[c]));
+        for (int c = tid; c < C; c += LB) fac_s[c] = expf(__fmul_rn(p.f3, p.logs3[c]));
     __syncthreads();
     // column sums over the workgroup's 256 pixels, one quantity at a time through a [256][C+1] tile (odd row stride: conflict-free)
     double* out = p.part + (size_t)blockIdx.x * 4 * C;
@@ -584,7 +587,7 @@ __global__ void __launch_bounds__(kBlock) flow_link_bwd_kernel(const LinkParams 
         __syncthreads();
         if (tid < C) {
             double sum = 0.0;
-            for (int r = 0; r < kBlock; ++r) sum += (double)tile[r * TS + tid];
+            for (int r = 0; r < LB; ++r) sum += (double)tile[r * TS + tid];
             out[q * C + tid] = sum;
         }
     };
@@ -662,8 +665,9 @@ __global__ void __launch_bounds__(kBlock) flow_link_bwd_kernel(const LinkParams 
                     for (int j = 0; j < MT; ++j) accw[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_[i], bv_[j], accw[i][j], 0, 0, 0);
             }
             __syncthreads();                                       // every wave is done reading the two tiles
-            float* redw = tile;                                    // [4 waves][C*C] (fits: 4 C^2 <= 256 (C+1) for C <= 48)
-            static_assert(4 * C * C <= 2 * kBlock * TS, "wave partials alias the tiles");
+            constexpr int NW = LB / 64;
+            float* redw = tile;                                    // [NW waves][C*C], over the two tiles
+            static_assert(NW * C * C <= 2 * LB * TS, "wave partials alias the tiles");
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -675,7 +679,12 @@ __global__ void __launch_bounds__(kBlock) flow_link_bwd_kernel(const LinkParams 
                     }
             __syncthreads();
             float* pw = p.part_w + (size_t)blockIdx.x * C * C;
-            for (int e = tid; e < C * C; e += kBlock) pw[e] = (redw[e] + redw[C * C + e]) + (redw[2 * C * C + e] + redw[3 * C * C + e]);
+            for (int e = tid; e < C * C; e += LB) {
+                float v = redw[e];
+#pragma unroll
+                for (int wv = 1; wv < NW; ++wv) v += redw[wv * C * C + e];
+                pw[e] = v;
+            }
         }
         colsum(0, q0);
         colsum(1, dy);
@@ -793,19 +802,32 @@ __global__ void __launch_bounds__(kBlock) flow_link_finish_kernel(const double* 
 }
 
 // per call: [blocks][4][C] fp64 column sums, then [blocks][C*C] fp32 partials of the 1x1 conv's weight gradient (rounded up to 8 bytes)
-template <int C>
-static void launch_flow_link(dim3 grid, hipStream_t s, const LinkParams& p) {
-    constexpr int kDyn = 2 * kBlock * (C + 1) * (int)sizeof(float);
+// pixels per workgroup of the link kernel (see flow_link_bwd_kernel); the partial buffers are laid out per workgroup, so the three
+// entry points below derive it from npix alike
+static int link_block(long npix) {
+    static const int forced = [] { const char* e = getenv("NFDP_LINK_BLOCK"); return e ? atoi(e) : 0; }();   // A/B measurements
+    if (forced == 64 || forced == 256) return forced;
+    (void)npix;
+    return 64;             // measured (rocprofv3, B = 512): 18.7 / 16.8 / 25.2 us per launch at the three levels against 22.7 / 23.0 / 32.0 with 256
+}
+template <int C, int LB>
+static void launch_flow_link_lb(hipStream_t s, const LinkParams& p) {
+    constexpr int kDyn = 2 * LB * (C + 1) * (int)sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_link_bwd_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_link_bwd_kernel<C, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
         attr_set = true;
     }
-    hipLaunchKernelGGL(flow_link_bwd_kernel<C>, grid, dim3(kBlock), kDyn, s, p);
+    hipLaunchKernelGGL((flow_link_bwd_kernel<C, LB>), dim3((unsigned)cdiv(p.npix, LB)), dim3(LB), kDyn, s, p);
+}
+template <int C>
+static void launch_flow_link(hipStream_t s, const LinkParams& p) {
+    if (link_block(p.npix) == 64) launch_flow_link_lb<C, 64>(s, p);
+    else launch_flow_link_lb<C, 256>(s, p);
 }
 
 extern "C" size_t nfdp_flow_link_bwd_part_bytes(long npix, int C) {
-    const size_t nblk = (size_t)cdiv(npix, kBlock);
+    const size_t nblk = (size_t)cdiv(npix, link_block(npix));
     return nblk * 4 * C * sizeof(double) + ((nblk * C * C * sizeof(float) + 7) & ~(size_t)7);
 }
 
@@ -822,16 +844,16 @@ extern "C" int nfdp_flow_link_bwd_f32(const float* dx_in, const float* xpre, con
     if (npix == 0) return NFDP_OK;
     LinkParams p{dx_in, xpre, wt, scale, bias, a_out, ypost, hout, gl, logs3, f3, dx_out, dc3_out, reinterpret_cast<double*>(part), npix, HW,
                  nullptr};
-    const dim3 grid((unsigned)cdiv(npix, kBlock));
-    if (xpre) p.part_w = reinterpret_cast<float*>(p.part + (size_t)grid.x * 4 * C);
+    const size_t nblk = (size_t)cdiv(npix, link_block(npix));
+    if (xpre) p.part_w = reinterpret_cast<float*>(p.part + nblk * 4 * C);
     hipStream_t s = as_stream(stream);
     switch (C) {
-        case 4: launch_flow_link<4>(grid, s, p); break;
-        case 8: launch_flow_link<8>(grid, s, p); break;
-        case 16: launch_flow_link<16>(grid, s, p); break;
-        case 12: launch_flow_link<12>(grid, s, p); break;
-        case 24: launch_flow_link<24>(grid, s, p); break;
-        case 48: launch_flow_link<48>(grid, s, p); break;
+        case 4: launch_flow_link<4>(s, p); break;
+        case 8: launch_flow_link<8>(s, p); break;
+        case 16: launch_flow_link<16>(s, p); break;
+        case 12: launch_flow_link<12>(s, p); break;
+        case 24: launch_flow_link<24>(s, p); break;
+        case 48: launch_flow_link<48>(s, p); break;
         default: nfdp_set_error("flow_link_bwd: unsupported C=%d", C); return NFDP_EUNSUPPORTED;
     }
     NFDP_CHECK_LAUNCH("flow_link_bwd");
@@ -850,7 +872,7 @@ extern "C" int nfdp_flow_link_finish_f32(const void* part, int n_calls, long npi
         f.dscale[i] = dscale[i]; f.dbias[i] = dbias[i]; f.dlogs3[i] = dlogs3[i]; f.dbias3[i] = dbias3[i]; f.dw[i] = dw[i];
         any_dw = any_dw || dw[i] != nullptr;
     }
-    f.n = n_calls; f.nblk = (int)cdiv(npix, kBlock); f.C = C; f.acc = accumulate; f.f3 = f3;
+    f.n = n_calls; f.nblk = (int)cdiv(npix, link_block(npix)); f.C = C; f.acc = accumulate; f.f3 = f3;
     f.call_doubles = (long)(nfdp_flow_link_bwd_part_bytes(npix, C) / sizeof(double));
     f.wblocks = (C * C + 63) / 64;
     hipLaunchKernelGGL(flow_link_finish_kernel, dim3(4 * n_calls + (any_dw ? n_calls * f.wblocks : 0)), dim3(kBlock), 0, as_stream(stream),
