@@ -314,6 +314,71 @@ __device__ __forceinline__ double lu_logdet_regs(const float* __restrict__ wm, i
     return sum;
 }
 
+// In-place Gauss-Jordan INVERSION with the same register scheme (lane = physical row, C fp64 registers, pivot row broadcast with
+// v_readlane, implicit partial pivoting: no row moves).  Step k with pivot row p = p_k and pivot value pv: row p becomes row k of the
+// working inverse (a[k] := 1, then the row is divided by pv), every other row r subtracts a_r[k] times it (a_r[k] := 0 first).  With
+// B = P A the row-permuted matrix (B[k] = A[p_k]) the registers end as B^-1, logical row i in physical row p_i, and A^-1 = B^-1 P:
+//   A^-1[i][p_k] = B^-1[i][k]  ->  lane r (pivot of step `mystep`) writes winv[mystep][p_k] = a[k] for every k.
+// The three-barriers-per-step workgroup kernel took ~100 us per level of 16 matrices whatever their size (3 launches on the critical
+// path of a training step); this one is one wave per matrix without a barrier.  Returns log|det| (valid in every lane).
+template <int C>
+__device__ __forceinline__ double gj_inverse_regs(const float* __restrict__ wm, float* __restrict__ winv, int lane, int* prow_s) {
+    double a[C];
+#pragma unroll
+    for (int j = 0; j < C; ++j) a[j] = lane < C ? (double)wm[lane * C + j] : 0.0;
+    bool used = lane >= C;
+    int mystep = -1;
+    double logdet = 0.0;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const unsigned key = used ? 0u : ((__float_as_uint((float)fabs(a[k])) & ~63u) | (unsigned)(63 - lane));
+        const int p = 63 - (int)(wave_umax(key) & 63u);
+        if (lane == 0) prow_s[k] = p;                              // (LDS: a register array of the 48 pivot rows spilled)
+        const double pv = readlane_f64(a[k], p);
+        const double rp = 1.0 / pv;
+        logdet += log(fabs(pv));
+        const bool mine = lane == p;
+        if (mine) { used = true; mystep = k; }
+        // one update formula for every row, a[j] -= f * pj with pj = a_p[j] / pv the normalised pivot row: the other rows use f = a[k];
+        // the pivot row itself f = pv - 1 (a_p[j] - (pv - 1) a_p[j] / pv = a_p[j] / pv), no per-element select.  Column k: the pivot
+        // row gets 1 / pv, the others -a[k] / pv.
+        const double f = mine ? pv - 1.0 : a[k];
+        const double ak = a[k];
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const double pj = readlane_f64(a[j], p) * rp;
+            a[j] = j == k ? (mine ? rp : -ak * rp) : a[j] - f * pj;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    if (winv != nullptr && lane < C) {
+#pragma unroll
+        for (int k = 0; k < C; ++k) winv[mystep * C + prow_s[k]] = (float)a[k];
+    }
+    return logdet;
+}
+
+__global__ void __launch_bounds__(64) gj_wave_kernel(const float* __restrict__ w, int C, float* __restrict__ logabsdet,
+                                                     float* __restrict__ winv) {
+    const float* wm = w + (size_t)blockIdx.x * C * C;
+    float* out = winv ? winv + (size_t)blockIdx.x * C * C : nullptr;
+    const int lane = threadIdx.x;
+    __shared__ int prow_s[64];
+    double r = 0.0;
+    switch (C) {                                                   // wave-uniform
+        case 4: r = gj_inverse_regs<4>(wm, out, lane, prow_s); break;
+        case 8: r = gj_inverse_regs<8>(wm, out, lane, prow_s); break;
+        case 12: r = gj_inverse_regs<12>(wm, out, lane, prow_s); break;
+        case 16: r = gj_inverse_regs<16>(wm, out, lane, prow_s); break;
+        case 24: r = gj_inverse_regs<24>(wm, out, lane, prow_s); break;
+        case 48: r = gj_inverse_regs<48>(wm, out, lane, prow_s); break;
+        default: break;
+    }
+    if (lane == 0) logabsdet[blockIdx.x] = (float)r;
+}
+static bool gj_wave_ok(int C) { return C == 4 || C == 8 || C == 12 || C == 16 || C == 24 || C == 48; }
+
 // One WAVE per matrix (C <= 64): lane = row, so a step needs no workgroup barrier - the argmax is one DPP wave reduction,
 // the pivot row is read as LDS broadcasts, every lane updates its own row.  LDS ops of one wave execute in order.
 __global__ void __launch_bounds__(64) logdet_wave_kernel(const LogdetTable tab, float* __restrict__ logabsdet) {
@@ -395,7 +460,10 @@ extern "C" int nfdp_invconv_prepare_f32(const float* w, int n, int C, float* log
     NFDP_REQUIRE(n >= 0 && C > 0 && C <= 256, NFDP_ESHAPE, "invconv_prepare: bad shape n=%d C=%d (C<=256)", n, C);
     if (n == 0) return NFDP_OK;
     const size_t red = (size_t)(3 * C + 4) * sizeof(double) + (size_t)(2 * C + 4) * sizeof(int) + 16;
-    if (C <= kMaxLdsC) {
+    static const bool wave_off = [] { const char* e = getenv("NFDP_GJ_WAVE"); return e && e[0] == '0'; }();   // A/B measurements
+    if (gj_wave_ok(C) && !wave_off) {
+        hipLaunchKernelGGL(gj_wave_kernel, dim3(n), dim3(64), 0, as_stream(stream), w, C, logabsdet, winv);
+    } else if (C <= kMaxLdsC) {
         const size_t lds = (size_t)C * 2 * C * sizeof(double) + red;
         hipLaunchKernelGGL((gauss_jordan_kernel<true>), dim3(n), dim3(kBlock), lds, as_stream(stream), w, C, logabsdet,
                            winv, nullptr);
