@@ -635,20 +635,21 @@ def test_batched_weight_packing_matches_the_single_launches():
         assert not pb.matches()
 
 
-@pytest.mark.parametrize("B,direct", [(8, False), (3, True), (37, False)])
-def test_fused_level_training_forward_matches_the_per_flow_nodes(B, direct):
+@pytest.mark.parametrize("B,direct,chan", [(8, False, 3), (3, True, 3), (37, False, 3), (5, False, 1), (16, True, 1)])
+def test_fused_level_training_forward_matches_the_per_flow_nodes(B, direct, chan):
     """training.FUSED_TRAIN_FORWARD: the forward of every Glow level is ONE persistent launch (nfdp_level_fused_train_bf16) that
     writes out what the backward needs; the per-flow autograd nodes (im2col + three GEMMs + coupling per flow) are the yardstick.
     Same rounding points (bf16 MFMA inputs, fp32 accumulation and flow state), different summation order inside the GEMMs: latents,
     bits/dim and every parameter gradient agree to bf16 round-off; ragged batches exercise the padded rows of the saved hidden
-    activations (8x8 / 4x4 levels own 2 / 8 images per workgroup)."""
+    activations (8x8 / 4x4 levels own 2 / 8 images per workgroup).  chan = 1: the geometries of one-channel 32x32 images (C = 4 at
+    16x16, 8 at 8x8, 16 at 4x4)."""
     from normalizing_flow import calculate_loss, initialize_with_zeros, training
     from tests.golden.synth import DEEP
-    flow, prior, _, _ = build(3, 3, 2, 51)
+    flow, prior, _, _ = build(chan, 3, 2, 51)
     flow.load_state_dict({k: T(synth_tensor(k, v.shape, 51, DEEP)) for k, v in flow.state_dict().items()})
     prior.load_state_dict({k: T(synth_tensor(k, v.shape, 52, DEEP)) for k, v in prior.state_dict().items()})
     flow.set_compute("bf16")
-    x = (T(synth_input("train_x", (B, 3, 32, 32), 8)) * 0.4).to(DEV)
+    x = (T(synth_input("train_x", (B, chan, 32, 32), 8)) * 0.4).to(DEV)
     params = list(flow.parameters()) + list(prior.parameters())
     names = [n for n, _ in flow.named_parameters()] + [n for n, _ in prior.named_parameters()]
     if direct:
@@ -661,7 +662,7 @@ def test_fused_level_training_forward_matches_the_per_flow_nodes(B, direct):
         ll, logp = initialize_with_zeros(2, B, torch.device(DEV))
         K.start_trace()
         latents, ll, logp = flow.transform(x, ll, logp)
-        loss = calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0)
+        loss = calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * float(chan))
         loss.backward()
         labels = [e["label"] for e in K.stop_trace()]
         return [z.detach().clone() for z in latents], loss.detach().clone(), [p.grad.clone() for p in params], labels
