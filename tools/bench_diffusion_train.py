@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Training step of the diffusion prior (reference diffusion_prior/trainer.py:134-150, frozen flow): per step the prior's per-part
+p_losses are summed, differentiated through the HIP backward kernels of the U-Nets and applied with the fused Adam.  BASELINE configs[3]
+shape: MNIST-like 32x32x1 images, Glow L=3 K=4 (frozen), three latent parts 2x16x16 / 4x8x8 / 16x4x4, dim-64 U-Nets, T=1000.
+usage: python tools/bench_diffusion_train.py [B=64] [steps=10]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "normalizing-flow-with-diffusion-prior-model_amd")]
+import numpy as np, torch
+import nfdp_hip as K
+from normalizing_flow import NFBackbone, initialize_with_zeros
+from diffusion_prior import DiffusionPrior, IdentityFormater
+from nfdp_hip.optim import FusedAdam
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+nf = NFBackbone(model_dir="", in_channel=1, L=3, K=4, learn_prior_mean_logs=True, freeze_flow=True).to(dev)
+fmt = IdentityFormater(3, 1, 32)
+shapes = fmt.get_input_shapes()
+prior = DiffusionPrior(latent_formater=fmt, unet_kwargs={"dim": 64, "dim_mults": (1, 2), "resnet_block_groups": 8},
+                       diffusion_kwargs={"timesteps": 1000, "beta_schedule": "cosine", "loss_type": "l2"},
+                       image_sizes=[int(s[1]) for s in shapes], latent_channels=[int(s[0]) for s in shapes]).to(dev)
+params = list(prior.parameters(only_trainable=True))
+opt = FusedAdam(params, lr=1e-4)
+x = (torch.rand(B, 1, 32, 32) - 0.5).to(dev)
+nf.set_eval_mode()
+prior.train()
+with torch.no_grad():
+    latents, _ = nf.transform(x, initialize_with_zeros(1, B, dev))
+print("latent parts:", [tuple(z.shape) for z in latents], " trainable parameters:", sum(p.numel() for p in params), flush=True)
+
+
+def step():
+    loss = sum(prior(latents))
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    return loss
+
+
+for _ in range(3):
+    loss = step()
+torch.cuda.synchronize()
+if os.environ.get("NFDP_GRAPH", "0") == "1":          # EXPERIMENTAL, off: capture dies in autograd's AccumulateGrad stream check (core dump)
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            g_loss = step()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        print(f"B={B}: {dt * 1e3:.2f} ms per training step (hipGraph replay), {B / dt:.0f} latent sets/s, loss {float(g_loss.detach()):.4f}",
+              flush=True)
+        K.bump_param_epoch()
+    except Exception as e:                            # noqa: BLE001
+        print(f"hipGraph capture failed: {type(e).__name__}: {e}", flush=True)
+K.start_trace()
+t0 = time.perf_counter()
+for _ in range(steps):
+    loss = step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+recs = K.stop_trace()
+gpu_ms = sum(r["ms"] for r in recs) / steps
+print(f"B={B}: {dt * 1e3:.2f} ms per training step (eager launches; {len(recs) // steps} ABI launches, {gpu_ms:.2f} ms of kernel time), "
+      f"{B / dt:.0f} latent sets/s, loss {float(loss.detach()):.4f}", flush=True)
