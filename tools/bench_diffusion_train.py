@@ -40,27 +40,34 @@ def step():
     return loss
 
 
+# The whole step as ONE hipGraph (timesteps and noise are drawn on the device, the fused Adam keeps its step count there).  torch's
+# recipe: every eager step BEFORE the capture runs on a side stream - autograd's AccumulateGrad nodes remember the stream they were
+# created on, and a capture that has to wait for the legacy default stream dies in hipStreamEndCapture (segfault, seen here).
+if os.environ.get("NFDP_GRAPH", "1") != "0":
+    warm = torch.cuda.Stream()
+    warm.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(warm):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(warm)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        g_loss = step()
+    for _ in range(2):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f"B={B}: {dt * 1e3:.2f} ms per training step (hipGraph replay), {B / dt:.0f} latent sets/s, loss {float(g_loss.detach()):.4f}", flush=True)
+    K.bump_param_epoch()
+    sys.exit(0)
 for _ in range(3):
     loss = step()
 torch.cuda.synchronize()
-if os.environ.get("NFDP_GRAPH", "0") == "1":          # EXPERIMENTAL, off: capture dies in autograd's AccumulateGrad stream check (core dump)
-    try:
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            g_loss = step()
-        for _ in range(2):
-            g.replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            g.replay()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
-        print(f"B={B}: {dt * 1e3:.2f} ms per training step (hipGraph replay), {B / dt:.0f} latent sets/s, loss {float(g_loss.detach()):.4f}",
-              flush=True)
-        K.bump_param_epoch()
-    except Exception as e:                            # noqa: BLE001
-        print(f"hipGraph capture failed: {type(e).__name__}: {e}", flush=True)
 K.start_trace()
 t0 = time.perf_counter()
 for _ in range(steps):
