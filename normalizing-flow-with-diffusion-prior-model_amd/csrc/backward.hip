@@ -1729,9 +1729,12 @@ static void wgrad_bf16_plan(int B, int H, int W, int Cin, int Cout, int k, Wgrad
 
 // The wide kernel's plan: dy has exactly 512 channels (two 256-row tiles), x up to 512 columns in tiles of 256 (128 when N <= 128);
 // one workgroup per CU, so 256 / tiles pixel slices of whole 32-pixel stages.
-static bool wgrad_wide_ok(long npix, int N, int Cout, int k) {
-    static const bool off = [] { const char* e = getenv("NFDP_WGRAD_WIDE"); return e && e[0] == '0'; }();   // A/B measurements
-    return !off && k == 1 && Cout == 512 && N >= 8 && N <= 512 && N % 8 == 0 && npix % W2_KC == 0 && npix >= 2 * W2_KC;
+static bool wgrad_wide_shape_ok(long npix, int N, int Cout, int k) {
+    return k == 1 && Cout == 512 && N >= 8 && N <= 512 && N % 8 == 0 && npix % W2_KC == 0 && npix >= 2 * W2_KC;
+}
+static bool wgrad_wide_ok(long npix, int N, int Cout, int k) {          // (the single-GEMM entries: switchable for A/B measurements)
+    static const bool off = [] { const char* e = getenv("NFDP_WGRAD_WIDE"); return e && e[0] == '0'; }();
+    return !off && wgrad_wide_shape_ok(npix, N, Cout, k);
 }
 static int wgrad_wide_tn(int N) { return N > 128 ? 256 : 128; }
 static void wgrad_wide_plan(long npix, int N, WgradParams* p) {
@@ -1841,7 +1844,7 @@ static bool wgrad3_plan(long npix, const int* cin, int n, WgradParams* p) {
     double denom = 0.0;
     double cost[3];
     for (int q = 0; q < n; ++q) {
-        if (!wgrad_wide_ok(npix, cin[q], 512, 1)) return false;
+        if (!wgrad_wide_shape_ok(npix, cin[q], 512, 1)) return false;
         const int tn = wgrad_wide_tn(cin[q]);
         cost[q] = tn == 256 ? 0.87 : 0.6;                  // measured us per 32-pixel stage of a workgroup
         denom += 2.0 * (double)cdiv(cin[q], tn) * cost[q];
