@@ -1846,7 +1846,9 @@ static bool wgrad3_plan(long npix, const int* cin, int n, WgradParams* p) {
     for (int q = 0; q < n; ++q) {
         if (!wgrad_wide_shape_ok(npix, cin[q], 512, 1)) return false;
         const int tn = wgrad_wide_tn(cin[q]);
-        cost[q] = tn == 256 ? 0.87 : 0.6;                  // measured us per 32-pixel stage of a workgroup
+        static const double c256 = [] { const char* e = getenv("NFDP_WGRAD3_C256"); return e ? atof(e) : 0.87; }();   // (sweeps)
+        static const double c128 = [] { const char* e = getenv("NFDP_WGRAD3_C128"); return e ? atof(e) : 0.6; }();
+        cost[q] = tn == 256 ? c256 : c128;                 // measured us per 32-pixel stage of a workgroup
         denom += 2.0 * (double)cdiv(cin[q], tn) * cost[q];
     }
     const long cap = npix / (8 * W2_KC);                   // at least 8 stages per slice
