@@ -635,6 +635,48 @@ def test_batched_weight_packing_matches_the_single_launches():
         assert not pb.matches()
 
 
+def test_training_step_at_the_benchmark_size():
+    """BASELINE configs[2] shape on one GPU (Glow L3 K16, 32x32x3, B = 512, bf16): the training step at the size bench.py --train times -
+    the chip-wide grids of the weight-gradient launches (40 / 24 / 24 pixel slices per level-0 flow), two workgroup rounds of the level-0
+    kernels.  Size-independent properties: the training-path loss equals the inference-path bits/dim on the same weights (same kernels
+    modulo the folded scales: bf16 round-off), every gradient is finite, a repeated step reproduces every gradient bit for bit, and the
+    gradient of the batch is the mean of the gradients of its two halves (linearity of the batched sums, fp32 summation order aside)."""
+    from normalizing_flow import calculate_loss, initialize_with_zeros
+    from tests.golden.synth import DEEP
+    B = 512
+    flow, prior, _, _ = build(3, 3, 16, 71)
+    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 71, DEEP)) for k, v in flow.state_dict().items()})
+    prior.load_state_dict({k: T(synth_tensor(k, v.shape, 72, DEEP)) for k, v in prior.state_dict().items()})
+    flow.set_compute("bf16")
+    x = (T(synth_input("train_x", (B, 3, 32, 32), 9)) * 0.4).to(DEV)
+    params = list(flow.parameters()) + list(prior.parameters())
+
+    def grads(xb):
+        for p in params:
+            p.grad = None
+        n = xb.shape[0]
+        ll, logp = initialize_with_zeros(2, n, torch.device(DEV))
+        latents, ll, logp = flow.transform(xb, ll, logp)
+        loss = calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0)
+        loss.backward()
+        return loss.detach().clone(), [p.grad.clone() for p in params]
+    l0, g0 = grads(x)
+    l1, g1 = grads(x)
+    assert all(torch.isfinite(g).all() for g in g0)
+    assert torch.equal(l0, l1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    with torch.no_grad():
+        ll, logp = initialize_with_zeros(2, B, torch.device(DEV))
+        latents, ll, logp = flow.transform(x, ll, logp)
+        bpd = calculate_loss(ll + logp + prior.compute_log_prob(latents[-1]), 32.0, 32 * 32 * 3.0)
+    assert_close(l0, bpd, 1e-4, "training-path loss vs inference-path bits/dim")
+    la, ga = grads(x[: B // 2])
+    lb, gb = grads(x[B // 2:])
+    assert_close(0.5 * (la + lb), l0, 1e-5, "loss of the halves")
+    fro = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+    errs = [fro(0.5 * (a + b), c) for a, b, c in zip(ga, gb, g0) if float(c.abs().max()) > 0]
+    assert max(errs) <= 2e-3, max(errs)
+
+
 @pytest.mark.parametrize("B,direct,chan", [(8, False, 3), (3, True, 3), (37, False, 3), (5, False, 1), (16, True, 1)])
 def test_fused_level_training_forward_matches_the_per_flow_nodes(B, direct, chan):
     """training.FUSED_TRAIN_FORWARD: the forward of every Glow level is ONE persistent launch (nfdp_level_fused_train_bf16) that
