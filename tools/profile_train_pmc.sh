@@ -11,7 +11,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES S
   rocprofv3 --pmc $pass --output-format csv -d "$OUT/celeba_$name" -- python3 tools/trace_celeba_fwd.py > "$OUT/celeba_$name.log" 2>&1
   echo "pmc pass $name done"
 done
-export NFDP_PMC_KERNEL_RE='pw_gemm_bf16_kernel|wgrad_bf16_dma_kernel|scale_bwd_vec_kernel|coupling_mlp_kernel<[^>]*>|wgrad_reduce_vec_kernel|im2col3x3_bf16_kernel|tap_shift_sum_kernel'
+export NFDP_PMC_KERNEL_RE='wgrad_bf16_multi_kernel|wgrad_reduce_multi_kernel|coupling_bwd_fused_kernel<[^>]*>|coupling_bwd_rs_kernel<[^>]*>|coupling_fused_kernel<[^>]*>|coupling_fused_rs_kernel<[^>]*>|flow_link_bwd_kernel<[^>]*>|coupling_mlp_kernel<[^>]*>|pw_gemm_bf16_kernel|tap_shift_sum_kernel'
 python3 tools/pmc_summary.py "$OUT/train_pmc_summary.json" "$OUT"/train_FETCH_SIZE "$OUT"/train_WRITE_SIZE "$OUT"/train_SQ_WAVE_CYCLES "$OUT"/train_TCC_HIT_sum > /dev/null
 python3 tools/pmc_summary.py "$OUT/celeba_pmc_summary.json" "$OUT"/celeba_FETCH_SIZE "$OUT"/celeba_WRITE_SIZE "$OUT"/celeba_SQ_WAVE_CYCLES "$OUT"/celeba_TCC_HIT_sum > /dev/null
 ls "$OUT"/*.json
