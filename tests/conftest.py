@@ -22,3 +22,22 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured parity figures (tests.util.record) -> gpurun_out/parity_metrics.json, merged over test runs."""
+    import json
+    from tests.util import _METRICS
+    if not _METRICS:
+        return
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    path = os.path.join(out, "parity_metrics.json")
+    old = {}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+        except Exception:
+            old = {}
+    old.update(_METRICS)
+    json.dump(old, open(path, "w"), indent=1, sort_keys=True)

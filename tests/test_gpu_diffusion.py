@@ -36,6 +36,72 @@ def test_unet_forward_golden(dg, tag):
     assert_close(yb, dg[f"unet{tag}_y"], 3e-2, "unet bf16")
 
 
+@torch.no_grad()
+def test_unet_celeba_part_golden():
+    """The U-Net of BASELINE configs[4]'s first latent part (6x64x64, dim_mults [1,2,2], groups 16) against the REFERENCE's outputs
+    (tests/golden/unet_celeba.npz): the chunked linear-attention core (n = 4096), LDS-staged 64x64 GroupNorm groups, full attention
+    at n = 256; forward, p_losses and one p_sample with the recorded noise."""
+    from diffusion_prior import GaussianDiffusion
+    cg = load_golden("unet_celeba.npz")
+    m = meta_of(cg)
+    x, t, eps = T(cg["x"]).to(DEV), T(cg["t"]).to(DEV), T(cg["eps"]).to(DEV)
+
+    def unet(compute):
+        from diffusion_prior import Unet
+        u = Unet(dim=64, dim_mults=tuple(m["mults"]), channels=m["ch"], resnet_block_groups=m["groups"], compute=compute)
+        u.load_state_dict(synth_sd(m["spec"], 27), strict=True)
+        return u.to(DEV)
+
+    u = unet("f32")
+    assert_close(u(x, t), cg["y"], TOL, "unet 6x64x64 f32")
+    assert_close(unet("bf16")(x, t), cg["y"], 3e-2, "unet 6x64x64 bf16")
+    d = GaussianDiffusion(u, image_size=64, timesteps=1000, beta_schedule="cosine", loss_type="l2", auto_normalize=False).to(DEV)
+    assert_close(d.p_losses(x * 0.8, t, noise=eps), cg["p_losses"], TOL, "p_losses 6x64x64")
+    img, x0 = d.p_sample(x * 0.8, int(t[0]), noise=T(cg["psample_noise"]).to(DEV))
+    assert_close(img, cg["psample_img"], TOL, "p_sample img 6x64x64")
+    assert_close(x0, cg["psample_x0"], TOL, "p_sample x0 6x64x64")
+
+
+@torch.no_grad()
+def test_config3_mnist_diffusion_prior_end_to_end():
+    """BASELINE configs[3] as one chain: frozen Glow L3 K4 on 1x32x32 encodes -> three dim-64 U-Net priors -> T = 1000 ancestral
+    reverse chain per latent part (hipGraph-captured step, parts interleaved on their own streams) -> Glow.sample decodes.
+    Untrained weights, so the check is finiteness, shapes and bitwise determinism under a fixed seed; the single steps and short
+    loops are pinned against the reference in the tests above."""
+    from normalizing_flow import NFBackbone
+    from diffusion_prior import DiffusionPrior, IdentityFormater
+    from tests.golden.synth import synth_tensor
+    B = 4
+    nf = NFBackbone(None, in_channel=1, L=3, K=4, learn_prior_mean_logs=True, freeze_flow=True)
+    nf.model.load_state_dict({k: T(synth_tensor(k, v.shape, 1)) for k, v in nf.model.state_dict().items()}, strict=True)
+    fmt = IdentityFormater(3, 1, 32)
+    shapes = fmt.get_input_shapes()
+    prior = DiffusionPrior(latent_formater=fmt, unet_kwargs=dict(dim=64, dim_mults=(1, 2), resnet_block_groups=8),
+                           diffusion_kwargs=dict(timesteps=1000, sampling_timesteps=1000, loss_type="l2", beta_schedule="cosine"),
+                           image_sizes=[int(s[1]) for s in shapes], latent_channels=[int(s[0]) for s in shapes])
+    g = torch.Generator().manual_seed(8)
+    for p in prior.parameters():                                    # away from the zero-output init
+        p.data.add_(0.02 * torch.randn(p.shape, generator=g).to(DEV))
+    x = torch.rand(B, 1, 32, 32, generator=g).to(DEV) - 0.5
+    lat, ldj = nf.transform(x, torch.zeros(B, dtype=torch.float64, device=DEV))
+    assert torch.isfinite(ldj).all()
+    losses = prior(lat)
+    assert len(losses) == 3 and all(torch.isfinite(l) for l in losses)
+    prior.sample_latents(B)                                         # captures the step graphs
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(2024)
+        zs = prior.sample_latents(B)
+        img = nf.sample(zs)
+        torch.cuda.synchronize()
+        runs.append([z.clone() for z in zs] + [img.clone()])
+    assert [tuple(z.shape) for z in runs[0][:3]] == [(B, *[int(v) for v in s]) for s in shapes]
+    assert runs[0][3].shape == (B, 1, 32, 32)
+    for a, b in zip(*runs):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+    assert all(float(z.abs().max()) <= 1.0 + 1e-6 for z in runs[0][:3])      # x0 clamp of the last step (:700-701)
+
+
 def make_diffusion(dg, timesteps=1000, **kw):
     from diffusion_prior import GaussianDiffusion
     u = make_unet(meta_of(dg)["m0"])

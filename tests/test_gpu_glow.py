@@ -7,7 +7,7 @@ import torch
 
 import nfdp_hip as K
 from oracle import nf_oracle as O
-from tests.util import load_golden, meta_of, synth_sd, T, assert_close, relerr
+from tests.util import load_golden, meta_of, synth_sd, T, assert_close, relerr, relerr_elem, record
 from tests.golden.synth import synth_tensor, images_5bit, DEEP
 
 pytestmark = pytest.mark.gpu
@@ -28,14 +28,18 @@ def build(m, compute="f32"):
     return flow, prior
 
 
-@pytest.mark.parametrize("tag", ["M", "N", "D"])
+@pytest.mark.parametrize("tag", ["M", "N", "D", "C"])
 @torch.no_grad()
 def test_glow_forward_nll_golden(tag):
+    """Reference outputs (tools/make_goldens.py).  C = BASELINE configs[4]'s image size and depth: 3x128x128, L = 5 (K = 2), whose
+    64x64 / 32x32 levels run `coupling_mlp_kernel` and whose 16x16 / 8x8 / 4x4 levels carry C = 48 / 96 / 192."""
     from normalizing_flow import calculate_loss
     g = load_golden(f"glow_{tag}.npz")
     m = meta_of(g)
+    size = m.get("size", 32)
     flow, prior = build(m)
     x = T(g["x"]).to(DEV)
+    assert x.shape[-1] == size
     ldj, logp = z64(m["B"]), z64(m["B"])
     zs, ldj_r, logp_r = flow.transform(x, ldj, logp)                     # trainer.py:155
     assert ldj_r is ldj and logp_r is logp                                # in-place accumulators, as the reference
@@ -46,14 +50,43 @@ def test_glow_forward_nll_golden(tag):
     logp += prior.compute_log_prob(zs[-1])                                # trainer.py:156
     assert_close(ldj, g["ldj"], TOL, "ldj")
     assert_close(logp, g["logp"], TOL, "logp")
-    bpd = calculate_loss(ldj + logp, 32.0, 32 * 32 * 3.0)                 # trainer.py:157-161
+    bpd = calculate_loss(ldj + logp, 32.0, size * size * 3.0)             # trainer.py:157-161
     assert_close(bpd, g["bpd"], TOL, "bpd")
     # NFBackbone path: logp=None
     zs2, _, none = flow.transform(x, z64(m["B"]), None)
     assert none is None and all(torch.equal(a, b) for a, b in zip(zs, zs2))
 
 
-@pytest.mark.parametrize("tag", ["M", "N", "D"])
+BF16_Z_TOL = 3e-2       # bf16 MFMA operands (8-bit mantissa), fp32 accumulation and flow state: latents / pixels at the 1e-2 level
+BF16_BPD_TOL = 1e-4     # ... while bits/dim (a mean over ~3k log terms per image) stays inside BASELINE.json's gate
+
+
+@pytest.mark.parametrize("tag", ["M", "N", "D", "C"])
+@torch.no_grad()
+def test_glow_bf16_mode_against_reference_goldens(tag):
+    """The bf16 speed mode (fused flow-step kernels; `coupling_mlp_kernel` at the 64x64 / 32x32 levels of C) against the REFERENCE's
+    outputs, forward + NLL and both inverses, at the separately stated bf16 tolerances."""
+    from normalizing_flow import calculate_loss
+    g = load_golden(f"glow_{tag}.npz")
+    m = meta_of(g)
+    size = m.get("size", 32)
+    flow, prior = build(m, "bf16")
+    x = T(g["x"]).to(DEV)
+    ldj, logp = z64(m["B"]), z64(m["B"])
+    zs, _, _ = flow.transform(x, ldj, logp)
+    for i, z in enumerate(zs):
+        assert_close(z, g[f"z{i}"], BF16_Z_TOL, f"bf16 z{i}")
+    logp += prior.compute_log_prob(zs[-1])
+    assert_close(ldj, g["ldj"], 1e-3, "bf16 ldj")
+    assert_close(logp, g["logp"], 1e-3, "bf16 logp")
+    assert_close(calculate_loss(ldj + logp, 32.0, size * size * 3.0), g["bpd"], BF16_BPD_TOL, "bf16 bpd")
+    gz = [T(g[f"z{i}"]).to(DEV) for i in range(m["L"])]
+    assert_close(flow.invert(gz), g["x_rec"], BF16_Z_TOL, "bf16 x_rec")
+    eps = [T(g[f"eps{j}"]).to(DEV) for j in range(m["L"] - 1)]
+    assert_close(flow.invert([gz[-1]], temperature=0.7, eps=eps), g["x_sampled"], BF16_Z_TOL, "bf16 x_sampled")
+
+
+@pytest.mark.parametrize("tag", ["M", "N", "D", "C"])
 @torch.no_grad()
 def test_glow_inverse_and_sampling_golden(tag):
     from normalizing_flow import postprocess_batch
@@ -159,8 +192,64 @@ def test_north_star_full_size_properties():
                            [e.double() for e in eps] if kw else None)
         ref32 = O.glow_inv(lat, sd, 3, 16, kw.get("temperature", 1.0), eps if kw else None)
         hip = flow.invert([z.to(DEV) for z in lat], **({"temperature": 0.7, "eps": [e.to(DEV) for e in eps]} if kw else {}))
-        e_hip, e_ref = relerr(hip, truth), relerr(ref32, truth)
+        e_hip, e_ref = relerr_elem(hip, truth), relerr_elem(ref32, truth)
+        record(f"north_star_f32_{what.replace(' ', '_')}_vs_fp64_truth", e_hip)
+        record(f"north_star_f32_oracle_{what.replace(' ', '_')}_vs_fp64_truth", e_ref)
         assert e_hip <= max(TOL, 2 * e_ref), f"{what}: hip {e_hip:.2e} vs fp64 truth, fp32 oracle {e_ref:.2e}"
+
+
+BF16_DEEP_Z_TOL = 5e-2     # 48 flows of bf16-operand networks: latents / pixels (fp32 state, 8-bit-mantissa network inputs)
+
+
+@torch.no_grad()
+def test_north_star_bf16_benched_path_against_oracle():
+    """The path `bench.py` times - bf16 fused level kernels, L3 K16, B = 512 (BASELINE configs[1]) - compared DIRECTLY with the
+    oracle on image slices of the same batch (first and last four: both ends of the grid): per-sample ldj / logp at 1e-3, bits/dim
+    inside BASELINE.json's 1e-4 gate, latents at the stated bf16 tolerance; and the bf16 inverse and sampling inverse at K = 16
+    against the oracle evaluated in fp64."""
+    from normalizing_flow import calculate_loss
+    flow, prior = _north_star("bf16")
+    x_np, _, _ = images_5bit("ns", (512, 3, 32, 32), 7)
+    x = T(x_np).to(DEV)
+    ldj, logp = z64(512), z64(512)
+    zs, _, _ = flow.transform(x, ldj, logp)
+    logp += prior.compute_log_prob(zs[-1])
+    sd = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
+    psd = {k: v.detach().cpu() for k, v in prior.state_dict().items()}
+    for lo in (0, 508):
+        sl = slice(lo, lo + 4)
+        zo, ldj_o, logp_o, bpd_o = O.fwd_nll(T(x_np[sl]), sd, psd, 3, 16)
+        for i, (a, b) in enumerate(zip(zs, zo)):
+            record(f"north_star_bf16_z{i}_vs_oracle_{lo}", relerr_elem(a[sl], b))
+            assert_close(a[sl], b, BF16_DEEP_Z_TOL, f"bf16 z{i} vs oracle")
+        assert_close(ldj[sl], ldj_o, 1e-3, "bf16 ldj vs oracle")
+        assert_close(logp[sl], logp_o, 1e-3, "bf16 logp vs oracle")
+        bpd4 = calculate_loss((ldj + logp)[sl].contiguous(), 32.0, 3072.0)
+        record(f"north_star_bf16_bpd_vs_oracle_{lo}", relerr(bpd4, bpd_o))
+        assert_close(bpd4, bpd_o, BF16_BPD_TOL, "bf16 bpd vs oracle")
+    # inverse with all latents / with Split sampling, inputs = the ORACLE's latents of the first four images, truth = fp64 oracle
+    sd64 = {k: v.double() for k, v in sd.items()}
+    zo, _, _, _ = O.fwd_nll(T(x_np[:4]), sd, psd, 3, 16)
+    eps = [torch.randn(4, 12, 8, 8, generator=torch.Generator().manual_seed(3)),
+           torch.randn(4, 6, 16, 16, generator=torch.Generator().manual_seed(4))]
+    # the batch the kernels see is the full 512 (rows 4.. are this run's own latents): the benched grid, not a 4-image launch
+    for what, use_eps in (("x_rec", False), ("sampled pixels", True)):
+        lat_o = [z.clone() for z in zo] if not use_eps else [zo[-1].clone()]
+        truth = O.glow_inv([z.double() for z in lat_o], sd64, 3, 16, 0.7 if use_eps else 1.0,
+                           [e.double() for e in eps] if use_eps else None)
+        full = [z.clone() for z in zs] if not use_eps else [zs[-1].clone()]
+        for f, o in zip(full, lat_o):
+            f[:4] = o.to(DEV)
+        kw = {}
+        if use_eps:
+            big = [torch.randn(512, *e.shape[1:], generator=torch.Generator().manual_seed(9)).to(DEV) for e in eps]
+            for bg, e in zip(big, eps):
+                bg[:4] = e.to(DEV)
+            kw = {"temperature": 0.7, "eps": big}
+        hip = flow.invert(full, **kw)[:4]
+        e = relerr_elem(hip, truth)
+        record(f"north_star_bf16_{what.replace(' ', '_')}_vs_fp64_truth", e)
+        assert e <= BF16_DEEP_Z_TOL, f"bf16 {what}: {e:.2e} vs the fp64 oracle"
 
 
 @torch.no_grad()

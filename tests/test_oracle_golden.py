@@ -103,14 +103,16 @@ def test_pre_post_bpd(ops):
         O.output_shapes(3, 3, 30 // 2 * 2 + 1)
 
 
-@pytest.mark.parametrize("tag", ["M", "N", "D"])
+@pytest.mark.parametrize("tag", ["M", "N", "D", "C"])
 def test_glow_composite(tag):
+    """M / N / D: 32x32 inputs; C: BASELINE configs[4]'s image size and depth (3x128x128, L = 5; K reduced to 2)."""
     g = load_golden(f"glow_{tag}.npz")
     m = meta_of(g)
     L, K, B, C = m["L"], m["K"], m["B"], m["C"]
     sd = synth_sd(m["flow_spec"], m["seed"])
     psd = synth_sd(m["prior_spec"], m["seed"])
     x = T(g["x"])
+    assert x.shape[-1] == m.get("size", 32)
     zs, ldj, logp, bpd = O.fwd_nll(x, sd, psd, L, K)
     for i, z in enumerate(zs):
         assert_close(z, g[f"z{i}"], TOL, f"z{i}")
@@ -178,6 +180,22 @@ def test_unet_forward(dg, tag):
     sd = synth_sd(m["spec"], 21)
     y = D.unet_forward(T(dg[f"unet{tag}_x"]), T(dg[f"unet{tag}_t"]), sd, 64, m["mults"], m["groups"])
     assert_close(y, dg[f"unet{tag}_y"], 1e-5, "unet")
+
+
+def test_unet_celeba_part():
+    """The U-Net of BASELINE configs[4]'s first latent part (6x64x64, dim_mults [1,2,2], groups 16): forward, p_losses and one
+    p_sample against the reference's outputs (tools/make_goldens.py celeba)."""
+    cg = load_golden("unet_celeba.npz")
+    m = meta_of(cg)
+    sd = synth_sd(m["spec"], 27)
+    model = lambda x, t: D.unet_forward(x, t, sd, 64, m["mults"], m["groups"])
+    x, t, eps = T(cg["x"]), T(cg["t"]), T(cg["eps"])
+    assert_close(model(x, t), cg["y"], 1e-5, "unet 6x64x64")
+    buf = D.diffusion_buffers("cosine", 1000)
+    assert_close(D.p_losses(buf, model, x * 0.8, t, eps, "l2"), cg["p_losses"], 1e-5, "p_losses")
+    img, xs = D.p_sample(buf, model, x * 0.8, int(t[0]), T(cg["psample_noise"]))
+    assert_close(img, cg["psample_img"], 1e-5, "p_sample img")
+    assert_close(xs, cg["psample_x0"], 1e-5, "p_sample x0")
 
 
 def test_diffusion_process(dg):

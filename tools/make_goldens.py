@@ -131,14 +131,15 @@ def gen_ops():
 
 # ------------------------------------------------------------------ Glow composite goldens
 @torch.no_grad()
-def gen_glow(tag, C, L, K, B, seed):
+def gen_glow(tag, C, L, K, B, seed, size=32):
     U = R["nf_utils"]
     flow = R["glow"].Glow(in_channel=C, L=L, K=K)
     prior = R["prior"].GaussianPrior(2 ** (L + 1) * C)
     spec = load_synth(flow, seed)
     pspec = load_synth(prior, seed)
-    x_np, u8, dq = images_5bit(f"glow{tag}", (B, C, 32, 32), seed)
+    x_np, u8, dq = images_5bit(f"glow{tag}", (B, C, size, size), seed)
     x = t(x_np)
+    n_pixel = size * size * 3.0                                         # trainer.py:133-134
     # sanity: same as reference preprocessing  (trainer.py:152-155)
     ref_x = U.preprocess_batch(t(u8).float() / 255.0, 5, 32.0) + t(dq) / 32.0
     assert torch.equal(ref_x, x), (ref_x - x).abs().max()
@@ -146,7 +147,7 @@ def gen_glow(tag, C, L, K, B, seed):
     zs, ldj, logp = flow.transform(x, ldj, logp)
     logp_flow = logp.clone()
     logp = logp + prior.compute_log_prob(zs[-1])
-    bpd = U.calculate_loss(ldj + logp, 32.0, 32 * 32 * 3.0)
+    bpd = U.calculate_loss(ldj + logp, 32.0, n_pixel)
     g = {"x": x_np, "ldj": n(ldj), "logp_flow": n(logp_flow), "logp": n(logp), "bpd": n(bpd)}
     for i, z in enumerate(zs):
         g[f"z{i}"] = n(z)
@@ -157,13 +158,15 @@ def gen_glow(tag, C, L, K, B, seed):
     torch.manual_seed(11)
     xs = flow.invert([zs[-1]], temperature=0.7)
     torch.manual_seed(11)
-    shapes = U.calculate_output_shapes(L, C, 32)
+    shapes = U.calculate_output_shapes(L, C, size)
     eps = [torch.zeros(B, *shapes[i]).normal_() for i in reversed(range(L - 1))]
     g["x_sampled"] = n(xs)
     for j, e in enumerate(eps):
         g[f"eps{j}"] = n(e)
     g["x_sampled_post"] = n(flow.sample([zs[-1]], postprocess_func=lambda v: U.postprocess_batch(v, 32.0), temperature=0.0))
     meta = {"C": C, "L": L, "K": K, "B": B, "seed": seed, "flow_spec": spec, "prior_spec": pspec}
+    if size != 32:
+        meta["size"] = size
     g["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, f"glow_{tag}.npz"), **g)
     print(f"glow_{tag}.npz bpd={float(bpd):.6f}  |z_last|max={float(zs[-1].abs().max()):.3f} "
@@ -278,6 +281,30 @@ def gen_diffusion():
     g["meta"] = np.array(json.dumps(specs))
     np.savez_compressed(os.path.join(OUT, "diffusion.npz"), **g)
     print("diffusion.npz", len(g), "arrays")
+
+
+@torch.no_grad()
+def gen_unet_celeba():
+    """The U-Net of BASELINE configs[4]'s first latent part (6x64x64, dim 64, dim_mults [1,2,2], groups 16; README.md:319-321):
+    n = 4096 positions in the linear attention of the first stage (chunked core), 64x64 GroupNorm groups, full attention at 16x16."""
+    GD = R["gd"]
+    g = {}
+    u = GD.Unet(dim=64, dim_mults=(1, 2, 2), channels=6, resnet_block_groups=16)
+    spec = {"spec": load_synth(u, 27), "ch": 6, "size": 64, "mults": [1, 2, 2], "groups": 16}
+    x = t(synth_input("unetC64", (1, 6, 64, 64), 27))
+    tt = torch.tensor([421], dtype=torch.long)
+    g["x"], g["t"], g["y"] = n(x), n(tt), n(u(x, tt))
+    d = GD.GaussianDiffusion(u, image_size=64, timesteps=1000, beta_schedule="cosine", loss_type="l2", auto_normalize=False)
+    eps = t(synth_input("unetC64eps", (1, 6, 64, 64), 27))
+    g["eps"], g["p_losses"] = n(eps), n(d.p_losses(x * 0.8, tt, noise=eps))
+    torch.manual_seed(421)
+    img, xs = d.p_sample((x * 0.8).clone(), 421)
+    torch.manual_seed(421)
+    g["psample_noise"] = n(torch.randn_like(x))
+    g["psample_img"], g["psample_x0"] = n(img), n(xs)
+    g["meta"] = np.array(json.dumps(spec))
+    np.savez_compressed(os.path.join(OUT, "unet_celeba.npz"), **g)
+    print("unet_celeba.npz", len(g), "arrays, |y|max", float(np.abs(g["y"]).max()))
 
 
 # ------------------------------------------------------------------ objectives pred_x0 / pred_v, self-conditioning, auto_normalize
@@ -478,13 +505,16 @@ def gen_train(C=3, L=3, K=2, B=2, seed=2):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "glow", "init", "diffusion", "variants", "embeddings", "vlb", "train"]
+    which = sys.argv[1:] or ["ops", "glow", "celeba", "init", "diffusion", "variants", "embeddings", "vlb", "train"]
     if "ops" in which:
         gen_ops()
     if "glow" in which:
         gen_glow("M", 1, 3, 4, 4, 1)      # BASELINE configs[0] shape (MNIST 1x32x32, L3 K4)
         gen_glow("N", 3, 3, 2, 2, 2)      # north-star shape with reduced K
         gen_glow("D", 3, 5, 1, 2, 3)      # CelebA depth (BASELINE configs[4]: L = 5 -> C up to 192) on 32x32 inputs
+    if "celeba" in which:
+        gen_glow("C", 3, 5, 2, 1, 6, size=128)   # BASELINE configs[4] image size and depth (3x128x128, L5), K reduced to 2
+        gen_unet_celeba()                        # ... and the U-Net of its first latent part (6x64x64, mults [1,2,2], groups 16)
     if "init" in which:
         gen_glow_init()
     if "diffusion" in which:
