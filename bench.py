@@ -38,13 +38,19 @@ PEAK = {"bf16": 2500.0, "f32": 157.3}      # dense MFMA TFLOP/s, /opt/skills/gui
 HBM_PEAK_GBS = 8000.0
 
 
-def build_models(L, K, compute, device, seed=1):
+def build_models(L, K, compute, device, seed=1, init="synthetic"):
+    """init "synthetic": the deterministic trained-like weights (identical on every rank by construction).
+    init "data": the reference's initial state - `Glow(...)` as constructed (each rank draws its OWN random QR factors for the 1x1
+    convs, transforms.py:112-114; zero ZeroConvs; ActNorms uninitialised) - left for the caller to initialise from data and
+    synchronise across ranks (nfdp_hip.dist.data_dependent_init)."""
     from normalizing_flow import Glow, GaussianPrior
     from normalizing_flow import glow as _glow
     _glow.set_weight_term_cache(False)          # every timed step recomputes the 1x1-conv log-dets / inverses, as the reference does
     from tests.golden.synth import synth_tensor, DEEP
     flow = Glow(in_channel=3, L=L, K=K, compute=compute)
     prior = GaussianPrior(2 ** (L + 1) * 3)
+    if init == "data":
+        return flow.to(device), prior.to(device), None, None
     fsd = {k: torch.from_numpy(np.array(synth_tensor(k, v.shape, seed, DEEP))) for k, v in flow.state_dict().items()}
     psd = {k: torch.from_numpy(np.array(synth_tensor(k, v.shape, seed, DEEP))) for k, v in prior.state_dict().items()}
     flow.load_state_dict(fsd)
@@ -166,10 +172,19 @@ def train_bench(args, rank, world, device, barrier):
     """One training step per iteration, written like the reference's loop body (normalizing_flow/trainer.py:152-167)."""
     import nfdp_hip as KH
     from nfdp_hip.optim import FusedAdam
-    from nfdp_hip.dist import FlatGradAllReduce, max_over_ranks
+    from nfdp_hip.dist import FlatGradAllReduce, max_over_ranks, broadcast_module, data_dependent_init
     from normalizing_flow import calculate_loss, initialize_with_zeros
-    flow, prior, _, _ = build_models(args.L, args.K, args.compute, device)
+    if args.init == "data":
+        torch.manual_seed(1000 + rank)         # every replica draws its own 1x1-conv factors, as independent processes would
+    flow, prior, _, _ = build_models(args.L, args.K, args.compute, device, init=args.init)
     _, _, u8_d, noise_d = make_batch(args.batch, rank, device)
+    if args.init == "data":
+        # utils.py:275-292 for replicas: rank 0 runs the data-dependent pass on its first batch, every rank takes the result
+        # (--init-mode global: every rank runs it on its shard with the ActNorm moments all-reduced = the global first batch)
+        x0 = KH.as_nchw(KH.preprocess_u8(u8_d, noise_d, 5))
+        data_dependent_init(flow, x0, src=0, mode=args.init_mode)
+    for m in (flow, prior):                    # replicas start from rank 0's state whatever the initialisation was
+        broadcast_module(m, src=0)
     params = list(flow.parameters()) + list(prior.parameters())
     # direct_grads=True: the backward launches add parameter gradients straight into the flat buffer; no reducer hangs on
     # autograd's AccumulateGrad nodes - FlatGradAllReduce averages the buffer in place after backward
@@ -200,7 +215,10 @@ def train_bench(args, rank, world, device, barrier):
     # issues one call per step (eager launching takes ~37 ms of host time for 24 ms of kernels).  One process: the whole step is one
     # graph.  Several ranks: forward + backward is one graph, the optimizer another, and the RCCL all-reduce of the flat gradient
     # buffer runs between the two replays, outside any capture.
-    graphed = not args.no_graph
+    # Several ranks: eager launches by default - no run of this code over RCCL with a live process group around a capture has
+    # been recorded yet; `--graph-multi` opts into the captured form (forward + backward | all-reduce | optimizer).
+    graphed = not args.no_graph and (world == 1 or args.graph_multi)
+    cap_kw = {"capture_error_mode": "thread_local"} if world > 1 else {}      # RCCL's watchdog thread may call into HIP during a capture
     if graphed and world == 1:
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -214,9 +232,9 @@ def train_bench(args, rank, world, device, barrier):
     elif graphed:
         torch.cuda.synchronize()
         g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fb):
+        with torch.cuda.graph(g_fb, **cap_kw):
             static_loss = fwd_bwd()
-        with torch.cuda.graph(g_opt):
+        with torch.cuda.graph(g_opt, **cap_kw):
             opt.step()
         def run():
             g_fb.replay()
@@ -248,7 +266,8 @@ def train_bench(args, rank, world, device, barrier):
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "optimizer": "nfdp fused clip+Adam (flat buffers)",
                        "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (forward+backward | all-reduce | optimizer)") if graphed else "eager",
-                       "gradient_allreduce": "in place on the flat gradient buffer, 32 MiB slices, after backward" if world > 1 else "none"},
+                       "gradient_allreduce": "in place on the flat gradient buffer (SUM), 32 MiB slices, after backward; 1/world in the clip pass" if world > 1 else "none",
+                       "init": args.init + (f" ({args.init_mode}: nfdp_hip.dist.data_dependent_init)" if args.init == "data" else " (identical on every rank)") + ", then broadcast from rank 0"},
             "loss_bits_per_dim": round(float(loss), 6) if bool(torch.isfinite(loss)) else None,
             "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
 
@@ -279,7 +298,7 @@ def inverse_bench(args, rank, world, device, barrier):
         if graphed:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
                 out = inv()
             run = g.replay
             run()
@@ -320,6 +339,12 @@ def main():
     ap.add_argument("--train", action="store_true",
                     help="time the TRAINING step instead (BASELINE configs[2]: trainer.py:152-167 body, HIP training path in the "
                          "--compute mode (fp32 activations), fused clip+Adam, RCCL all-reduce of the flat gradient buffer for N>1); not the headline metric")
+    ap.add_argument("--init", default="synthetic", choices=["synthetic", "data"],
+                    help="--train: 'synthetic' trained-like weights, or 'data' = the reference's initial state (random 1x1 convs, zero "
+                         "ZeroConvs) + data-dependent ActNorm init on the first batch, synchronised across ranks")
+    ap.add_argument("--init-mode", default="rank0", choices=["rank0", "global"],
+                    help="--init data: ActNorm statistics of rank 0's first batch broadcast (parity semantics) or of the global batch (all-reduced moments)")
+    ap.add_argument("--graph-multi", action="store_true", help="--train with several ranks: replay hipGraphs around the all-reduce instead of eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -381,7 +406,8 @@ def main():
                 torch.cuda.current_stream().wait_stream(warm)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                # with a live RCCL process group its watchdog thread may call into HIP while this thread captures
+                with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
                     g_out = step(flow, prior, u8_d, noise_d)
 
                 def run_step():

@@ -479,6 +479,12 @@ int nfdp_fused_adam_step_dev_f32(float* p, float* g, float* m, float* v, long n,
 int nfdp_fused_adam_step_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int adamw, long step, void* ws,
                              float* norm_out, nfdp_stream_t stream);
+/* Data-parallel form: g holds the all-reduced SUM over the ranks; grad_scale = 1/world (0 < grad_scale <= 1) is applied where the
+ * clip pass / the Adam pass read the gradient anyway (g is left holding the averaged, clipped gradient, as torch's in-place clips
+ * leave it) - no separate pass over the buffer.  Everything else as nfdp_fused_adam_step_dev_f32. */
+int nfdp_fused_adam_step_dev_scaled_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm,
+                                        double* hyper, float beta1, float beta2, float eps, float weight_decay, int adamw,
+                                        float grad_scale, void* ws, float* norm_out, nfdp_stream_t stream);
 
 /* ---------------------------------------------------------------- backward of the U-Net glue ops (diffusion-prior training:
  * loss.backward() of diffusion_prior/trainer.py:134-150 through GaussianDiffusion.p_losses); the convolutions use

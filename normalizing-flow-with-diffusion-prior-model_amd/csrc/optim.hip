@@ -12,17 +12,17 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kMaxPartials = 1024;
 
-// g[i] = clamp(g[i], -clip, clip) for i < n_clip (clip <= 0: no clamp); partial[blk] = sum of the clamped squares
-__global__ void __launch_bounds__(kBlock) clip_value_sumsq_kernel(float* __restrict__ g, long n_clip, float clip,
+// g[i] = clamp(scale * g[i], -clip, clip) for i < n_clip (clip <= 0: no clamp); partial[blk] = sum of the clamped squares.
+// scale = 1/world turns the all-reduced SUM of the data-parallel ranks into the average in the pass that reads the gradient anyway.
+__global__ void __launch_bounds__(kBlock) clip_value_sumsq_kernel(float* __restrict__ g, long n_clip, float clip, float scale,
                                                                  double* __restrict__ partial) {
     __shared__ double red[kBlock / 64];
     double acc = 0.0;
     for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < n_clip; i += (long)gridDim.x * kBlock) {
         float v = g[i];
-        if (clip > 0.f) {
-            v = fminf(fmaxf(v, -clip), clip);
-            g[i] = v;
-        }
+        if (scale != 1.0f) v *= scale;
+        if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
+        if (clip > 0.f || scale != 1.0f) g[i] = v;
         acc += (double)v * (double)v;
     }
     acc = wave_sum_d(acc);
@@ -38,7 +38,8 @@ __global__ void __launch_bounds__(kBlock) adam_step_kernel(float* __restrict__ p
                                                           const double* __restrict__ partial, int n_partial, float max_norm,
                                                           float lr, float beta1, float beta2, float eps, float weight_decay,
                                                           int adamw, float bias_c1, float bias_c2_sqrt,
-                                                          float* __restrict__ norm_out, const double* __restrict__ hyper) {
+                                                          float* __restrict__ norm_out, const double* __restrict__ hyper,
+                                                          float grad_scale, long scaled_upto) {
     __shared__ float coef_s, hyp_s[3];
     if (threadIdx.x == 0) {
         if (hyper != nullptr) {                  // device-resident learning rate and step count: the launch is replayable in a hipGraph
@@ -66,6 +67,10 @@ __global__ void __launch_bounds__(kBlock) adam_step_kernel(float* __restrict__ p
     const float step_size = lr / hyp_s[1];
     for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
         float gi = g[i];
+        if (i >= scaled_upto && grad_scale != 1.0f) {                      // elements the clip pass did not visit: 1/world here
+            gi *= grad_scale;
+            g[i] = gi;
+        }
         if (i < n_clip && coef != 1.0f) {
             gi *= coef;
             g[i] = gi;                                                     // clip_grad_norm_ scales the gradients in place
@@ -94,7 +99,7 @@ extern "C" size_t nfdp_fused_adam_ws_bytes(void) { return kMaxPartials * sizeof(
 
 static int fused_adam_launch(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int adamw, long step, double* hyper, void* ws,
-                             float* norm_out, nfdp_stream_t stream);
+                             float* norm_out, nfdp_stream_t stream, float grad_scale = 1.0f);
 
 extern "C" int nfdp_fused_adam_step_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value,
                                         float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
@@ -112,26 +117,40 @@ extern "C" int nfdp_fused_adam_step_dev_f32(float* p, float* g, float* m, float*
                              norm_out, stream);
 }
 
+extern "C" int nfdp_fused_adam_step_dev_scaled_f32(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value,
+                                                   float max_norm, double* hyper, float beta1, float beta2, float eps,
+                                                   float weight_decay, int adamw, float grad_scale, void* ws, float* norm_out,
+                                                   nfdp_stream_t stream) {
+    NFDP_REQUIRE(hyper, NFDP_EINVAL, "fused_adam_step_dev_scaled: null hyper");
+    NFDP_REQUIRE(grad_scale > 0.f && grad_scale <= 1.f, NFDP_EINVAL, "fused_adam_step_dev_scaled: grad_scale=%g (expected 1/world)",
+                 (double)grad_scale);
+    return fused_adam_launch(p, g, m, v, n, n_clip, clip_value, max_norm, 0.f, beta1, beta2, eps, weight_decay, adamw, 1, hyper, ws,
+                             norm_out, stream, grad_scale);
+}
+
 static int fused_adam_launch(float* p, float* g, float* m, float* v, long n, long n_clip, float clip_value, float max_norm, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int adamw, long step, double* hyper, void* ws,
-                             float* norm_out, nfdp_stream_t stream) {
+                             float* norm_out, nfdp_stream_t stream, float grad_scale) {
     NFDP_REQUIRE(p && g && m && v && ws, NFDP_EINVAL, "fused_adam_step: null pointer");
     NFDP_REQUIRE(n > 0 && n_clip >= 0 && n_clip <= n, NFDP_ESHAPE, "fused_adam_step: bad sizes n=%ld n_clip=%ld", n, n_clip);
     hipStream_t s = as_stream(stream);
     if (hyper) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, s, hyper);      // step count += 1 on the device
     double* partial = reinterpret_cast<double*>(ws);
     int nblk = 1;
+    long scaled_upto = 0;                                  // gradient elements [0, scaled_upto) get grad_scale in the clip pass
     if (n_clip > 0 && (clip_value > 0.f || max_norm > 0.f)) {
         long gsz = cdiv(n_clip, (long)kBlock * 8);
         nblk = (int)(gsz > kMaxPartials ? kMaxPartials : (gsz < 1 ? 1 : gsz));
-        hipLaunchKernelGGL(clip_value_sumsq_kernel, dim3(nblk), dim3(kBlock), 0, s, g, n_clip, clip_value, partial);
+        hipLaunchKernelGGL(clip_value_sumsq_kernel, dim3(nblk), dim3(kBlock), 0, s, g, n_clip, clip_value, grad_scale, partial);
+        scaled_upto = n_clip;
     } else {
         max_norm = 0.f;
     }
     const float bias_c1 = (float)(1.0 - pow((double)beta1, (double)step));
     const float bias_c2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(adam_step_kernel, dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, s, p, g, m, v, n, n_clip, partial, nblk,
-                       max_norm, lr, beta1, beta2, eps, weight_decay, adamw, bias_c1, bias_c2_sqrt, norm_out, hyper);
+                       max_norm, lr, beta1, beta2, eps, weight_decay, adamw, bias_c1, bias_c2_sqrt, norm_out, hyper, grad_scale,
+                       scaled_upto);
     NFDP_CHECK_LAUNCH("fused_adam_step");
     return NFDP_OK;
 }

@@ -3,8 +3,16 @@
 The flow treats samples independently, so forward/NLL and sampling shard over the batch with no
 exchange; the only collectives are the global bits/dim — all-reduce(SUM) of the fp64 pair (sum_b bpd_b, count) —
 and MAX of a timing.  Backend "nccl" is RCCL over xGMI on MI355X; "gloo" drives the CPU tests.
+
+Replica initialisation (SURVEY.md §8e "Init"): the reference's initial state is random (`InvConv2d` draws a QR factor,
+transforms.py:112-114) and data-dependent (`ActNorm`, transforms.py:74-78, through `data_dependent_nf_initialization`,
+utils.py:275-292), so replicas that initialise on their own diverge from step 0.  `broadcast_module` copies rank `src`'s parameters
+and buffers to every rank; `data_dependent_init` runs the reference's initialisation pass either on rank `src`'s batch alone and
+broadcasts the result (mode "rank0": exactly the single-process semantics with that batch - the parity mode), or on every rank's
+shard with each ActNorm's moments all-reduced as it initialises (mode "global": the statistics of the GLOBAL first batch).
 """
-from typing import Tuple
+import contextlib
+from typing import Iterable, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -34,6 +42,130 @@ def max_over_ranks(value: float, device) -> float:
             t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def _multi(group=None) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, group=None) -> int:
+    """In-place broadcast of rank `src`'s values, coalesced into ONE flat collective per dtype (a Glow L3 K16 has 726 state
+    entries: 88 MB fp32 go out as one xGMI-sized message, the uint8 flags as another).  Returns the number of collectives."""
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    if not _multi(group) or not tensors:
+        return 0
+    host = dist.get_backend(group) == "gloo"
+    n = 0
+    with torch.no_grad():
+        for dtype in sorted({t.dtype for t in tensors}, key=str):           # same order on every rank
+            part = [t for t in tensors if t.dtype == dtype]
+            flat = torch.cat([t.detach().reshape(-1) for t in part])
+            dev = flat.device
+            if host and flat.is_cuda:                                        # CPU rehearsal backend
+                flat = flat.cpu()
+            dist.broadcast(flat, src=src, group=group)
+            n += 1
+            flat = flat.to(dev)
+            off = 0
+            for t in part:
+                k = t.numel()
+                t.copy_(flat[off:off + k].view(t.shape))                     # bumps the tensor version: layout caches / init flags follow
+                off += k
+    return n
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0, group=None, buffers: bool = True) -> int:
+    """Every parameter (and buffer: ActNorm's `is_initialized`, the diffusion schedules) of `module` takes rank `src`'s value.
+    Call it once after construction / checkpoint loading / data-dependent initialisation; a no-op without a process group."""
+    ts = [p.data for p in module.parameters()]
+    if buffers:
+        ts += [b for b in module.buffers()]
+    n = broadcast_tensors(ts, src=src, group=group)
+    if n:
+        from . import bump_param_epoch
+        bump_param_epoch()
+    return n
+
+
+def merge_moments(mean: torch.Tensor, var_unbiased: torch.Tensor, count: float, group=None) -> Tuple[torch.Tensor, torch.Tensor, float]:
+    """Per-channel (mean, unbiased variance, count) of this rank's rows -> those of all ranks' rows together: ONE all-reduce(SUM) of
+    [n, n mean, (n-1) var + n mean^2] in fp64 (the pooled-variance identity, exact up to fp64 round-off)."""
+    m, v = mean.double(), var_unbiased.double()
+    n = float(count)
+    pack = torch.cat([torch.tensor([n], dtype=torch.float64, device=m.device), n * m, (n - 1.0) * v + n * m * m])
+    if _multi(group):
+        dev = pack.device
+        if dist.get_backend(group) == "gloo" and pack.is_cuda:
+            pack = pack.cpu()
+        dist.all_reduce(pack, op=dist.ReduceOp.SUM, group=group)
+        pack = pack.to(dev)
+    c = m.numel()
+    n_all = float(pack[0])
+    mean_all = pack[1:1 + c] / n_all
+    var_all = (pack[1 + c:] - n_all * mean_all * mean_all) / max(n_all - 1.0, 1.0)
+    return mean_all, var_all.clamp_min(0.0), n_all
+
+
+_ACTNORM_SYNC = {"group": None, "active": False}
+
+
+def actnorm_init_sync(scale: torch.Tensor, bias: torch.Tensor, rows: int) -> None:
+    """Called by ActNorm.init_from after the local init kernel when a "global" initialisation pass is running: recover this rank's
+    moments from (scale, bias) = (-log(std + 1e-6), -mean) (transforms.py:76-77), merge them over the ranks and rewrite both."""
+    if not _ACTNORM_SYNC["active"]:
+        return
+    with torch.no_grad():
+        mean = -bias.double().reshape(-1)
+        std = torch.exp(-scale.double().reshape(-1)) - 1e-6
+        mean_all, var_all, _ = merge_moments(mean, std * std, rows, _ACTNORM_SYNC["group"])
+        scale.copy_((-torch.log(var_all.sqrt() + 1e-6)).to(scale.dtype).view(scale.shape))
+        bias.copy_((-mean_all).to(bias.dtype).view(bias.shape))
+
+
+@contextlib.contextmanager
+def global_actnorm_init(group=None):
+    """Inside this context every ActNorm that initialises merges its moments over the ranks (145 small all-reduces for L3 K16,
+    first batch only)."""
+    _ACTNORM_SYNC.update(group=group, active=_multi(group))
+    try:
+        yield
+    finally:
+        _ACTNORM_SYNC.update(group=None, active=False)
+
+
+@torch.no_grad()
+def data_dependent_init(flow: torch.nn.Module, batch: torch.Tensor, src: int = 0, mode: str = "rank0", group=None,
+                        n_bins: Optional[float] = None) -> None:
+    """The reference's `data_dependent_nf_initialization` (utils.py:275-292: one no-grad `flow.transform` of the first batch, which
+    initialises every ActNorm) for replicas.  `batch` is this rank's preprocessed first batch (dequantisation noise of
+    trainer.py:155 is added here when `n_bins` is given).
+
+    mode "rank0": only rank `src` runs the pass, then `broadcast_module(flow, src)` - every replica ends up with what a single
+    process given rank `src`'s batch would have (the parity semantics; also carries rank `src`'s random 1x1-conv weights).
+    mode "global": parameters are broadcast first (so the activations agree), then every rank runs the pass on its own shard with the
+    ActNorm moments merged across ranks: single-process semantics with the GLOBAL first batch."""
+    if mode not in ("rank0", "global"):
+        raise ValueError(f"data_dependent_init: mode {mode!r}")
+    rank = dist.get_rank(group) if _multi(group) else src
+
+    def run():
+        was = flow.training
+        flow.eval()
+        x = batch if n_bins is None else batch + torch.rand_like(batch) / n_bins
+        b = x.shape[0]
+        ldj = torch.zeros(b, dtype=torch.float64, device=x.device)
+        logp = torch.zeros(b, dtype=torch.float64, device=x.device)
+        flow.transform(x, ldj, logp)
+        flow.train(was)
+
+    if mode == "rank0":
+        if rank == src:
+            run()
+        broadcast_module(flow, src=src, group=group)
+    else:
+        broadcast_module(flow, src=src, group=group)
+        with global_actnorm_init(group):
+            run()
 
 
 class BucketedGradAllReduce:
@@ -140,13 +272,29 @@ class BucketedGradAllReduce:
 class FlatGradAllReduce:
     """Gradient averaging on nfdp_hip.optim.FusedAdam's flat gradient buffer: after backward, `finish()` all-reduces the buffer IN PLACE
     in a few large slices (default 32 MiB: three collectives for the 88 MB of Glow L3 K16, sized for xGMI's per-link-bound rings)
-    and scales by 1/world - no hooks, no gather / scatter copies, so the backward launches keep adding parameter gradients straight
-    into the buffer (FusedAdam(direct_grads=True)).  The collectives are asynchronous; they are waited for (on the stream) at the end
-    of finish(), before the clips and the Adam launch read the buffer."""
+    - no hooks, no gather / scatter copies, so the backward launches keep adding parameter gradients straight into the buffer
+    (FusedAdam(direct_grads=True)).  The buffer then holds the SUM over ranks; the 1/world of the average is folded into the
+    optimizer's clip pass (`FusedAdam.grad_scale`, applied where `clip_value_sumsq_kernel` / `adam_step_kernel` read the gradient
+    anyway) instead of a separate pass over the 88 MB.  From construction on, every `optimizer.step()` therefore expects a finish()
+    before it; `remove()` detaches.  The collectives are asynchronous; they are waited for (on the stream) at the end of finish(),
+    before the clips and the Adam launch read the buffer.
 
-    def __init__(self, optimizer, bucket_bytes: int = 32 << 20, group=None):
+    sync_state: at construction the optimizer's flat parameter buffer, both moment buffers and the (lr, step) pair take rank 0's
+    values - replicas built from different seeds or initialised on different batches start identical."""
+
+    def __init__(self, optimizer, bucket_bytes: int = 32 << 20, group=None, sync_state: bool = True):
         self.opt, self.group = optimizer, group
         self.step_elems = max(1, bucket_bytes // 4)
+        if self._active():
+            self.opt.grad_scale = 1.0 / dist.get_world_size(group)
+            if sync_state:
+                n = broadcast_tensors([self.opt.flat_param, self.opt.exp_avg, self.opt.exp_avg_sq, self.opt._hyper], src=0, group=group)
+                if n:
+                    from . import bump_param_epoch
+                    bump_param_epoch()
+
+    def remove(self) -> None:
+        self.opt.grad_scale = 1.0
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -155,7 +303,7 @@ class FlatGradAllReduce:
     def finish(self) -> None:
         if not self._active():
             return
-        flat, world = self.opt.flat_grad, dist.get_world_size(self.group)
+        flat = self.opt.flat_grad
         gloo = dist.get_backend(self.group) == "gloo"
         works = []
         # last slices first: backward finishes the last Glow level's gradients first, and they sit at the end of the buffer
@@ -169,4 +317,3 @@ class FlatGradAllReduce:
                 works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
             w.wait()
-        flat.mul_(1.0 / world)

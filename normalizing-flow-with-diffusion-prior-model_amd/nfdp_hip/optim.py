@@ -42,6 +42,7 @@ class FusedAdam:
             raise ValueError("FusedAdam: parameters must be fp32 tensors on one device")
         self.lr, self.betas, self.eps, self.weight_decay, self.adamw = lr, betas, eps, weight_decay, adamw
         self.clip_value, self.max_norm = clip_value, max_norm
+        self.grad_scale = 1.0          # 1/world under nfdp_hip.dist.FlatGradAllReduce: flat_grad then holds the SUM over the ranks
         self.n = sum(p.numel() for p in self.params)
         self.n_clip = sum(p.numel() for p in self.clipped)
         self.flat_param = torch.empty(self.n, device=dev, dtype=torch.float32)
@@ -88,9 +89,10 @@ class FusedAdam:
             self._hyper[0:1].copy_(torch.tensor([float(self.lr)], dtype=torch.float64), non_blocking=True)
             self._lr_uploaded = float(self.lr)
         b1, b2 = self.betas
-        _call("nfdp_fused_adam_step_dev_f32", _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
-              self.n, self.n_clip, float(self.clip_value or 0.0), float(self.max_norm or 0.0), _ptr(self._hyper), float(b1), float(b2),
-              float(self.eps), float(self.weight_decay), int(self.adamw), _ptr(self._ws), _ptr(self.grad_norm), _stream())
+        _call("nfdp_fused_adam_step_dev_scaled_f32", _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg),
+              _ptr(self.exp_avg_sq), self.n, self.n_clip, float(self.clip_value or 0.0), float(self.max_norm or 0.0), _ptr(self._hyper),
+              float(b1), float(b2), float(self.eps), float(self.weight_decay), int(self.adamw), float(self.grad_scale), _ptr(self._ws),
+              _ptr(self.grad_norm), _stream())
         self._host_steps += 1
         bump_param_epoch()          # parameters changed through an alias: invalidate the kernel-layout weight caches
 
@@ -155,7 +157,20 @@ class FusedAdam:
             raise ValueError(f"FusedAdam.load_state_dict: parameters carry different step counts {sorted(steps)}; "
                              "one flat launch has one bias correction")
         self._hyper[1] = float(steps.pop() if steps else 0)
-        g0 = sd["param_groups"][0]
+        groups = sd["param_groups"]
+        g0 = groups[0]
+        # one flat launch = one plain Adam / AdamW: refuse what it cannot represent instead of loading it as something else
+        for g in groups:
+            if g.get("amsgrad", False) or g.get("maximize", False):
+                raise ValueError("FusedAdam.load_state_dict: the checkpoint's optimizer uses amsgrad / maximize, which the fused "
+                                 "launch does not implement")
+            if "decoupled_weight_decay" in g and bool(g["decoupled_weight_decay"]) != bool(self.adamw):
+                raise ValueError(f"FusedAdam.load_state_dict: checkpoint decoupled_weight_decay={g['decoupled_weight_decay']} but this "
+                                 f"optimizer was built with adamw={self.adamw}")
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in g and k in g0 and tuple(np_flat(g[k])) != tuple(np_flat(g0[k])):
+                    raise ValueError(f"FusedAdam.load_state_dict: param groups differ in {k} ({g0[k]} vs {g[k]}); one flat launch "
+                                     "has one set of hyper-parameters")
         self.lr = float(g0.get("lr", self.lr))
         self.betas = tuple(g0.get("betas", self.betas))
         self.eps = float(g0.get("eps", self.eps))
@@ -168,13 +183,24 @@ class FusedAdam:
         return [_Group(self)]
 
 
+def np_flat(v):
+    return tuple(float(x) for x in v) if isinstance(v, (tuple, list)) else (float(v),)
+
+
 class _Group(dict):
+    """A param-group view: writes to lr / betas / eps / weight_decay reach the optimizer (next step()); the other keys describe what
+    the fused launch is and cannot be changed."""
+    _WRITABLE = {"lr": float, "eps": float, "weight_decay": float, "betas": lambda v: (float(v[0]), float(v[1]))}
+
     def __init__(self, opt):
         super().__init__(opt._param_group())
-        self["params"] = opt.params
+        super().__setitem__("params", opt.params)
         self._opt = opt
 
     def __setitem__(self, k, v):
+        if hasattr(self, "_opt"):
+            if k in self._WRITABLE:
+                setattr(self._opt, k, self._WRITABLE[k](v))
+            elif k not in self or self[k] != v:
+                raise KeyError(f"FusedAdam param group: {k!r} is read-only (the fused launch is plain Adam/AdamW)")
         super().__setitem__(k, v)
-        if k == "lr" and hasattr(self, "_opt"):
-            self._opt.lr = float(v)

@@ -61,6 +61,9 @@ class ActNorm(Transform):
     def init_from(self, xh: Tensor) -> None:
         """scale = -log(std+1e-6), bias = -mean over (B,H,W)  (reference transforms.py:74-78)."""
         K.actnorm_init(xh, self.scale.view(-1), self.bias.view(-1))
+        from nfdp_hip import dist as _dist
+        if _dist._ACTNORM_SYNC["active"]:                       # nfdp_hip.dist.data_dependent_init(mode="global"): moments of all ranks
+            _dist.actnorm_init_sync(self.scale.data, self.bias.data, xh.numel() // xh.shape[-1])
         self.is_initialized.fill_(1)
         buf = self.is_initialized
         self._init_cache = ((id(buf), buf.data_ptr(), buf._version), True)

@@ -172,6 +172,23 @@ def test_fused_adam_state_dict_is_torch_adam_layout():
     assert opt.step_count == 7 and opt.lr == 1e-3
     with pytest.raises(ValueError):
         opt.load_state_dict(torch.optim.Adam(mk()[:2]).state_dict())
+    # what one flat plain-Adam launch cannot represent is refused, not loaded as something else
+    pa = mk()
+    ams = torch.optim.Adam(pa, amsgrad=True)
+    with pytest.raises(ValueError, match="amsgrad"):
+        opt.load_state_dict(ams.state_dict())
+    with pytest.raises(ValueError, match="decoupled_weight_decay"):
+        opt.load_state_dict(torch.optim.AdamW(mk()).state_dict())
+    two = torch.optim.Adam([{"params": pa[:2], "lr": 1e-3}, {"params": pa[2:], "lr": 1e-4}])
+    with pytest.raises(ValueError, match="differ in lr"):
+        opt.load_state_dict(two.state_dict())
+    FusedAdam(mk(), adamw=True).load_state_dict(torch.optim.AdamW(mk()).state_dict())
+    # param-group writes: the four hyper-parameters reach the optimizer, anything else is read-only
+    grp = opt.param_groups[0]
+    grp["weight_decay"], grp["betas"], grp["eps"] = 0.02, (0.8, 0.9), 1e-7
+    assert opt.weight_decay == 0.02 and opt.betas == (0.8, 0.9) and opt.eps == 1e-7
+    with pytest.raises(KeyError):
+        grp["amsgrad"] = True
 
 
 def test_actnorm_init_mirror_follows_the_buffer():

@@ -115,8 +115,11 @@ def _grad_worker(rank, world, port, out):
     flat = FlatGradAllReduce(opt, bucket_bytes=256)
     opt.zero_grad()
     ((model(x[lo:hi]) - y[lo:hi]) ** 2).mean().backward()
-    flat.finish()
-    err3 = max(float((p.grad - b).abs().max()) for p, b in zip(model.parameters(), ref))
+    flat.finish()                                                   # the buffer now holds the SUM; 1/world rides on the optimizer's clip pass
+    assert opt.grad_scale == 0.5
+    err3 = max(float((p.grad * opt.grad_scale - b).abs().max()) for p, b in zip(model.parameters(), ref))
+    flat.remove()
+    assert opt.grad_scale == 1.0
     auto = FusedAdam([torch.nn.Parameter(torch.ones(2))]).direct_grads      # "auto" under a 2-rank group: off
     if rank == 0:
         out.put((err, err2, err3, auto))
@@ -137,3 +140,116 @@ def test_world2_gloo_bucketed_gradient_allreduce():
         assert p.exitcode == 0
     assert err <= 1e-6 and err2 <= 2e-6 and err3 <= 1e-6
     assert auto is False
+
+
+def _init_worker(rank, world, port, out):
+    """Replica initialisation (nfdp_hip.dist.broadcast_module / data_dependent_init / merge_moments / FlatGradAllReduce(sync_state)):
+    each rank builds its own Glow (its own random 1x1-conv QR factors) and holds its own first batch.  The HIP kernels need a GPU, so
+    the data-dependent pass itself is played here by the oracle (the checker) writing into the module's state."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "normalizing-flow-with-diffusion-prior-model_amd")]
+    from nfdp_hip import dist as D
+    from nfdp_hip.optim import FusedAdam
+    from normalizing_flow import Glow
+    from oracle import nf_oracle as O
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    C, L, Kf, B, S = 1, 2, 1, 6, 8
+    torch.manual_seed(100 + rank)                                   # different seeds: different QR draws per replica
+    flow = Glow(in_channel=C, L=L, K=Kf).cpu()
+    x_all = torch.rand(world * B, C, S, S, generator=torch.Generator().manual_seed(7)) - 0.5
+    lo, hi = D.shard_range(world * B, rank, world)
+    x = x_all[lo:hi]
+
+    def gather_sd(m):
+        flat = torch.cat([v.detach().reshape(-1).double() for v in m.state_dict().values()])
+        parts = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(parts, flat)
+        return parts
+
+    parts = gather_sd(flow)
+    differ_before = float((parts[0] - parts[1]).abs().max())
+    # ---- mode "rank0": rank 0 initialises on ITS batch, everyone takes the result
+    psd = {"_GaussianPrior__conv.weight": torch.zeros(2 * 8 * C, 2 * 8 * C, 3, 3), "_GaussianPrior__conv.bias": torch.zeros(2 * 8 * C),
+           "_GaussianPrior__conv.logs": torch.zeros(1, 2 * 8 * C, 1, 1)}
+    if rank == 0:
+        sd = {k: v.clone() for k, v in flow.state_dict().items()}
+        O.fwd_nll(x, sd, psd, L, Kf, init=True, img_size=S)         # the oracle's data-dependent init writes scale / bias into sd
+        sd.update({k: torch.tensor(1, dtype=torch.uint8) for k in sd if k.endswith("is_initialized")})   # what ActNorm.init_from sets
+        flow.load_state_dict(sd)
+    n_coll = D.broadcast_module(flow, src=0)
+    parts = gather_sd(flow)
+    same_after = float((parts[0] - parts[1]).abs().max())
+    inited = all(int(v) == 1 for k, v in flow.state_dict().items() if k.endswith("is_initialized"))
+    # every replica == the single-process init on rank 0's batch
+    ref_sd = None
+    w0 = flow.state_dict()["blocks.0.flows.0.invconv2d.weight"].clone()
+    # ---- global-batch variant: merged moments == moments of the concatenated batch
+    h = x * 1.7 + 0.3 * rank
+    mean = h.mean(dim=(0, 2, 3))
+    var = h.transpose(0, 1).reshape(C, -1).var(dim=1, unbiased=True)
+    m_all, v_all, n_all = D.merge_moments(mean, var, h.numel() // C)
+    h_all = torch.cat([x_all[:B] * 1.7, x_all[B:] * 1.7 + 0.3])
+    err_m = float((m_all - h_all.mean(dim=(0, 2, 3)).double()).abs().max())
+    err_v = float((v_all - h_all.transpose(0, 1).reshape(C, -1).double().var(dim=1, unbiased=True)).abs().max())
+    s_loc, b_loc = O.actnorm_init(h)
+    s_loc, b_loc = s_loc.clone(), b_loc.clone()
+    with D.global_actnorm_init():
+        D.actnorm_init_sync(s_loc, b_loc, h.numel() // C)
+    s_ref, b_ref = O.actnorm_init(h_all)
+    err_s = max(float((s_loc - s_ref).abs().max()), float((b_loc - b_ref).abs().max()))
+    # ---- one data-parallel training step from the synchronised state: per-rank shard gradients through the oracle's autograd,
+    # summed in place on FusedAdam's flat buffer, averaged by grad_scale, torch Adam arithmetic on the host (FusedAdam.step is HIP)
+    opt = FusedAdam(flow.parameters(), lr=1e-3, direct_grads=True)
+    torch.manual_seed(rank)                                          # desynchronise again on purpose: sync_state must repair it
+    with torch.no_grad():
+        opt.flat_param.add_(0.01 * torch.randn(opt.n) * (rank > 0))
+    red = D.FlatGradAllReduce(opt)
+
+    def loss_of(xb, params):
+        sdp = dict(flow.state_dict())
+        sdp.update(params)
+        _, _, _, bpd = O.fwd_nll(xb, sdp, psd, L, Kf, img_size=S)
+        return bpd
+
+    names = [n for n, _ in flow.named_parameters()]
+    leaf = {n: p.detach().clone().requires_grad_(True) for n, p in flow.named_parameters()}
+    loss_of(x, leaf).backward()
+    opt.zero_grad()
+    with torch.no_grad():
+        for n, p in flow.named_parameters():
+            p.grad.copy_(leaf[n].grad)
+    red.finish()
+    g_avg = opt.flat_grad * opt.grad_scale
+    ref_leaf = {n: p.detach().clone().requires_grad_(True) for n, p in flow.named_parameters()}
+    loss_of(x_all, ref_leaf).backward()                              # equal shards: mean of shard means = global mean
+    g_ref = torch.cat([ref_leaf[n].grad.reshape(-1) for n in names])
+    err_g = float((g_avg - g_ref).abs().max() / g_ref.abs().max())
+    with torch.no_grad():                                            # Adam step 1 on the host: p -= lr * g / (|g| + eps)
+        opt.flat_param.sub_(1e-3 * g_avg / (g_avg.abs() + 1e-8))
+    parts = gather_sd(flow)
+    same_post_step = float((parts[0] - parts[1]).abs().max())
+    if rank == 0:
+        out.put(dict(differ_before=differ_before, same_after=same_after, inited=inited, n_coll=n_coll, err_m=err_m, err_v=err_v,
+                     err_s=err_s, err_g=err_g, same_post_step=same_post_step, scale=opt.grad_scale))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_replica_initialisation_and_first_step():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_init_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    r = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert r["differ_before"] > 1e-3, "replicas built from different seeds should differ before the broadcast"
+    assert r["same_after"] == 0.0 and r["inited"] and r["n_coll"] == 2          # one fp32 collective + one for the uint8 flags
+    assert r["err_m"] < 1e-6 and r["err_v"] < 1e-6 and r["err_s"] < 1e-5          # the per-rank moments going in are fp32
+    assert r["scale"] == 0.5 and r["err_g"] < 1e-5
+    assert r["same_post_step"] == 0.0, "replicas must hold identical weights after the first data-parallel step"
