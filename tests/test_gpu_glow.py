@@ -23,8 +23,8 @@ def build(m, compute="f32"):
     from normalizing_flow import Glow, GaussianPrior
     flow = Glow(in_channel=m["C"], L=m["L"], K=m["K"], compute=compute)
     prior = GaussianPrior(2 ** (m["L"] + 1) * m["C"])
-    flow.load_state_dict(synth_sd(m["flow_spec"], m["seed"]), strict=True)
-    prior.load_state_dict(synth_sd(m["prior_spec"], m["seed"]), strict=True)
+    flow.load_state_dict(synth_sd(m["flow_spec"], m["seed"], profile=m.get("profile")), strict=True)
+    prior.load_state_dict(synth_sd(m["prior_spec"], m["seed"], profile=m.get("profile")), strict=True)
     return flow, prior
 
 
@@ -57,7 +57,7 @@ def test_glow_forward_nll_golden(tag):
     assert none is None and all(torch.equal(a, b) for a, b in zip(zs, zs2))
 
 
-BF16_Z_TOL = 3e-2       # bf16 MFMA operands (8-bit mantissa), fp32 accumulation and flow state: latents / pixels at the 1e-2 level
+BF16_Z_TOL = 5e-2       # bf16 MFMA operands (8-bit mantissa), fp32 accumulation and flow state: latents / pixels at the 1e-2 level
 BF16_BPD_TOL = 1e-4     # ... while bits/dim (a mean over ~3k log terms per image) stays inside BASELINE.json's gate
 
 
@@ -181,9 +181,8 @@ def test_north_star_full_size_properties():
     assert_close(logp[:4], logp_o, TOL, "logp vs oracle")
     bpd4 = calculate_loss((ldj + logp)[:4].contiguous(), 32.0, 3072.0)
     assert_close(bpd4, bpd_o, TOL, "bpd vs oracle")
-    # inverse + Split sampling (sampled pixels) on the same slice with the same injected noise.  A 48-flow fp32
-    # inverse carries its own rounding noise in ANY implementation, so the yardstick is the oracle evaluated in
-    # fp64: the HIP result must be within 1e-4 of it, or no further from it than 2x the fp32 oracle itself.
+    # inverse + Split sampling (sampled pixels) on the same slice with the same injected noise, against the oracle evaluated in fp64
+    # (the fp32 oracle's own distance from it is recorded beside the HIP path's): within BASELINE.json's 1e-4, element-wise.
     sd64 = {k: v.double() for k, v in sd.items()}
     z_in = [z[:4].cpu().contiguous() for z in zs]
     eps = [torch.randn(4, 12, 8, 8), torch.randn(4, 6, 16, 16)]
@@ -195,7 +194,8 @@ def test_north_star_full_size_properties():
         e_hip, e_ref = relerr_elem(hip, truth), relerr_elem(ref32, truth)
         record(f"north_star_f32_{what.replace(' ', '_')}_vs_fp64_truth", e_hip)
         record(f"north_star_f32_oracle_{what.replace(' ', '_')}_vs_fp64_truth", e_ref)
-        assert e_hip <= max(TOL, 2 * e_ref), f"{what}: hip {e_hip:.2e} vs fp64 truth, fp32 oracle {e_ref:.2e}"
+        # measured on MI355X (profiles/r03_parity_metrics.json): 8.6e-6 / 3.2e-6 for the HIP path, 1.1e-5 / 3.4e-6 for the fp32 oracle
+        assert e_hip <= TOL, f"{what}: hip {e_hip:.2e} vs fp64 truth (fp32 oracle itself: {e_ref:.2e})"
 
 
 BF16_DEEP_Z_TOL = 5e-2     # 48 flows of bf16-operand networks: latents / pixels (fp32 state, 8-bit-mantissa network inputs)

@@ -109,8 +109,8 @@ def test_glow_composite(tag):
     g = load_golden(f"glow_{tag}.npz")
     m = meta_of(g)
     L, K, B, C = m["L"], m["K"], m["B"], m["C"]
-    sd = synth_sd(m["flow_spec"], m["seed"])
-    psd = synth_sd(m["prior_spec"], m["seed"])
+    sd = synth_sd(m["flow_spec"], m["seed"], profile=m.get("profile"))
+    psd = synth_sd(m["prior_spec"], m["seed"], profile=m.get("profile"))
     x = T(g["x"])
     assert x.shape[-1] == m.get("size", 32)
     zs, ldj, logp, bpd = O.fwd_nll(x, sd, psd, L, K)

@@ -19,9 +19,11 @@ def meta_of(g):
     return json.loads(str(g["meta"]))
 
 
-def synth_sd(spec, seed, prefix=""):
-    """{key: torch tensor} for a [(key, shape)] spec, using the shared synthesis rule."""
-    return {k: torch.from_numpy(np.array(synth_tensor(prefix + k, s, seed))) for k, s in spec}
+def synth_sd(spec, seed, prefix="", profile=None):
+    """{key: torch tensor} for a [(key, shape)] spec, using the shared synthesis rule (profile: a golden's meta["profile"] name)."""
+    from tests.golden.synth import GOLDEN, DEEP
+    prof = {None: GOLDEN, "GOLDEN": GOLDEN, "DEEP": DEEP}[profile]
+    return {k: torch.from_numpy(np.array(synth_tensor(prefix + k, s, seed, prof))) for k, s in spec}
 
 
 def T(a):

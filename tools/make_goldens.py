@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from ref_import import import_reference
-from tests.golden.synth import synth_tensor, synth_input, images_5bit
+from tests.golden.synth import synth_tensor, synth_input, images_5bit, GOLDEN, DEEP
 
 R = import_reference()
 T = R["transforms"]
@@ -29,9 +29,9 @@ OUT = os.path.join(ROOT, "tests", "golden")
 torch.set_num_threads(8)
 
 
-def load_synth(module, seed, overrides=None):
+def load_synth(module, seed, overrides=None, profile=GOLDEN):
     sd = module.state_dict()
-    new = {k: torch.from_numpy(np.array(synth_tensor(k, v.shape, seed))) for k, v in sd.items()}
+    new = {k: torch.from_numpy(np.array(synth_tensor(k, v.shape, seed, profile))) for k, v in sd.items()}
     if overrides:
         new.update(overrides)
     module.load_state_dict(new, strict=True)
@@ -131,12 +131,16 @@ def gen_ops():
 
 # ------------------------------------------------------------------ Glow composite goldens
 @torch.no_grad()
-def gen_glow(tag, C, L, K, B, seed, size=32):
+def gen_glow(tag, C, L, K, B, seed, size=32, profile="GOLDEN"):
+    """profile "DEEP" (tests/golden/synth.py): near-orthogonal 1x1 convs and gentler coupling scales, so that the SAMPLING inverse of a
+    deep / large model stays well conditioned (with the GOLDEN profile the 3x128x128 L5 sample reaches |x| ~ 1e10 and the
+    reference's own fp32 result is 1.4e-4 away from an fp64 evaluation - no fp32 implementation can be held to 1e-4 there)."""
     U = R["nf_utils"]
     flow = R["glow"].Glow(in_channel=C, L=L, K=K)
     prior = R["prior"].GaussianPrior(2 ** (L + 1) * C)
-    spec = load_synth(flow, seed)
-    pspec = load_synth(prior, seed)
+    prof = {"GOLDEN": GOLDEN, "DEEP": DEEP}[profile]
+    spec = load_synth(flow, seed, profile=prof)
+    pspec = load_synth(prior, seed, profile=prof)
     x_np, u8, dq = images_5bit(f"glow{tag}", (B, C, size, size), seed)
     x = t(x_np)
     n_pixel = size * size * 3.0                                         # trainer.py:133-134
@@ -167,10 +171,12 @@ def gen_glow(tag, C, L, K, B, seed, size=32):
     meta = {"C": C, "L": L, "K": K, "B": B, "seed": seed, "flow_spec": spec, "prior_spec": pspec}
     if size != 32:
         meta["size"] = size
+    if profile != "GOLDEN":
+        meta["profile"] = profile
     g["meta"] = np.array(json.dumps(meta))
     np.savez_compressed(os.path.join(OUT, f"glow_{tag}.npz"), **g)
     print(f"glow_{tag}.npz bpd={float(bpd):.6f}  |z_last|max={float(zs[-1].abs().max()):.3f} "
-          f"rec_err={float((flow.invert(zs) - x).abs().max()):.2e}")
+          f"rec_err={float((flow.invert(zs) - x).abs().max()):.2e} |x_sampled|max={float(xs.abs().max()):.3f}")
 
 
 @torch.no_grad()
@@ -513,7 +519,7 @@ if __name__ == "__main__":
         gen_glow("N", 3, 3, 2, 2, 2)      # north-star shape with reduced K
         gen_glow("D", 3, 5, 1, 2, 3)      # CelebA depth (BASELINE configs[4]: L = 5 -> C up to 192) on 32x32 inputs
     if "celeba" in which:
-        gen_glow("C", 3, 5, 2, 1, 6, size=128)   # BASELINE configs[4] image size and depth (3x128x128, L5), K reduced to 2
+        gen_glow("C", 3, 5, 2, 1, 6, size=128, profile="DEEP")   # BASELINE configs[4] image size and depth (3x128x128, L5), K reduced to 2
         gen_unet_celeba()                        # ... and the U-Net of its first latent part (6x64x64, mults [1,2,2], groups 16)
     if "init" in which:
         gen_glow_init()
