@@ -44,7 +44,7 @@ def test_fused_matches_unfused_and_oracle(c, hw, b):
     assert_close(y1, yo, 2e-2, "fused vs fp32 oracle y")
     assert_close(l1, lo, 2e-2, "fused vs fp32 oracle ldj")
     i1, i2 = fused.invert(y1), plain.invert(y1)
-    assert_close(i1, i2, 3e-3, "fused vs unfused inverse")
+    assert_close(i1, i2, 6e-3, "fused vs unfused inverse")
     assert relerr(i1, xd) < 2e-2                                                     # round trip at bf16 accuracy
     # determinism
     y1b, _, _ = fused.transform(xd, torch.zeros(b, dtype=torch.float64, device=DEV), None)
