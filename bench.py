@@ -142,29 +142,67 @@ def host_cores(cap=16):
     return max(1, min(n, int(os.environ.get("NFDP_CPU_THREADS", cap))))
 
 
-def cpu_baseline(fsd, psd, L, K, u8, noise, n_bits=5, budget_s=12.0):
-    """The oracle (port of the reference's CPU path) on the host cores: a bounded sample of the same workload."""
+def cpu_model():
+    """(model string, physical cores of the machine, logical CPUs of the machine) from /proc/cpuinfo."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+                logical += 1
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, (len(phys) or None), (logical or None)
+
+
+def cpu_baseline(fsd, psd, L, K, u8, noise, n_bits=5):
+    """The oracle (port of the reference's CPU path) on the host cores, BASELINE.md section 4's protocol on a bounded sample:
+    B = 64 on all threads this process may use (3 warm-up + 5 timed batches, median), B = 512 once, and B = 64 on ONE thread
+    (one timed batch); about 25-30 s of CPU work in all.  `value` is the all-thread B = 64 median."""
     from oracle import nf_oracle as O
     cores = host_cores()
-    torch.set_num_threads(cores)
-    bs = 16
     x = O.preprocess(u8.float() / 255.0, n_bits) + noise / 2.0 ** n_bits
-    with torch.no_grad():
+    model, phys, logical = cpu_model()
+
+    def timed(xb):
         t0 = time.perf_counter()
-        O.fwd_nll(x[:4], fsd, psd, L, K)                                # warm-up
-        log(f"cpu_baseline: {cores} threads, warm-up 4 images {time.perf_counter() - t0:.1f} s")
-        n, t0 = 0, time.perf_counter()
-        last = t0
-        while n < 2 * bs or time.perf_counter() - t0 < budget_s:       # ~budget_s of CPU work, wrapping over the batch
-            i0 = n % (x.shape[0] - bs + 1)
-            _, _, _, bpd = O.fwd_nll(x[i0:i0 + bs], fsd, psd, L, K)
-            n += bs
-            if time.perf_counter() - last > 3.0:
-                last = time.perf_counter()
-                log(f"cpu_baseline: {n} images, {last - t0:.1f} s")
-        dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 2), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} images in batches of {bs} (fp32, torch-CPU oracle, {cores} threads), {dt:.1f} s",
+        out = O.fwd_nll(xb, fsd, psd, L, K)
+        return time.perf_counter() - t0, out[3]
+
+    with torch.no_grad():
+        torch.set_num_threads(cores)
+        t_all = []
+        for i in range(8):                                              # 3 warm-up + 5 timed batches of 64, wrapping over the batch
+            i0 = (64 * i) % max(1, x.shape[0] - 63)
+            dt, bpd = timed(x[i0:i0 + 64])
+            if i >= 3:
+                t_all.append(dt)
+        med = sorted(t_all)[len(t_all) // 2]
+        log(f"cpu_baseline: {cores} threads, B=64: median {med:.2f} s per batch ({64 / med:.1f} img/s)")
+        dt512, bpd512 = timed(x[:512]) if x.shape[0] >= 512 else (None, None)
+        if dt512 is not None:
+            log(f"cpu_baseline: {cores} threads, B=512: {dt512:.2f} s ({512 / dt512:.1f} img/s)")
+        torch.set_num_threads(1)
+        timed(x[:2])                                                    # 1-thread warm-up
+        dt1, _ = timed(x[:64])
+        log(f"cpu_baseline: 1 thread, B=64: {dt1:.2f} s ({64 / dt1:.1f} img/s)")
+        torch.set_num_threads(cores)
+    return {"value": round(64 / med, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": (f"B=64 x (3 warm-up + 5 timed, median) on {cores} threads; B=512 x 1; B=64 x 1 on one thread "
+                       f"(fp32, no_grad, torch-CPU oracle = port of trainer.py:154-161)"),
+            "images_per_s_b64": round(64 / med, 2),
+            "images_per_s_b512": round(512 / dt512, 2) if dt512 else None,
+            "images_per_s_b64_1thread": round(64 / dt1, 2),
+            "cpu_model": model, "machine_physical_cores": phys, "machine_logical_cpus": logical, "threads": cores,
+            "torch": torch.__version__,
             "bits_per_dim_last_batch": float(bpd)}
 
 
@@ -272,10 +310,39 @@ def train_bench(args, rank, world, device, barrier):
             "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)
 
 
+def time_invert(flow, zs, xh, sample, steps, warmup, graph=True, cap_kw=None):
+    """Times Glow.invert (reference glow.py:203-228) on the latents `zs` of a batch: all latents given (exact reconstruction) or only
+    the last one (the Split layers sample from their learned priors at temperature 0.7: the sampling path), as a hipGraph replay like
+    the forward leg.  Returns (seconds for `steps` calls on this rank, round-trip max rel err or None, finite)."""
+    lat = zs if not sample else [zs[-1]]
+    temp = 1.0 if not sample else 0.7
+
+    def inv():
+        return flow.invert_nhwc(lat, temperature=temp)
+
+    for _ in range(max(warmup, 2)):
+        out = inv()
+    rt = float((out - xh).abs().max() / xh.abs().max()) if not sample else None
+    if graph:
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, **(cap_kw or {})):
+            out = inv()
+        run = g.replay
+        run()
+    else:
+        run = inv
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, rt, bool(torch.isfinite(out).all())
+
+
 def inverse_bench(args, rank, world, device, barrier):
-    """BASELINE configs[1] is forward + INVERSE: times Glow.invert (reference glow.py:203-228) on the latents of the same
-    synthetic batch - all latents given (exact reconstruction) or only the last one (the Split layers sample from their learned
-    priors, temperature 0.7: the sampling path) - as a hipGraph replay like the forward leg."""
+    """BASELINE configs[1] is forward + INVERSE: `--inverse` / `--sample` as the timed quantity of their own run (the default run
+    reports both as `legs` beside the forward number)."""
     import nfdp_hip as KH
     from nfdp_hip.dist import max_over_ranks
     flow, prior, _, _ = build_models(args.L, args.K, args.compute, device)
@@ -285,32 +352,12 @@ def inverse_bench(args, rank, world, device, barrier):
         ldj = torch.zeros(args.batch, dtype=torch.float64, device=device)
         logp = torch.zeros(args.batch, dtype=torch.float64, device=device)
         zs = [z.contiguous() for z in flow.transform_nhwc(xh, ldj, logp)]
-        lat = zs if not args.sample else [zs[-1]]
-        temp = 1.0 if not args.sample else 0.7
-
-        def inv():
-            return flow.invert_nhwc(lat, temperature=temp)
-
-        for _ in range(max(args.warmup, 2)):
-            out = inv()
-        rt = float((out - xh).abs().max() / xh.abs().max()) if not args.sample else None
         graphed = not args.no_graph
-        if graphed:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
-                out = inv()
-            run = g.replay
-            run()
-        else:
-            run = inv
         barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            run()
+        elapsed, rt, finite = time_invert(flow, zs, xh, args.sample, args.steps, args.warmup, graphed,
+                                          {"capture_error_mode": "thread_local"} if world > 1 else {})
         barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0, device)
-        finite = bool(torch.isfinite(out).all())
+        elapsed = max_over_ranks(elapsed, device)
     if rank == 0:
         what = "inverse (all latents given)" if not args.sample else "sampling inverse (last latent given, Split priors sampled, T=0.7)"
         print(json.dumps({
@@ -322,6 +369,91 @@ def inverse_bench(args, rank, world, device, barrier):
                                    "glow.py:203-228)", "batch_per_gpu": args.batch, "parallelism": f"dp{world}",
                        "launch": "hipGraph replay" if graphed else "eager"},
             "round_trip_max_rel_err": rt, "finite": finite}), flush=True)
+
+
+def extra_legs(args, flow, prior, u8_d, noise_d, device):
+    """The other quantities BASELINE configs[1] names, measured in the same process right after the headline's timed region (one
+    GPU): the bf16 inverse and sampling inverse on the same batch's latents, and the exact-fp32 forward + NLL (the mode that meets
+    the 1e-4 pixel gate).  Each as a hipGraph replay; ms per 512-image step."""
+    import nfdp_hip as KH
+    legs = {}
+    B = args.batch
+    n = max(5, args.steps // 2)
+    with torch.no_grad():
+        xh = KH.preprocess_u8(u8_d, noise_d, 5)
+        zs = [z.contiguous() for z in flow.transform_nhwc(xh, torch.zeros(B, dtype=torch.float64, device=device),
+                                                           torch.zeros(B, dtype=torch.float64, device=device))]
+        for name, sample in (("inverse", False), ("sample", True)):
+            dt, rt, finite = time_invert(flow, zs, xh, sample, n, 2, not args.no_graph)
+            legs[name] = {"ms_per_step": round(dt / n * 1e3, 3), "images_per_s": round(B * n / dt, 1), "steps": n, "dtype": args.compute,
+                          "finite": finite}
+            if rt is not None:
+                legs[name]["round_trip_max_rel_err"] = rt
+            log(f"leg {name}: {legs[name]['ms_per_step']} ms/step")
+        other = "f32" if args.compute == "bf16" else "bf16"
+        flow2, prior2, _, _ = build_models(args.L, args.K, other, device)
+        for _ in range(2):
+            out = step(flow2, prior2, u8_d, noise_d)
+        n2 = max(3, n // 3) if other == "f32" else n
+        run = lambda: step(flow2, prior2, u8_d, noise_d)
+        if not args.no_graph:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = step(flow2, prior2, u8_d, noise_d)
+            run = g.replay
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n2):
+            run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        legs[f"forward_{other}"] = {"ms_per_step": round(dt / n2 * 1e3, 3), "images_per_s": round(B * n2 / dt, 1), "steps": n2,
+                                    "dtype": other, "bits_per_dim": round(float(out[0] / out[1]), 6)}
+        log(f"leg forward_{other}: {legs[f'forward_{other}']['ms_per_step']} ms/step")
+    return legs
+
+
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) over the fused flow-step kernel sources: stamps a PMC summary with the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(PKG, "csrc")
+    for f in ("coupling_fused_impl.inc", "coupling_fused_v.hip", "coupling_fused_a.hip"):
+        try:
+            h.update(open(os.path.join(csrc, f), "rb").read())
+        except OSError:
+            h.update(f.encode())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(lbl, batch):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed rocprofv3 --pmc summary (separate passes, tools/
+    profile_round.sh), with the provenance a reader needs: which file, which kernel sources it was collected on, and whether those
+    are the sources of this run (bench.py cannot collect counters itself: they need rocprofv3 around the process)."""
+    import glob
+    key = {"level_fused<12,16>": "coupling_fused_kernel<12, 16, 2, false, false>",
+           "level_fused<24,8>": "coupling_fused_rs2_kernel<24, 8, 4, false>",
+           "level_fused<48,4>": "coupling_fused_rs_kernel<48, 4, false>"}.get(lbl.split(" ")[0])
+    if key is None or batch != 512:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True)
+    files = [f for f in files if "train" not in f and "celeba" not in f and "wgrad" not in f]
+    cur = kernel_source_sha16()
+    for f in files:
+        try:
+            pmc = json.load(open(f))
+            meta = pmc.get("_meta", {})
+            return {"traffic": int(pmc[key]["hbm_bytes_per_launch"]),
+                    "traffic_note": ("bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2: gfx950 tallies 128-B reads at 64 B) + WRITE_SIZE in "
+                                     "separate passes (tools/profile_round.sh), read from a committed summary"),
+                    "traffic_source": {"file": os.path.relpath(f, ROOT), "kernel_source_sha16": meta.get("kernel_source_sha16"),
+                                       "git_head": meta.get("git_head"), "current_kernel_source_sha16": cur,
+                                       "taken_on_current_kernel_sources": (meta.get("kernel_source_sha16") == cur) if meta else None}}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def main():
@@ -347,6 +479,7 @@ def main():
     ap.add_argument("--graph-multi", action="store_true", help="--train with several ranks: replay hipGraphs around the all-reduce instead of eager launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the inverse / sampling / other-precision legs of the default run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -465,19 +598,9 @@ def main():
                 ach = a["bytes"] / a["n"] / avg_s / 1e9
                 roofline = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
-            # HBM traffic of the same kernel/shape from a separate rocprofv3 --pmc pass (committed summary):
-            # FETCH_SIZE doubled for wide coalesced reads on gfx950 (MI355X_MICROARCH.md §HBM) + WRITE_SIZE, per launch
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_d_pmc_summary.json")))
-                key = {"level_fused<12,16>": "coupling_fused_kernel<12, 16, 2, false, false>",
-                       "level_fused<24,8>": "coupling_fused_rs2_kernel<24, 8, 4, false>",
-                       "level_fused<48,4>": "coupling_fused_rs_kernel<48, 4, false>"}.get(lbl.split(" ")[0])
-                if key and args.batch == 512:
-                    roofline["traffic"] = int(pmc[key]["hbm_bytes_per_launch"])
-                    roofline["traffic_note"] = ("bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2: gfx950 tallies 128-B reads at 64 B) + "
-                                                "WRITE_SIZE in separate passes, profiles/r02_d_pmc_summary.json (tools/profile_round.sh)")
-            except (OSError, KeyError, ValueError):
-                pass
+            tr_info = pmc_traffic(lbl, args.batch)
+            if tr_info:
+                roofline.update(tr_info)
             roofline.update({"kernel": lbl, "avg_launch_us": round(avg_s * 1e6, 2),
                              "avg_launch_us_isolated_eager": round(eager_avg_us, 2),
                              "timing": ("HIP events around a hipGraph of 4 back-to-back launches of this kernel (the timed region replays "
@@ -510,6 +633,8 @@ def main():
         }
         if roofline is not None:
             res["roofline"] = roofline
+        if world == 1 and not args.no_legs:
+            res["legs"] = extra_legs(args, flow, prior, u8_d, noise_d, device)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(fsd, psd, args.L, args.K, u8, noise)
         print(json.dumps(res), flush=True)

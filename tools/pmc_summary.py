@@ -46,5 +46,18 @@ for k, ctrs in sorted(acc.items()):
     if "TCC_HIT_sum" in e and "TCC_MISS_sum" in e and e["TCC_HIT_sum"] + e["TCC_MISS_sum"] > 0:
         e["TCC_hit_rate"] = round(e["TCC_HIT_sum"] / (e["TCC_HIT_sum"] + e["TCC_MISS_sum"]), 4)
     res[k] = e
+# provenance: the kernel sources and the commit the counters were collected on (bench.py reports whether they are still current)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from bench import kernel_source_sha16
+    head = None
+    try:
+        import subprocess
+        head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        pass
+    res["_meta"] = {"kernel_source_sha16": kernel_source_sha16(), "git_head": head or os.environ.get("NFDP_GIT_HEAD")}
+except Exception as e:      # noqa: BLE001
+    res["_meta"] = {"error": str(e)}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
