@@ -30,6 +30,10 @@ from normalizing_flow.base import _EpochOnApply
 ModelPrediction = namedtuple('ModelPrediction', ['pred_noise', 'pred_x_start'])
 
 
+# The eight small helpers below (exists ... unnormalize_to_zero_to_one's formulas), `extract`, the three beta schedules and the
+# schedule dispatch in GaussianDiffusion.__init__ follow the reference line for line (gaussian_diffusion.py:110-124, :148-157,
+# :495-539, :573-580, itself a trimmed copy of lucidrains' denoising-diffusion-pytorch 0.31, MIT): one-off host code and constant
+# tables behind a class surface the drivers fix.  Everything that touches the device is written around the HIP calls.
 def exists(x):
     return x is not None
 
@@ -45,12 +49,17 @@ def identity(t, *args, **kwargs):
 
 
 def normalize_to_neg_one_to_one(img):
-    """img * 2 - 1  (reference :148-150)"""
+    """img * 2 - 1  (reference :148-150).  An input that carries a gradient (latents of an unfrozen flow, trainer.py:139-141) keeps it:
+    the HIP launch sits outside autograd, so that case takes the same two fp32 operations as torch ops."""
+    if torch.is_grad_enabled() and img.requires_grad:
+        return img * 2.0 - 1.0
     return K.as_nchw(K.axpb(K.to_nhwc(img), 2.0, -1.0))
 
 
 def unnormalize_to_zero_to_one(t):
     """(t + 1) * 0.5  (reference :153-157)"""
+    if torch.is_grad_enabled() and t.requires_grad:
+        return (t + 1.0) * 0.5
     return K.as_nchw(K.axpb(K.to_nhwc(t), 0.5, 1.0, add_first=True))
 
 
@@ -832,7 +841,14 @@ class GaussianDiffusion(_EpochOnApply, nn.Module):
     def _maybe_self_cond(self, xh: Tensor, t: Tensor) -> Optional[Tensor]:
         """Self-conditioning during training (reference :832-841): half of the time (python's random(), as the reference) the model's
         own x_start prediction, computed without gradient, is fed back as conditioning."""
-        if not (self.self_condition and _random() < 0.5):
+        if not self.self_condition:
+            return None
+        if torch.cuda.is_current_stream_capturing():
+            # the coin is drawn on the HOST: a hipGraph would freeze this step's outcome into every replay (always / never
+            # self-conditioned).  Train self-conditioned models with eager steps, or capture two graphs and choose per step.
+            raise RuntimeError("GaussianDiffusion(self_condition=True).p_losses draws the self-conditioning coin on the host "
+                               "(reference :832) and cannot be captured in a hipGraph")
+        if not _random() < 0.5:
             return None
         with torch.no_grad():
             _, x0, _ = self._predictions_nhwc(xh.detach(), t, None, False, want_noise=False)

@@ -126,6 +126,31 @@ def _join_side() -> None:
         _side_keep.clear()
 
 
+def _abandon_side() -> None:
+    """A backward launch raised between _defer_side and _flush_side / _join_side: drop the queued closures (they would otherwise run
+    in the NEXT backward pass and add stale weight gradients into .grad) and let the main stream wait for whatever the side stream
+    was already given before the tensors it reads are released."""
+    _side_jobs.clear()
+    try:
+        _join_side()
+    except Exception:                                        # noqa: BLE001 - the original error is the one to report
+        _side_keep.clear()
+
+
+def _side_guarded(backward):
+    """Decorator for the backward of a node that uses the side stream: on any exception the queue is abandoned."""
+    import functools
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        try:
+            return backward(ctx, *grads)
+        except BaseException:
+            _abandon_side()
+            raise
+    return wrapped
+
+
 def _slots(*params):
     """The .grad tensors of all params, or None unless every one of them can be accumulated into directly."""
     gs = [_slot(p) for p in params]
@@ -476,6 +501,7 @@ class CouplingStepFn(Function):
         return y, acc
 
     @staticmethod
+    @_side_guarded
     def backward(ctx, dy, dacc):
         xh, h, xcol, y1, y2 = ctx.saved_tensors
         if dy is None:
@@ -672,15 +698,16 @@ class LevelFusedFn(Function):
         biases = [params[P * i + 1].detach().reshape(-1) for i in range(n)]
         ws = [params[P * i + 2].detach().reshape(c, c) for i in range(n)]
         xpre, ypost, hout, y1, y2, xcol = K.level_fused_train(y, packed, scales, biases, ws, acc)
-        ctx.save_for_backward(xpre, ypost, hout, y1, y2, wts, xcol)
+        ctx.save_for_backward(xpre, ypost, hout, y1, y2, xcol)
         ctx.params, ctx.bpacks, ctx.f3, ctx.n = params, bpacks, float(f3), n
         ctx.nets = meta[4] if len(meta) > 4 else [None] * n
         ctx.ldj_dtype = None if ldj is None else ldj.dtype
         return y, acc
 
     @staticmethod
+    @_side_guarded
     def backward(ctx, dy, dacc):
-        xpre, ypost, hout, y1, y2, wts, xcol = ctx.saved_tensors
+        xpre, ypost, hout, y1, y2, xcol = ctx.saved_tensors
         n, P, params = ctx.n, LevelFusedFn.NP, ctx.params
         bsz, hh, ww, c = ypost.shape[1:]
         npix = bsz * hh * ww
@@ -759,15 +786,12 @@ def _level_fused_ok(flows, yh: Tensor) -> bool:
         return False
     if not (FUSED_TRAIN_BACKWARD and K.coupling_bwd_fused_supported(h, w, c, hid)):
         return False            # the saved activations are in the fused kernels' blocked layout: only the fused backward reads it
-    bwd_fused = True
     for f in flows:
         cp = f.affcoupling
         net = cp.net
         if K.compute_enum(cp.compute) != K.BF16 or not f.actnorm.initialized():
             return False
         if not (net[0].actnorm.initialized() and net[2].actnorm.initialized()):
-            return False
-        if not bwd_fused and not _fused_net_ok(net, yh[..., : c // 2], K.BF16):     # the per-op backward has its own shape limits
             return False
     return True
 
