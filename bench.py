@@ -256,31 +256,23 @@ def train_bench(args, rank, world, device, barrier):
     # Several ranks: eager launches by default - no run of this code over RCCL with a live process group around a capture has
     # been recorded yet; `--graph-multi` opts into the captured form (forward + backward | all-reduce | optimizer).
     graphed = not args.no_graph and (world == 1 or args.graph_multi)
-    cap_kw = {"capture_error_mode": "thread_local"} if world > 1 else {}      # RCCL's watchdog thread may call into HIP during a capture
     if graphed and world == 1:
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = train_step()
+        from nfdp_hip.graphs import capture_step
+        cap = capture_step(train_step, warmup=1)          # side-stream warm-up + capture (nfdp_hip.graphs)
         def run():
-            graph.replay()
-            KH.bump_param_epoch()          # the replay updated the parameters: eager code afterwards must rebuild its weight caches
+            cap()
         run()
-        loss = static_loss
+        loss = cap.outputs
     elif graphed:
-        torch.cuda.synchronize()
-        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fb, **cap_kw):
-            static_loss = fwd_bwd()
-        with torch.cuda.graph(g_opt, **cap_kw):
-            opt.step()
+        from nfdp_hip.graphs import capture_step
+        cap_fb = capture_step(fwd_bwd, warmup=1, mutates_params=False)
+        cap_opt = capture_step(opt.step, warmup=1)
         def run():
-            g_fb.replay()
+            cap_fb()
             reducer.finish()
-            g_opt.replay()
-            KH.bump_param_epoch()
+            cap_opt()
         run()
-        loss = static_loss
+        loss = cap_fb.outputs
     else:
         def run():
             nonlocal loss

@@ -63,6 +63,16 @@ int nfdp_get_f32_products(void);
  * first C/2 channels ([npix][xcol_ld] bf16, xcol_ld >= 9*C/2 rounded up to 16), packed = nfdp_coupling_fused_pack image,
  * T [npix][9*C] fp32 (n = tap*C + co) for nfdp_tap_shift_sum_f32 (add = bias, mul = logs, mul_exp = 3).  C in {4,8,16,12,24,48}. */
 int nfdp_coupling_mlp_bf16(const void* xcol, int xcol_ld, long npix, const void* packed, float* T, int C, nfdp_stream_t stream);
+/* The same network in EXACT fp32 (v_mfma_f32_32x32x2_f32: fp32 products and sums), hidden activations on chip: the fp32-accurate fast
+ * path of compute="f32" (utils.py:83-89 is fp32 end to end).  Reads the C/2-channel half x [B,H,W,*] fp32 NHWC (pixel stride x_ld
+ * floats) directly - the 3x3 gather of the first conv happens in the kernel - and writes T [B*H*W][9*C] fp32 (n = tap*C + co) for
+ * nfdp_tap_shift_sum_f32.  packed: nfdp_coupling_mlp_f32_pack's image (nfdp_coupling_mlp_f32_packed_bytes(C) bytes, 0 = C unsupported)
+ * of w1 [512][C/2][3][3], scale1/bias1 [512], w2 [512][512], scale2/bias2 [512], w3 [C][512][3][3]; the ZeroConv2d's bias / logs are
+ * applied by the shift-sum.  C in {4,8,12,16,24,48}; any image size.  Bound: fp32 matrix pipe (157 TFLOP/s). */
+size_t nfdp_coupling_mlp_f32_packed_bytes(int C);
+int nfdp_coupling_mlp_f32_pack(const float* w1, const float* scale1, const float* bias1, const float* w2, const float* scale2,
+                               const float* bias2, const float* w3, void* packed, int C, nfdp_stream_t stream);
+int nfdp_coupling_mlp_f32(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, nfdp_stream_t stream);
 /* Explicit im2col of a narrow tensor for a 3x3 "same" conv (training path of the C/2 -> 512 convs, utils.py:67): x [B,H,W,C] fp32
  * with pixel stride x_ld -> out [B*H*W][Kpad] bf16, out[p][tap*C + c] = x[p + shift(tap)][c] (zero outside the image and for
  * columns >= 9C); Kpad >= 9C, Kpad % 8 == 0, out 16-byte aligned. */

@@ -1,0 +1,310 @@
+// The coupling network in EXACT fp32 with the hidden activations on chip: the fp32-accurate fast path.
+//
+// Reference arithmetic: coupling_network  normalizing_flow/utils.py:83-89  (Conv2dActNorm :67-69, ZeroConv2d :43-44), fp32 end to end.
+//
+//   x_a --gather (3x3 taps, zero padding)--> GEMM1 (9*C/2 -> 512) -> (.+b1)*e^s1 -> ReLU -> GEMM2 (512 -> 512) -> (.+b2)*e^s2 -> ReLU
+//       -> GEMM3 (512 -> 9 taps x C, pointwise)  ==> T[pixel][tap*C + co]   (nfdp_tap_shift_sum_f32 adds the taps up, + bias, * e^{3 logs})
+//
+// Why this kernel exists.  The bf16 fused flow-step kernels meet BASELINE.json's bits/dim gate but not its 1e-4 PIXEL gate (8-bit
+// mantissa operands: 1e-2 on latents and sampled pixels); the per-op fp32 path meets it at 34 ms per 512-image step, 16 ms of which
+// are the three narrow 512 -> C 3x3 convs (10-43 TFLOP/s as implicit GEMMs) and the rest moves two 268 MB hidden tensors per flow
+// through HBM.  gfx950 has no TF32-like mode; v_mfma_f32_32x32x2_f32 multiplies and accumulates in plain fp32 at 1/16 of the bf16
+// rate, so at that rate everything except the matrix pipe is cheap and the design is the simple one:
+//  * a workgroup = 4 waves = 128 consecutive pixels (any image size: the spatial parts of the two 3x3 convs are a gather in front and
+//    the tap shift-sum behind), one wave per SIMD with the whole 512-register budget, every wave 32 pixels;
+//  * all three GEMMs TRANSPOSED (rows = output channel, lanes = pixel): a 32x32 accumulator tile of one GEMM, after its epilogue, IS
+//    the B operand of the next - register r of lane (h, p) holds channel drow(r, h) of pixel p, and the instruction's two k values are
+//    the two lane halves, so "k-pair r" of a hidden block is accumulator register r as it stands.  The 512 hidden channels of 32
+//    pixels are 256 registers; H2 is produced one 32-channel block at a time and consumed at once by GEMM3 (tap accumulators: up to 7
+//    row tiles = 112 registers; C = 48 has 14 and runs the GEMM2/3 loop twice over the retained H1);
+//  * weights are read straight from global memory (L2) in MFMA-fragment order, one global_load_dwordx4 per lane = 4 k-pairs of a
+//    32-row tile = 1 KiB per wave-instruction per 4 MFMAs (256 cycles): 16 B/clk per CU, far under the per-CU L2 rate, so no LDS
+//    staging and no barriers at all; an 8-deep register ring keeps ~1 us of weights in flight per wave;
+//  * products and sums are fp32 FMAs in a fixed order (k ascending within the permuted order baked into the images): results match
+//    the per-op fp32 kernels and the reference to summation order (tests: goldens at 1e-4, element-wise).
+// Bound: fp32 matrix pipe, 157.3 TFLOP/s; algorithmic work 2*(9*C/2*512 + 512^2 + 9*C*512) FLOP per pixel.
+#include <type_traits>
+#include <utility>
+#include "nfdp_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int HID = 512;
+constexpr int NHB = HID / 32;
+constexpr int D = 8;                                   // weight fragments in flight per wave (1 KiB each)
+constexpr int FRAG = 256;                              // floats per fragment: 64 lanes x 4 k-pairs
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__host__ __device__ constexpr int drow(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+template <int C>
+struct GeoF {
+    static constexpr int Ch = C / 2;
+    static constexpr int K1 = 9 * Ch;
+    static constexpr int NQ1 = (K1 + 7) / 8;           // fragments (4 k-pairs = 8 k) per hidden block of GEMM1
+    static constexpr int KP1 = 4 * NQ1;                // k-pairs of GEMM1, padded
+    static constexpr int NROW = 9 * C;
+    static constexpr int NRT = (NROW + 31) / 32;
+    static constexpr int NG = (NRT + 6) / 7;           // GEMM3 row groups (tap accumulators: at most 7 tiles = 112 registers)
+    static constexpr int NRTG = (NRT + NG - 1) / NG;
+    static constexpr int NB = 4 * NHB + 4 * NRTG;      // fragments one hidden block of GEMM2 + its GEMM3 slice consume
+    static constexpr int NBP = (NB + D - 1) / D * D;   // ... padded so the register ring's phase is the same in every iteration
+    static constexpr int NW1 = NHB * NQ1;
+    static constexpr long S1 = 0;                                      // fragment index of the W1 stream
+    static constexpr long S2 = NW1;                                    // ... of the GEMM2/3 stream
+    static constexpr long NFRAG = NW1 + (long)NG * NHB * NBP + D;      // + D zero fragments the prefetch runs into
+    static constexpr long PARAMS = NFRAG * FRAG;                       // float offset of b1 | e^s1 | b2 | e^s2 (natural channel order)
+    static constexpr long TOTAL_FLOATS = PARAMS + 4 * HID;
+    static_assert(C % 4 == 0, "rows of T are written as float4");
+};
+
+// ----------------------------------------------------------------------------- packer
+template <int C>
+__global__ void pack_mlp_f32_kernel(const float* __restrict__ w1, const float* __restrict__ scale1, const float* __restrict__ bias1,
+                                    const float* __restrict__ w2, const float* __restrict__ scale2, const float* __restrict__ bias2,
+                                    const float* __restrict__ w3, float* __restrict__ out) {
+    using G = GeoF<C>;
+    for (long e = blockIdx.x * (long)kThreads + threadIdx.x; e < G::TOTAL_FLOATS; e += (long)gridDim.x * kThreads) {
+        float v = 0.f;
+        if (e >= G::PARAMS) {
+            const int q = (int)(e - G::PARAMS), which = q / HID, ch = q % HID;
+            v = which == 0 ? bias1[ch] : which == 1 ? expf(scale1[ch]) : which == 2 ? bias2[ch] : expf(scale2[ch]);
+        } else {
+            const long f = e / FRAG;
+            const int l = (int)(e % FRAG) / 4, i = (int)(e % 4);
+            const int m = l & 31, h = l >> 5;
+            if (f < G::S2) {                                            // W1[hb][q]: k = 2*(4q+i) + h, columns (tap, ci)
+                const int hb = (int)(f / G::NQ1), q = (int)(f % G::NQ1);
+                const int k = 2 * (4 * q + i) + h;
+                if (k < G::K1) v = w1[((long)(32 * hb + m) * G::Ch + k % G::Ch) * 9 + k / G::Ch];
+            } else if (f < G::NFRAG - D) {
+                const long r = f - G::S2;
+                const int g = (int)(r / (NHB * G::NBP)), hb2 = (int)(r / G::NBP) % NHB, j = (int)(r % G::NBP);
+                if (j < 4 * NHB) {                                      // W2[hb2][hb][q4]: input channel 32 hb + 8 q4 + 4 h + i
+                    const int hb = j / 4, q4 = j % 4;
+                    v = w2[(long)(32 * hb2 + m) * HID + 32 * hb + 8 * q4 + 4 * h + i];
+                } else if (j < G::NB) {                                 // W3 slice [rtl][q4]: row n = tap*C + co, input channel of block hb2
+                    const int rtl = (j - 4 * NHB) / 4, q4 = (j - 4 * NHB) % 4;
+                    const int n = 32 * (g * G::NRTG + rtl) + m, in = 32 * hb2 + 8 * q4 + 4 * h + i;
+                    if (n < G::NROW) v = w3[((long)(n % C) * HID + in) * 9 + n / C];
+                }
+            }
+        }
+        out[e] = v;
+    }
+}
+
+// ----------------------------------------------------------------------------- helpers
+template <class F, int... I>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ f32x4 ld_frag(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// relu((acc + b) * e^s) per row: lane half h holds rows drow(r, h) = 8 (r >> 2) + 4 h + (r & 3): four float4s of each vector
+__device__ __forceinline__ void epilogue(f32x16& acc, const float* __restrict__ bvec, const float* __restrict__ evec, int ch0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bvec + ch0 + 8 * q);
+        const f32x4 e = *reinterpret_cast<const f32x4*>(evec + ch0 + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q + i] = fmaxf(__fmul_rn(__fadd_rn(acc[4 * q + i], b[i]), e[i]), 0.f);
+    }
+}
+
+// ----------------------------------------------------------------------------- the kernel
+template <int C>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
+coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H, int W, const float* __restrict__ img,
+                        float* __restrict__ T) {
+    using G = GeoF<C>;
+    constexpr int Ch = G::Ch;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = lane >> 5, p = lane & 31;
+    const long pix = (long)blockIdx.x * 128 + wave * 32 + p;
+    const bool live = pix < npix;
+    const long pc = live ? pix : npix - 1;                               // clamped: absent pixels compute on a copy, store nothing
+    const int xx = (int)(pc % W), yy = (int)((pc / W) % H);
+    const float* __restrict__ params = img + G::PARAMS;
+
+    // ---- the wave's B operands of GEMM1: k-pair jj of lane (h, p) is column k = 2 jj + h of the pixel's im2col row, k = tap*Ch + ci
+    unsigned vmask = 0;
+    int poff[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const bool ok = (unsigned)(yy + dy) < (unsigned)H && (unsigned)(xx + dx) < (unsigned)W;
+        vmask |= ok ? 1u << tap : 0u;
+        poff[tap] = ok ? (dy * W + dx) * x_ld : 0;
+    }
+    const float* __restrict__ xrow = x + pc * x_ld;
+    float bx[G::KP1];
+    sfor<G::KP1>([&](auto jc) {
+        constexpr int jj = decltype(jc)::value;
+        constexpr int k0 = 2 * jj, k1 = 2 * jj + 1;
+        constexpr int t0 = k0 < G::K1 ? k0 / Ch : 9, t1 = k1 < G::K1 ? k1 / Ch : 9;      // tap 9: beyond K1, never valid
+        constexpr int c0 = k0 < G::K1 ? k0 % Ch : 0, c1 = k1 < G::K1 ? k1 % Ch : 0;
+        const int tap = h ? t1 : t0;
+        const bool ok = tap < 9 && ((vmask >> tap) & 1u);
+        int off = 0;
+        if constexpr (t0 < 9) { if (!h) off = poff[t0] + c0; }
+        if constexpr (t1 < 9) { if (h) off = poff[t1] + c1; }
+        const float v = xrow[ok ? off : 0];
+        bx[jj] = ok ? v : 0.f;
+    });
+
+    // ---- GEMM1: 16 hidden blocks, A fragments streamed in order through the register ring
+    const float* __restrict__ wp = img + (long)lane * 4;                  // this lane's 16 bytes of fragment 0
+    f32x4 ring[D];
+    sfor<D>([&](auto i) { ring[decltype(i)::value] = ld_frag(wp + (long)decltype(i)::value * FRAG); });
+    f32x16 h1[NHB];
+    sfor<NHB>([&](auto hbc) {
+        constexpr int hb = decltype(hbc)::value;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        sfor<G::NQ1>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            constexpr int f = hb * G::NQ1 + q;                            // fragment index in the whole stream
+            const f32x4 a = ring[f % D];
+            ring[f % D] = ld_frag(wp + (long)(f + D) * FRAG);             // the stream is one array: GEMM1 runs on into GEMM2/3's
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bx[4 * q + i], acc, 0, 0, 0);
+        });
+        epilogue(acc, params, params + HID, 32 * hb + 4 * h);
+        h1[hb] = acc;
+    });
+
+    // ---- GEMM2 + GEMM3, one hidden block of H2 at a time; NG passes over the retained H1 when GEMM3 has more than 7 row tiles
+    constexpr int PH = G::NW1 % D;                                        // ring phase at the start of the GEMM2/3 stream
+    const float* __restrict__ sp = wp + (long)G::S2 * FRAG;               // fragment j of the current block: sp + j * FRAG
+#pragma unroll 1
+    for (int g = 0; g < G::NG; ++g) {
+        f32x16 tap[G::NRTG];
+#pragma unroll
+        for (int t = 0; t < G::NRTG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tap[t][r] = 0.f;
+#pragma unroll 1
+        for (int hb2 = 0; hb2 < NHB; ++hb2) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            sfor<4 * NHB>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int hb = j / 4, q4 = j % 4;
+                const f32x4 a = ring[(PH + j) % D];
+                ring[(PH + j) % D] = ld_frag(sp + (long)(j + D) * FRAG);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], h1[hb][4 * q4 + i], acc, 0, 0, 0);
+            });
+            epilogue(acc, params + 2 * HID, params + 3 * HID, 32 * hb2 + 4 * h);
+            sfor<G::NBP - 4 * NHB>([&](auto jc) {
+                constexpr int j = 4 * NHB + decltype(jc)::value;
+                const f32x4 a = ring[(PH + j) % D];
+                ring[(PH + j) % D] = ld_frag(sp + (long)(j + D) * FRAG);
+                if constexpr (j < G::NB) {
+                    constexpr int rtl = (j - 4 * NHB) / 4, q4 = (j - 4 * NHB) % 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tap[rtl] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], acc[4 * q4 + i], tap[rtl], 0, 0, 0);
+                } else {
+                    asm volatile("" ::"v"(a));                            // padding fragment: loaded (keeps the ring phase), not used
+                }
+            });
+            sp += (long)G::NBP * FRAG;
+        }
+        // ---- this group's tap contributions: lane (h, p) holds rows 32 rt + 8 q + 4 h + 0..3 of pixel p as one float4
+        if (live) {
+            float* __restrict__ trow = T + pix * (long)G::NROW;
+#pragma unroll
+            for (int t = 0; t < G::NRTG; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n0 = 32 * (g * G::NRTG + t) + 8 * q + 4 * h;
+                    if (n0 < G::NROW) {
+                        f32x4 v = {tap[t][4 * q], tap[t][4 * q + 1], tap[t][4 * q + 2], tap[t][4 * q + 3]};
+                        *reinterpret_cast<f32x4*>(trow + n0) = v;
+                    }
+                }
+        }
+    }
+    // drain the ring (its last D loads hit the zero fragments behind the stream)
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        const f32x4 r = ring[i];
+        asm volatile("" ::"v"(r));
+    }
+}
+
+template <int C>
+int launch_mlp(const float* x, int x_ld, long npix, int H, int W, const float* img, float* T, hipStream_t s) {
+    const long nwg = cdiv(npix, 128);
+    hipLaunchKernelGGL((coupling_mlp_f32_kernel<C>), dim3((unsigned)nwg), dim3(kThreads), 0, s, x, x_ld, npix, H, W, img, T);
+    return NFDP_OK;
+}
+
+template <int C>
+int launch_pack(const float* w1, const float* s1, const float* b1, const float* w2, const float* s2, const float* b2, const float* w3,
+                float* out, hipStream_t s) {
+    hipLaunchKernelGGL((pack_mlp_f32_kernel<C>), dim3(stream_grid(GeoF<C>::TOTAL_FLOATS, kThreads)), dim3(kThreads), 0, s, w1, s1, b1, w2,
+                       s2, b2, w3, out);
+    return NFDP_OK;
+}
+
+}  // namespace
+
+#define NFDP_MLP_F32_DISPATCH(C, CALL)                 \
+    switch (C) {                                       \
+        case 4: CALL(4); break;                        \
+        case 8: CALL(8); break;                        \
+        case 12: CALL(12); break;                      \
+        case 16: CALL(16); break;                      \
+        case 24: CALL(24); break;                      \
+        case 48: CALL(48); break;                      \
+        default: break;                                \
+    }
+
+extern "C" size_t nfdp_coupling_mlp_f32_packed_bytes(int C) {
+    size_t n = 0;
+#define CALL(CC) n = (size_t)GeoF<CC>::TOTAL_FLOATS * 4
+    NFDP_MLP_F32_DISPATCH(C, CALL)
+#undef CALL
+    return n;
+}
+
+extern "C" int nfdp_coupling_mlp_f32_pack(const float* w1, const float* scale1, const float* bias1, const float* w2, const float* scale2,
+                                          const float* bias2, const float* w3, void* packed, int C, nfdp_stream_t stream) {
+    NFDP_REQUIRE(w1 && scale1 && bias1 && w2 && scale2 && bias2 && w3 && packed, NFDP_EINVAL, "coupling_mlp_f32_pack: null pointer");
+    NFDP_REQUIRE(nfdp_coupling_mlp_f32_packed_bytes(C) != 0, NFDP_EUNSUPPORTED, "coupling_mlp_f32_pack: C=%d (supported: 4,8,12,16,24,48)", C);
+    NFDP_REQUIRE(((uintptr_t)packed & 15) == 0, NFDP_ESHAPE, "coupling_mlp_f32_pack: packed must be 16-byte aligned");
+    int rc = NFDP_OK;
+#define CALL(CC) rc = launch_pack<CC>(w1, scale1, bias1, w2, scale2, bias2, w3, reinterpret_cast<float*>(packed), as_stream(stream))
+    NFDP_MLP_F32_DISPATCH(C, CALL)
+#undef CALL
+    NFDP_CHECK_LAUNCH("coupling_mlp_f32_pack");
+    return rc;
+}
+
+extern "C" int nfdp_coupling_mlp_f32(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C,
+                                     nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && packed && T, NFDP_EINVAL, "coupling_mlp_f32: null pointer");
+    NFDP_REQUIRE(nfdp_coupling_mlp_f32_packed_bytes(C) != 0, NFDP_EUNSUPPORTED, "coupling_mlp_f32: C=%d (supported: 4,8,12,16,24,48)", C);
+    NFDP_REQUIRE(B >= 0 && H > 0 && W > 0 && x_ld >= C / 2, NFDP_ESHAPE, "coupling_mlp_f32: bad shape B=%d H=%d W=%d x_ld=%d", B, H, W, x_ld);
+    NFDP_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)T & 15) == 0, NFDP_ESHAPE, "coupling_mlp_f32: packed / T must be 16-byte aligned");
+    const long npix = (long)B * H * W;
+    if (npix == 0) return NFDP_OK;
+    NFDP_REQUIRE(cdiv(npix, 128) < (1L << 31), NFDP_ESHAPE, "coupling_mlp_f32: too many pixels");
+    int rc = NFDP_OK;
+#define CALL(CC) rc = launch_mlp<CC>(x, x_ld, npix, H, W, reinterpret_cast<const float*>(packed), T, as_stream(stream))
+    NFDP_MLP_F32_DISPATCH(C, CALL)
+#undef CALL
+    NFDP_CHECK_LAUNCH("coupling_mlp_f32");
+    return rc;
+}

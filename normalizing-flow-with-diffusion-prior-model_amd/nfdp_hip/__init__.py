@@ -1422,6 +1422,47 @@ def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: t
     return out
 
 
+_F32_FUSED = True
+
+
+def set_f32_fused(on: bool) -> None:
+    """compute="f32": run the coupling networks on the exact-fp32 on-chip kernel (nfdp_coupling_mlp_f32, default) or conv by conv."""
+    global _F32_FUSED
+    _F32_FUSED = bool(on)
+
+
+def coupling_mlp_f32_supported(c: int, n_features: int) -> bool:
+    return _F32_FUSED and n_features == 512 and lib().nfdp_coupling_mlp_f32_packed_bytes(c) != 0
+
+
+def coupling_mlp_f32_pack(w1, scale1, bias1, w2, scale2, bias2, w3, out=None) -> torch.Tensor:
+    c = w3.shape[0]
+    n = lib().nfdp_coupling_mlp_f32_packed_bytes(c)
+    if n == 0:
+        raise NfdpError(f"coupling_mlp_f32_pack: C={c} unsupported")
+    if out is None or out.numel() != n:
+        out = torch.empty(n, device=w1.device, dtype=torch.uint8)
+    for t in (w1, scale1, bias1, w2, scale2, bias2, w3):
+        _need(t, torch.float32, "coupling_mlp_f32_pack"); _dense(t, "coupling_mlp_f32_pack")
+    _call("nfdp_coupling_mlp_f32_pack", _ptr(w1), _ptr(scale1), _ptr(bias1), _ptr(w2), _ptr(scale2), _ptr(bias2), _ptr(w3), _ptr(out), c,
+          _stream())
+    return out
+
+
+def coupling_net_tiled_f32(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: torch.Tensor, logs: torch.Tensor,
+                           mul_exp: float) -> torch.Tensor:
+    """NN(x_a) of an affine coupling in exact fp32, hidden activations on chip: nfdp_coupling_mlp_f32 (3x3 gather + three fp32-MFMA
+    GEMMs) -> tap shift-sum with the ZeroConv2d epilogue.  xh_a: [B,H,W,C/2] fp32 pixel-strided view; returns (log_s | t) [B,H,W,C]."""
+    _need(xh_a, torch.float32, "coupling_net_tiled_f32")
+    b, h, w, _ = xh_a.shape
+    t = torch.empty((b, h, w, 9 * c), device=xh_a.device, dtype=torch.float32)
+    _call("nfdp_coupling_mlp_f32", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled_f32"), b, h, w, _ptr(packed), _ptr(t), c, _stream(),
+          label=f"coupling_mlp_f32<{c}> hw{h}", flops=2.0 * b * h * w * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c))
+    out = torch.empty((b, h, w, c), device=xh_a.device, dtype=torch.float32)
+    _call("nfdp_tap_shift_sum_f32", _ptr(t), _ptr(out), b, h, w, c, _ptr(bias), _ptr(logs), float(mul_exp), 0, _stream())
+    return out
+
+
 def use_narrow_conv(cin: int, cout: int, k: int) -> bool:
     return k == 3 and cout <= 64 and cin >= 4 * cout and cin >= 128
 

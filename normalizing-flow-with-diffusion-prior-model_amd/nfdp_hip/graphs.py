@@ -50,3 +50,65 @@ class Graphed:
             from . import bump_param_epoch
             bump_param_epoch()
         return self._out
+
+
+class CapturedStep:
+    """A whole training (or evaluation) step captured once as a hipGraph: `step = capture_step(fn); step()` replays it and returns the
+    captured outputs (tensors written in place by every replay).  See capture_step."""
+
+    def __init__(self, graph, outputs, mutates_params: bool):
+        self.graph, self.outputs, self._mutates = graph, outputs, mutates_params
+
+    def __call__(self):
+        self.graph.replay()
+        if self._mutates:
+            from . import bump_param_epoch
+            bump_param_epoch()          # the replay updated parameters behind torch's version counters: weight-layout caches follow
+        return self.outputs
+
+    replay = __call__
+
+
+def capture_step(fn: Callable, warmup: int = 3, mutates_params: bool = True, capture_error_mode: str = None) -> CapturedStep:
+    """Capture `fn()` - a complete step with no arguments that reads its inputs from fixed tensors, e.g.
+
+        def fn():
+            loss = sum(prior(latents)); opt.zero_grad(); loss.backward(); opt.step(); return loss
+
+    - as ONE hipGraph, the one way this package captures steps (bench.py, tools/bench_diffusion_train.py):
+      * `warmup` eager calls first, on a SIDE stream (torch's recipe for whole-step capture: lazily created state - packed weight
+        images, workspaces, autograd's accumulation nodes, optimizer state - is then built outside the capture and not bound to the
+        legacy default stream), joined back before the capture;
+      * refuses (RuntimeError) to nest inside a running capture, to capture with warmup < 1, and a step that syncs with the host
+        fails inside torch.cuda.graph with torch's own error rather than hanging;
+      * with a process group of more than one rank the capture runs in "thread_local" error mode (RCCL's watchdog thread may call
+        into HIP meanwhile); pass capture_error_mode to override.
+    fn must use static shapes and draw its randomness on the device (GaussianDiffusion.forward does; self_condition=True does not
+    and raises).  The returned object replays the graph; its outputs alias fn's return value.
+
+    Round 2 recorded a host segfault in hipStreamEndCapture for a step captured after eager steps on the legacy default stream
+    and blamed autograd's AccumulateGrad nodes.  tools/probe_capture_abort.py (profiles/r03_probe_capture_abort.json: 15 child
+    processes - Glow and diffusion-prior steps, default- and side-stream warm-up, direct / AccumulateGrad / torch.optim.Adam
+    gradients, including the original configuration) does NOT reproduce it on the current code: every combination captures and
+    replays.  The side-stream warm-up is kept because it is torch's documented contract, not because of that crash."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("capture_step needs the GPU (there is no CPU fallback)")
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("capture_step: a capture is already running on this stream (captures do not nest)")
+    if warmup < 1:
+        raise RuntimeError("capture_step: at least one warm-up call is needed (lazily built state must exist before the capture)")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(warmup):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if capture_error_mode is None:
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        capture_error_mode = "thread_local" if multi else "global"
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, capture_error_mode=capture_error_mode):
+        out = fn()
+    return CapturedStep(graph, out, mutates_params)

@@ -153,6 +153,12 @@ class AffineCoupling(Transform):
                 K.coupling_mlp_supported(c, self.n_features) and self.net.fused_ready():
             zc = self.net[-1]
             return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(), c, zc.bias, zc.logs.view(-1), zc.logscale_factor)
+        if self.fused and K.compute_enum(self.compute) == K.F32 and xh.dtype == torch.float32 and \
+                K.coupling_mlp_f32_supported(c, self.n_features) and self.net.fused_ready():
+            # exact fp32 with the hidden activations on chip (any image size): 3x3 gather + three fp32-MFMA GEMMs in one launch
+            zc = self.net[-1]
+            return K.coupling_net_tiled_f32(xh[..., : c // 2], self.net.mlp_f32_packed(), c, zc.bias, zc.logs.view(-1),
+                                            zc.logscale_factor)
         return self.net.forward_nhwc(xh[..., : c // 2], compute=self.compute)
 
     def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], ldj_const: Optional[Tensor] = None) -> Tensor:

@@ -160,6 +160,20 @@ class CouplingNet(nn.Sequential):
             self._fused_key = key
         return self._fused
 
+    def mlp_f32_packed(self):
+        """The fragment-ordered fp32 image of the network for nfdp_coupling_mlp_f32 (compute="f32"), rebuilt when a parameter changes;
+        None while a hidden ActNorm still awaits its data-dependent init."""
+        c1, c2, zc = self[0], self[2], self[4]
+        if not (c1.actnorm.initialized() and c2.actnorm.initialized()):
+            return None
+        ts = (c1.conv.weight, c1.actnorm.scale, c1.actnorm.bias, c2.conv.weight, c2.actnorm.scale, c2.actnorm.bias, zc.weight)
+        key = tuple((t.data_ptr(), t._version) for t in ts) + (K.param_epoch(),)
+        if getattr(self, "_mlp_f32_key", None) != key:
+            self._mlp_f32 = K.coupling_mlp_f32_pack(*[t.detach().reshape(-1) if t.dim() != 4 else t.detach().contiguous() for t in ts],
+                                                    out=getattr(self, "_mlp_f32", None))
+            self._mlp_f32_key = key
+        return self._mlp_f32
+
     def _pack_params(self):
         c1, c2, zc = self[0], self[2], self[4]
         return (c1.conv.weight, c1.actnorm.scale, c1.actnorm.bias, c2.conv.weight, c2.actnorm.scale, c2.actnorm.bias,

@@ -210,3 +210,43 @@ def test_tiled_coupling_network_any_image_size(c, hw, b):
     assert torch.isfinite(y).all() and torch.isfinite(ldj).all()
     xr = cp.invert_nhwc_(y.clone())
     assert float((xr - x).abs().max()) < 1e-4 * float(x.abs().max())       # same NN(x_a) both ways: exact up to the 1e-6 quirk
+
+
+# ----------------------------------------------------------------------------- exact fp32, hidden activations on chip
+F32_GEOMS = [(4, 16, 16, 3), (12, 16, 16, 5), (8, 8, 8, 5), (24, 8, 8, 7), (16, 4, 4, 11), (48, 4, 4, 19), (12, 6, 10, 3), (24, 32, 32, 1)]
+
+
+@pytest.mark.parametrize("c,hh,ww,b", F32_GEOMS)
+@torch.no_grad()
+def test_f32_onchip_coupling_network_against_oracle(c, hh, ww, b):
+    """nfdp_coupling_mlp_f32 (3x3 gather + three exact-fp32 MFMA GEMMs, hidden activations in registers) + tap shift-sum = NN(x_a) of
+    utils.py:83-89 in fp32: against the CPU oracle and the conv-by-conv fp32 HIP path, every supported channel count, square and
+    non-square images, pixel counts that are not a multiple of the 128-pixel workgroup; then the whole coupling layer forward /
+    inverse through AffineCoupling(compute="f32") on a channel-strided view (x_ld = C)."""
+    from normalizing_flow import AffineCoupling
+    m = AffineCoupling(c, n_features=512, compute="f32")
+    sd = {k: T(synth_tensor("flows.3.affcoupling." + k, v.shape, 11, DEEP)) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    osd = {"flows.3.affcoupling." + k: v for k, v in sd.items()}
+    x = T(synth_input(f"f32x{c}_{hh}", (b, c, hh, ww), 5)) * 0.6
+    xh = K.to_nhwc(x.to(DEV)).contiguous()
+    assert K.coupling_mlp_f32_supported(c, 512)
+    K.start_trace()
+    h_fused = m._net_nhwc(xh)
+    labels = [e["label"] for e in K.stop_trace()]
+    assert any(lb.startswith("coupling_mlp_f32") for lb in labels), labels          # the on-chip kernel really ran
+    h_ref = O.coupling_net(x[:, : c // 2], osd, "flows.3.affcoupling.net.")
+    assert_close(K.as_nchw(h_fused), h_ref, 2e-5, "on-chip fp32 network vs oracle")
+    K.set_f32_fused(False)
+    try:
+        h_plain = m._net_nhwc(xh)
+    finally:
+        K.set_f32_fused(True)
+    assert_close(h_fused, h_plain, 2e-5, "on-chip fp32 network vs conv-by-conv fp32")
+    ldj = torch.zeros(b, dtype=torch.float64, device=DEV)
+    y, ldj, _ = m.transform(x.to(DEV), ldj, None)
+    yo, lo = O.coupling_fwd(x, osd, "flows.3.affcoupling.net.", torch.zeros(b, dtype=torch.float64))
+    assert_close(y, yo, 1e-5, "coupling forward")
+    assert_close(ldj, lo, 1e-6, "coupling log-det")
+    assert_close(m.invert(y), O.coupling_inv(yo, osd, "flows.3.affcoupling.net."), 1e-5, "coupling inverse")

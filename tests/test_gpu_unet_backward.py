@@ -249,3 +249,65 @@ def test_joint_training_gradient_reaches_the_flow():
     assert n_checked >= 10
     for k, p in u.named_parameters():
         assert relerr(p.grad, uo[k].grad) <= 2e-4, f"unet grad {k}"
+
+
+def test_captured_diffusion_training_step_matches_eager():
+    """nfdp_hip.graphs.capture_step on the diffusion-prior training step (diffusion_prior/trainer.py:134-150 with the fused Adam): the
+    captured step replays the eager step - same loss, same gradients, same parameters after each of three steps (timesteps and noise
+    injected so both consume identical randomness).  Eager steps run on the DEFAULT stream before the capture on purpose: that order
+    is what round 2 reported as a host segfault in hipStreamEndCapture (see tools/probe_capture_abort.py)."""
+    from normalizing_flow import NFBackbone, initialize_with_zeros
+    from diffusion_prior import DiffusionPrior, IdentityFormater
+    from nfdp_hip.optim import FusedAdam
+    from nfdp_hip.graphs import capture_step
+    B = 8
+    nf = NFBackbone(model_dir="", in_channel=1, L=2, K=1, learn_prior_mean_logs=True, freeze_flow=True).to(DEV)
+    fmt = IdentityFormater(2, 1, 16)
+    shapes = fmt.get_input_shapes()
+
+    def make():
+        torch.manual_seed(3)
+        prior = DiffusionPrior(latent_formater=fmt, unet_kwargs={"dim": 32, "dim_mults": (1, 2), "resnet_block_groups": 8},
+                               diffusion_kwargs={"timesteps": 50, "beta_schedule": "cosine", "loss_type": "l2"},
+                               image_sizes=[int(s[1]) for s in shapes], latent_channels=[int(s[0]) for s in shapes]).to(DEV)
+        g = torch.Generator().manual_seed(5)
+        for p in prior.parameters():                                  # away from the zero-output init, identically for both copies
+            p.data.add_(0.05 * torch.randn(p.shape, generator=g).to(DEV))
+        prior.train()
+        return prior, FusedAdam(list(prior.parameters(only_trainable=True)), lr=1e-3)
+
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(B, 1, 16, 16, generator=g) - 0.5).to(DEV)
+    with torch.no_grad():
+        latents, _ = nf.transform(x, initialize_with_zeros(1, B, torch.device(DEV)))
+    ts = [torch.randint(0, 50, (B,), generator=g).to(DEV) for _ in latents]
+    eps = [torch.randn(z.shape, generator=g).to(DEV) for z in latents]
+
+    def step_of(prior, opt):
+        def step():
+            loss = sum(pr.diffusion.p_losses(z, t, noise=e) for pr, z, t, e in zip(prior.priors, latents, ts, eps))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+
+    pe, oe = make()
+    pc, oc = make()
+    eager, cstep = step_of(pe, oe), step_of(pc, oc)
+    for _ in range(2):                                                # eager steps on the legacy default stream first, for BOTH copies
+        eager()
+        cstep()
+    cap = capture_step(cstep, warmup=1)                               # one more (side-stream) warm-up step, then the capture's own
+    eager()
+    eager()                                                           # ... so the eager copy has taken as many steps: 2 + 1 + 1
+    with pytest.raises(RuntimeError):
+        capture_step(cstep, warmup=0)
+    for k in range(3):
+        l_e = eager()
+        l_c = cap()
+        torch.cuda.synchronize()
+        assert_close(l_c, l_e.detach(), 1e-5, f"replay {k}: loss")
+        assert relerr(oc.flat_grad, oe.flat_grad) <= 1e-4, f"replay {k}: gradient {relerr(oc.flat_grad, oe.flat_grad):.2e}"
+        assert relerr(oc.flat_param, oe.flat_param) <= 1e-5, f"replay {k}: parameters"
+    assert oc.step_count == oe.step_count == 7

@@ -40,20 +40,12 @@ def step():
     return loss
 
 
-# The whole step as ONE hipGraph (timesteps and noise are drawn on the device, the fused Adam keeps its step count there).  torch's
-# recipe: every eager step BEFORE the capture runs on a side stream - autograd's AccumulateGrad nodes remember the stream they were
-# created on, and a capture that has to wait for the legacy default stream dies in hipStreamEndCapture (segfault, seen here).
+# The whole step as ONE hipGraph (timesteps and noise are drawn on the device, the fused Adam keeps its step count there), through the
+# package's one capture helper (side-stream warm-up, nfdp_hip.graphs.capture_step).
 if os.environ.get("NFDP_GRAPH", "1") != "0":
-    warm = torch.cuda.Stream()
-    warm.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(warm):
-        for _ in range(3):
-            step()
-    torch.cuda.current_stream().wait_stream(warm)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        g_loss = step()
+    from nfdp_hip.graphs import capture_step
+    g = capture_step(step, warmup=3)
+    g_loss = g.outputs
     for _ in range(2):
         g.replay()
     torch.cuda.synchronize()

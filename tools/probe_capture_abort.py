@@ -20,6 +20,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [(m, w, g) for m in ("diffusion", "glow") for w in ("default", "side") for g in ("direct", "accumulate", "torchadam")]
+# the configuration round 2's crash was seen in (tools/bench_diffusion_train.py: K = 4, dim 64, T = 1000, B = 64), default-stream warm-up
+CASES += [("diffusion_big", "default", g) for g in ("direct", "accumulate", "torchadam")]
+if os.environ.get("NFDP_PROBE_ONLY"):
+    CASES = [c for c in CASES if c[0] == os.environ["NFDP_PROBE_ONLY"]]
 
 
 def child(case):
@@ -32,14 +36,17 @@ def child(case):
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
     B = 16
+    big = model == "diffusion_big"
+    if big:
+        model, B = "diffusion", 64
     if model == "diffusion":
         from normalizing_flow import NFBackbone, initialize_with_zeros
         from diffusion_prior import DiffusionPrior, IdentityFormater
-        nf = NFBackbone(model_dir="", in_channel=1, L=3, K=2, learn_prior_mean_logs=True, freeze_flow=True).to(dev)
+        nf = NFBackbone(model_dir="", in_channel=1, L=3, K=4 if big else 2, learn_prior_mean_logs=True, freeze_flow=True).to(dev)
         fmt = IdentityFormater(3, 1, 32)
         shapes = fmt.get_input_shapes()
-        prior = DiffusionPrior(latent_formater=fmt, unet_kwargs={"dim": 32, "dim_mults": (1, 2), "resnet_block_groups": 8},
-                               diffusion_kwargs={"timesteps": 100, "beta_schedule": "cosine", "loss_type": "l2"},
+        prior = DiffusionPrior(latent_formater=fmt, unet_kwargs={"dim": 64 if big else 32, "dim_mults": (1, 2), "resnet_block_groups": 8},
+                               diffusion_kwargs={"timesteps": 1000 if big else 100, "beta_schedule": "cosine", "loss_type": "l2"},
                                image_sizes=[int(s[1]) for s in shapes], latent_channels=[int(s[0]) for s in shapes]).to(dev)
         params = list(prior.parameters(only_trainable=True))
         x = (torch.rand(B, 1, 32, 32) - 0.5).to(dev)
