@@ -10,13 +10,14 @@
 // are the three narrow 512 -> C 3x3 convs (10-43 TFLOP/s as implicit GEMMs) and the rest moves two 268 MB hidden tensors per flow
 // through HBM.  gfx950 has no TF32-like mode; v_mfma_f32_32x32x2_f32 multiplies and accumulates in plain fp32 at 1/16 of the bf16
 // rate, so at that rate everything except the matrix pipe is cheap and the design is the simple one:
-//  * a workgroup = 4 waves = 128 consecutive pixels (any image size: the spatial parts of the two 3x3 convs are a gather in front and
-//    the tap shift-sum behind), one wave per SIMD with the whole 512-register budget, every wave 32 pixels;
+//  * a workgroup = ONE wave = 32 consecutive pixels (any image size: the spatial parts of the two 3x3 convs are a gather in front and
+//    the tap shift-sum behind) with the whole 512-register budget of its SIMD; waves share nothing, so there is no LDS and no barrier,
+//    four of them run per CU, and the 4x4 level of a 512-image batch (8192 pixels) still gives every CU a wave;
 //  * all three GEMMs TRANSPOSED (rows = output channel, lanes = pixel): a 32x32 accumulator tile of one GEMM, after its epilogue, IS
 //    the B operand of the next - register r of lane (h, p) holds channel drow(r, h) of pixel p, and the instruction's two k values are
 //    the two lane halves, so "k-pair r" of a hidden block is accumulator register r as it stands.  The 512 hidden channels of 32
 //    pixels are 256 registers; H2 is produced one 32-channel block at a time and consumed at once by GEMM3 (tap accumulators: up to 7
-//    row tiles = 112 registers; C = 48 has 14 and runs the GEMM2/3 loop twice over the retained H1);
+//    row tiles = 112 registers; C = 48 has 14: two waves (blockIdx.y) take seven each and both compute H1 and H2);
 //  * weights are read straight from global memory (L2) in MFMA-fragment order, one global_load_dwordx4 per lane = 4 k-pairs of a
 //    32-row tile = 1 KiB per wave-instruction per 4 MFMAs (256 cycles): 16 B/clk per CU, far under the per-CU L2 rate, so no LDS
 //    staging and no barriers at all; an 8-deep register ring keeps ~1 us of weights in flight per wave;
@@ -29,7 +30,8 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = 256;                         // packer
+constexpr int kWave = 64;                              // the network kernel: one wave per workgroup
 constexpr int HID = 512;
 constexpr int NHB = HID / 32;
 constexpr int D = 8;                                   // weight fragments in flight per wave (1 KiB each)
@@ -121,14 +123,14 @@ __device__ __forceinline__ void epilogue(f32x16& acc, const float* __restrict__ 
 
 // ----------------------------------------------------------------------------- the kernel
 template <int C>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 1)))
+__global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1)))
 coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H, int W, const float* __restrict__ img,
                         float* __restrict__ T) {
     using G = GeoF<C>;
     constexpr int Ch = G::Ch;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x;
     const int h = lane >> 5, p = lane & 31;
-    const long pix = (long)blockIdx.x * 128 + wave * 32 + p;
+    const long pix = (long)blockIdx.x * 32 + p;
     const bool live = pix < npix;
     const long pc = live ? pix : npix - 1;                               // clamped: absent pixels compute on a copy, store nothing
     const int xx = (int)(pc % W), yy = (int)((pc / W) % H);
@@ -177,16 +179,21 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
             ring[f % D] = ld_frag(wp + (long)(f + D) * FRAG);             // the stream is one array: GEMM1 runs on into GEMM2/3's
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bx[4 * q + i], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);      // keep the refill where it is: under register pressure hipcc sinks it to its use
         });
         epilogue(acc, params, params + HID, 32 * hb + 4 * h);
         h1[hb] = acc;
     });
 
-    // ---- GEMM2 + GEMM3, one hidden block of H2 at a time; NG passes over the retained H1 when GEMM3 has more than 7 row tiles
+    // ---- GEMM2 + GEMM3, one hidden block of H2 at a time; GEMM3's row tiles in groups of at most 7, one group per wave (blockIdx.y)
     constexpr int PH = G::NW1 % D;                                        // ring phase at the start of the GEMM2/3 stream
-    const float* __restrict__ sp = wp + (long)G::S2 * FRAG;               // fragment j of the current block: sp + j * FRAG
-#pragma unroll 1
-    for (int g = 0; g < G::NG; ++g) {
+    const int g = G::NG > 1 ? (int)blockIdx.y : 0;
+    const float* __restrict__ sp = wp + ((long)G::S2 + (long)g * NHB * G::NBP) * FRAG;      // fragment j of the current block: sp + j * FRAG
+    if (G::NG > 1 && g > 0) {                                             // this group's stream is not behind GEMM1's: restart the ring
+#pragma unroll
+        for (int i = 0; i < D; ++i) ring[(PH + i) % D] = ld_frag(sp + (long)i * FRAG);
+    }
+    {
         f32x16 tap[G::NRTG];
 #pragma unroll
         for (int t = 0; t < G::NRTG; ++t)
@@ -204,6 +211,7 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
                 ring[(PH + j) % D] = ld_frag(sp + (long)(j + D) * FRAG);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], h1[hb][4 * q4 + i], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             });
             epilogue(acc, params + 2 * HID, params + 3 * HID, 32 * hb2 + 4 * h);
             sfor<G::NBP - 4 * NHB>([&](auto jc) {
@@ -217,6 +225,7 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
                 } else {
                     asm volatile("" ::"v"(a));                            // padding fragment: loaded (keeps the ring phase), not used
                 }
+                __builtin_amdgcn_sched_barrier(0);
             });
             sp += (long)G::NBP * FRAG;
         }
@@ -245,8 +254,8 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
 
 template <int C>
 int launch_mlp(const float* x, int x_ld, long npix, int H, int W, const float* img, float* T, hipStream_t s) {
-    const long nwg = cdiv(npix, 128);
-    hipLaunchKernelGGL((coupling_mlp_f32_kernel<C>), dim3((unsigned)nwg), dim3(kThreads), 0, s, x, x_ld, npix, H, W, img, T);
+    const long nwg = cdiv(npix, 32);
+    hipLaunchKernelGGL((coupling_mlp_f32_kernel<C>), dim3((unsigned)nwg, GeoF<C>::NG), dim3(kWave), 0, s, x, x_ld, npix, H, W, img, T);
     return NFDP_OK;
 }
 
@@ -300,7 +309,7 @@ extern "C" int nfdp_coupling_mlp_f32(const float* x, int x_ld, int B, int H, int
     NFDP_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)T & 15) == 0, NFDP_ESHAPE, "coupling_mlp_f32: packed / T must be 16-byte aligned");
     const long npix = (long)B * H * W;
     if (npix == 0) return NFDP_OK;
-    NFDP_REQUIRE(cdiv(npix, 128) < (1L << 31), NFDP_ESHAPE, "coupling_mlp_f32: too many pixels");
+    NFDP_REQUIRE(cdiv(npix, 32) < (1L << 31), NFDP_ESHAPE, "coupling_mlp_f32: too many pixels");
     int rc = NFDP_OK;
 #define CALL(CC) rc = launch_mlp<CC>(x, x_ld, npix, H, W, reinterpret_cast<const float*>(packed), T, as_stream(stream))
     NFDP_MLP_F32_DISPATCH(C, CALL)
