@@ -34,7 +34,7 @@ constexpr int kThreads = 256;                         // packer
 constexpr int kWave = 64;                              // the network kernel: one wave per workgroup
 constexpr int HID = 512;
 constexpr int NHB = HID / 32;
-constexpr int D = 8;                                   // weight fragments in flight per wave (1 KiB each)
+constexpr int DMAX = 16;                               // weight fragments in flight per wave (1 KiB each): 16, or 8 where registers are short
 constexpr int FRAG = 256;                              // floats per fragment: 64 lanes x 4 k-pairs
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -47,6 +47,7 @@ struct GeoF {
     static constexpr int K1 = 9 * Ch;
     static constexpr int NQ1 = (K1 + 7) / 8;           // fragments (4 k-pairs = 8 k) per hidden block of GEMM1
     static constexpr int KP1 = 4 * NQ1;                // k-pairs of GEMM1, padded
+    static constexpr int D = C >= 48 ? 8 : (C >= 16 ? 12 : DMAX);   // ring depth, by what the registers leave (no scratch in the loops)
     static constexpr int NROW = 9 * C;
     static constexpr int NRT = (NROW + 31) / 32;
     static constexpr int NG = (NRT + 6) / 7;           // GEMM3 row groups (tap accumulators: at most 7 tiles = 112 registers)
@@ -81,7 +82,7 @@ __global__ void pack_mlp_f32_kernel(const float* __restrict__ w1, const float* _
                 const int hb = (int)(f / G::NQ1), q = (int)(f % G::NQ1);
                 const int k = 2 * (4 * q + i) + h;
                 if (k < G::K1) v = w1[((long)(32 * hb + m) * G::Ch + k % G::Ch) * 9 + k / G::Ch];
-            } else if (f < G::NFRAG - D) {
+            } else if (f < G::NFRAG - G::D) {
                 const long r = f - G::S2;
                 const int g = (int)(r / (NHB * G::NBP)), hb2 = (int)(r / G::NBP) % NHB, j = (int)(r % G::NBP);
                 if (j < 4 * NHB) {                                      // W2[hb2][hb][q4]: input channel 32 hb + 8 q4 + 4 h + i
@@ -110,15 +111,24 @@ __device__ __forceinline__ void sfor(F&& f) {
 
 __device__ __forceinline__ f32x4 ld_frag(const float* __restrict__ p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// relu((acc + b) * e^s) per row: lane half h holds rows drow(r, h) = 8 (r >> 2) + 4 h + (r & 3): four float4s of each vector
-__device__ __forceinline__ void epilogue(f32x16& acc, const float* __restrict__ bvec, const float* __restrict__ evec, int ch0) {
+// relu((acc + b) * e^s) per row: lane half h holds rows drow(r, h) = 8 (r >> 2) + 4 h + (r & 3), i.e. four float4s of each parameter
+// vector.  The parameters are REQUESTED at the top of a hidden block (they are older than every weight fragment of the block, so they
+// are back long before its 256 MFMAs are done) - loaded in the epilogue itself they exposed a full L2 latency per block.
+struct EpiRegs { f32x4 b[4], e[4]; };
+__device__ __forceinline__ EpiRegs epi_load(const float* __restrict__ bvec, const float* __restrict__ evec, int ch0) {
+    EpiRegs r;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bvec + ch0 + 8 * q);
-        const f32x4 e = *reinterpret_cast<const f32x4*>(evec + ch0 + 8 * q);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * q + i] = fmaxf(__fmul_rn(__fadd_rn(acc[4 * q + i], b[i]), e[i]), 0.f);
+        r.b[q] = *reinterpret_cast<const f32x4*>(bvec + ch0 + 8 * q);
+        r.e[q] = *reinterpret_cast<const f32x4*>(evec + ch0 + 8 * q);
     }
+    return r;
+}
+__device__ __forceinline__ void epilogue(f32x16& acc, const EpiRegs& p) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * q + i] = fmaxf(__fmul_rn(__fadd_rn(acc[4 * q + i], p.b[q][i]), p.e[q][i]), 0.f);
 }
 
 // ----------------------------------------------------------------------------- the kernel
@@ -127,7 +137,7 @@ __global__ void __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(1, 1
 coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H, int W, const float* __restrict__ img,
                         float* __restrict__ T) {
     using G = GeoF<C>;
-    constexpr int Ch = G::Ch;
+    constexpr int Ch = G::Ch, D = G::D;
     const int lane = threadIdx.x;
     const int h = lane >> 5, p = lane & 31;
     const long pix = (long)blockIdx.x * 32 + p;
@@ -172,6 +182,8 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const EpiRegs ep = epi_load(params, params + HID, 32 * hb + 4 * h);
+        __builtin_amdgcn_sched_barrier(0);
         sfor<G::NQ1>([&](auto qc) {
             constexpr int q = decltype(qc)::value;
             constexpr int f = hb * G::NQ1 + q;                            // fragment index in the whole stream
@@ -181,7 +193,7 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
             for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bx[4 * q + i], acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);      // keep the refill where it is: under register pressure hipcc sinks it to its use
         });
-        epilogue(acc, params, params + HID, 32 * hb + 4 * h);
+        epilogue(acc, ep);
         h1[hb] = acc;
     });
 
@@ -189,8 +201,8 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
     constexpr int PH = G::NW1 % D;                                        // ring phase at the start of the GEMM2/3 stream
     const int g = G::NG > 1 ? (int)blockIdx.y : 0;
     const float* __restrict__ sp = wp + ((long)G::S2 + (long)g * NHB * G::NBP) * FRAG;      // fragment j of the current block: sp + j * FRAG
-    if (G::NG > 1 && g > 0) {                                             // this group's stream is not behind GEMM1's: restart the ring
-#pragma unroll
+    if constexpr (G::NG > 1) {                                            // a group's stream is not behind GEMM1's: restart the ring
+#pragma unroll                                                            // (unconditionally: a branch on g here made hipcc spill 493 registers)
         for (int i = 0; i < D; ++i) ring[(PH + i) % D] = ld_frag(sp + (long)i * FRAG);
     }
     {
@@ -204,6 +216,8 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const EpiRegs ep = epi_load(params + 2 * HID, params + 3 * HID, 32 * hb2 + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);
             sfor<4 * NHB>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
                 constexpr int hb = j / 4, q4 = j % 4;
@@ -213,7 +227,7 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
                 for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], h1[hb][4 * q4 + i], acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             });
-            epilogue(acc, params + 2 * HID, params + 3 * HID, 32 * hb2 + 4 * h);
+            epilogue(acc, ep);
             sfor<G::NBP - 4 * NHB>([&](auto jc) {
                 constexpr int j = 4 * NHB + decltype(jc)::value;
                 const f32x4 a = ring[(PH + j) % D];
