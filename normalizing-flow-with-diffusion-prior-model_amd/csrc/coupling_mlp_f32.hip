@@ -198,11 +198,18 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
     });
 
     // ---- GEMM2 + GEMM3, one hidden block of H2 at a time; GEMM3's row tiles in groups of at most 7, one group per wave (blockIdx.y)
-    constexpr int PH = G::NW1 % D;                                        // ring phase at the start of the GEMM2/3 stream
+    constexpr int PH = 0;                                                 // ring phase at the start of the GEMM2/3 walk
+    static_assert(4 * NHB + D <= G::NBP, "the refills of GEMM2's fragments stay inside the block");
     const int g = G::NG > 1 ? (int)blockIdx.y : 0;
-    const float* __restrict__ sp = wp + ((long)G::S2 + (long)g * NHB * G::NBP) * FRAG;      // fragment j of the current block: sp + j * FRAG
-    if constexpr (G::NG > 1) {                                            // a group's stream is not behind GEMM1's: restart the ring
-#pragma unroll                                                            // (unconditionally: a branch on g here made hipcc spill 493 registers)
+    // Every wave of the launch walks the same weight image; in lockstep they would all ask the same L2 channel for the same KiB at the
+    // same time (measured: 69 % of the fp32 matrix peak at the 16x16 level).  H2's blocks are independent, so wave t starts at block
+    // t mod 16 and wraps: at any moment the chip's reads are spread over the whole image.  (GEMM3 then adds the blocks' contributions in
+    // a rotated order: fp32 sums that differ between tiles by rounding only, fixed for a given pixel index.)
+    const float* __restrict__ gbase = wp + ((long)G::S2 + (long)g * NHB * G::NBP) * FRAG;   // block b of this group: gbase + b * NBP * FRAG
+    const int rot = (int)(blockIdx.x & (NHB - 1));
+    const float* __restrict__ sp = gbase + (long)rot * G::NBP * FRAG;     // fragment j of the current block: sp + j * FRAG
+    {                                                                     // the ring restarts at the first block of this wave's walk
+#pragma unroll
         for (int i = 0; i < D; ++i) ring[(PH + i) % D] = ld_frag(sp + (long)i * FRAG);
     }
     {
@@ -212,7 +219,9 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
 #pragma unroll
             for (int r = 0; r < 16; ++r) tap[t][r] = 0.f;
 #pragma unroll 1
-        for (int hb2 = 0; hb2 < NHB; ++hb2) {
+        for (int it = 0; it < NHB; ++it) {
+            const int hb2 = (rot + it) & (NHB - 1);
+            const float* __restrict__ spn = gbase + (long)((hb2 + 1) & (NHB - 1)) * G::NBP * FRAG;    // the next block of the walk
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -222,7 +231,7 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
                 constexpr int j = decltype(jc)::value;
                 constexpr int hb = j / 4, q4 = j % 4;
                 const f32x4 a = ring[(PH + j) % D];
-                ring[(PH + j) % D] = ld_frag(sp + (long)(j + D) * FRAG);
+                ring[(PH + j) % D] = ld_frag(sp + (long)(j + D) * FRAG);              // (j + D < NBP here: 64 + D <= NBP)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], h1[hb][4 * q4 + i], acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -231,7 +240,8 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
             sfor<G::NBP - 4 * NHB>([&](auto jc) {
                 constexpr int j = 4 * NHB + decltype(jc)::value;
                 const f32x4 a = ring[(PH + j) % D];
-                ring[(PH + j) % D] = ld_frag(sp + (long)(j + D) * FRAG);
+                if constexpr (j + D < G::NBP) ring[(PH + j) % D] = ld_frag(sp + (long)(j + D) * FRAG);
+                else ring[(PH + j) % D] = ld_frag(spn + (long)(j + D - G::NBP) * FRAG);   // the ring runs on into the next block
                 if constexpr (j < G::NB) {
                     constexpr int rtl = (j - 4 * NHB) / 4, q4 = (j - 4 * NHB) % 4;
 #pragma unroll
@@ -241,7 +251,7 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
                 }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            sp += (long)G::NBP * FRAG;
+            sp = spn;
         }
         // ---- this group's tap contributions: lane (h, p) holds rows 32 rt + 8 q + 4 h + 0..3 of pixel p as one float4
         if (live) {
