@@ -87,7 +87,7 @@ def capture_step(fn: Callable, warmup: int = 3, mutates_params: bool = True, cap
     and raises).  The returned object replays the graph; its outputs alias fn's return value.
 
     Round 2 recorded a host segfault in hipStreamEndCapture for a step captured after eager steps on the legacy default stream
-    and blamed autograd's AccumulateGrad nodes.  tools/probe_capture_abort.py (profiles/r03_probe_capture_abort.json: 15 child
+    and blamed autograd's AccumulateGrad nodes.  tools/probe_capture_abort.py (profiles/r03_probe_capture_abort.txt: 15 child
     processes - Glow and diffusion-prior steps, default- and side-stream warm-up, direct / AccumulateGrad / torch.optim.Adam
     gradients, including the original configuration) does NOT reproduce it on the current code: every combination captures and
     replays.  The side-stream warm-up is kept because it is torch's documented contract, not because of that crash."""
