@@ -357,3 +357,30 @@ def test_captured_sampling_graph_follows_weight_updates(dg):
     d.use_graph = False
     ref = d.p_sample_loop(shape, x_T=x_T.permute(0, 3, 1, 2), noises=[n.permute(0, 3, 1, 2) for n in noises] + [None])
     assert_close(s_new, ref, 1e-5, "captured loop after a weight update vs eager loop")
+
+
+@torch.no_grad()
+def test_time_path_table_equals_the_direct_time_path(dg):
+    """Unet._scale_shifts_for: the [T, sum 2*dim_out] table gathered at `time` against the four launches it replaces (sinusoidal
+    embedding, two Linears, the blocks' projections), and the U-Net output through either; the table follows a weight update."""
+    m = meta_of(dg)["m0"]
+    u = make_unet(m)
+    x, t = T(dg["unetm0_x"]).to(DEV), torch.tensor([3, 977], device=DEV)
+    direct = u._all_scale_shifts(u.time_embedding(t, silu_out=True))
+    assert u._time_table(x.device) is None                          # a bare Unet has no table ...
+    y_direct = u(x, t)
+    u.enable_time_table(1000)                                       # ... GaussianDiffusion enables it with its T
+    tab = u._scale_shifts_for(t)
+    for k in direct:
+        assert_close(tab[k], direct[k], 1e-6, "scale/shift rows")
+    assert_close(u(x, t), y_direct, 1e-6, "U-Net output through the table")
+    assert_close(u(x, t), dg["unetm0_y"], TOL, "U-Net output through the table vs the reference")
+    key0 = u._tt_key
+    u.time_mlp[1].weight.mul_(1.01)                                 # what an optimizer step does
+    after = u._scale_shifts_for(t)
+    assert u._tt_key != key0
+    ref = u._all_scale_shifts(u.time_embedding(t, silu_out=True))
+    for k in ref:
+        assert_close(after[k], ref[k], 1e-6, "rows after a weight update")
+    with torch.enable_grad():
+        assert u._time_table(x.device) is None                      # the differentiable path computes the time MLP (it has gradients)
