@@ -215,6 +215,12 @@ int nfdp_coupling_fused_im2col_cols(int C, int backward);
 int nfdp_level_fused_train_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
                                 const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
                                 float* xpre, float* ypost, float* hout, void* y1, void* y2, void* xcol, nfdp_stream_t stream);
+/* The same with keep_hidden = 0: all flows write y1 / y2 / xcol into ONE flow-sized slot (the buffers are one flow large) - the forward
+ * of a step that recomputes the hidden activations in its backward pass (normalizing_flow.training.RECOMPUTE_FLOWS: per group of flows
+ * the launch is repeated from the group's saved input state xpre[first flow] with keep_hidden = 1). */
+int nfdp_level_fused_train_ex_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
+                                const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
+                                float* xpre, float* ypost, float* hout, void* y1, void* y2, void* xcol, int keep_hidden, nfdp_stream_t stream);
 /* Backward of the coupling network's data path in one launch (autograd of utils.py:83-89 w.r.t. its input, training step
  * normalizing_flow/trainer.py:164): dc3 [B][H*W][C] fp32 = gradient at the ZeroConv2d's raw conv output (after its scale backward);
  * y1, y2 = the hidden activations saved by nfdp_level_fused_train_bf16 (blocked layout, Bpad images).  Writes dc2, dc1 (same layout as

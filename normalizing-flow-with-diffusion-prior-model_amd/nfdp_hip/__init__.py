@@ -586,12 +586,13 @@ def level_fused(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torc
           nbytes=8.0 * xh.numel())
 
 
-def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torch.Tensor]):
+def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torch.Tensor], keep_hidden: bool = True):
     """Training forward of a whole Glow level in ONE persistent launch (nfdp_level_fused_train_bf16): xh [B,H,W,C] is updated in
     place; ldj[b] += the flows' per-sample coupling log-dets only.  -> (xpre, ypost, hout [n,B,H,W,C] fp32; y1, y2
     [n,Bpad,H,W,512] bf16; xcol [n,Bpad,H,W,cols] bf16): per flow the tile before / after the flow head, the zero conv's output, the
     two hidden activations - y1 / y2 in the fused kernels' BLOCKED layout (blocked_to_rows), not [pixel][512] rows - and the im2col
-    rows of the coupling network's input."""
+    rows of the coupling network's input.  keep_hidden=False: y1 / y2 / xcol are one flow large and every flow overwrites them (returned as
+    None): the forward of a step that recomputes them in its backward pass."""
     _need(xh, torch.float32, "level_fused_train"); _dense(xh, "level_fused_train")
     b, h, wd, c = xh.shape
     n = len(packed)
@@ -607,15 +608,19 @@ def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optiona
     xpre = torch.empty((n, b, h, wd, c), device=dev, dtype=torch.float32)
     ypost = torch.empty((n, b, h, wd, c), device=dev, dtype=torch.float32)
     hout = torch.empty((n, b, h, wd, c), device=dev, dtype=torch.float32)
-    y1 = torch.empty((n, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
-    y2 = torch.empty((n, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
-    xcol = torch.empty((n, bpad, h, wd, lib().nfdp_coupling_fused_im2col_cols(c, 0)), device=dev, dtype=torch.bfloat16)
+    nh = n if keep_hidden else 1
+    y1 = torch.empty((nh, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
+    y2 = torch.empty((nh, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
+    xcol = torch.empty((nh, bpad, h, wd, lib().nfdp_coupling_fused_im2col_cols(c, 0)), device=dev, dtype=torch.bfloat16)
     tab = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
     ch = c // 2
     flops = n * 2.0 * b * h * wd * (9 * ch * 512 + 512 * 512 + 9 * 512 * c + c * c)
-    _call("nfdp_level_fused_train_bf16", _ptr(xh), b, h, wd, c, n, tab(packed), tab(scales), tab(biases), tab(ws), _ptr(ldj),
-          _ptr(xpre), _ptr(ypost), _ptr(hout), _ptr(y1), _ptr(y2), _ptr(xcol), _stream(), label=f"level_fused_train<{c},{wd}> x{n}",
-          flops=flops, nbytes=8.0 * xh.numel() + 12.0 * n * xh.numel() + 2048.0 * n * bpad * h * wd)
+    _call("nfdp_level_fused_train_ex_bf16", _ptr(xh), b, h, wd, c, n, tab(packed), tab(scales), tab(biases), tab(ws), _ptr(ldj),
+          _ptr(xpre), _ptr(ypost), _ptr(hout), _ptr(y1), _ptr(y2), _ptr(xcol), int(keep_hidden), _stream(),
+          label=f"level_fused_train<{c},{wd}> x{n}", flops=flops,
+          nbytes=8.0 * xh.numel() + 12.0 * n * xh.numel() + 2048.0 * n * bpad * h * wd)
+    if not keep_hidden:
+        return xpre, ypost, hout, None, None, None
     return xpre, ypost, hout, y1, y2, xcol
 
 

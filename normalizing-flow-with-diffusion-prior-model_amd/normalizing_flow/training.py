@@ -65,6 +65,12 @@ def _slot(p):
 # hipGraph.  Tensors they read are kept referenced until the join, so the caching allocator cannot hand their memory to a
 # main-stream launch while the side stream still reads it.
 WGRAD_SIDE_STREAM = True
+# Activation recomputation for the fused training path (reference trainer.py:163-167 keeps every activation): 0 = keep the
+# hidden activations of all flows (fastest, 9.7 GiB at B = 512 L3 K16); G > 0 = keep only the flow-state tensors and, in the backward
+# pass, re-run the training forward of G flows at a time from the group's saved input (bit-identical activations, so bit-identical
+# gradients; one extra forward per step; the hidden tensors of G flows live at a time).  A flow is invertible, so its input COULD also be
+# recomputed from its output - not done: the flow state is 6 MB per flow here, the hidden activations are 268 MB.
+RECOMPUTE_FLOWS = 0
 _side_streams = {}
 _side_keep = []
 
@@ -697,8 +703,16 @@ class LevelFusedFn(Function):
         scales = [params[P * i].detach().reshape(-1) for i in range(n)]
         biases = [params[P * i + 1].detach().reshape(-1) for i in range(n)]
         ws = [params[P * i + 2].detach().reshape(c, c) for i in range(n)]
-        xpre, ypost, hout, y1, y2, xcol = K.level_fused_train(y, packed, scales, biases, ws, acc)
-        ctx.save_for_backward(xpre, ypost, hout, y1, y2, xcol)
+        ctx.recompute = int(RECOMPUTE_FLOWS) if RECOMPUTE_FLOWS else 0
+        if ctx.recompute:
+            # activation recomputation: the 512-channel hidden activations (2 x 134 MB per level-0 flow at B = 512) are not kept; the
+            # backward pass re-runs this launch per group of `recompute` flows from the group's saved input state xpre[first flow]
+            xpre, ypost, hout, _, _, _ = K.level_fused_train(y, packed, scales, biases, ws, acc, keep_hidden=False)
+            ctx.save_for_backward(xpre, ypost, hout)
+            ctx.fwd_args = (packed, scales, biases, ws)
+        else:
+            xpre, ypost, hout, y1, y2, xcol = K.level_fused_train(y, packed, scales, biases, ws, acc)
+            ctx.save_for_backward(xpre, ypost, hout, y1, y2, xcol)
         ctx.params, ctx.bpacks, ctx.f3, ctx.n = params, bpacks, float(f3), n
         ctx.nets = meta[4] if len(meta) > 4 else [None] * n
         ctx.ldj_dtype = None if ldj is None else ldj.dtype
@@ -707,7 +721,31 @@ class LevelFusedFn(Function):
     @staticmethod
     @_side_guarded
     def backward(ctx, dy, dacc):
-        xpre, ypost, hout, y1, y2, xcol = ctx.saved_tensors
+        if ctx.recompute:
+            xpre, ypost, hout = ctx.saved_tensors
+            G = ctx.recompute
+            packed_f, scales_f, biases_f, ws_f = ctx.fwd_args
+            cache = {}
+
+            def hidden(i):
+                """(xcol, y1, y2) of flow i: the training forward of its group of G flows, re-run from the group's saved input."""
+                g0 = (i // G) * G
+                if cache.get("g0") != g0:
+                    if cache:
+                        _flush_side()                              # the side stream still reads the previous group's tensors (weight
+                        _join_side()                               # gradients): join before they are released
+                    cache.clear()                                  # drop the previous group's tensors before allocating the next
+                    g1 = min(g0 + G, ctx.n)
+                    _, _, _, y1g, y2g, xcolg = K.level_fused_train(xpre[g0].clone(), packed_f[g0:g1], scales_f[g0:g1], biases_f[g0:g1],
+                                                                   ws_f[g0:g1], None)
+                    cache.update(g0=g0, t=(xcolg, y1g, y2g))
+                xc, a1, a2 = cache["t"]
+                return xc[i - g0], a1[i - g0], a2[i - g0]
+        else:
+            xpre, ypost, hout, y1, y2, xcol = ctx.saved_tensors
+
+            def hidden(i):
+                return xcol[i], y1[i], y2[i]
         n, P, params = ctx.n, LevelFusedFn.NP, ctx.params
         bsz, hh, ww, c = ypost.shape[1:]
         npix = bsz * hh * ww
@@ -735,7 +773,8 @@ class LevelFusedFn(Function):
         for i in reversed(range(n)):
             scale, bias, weight = params[P * i: P * i + 3]
             net = params[P * i + 3: P * i + 12]
-            g9 = _net_backward_fused(dc3, dx, xcol[i], y1[i], y2[i], net, ctx.nets[i], packed=rev[i])   # dx[..., :c/2] += network input gradient
+            xc_i, y1_i, y2_i = hidden(i)
+            g9 = _net_backward_fused(dc3, dx, xc_i, y1_i, y2_i, net, ctx.nets[i], packed=rev[i])   # dx[..., :c/2] += network input gradient
             head = (xpre[i], weight.detach().reshape(c, c), scale.detach().reshape(-1), bias.detach().reshape(-1))
             cpl = (ypost[i - 1], hout[i - 1], gl, l3(i - 1), f3) if i > 0 else None
             # (the 1x1 conv's weight gradient dW = sum_p dx (x) a, transforms.py:132, is left in the call's partial buffer too)

@@ -9,7 +9,7 @@ import torch.nn.functional as F
 import nfdp_hip as K
 from oracle import nf_oracle as O
 from tests.util import T, assert_close, relerr
-from tests.golden.synth import synth_tensor, synth_input
+from tests.golden.synth import synth_tensor, synth_input, DEEP
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -939,3 +939,40 @@ def test_flow_link_backward_kernel(c, hw, B):
     assert_close(dws[1].view(c, c), dw_ref, 1e-5, "1x1 conv dW (both)")
     assert_close(dws[2] - 0.5, dw_ref, 1e-5, "1x1 conv dW (head only, accumulated)")
     assert_close(K.conv_wgrad(a, dx_in, 1).view(c, c), dw_ref, 1e-5, "the split-K GEMM it replaces")
+
+
+def test_activation_recomputation_gives_bit_identical_gradients():
+    """training.RECOMPUTE_FLOWS = G: the fused training forward keeps only the flow-state tensors and the backward pass re-runs it per
+    group of G flows from the group's saved input - the same kernel on the same fp32 inputs, so loss and every parameter gradient
+    must equal the store-everything step bit for bit, for a group size that divides the level and one that does not."""
+    from normalizing_flow import Glow, GaussianPrior, calculate_loss, training
+    B = 6
+    x = (T(synth_input("recomp_x", (B, 3, 32, 32), 9)) * 0.4).to(DEV)
+
+    def run(group):
+        flow, prior = Glow(in_channel=3, L=3, K=4, compute="bf16").to(DEV), GaussianPrior(48).to(DEV)
+        flow.load_state_dict({k: T(synth_tensor(k, v.shape, 5, DEEP)) for k, v in flow.state_dict().items()})
+        prior.load_state_dict({k: T(synth_tensor(k, v.shape, 5, DEEP)) for k, v in prior.state_dict().items()})
+        training.RECOMPUTE_FLOWS = group
+        try:
+            K.start_trace()
+            ldj = torch.zeros(B, dtype=torch.float64, device=DEV)
+            logp = torch.zeros(B, dtype=torch.float64, device=DEV)
+            zs, ldj, logp = flow.transform(x, ldj, logp)
+            loss = calculate_loss(ldj + logp + prior.compute_log_prob(zs[-1]), 32.0, 3072.0)
+            loss.backward()
+            labels = [e["label"] for e in K.stop_trace()]
+        finally:
+            training.RECOMPUTE_FLOWS = 0
+        n_fwd = sum(lb.startswith("level_fused_train") for lb in labels)
+        return loss.detach(), {k: p.grad.clone() for k, p in flow.named_parameters() if p.grad is not None}, n_fwd
+
+    l0, g0, n0 = run(0)
+    assert n0 == 3                                                   # one training-forward launch per level
+    for group in (2, 3):
+        l1, g1, n1 = run(group)
+        assert n1 == 3 + 3 * ((4 + group - 1) // group)              # + one launch per group and level in the backward pass
+        assert torch.equal(l0, l1)
+        assert g0.keys() == g1.keys()
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
