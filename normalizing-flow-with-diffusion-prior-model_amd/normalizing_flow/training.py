@@ -71,6 +71,11 @@ WGRAD_SIDE_STREAM = True
 # gradients; one extra forward per step; the hidden tensors of G flows live at a time).  A flow is invertible, so its input COULD also be
 # recomputed from its output - not done: the flow state is 6 MB per flow here, the hidden activations are 268 MB.
 RECOMPUTE_FLOWS = 0
+# The main stream waits for the side stream's weight gradients every SIDE_JOIN_EVERY flows of a level's backward pass (0: once, at the
+# end of the level).  Tensors the side stream reads - a flow's hidden-activation gradients, 0.3 GB at level 0 - are kept referenced
+# until the join; joining every few flows bounds that to a few flows' worth instead of a whole level's 4.5 GB.
+import os as _os
+SIDE_JOIN_EVERY = int(_os.environ.get("NFDP_SIDE_JOIN_EVERY", "0"))
 _side_streams = {}
 _side_keep = []
 
@@ -780,6 +785,8 @@ class LevelFusedFn(Function):
             # (the 1x1 conv's weight gradient dW = sum_p dx (x) a, transforms.py:132, is left in the call's partial buffer too)
             dx_next, dc3, _ = K.flow_link_bwd(dx, part[n - i], head=head, coupling=cpl, want_a=False)
             _flush_side()                                            # one fork per flow: the coupling network's weight gradients
+            if SIDE_JOIN_EVERY and (n - i) % SIDE_JOIN_EVERY == 0 and i > 0:
+                _join_side()
             if g9 is not None:
                 grads[P * i + 3: P * i + 10] = list(g9)
             dx = dx_next
