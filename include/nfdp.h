@@ -73,6 +73,11 @@ size_t nfdp_coupling_mlp_f32_packed_bytes(int C);
 int nfdp_coupling_mlp_f32_pack(const float* w1, const float* scale1, const float* bias1, const float* w2, const float* scale2,
                                const float* bias2, const float* w3, void* packed, int C, nfdp_stream_t stream);
 int nfdp_coupling_mlp_f32(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, nfdp_stream_t stream);
+/* variant: 0 = chosen by the pixel count (what nfdp_coupling_mlp_f32 does), 1 = one wave per 32-pixel tile, 2 = four waves per tile
+ * splitting the output rows of every GEMM (hidden blocks through LDS; for small pixel counts such as the 4x4 level).  The two differ in
+ * fp32 summation order only. */
+int nfdp_coupling_mlp_f32_ex(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, int variant,
+                             nfdp_stream_t stream);
 /* Explicit im2col of a narrow tensor for a 3x3 "same" conv (training path of the C/2 -> 512 convs, utils.py:67): x [B,H,W,C] fp32
  * with pixel stride x_ld -> out [B*H*W][Kpad] bf16, out[p][tap*C + c] = x[p + shift(tap)][c] (zero outside the image and for
  * columns >= 9C); Kpad >= 9C, Kpad % 8 == 0, out 16-byte aligned. */

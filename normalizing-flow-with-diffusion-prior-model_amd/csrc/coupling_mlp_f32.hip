@@ -59,7 +59,13 @@ struct GeoF {
     static constexpr long S2 = NW1;                                    // ... of the GEMM2/3 stream
     static constexpr long NFRAG = NW1 + (long)NG * NHB * NBP + D;      // + D zero fragments the prefetch runs into
     static constexpr long PARAMS = NFRAG * FRAG;                       // float offset of b1 | e^s1 | b2 | e^s2 (natural channel order)
-    static constexpr long TOTAL_FLOATS = PARAMS + 4 * HID;
+    // Row-split streams (coupling_mlp_f32_rs_kernel: 4 waves share a 32-pixel tile, wave w owns hidden blocks w, w+4, w+8, w+12 of both
+    // hidden GEMMs and tap-row tiles w, w+4, ...): per wave one linear stream [4 x NQ1 W1 | 4 x 64 W2 | 16 x NTW x 4 W3] fragments.
+    static constexpr int DR = 16;                                      // ring depth of the row-split kernel (registers are plentiful there)
+    static constexpr int NTW = (NRT + 3) / 4;                          // tap-row tiles per wave
+    static constexpr int NRS = 4 * NQ1 + 4 * 4 * NHB + NHB * NTW * 4;  // fragments per wave
+    static constexpr long RS_OFF = PARAMS + 4 * HID;                   // float offset of wave 0's stream
+    static constexpr long TOTAL_FLOATS = RS_OFF + 4L * NRS * FRAG;
     static_assert(C % 4 == 0, "rows of T are written as float4");
 };
 
@@ -71,7 +77,27 @@ __global__ void pack_mlp_f32_kernel(const float* __restrict__ w1, const float* _
     using G = GeoF<C>;
     for (long e = blockIdx.x * (long)kThreads + threadIdx.x; e < G::TOTAL_FLOATS; e += (long)gridDim.x * kThreads) {
         float v = 0.f;
-        if (e >= G::PARAMS) {
+        if (e >= G::RS_OFF) {                                           // ---- the four row-split streams
+            const long r = e - G::RS_OFF;
+            const int w = (int)(r / ((long)G::NRS * FRAG));
+            const int n = (int)(r / FRAG) % G::NRS;
+            const int l = (int)(r % FRAG) / 4, i = (int)(r % 4);
+            const int m = l & 31, h = l >> 5;
+            if (n < 4 * G::NQ1) {                                       // W1 of hidden block w + 4 (n / NQ1)
+                const int hb = w + 4 * (n / G::NQ1), q = n % G::NQ1;
+                const int k = 2 * (4 * q + i) + h;
+                if (k < G::K1) v = w1[((long)(32 * hb + m) * G::Ch + k % G::Ch) * 9 + k / G::Ch];
+            } else if (n < 4 * G::NQ1 + 16 * NHB) {                     // W2 rows of hidden block w + 4 i2, input block hb, quarter q4
+                const int j = n - 4 * G::NQ1;
+                const int hb2 = w + 4 * (j / (4 * NHB)), hb = (j % (4 * NHB)) / 4, q4 = j % 4;
+                v = w2[(long)(32 * hb2 + m) * HID + 32 * hb + 8 * q4 + 4 * h + i];
+            } else {                                                    // W3: input block hb2, this wave's tile t (rows of tile w + 4 t), quarter q4
+                const int j = n - 4 * G::NQ1 - 16 * NHB;
+                const int hb2 = j / (4 * G::NTW), t = (j / 4) % G::NTW, q4 = j % 4;
+                const int nrow = 32 * (w + 4 * t) + m, in = 32 * hb2 + 8 * q4 + 4 * h + i;
+                if (nrow < G::NROW) v = w3[((long)(nrow % C) * HID + in) * 9 + nrow / C];
+            }
+        } else if (e >= G::PARAMS) {
             const int q = (int)(e - G::PARAMS), which = q / HID, ch = q % HID;
             v = which == 0 ? bias1[ch] : which == 1 ? expf(scale1[ch]) : which == 2 ? bias2[ch] : expf(scale2[ch]);
         } else {
@@ -276,10 +302,187 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
     }
 }
 
+
+// ----------------------------------------------------------------------------- row-split variant for small pixel counts
+// With few pixels (the 4x4 level of a 512-image batch: 8192 pixels = 256 tiles) one wave per tile leaves three SIMDs of every CU idle,
+// and C = 48 additionally computes H1 and H2 twice (two row groups).  Here FOUR waves share a 32-pixel tile and split the OUTPUT ROWS of
+// every GEMM: wave w computes hidden blocks w, w+4, w+8, w+12 of GEMM1 and of GEMM2 and tap-row tiles w, w+4, ... of GEMM3 - no work is
+// duplicated.  The hidden blocks meet in LDS exactly as they leave the accumulators ([block][lane][16 floats]: the reading lane is the
+// writing lane, so no transposition), 64 KB for H1 and 64 KB for H2, two barriers per launch; a wave's B operands of a block are four
+// ds_read_b128 per 16 MFMAs (1024 cycles), requested one block ahead.  Weights: each wave walks its own linear stream of the image
+// (GeoF::RS_OFF) through a 16-deep register ring.  Per wave and flow at C = 48: 432 + 1024 + 1024 MFMAs (one-wave-per-tile: 7616).
 template <int C>
-int launch_mlp(const float* x, int x_ld, long npix, int H, int W, const float* img, float* T, hipStream_t s) {
+__global__ void __launch_bounds__(256) coupling_mlp_f32_rs_kernel(const float* __restrict__ x, int x_ld, long npix, int H, int W,
+                                                                  const float* __restrict__ img, float* __restrict__ T) {
+    using G = GeoF<C>;
+    constexpr int Ch = G::Ch, D = G::DR, NRS = G::NRS, NQ1 = G::NQ1, NTW = G::NTW;
+    extern __shared__ __attribute__((aligned(16))) float rs_lds[];
+    float* H1s = rs_lds;                                   // [16 blocks][64 lanes][16]
+    float* H2s = rs_lds + NHB * 64 * 16;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, p = lane & 31;
+    const long pix = (long)blockIdx.x * 32 + p;
+    const bool live = pix < npix;
+    const long pc = live ? pix : npix - 1;
+    const int xx = (int)(pc % W), yy = (int)((pc / W) % H);
+    const float* __restrict__ params = img + G::PARAMS;
+
+    unsigned vmask = 0;
+    int poff[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const bool ok = (unsigned)(yy + dy) < (unsigned)H && (unsigned)(xx + dx) < (unsigned)W;
+        vmask |= ok ? 1u << tap : 0u;
+        poff[tap] = ok ? (dy * W + dx) * x_ld : 0;
+    }
+    const float* __restrict__ xrow = x + pc * x_ld;
+    float bx[G::KP1];
+    sfor<G::KP1>([&](auto jc) {
+        constexpr int jj = decltype(jc)::value;
+        constexpr int k0 = 2 * jj, k1 = 2 * jj + 1;
+        constexpr int t0 = k0 < G::K1 ? k0 / Ch : 9, t1 = k1 < G::K1 ? k1 / Ch : 9;
+        constexpr int c0 = k0 < G::K1 ? k0 % Ch : 0, c1 = k1 < G::K1 ? k1 % Ch : 0;
+        const int tap = h ? t1 : t0;
+        const bool ok = tap < 9 && ((vmask >> tap) & 1u);
+        int off = 0;
+        if constexpr (t0 < 9) { if (!h) off = poff[t0] + c0; }
+        if constexpr (t1 < 9) { if (h) off = poff[t1] + c1; }
+        const float v = xrow[ok ? off : 0];
+        bx[jj] = ok ? v : 0.f;
+    });
+
+    const float* __restrict__ sp = img + G::RS_OFF + (long)w * NRS * FRAG + (long)lane * 4;     // fragment n of this wave: sp + n * FRAG
+    f32x4 ring[D];
+    sfor<D>([&](auto i) { ring[decltype(i)::value] = ld_frag(sp + (long)decltype(i)::value * FRAG); });
+    auto next = [&](auto nc) {                              // consume fragment n, refill its slot with fragment n + D
+        constexpr int n = decltype(nc)::value;
+        const f32x4 a = ring[n % D];
+        if constexpr (n + D < NRS) ring[n % D] = ld_frag(sp + (long)(n + D) * FRAG);
+        return a;
+    };
+    float* mine = H1s + lane * 16;                          // this lane's 16 floats of block 0 (blocks are 1024 floats apart)
+
+    // ---- GEMM1: hidden blocks w, w+4, w+8, w+12
+    sfor<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int hb = w + 4 * i;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const EpiRegs ep = epi_load(params, params + HID, 32 * hb + 4 * h);
+        __builtin_amdgcn_sched_barrier(0);
+        sfor<NQ1>([&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            const f32x4 a = next(std::integral_constant<int, i * NQ1 + q>{});
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ii], bx[4 * q + ii], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        epilogue(acc, ep);
+        float* dst = mine + hb * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(dst + 4 * q) = v;
+        }
+    });
+    __syncthreads();
+
+    // ---- GEMM2: hidden blocks w, w+4, ... of H2; B operands = H1 blocks from LDS, one block ahead
+    constexpr int N1 = 4 * NQ1;
+    auto load_blk = [&](const float* base, int blk, f32x4 (&bv)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(base + blk * 1024 + lane * 16 + 4 * q);
+    };
+    sfor<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int hb2 = w + 4 * i;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const EpiRegs ep = epi_load(params + 2 * HID, params + 3 * HID, 32 * hb2 + 4 * h);
+        f32x4 bv[2][4];
+        load_blk(H1s, 0, bv[0]);
+        sfor<NHB>([&](auto hc) {
+            constexpr int hb = decltype(hc)::value;
+            if constexpr (hb + 1 < NHB) load_blk(H1s, hb + 1, bv[(hb + 1) & 1]);
+            sfor<4>([&](auto qc) {
+                constexpr int q4 = decltype(qc)::value;
+                const f32x4 a = next(std::integral_constant<int, N1 + i * 4 * NHB + hb * 4 + q4>{});
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ii], bv[hb & 1][q4][ii], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        epilogue(acc, ep);
+        float* dst = H2s + lane * 16 + hb2 * 1024;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(dst + 4 * q) = v;
+        }
+    });
+    __syncthreads();
+
+    // ---- GEMM3: tap-row tiles w, w+4, ... over all 16 blocks of H2
+    constexpr int N2 = N1 + 16 * NHB;
+    f32x16 tap[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tap[t][r] = 0.f;
+    {
+        f32x4 bv[2][4];
+        load_blk(H2s, 0, bv[0]);
+        sfor<NHB>([&](auto hc) {
+            constexpr int hb2 = decltype(hc)::value;
+            if constexpr (hb2 + 1 < NHB) load_blk(H2s, hb2 + 1, bv[(hb2 + 1) & 1]);
+            sfor<NTW>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                sfor<4>([&](auto qc) {
+                    constexpr int q4 = decltype(qc)::value;
+                    const f32x4 a = next(std::integral_constant<int, N2 + (hb2 * NTW + t) * 4 + q4>{});
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) tap[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ii], bv[hb2 & 1][q4][ii], tap[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        });
+    }
+    if (live) {
+        float* __restrict__ trow = T + pix * (long)G::NROW;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n0 = 32 * (w + 4 * t) + 8 * q + 4 * h;
+                if (n0 < G::NROW) {
+                    const f32x4 v = {tap[t][4 * q], tap[t][4 * q + 1], tap[t][4 * q + 2], tap[t][4 * q + 3]};
+                    *reinterpret_cast<f32x4*>(trow + n0) = v;
+                }
+            }
+    }
+}
+
+// variant 0: by the pixel count (row split while one wave per tile would leave the chip under ~3 waves per CU), 1: one wave per tile,
+// 2: row split
+template <int C>
+int launch_mlp(const float* x, int x_ld, long npix, int H, int W, const float* img, float* T, int variant, hipStream_t s) {
     const long nwg = cdiv(npix, 32);
-    hipLaunchKernelGGL((coupling_mlp_f32_kernel<C>), dim3((unsigned)nwg, GeoF<C>::NG), dim3(kWave), 0, s, x, x_ld, npix, H, W, img, T);
+    const bool rs = variant == 2 || (variant == 0 && nwg * GeoF<C>::NG < 768);
+    if (rs) {
+        constexpr int kLds = 2 * NHB * 64 * 16 * (int)sizeof(float);             // H1 + H2: 128 KB
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&coupling_mlp_f32_rs_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((coupling_mlp_f32_rs_kernel<C>), dim3((unsigned)nwg), dim3(256), kLds, s, x, x_ld, npix, H, W, img, T);
+    } else {
+        hipLaunchKernelGGL((coupling_mlp_f32_kernel<C>), dim3((unsigned)nwg, GeoF<C>::NG), dim3(kWave), 0, s, x, x_ld, npix, H, W, img, T);
+    }
     return NFDP_OK;
 }
 
@@ -325,9 +528,17 @@ extern "C" int nfdp_coupling_mlp_f32_pack(const float* w1, const float* scale1, 
     return rc;
 }
 
+extern "C" int nfdp_coupling_mlp_f32_ex(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, int variant,
+                                        nfdp_stream_t stream);
 extern "C" int nfdp_coupling_mlp_f32(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C,
                                      nfdp_stream_t stream) {
+    return nfdp_coupling_mlp_f32_ex(x, x_ld, B, H, W, packed, T, C, 0, stream);
+}
+
+extern "C" int nfdp_coupling_mlp_f32_ex(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, int variant,
+                                        nfdp_stream_t stream) {
     NFDP_REQUIRE(x && packed && T, NFDP_EINVAL, "coupling_mlp_f32: null pointer");
+    NFDP_REQUIRE(variant >= 0 && variant <= 2, NFDP_EINVAL, "coupling_mlp_f32: variant=%d (0 auto, 1 one wave per tile, 2 row split)", variant);
     NFDP_REQUIRE(nfdp_coupling_mlp_f32_packed_bytes(C) != 0, NFDP_EUNSUPPORTED, "coupling_mlp_f32: C=%d (supported: 4,8,12,16,24,48)", C);
     NFDP_REQUIRE(B >= 0 && H > 0 && W > 0 && x_ld >= C / 2, NFDP_ESHAPE, "coupling_mlp_f32: bad shape B=%d H=%d W=%d x_ld=%d", B, H, W, x_ld);
     NFDP_REQUIRE(((uintptr_t)packed & 15) == 0 && ((uintptr_t)T & 15) == 0, NFDP_ESHAPE, "coupling_mlp_f32: packed / T must be 16-byte aligned");
@@ -335,7 +546,7 @@ extern "C" int nfdp_coupling_mlp_f32(const float* x, int x_ld, int B, int H, int
     if (npix == 0) return NFDP_OK;
     NFDP_REQUIRE(cdiv(npix, 32) < (1L << 31), NFDP_ESHAPE, "coupling_mlp_f32: too many pixels");
     int rc = NFDP_OK;
-#define CALL(CC) rc = launch_mlp<CC>(x, x_ld, npix, H, W, reinterpret_cast<const float*>(packed), T, as_stream(stream))
+#define CALL(CC) rc = launch_mlp<CC>(x, x_ld, npix, H, W, reinterpret_cast<const float*>(packed), T, variant, as_stream(stream))
     NFDP_MLP_F32_DISPATCH(C, CALL)
 #undef CALL
     NFDP_CHECK_LAUNCH("coupling_mlp_f32");

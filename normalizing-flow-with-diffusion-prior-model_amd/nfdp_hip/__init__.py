@@ -1455,14 +1455,14 @@ def coupling_mlp_f32_pack(w1, scale1, bias1, w2, scale2, bias2, w3, out=None) ->
 
 
 def coupling_net_tiled_f32(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: torch.Tensor, logs: torch.Tensor,
-                           mul_exp: float) -> torch.Tensor:
+                           mul_exp: float, variant: int = 0) -> torch.Tensor:
     """NN(x_a) of an affine coupling in exact fp32, hidden activations on chip: nfdp_coupling_mlp_f32 (3x3 gather + three fp32-MFMA
     GEMMs) -> tap shift-sum with the ZeroConv2d epilogue.  xh_a: [B,H,W,C/2] fp32 pixel-strided view; returns (log_s | t) [B,H,W,C]."""
     _need(xh_a, torch.float32, "coupling_net_tiled_f32")
     b, h, w, _ = xh_a.shape
     t = torch.empty((b, h, w, 9 * c), device=xh_a.device, dtype=torch.float32)
-    _call("nfdp_coupling_mlp_f32", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled_f32"), b, h, w, _ptr(packed), _ptr(t), c, _stream(),
-          label=f"coupling_mlp_f32<{c}> hw{h}", flops=2.0 * b * h * w * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c))
+    _call("nfdp_coupling_mlp_f32_ex", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled_f32"), b, h, w, _ptr(packed), _ptr(t), c, int(variant),
+          _stream(), label=f"coupling_mlp_f32<{c}> hw{h}", flops=2.0 * b * h * w * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c))
     out = torch.empty((b, h, w, c), device=xh_a.device, dtype=torch.float32)
     _call("nfdp_tap_shift_sum_f32", _ptr(t), _ptr(out), b, h, w, c, _ptr(bias), _ptr(logs), float(mul_exp), 0, _stream())
     return out

@@ -238,6 +238,11 @@ def test_f32_onchip_coupling_network_against_oracle(c, hh, ww, b):
     assert any(lb.startswith("coupling_mlp_f32") for lb in labels), labels          # the on-chip kernel really ran
     h_ref = O.coupling_net(x[:, : c // 2], osd, "flows.3.affcoupling.net.")
     assert_close(K.as_nchw(h_fused), h_ref, 2e-5, "on-chip fp32 network vs oracle")
+    zc = m.net[-1]
+    for variant, what in ((1, "one wave per tile"), (2, "four waves per tile, rows split")):     # both kernels, whatever the auto choice was
+        hv = K.coupling_net_tiled_f32(xh[..., : c // 2], m.net.mlp_f32_packed(), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
+                                      variant=variant)
+        assert_close(K.as_nchw(hv), h_ref, 2e-5, f"on-chip fp32 network ({what}) vs oracle")
     K.set_f32_fused(False)
     try:
         h_plain = m._net_nhwc(xh)
