@@ -24,6 +24,7 @@
 //  * products and sums are fp32 FMAs in a fixed order (k ascending within the permuted order baked into the images): results match
 //    the per-op fp32 kernels and the reference to summation order (tests: goldens at 1e-4, element-wise).
 // Bound: fp32 matrix pipe, 157.3 TFLOP/s; algorithmic work 2*(9*C/2*512 + 512^2 + 9*C*512) FLOP per pixel.
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 #include "nfdp_common.h"
@@ -308,7 +309,7 @@ coupling_mlp_f32_kernel(const float* __restrict__ x, int x_ld, long npix, int H,
 // and C = 48 additionally computes H1 and H2 twice (two row groups).  Here FOUR waves share a 32-pixel tile and split the OUTPUT ROWS of
 // every GEMM: wave w computes hidden blocks w, w+4, w+8, w+12 of GEMM1 and of GEMM2 and tap-row tiles w, w+4, ... of GEMM3 - no work is
 // duplicated.  The hidden blocks meet in LDS exactly as they leave the accumulators ([block][lane][16 floats]: the reading lane is the
-// writing lane, so no transposition), 64 KB for H1 and 64 KB for H2, two barriers per launch; a wave's B operands of a block are four
+// writing lane, so no transposition), 64 KB (H2 takes H1's place after a barrier), three barriers per launch; a wave's B operands of a block are four
 // ds_read_b128 per 16 MFMAs (1024 cycles), requested one block ahead.  Weights: each wave walks its own linear stream of the image
 // (GeoF::RS_OFF) through a 16-deep register ring.  Per wave and flow at C = 48: 432 + 1024 + 1024 MFMAs (one-wave-per-tile: 7616).
 template <int C>
@@ -318,7 +319,7 @@ __global__ void __launch_bounds__(256) coupling_mlp_f32_rs_kernel(const float* _
     constexpr int Ch = G::Ch, D = G::DR, NRS = G::NRS, NQ1 = G::NQ1, NTW = G::NTW;
     extern __shared__ __attribute__((aligned(16))) float rs_lds[];
     float* H1s = rs_lds;                                   // [16 blocks][64 lanes][16]
-    float* H2s = rs_lds + NHB * 64 * 16;
+    float* H2s = rs_lds;                                   // ... H2 overwrites H1 once every wave has finished GEMM2
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, p = lane & 31;
@@ -396,6 +397,7 @@ __global__ void __launch_bounds__(256) coupling_mlp_f32_rs_kernel(const float* _
 #pragma unroll
         for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(base + blk * 1024 + lane * 16 + 4 * q);
     };
+    f32x16 acc2[4];                                        // this wave's four H2 blocks stay in registers until every wave has read H1
     sfor<4>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
         const int hb2 = w + 4 * i;
@@ -417,10 +419,15 @@ __global__ void __launch_bounds__(256) coupling_mlp_f32_rs_kernel(const float* _
             });
         });
         epilogue(acc, ep);
-        float* dst = H2s + lane * 16 + hb2 * 1024;
+        acc2[i] = acc;
+    });
+    __syncthreads();                                       // H1 is dead: H2 takes its place (64 KB of LDS per workgroup, two workgroups per CU)
+    sfor<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        float* dst = H2s + lane * 16 + (w + 4 * i) * 1024;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            const f32x4 v = {acc2[i][4 * q], acc2[i][4 * q + 1], acc2[i][4 * q + 2], acc2[i][4 * q + 3]};
             *reinterpret_cast<f32x4*>(dst + 4 * q) = v;
         }
     });
@@ -471,9 +478,11 @@ __global__ void __launch_bounds__(256) coupling_mlp_f32_rs_kernel(const float* _
 template <int C>
 int launch_mlp(const float* x, int x_ld, long npix, int H, int W, const float* img, float* T, int variant, hipStream_t s) {
     const long nwg = cdiv(npix, 32);
+    static const int forced = [] { const char* e = getenv("NFDP_F32_VARIANT"); return e ? atoi(e) : 0; }();     // A/B measurements
+    if (variant == 0 && (forced == 1 || forced == 2)) variant = forced;
     const bool rs = variant == 2 || (variant == 0 && nwg * GeoF<C>::NG < 768);
     if (rs) {
-        constexpr int kLds = 2 * NHB * 64 * 16 * (int)sizeof(float);             // H1 + H2: 128 KB
+        constexpr int kLds = NHB * 64 * 16 * (int)sizeof(float);                 // H1, then H2 in its place: 64 KB
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&coupling_mlp_f32_rs_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
