@@ -407,6 +407,16 @@ def extra_legs(args, flow, prior, u8_d, noise_d, device):
         legs[f"forward_{other}"] = {"ms_per_step": round(dt / n2 * 1e3, 3), "images_per_s": round(B * n2 / dt, 1), "steps": n2,
                                     "dtype": other, "bits_per_dim": round(float(out[0] / out[1]), 6)}
         log(f"leg forward_{other}: {legs[f'forward_{other}']['ms_per_step']} ms/step")
+        # ... and the inverse / sampling inverse in that precision (fp32: the mode BASELINE.json's 1e-4 pixel gate is stated for)
+        zs2 = [z.contiguous() for z in flow2.transform_nhwc(xh, torch.zeros(B, dtype=torch.float64, device=device),
+                                                            torch.zeros(B, dtype=torch.float64, device=device))]
+        for name, sample in ((f"inverse_{other}", False), (f"sample_{other}", True)):
+            dt, rt, finite = time_invert(flow2, zs2, xh, sample, n2, 1, not args.no_graph)
+            legs[name] = {"ms_per_step": round(dt / n2 * 1e3, 3), "images_per_s": round(B * n2 / dt, 1), "steps": n2, "dtype": other,
+                          "finite": finite}
+            if rt is not None:
+                legs[name]["round_trip_max_rel_err"] = rt
+            log(f"leg {name}: {legs[name]['ms_per_step']} ms/step")
     return legs
 
 
