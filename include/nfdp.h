@@ -284,6 +284,17 @@ int nfdp_gauss_sample_f32(const float* h, int h_mode, const float* eps, float* o
 /* GaussianPrior's degenerate conv on zeros (prior.py:79-80): h[n] = bias[n]*exp(3*logs[n]). */
 int nfdp_zeroconv_bias_only_f32(const float* bias, const float* logs, float* h, int n, nfdp_stream_t stream);
 
+/* Block of the U-Net in ONE launch: WeightStandardizedConv2d (w_packed = nfdp_conv_pack_weights of the standardised weight, fp32) ->
+ * GroupNorm(groups, gamma, beta, eps) -> x*(scale+1)+shift (scale_shift [B][2*Cout] rows, stride ss_ld; nullable) -> SiLU -> + residual
+ * (nullable) - gaussian_diffusion.py:267-276, :301 - on the split-K fp32 conv with the normalisation in its epilogue.  Available when a
+ * workgroup's pixel tile holds whole images and its 64 output channels whole groups (H*W divides 64, (Cout/groups) divides 64 and is a
+ * multiple of 4, Cout % 64 == 0, Cin % 8 == 0, K*K*Cin >= 256): the 8x8 / 4x4 / 2x2 stages.  nfdp_conv2d_gn_silu_supported returns 1
+ * there; elsewhere callers run nfdp_conv2d_nhwc + nfdp_groupnorm_silu_res_f32. */
+int nfdp_conv2d_gn_silu_supported(int B, int H, int W, int Cin, int Cout, int K, int groups);
+int nfdp_conv2d_gn_silu_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin, int Cout,
+                                 int K, const float* bias, int groups, const float* gamma, const float* beta, const float* scale_shift,
+                                 int ss_ld, float eps, const float* residual, int res_ld, nfdp_stream_t stream);
+
 /* ---------------------------------------------------------------- diffusion prior: U-Net blocks
  * (diffusion_prior/gaussian_diffusion.py; the convolutions themselves use nfdp_conv2d_nhwc) */
 /* WeightStandardizedConv2d.forward :189-197: out[o] = (w[o]-mean_o) * rsqrt(var_o(biased) + eps) over fan_in. */

@@ -40,6 +40,13 @@ struct ConvParams {
     const void* mask_y = nullptr;     // pw_gemm masked epilogue (fused scale/ReLU backward): the saved layer output, bf16
     int mask_ld = 0;
     double* part = nullptr;           // [Mt][2][Cout] partial sums of  g*y  and  dc
+    // split-K conv with the Block epilogue (GroupNorm -> x*(scale+1)+shift -> SiLU (+ residual)): conv_splitk_f32_kernel<.., GN = true>
+    const float* gn_gamma = nullptr;
+    const float* gn_beta = nullptr;
+    const float* gn_ss = nullptr;     // [B][2*Cout] rows (scale | shift), row stride gn_ss_ld; null: no scale/shift
+    const float* gn_res = nullptr;    // residual [npix][gn_res_ld], added after the SiLU; null: none
+    int gn_ss_ld = 0, gn_res_ld = 0, gn_groups = 0;
+    float gn_eps = 0.f;
 };
 
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
@@ -335,7 +342,12 @@ constexpr int SK_LD = 64 + 4;                                  // partial-tile r
 // PT: 16-pixel tiles per workgroup (4 = the 64 x 64 tile; 2 / 1 when 64-pixel tiles would leave CUs without a workgroup: the 8x8 and
 // 4x4 levels of a B = 64 reverse step have 4096 / 1024 pixels - every wave's MFMA chain, the critical path of the launch, shrinks
 // with PT while the weight fragments are re-read from L2)
-template <int SK_WAVES, int SK_KL, bool EMU, int PT = 4>       // waves per workgroup, consecutive k per lane per stage (a stage is 4*SK_KL deep)
+// GN: the Block epilogue (reference gaussian_diffusion.py:267-276: GroupNorm -> x*(scale+1)+shift -> SiLU, and ResnetBlock's residual add
+// :301) inside the conv's launch.  Possible when the workgroup's MT pixels are whole images (H*W divides MT: the 8x8, 4x4 and 2x2 stages
+// of the U-Nets) and its 64 output channels are whole groups: the summed tile is already in LDS, the statistics of its (image, group)
+// sets are taken there in fp64 (two passes, like groupnorm_silu_kernel), and the launch of that kernel - 9 us at its latency floor, 22
+// per reverse step - and one round trip of the activation through memory disappear.
+template <int SK_WAVES, int SK_KL, bool EMU, int PT = 4, bool GN = false>       // waves per workgroup, consecutive k per lane per stage (a stage is 4*SK_KL deep)
 __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const ConvParams P) {
     constexpr int SK_BK = 4 * SK_KL, SK_THREADS = SK_WAVES * 64;
     static_assert(!EMU || SK_KL == 8, "the bf16 MFMA takes 8 consecutive k per lane");
@@ -463,6 +475,82 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
                 make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
     __syncthreads();
     constexpr int NF4 = MT * 16;                                   // float4 of the MT x 64 tile
+    if constexpr (GN) {
+        // ---- A. summed tile (+ bias) back into wave 0's region
+#pragma unroll
+        for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
+            const int idx = tid + SK_THREADS * e;
+            if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
+            const int m = idx >> 4, n4 = (idx & 15) * 4;
+            float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
+#pragma unroll
+            for (int w = 1; w < SK_WAVES; ++w) {
+                const float4 t = *reinterpret_cast<const float4*>(part + (w * MT + m) * SK_LD + n4);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            if (P.add && n0 + n4 < P.Cout) {
+                const float4 a4 = *reinterpret_cast<const float4*>(P.add + n0 + n4);
+                v.x = __fadd_rn(v.x, a4.x); v.y = __fadd_rn(v.y, a4.y); v.z = __fadd_rn(v.z, a4.z); v.w = __fadd_rn(v.w, a4.w);
+            }
+            __syncthreads();                                       // (uniform trip count: every thread has read its operands of pass e)
+            *reinterpret_cast<float4*>(part + m * SK_LD + n4) = v;
+        }
+        __syncthreads();
+        // ---- B. statistics of the tile's (image, group) sets: 32 lanes per set, fp64, mean first then the centred squares
+        const int cpg = P.Cout / P.gn_groups, gpt = 64 / cpg, ipt = MT / HW, nset = ipt * gpt, nval = HW * cpg;
+        double* stat = reinterpret_cast<double*>(part + MT * SK_LD);           // wave 1's region: free after pass A
+        const int l32 = tid & 31;
+        for (int st = tid >> 5; st < nset; st += SK_THREADS / 32) {
+            const int img = st / gpt, grp = st - img * gpt;
+            const float* src = part + (img * HW) * SK_LD + grp * cpg;
+            double s1 = 0.0;
+            for (int i = l32; i < nval; i += 32) s1 += (double)src[(i / cpg) * SK_LD + (i % cpg)];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 32);
+            const double mean = s1 / nval;
+            double s2 = 0.0;
+            for (int i = l32; i < nval; i += 32) {
+                const double d = (double)src[(i / cpg) * SK_LD + (i % cpg)] - mean;
+                s2 += d * d;
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 32);
+            if (l32 == 0) {
+                stat[2 * st] = mean;
+                stat[2 * st + 1] = 1.0 / sqrt(s2 / nval + (double)P.gn_eps);
+            }
+        }
+        __syncthreads();
+        // ---- C. normalise, scale/shift, SiLU, residual; float4 rows out
+#pragma unroll
+        for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
+            const int idx = tid + SK_THREADS * e;
+            if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
+            const int m = idx >> 4, n4 = (idx & 15) * 4;
+            const long p = m0 + m;
+            const int n = n0 + n4;
+            if (p >= P.npix || n >= P.Cout) continue;
+            const float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
+            const int st = (m / HW) * gpt + n4 / cpg;
+            const float mu = (float)stat[2 * st], rs = (float)stat[2 * st + 1];
+            const float4 ga = *reinterpret_cast<const float4*>(P.gn_gamma + n), be = *reinterpret_cast<const float4*>(P.gn_beta + n);
+            float o[4] = {v.x, v.y, v.z, v.w};
+            const float gq[4] = {ga.x, ga.y, ga.z, ga.w}, bq[4] = {be.x, be.y, be.z, be.w};
+            const float* sr = P.gn_ss ? P.gn_ss + (p / HW) * (long)P.gn_ss_ld : nullptr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[r], mu), rs), gq[r]), bq[r]);
+                if (sr) t = __fadd_rn(__fmul_rn(t, __fadd_rn(sr[n + r], 1.0f)), sr[P.Cout + n + r]);
+                o[r] = t / (1.0f + expf(-t));
+            }
+            if (P.gn_res) {
+                const float4 rv = *reinterpret_cast<const float4*>(P.gn_res + p * P.gn_res_ld + n);
+                o[0] = __fadd_rn(o[0], rv.x); o[1] = __fadd_rn(o[1], rv.y); o[2] = __fadd_rn(o[2], rv.z); o[3] = __fadd_rn(o[3], rv.w);
+            }
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + p * P.y_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
         const int idx = tid + SK_THREADS * e;
@@ -1013,6 +1101,72 @@ extern "C" int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const v
                                                 float* dadd, void* ws, nfdp_stream_t stream) {
     return nfdp_pointwise_dgrad_masked_bf16_ex(x, x_ld, w_packed, y_saved, y_ld, mul, f, npix, Cin, Cout, dc, dc_ld, dmul, dadd, ws, 0,
                                                stream);
+}
+
+// ---- split-K conv with the Block epilogue (GroupNorm -> scale/shift -> SiLU -> + residual) in the same launch
+static int gn_pixel_tiles(long npix, int Cout, int HW) {
+    const long t64 = cdiv(npix, 64) * cdiv(Cout, 64);
+    int pt = t64 >= 256 ? 4 : (2 * t64 >= 256 ? 2 : 1);
+    while ((16 * pt) % HW != 0 && pt < 4) pt *= 2;             // whole images per workgroup
+    return (16 * pt) % HW == 0 ? pt : 0;
+}
+
+extern "C" int nfdp_conv2d_gn_silu_supported(int B, int H, int W, int Cin, int Cout, int K, int groups) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || (K % 2) != 1 || K > 7) return 0;
+    if (Cin % 8 != 0 || Cout % 64 != 0 || Cout % groups != 0) return 0;
+    const int cpg = Cout / groups, HW = H * W;
+    if (cpg % 4 != 0 || 64 % cpg != 0 || HW > 64 || 64 % HW != 0) return 0;
+    const long npix = (long)B * HW;
+    if (kpad_for(Cin, K, K) < 8 * 32 || cdiv(npix, 64) * cdiv(Cout, 64) > 1024) return 0;       // the split-K kernel's own range
+    return gn_pixel_tiles(npix, Cout, HW) != 0;
+}
+
+extern "C" int nfdp_conv2d_gn_silu_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
+                                            int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
+                                            const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld,
+                                            nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && w_packed && y && gamma && beta, NFDP_EINVAL, "conv2d_gn_silu: null pointer");
+    NFDP_REQUIRE(nfdp_conv2d_gn_silu_supported(B, H, W, Cin, Cout, K, groups), NFDP_EUNSUPPORTED,
+                 "conv2d_gn_silu: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d K=%d groups=%d", B, H, W, Cin, Cout, K, groups);
+    NFDP_REQUIRE(x_ld >= Cin && x_ld % 4 == 0 && y_ld >= Cout && y_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0, NFDP_ESHAPE,
+                 "conv2d_gn_silu: rows must be 16-byte aligned");
+    NFDP_REQUIRE((bias == nullptr || (uintptr_t)bias % 16 == 0) && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0, NFDP_ESHAPE,
+                 "conv2d_gn_silu: parameter vectors must be 16-byte aligned");
+    NFDP_REQUIRE(scale_shift == nullptr || ss_ld >= 2 * Cout, NFDP_ESHAPE, "conv2d_gn_silu: scale_shift rows shorter than 2*Cout");
+    NFDP_REQUIRE(residual == nullptr || (res_ld >= Cout && res_ld % 4 == 0 && ((uintptr_t)residual % 16) == 0), NFDP_ESHAPE,
+                 "conv2d_gn_silu: residual rows must be 16-byte aligned");
+    const long npix = (long)B * H * W;
+    ConvParams P;
+    P.x = x; P.w = w_packed; P.y = y; P.add = bias; P.mul = nullptr; P.npix = npix;
+    P.x_ld = x_ld; P.y_ld = y_ld; P.y_bf16 = 0;
+    P.H = H; P.W = W; P.Cin = Cin; P.Cout = Cout; P.KH = K; P.KW = K; P.pad = (K - 1) / 2;
+    P.K = Cin * K * K; P.Kpad = kpad_for(Cin, K, K); P.relu = 0; P.mul_exp = 0.f;
+    P.gn_gamma = gamma; P.gn_beta = beta; P.gn_ss = scale_shift; P.gn_ss_ld = ss_ld; P.gn_res = residual; P.gn_res_ld = res_ld;
+    P.gn_groups = groups; P.gn_eps = eps;
+    P.Nt = (int)cdiv(Cout, 64);
+    const int pt = gn_pixel_tiles(npix, Cout, H * W);
+    P.Mt = (int)cdiv(npix, 16 * pt);
+    const dim3 grid(P.Mt * P.Nt);
+    hipStream_t s = as_stream(stream);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<8, 4, false, 4, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * SK_LD * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<4, 8, true, 4, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
+        attr_set = true;
+    }
+    if (g_f32_products == 1) {
+        if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 4, true>), grid, dim3(256), 4 * 64 * SK_LD * 4, s, P);
+        else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 2, true>), grid, dim3(256), 4 * 32 * SK_LD * 4, s, P);
+        else hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 1, true>), grid, dim3(256), 4 * 16 * SK_LD * 4, s, P);
+    } else {
+        if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false, 4, true>), grid, dim3(512), 8 * 64 * SK_LD * 4, s, P);
+        else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false, 2, true>), grid, dim3(512), 8 * 32 * SK_LD * 4, s, P);
+        else hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false, 1, true>), grid, dim3(512), 8 * 16 * SK_LD * 4, s, P);
+    }
+    NFDP_CHECK_LAUNCH("conv2d_gn_silu");
+    return NFDP_OK;
 }
 
 extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,

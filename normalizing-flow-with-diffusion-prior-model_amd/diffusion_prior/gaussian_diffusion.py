@@ -185,6 +185,12 @@ class Block(nn.Module):
         self.act = _Marker("silu")
 
     def forward_nhwc(self, xh, scale_shift=None, compute=None, residual=None):
+        cenum = K.compute_enum(compute)
+        if cenum == K.F32 and not torch.is_grad_enabled() and \
+                K.conv2d_gn_silu_supported(xh, self.proj.cout, self.proj.k, self.norm.num_groups, self.proj.bias, self.norm.weight, self.norm.bias):
+            # the whole Block as ONE launch: the conv's summed tile is normalised in its epilogue (8x8 / 4x4 / 2x2 stages)
+            return K.conv2d_gn_silu(xh, self.proj.packed(cenum), self.proj.cout, self.proj.k, self.proj.bias, self.norm.num_groups,
+                                    self.norm.weight, self.norm.bias, scale_shift, 1e-5, residual)
         h = self.proj.forward_nhwc(xh, compute)
         return K.groupnorm_silu(h, self.norm.num_groups, self.norm.weight, self.norm.bias, scale_shift, 1e-5, residual)
 

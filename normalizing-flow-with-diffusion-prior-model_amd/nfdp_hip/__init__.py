@@ -753,6 +753,47 @@ def groupnorm_silu(xh: torch.Tensor, groups: int, gamma, beta, scale_shift: Opti
     return y
 
 
+_CONV_GN_FUSED = True
+
+
+def set_conv_gn_fused(on: bool) -> None:
+    """U-Net Block (WS-conv -> GroupNorm -> scale/shift -> SiLU [-> + residual]) as one launch where the geometry allows (default) or as
+    conv + GroupNorm launches."""
+    global _CONV_GN_FUSED
+    _CONV_GN_FUSED = bool(on)
+
+
+def conv2d_gn_silu_supported(xh: torch.Tensor, cout: int, k: int, groups: int, *vectors) -> bool:
+    """The one-launch Block is available for this input (fp32 NHWC, no grad) and these parameter vectors (16-byte aligned)?"""
+    if not (_CONV_GN_FUSED and xh.is_cuda and xh.dtype == torch.float32 and xh.dim() == 4 and xh.stride(3) == 1):
+        return False
+    b, h, w, cin = xh.shape
+    if any(v is not None and v.data_ptr() % 16 != 0 for v in vectors) or xh.data_ptr() % 16 != 0 or xh.stride(2) % 4 != 0:
+        return False
+    return bool(lib().nfdp_conv2d_gn_silu_supported(b, h, w, cin, cout, k, groups))
+
+
+def conv2d_gn_silu(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bias, groups: int, gamma, beta,
+                   scale_shift: Optional[torch.Tensor], eps: float = 1e-5, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Block of the U-Net in one launch (nfdp_conv2d_gn_silu_nhwc_f32); check conv2d_gn_silu_supported first."""
+    _need(xh, torch.float32, "conv2d_gn_silu")
+    b, h, w, cin = xh.shape
+    y = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
+    ss_ld = 0
+    if scale_shift is not None:
+        assert scale_shift.shape == (b, 2 * cout) and scale_shift.stride(1) == 1
+        ss_ld = scale_shift.stride(0) if b > 1 else 2 * cout
+    res_ld = 0
+    if residual is not None:
+        _need(residual, torch.float32, "conv2d_gn_silu residual"); _dense(residual, "conv2d_gn_silu residual")
+        assert residual.shape == y.shape
+        res_ld = cout
+    _call("nfdp_conv2d_gn_silu_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_gn_silu"), _ptr(packed), _ptr(y), cout, b, h, w, cin, cout, k,
+          _ptr(bias), groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, float(eps), _ptr(residual), res_ld, _stream(),
+          label=f"conv_splitk_f32+gn k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * k * k * cout)
+    return y
+
+
 def chan_layernorm(xh: torch.Tensor, gain: torch.Tensor, residual: Optional[torch.Tensor] = None, eps: float = 1e-5):
     _need(xh, torch.float32, "chan_layernorm"); _dense(xh, "chan_layernorm")
     c = xh.shape[-1]

@@ -384,3 +384,48 @@ def test_time_path_table_equals_the_direct_time_path(dg):
         assert_close(after[k], ref[k], 1e-6, "rows after a weight update")
     with torch.enable_grad():
         assert u._time_table(x.device) is None                      # the differentiable path computes the time MLP (it has gradients)
+
+
+@pytest.mark.parametrize("b,cin,cout,hw,groups,with_ss,with_res", [(5, 64, 64, 8, 8, True, False), (7, 128, 128, 4, 8, True, True),
+                                                                      (3, 192, 128, 2, 8, False, True), (64, 64, 128, 8, 16, True, True),
+                                                                      (2, 128, 64, 8, 8, True, False)])
+@torch.no_grad()
+def test_block_in_one_launch_matches_conv_then_groupnorm(b, cin, cout, hw, groups, with_ss, with_res):
+    """Block (WS-conv -> GroupNorm -> scale/shift -> SiLU -> + residual, gaussian_diffusion.py:267-276, :301) as ONE launch
+    (nfdp_conv2d_gn_silu_nhwc_f32: GroupNorm in the split-K conv's epilogue) against the two launches it replaces and against torch,
+    for whole-image pixel tiles of 64 / 32 / 16 pixels, groups of 4..16 channels, ragged batches."""
+    import torch.nn.functional as F
+    from diffusion_prior.gaussian_diffusion import Block
+    g = torch.Generator().manual_seed(b * 100 + hw)
+    blk = Block(cin, cout, groups=groups).to(DEV)
+    for p in blk.parameters():
+        p.data.copy_((torch.randn(p.shape, generator=g) * (0.3 if p.dim() == 1 else 0.08)).to(DEV))
+    blk.norm.weight.data.add_(1.0)
+    x = torch.randn(b, hw, hw, cin, generator=g).to(DEV)
+    ss = (torch.randn(b, 2 * cout + 8, generator=g) * 0.5).to(DEV)[:, 4:4 + 2 * cout] if with_ss else None      # a column slice, as the U-Net passes
+    res = torch.randn(b, hw, hw, cout, generator=g).to(DEV) if with_res else None
+    assert K.conv2d_gn_silu_supported(x, cout, 3, groups, blk.proj.bias, blk.norm.weight, blk.norm.bias)
+    K.start_trace()
+    fused = blk.forward_nhwc(x, ss, "f32", residual=res)
+    labels = [e["label"] for e in K.stop_trace()]
+    assert any(lb.startswith("conv_splitk_f32+gn") for lb in labels) and not any(lb.startswith("groupnorm") for lb in labels), labels
+    K.set_conv_gn_fused(False)
+    try:
+        plain = blk.forward_nhwc(x, ss, "f32", residual=res)
+    finally:
+        K.set_conv_gn_fused(True)
+    assert_close(fused, plain, 2e-5, "one launch vs conv + GroupNorm launches")
+    # torch reference of the same Block
+    w = blk.proj.weight.detach().cpu()
+    mean, var = w.mean(dim=(1, 2, 3), keepdim=True), w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    wn = (w - mean) * (var + 1e-5).rsqrt()
+    h = F.conv2d(x.cpu().permute(0, 3, 1, 2), wn, blk.proj.bias.detach().cpu(), padding=1)
+    h = F.group_norm(h, groups, blk.norm.weight.detach().cpu(), blk.norm.bias.detach().cpu(), eps=1e-5)
+    if with_ss:
+        sc = ss.cpu()
+        h = h * (sc[:, :cout, None, None] + 1) + sc[:, cout:, None, None]
+    h = F.silu(h)
+    if with_res:
+        h = h + res.cpu().permute(0, 3, 1, 2)
+    assert_close(fused.permute(0, 3, 1, 2), h, 5e-5, "one-launch Block vs torch")
+    assert not K.conv2d_gn_silu_supported(torch.zeros(2, 16, 16, cin, device=DEV), cout, 3, groups)       # 256-pixel images: two launches
