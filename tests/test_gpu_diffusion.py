@@ -386,9 +386,9 @@ def test_time_path_table_equals_the_direct_time_path(dg):
         assert u._time_table(x.device) is None                      # the differentiable path computes the time MLP (it has gradients)
 
 
-@pytest.mark.parametrize("b,cin,cout,hw,groups,with_ss,with_res", [(5, 64, 64, 8, 8, True, False), (7, 128, 128, 4, 8, True, True),
-                                                                      (3, 192, 128, 2, 8, False, True), (64, 64, 128, 8, 16, True, True),
-                                                                      (2, 128, 64, 8, 8, True, False)])
+@pytest.mark.parametrize("b,cin,cout,hw,groups,with_ss,with_res", [(260, 64, 64, 8, 8, True, False), (7, 128, 128, 4, 8, True, True),
+                                                                      (3, 192, 128, 2, 8, False, True), (130, 64, 128, 8, 16, True, True),
+                                                                      (64, 128, 128, 4, 8, True, True), (33, 128, 64, 4, 8, True, False)])
 @torch.no_grad()
 def test_block_in_one_launch_matches_conv_then_groupnorm(b, cin, cout, hw, groups, with_ss, with_res):
     """Block (WS-conv -> GroupNorm -> scale/shift -> SiLU -> + residual, gaussian_diffusion.py:267-276, :301) as ONE launch
@@ -429,3 +429,4 @@ def test_block_in_one_launch_matches_conv_then_groupnorm(b, cin, cout, hw, group
         h = h + res.cpu().permute(0, 3, 1, 2)
     assert_close(fused.permute(0, 3, 1, 2), h, 5e-5, "one-launch Block vs torch")
     assert not K.conv2d_gn_silu_supported(torch.zeros(2, 16, 16, cin, device=DEV), cout, 3, groups)       # 256-pixel images: two launches
+    assert not K.conv2d_gn_silu_supported(torch.zeros(8, 8, 8, cin, device=DEV), cout, 3, groups)         # few 64-pixel images: the plain conv's smaller tiles win
