@@ -147,3 +147,25 @@ def test_unet_with_learned_or_random_time_embedding(tag):
         assert u.time_mlp[0].weights.grad is None
     with pytest.raises(AssertionError):
         GaussianDiffusion(u, image_size=16, timesteps=8)
+
+
+def test_auto_normalize_keeps_the_gradient_of_a_latent_that_requires_grad():
+    """GaussianDiffusion(auto_normalize=True).forward on an input that carries a gradient (latents of an unfrozen flow,
+    diffusion_prior/trainer.py:139-141): the [0,1] -> [-1,1] map must stay inside autograd (d loss / d img = 2 * d loss / d x_start)."""
+    from diffusion_prior import Unet, GaussianDiffusion
+    u = Unet(dim=32, dim_mults=(1, 2), channels=2, resnet_block_groups=8, compute="f32").to(DEV)
+    d = GaussianDiffusion(u, image_size=8, timesteps=20, beta_schedule="cosine", loss_type="l2", auto_normalize=True).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    for p in u.parameters():
+        p.data.add_(0.05 * torch.randn(p.shape, generator=g).to(DEV))
+    img = torch.rand(2, 2, 8, 8, generator=g).to(DEV).requires_grad_(True)
+    t = torch.tensor([3, 11], device=DEV)
+    eps = torch.randn(2, 2, 8, 8, generator=g).to(DEV)
+    loss = d.p_losses(d.normalize(img), t, noise=eps)
+    loss.backward()
+    assert img.grad is not None and float(img.grad.abs().max()) > 0
+    x = (img.detach() * 2 - 1).requires_grad_(True)
+    d.p_losses(x, t, noise=eps).backward()
+    assert_close(img.grad, 2 * x.grad, 1e-5, "gradient through normalize")
+    with torch.no_grad():
+        assert_close(d.normalize(img.detach()), img.detach() * 2 - 1, 1e-7, "HIP normalize (no grad)")
