@@ -268,7 +268,7 @@ def train_bench(args, rank, world, device, barrier):
     elif graphed:
         from nfdp_hip.graphs import capture_step
         cap_fb = capture_step(fwd_bwd, warmup=1, mutates_params=False)
-        cap_opt = capture_step(opt.step, warmup=1)
+        cap_opt = capture_step(opt.step, warmup=1, warmup_fn=train_step)      # (an eager optimizer step needs the all-reduce in front of it)
         def run():
             cap_fb()
             reducer.finish()

@@ -209,6 +209,10 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
         return torch.empty((b, h, w, c), device=x.device, dtype=torch.float32)
     if is_nhwc_view(x):
         return x.permute(0, 2, 3, 1)
+    if torch.is_grad_enabled() and x.requires_grad:
+        # a tensor that carries a gradient (latents of an unfrozen flow, a normalised image) must stay inside autograd: the HIP copy
+        # below is invisible to it and would silently cut the graph.  permute + contiguous are tracked views / copies (plumbing).
+        return x.permute(0, 2, 3, 1).contiguous()
     x = x.contiguous()
     b, c, h, w = x.shape
     y = torch.empty((b, h, w, c), device=x.device, dtype=torch.float32)

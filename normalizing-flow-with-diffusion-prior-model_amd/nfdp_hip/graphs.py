@@ -69,7 +69,8 @@ class CapturedStep:
     replay = __call__
 
 
-def capture_step(fn: Callable, warmup: int = 3, mutates_params: bool = True, capture_error_mode: str = None) -> CapturedStep:
+def capture_step(fn: Callable, warmup: int = 3, mutates_params: bool = True, capture_error_mode: str = None,
+                 warmup_fn: Callable = None) -> CapturedStep:
     """Capture `fn()` - a complete step with no arguments that reads its inputs from fixed tensors, e.g.
 
         def fn():
@@ -83,6 +84,8 @@ def capture_step(fn: Callable, warmup: int = 3, mutates_params: bool = True, cap
         fails inside torch.cuda.graph with torch's own error rather than hanging;
       * with a process group of more than one rank the capture runs in "thread_local" error mode (RCCL's watchdog thread may call
         into HIP meanwhile); pass capture_error_mode to override.
+    warmup_fn: what the warm-up calls run when `fn` alone is not a valid eager step - e.g. fn = optimizer.step under data parallelism,
+    whose eager form needs the gradient all-reduce in front of it: pass the whole training step.
     fn must use static shapes and draw its randomness on the device (GaussianDiffusion.forward does; self_condition=True does not
     and raises).  The returned object replays the graph; its outputs alias fn's return value.
 
@@ -101,7 +104,7 @@ def capture_step(fn: Callable, warmup: int = 3, mutates_params: bool = True, cap
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(warmup):
-            fn()
+            (warmup_fn or fn)()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     if capture_error_mode is None:
