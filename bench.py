@@ -267,7 +267,9 @@ def train_bench(args, rank, world, device, barrier):
         loss = cap.outputs
     elif graphed:
         from nfdp_hip.graphs import capture_step
-        cap_fb = capture_step(fwd_bwd, warmup=1, mutates_params=False)
+        # (warm-up = whole steps: the capture must start from the state every replay starts from - right after an optimizer update,
+        # weight-layout caches stale - so that the re-packing launches are part of the captured forward)
+        cap_fb = capture_step(fwd_bwd, warmup=1, mutates_params=False, warmup_fn=train_step)
         cap_opt = capture_step(opt.step, warmup=1, warmup_fn=train_step)      # (an eager optimizer step needs the all-reduce in front of it)
         def run():
             cap_fb()

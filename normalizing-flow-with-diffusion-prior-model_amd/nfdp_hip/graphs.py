@@ -84,7 +84,12 @@ def capture_step(fn: Callable, warmup: int = 3, mutates_params: bool = True, cap
         fails inside torch.cuda.graph with torch's own error rather than hanging;
       * with a process group of more than one rank the capture runs in "thread_local" error mode (RCCL's watchdog thread may call
         into HIP meanwhile); pass capture_error_mode to override.
-    warmup_fn: what the warm-up calls run when `fn` alone is not a valid eager step - e.g. fn = optimizer.step under data parallelism,
+    The warm-up must leave the state every replay will start from.  For a training step that is "right after an optimizer update":
+    the kernel-layout weight caches are then stale, so the capture records the re-packing launches and every replay re-packs the
+    weights the previous replay updated.  A forward+backward captured after a warm-up WITHOUT an optimizer step finds valid caches,
+    records no re-packing and replays on the weights of capture time for ever (seen as a diverging loss in the two-graph
+    data-parallel form of bench.py --train before warmup_fn existed).
+    warmup_fn: what the warm-up calls run when `fn` alone is not such a step - e.g. fn = optimizer.step under data parallelism,
     whose eager form needs the gradient all-reduce in front of it: pass the whole training step.
     fn must use static shapes and draw its randomness on the device (GaussianDiffusion.forward does; self_condition=True does not
     and raises).  The returned object replays the graph; its outputs alias fn's return value.
