@@ -976,3 +976,51 @@ def test_activation_recomputation_gives_bit_identical_gradients():
         assert g0.keys() == g1.keys()
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
+
+
+def test_two_graph_training_step_repacks_its_weights():
+    """The data-parallel form of the captured training step (bench.py --train --graph-multi): forward + backward as one hipGraph, the
+    optimizer as another, an eager gradient exchange between the replays.  The forward graph must have been captured from the state
+    every replay starts from (right after an optimizer update: weight-layout caches stale), so that it re-packs the weights the
+    previous replay updated - captured after a warm-up without an optimizer step it would replay on the weights of capture time.
+    Checked: three replayed steps equal three eager steps (loss and every parameter)."""
+    from normalizing_flow import Glow, GaussianPrior, calculate_loss
+    from nfdp_hip.optim import FusedAdam
+    from nfdp_hip.graphs import capture_step
+    B = 8
+    x = (T(synth_input("two_graph_x", (B, 3, 32, 32), 4)) * 0.4).to(DEV)
+
+    def make():
+        flow, prior = Glow(in_channel=3, L=3, K=2, compute="bf16").to(DEV), GaussianPrior(48).to(DEV)
+        flow.load_state_dict({k: T(synth_tensor(k, v.shape, 6, DEEP)) for k, v in flow.state_dict().items()})
+        prior.load_state_dict({k: T(synth_tensor(k, v.shape, 6, DEEP)) for k, v in prior.state_dict().items()})
+        opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-3, clip_value=1, max_norm=1, direct_grads=True)
+
+        def fwd_bwd():
+            ldj = torch.zeros(B, dtype=torch.float64, device=DEV)
+            logp = torch.zeros(B, dtype=torch.float64, device=DEV)
+            zs, ldj, logp = flow.transform(x, ldj, logp)
+            loss = calculate_loss(ldj + logp + prior.compute_log_prob(zs[-1]), 32.0, 3072.0)
+            opt.zero_grad()
+            loss.backward()
+            return loss.detach()
+
+        def step():
+            loss = fwd_bwd()
+            opt.step()
+            return loss
+        return opt, fwd_bwd, step
+
+    oe, _, eager = make()
+    oc, fwd_bwd, cstep = make()
+    g_fb = capture_step(fwd_bwd, warmup=1, mutates_params=False, warmup_fn=cstep)
+    g_opt = capture_step(oc.step, warmup=1, warmup_fn=cstep)
+    eager(); eager()                                                  # the two warm-up steps of the captured copy
+    for k in range(3):
+        l_e = eager()
+        l_c = g_fb()
+        g_opt()                                                       # (a multi-rank run all-reduces the flat gradient buffer between the two)
+        torch.cuda.synchronize()
+        assert_close(l_c, l_e, 1e-6, f"step {k}: loss")
+        assert relerr(oc.flat_param, oe.flat_param) <= 1e-6, f"step {k}: parameters {relerr(oc.flat_param, oe.flat_param):.2e}"
+    assert float((oe.flat_param - oc.flat_param).abs().max()) < 1e-5
