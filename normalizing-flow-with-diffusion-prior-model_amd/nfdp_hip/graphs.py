@@ -119,4 +119,9 @@ def capture_step(fn: Callable, warmup: int = 3, mutates_params: bool = True, cap
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph, capture_error_mode=capture_error_mode):
         out = fn()
+    # The capture RECORDED launches without running them, but the Python-side bookkeeping ran: weight-layout caches whose re-packing was
+    # just recorded are marked up to date although their buffers still hold the previous weights.  Eager code that runs before the first
+    # replay (e.g. the warm-up of a second capture) must not trust them.
+    from . import bump_param_epoch
+    bump_param_epoch()
     return CapturedStep(graph, out, mutates_params)

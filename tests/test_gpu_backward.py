@@ -994,7 +994,7 @@ def test_two_graph_training_step_repacks_its_weights():
         flow, prior = Glow(in_channel=3, L=3, K=2, compute="bf16").to(DEV), GaussianPrior(48).to(DEV)
         flow.load_state_dict({k: T(synth_tensor(k, v.shape, 6, DEEP)) for k, v in flow.state_dict().items()})
         prior.load_state_dict({k: T(synth_tensor(k, v.shape, 6, DEEP)) for k, v in prior.state_dict().items()})
-        opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-3, clip_value=1, max_norm=1, direct_grads=True)
+        opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-4, clip_value=1, max_norm=1, direct_grads=True)
 
         def fwd_bwd():
             ldj = torch.zeros(B, dtype=torch.float64, device=DEV)
