@@ -476,10 +476,14 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
     __syncthreads();
     constexpr int NF4 = MT * 16;                                   // float4 of the MT x 64 tile
     if constexpr (GN) {
-        // ---- A. summed tile (+ bias) back into wave 0's region
+        // ---- A. summed tile (+ bias) back into wave 0's region: all sums first (registers), ONE barrier, then the stores - a barrier
+        // inside the loop would be skipped by the threads without an element (MT = 16 with 512 threads) and pair up with a later one
+        constexpr int NE = (NF4 + SK_THREADS - 1) / SK_THREADS;
+        float4 sums[NE];
 #pragma unroll
-        for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
+        for (int e = 0; e < NE; ++e) {
             const int idx = tid + SK_THREADS * e;
+            sums[e] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
             const int m = idx >> 4, n4 = (idx & 15) * 4;
             float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
@@ -492,8 +496,14 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
                 const float4 a4 = *reinterpret_cast<const float4*>(P.add + n0 + n4);
                 v.x = __fadd_rn(v.x, a4.x); v.y = __fadd_rn(v.y, a4.y); v.z = __fadd_rn(v.z, a4.z); v.w = __fadd_rn(v.w, a4.w);
             }
-            __syncthreads();                                       // (uniform trip count: every thread has read its operands of pass e)
-            *reinterpret_cast<float4*>(part + m * SK_LD + n4) = v;
+            sums[e] = v;
+        }
+        __syncthreads();                                           // every thread has read the partial tiles
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + SK_THREADS * e;
+            if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
+            *reinterpret_cast<float4*>(part + (idx >> 4) * SK_LD + (idx & 15) * 4) = sums[e];
         }
         __syncthreads();
         // ---- B. statistics of the tile's (image, group) sets: 32 lanes per set, fp64, mean first then the centred squares
