@@ -9,7 +9,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-legs --no-graph > "$OUT/bench_under_rocprof.json" 2> "$OUT/bench_under_rocprof.err"
 echo "stats pass done"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum"; do
   name=$(echo $pass | cut -d' ' -f1)
