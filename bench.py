@@ -441,7 +441,7 @@ def pmc_traffic(lbl, batch):
     are the sources of this run (bench.py cannot collect counters itself: they need rocprofv3 around the process)."""
     import glob
     key = {"level_fused<12,16>": "coupling_fused_kernel<12, 16, 2, false, false>",
-           "level_fused<24,8>": "coupling_fused_rs2_kernel<24, 8, 4, false>",
+           "level_fused<24,8>": "coupling_fused_rs2_kernel<24, 8, 2, false>",
            "level_fused<48,4>": "coupling_fused_rs_kernel<48, 4, false>"}.get(lbl.split(" ")[0])
     if key is None or batch != 512:
         return None
