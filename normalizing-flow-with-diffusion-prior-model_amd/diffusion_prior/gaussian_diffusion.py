@@ -356,7 +356,9 @@ class Unet(_EpochOnApply, nn.Module):
         T_ = int(getattr(self, "_tt_T", 0) or 0)
         if T_ <= 0 or torch.is_grad_enabled() or device.type != "cuda":
             return None
-        deps = [p for m in (self.time_mlp,) for p in m.parameters()] + [p for b in self._resnet_blocks() for p in b.mlp.parameters()]
+        deps = getattr(self, "_tt_deps", None)
+        if deps is None:                                  # the module structure is fixed after construction
+            deps = self._tt_deps = list(self.time_mlp.parameters()) + [p for b in self._resnet_blocks() for p in b.mlp.parameters()]
         key = (T_, K.compute_enum(self.compute), K.param_epoch(), str(device)) + tuple((p.data_ptr(), p._version) for p in deps)
         if getattr(self, "_tt_key", None) != key:
             if torch.cuda.is_current_stream_capturing():
