@@ -130,6 +130,41 @@ def test_rowsplit_kernel_bit_identical(C, hw, inverse):
         assert torch.isfinite(outs[1][0]).all()
 
 
+@pytest.mark.parametrize("inverse", [False, True])
+@torch.no_grad()
+def test_level0_eight_wave_form_bit_identical(inverse):
+    """The 16x16 level has a second form of its kernel: 8 waves x 32 pixels (two waves per SIMD at 256 registers) instead of 4 waves x
+    64 pixels.  Same packed weights, same k order and rounding points: identical bits, full and ragged batches.  (It is not the default -
+    measured 0-3 % slower, DESIGN.md 4.2 - and stays reachable through NFDP_L0_WAVES=8 for A/B runs.)"""
+    import ctypes
+    import numpy as np
+    setter = K.lib().nfdp_debug_set_l0_waves
+    setter.argtypes, setter.restype = [ctypes.c_int], None
+    from normalizing_flow.glow import StepFlow
+    from tests.golden.synth import synth_tensor, DEEP
+    flow = StepFlow(12, 512, compute="bf16").to("cuda")
+    flow.load_state_dict({k: torch.from_numpy(np.array(synth_tensor("flows.2." + k, v.shape, 7, DEEP))) for k, v in flow.state_dict().items()})
+    torch.manual_seed(3 + inverse)
+    try:
+        for B in (1, 3, 64):
+            x = torch.randn(B, 16, 16, 12, device="cuda")
+            outs = []
+            for nw in (4, 8):
+                setter(nw)
+                xh = x.clone()
+                ldj = torch.zeros(B, dtype=torch.float64, device="cuda")
+                if inverse:
+                    flow.invert_nhwc_(xh)
+                else:
+                    flow.transform_nhwc_(xh, ldj)
+                outs.append((xh, ldj))
+            assert torch.equal(outs[0][0], outs[1][0]), f"B={B}: state differs"
+            assert torch.equal(outs[0][1], outs[1][1]), f"B={B}: ldj differs"
+            assert torch.isfinite(outs[1][0]).all()
+    finally:
+        setter(-1)
+
+
 @pytest.mark.parametrize("C,hw,B", [(12, 16, 5), (24, 8, 7), (48, 4, 9), (4, 16, 2), (8, 8, 3), (16, 4, 5)])
 @pytest.mark.parametrize("inverse", [False, True])
 @torch.no_grad()
