@@ -217,7 +217,9 @@ def train_bench(args, rank, world, device, barrier):
     flow, prior, _, _ = build_models(args.L, args.K, args.compute, device, init=args.init)
     _, _, u8_d, noise_d = make_batch(args.batch, rank, device)
     from normalizing_flow import training as _training
-    _training.RECOMPUTE_FLOWS = int(args.recompute)
+    # "G" (every level) or "H:G,H:G" (per level by spatial size, e.g. 16:8)
+    rc = str(args.recompute)
+    _training.RECOMPUTE_FLOWS = ({int(k): int(v) for k, v in (kv.split(":") for kv in rc.split(","))} if ":" in rc else int(rc))
     if args.init == "data":
         # utils.py:275-292 for replicas: rank 0 runs the data-dependent pass on its first batch, every rank takes the result
         # (--init-mode global: every rank runs it on its shard with the ActNorm moments all-reduced = the global first batch)
@@ -299,7 +301,7 @@ def train_bench(args, rank, world, device, barrier):
                                    "(BASELINE configs[2] shape; forward, bits/dim, backward, clip_grad_value_/norm_ 1, Adam lr 1e-4 - the synthetic trained-like weights diverge at the reference's 1e-3)",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "optimizer": "nfdp fused clip+Adam (flat buffers)",
-                       "activations": "kept" if not args.recompute else f"hidden activations recomputed in the backward pass, {args.recompute} flows at a time",
+                       "activations": "kept" if args.recompute in ("0", 0) else f"hidden activations recomputed in the backward pass, {args.recompute} flows at a time (H:G = per level by spatial size)",
                        "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (forward+backward | all-reduce | optimizer)") if graphed else "eager",
                        "gradient_allreduce": "in place on the flat gradient buffer (SUM), 32 MiB slices, after backward; 1/world in the clip pass" if world > 1 else "none",
                        "init": args.init + (f" ({args.init_mode}: nfdp_hip.dist.data_dependent_init)" if args.init == "data" else " (identical on every rank)") + ", then broadcast from rank 0"},
@@ -483,7 +485,7 @@ def main():
                          "ZeroConvs) + data-dependent ActNorm init on the first batch, synchronised across ranks")
     ap.add_argument("--init-mode", default="rank0", choices=["rank0", "global"],
                     help="--init data: ActNorm statistics of rank 0's first batch broadcast (parity semantics) or of the global batch (all-reduced moments)")
-    ap.add_argument("--recompute", type=int, default=0, metavar="G",
+    ap.add_argument("--recompute", type=str, default="0", metavar="G | H:G,...",
                     help="--train: activation recomputation - keep only the flow-state tensors and re-run the training forward of G flows "
                          "at a time in the backward pass (normalizing_flow.training.RECOMPUTE_FLOWS; 0 = keep every activation)")
     ap.add_argument("--graph-multi", action="store_true", help="--train with several ranks: replay hipGraphs around the all-reduce instead of eager launches")

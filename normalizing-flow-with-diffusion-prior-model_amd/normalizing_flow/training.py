@@ -70,7 +70,18 @@ WGRAD_SIDE_STREAM = True
 # pass, re-run the training forward of G flows at a time from the group's saved input (bit-identical activations, so bit-identical
 # gradients; one extra forward per step; the hidden tensors of G flows live at a time).  A flow is invertible, so its input COULD also be
 # recomputed from its output - not done: the flow state is 6 MB per flow here, the hidden activations are 268 MB.
+# A dict {H: G} sets G per level by its spatial size (levels not named keep their activations): {16: 8} recomputes only the 16x16 level,
+# which holds 4.5 of the 6.9 GiB, in two groups.
 RECOMPUTE_FLOWS = 0
+
+
+def _recompute_group(h: int) -> int:
+    r = RECOMPUTE_FLOWS
+    if isinstance(r, dict):
+        return int(r.get(int(h), 0))
+    return int(r) if r else 0
+
+
 # The main stream waits for the side stream's weight gradients every SIDE_JOIN_EVERY flows of a level's backward pass (0: once, at the
 # end of the level).  Tensors the side stream reads - a flow's hidden-activation gradients, 0.3 GB at level 0 - are kept referenced
 # until the join; joining every few flows bounds that to a few flows' worth instead of a whole level's 4.5 GB.
@@ -708,7 +719,7 @@ class LevelFusedFn(Function):
         scales = [params[P * i].detach().reshape(-1) for i in range(n)]
         biases = [params[P * i + 1].detach().reshape(-1) for i in range(n)]
         ws = [params[P * i + 2].detach().reshape(c, c) for i in range(n)]
-        ctx.recompute = int(RECOMPUTE_FLOWS) if RECOMPUTE_FLOWS else 0
+        ctx.recompute = _recompute_group(xh.shape[1])
         if ctx.recompute:
             # activation recomputation: the 512-channel hidden activations (2 x 134 MB per level-0 flow at B = 512) are not kept; the
             # backward pass re-runs this launch per group of `recompute` flows from the group's saved input state xpre[first flow]

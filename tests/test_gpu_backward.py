@@ -976,6 +976,10 @@ def test_activation_recomputation_gives_bit_identical_gradients():
         assert g0.keys() == g1.keys()
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
+    # per level by spatial size: only the 16x16 level (which holds most of the memory) recomputes, in groups of 2
+    l2, g2, n2 = run({16: 2})
+    assert n2 == 3 + 2
+    assert torch.equal(l0, l2) and all(torch.equal(g0[k], g2[k]) for k in g0)
 
 
 def test_two_graph_training_step_repacks_its_weights():
