@@ -442,9 +442,10 @@ def pmc_traffic(lbl, batch):
     profile_round.sh), with the provenance a reader needs: which file, which kernel sources it was collected on, and whether those
     are the sources of this run (bench.py cannot collect counters itself: they need rocprofv3 around the process)."""
     import glob
-    key = {"level_fused<12,16>": "coupling_fused_kernel<12, 16, 2, false, false>",
-           "level_fused<24,8>": "coupling_fused_rs2_kernel<24, 8, 2, false>",
-           "level_fused<48,4>": "coupling_fused_rs_kernel<48, 4, false>"}.get(lbl.split(" ")[0])
+    # (prefixes: the kernels' later template arguments - wave count, MFMA shape - vary with the build's defaults)
+    key = {"level_fused<12,16>": "coupling_fused_kernel<12, 16, 2, false, false",
+           "level_fused<24,8>": "coupling_fused_rs2_kernel<24, 8, 2, false",
+           "level_fused<48,4>": "coupling_fused_rs_kernel<48, 4, false"}.get(lbl.split(" ")[0])
     if key is None or batch != 512:
         return None
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True)
@@ -454,13 +455,14 @@ def pmc_traffic(lbl, batch):
         try:
             pmc = json.load(open(f))
             meta = pmc.get("_meta", {})
-            return {"traffic": int(pmc[key]["hbm_bytes_per_launch"]),
+            name = next(k for k in pmc if k.startswith(key))
+            return {"traffic": int(pmc[name]["hbm_bytes_per_launch"]), "traffic_kernel": name,
                     "traffic_note": ("bytes/launch, rocprofv3 --pmc FETCH_SIZE (x2: gfx950 tallies 128-B reads at 64 B) + WRITE_SIZE in "
                                      "separate passes (tools/profile_round.sh), read from a committed summary"),
                     "traffic_source": {"file": os.path.relpath(f, ROOT), "kernel_source_sha16": meta.get("kernel_source_sha16"),
                                        "git_head": meta.get("git_head"), "current_kernel_source_sha16": cur,
                                        "taken_on_current_kernel_sources": (meta.get("kernel_source_sha16") == cur) if meta else None}}
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, StopIteration):
             continue
     return None
 

@@ -172,6 +172,11 @@ int nfdp_coupling_fwd_chunked_f32(float* x, const float* h, int B, int HW, int C
  * nfdp_coupling_fused_pack from the nine parameter tensors of one coupling network in the reference's layouts:
  * w1 [512,C/2,3,3], scale1/bias1 [512], w2 [512,512(,1,1)], scale2/bias2 [512], w3 [C,512,3,3], bias3 [C], logs3 [C]. */
 int nfdp_coupling_fused_supported(int H, int W, int C, int n_features);
+/* Which image the fused kernels of a geometry read (0: geometry unsupported): 1 = nfdp_coupling_fused_pack / _pack_ex(fold_scales = 1),
+ * 2 = _pack_ex(fold_scales = 2): the 16x16 levels run their GEMMs on v_mfma_f32_16x16x32_bf16 and read 16-row x 32-deep fragments.
+ * nfdp_coupling_fused_bf16 / nfdp_stepflow_fused_bf16 / nfdp_level_fused_bf16 must be handed the kind this returns for their H, W, C;
+ * nfdp_coupling_mlp_bf16 (any image size) reads kind 1. */
+int nfdp_coupling_fused_image_kind(int H, int W, int C);
 size_t nfdp_coupling_fused_packed_bytes(int C);
 int nfdp_coupling_fused_pack(const float* w1, const float* scale1, const float* bias1, const float* w2,
                              const float* scale2, const float* bias2, const float* w3, const float* bias3,

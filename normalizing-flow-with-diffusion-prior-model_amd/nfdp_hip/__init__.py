@@ -489,9 +489,15 @@ def coupling_fused_supported(h: int, w: int, c: int, n_features: int) -> bool:
     return bool(lib().nfdp_coupling_fused_supported(h, w, c, n_features))
 
 
-def coupling_fused_pack(w1, s1, b1, w2, s2, b2, w3, b3, l3, fold: bool = True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """fold=True: the inference image (hidden ActNorm scales folded into the next GEMM's weights); fold=False: the image of the
-    training forward (level_fused_train).  `out`: re-use an existing image buffer."""
+def coupling_fused_image_kind(h: int, w: int, c: int) -> int:
+    """Which inference image the fused kernels of this geometry read: 1 (fold=True) or 2 (fold=2: 16x16x32 fragments); 0 = unsupported."""
+    return int(lib().nfdp_coupling_fused_image_kind(h, w, c))
+
+
+def coupling_fused_pack(w1, s1, b1, w2, s2, b2, w3, b3, l3, fold=True, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fold=True (1): the inference image (hidden ActNorm scales folded into the next GEMM's weights); fold=2: the same in the fragment
+    layout of the 16x16 levels' kernel (coupling_fused_image_kind); fold=False: the image of the training forward (level_fused_train).
+    `out`: re-use an existing image buffer."""
     c = w3.shape[0]
     nbytes = lib().nfdp_coupling_fused_packed_bytes(c)
     packed = out if out is not None and out.numel() == nbytes else torch.empty(nbytes, device=w1.device, dtype=torch.uint8)

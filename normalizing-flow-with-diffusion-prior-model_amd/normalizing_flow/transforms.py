@@ -142,7 +142,7 @@ class AffineCoupling(Transform):
         _, h, w, c = xh.shape
         if not K.coupling_fused_supported(h, w, c, self.n_features):
             return None
-        return self.net.fused_packed()
+        return self.net.fused_packed(K.coupling_fused_image_kind(h, w, c))
 
     def _net_nhwc(self, xh: Tensor) -> Tensor:
         """NN(x_a) -> (log_s | t).  Images larger than the fused flow-step kernels' (which own whole 16x16 / 8x8 / 4x4 images) take

@@ -146,19 +146,23 @@ class CouplingNet(nn.Sequential):
     def fused_ready(self) -> bool:
         return self[0].actnorm.initialized() and self[2].actnorm.initialized()
 
-    def fused_packed(self):
+    def fused_packed(self, kind: int = 1):
         """MFMA-register-image pack of all nine parameter tensors for nfdp_coupling_fused_bf16, rebuilt when any
-        of them changes.  None while a hidden ActNorm still awaits its data-dependent init."""
+        of them changes.  None while a hidden ActNorm still awaits its data-dependent init.  kind: the fragment layout the consuming
+        kernel reads (K.coupling_fused_image_kind for the whole-image kernels; the tiled path reads kind 1); one cached image per kind."""
         c1, c2, zc = self[0], self[2], self[4]
         if not (c1.actnorm.initialized() and c2.actnorm.initialized()):
             return None
         ts = (c1.conv.weight, c1.actnorm.scale, c1.actnorm.bias, c2.conv.weight, c2.actnorm.scale, c2.actnorm.bias,
               zc.weight, zc.bias, zc.logs)
         key = tuple((t.data_ptr(), t._version) for t in ts) + (K.param_epoch(),)
-        if getattr(self, "_fused_key", None) != key:
-            self._fused = K.coupling_fused_pack(*[t.detach().reshape(-1) if t.dim() != 4 else t.detach() for t in ts])
-            self._fused_key = key
-        return self._fused
+        cache = self.__dict__.setdefault("_fused_images", {})
+        hit = cache.get(kind)
+        if hit is None or hit[0] != key:
+            img = K.coupling_fused_pack(*[t.detach().reshape(-1) if t.dim() != 4 else t.detach() for t in ts], fold=kind,
+                                        out=None if hit is None else hit[1])
+            cache[kind] = hit = (key, img)
+        return hit[1]
 
     def mlp_f32_packed(self):
         """The fragment-ordered fp32 image of the network for nfdp_coupling_mlp_f32 (compute="f32"), rebuilt when a parameter changes;

@@ -130,6 +130,45 @@ def test_rowsplit_kernel_bit_identical(C, hw, inverse):
         assert torch.isfinite(outs[1][0]).all()
 
 
+@pytest.mark.parametrize("C", [12, 4])
+@pytest.mark.parametrize("inverse", [False, True])
+@torch.no_grad()
+def test_level0_16x16x32_form_against_32x32x16_form(C, inverse):
+    """The 16x16 levels run their three GEMMs on v_mfma_f32_16x16x32_bf16 (image kind 2: 16-row x 32-deep fragments, hidden channels
+    walked as chan16) - the same bf16 operands and fp32 accumulation as the 32x32x16 kernel, summed in a different order.  The two must
+    agree to fp32-summation-order accuracy where no bf16 rounding of a hidden activation flips, and to bf16 accuracy overall; full and
+    ragged batches; the log-det too."""
+    import ctypes
+    import numpy as np
+    setter = K.lib().nfdp_debug_set_l0_k16
+    setter.argtypes, setter.restype = [ctypes.c_int], None
+    from normalizing_flow.glow import StepFlow
+    from tests.golden.synth import synth_tensor, DEEP
+    flow = StepFlow(C, 512, compute="bf16").to("cuda")
+    flow.load_state_dict({k: torch.from_numpy(np.array(synth_tensor("flows.1." + k, v.shape, 11, DEEP))) for k, v in flow.state_dict().items()})
+    torch.manual_seed(5 + inverse)
+    try:
+        for B in (1, 3, 64):
+            x = torch.randn(B, 16, 16, C, device="cuda")
+            outs = []
+            for k16 in (0, 1):
+                setter(k16)
+                assert K.coupling_fused_image_kind(16, 16, C) == 1 + k16
+                xh = x.clone()
+                ldj = torch.zeros(B, dtype=torch.float64, device="cuda")
+                if inverse:
+                    flow.invert_nhwc_(xh)
+                else:
+                    flow.transform_nhwc_(xh, ldj)
+                outs.append((xh, ldj))
+            assert torch.isfinite(outs[1][0]).all()
+            assert_close(outs[1][0], outs[0][0], 6e-3, f"C={C} B={B} state, 16x16x32 vs 32x32x16")
+            assert_close(outs[1][1], outs[0][1], 6e-3, f"C={C} B={B} ldj")
+            assert not torch.equal(outs[0][0], x)
+    finally:
+        setter(-1)
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 @torch.no_grad()
 def test_level0_eight_wave_form_bit_identical(inverse):
@@ -140,6 +179,9 @@ def test_level0_eight_wave_form_bit_identical(inverse):
     import numpy as np
     setter = K.lib().nfdp_debug_set_l0_waves
     setter.argtypes, setter.restype = [ctypes.c_int], None
+    k16 = K.lib().nfdp_debug_set_l0_k16                      # both forms here are 32x32x16 kernels reading images of kind 1
+    k16.argtypes, k16.restype = [ctypes.c_int], None
+    k16(0)
     from normalizing_flow.glow import StepFlow
     from tests.golden.synth import synth_tensor, DEEP
     flow = StepFlow(12, 512, compute="bf16").to("cuda")
@@ -163,6 +205,7 @@ def test_level0_eight_wave_form_bit_identical(inverse):
             assert torch.isfinite(outs[1][0]).all()
     finally:
         setter(-1)
+        k16(-1)
 
 
 @pytest.mark.parametrize("C,hw,B", [(12, 16, 5), (24, 8, 7), (48, 4, 9), (4, 16, 2), (8, 8, 3), (16, 4, 5)])
