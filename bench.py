@@ -303,7 +303,7 @@ def train_bench(args, rank, world, device, barrier):
                        "optimizer": "nfdp fused clip+Adam (flat buffers)",
                        "activations": "kept" if args.recompute in ("0", 0) else f"hidden activations recomputed in the backward pass, {args.recompute} flows at a time (H:G = per level by spatial size)",
                        "launch": ("hipGraph replay" if world == 1 else "hipGraph replay (forward+backward | all-reduce | optimizer)") if graphed else "eager",
-                       "gradient_allreduce": "in place on the flat gradient buffer (SUM), 32 MiB slices, after backward; 1/world in the clip pass" if world > 1 else "none",
+                       "gradient_allreduce": "in place on the flat gradient buffer (SUM), 32 MiB slices started as each Glow level's gradients become final (eager launches; inside a captured step: after backward); 1/world in the clip pass" if world > 1 else "none",
                        "init": args.init + (f" ({args.init_mode}: nfdp_hip.dist.data_dependent_init)" if args.init == "data" else " (identical on every rank)") + ", then broadcast from rank 0"},
             "loss_bits_per_dim": round(float(loss), 6) if bool(torch.isfinite(loss)) else None,
             "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2)}), flush=True)

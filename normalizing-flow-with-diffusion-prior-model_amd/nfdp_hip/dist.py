@@ -269,22 +269,48 @@ class BucketedGradAllReduce:
         self._handles = []
 
 
+_FLAT_REDUCERS = []          # live FlatGradAllReduce objects: the backward pass tells them which gradients are final (grads_ready)
+
+
+def grads_ready(params, include: bool = True) -> None:
+    """Called by a backward node of a chain model.  include=False (at the START of the node's backward): the gradients of every
+    parameter AFTER `params` in forward order are final - the nodes that produce them ran earlier in the backward pass, and autograd
+    runs AccumulateGrad nodes ahead of everything else that is ready.  include=True (at its END, when the node wrote its parameter
+    gradients into the buffer itself and has joined its side stream): those of `params` too.  normalizing_flow.training.LevelFusedFn
+    .backward calls both per Glow level.  Every live FlatGradAllReduce then starts the collectives of the buffer slices that lie
+    wholly in the final part, while the backward pass of the earlier levels is still running.  No-op without a process group,
+    during hipGraph capture, and for parameters of other optimizers."""
+    if not _FLAT_REDUCERS:
+        return
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return
+    for r in list(_FLAT_REDUCERS):
+        r._suffix_ready(params, include)
+
+
 class FlatGradAllReduce:
-    """Gradient averaging on nfdp_hip.optim.FusedAdam's flat gradient buffer: after backward, `finish()` all-reduces the buffer IN PLACE
-    in a few large slices (default 32 MiB: three collectives for the 88 MB of Glow L3 K16, sized for xGMI's per-link-bound rings)
-    - no hooks, no gather / scatter copies, so the backward launches keep adding parameter gradients straight into the buffer
-    (FusedAdam(direct_grads=True)).  The buffer then holds the SUM over ranks; the 1/world of the average is folded into the
-    optimizer's clip pass (`FusedAdam.grad_scale`, applied where `clip_value_sumsq_kernel` / `adam_step_kernel` read the gradient
-    anyway) instead of a separate pass over the 88 MB.  From construction on, every `optimizer.step()` therefore expects a finish()
-    before it; `remove()` detaches.  The collectives are asynchronous; they are waited for (on the stream) at the end of finish(),
-    before the clips and the Adam launch read the buffer.
+    """Gradient averaging on nfdp_hip.optim.FusedAdam's flat gradient buffer: the buffer is all-reduced IN PLACE in a few large slices
+    (default 32 MiB: three collectives for the 88 MB of Glow L3 K16, sized for xGMI's per-link-bound rings) - no hooks, no gather /
+    scatter copies, so the backward launches keep adding parameter gradients straight into the buffer (FusedAdam(direct_grads=True)).
+    **Overlapped with backward**: the optimizer's parameters are laid out in forward order, so the backward pass finishes them from the
+    end of the buffer; each Glow level reports when its gradients are final (`grads_ready`), and every slice that lies wholly behind
+    that point is started at once - the last level's slice travels while levels 1 and 0 are still in backward.  `finish()`, after
+    backward, starts what is left and waits for all of them (on the stream) before the clips and the Adam launch read the buffer.
+    The buffer then holds the SUM over ranks; the 1/world of the average is folded into the optimizer's clip pass
+    (`FusedAdam.grad_scale`, applied where `clip_value_sumsq_kernel` / `adam_step_kernel` read the gradient anyway) instead of a
+    separate pass over the 88 MB.  From construction on, every `optimizer.step()` therefore expects a finish() before it; `remove()`
+    detaches.  overlap=False: everything in finish().
 
     sync_state: at construction the optimizer's flat parameter buffer, both moment buffers and the (lr, step) pair take rank 0's
     values - replicas built from different seeds or initialised on different batches start identical."""
 
-    def __init__(self, optimizer, bucket_bytes: int = 32 << 20, group=None, sync_state: bool = True):
+    def __init__(self, optimizer, bucket_bytes: int = 32 << 20, group=None, sync_state: bool = True, overlap: bool = True):
         self.opt, self.group = optimizer, group
         self.step_elems = max(1, bucket_bytes // 4)
+        self.overlap = bool(overlap)
+        self._works, self._sent_lo = [], None      # collectives in flight; lowest element already handed to a collective this step
+        self.early_slices = 0                       # slices started before finish() in the last step (diagnostics / tests)
+        self._early = 0
         if self._active():
             self.opt.grad_scale = 1.0 / dist.get_world_size(group)
             if sync_state:
@@ -292,28 +318,71 @@ class FlatGradAllReduce:
                 if n:
                     from . import bump_param_epoch
                     bump_param_epoch()
+            _FLAT_REDUCERS.append(self)
 
     def remove(self) -> None:
         self.opt.grad_scale = 1.0
+        if self in _FLAT_REDUCERS:
+            _FLAT_REDUCERS.remove(self)
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _bounds(self):
+        """Slice boundaries, counted from the END of the buffer (the slice that is final first is a whole one)."""
+        n = self.opt.flat_grad.numel()
+        return list(range(n, 0, -self.step_elems)) + [0]                      # n, n - step, ..., 0
+
+    @torch.no_grad()
+    def _send(self, lo: int, hi: int) -> None:
+        part = self.opt.flat_grad[lo:hi]
+        if dist.get_backend(self.group) == "gloo" and part.is_cuda:      # CPU rehearsal backend
+            host = part.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            part.copy_(host)
+        else:
+            self._works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    @torch.no_grad()
+    def _send_down_to(self, ready_lo: int) -> int:
+        """Start the collectives of every not-yet-sent slice that lies wholly at or above element `ready_lo`; -> slices started."""
+        b = self._bounds()
+        sent_lo = b[0] if self._sent_lo is None else self._sent_lo
+        started = 0
+        for hi, lo in zip(b[:-1], b[1:]):
+            if hi > sent_lo:
+                continue                                                 # already travelling
+            if lo < ready_lo:
+                break
+            self._send(lo, hi)
+            sent_lo = lo
+            started += 1
+        self._sent_lo = sent_lo
+        return started
+
+    def _suffix_ready(self, params, include: bool = True) -> None:
+        if not (self.overlap and self._active()):
+            return
+        flat = self.opt.flat_grad
+        base, n = flat.data_ptr(), flat.numel()
+        los, his = [], []
+        for p in params:
+            g = getattr(p, "grad", None)
+            if g is None or g.data_ptr() < base:
+                continue
+            off = (g.data_ptr() - base) // 4
+            if off < n:
+                los.append(off)
+                his.append(off + g.numel())
+        if los:
+            self._early += self._send_down_to(min(los) if include else max(his))
 
     @torch.no_grad()
     def finish(self) -> None:
         if not self._active():
             return
-        flat = self.opt.flat_grad
-        gloo = dist.get_backend(self.group) == "gloo"
-        works = []
-        # last slices first: backward finishes the last Glow level's gradients first, and they sit at the end of the buffer
-        for lo in reversed(range(0, flat.numel(), self.step_elems)):
-            part = flat[lo:lo + self.step_elems]
-            if gloo and part.is_cuda:                      # CPU rehearsal backend
-                host = part.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
-                part.copy_(host)
-            else:
-                works.append(dist.all_reduce(part, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
+        self._send_down_to(0)
+        for w in self._works:
             w.wait()
+        self._works, self._sent_lo = [], None
+        self.early_slices, self._early = self._early, 0

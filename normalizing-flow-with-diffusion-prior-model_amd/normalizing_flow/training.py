@@ -737,6 +737,8 @@ class LevelFusedFn(Function):
     @staticmethod
     @_side_guarded
     def backward(ctx, dy, dacc):
+        from nfdp_hip import dist as _dist
+        _dist.grads_ready(ctx.params, include=False)      # data parallelism: the later levels' gradient slices can travel now
         if ctx.recompute:
             xpre, ypost, hout = ctx.saved_tensors
             G = ctx.recompute
@@ -828,6 +830,8 @@ class LevelFusedFn(Function):
                 if cf >= 0:
                     grads[P * cf + 11], grads[P * cf + 10] = o[2].view_as(tup[2]), o[3].view_as(tup[3])
         _join_side()
+        if all(g is None for g in grads):                 # every gradient of this level went straight into the optimizer's buffer
+            _dist.grads_ready(ctx.params, include=True)
         dl = None
         if ctx.ldj_dtype is not None and dacc is not None:
             dl = dacc if dacc.dtype == ctx.ldj_dtype else dacc.to(ctx.ldj_dtype)

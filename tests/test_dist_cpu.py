@@ -142,6 +142,63 @@ def test_world2_gloo_bucketed_gradient_allreduce():
     assert auto is False
 
 
+def _overlap_worker(rank, world, port, out):
+    """FlatGradAllReduce overlapped with backward: a chain of five parameter blocks whose gradients become final from the last block
+    backwards (what a Glow backward pass does, level by level); each block reports grads_ready(include=False) when its backward
+    starts and grads_ready(include=True) when it has written its own gradients."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "normalizing-flow-with-diffusion-prior-model_amd")]
+    from nfdp_hip import dist as D
+    from nfdp_hip.optim import FusedAdam
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sizes = [37, 5, 64, 11, 23]                                       # 140 elements, slices of 16 from the end: boundaries 140, 124, ...
+    params = [torch.nn.Parameter(torch.zeros(k)) for k in sizes]
+    opt = FusedAdam(params, lr=1e-3, direct_grads=True)
+    g = torch.Generator().manual_seed(3)
+    grads = [[torch.randn(k, generator=g) for k in sizes] for _ in range(world)]      # every rank knows every rank's gradients
+    want = torch.cat([sum(grads[r][i] for r in range(world)) for i in range(len(sizes))])
+    res = {}
+    for overlap in (True, False):
+        red = D.FlatGradAllReduce(opt, bucket_bytes=64, overlap=overlap)
+        early_seen = []
+        for step in range(2):                                        # two steps: the per-step bookkeeping must reset
+            opt.zero_grad()
+            for i in reversed(range(len(params))):
+                D.grads_ready([params[i]], include=False)
+                with torch.no_grad():
+                    params[i].grad.add_(grads[rank][i])
+                D.grads_ready([params[i]], include=True)
+            red.finish()
+            early_seen.append(red.early_slices)
+            assert torch.allclose(opt.flat_grad, want, atol=1e-6), (overlap, step, float((opt.flat_grad - want).abs().max()))
+        res[overlap] = early_seen
+        red.remove()
+    assert not D._FLAT_REDUCERS
+    if rank == 0:
+        out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_flat_allreduce_overlaps_with_backward():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # 140 elements in slices of 16 from the end = 9 slices; all but the first block's leading slice(s) are started before finish():
+    # after block 1 reports, everything from element 37 up is final -> slices [44, 140) = 6 whole slices; block 0's own report adds the rest
+    assert res[True] == [9, 9], res
+    assert res[False] == [0, 0], res
+
+
 def _init_worker(rank, world, port, out):
     """Replica initialisation (nfdp_hip.dist.broadcast_module / data_dependent_init / merge_moments / FlatGradAllReduce(sync_state)):
     each rank builds its own Glow (its own random 1x1-conv QR factors) and holds its own first batch.  The HIP kernels need a GPU, so
