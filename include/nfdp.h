@@ -148,6 +148,12 @@ int nfdp_conv_pack_weights_ex(const float* w_oihw, void* w_packed, int Cout, int
 int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
                      int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
                      float mul_exp, int relu, int compute, nfdp_stream_t stream);
+/* conv2d(torch.cat((x1, x2), dim=1)) without materialising the concatenation - the U-Net's skip connections
+ * (diffusion_prior/gaussian_diffusion.py:479-486: `torch.cat((x, h.pop()), dim=1)` in front of every up-path ResnetBlock): exact fp32,
+ * both inputs fp32 pixel-strided with 16-byte aligned rows, Cin1 % 8 == 0, Cin2 % 4 == 0; w_packed is the packed weight of the
+ * (Cin1 + Cin2)-channel conv (nfdp_conv_pack_weights, compute NFDP_F32); `add` = bias or null. */
+int nfdp_conv2d_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed, float* y,
+                             int y_ld, int B, int H, int W, int Cout, int K, const float* add, nfdp_stream_t stream);
 
 /* ---------------------------------------------------------------- affine coupling (transforms.py:166-201) */
 /* x: [B,HW,C] flow tensor (x_a = channels [0,C/2), x_b = [C/2,C)); h: NN output [B,HW,C] (log_s | t).
@@ -299,6 +305,12 @@ int nfdp_conv2d_gn_silu_supported(int B, int H, int W, int Cin, int Cout, int K,
 int nfdp_conv2d_gn_silu_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin, int Cout,
                                  int K, const float* bias, int groups, const float* gamma, const float* beta, const float* scale_shift,
                                  int ss_ld, float eps, const float* residual, int res_ld, nfdp_stream_t stream);
+/* The same Block on torch.cat((x1, x2), dim=1) (see nfdp_conv2d_cat_nhwc_f32); supported where nfdp_conv2d_gn_silu_supported(B, H, W,
+ * Cin1 + Cin2, ...) is and Cin1 % 8 == 0, Cin2 % 8 == 0. */
+int nfdp_conv2d_gn_silu_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed,
+                                     float* y, int y_ld, int B, int H, int W, int Cout, int K, const float* bias, int groups,
+                                     const float* gamma, const float* beta, const float* scale_shift, int ss_ld, float eps,
+                                     const float* residual, int res_ld, nfdp_stream_t stream);
 
 /* ---------------------------------------------------------------- diffusion prior: U-Net blocks
  * (diffusion_prior/gaussian_diffusion.py; the convolutions themselves use nfdp_conv2d_nhwc) */

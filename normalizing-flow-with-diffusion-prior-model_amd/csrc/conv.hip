@@ -47,6 +47,10 @@ struct ConvParams {
     const float* gn_res = nullptr;    // residual [npix][gn_res_ld], added after the SiLU; null: none
     int gn_ss_ld = 0, gn_res_ld = 0, gn_groups = 0;
     float gn_eps = 0.f;
+    // two-source input (torch.cat((x, skip), dim=1) without the concatenated tensor, reference gaussian_diffusion.py:479-486): input
+    // channels [0, Cin1) come from x, [Cin1, Cin) from x2 (fp32, row stride x2_ld); Cin1 % 8 == 0.  Default: one source.
+    const void* x2 = nullptr;
+    int x2_ld = 0, Cin1 = 1 << 30;
 };
 
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
@@ -139,7 +143,10 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
                     areg[i] = __builtin_bit_cast(AReg, v);
                 } else {
                     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (ok) v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(P.x) + off);
+                    const bool second = ci >= P.Cin1;             // (two-source input: the 4 channels of a load never straddle Cin1)
+                    const float* src = second ? reinterpret_cast<const float*>(P.x2) + ((long)rp[i] + dy * P.W + dx) * P.x2_ld + (ci - P.Cin1)
+                                              : reinterpret_cast<const float*>(P.x) + off;
+                    if (ok) v = *reinterpret_cast<const float4*>(src);
                     areg[i] = __builtin_bit_cast(AReg, v);
                 }
             }
@@ -164,7 +171,11 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
                     const bool ok = kokj[j] && rp[i] >= 0 && (unsigned)iy < (unsigned)P.H && (unsigned)ix < (unsigned)P.W;
                     const long off = ((long)rp[i] + dy * P.W + dx) * P.x_ld + cij[j];
                     float v = 0.f;
-                    if (ok) v = XBF16 ? (float)reinterpret_cast<const __bf16*>(P.x)[off] : reinterpret_cast<const float*>(P.x)[off];
+                    if (ok) {
+                        if (XBF16) v = (float)reinterpret_cast<const __bf16*>(P.x)[off];
+                        else if (cij[j] >= P.Cin1) v = reinterpret_cast<const float*>(P.x2)[((long)rp[i] + dy * P.W + dx) * P.x2_ld + (cij[j] - P.Cin1)];
+                        else v = reinterpret_cast<const float*>(P.x)[off];
+                    }
                     e[j] = v;
                 }
                 const float4 f = make_float4(e[0], e[1], e[2], e[3]);
@@ -360,6 +371,7 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, q = lane >> 4;
     const float* __restrict__ xg = reinterpret_cast<const float*>(P.x);
+    const float* __restrict__ x2g = reinterpret_cast<const float*>(P.x2);
     const float* __restrict__ wg = reinterpret_cast<const float*>(P.w);
     const int HW = P.H * P.W;
 
@@ -393,6 +405,7 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
         const int tap = k0 / P.Cin, ci = k0 - tap * P.Cin;
         const int dy = tap / P.KW - P.pad, dx = tap - (tap / P.KW) * P.KW - P.pad;
         const bool kok = k0 < P.K;
+        const bool second = kok && ci >= P.Cin1;        // two-source input: this lane's SK_KL channels lie wholly in x2 (Cin1 % 8 == 0)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -403,7 +416,8 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
             const bool ok = kok && pok[j] && (unsigned)y < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
             // always load (from a clamped, valid address) and mask the bits: a "load or zero" select makes hipcc branch
             // around every dword and wait for each one
-            const float* src = xg + (pbase[j] + (ok ? y * P.W + xx : 0)) * P.x_ld + (ok ? ci : 0);
+            const float* src = second ? x2g + (pbase[j] + (ok ? y * P.W + xx : 0)) * P.x2_ld + (ok ? ci - P.Cin1 : 0)
+                                      : xg + (pbase[j] + (ok ? y * P.W + xx : 0)) * P.x_ld + (ok ? ci : 0);
             const unsigned msk = ok ? 0xffffffffu : 0u;
 #pragma unroll
             for (int h = 0; h < SK_KL / 4; ++h) {
@@ -1132,15 +1146,42 @@ extern "C" int nfdp_conv2d_gn_silu_supported(int B, int H, int W, int Cin, int C
     return gn_pixel_tiles(npix, Cout, HW) != 0;
 }
 
+static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
+                               int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
+                               const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld,
+                               nfdp_stream_t stream, const float* x2, int x2_ld, int cin1);
+
 extern "C" int nfdp_conv2d_gn_silu_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
                                             int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
                                             const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld,
                                             nfdp_stream_t stream) {
+    return conv2d_gn_silu_impl(x, x_ld, w_packed, y, y_ld, B, H, W, Cin, Cout, K, bias, groups, gamma, beta, scale_shift, ss_ld, eps,
+                               residual, res_ld, stream, nullptr, 0, 0);
+}
+
+// the same on torch.cat((x1, x2), dim=1) without the concatenated tensor (see nfdp_conv2d_cat_nhwc_f32)
+extern "C" int nfdp_conv2d_gn_silu_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2,
+                                                const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cout, int K,
+                                                const float* bias, int groups, const float* gamma, const float* beta,
+                                                const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld,
+                                                nfdp_stream_t stream) {
+    NFDP_REQUIRE(x1 && x2, NFDP_EINVAL, "conv2d_gn_silu_cat: null pointer");
+    NFDP_REQUIRE(Cin1 > 0 && Cin2 > 0 && Cin1 % 8 == 0 && Cin2 % 8 == 0, NFDP_EUNSUPPORTED,
+                 "conv2d_gn_silu_cat: channel counts %d + %d (multiples of 8)", Cin1, Cin2);
+    NFDP_REQUIRE(x2_ld >= Cin2 && x2_ld % 4 == 0 && ((uintptr_t)x2 % 16) == 0, NFDP_ESHAPE, "conv2d_gn_silu_cat: rows must be 16-byte aligned");
+    return conv2d_gn_silu_impl(x1, x1_ld, w_packed, y, y_ld, B, H, W, Cin1 + Cin2, Cout, K, bias, groups, gamma, beta, scale_shift, ss_ld,
+                               eps, residual, res_ld, stream, x2, x2_ld, Cin1);
+}
+
+static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
+                               int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
+                               const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld,
+                               nfdp_stream_t stream, const float* x2, int x2_ld, int cin1) {
     NFDP_REQUIRE(x && w_packed && y && gamma && beta, NFDP_EINVAL, "conv2d_gn_silu: null pointer");
     NFDP_REQUIRE(nfdp_conv2d_gn_silu_supported(B, H, W, Cin, Cout, K, groups), NFDP_EUNSUPPORTED,
                  "conv2d_gn_silu: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d K=%d groups=%d", B, H, W, Cin, Cout, K, groups);
-    NFDP_REQUIRE(x_ld >= Cin && x_ld % 4 == 0 && y_ld >= Cout && y_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0, NFDP_ESHAPE,
-                 "conv2d_gn_silu: rows must be 16-byte aligned");
+    NFDP_REQUIRE(x_ld >= (x2 ? cin1 : Cin) && x_ld % 4 == 0 && y_ld >= Cout && y_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0,
+                 NFDP_ESHAPE, "conv2d_gn_silu: rows must be 16-byte aligned");
     NFDP_REQUIRE((bias == nullptr || (uintptr_t)bias % 16 == 0) && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0, NFDP_ESHAPE,
                  "conv2d_gn_silu: parameter vectors must be 16-byte aligned");
     NFDP_REQUIRE(scale_shift == nullptr || ss_ld >= 2 * Cout, NFDP_ESHAPE, "conv2d_gn_silu: scale_shift rows shorter than 2*Cout");
@@ -1154,6 +1195,7 @@ extern "C" int nfdp_conv2d_gn_silu_nhwc_f32(const float* x, int x_ld, const void
     P.K = Cin * K * K; P.Kpad = kpad_for(Cin, K, K); P.relu = 0; P.mul_exp = 0.f;
     P.gn_gamma = gamma; P.gn_beta = beta; P.gn_ss = scale_shift; P.gn_ss_ld = ss_ld; P.gn_res = residual; P.gn_res_ld = res_ld;
     P.gn_groups = groups; P.gn_eps = eps;
+    if (x2) { P.x2 = x2; P.x2_ld = x2_ld; P.Cin1 = cin1; }
     P.Nt = (int)cdiv(Cout, 64);
     const int pt = gn_pixel_tiles(npix, Cout, H * W);
     P.Mt = (int)cdiv(npix, 16 * pt);
@@ -1180,13 +1222,37 @@ extern "C" int nfdp_conv2d_gn_silu_nhwc_f32(const float* x, int x_ld, const void
     return NFDP_OK;
 }
 
+static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
+                       int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
+                       float mul_exp, int relu, int compute, nfdp_stream_t stream, const void* x2, int x2_ld, int cin1);
+
 extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
                                 int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
                                 float mul_exp, int relu, int compute, nfdp_stream_t stream) {
+    return conv2d_impl(x, x_dtype, x_ld, w_packed, y, y_dtype, y_ld, B, H, W, Cin, Cout, KH, KW, add, mul, mul_exp, relu, compute, stream,
+                       nullptr, 0, 0);
+}
+
+// conv2d(torch.cat((x1, x2), dim=1)) without the concatenated tensor (the U-Net's skip connections, reference
+// gaussian_diffusion.py:479-486): exact fp32, both inputs fp32 pixel-strided, Cin1 % 8 == 0.
+extern "C" int nfdp_conv2d_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed,
+                                        float* y, int y_ld, int B, int H, int W, int Cout, int K, const float* add, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x1 && x2, NFDP_EINVAL, "conv2d_cat: null pointer");
+    NFDP_REQUIRE(Cin1 > 0 && Cin2 > 0 && Cin1 % 8 == 0 && Cin2 % 4 == 0, NFDP_EUNSUPPORTED,
+                 "conv2d_cat: channel counts %d + %d (first a multiple of 8, second of 4)", Cin1, Cin2);
+    NFDP_REQUIRE(x1_ld >= Cin1 && x2_ld >= Cin2 && x1_ld % 4 == 0 && x2_ld % 4 == 0 && (((uintptr_t)x1 | (uintptr_t)x2) % 16) == 0,
+                 NFDP_ESHAPE, "conv2d_cat: input rows must be 16-byte aligned");
+    return conv2d_impl(x1, NFDP_F32, x1_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin1 + Cin2, Cout, K, K, add, nullptr, 0.f, 0, NFDP_F32,
+                       stream, x2, x2_ld, Cin1);
+}
+
+static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
+                       int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
+                       float mul_exp, int relu, int compute, nfdp_stream_t stream, const void* x2, int x2_ld, int cin1) {
     NFDP_REQUIRE(x && w_packed && y, NFDP_EINVAL, "conv2d: null pointer");
     NFDP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NFDP_ESHAPE, "conv2d: bad shape");
     NFDP_REQUIRE(KH == KW && (KH % 2) == 1 && KH <= 7, NFDP_EUNSUPPORTED, "conv2d: kernel %dx%d (odd square <= 7 only)", KH, KW);
-    NFDP_REQUIRE(x_ld >= Cin && y_ld >= Cout, NFDP_ESHAPE, "conv2d: ld smaller than channel count");
+    NFDP_REQUIRE(x_ld >= (x2 ? cin1 : Cin) && y_ld >= Cout, NFDP_ESHAPE, "conv2d: ld smaller than channel count");
     NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_BF16, NFDP_EINVAL, "conv2d: compute=%d", compute);
     NFDP_REQUIRE((x_dtype == NFDP_F32 || x_dtype == NFDP_BF16) && (y_dtype == NFDP_F32 || y_dtype == NFDP_BF16), NFDP_EINVAL,
                  "conv2d: bad dtype");
@@ -1200,6 +1266,7 @@ extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void
     P.x_ld = x_ld; P.y_ld = y_ld; P.y_bf16 = (y_dtype == NFDP_BF16);
     P.H = H; P.W = W; P.Cin = Cin; P.Cout = Cout; P.KH = KH; P.KW = KW; P.pad = (KH - 1) / 2;
     P.K = Cin * KH * KW; P.Kpad = kpad_for(Cin, KH, KW); P.relu = relu; P.Mt = 0; P.Nt = 0; P.mul_exp = mul_exp;
+    if (x2) { P.x2 = x2; P.x2_ld = x2_ld; P.Cin1 = cin1; }
     const int esz = (x_dtype == NFDP_BF16) ? 2 : 4;
     // vector path: 4 consecutive k stay inside one tap and the 4-element load is naturally aligned
     const bool vec = (Cin % 4 == 0) && (x_ld % 4 == 0) && (((uintptr_t)x) % (4 * esz) == 0);

@@ -89,8 +89,11 @@ class _Conv(nn.Module):
             self._packed, self._key = K.conv_pack(w, compute), key
         return self._packed
 
-    def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None) -> Tensor:
+    def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None, x2: Optional[Tensor] = None) -> Tensor:
+        """x2: the input is torch.cat((xh, x2), dim=channels), read from the two tensors (exact-fp32 inference; K.cat_sources_ok)."""
         c = K.compute_enum(compute)
+        if x2 is not None:
+            return K.conv2d_cat(xh, x2, self.packed(c), self.cout, self.k, add=self.bias)
         return K.conv2d(xh, self.packed(c), self.cout, self.k, add=self.bias, compute=c, out_dtype=K.F32)
 
 
@@ -184,14 +187,15 @@ class Block(nn.Module):
         self.norm = _GroupNormParams(groups, dim_out)
         self.act = _Marker("silu")
 
-    def forward_nhwc(self, xh, scale_shift=None, compute=None, residual=None):
+    def forward_nhwc(self, xh, scale_shift=None, compute=None, residual=None, x2=None):
         cenum = K.compute_enum(compute)
         if cenum == K.F32 and not torch.is_grad_enabled() and \
-                K.conv2d_gn_silu_supported(xh, self.proj.cout, self.proj.k, self.norm.num_groups, self.proj.bias, self.norm.weight, self.norm.bias):
+                K.conv2d_gn_silu_supported(xh, self.proj.cout, self.proj.k, self.norm.num_groups, self.proj.bias, self.norm.weight, self.norm.bias,
+                                           extra_cin=0 if x2 is None else x2.shape[3]):
             # the whole Block as ONE launch: the conv's summed tile is normalised in its epilogue (8x8 / 4x4 / 2x2 stages)
             return K.conv2d_gn_silu(xh, self.proj.packed(cenum), self.proj.cout, self.proj.k, self.proj.bias, self.norm.num_groups,
-                                    self.norm.weight, self.norm.bias, scale_shift, 1e-5, residual)
-        h = self.proj.forward_nhwc(xh, compute)
+                                    self.norm.weight, self.norm.bias, scale_shift, 1e-5, residual, x2=x2)
+        h = self.proj.forward_nhwc(xh, compute, x2=x2)
         return K.groupnorm_silu(h, self.norm.num_groups, self.norm.weight, self.norm.bias, scale_shift, 1e-5, residual)
 
 
@@ -211,8 +215,16 @@ class ResnetBlock(nn.Module):
         ss = scale_shift
         if ss is None and exists(self.mlp) and exists(temb):
             ss = K.linear(temb, self.mlp[1].weight, self.mlp[1].bias, pre_act=1)
-        h = self.block1.forward_nhwc(xh, ss, compute)
-        res = self.res_conv.forward_nhwc(xh, compute) if isinstance(self.res_conv, _Conv) else xh
+        x2 = None
+        if isinstance(xh, tuple):
+            # (x, skip): the reference's torch.cat((x, h.pop()), dim=1) (:479-486).  In exact-fp32 inference the two convs that read it
+            # (block1's 3x3 and the 1x1 res_conv: dim != dim_out here) read the two tensors; otherwise it is materialised.
+            xh, x2 = xh
+            if not (K.compute_enum(compute) == K.F32 and not torch.is_grad_enabled() and isinstance(self.res_conv, _Conv)
+                    and K.cat_sources_ok(xh, x2)):
+                xh, x2 = K.concat_channels(xh, x2), None
+        h = self.block1.forward_nhwc(xh, ss, compute, x2=x2)
+        res = self.res_conv.forward_nhwc(xh, compute, x2=x2) if isinstance(self.res_conv, _Conv) else xh
         return self.block2.forward_nhwc(h, None, compute, residual=res.contiguous())   # h + res folded into block2's epilogue
 
 
@@ -404,14 +416,14 @@ class Unet(_EpochOnApply, nn.Module):
         x = _attn_block_nhwc(self.mid_attn, x, c)
         x = rb(self.mid_block2, x)
         for block1, block2, attn, upsample in self.ups:
-            x = rb(block1, K.concat_channels(x, hs.pop()))
-            x = rb(block2, K.concat_channels(x, hs.pop()))
+            x = rb(block1, (x, hs.pop()))                                # torch.cat((x, h.pop()), dim=1): read from both tensors
+            x = rb(block2, (x, hs.pop()))
             x = _attn_block_nhwc(attn, x, c)
             if isinstance(upsample, nn.Sequential):
                 x = upsample[1].forward_nhwc(K.upsample2x(x), c)         # nearest x2 + 3x3  (:169-173)
             else:
                 x = upsample.forward_nhwc(x, c)
-        x = rb(self.final_res_block, K.concat_channels(x, r))
+        x = rb(self.final_res_block, (x, r))
         return self.final_conv.forward_nhwc(x, c)
 
     def forward(self, x, time, x_self_cond=None):

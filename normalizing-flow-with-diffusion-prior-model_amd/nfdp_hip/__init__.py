@@ -773,19 +773,51 @@ def set_conv_gn_fused(on: bool) -> None:
     _CONV_GN_FUSED = bool(on)
 
 
-def conv2d_gn_silu_supported(xh: torch.Tensor, cout: int, k: int, groups: int, *vectors) -> bool:
-    """The one-launch Block is available for this input (fp32 NHWC, no grad) and these parameter vectors (16-byte aligned)?"""
+def conv2d_gn_silu_supported(xh: torch.Tensor, cout: int, k: int, groups: int, *vectors, extra_cin: int = 0) -> bool:
+    """The one-launch Block is available for this input (fp32 NHWC, no grad) and these parameter vectors (16-byte aligned)?
+    extra_cin: channels of a second source (the input is then the concatenation, see conv2d_gn_silu's x2)."""
     if not (_CONV_GN_FUSED and xh.is_cuda and xh.dtype == torch.float32 and xh.dim() == 4 and xh.stride(3) == 1):
         return False
     b, h, w, cin = xh.shape
+    cin += extra_cin
     if any(v is not None and v.data_ptr() % 16 != 0 for v in vectors) or xh.data_ptr() % 16 != 0 or xh.stride(2) % 4 != 0:
         return False
     return bool(lib().nfdp_conv2d_gn_silu_supported(b, h, w, cin, cout, k, groups))
 
 
+def cat_sources_ok(x1: torch.Tensor, x2: torch.Tensor) -> bool:
+    """Can a conv read torch.cat((x1, x2), dim=-1) from the two tensors (nfdp_conv2d_cat_nhwc_f32 / _gn_silu_cat_)?"""
+    if not (_CONV_CAT and x1.is_cuda and x1.dtype == torch.float32 and x2.dtype == torch.float32 and x1.dim() == 4 and x2.dim() == 4):
+        return False
+    if x1.shape[:3] != x2.shape[:3] or x1.shape[3] % 8 != 0 or x2.shape[3] % 8 != 0 or x1.stride(3) != 1 or x2.stride(3) != 1:
+        return False
+    return all(t.data_ptr() % 16 == 0 and t.stride(2) % 4 == 0 for t in (x1, x2))
+
+
+_CONV_CAT = True
+
+
+def set_conv_cat(on: bool) -> None:
+    """Two-source convs for the U-Net's skip connections (default on); off: concat_channels + the one-source conv (A/B runs, tests)."""
+    global _CONV_CAT
+    _CONV_CAT = bool(on)
+
+
+def conv2d_cat(x1: torch.Tensor, x2: torch.Tensor, packed: torch.Tensor, cout: int, k: int, add=None) -> torch.Tensor:
+    """conv2d(torch.cat((x1, x2), dim=-1)) in exact fp32 without the concatenated tensor; check cat_sources_ok first."""
+    b, h, w, c1 = x1.shape
+    c2 = x2.shape[3]
+    out = torch.empty((b, h, w, cout), device=x1.device, dtype=torch.float32)
+    _call("nfdp_conv2d_cat_nhwc_f32", _ptr(x1), _ld(x1, "conv2d_cat"), c1, _ptr(x2), _ld(x2, "conv2d_cat"), c2, _ptr(packed), _ptr(out), cout,
+          b, h, w, cout, k, _ptr(add), _stream(), label=f"conv2d_cat k{k} {c1}+{c2}->{cout} hw{h}", flops=2.0 * b * h * w * (c1 + c2) * k * k * cout)
+    return out
+
+
 def conv2d_gn_silu(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bias, groups: int, gamma, beta,
-                   scale_shift: Optional[torch.Tensor], eps: float = 1e-5, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Block of the U-Net in one launch (nfdp_conv2d_gn_silu_nhwc_f32); check conv2d_gn_silu_supported first."""
+                   scale_shift: Optional[torch.Tensor], eps: float = 1e-5, residual: Optional[torch.Tensor] = None,
+                   x2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Block of the U-Net in one launch (nfdp_conv2d_gn_silu_nhwc_f32); check conv2d_gn_silu_supported first.  x2: the input is
+    torch.cat((xh, x2), dim=-1), read from the two tensors (cat_sources_ok)."""
     _need(xh, torch.float32, "conv2d_gn_silu")
     b, h, w, cin = xh.shape
     y = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
@@ -798,6 +830,13 @@ def conv2d_gn_silu(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bi
         _need(residual, torch.float32, "conv2d_gn_silu residual"); _dense(residual, "conv2d_gn_silu residual")
         assert residual.shape == y.shape
         res_ld = cout
+    if x2 is not None:
+        c2 = x2.shape[3]
+        _call("nfdp_conv2d_gn_silu_cat_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_gn_silu"), cin, _ptr(x2), _ld(x2, "conv2d_gn_silu"), c2,
+              _ptr(packed), _ptr(y), cout, b, h, w, cout, k, _ptr(bias), groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld,
+              float(eps), _ptr(residual), res_ld, _stream(),
+              label=f"conv_splitk_f32+gn cat k{k} {cin}+{c2}->{cout} hw{h}", flops=2.0 * b * h * w * (cin + c2) * k * k * cout)
+        return y
     _call("nfdp_conv2d_gn_silu_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_gn_silu"), _ptr(packed), _ptr(y), cout, b, h, w, cin, cout, k,
           _ptr(bias), groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, float(eps), _ptr(residual), res_ld, _stream(),
           label=f"conv_splitk_f32+gn k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * k * k * cout)

@@ -430,3 +430,53 @@ def test_block_in_one_launch_matches_conv_then_groupnorm(b, cin, cout, hw, group
     assert_close(fused.permute(0, 3, 1, 2), h, 5e-5, "one-launch Block vs torch")
     assert not K.conv2d_gn_silu_supported(torch.zeros(2, 16, 16, cin, device=DEV), cout, 3, groups)       # 256-pixel images: two launches
     assert not K.conv2d_gn_silu_supported(torch.zeros(8, 8, 8, cin, device=DEV), cout, 3, groups)         # few 64-pixel images: the plain conv's smaller tiles win
+
+
+@pytest.mark.parametrize("b,c1,c2,cout,hw,k", [(64, 64, 64, 64, 16, 3), (64, 128, 64, 128, 8, 3), (64, 128, 128, 128, 4, 3),
+                                              (64, 64, 64, 64, 16, 1), (5, 128, 64, 128, 8, 1), (3, 64, 64, 64, 6, 3)])
+@torch.no_grad()
+def test_two_source_conv_equals_conv_of_the_concatenation(b, c1, c2, cout, hw, k):
+    """nfdp_conv2d_cat_nhwc_f32: conv2d(torch.cat((x1, x2), dim=1)) read from the two tensors (the U-Net's skip connections,
+    gaussian_diffusion.py:479-486) - the same kernels walking the same K order, so identical bits to the conv of the materialised
+    concatenation; also from channel slices of wider tensors, and against torch."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(c1 + hw + k)
+    wide = torch.randn(b, hw, hw, c1 + 8, generator=g).to(DEV)
+    x1 = wide[..., :c1]                                              # a pixel-strided view
+    x2 = torch.randn(b, hw, hw, c2, generator=g).to(DEV)
+    w = (torch.randn(cout, c1 + c2, k, k, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(cout, generator=g).to(DEV)
+    packed = K.conv_pack(w, K.F32)
+    assert K.cat_sources_ok(x1, x2)
+    two = K.conv2d_cat(x1, x2, packed, cout, k, add=bias)
+    one = K.conv2d(K.concat_channels(x1.contiguous(), x2), packed, cout, k, add=bias)
+    assert torch.equal(two, one)
+    ref = F.conv2d(torch.cat((x1, x2), dim=3).permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), bias.cpu().double(), padding=k // 2)
+    assert_close(two.permute(0, 3, 1, 2), ref, 2e-5, "two-source conv vs torch fp64")
+
+
+@torch.no_grad()
+def test_unet_reads_skip_connections_from_both_tensors():
+    """Unet.forward_nhwc in exact fp32: no concat launch is left (every up-path ResnetBlock's 3x3 and 1x1 convs read (x, skip) as two
+    sources, the one-launch Blocks of the 8x8 / 4x4 stages included) and the output equals the run that materialises the
+    concatenations bit for bit, for the three latent-part geometries of the 3x32x32 model."""
+    from diffusion_prior import Unet
+    for ch, size in ((6, 16), (12, 8), (48, 4)):
+        torch.manual_seed(ch)
+        u = Unet(dim=64, dim_mults=(1, 2), channels=ch, resnet_block_groups=8).to(DEV)
+        x = torch.randn(8, size, size, ch, device=DEV)
+        t = torch.randint(0, 1000, (8,), device=DEV)
+        K.start_trace()
+        a = u.forward_nhwc(x, t)
+        labels = [e["label"] for e in K.stop_trace()]
+        assert not any("concat" in lb for lb in labels), labels
+        assert sum("cat" in lb for lb in labels) == 10, labels               # 5 ResnetBlocks x (3x3 conv + 1x1 res_conv)
+        K.set_conv_cat(False)
+        try:
+            K.start_trace()
+            bref = u.forward_nhwc(x, t)
+            labels = [e["label"] for e in K.stop_trace()]
+        finally:
+            K.set_conv_cat(True)
+        assert sum("concat" in lb for lb in labels) == 5
+        assert torch.equal(a, bref), f"{ch}x{size}x{size}"
