@@ -269,7 +269,9 @@ class BucketedGradAllReduce:
         self._handles = []
 
 
-_FLAT_REDUCERS = []          # live FlatGradAllReduce objects: the backward pass tells them which gradients are final (grads_ready)
+import weakref
+
+_FLAT_REDUCERS = weakref.WeakSet()     # live FlatGradAllReduce objects: the backward pass tells them which gradients are final (grads_ready)
 
 
 def grads_ready(params, include: bool = True) -> None:
@@ -318,12 +320,11 @@ class FlatGradAllReduce:
                 if n:
                     from . import bump_param_epoch
                     bump_param_epoch()
-            _FLAT_REDUCERS.append(self)
+            _FLAT_REDUCERS.add(self)
 
     def remove(self) -> None:
         self.opt.grad_scale = 1.0
-        if self in _FLAT_REDUCERS:
-            _FLAT_REDUCERS.remove(self)
+        _FLAT_REDUCERS.discard(self)
 
     def _active(self) -> bool:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
