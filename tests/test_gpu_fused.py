@@ -148,7 +148,7 @@ def test_level0_16x16x32_form_against_32x32x16_form(C, inverse):
     flow.load_state_dict({k: torch.from_numpy(np.array(synth_tensor("flows.1." + k, v.shape, 11, DEEP))) for k, v in flow.state_dict().items()})
     torch.manual_seed(5 + inverse)
     try:
-        for B in (1, 3, 64):
+        for B in (1, 3, 64, 300):                             # 300: more images than CUs - some workgroups own two (TPW = 2)
             x = torch.randn(B, 16, 16, C, device="cuda")
             outs = []
             for k16 in (0, 1):
@@ -208,7 +208,7 @@ def test_level0_eight_wave_form_bit_identical(inverse):
         k16(-1)
 
 
-@pytest.mark.parametrize("C,hw,B", [(12, 16, 5), (24, 8, 7), (48, 4, 9), (4, 16, 2), (8, 8, 3), (16, 4, 5)])
+@pytest.mark.parametrize("C,hw,B", [(12, 16, 5), (12, 16, 300), (24, 8, 7), (48, 4, 9), (4, 16, 2), (4, 16, 257), (8, 8, 3), (16, 4, 5)])
 @pytest.mark.parametrize("inverse", [False, True])
 @torch.no_grad()
 def test_level_launch_bit_identical_to_per_flow_launches(C, hw, B, inverse):
