@@ -15,7 +15,8 @@ from normalizing_flow.glow import _level_tables
 B = int(os.environ.get("NFDP_B", "512"))
 dev = torch.device("cuda", 0)
 lib = ctypes.CDLL(K.LIB_PATH)
-for c, hw, fn in [(12, 16, "nfdp_debug_read_stamps_v")]:
+LEVELS = {"0": (12, 16, "nfdp_debug_read_stamps_v", 8), "1": (24, 8, "nfdp_debug_read_stamps_a", 10), "2": (48, 4, "nfdp_debug_read_stamps_a", 10)}
+for c, hw, fn, END in [LEVELS[k] for k in os.environ.get("NFDP_LEVELS", "0").split(",")]:
     with torch.no_grad():
         flows = []
         for f in range(16):
@@ -48,8 +49,14 @@ for c, hw, fn in [(12, 16, "nfdp_debug_read_stamps_v")]:
             print("   last flow, cycles per phase (median over workgroups): " +
                   ", ".join(f"{n} {np.median(d[:, i]):.0f}" for i, n in enumerate(names)) + f"; flow {np.median(a[:, 7] - a[:, 9]):.0f}", flush=True)
             continue
-        cyc = a[:, 8] - a[:, 0]
-        rt = a[:, 12] - a[:, 4]
+        a = a[(a[:, END] > a[:, 0]) & (a[:, 0] > 0)]
+        if END == 10:                       # row-split levels: 512 / 256 workgroups; keep the rows of this launch only
+            a = a[: (B * hw * hw) // (64 if hw == 8 and os.environ.get("NFDP_RS2_NCT") != "4" else (128 if hw == 8 else 32))]
+        cyc = a[:, END] - a[:, 0]
+        rt = a[:, END + 4] - a[:, 4]
         clk = cyc / rt * 0.1            # GHz
+        t0 = a[:, 4] - a[:, 4].min()
+        print(f"   {len(a)} workgroups; starts (s_memrealtime, 10 ns units after the first): median {np.median(t0):.0f}, max {t0.max()}; "
+              f"ends after the first start: median {np.median(a[:, END + 4] - a[:, 4].min()):.0f}, max {(a[:, END + 4] - a[:, 4].min()).max()}", flush=True)
         print(f"C={c} hw={hw} B={B}: launch+copy {e0.elapsed_time(e1) / 20 * 1e3:.1f} us; per workgroup: cycles median {np.median(cyc):.0f}, "
               f"time median {np.median(rt) * 10:.0f} ns, clock median {np.median(clk):.3f} GHz (min {clk.min():.3f}, max {clk.max():.3f})", flush=True)
