@@ -190,15 +190,24 @@ def cpu_baseline(fsd, psd, L, K, u8, noise, n_bits=5):
         dt512, bpd512 = timed(x[:512]) if x.shape[0] >= 512 else (None, None)
         if dt512 is not None:
             log(f"cpu_baseline: {cores} threads, B=512: {dt512:.2f} s ({512 / dt512:.1f} img/s)")
+        # the best case for the CPU: B = 16 slices (the working set of a slice stays in the cache hierarchy; rounds 1-2 reported this figure)
+        t16 = []
+        for i in range(6):
+            dt, _ = timed(x[16 * i:16 * i + 16])
+            if i >= 1:
+                t16.append(dt)
+        med16 = sorted(t16)[len(t16) // 2]
+        log(f"cpu_baseline: {cores} threads, B=16: median {med16:.2f} s per batch ({16 / med16:.1f} img/s)")
         torch.set_num_threads(1)
         timed(x[:2])                                                    # 1-thread warm-up
         dt1, _ = timed(x[:64])
         log(f"cpu_baseline: 1 thread, B=64: {dt1:.2f} s ({64 / dt1:.1f} img/s)")
         torch.set_num_threads(cores)
     return {"value": round(64 / med, 2), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": (f"B=64 x (3 warm-up + 5 timed, median) on {cores} threads; B=512 x 1; B=64 x 1 on one thread "
+            "sample": (f"B=64 x (3 warm-up + 5 timed, median) on {cores} threads; B=512 x 1; B=16 x (1 + 5, median: the CPU's best case); B=64 x 1 on one thread "
                        f"(fp32, no_grad, torch-CPU oracle = port of trainer.py:154-161)"),
             "images_per_s_b64": round(64 / med, 2),
+            "images_per_s_b16": round(16 / med16, 2),
             "images_per_s_b512": round(512 / dt512, 2) if dt512 else None,
             "images_per_s_b64_1thread": round(64 / dt1, 2),
             "cpu_model": model, "machine_physical_cores": phys, "machine_logical_cpus": logical, "threads": cores,
@@ -206,11 +215,12 @@ def cpu_baseline(fsd, psd, L, K, u8, noise, n_bits=5):
             "bits_per_dim_last_batch": float(bpd)}
 
 
-def train_bench(args, rank, world, device, barrier):
-    """One training step per iteration, written like the reference's loop body (normalizing_flow/trainer.py:152-167)."""
+def train_objects(args, rank, world, device, recompute):
+    """The training step of the reference's loop body (normalizing_flow/trainer.py:152-167) on the HIP training path: returns
+    (train_step, fwd_bwd, opt, reducer).  Shared by `--train` and by the `legs.train*` entries of the default run."""
     import nfdp_hip as KH
     from nfdp_hip.optim import FusedAdam
-    from nfdp_hip.dist import FlatGradAllReduce, max_over_ranks, broadcast_module, data_dependent_init
+    from nfdp_hip.dist import FlatGradAllReduce, broadcast_module, data_dependent_init
     from normalizing_flow import calculate_loss, initialize_with_zeros
     if args.init == "data":
         torch.manual_seed(1000 + rank)         # every replica draws its own 1x1-conv factors, as independent processes would
@@ -218,7 +228,7 @@ def train_bench(args, rank, world, device, barrier):
     _, _, u8_d, noise_d = make_batch(args.batch, rank, device)
     from normalizing_flow import training as _training
     # "G" (every level) or "H:G,H:G" (per level by spatial size, e.g. 16:8)
-    rc = str(args.recompute)
+    rc = str(recompute)
     _training.RECOMPUTE_FLOWS = ({int(k): int(v) for k, v in (kv.split(":") for kv in rc.split(","))} if ":" in rc else int(rc))
     if args.init == "data":
         # utils.py:275-292 for replicas: rank 0 runs the data-dependent pass on its first batch, every rank takes the result
@@ -227,7 +237,6 @@ def train_bench(args, rank, world, device, barrier):
         data_dependent_init(flow, x0, src=0, mode=args.init_mode)
     for m in (flow, prior):                    # replicas start from rank 0's state whatever the initialisation was
         broadcast_module(m, src=0)
-    params = list(flow.parameters()) + list(prior.parameters())
     # direct_grads=True: the backward launches add parameter gradients straight into the flat buffer; no reducer hangs on
     # autograd's AccumulateGrad nodes - FlatGradAllReduce averages the buffer in place after backward
     opt = FusedAdam(clipped=flow.parameters(), unclipped=prior.parameters(), lr=1e-4, clip_value=1, max_norm=1, direct_grads=True)
@@ -251,6 +260,13 @@ def train_bench(args, rank, world, device, barrier):
         opt.step()                             # clip_grad_value_(1) + clip_grad_norm_(1) + Adam, two launches
         return loss
 
+    return train_step, fwd_bwd, opt, reducer
+
+
+def train_bench(args, rank, world, device, barrier):
+    """One training step per iteration, written like the reference's loop body (normalizing_flow/trainer.py:152-167)."""
+    from nfdp_hip.dist import max_over_ranks
+    train_step, fwd_bwd, opt, reducer = train_objects(args, rank, world, device, args.recompute)
     for _ in range(max(args.warmup, 1)):
         loss = train_step()
     # The step is ~1400 kernel launches through the C ABI plus torch's glue: captured once as hipGraphs and replayed, so the host
@@ -424,6 +440,151 @@ def extra_legs(args, flow, prior, u8_d, noise_d, device):
     return legs
 
 
+GLOW_TRAIN_FLOPS_PER_IMAGE = 3 * 4.012e9       # forward + two backward GEMM passes of the coupling networks
+
+
+def glow_fwd_flops(L, K, size, channels, batch, hidden=512):
+    """Coupling-network FLOPs of one Glow forward: per flow and pixel 2 (9 C/2 512 + 512^2 + 9 512 C)."""
+    tot, c, hw = 0.0, channels, size
+    for _ in range(L):
+        c, hw = c * 4, hw // 2
+        tot += K * 2.0 * hw * hw * (9 * (c // 2) * hidden + hidden * hidden + 9 * hidden * c)
+        c //= 2
+    return tot * batch
+
+
+def timed_graph(fn, n, warm=2, graph=True):
+    """seconds per call of `fn` replayed as a hipGraph (side-stream warm-up first, torch's contract for whole-step capture)."""
+    for _ in range(warm):
+        fn()
+    run = fn
+    if graph:
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        run = g.replay
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n
+
+
+def other_config_legs(args, device):
+    """BASELINE configs[2], [4] and [3] in the same process, after the headline: the training step (B = 512, bf16, with and without
+    activation recomputation at the 16x16 level), the CelebA-shape Glow (L5 K16 128x128x3, B = 32) forward / inverse, and the
+    diffusion-prior sampling loop (3 MNIST latent parts, B = 64, T = 1000).  Each entry: ms, a throughput, and `frac` = algorithmic
+    coupling-network / conv FLOPs per second over the dense bf16 MFMA peak.  Budget: about a minute."""
+    import copy
+    import nfdp_hip as KH
+    legs = {}
+    # ---- configs[2]: training step
+    for name, rc in (("train", "0"), ("train_recompute_16:4", "16:4")):
+        try:
+            a = copy.copy(args)
+            a.init, a.init_mode = "synthetic", "rank0"
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            train_step, _, _, _ = train_objects(a, 0, 1, device, rc)
+            for _ in range(2):
+                loss = train_step()
+            from nfdp_hip.graphs import capture_step
+            cap = capture_step(train_step, warmup=1)
+            cap()
+            torch.cuda.synchronize()
+            n = 10
+            t0 = time.perf_counter()
+            for _ in range(n):
+                cap()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            loss = cap.outputs
+            legs[name] = {"ms_per_step": round(dt * 1e3, 3), "images_per_s": round(args.batch / dt, 1), "steps": n, "dtype": args.compute,
+                          "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 2),
+                          "loss_bits_per_dim": round(float(loss), 6) if bool(torch.isfinite(loss)) else None,
+                          "frac": round(GLOW_TRAIN_FLOPS_PER_IMAGE * args.batch / dt / 1e12 / PEAK[args.compute], 4),
+                          "workload": f"Glow L{args.L}K{args.K} 32x32x3 training step (fwd, bits/dim, bwd, both clips, fused Adam), batch {args.batch}, "
+                                      f"hipGraph replay; recompute {rc} (trainer.py:152-167)"}
+            log(f"leg {name}: {legs[name]['ms_per_step']} ms/step, {legs[name]['peak_memory_gib']} GiB")
+            del cap, train_step
+        except Exception as e:                                   # noqa: BLE001 - a leg must not take the headline down
+            legs[name] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"leg {name} failed: {legs[name]['error']}")
+    from normalizing_flow import training as _training
+    _training.RECOMPUTE_FLOWS = 0
+    torch.cuda.empty_cache()
+    with torch.no_grad():
+        # ---- configs[4]: CelebA-shape Glow
+        try:
+            from normalizing_flow import Glow, GaussianPrior
+            from tests.golden.synth import synth_tensor, DEEP
+            Bc = 32
+            flow = Glow(in_channel=3, L=5, K=16, compute=args.compute)
+            prior = GaussianPrior(2 ** 6 * 3)
+            flow.load_state_dict({k: torch.from_numpy(np.array(synth_tensor(k, v.shape, 1, DEEP))) for k, v in flow.state_dict().items()})
+            prior.load_state_dict({k: torch.from_numpy(np.array(synth_tensor(k, v.shape, 2, DEEP))) for k, v in prior.state_dict().items()})
+            flow.to(device); prior.to(device)
+            g = torch.Generator().manual_seed(0)
+            x = ((torch.randint(0, 256, (Bc, 3, 128, 128), generator=g) // 8).float() / 32.0 - 0.5
+                 + torch.rand(Bc, 3, 128, 128, generator=g) / 32.0).to(device)
+            xh = KH.to_nhwc(x).contiguous()
+
+            def fwd():
+                ldj = torch.zeros(Bc, dtype=torch.float64, device=device); logp = torch.zeros(Bc, dtype=torch.float64, device=device)
+                zs = flow.transform_nhwc(xh, ldj, logp)
+                prior.accumulate_log_prob_nhwc(zs[-1], logp)
+                return zs, ldj, logp
+
+            zs, ldj, logp = fwd()
+            bpd = float((-(ldj + logp) / (np.log(2.0) * 128 * 128 * 3) + 5.0).mean())
+            fl = glow_fwd_flops(5, 16, 128, 3, Bc)
+            dt = timed_graph(fwd, 10)
+            lat = [z.contiguous() for z in zs]
+            dti = timed_graph(lambda: flow.invert_nhwc(lat), 10)
+            dts = timed_graph(lambda: flow.invert_nhwc([lat[-1]], temperature=0.7), 10)
+            legs["celeba"] = {"forward_ms": round(dt * 1e3, 3), "inverse_ms": round(dti * 1e3, 3), "sample_ms": round(dts * 1e3, 3),
+                              "images_per_s": round(Bc / dt, 1), "batch": Bc, "dtype": args.compute, "bits_per_dim": round(bpd, 6),
+                              "frac": round(fl / dt / 1e12 / PEAK[args.compute], 4), "frac_inverse": round(fl / dti / 1e12 / PEAK[args.compute], 4),
+                              "workload": "Glow L5 K16 128x128x3 forward+NLL / inverse / sampling inverse (T=0.7), batch 32, hipGraph replay "
+                                          "(BASELINE configs[4] shape; glow.py:172-228)"}
+            log(f"leg celeba: fwd {legs['celeba']['forward_ms']} ms, inverse {legs['celeba']['inverse_ms']} ms")
+            del flow, prior, zs, lat
+        except Exception as e:                                   # noqa: BLE001
+            legs["celeba"] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"leg celeba failed: {legs['celeba']['error']}")
+        torch.cuda.empty_cache()
+        # ---- configs[3]: the diffusion-prior sampling loop
+        try:
+            from diffusion_prior import DiffusionPrior, IdentityFormater
+            Bs, T = 64, 1000
+            fmt = IdentityFormater(3, 1, 32)
+            shapes = fmt.get_input_shapes()
+            dp = DiffusionPrior(latent_formater=fmt, unet_kwargs=dict(dim=64, dim_mults=(1, 2), resnet_block_groups=8),
+                                diffusion_kwargs=dict(timesteps=T, sampling_timesteps=T, loss_type="l2", beta_schedule="cosine"),
+                                image_sizes=[int(sh[1]) for sh in shapes], latent_channels=[int(sh[0]) for sh in shapes])
+            dp.concurrent_parts = True
+            dp.sample_latents(Bs)                     # captures the per-part step graphs / creates the streams
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            zs = dp.sample_latents(Bs)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            legs["sample_latents"] = {"seconds": round(dt, 4), "ms_per_reverse_step": round(dt / T * 1e3, 4), "latent_sets_per_s": round(Bs / dt, 2),
+                                      "batch": Bs, "timesteps": T, "dtype": "f32", "finite": bool(all(torch.isfinite(z).all() for z in zs)),
+                                      "workload": "DiffusionPrior.sample_latents: 3 MNIST latent parts (2x16x16, 4x8x8, 16x4x4), U-Net dim 64 mults "
+                                                  "[1,2] groups 8, T = 1000 p_sample steps per part, one captured step graph and stream per part "
+                                                  "(BASELINE configs[3]; gaussian_diffusion.py:717-733, model.py:121-134)"}
+            log(f"leg sample_latents: {legs['sample_latents']['seconds']} s")
+        except Exception as e:                                   # noqa: BLE001
+            legs["sample_latents"] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"leg sample_latents failed: {legs['sample_latents']['error']}")
+    torch.cuda.empty_cache()
+    return legs
+
+
 def kernel_source_sha16():
     """sha256 (first 16 hex digits) over the fused flow-step kernel sources: stamps a PMC summary with the code it was taken on."""
     import hashlib
@@ -494,6 +655,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the inverse / sampling / other-precision legs of the default run")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the training / CelebA-shape / diffusion-sampling legs (BASELINE configs[2..4])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -649,6 +811,9 @@ def main():
             res["roofline"] = roofline
         if world == 1 and not args.no_legs:
             res["legs"] = extra_legs(args, flow, prior, u8_d, noise_d, device)
+            if not args.no_config_legs:
+                del flow, prior
+                res["legs"].update(other_config_legs(args, device))
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(fsd, psd, args.L, args.K, u8, noise)
         print(json.dumps(res), flush=True)
