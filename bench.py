@@ -675,6 +675,16 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        # first contact with RCCL outside any timed region and outside any capture: communicator set-up (ring / tree construction
+        # over xGMI) happens in the first collective
+        t0 = time.perf_counter()
+        w = torch.ones(1, device=device)
+        dist.all_reduce(w)
+        torch.cuda.synchronize()
+        assert int(w.item()) == world, f"warm-up all-reduce returned {float(w)} on a world of {world}"
+        if rank == 0:
+            log(f"{backend} warm-up all-reduce over {world} ranks: {time.perf_counter() - t0:.2f} s")
 
     import nfdp_hip as KH
     log(f"rank {rank}/{world}: building Glow L{args.L}K{args.K} ({args.compute}) and the synthetic batch")

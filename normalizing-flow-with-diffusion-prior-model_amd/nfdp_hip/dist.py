@@ -274,20 +274,28 @@ import weakref
 _FLAT_REDUCERS = weakref.WeakSet()     # live FlatGradAllReduce objects: the backward pass tells them which gradients are final (grads_ready)
 
 
-def grads_ready(params, include: bool = True) -> None:
+def grads_ready(params, include: bool = True, producer_streams=()) -> None:
     """Called by a backward node of a chain model.  include=False (at the START of the node's backward): the gradients of every
     parameter AFTER `params` in forward order are final - the nodes that produce them ran earlier in the backward pass, and autograd
     runs AccumulateGrad nodes ahead of everything else that is ready.  include=True (at its END, when the node wrote its parameter
     gradients into the buffer itself and has joined its side stream): those of `params` too.  normalizing_flow.training.LevelFusedFn
     .backward calls both per Glow level.  Every live FlatGradAllReduce then starts the collectives of the buffer slices that lie
     wholly in the final part, while the backward pass of the earlier levels is still running.  No-op without a process group,
-    during hipGraph capture, and for parameters of other optimizers."""
+    during hipGraph capture, and for parameters of other optimizers.
+    producer_streams: HIP streams other than the current one that wrote into the gradients being reported (the weight-gradient side
+    stream of normalizing_flow.training).  The caller has joined them already (current stream waits on them); the reducer does not rely
+    on that: before it hands a slice to the collective it records an event on each of them and makes the current stream wait for it, so
+    the dependency RCCL's stream inherits from the current stream provably covers every producer."""
     if not _FLAT_REDUCERS:
         return
     if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
         return
     for r in list(_FLAT_REDUCERS):
-        r._suffix_ready(params, include)
+        r._producers = tuple(producer_streams)
+        try:
+            r._suffix_ready(params, include)
+        finally:
+            r._producers = ()
 
 
 class FlatGradAllReduce:
@@ -313,6 +321,7 @@ class FlatGradAllReduce:
         self._works, self._sent_lo = [], None      # collectives in flight; lowest element already handed to a collective this step
         self.early_slices = 0                       # slices started before finish() in the last step (diagnostics / tests)
         self._early = 0
+        self._producers = ()                        # streams named by the grads_ready call in progress
         if self._active():
             self.opt.grad_scale = 1.0 / dist.get_world_size(group)
             if sync_state:
@@ -337,6 +346,15 @@ class FlatGradAllReduce:
     @torch.no_grad()
     def _send(self, lo: int, hi: int) -> None:
         part = self.opt.flat_grad[lo:hi]
+        if part.is_cuda:
+            # explicit ordering: every stream that produced these gradients -> the current stream -> (torch's ProcessGroupNCCL makes its
+            # own stream wait for the current stream at the call) the collective
+            cur = torch.cuda.current_stream(part.device)
+            for st in self._producers:
+                if st is not None and st != cur:
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    cur.wait_event(ev)
         if dist.get_backend(self.group) == "gloo" and part.is_cuda:      # CPU rehearsal backend
             host = part.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)

@@ -831,7 +831,7 @@ class LevelFusedFn(Function):
                     grads[P * cf + 11], grads[P * cf + 10] = o[2].view_as(tup[2]), o[3].view_as(tup[3])
         _join_side()
         if all(g is None for g in grads):                 # every gradient of this level went straight into the optimizer's buffer
-            _dist.grads_ready(ctx.params, include=True)
+            _dist.grads_ready(ctx.params, include=True, producer_streams=tuple(_side_streams.values()))
         dl = None
         if ctx.ldj_dtype is not None and dacc is not None:
             dl = dacc if dacc.dtype == ctx.ldj_dtype else dacc.to(ctx.ldj_dtype)

@@ -182,6 +182,80 @@ def _overlap_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _early_slice_property_worker(rank, world, port, out):
+    """Property of FlatGradAllReduce._send_down_to: whatever the parameter sizes, the slice size and the order of the reports, a slice is
+    handed to a collective only when EVERY parameter it overlaps has had its grads_ready(include=True) (or lies behind a reporting
+    node's include=False point), and after finish() every element has been sent exactly once."""
+    import sys, random
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "normalizing-flow-with-diffusion-prior-model_amd")]
+    from nfdp_hip import dist as D
+    from nfdp_hip.optim import FusedAdam
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rnd = random.Random(11)                                          # the same sequence on every rank
+    trials = 0
+    for trial in range(12):
+        sizes = [rnd.randint(1, 70) for _ in range(rnd.randint(2, 9))]
+        params = [torch.nn.Parameter(torch.zeros(k)) for k in sizes]
+        opt = FusedAdam(params, lr=1e-3, direct_grads=True)
+        red = D.FlatGradAllReduce(opt, bucket_bytes=4 * rnd.randint(3, 50), overlap=True)
+        base = opt.flat_grad.data_ptr()
+        span = [((p.grad.data_ptr() - base) // 4, (p.grad.data_ptr() - base) // 4 + p.numel()) for p in params]
+        n = opt.flat_grad.numel()
+        # nodes = runs of consecutive parameters (a Glow level owns several), reporting from the last node backwards
+        cuts = sorted(rnd.sample(range(1, len(params)), rnd.randint(0, len(params) - 1))) if len(params) > 1 else []
+        nodes = [list(range(a, b)) for a, b in zip([0] + cuts, cuts + [len(params)])]
+        final = set()                                                 # parameters whose gradient is final
+        sent = []
+        real_send = red._send
+
+        def spy(lo, hi):
+            for i, (a, b) in enumerate(span):
+                if a < hi and lo < b:
+                    assert i in final, (trial, "slice", (lo, hi), "overlaps parameter", i, span[i], "not reported final", sorted(final))
+            sent.append((lo, hi))
+            real_send(lo, hi)
+
+        red._send = spy
+        for step in range(2):
+            final.clear(); sent.clear()
+            opt.zero_grad()
+            for node in reversed(nodes):
+                # at the start of a node's backward everything behind it is final (those nodes ran before)
+                D.grads_ready([params[i] for i in node], include=False)
+                with torch.no_grad():
+                    for i in node:
+                        params[i].grad.add_(float(rank + 1))
+                final.update(node)
+                D.grads_ready([params[i] for i in node], include=True)
+            final.update(range(len(params)))
+            red.finish()
+            cover = sorted(sent)
+            assert cover[0][0] == 0 and cover[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover, cover[1:])), cover
+            assert torch.allclose(opt.flat_grad, torch.full((n,), float(sum(r + 1 for r in range(world)))))
+        red.remove()
+        trials += 1
+    if rank == 0:
+        out.put(trials)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_early_slices_never_contain_an_unreported_parameter():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_early_slice_property_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    trials = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert trials == 12
+
+
 def test_world2_gloo_flat_allreduce_overlaps_with_backward():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

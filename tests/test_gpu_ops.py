@@ -83,6 +83,39 @@ def test_actnorm_reference_unittest():
     assert logdet.dtype == torch.float32 and torch.isfinite(logdet).all()
 
 
+def test_invconv_reference_unittest():
+    """tests/transformations.py:45-65 of the reference, 1:1: `TestInvConv2d` - x ~ N(0, 1) of shape [32, 3, 28, 28], a freshly constructed
+    layer (random orthogonal weight, transforms.py:112-114), fp32 accumulators, ||invert(transform(x)) - x||_2 < EPS = 1e-3."""
+    from normalizing_flow import InvConv2d
+    x = torch.randn(32, 3, 28, 28, device=DEV)
+    f = InvConv2d(in_channels=3).to(DEV)
+    logdet, logp = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    y, logdet, logp = f.transform(x, logdet, logp)
+    inv_y = f.invert(y)
+    assert x.size() == y.size()
+    assert (inv_y - x).norm() < 1e-3
+    assert logdet.dtype == torch.float32 and torch.isfinite(logdet).all()
+
+
+def test_affine_coupling_reference_unittest():
+    """tests/transformations.py:68-86 of the reference, 1:1: `TestAffCoupling` - x ~ N(0, 1) of shape [32, 4, 28, 28], a freshly constructed
+    AffineCoupling(4) (its ZeroConv2d is zero, utils.py:17-44: log_s = t = 0, s = sigmoid(2)), fp32 accumulators,
+    ||invert(transform(x)) - x||_2 < EPS = 1e-3.  28x28 is outside the fused kernels' table: the per-op path."""
+    from normalizing_flow import AffineCoupling
+    x = torch.randn(32, 4, 28, 28, device=DEV)
+    f = AffineCoupling(4).to(DEV)
+    logdet, logp = torch.zeros(32, device=DEV), torch.zeros(32, device=DEV)
+    y, logdet, logp = f.transform(x, logdet, logp)
+    inv_y = f.invert(y)
+    assert x.size() == y.size() == inv_y.size()
+    assert (inv_y - x).norm() < 1e-3
+    # what the zero-initialised network implies (transforms.py:179-185): x_a passes, x_b is scaled by sigmoid(2), log-det = 2 * 28 * 28 * log(s + 1e-6)
+    s = 1.0 / (1.0 + np.exp(-2.0))
+    assert torch.equal(y[:, :2], x[:, :2])
+    assert (y[:, 2:] - x[:, 2:] * s).abs().max() < 1e-6
+    assert (logdet - 2 * 28 * 28 * np.log(s + 1e-6)).abs().max() < 1e-2
+
+
 @pytest.mark.parametrize("c", [4, 12, 48])
 def test_invconv(ops, c):
     from normalizing_flow import InvConv2d
