@@ -44,6 +44,7 @@ for c, hw, fn, END in [LEVELS[k] for k in os.environ.get("NFDP_LEVELS", "0").spl
         assert f(ctypes.addressof(buf)) == 0
         a = np.frombuffer(buf, dtype=np.uint64).reshape(512, 16).astype(np.int64)
         if os.environ.get("NFDP_PHASES"):       # full -DNFDP_FUSED_STAMPS build: stamps 1..7 are those of the LAST flow of the launch
+            a = a[(a[:, 9] > 0) & (a[:, 7] > a[:, 9])]                  # the workgroups this launch stamped
             names = ["head", "im2col", "GEMM1", "GEMM2/3", "tap sums", "coupling+ldj"]
             d = np.diff(a[:, [9, 2, 3, 4, 5, 6, 7]], axis=1)
             print("   last flow, cycles per phase (median over workgroups): " +
