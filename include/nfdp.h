@@ -164,6 +164,13 @@ int nfdp_conv2d_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* 
 int nfdp_coupling_fwd_f32(float* x, const float* h, int B, int HW, int C, double* ldj, const float* ldj_const,
                           nfdp_stream_t stream);
 int nfdp_coupling_inv_f32(float* y, const float* h, int B, int HW, int C, nfdp_stream_t stream);
+/* The narrow 3x3 output conv's tap shift-sum (nfdp_tap_shift_sum_f32) and the coupling (nfdp_coupling_fwd_f32 / _inv_f32) in one pass:
+ * T [B*H*W][9*C] tap contributions (n = tap*C + co); h = (sum of taps + add) * exp(f * mul) is consumed at once, x's second channel
+ * half is updated in place; forward: ldj[b] (+ ldj_const[0..1]) += sum log(s + 1e-6).  ws: nfdp_tap_coupling_ws_bytes(B, H*W, C) bytes
+ * when that is non-zero and ldj is given.  Replaces transforms.py:179-185 / :196-200 after utils.py:43-44 (reference). */
+size_t nfdp_tap_coupling_ws_bytes(int B, int HW, int C);
+int nfdp_tap_coupling_f32(float* x, const float* T, int B, int H, int W, int C, const float* add, const float* mul, float f, double* ldj,
+                          const float* ldj_const, void* ws, int inverse, nfdp_stream_t stream);
 /* coupling_fwd for large images at small batch: the pixels of a sample spread over several workgroups, chunk sums of the log-det in
  * ws (nfdp_coupling_chunked_ws_bytes; 0 = use nfdp_coupling_fwd_f32), added to ldj in chunk order by a second launch. */
 size_t nfdp_coupling_chunked_ws_bytes(int B, int HW, int C);

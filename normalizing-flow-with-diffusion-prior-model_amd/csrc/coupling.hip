@@ -94,6 +94,71 @@ __global__ void __launch_bounds__(kBlock) coupling_chunk_kernel(float* __restric
     }
 }
 
+// The ZeroConv2d's tap shift-sum (backward.hip: tap_shift_sum_kernel) and the coupling in ONE pass: T [B*H*W][9*C] holds the tap
+// contributions of the narrow 3x3 output conv (n = tap*C + co), and
+//   h[p][co] = (sum_tap T[p + d(tap)][tap*C + co] + add[co]) * exp(f * mul[co])   (same expression and tap order: bit-identical)
+// is consumed at once - (log_s | t) never goes to memory, two launches and a pass over h less per flow (the tiled path of images larger
+// than the whole-image kernels' 16x16).  A thread owns VEC consecutive channel pairs of one pixel: VEC-wide loads of T (16 bytes for
+// C % 8 == 0).  Grid (B, chunks): chunk sums of log(s + 1e-6) go to part[b][chunk] when gridDim.y > 1 (coupling_ldj_finish_kernel adds
+// them in chunk order), else straight into ldj[b].
+template <bool INV, int VEC>
+__global__ void __launch_bounds__(kBlock) tap_coupling_kernel(float* __restrict__ x, const float* __restrict__ T, int H, int W, int C,
+                                                              const float* __restrict__ add, const float* __restrict__ mul, float f,
+                                                              double* __restrict__ ldj, const float* __restrict__ ldj_const,
+                                                              double* __restrict__ part) {
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ double red[kBlock / 64];
+    const int Ch = C >> 1, G = Ch / VEC, HW = H * W, ld = 9 * C;
+    const long base = (long)blockIdx.x * HW;
+    const int n = HW * G;
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int e0 = blockIdx.y * per, e1 = (e0 + per) < n ? (e0 + per) : n;
+    double acc = 0.0;
+    for (int e = e0 + threadIdx.x; e < e1; e += kBlock) {
+        const int p = e / G, c = (e - p * G) * VEC;
+        const int xx = p % W, y = p / W;
+        float a_ls[VEC], a_t[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { a_ls[j] = 0.f; a_t[j] = 0.f; }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const bool ok = (unsigned)(y + dy) < (unsigned)H && (unsigned)(xx + dx) < (unsigned)W;
+            // (an out-of-image tap reads the pixel's own row and adds +0: x + 0 == x bit for bit, the sums start from +0)
+            const float* row = T + (base + (ok ? p + (long)dy * W + dx : p)) * ld + tap * C + c;
+            const vec_t u = *reinterpret_cast<const vec_t*>(row), v = *reinterpret_cast<const vec_t*>(row + Ch);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { a_ls[j] += ok ? u[j] : 0.f; a_t[j] += ok ? v[j] : 0.f; }
+        }
+        float* xb = x + (base + p) * C + Ch + c;
+        vec_t xv = *reinterpret_cast<const vec_t*>(xb);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float log_s = __fmul_rn(__fadd_rn(a_ls[j], add[c + j]), expf(__fmul_rn(f, mul[c + j])));
+            const float t = __fmul_rn(__fadd_rn(a_t[j], add[Ch + c + j]), expf(__fmul_rn(f, mul[Ch + c + j])));
+            const float s = sigmoid_p2(log_s);
+            if (!INV) {
+                xv[j] = __fmul_rn(__fadd_rn(xv[j], t), s);
+                acc += (double)logf(__fadd_rn(s, 1e-6f));
+            } else {
+                xv[j] = __fsub_rn(__fdiv_rn(xv[j], __fadd_rn(s, 1e-6f)), t);
+            }
+        }
+        *reinterpret_cast<vec_t*>(xb) = xv;
+    }
+    if (!INV && (ldj || part)) {
+        const double s = block_sum_d(acc, red);
+        if (threadIdx.x == 0) {
+            if (part) part[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = s;
+            else {
+                double v = ldj[blockIdx.x];
+                if (ldj_const) v = (v + (double)ldj_const[0]) + (double)ldj_const[1];
+                ldj[blockIdx.x] = v + s;
+            }
+        }
+    }
+}
+
 __global__ void coupling_ldj_finish_kernel(double* __restrict__ ldj, int B, const double* __restrict__ part, int nch,
                                            const float* __restrict__ ldj_const) {
     const int b = blockIdx.x * kBlock + threadIdx.x;
@@ -233,6 +298,45 @@ extern "C" int nfdp_coupling_fwd_chunked_f32(float* x, const float* h, int B, in
         hipLaunchKernelGGL(coupling_ldj_finish_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, as_stream(stream), ldj, B,
                            reinterpret_cast<const double*>(ws), nch, ldj_const);
     NFDP_CHECK_LAUNCH("coupling_fwd_chunked");
+    return NFDP_OK;
+}
+
+// chunks per sample of the tap+coupling pass: ~1024 thread-items (pixel x channel group) per workgroup, one chunk for small images
+static int tap_vec(int C) { return (C / 2) % 4 == 0 ? 4 : ((C / 2) % 2 == 0 ? 2 : 1); }
+static int tap_chunks(int B, int HW, int C) {
+    const long n = (long)HW * ((C / 2) / tap_vec(C));
+    if (B <= 0 || n <= 2048) return 1;
+    long nch = (n + 1023) / 1024;
+    return (int)(nch > 256 ? 256 : nch);
+}
+
+extern "C" size_t nfdp_tap_coupling_ws_bytes(int B, int HW, int C) {
+    const int nch = tap_chunks(B, HW, C);
+    return nch > 1 ? (size_t)B * nch * sizeof(double) : 0;
+}
+
+extern "C" int nfdp_tap_coupling_f32(float* x, const float* T, int B, int H, int W, int C, const float* add, const float* mul, float f,
+                                     double* ldj, const float* ldj_const, void* ws, int inverse, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && T && add && mul, NFDP_EINVAL, "tap_coupling: null pointer");
+    NFDP_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && C % 2 == 0, NFDP_ESHAPE, "tap_coupling: bad shape");
+    if (B == 0) return NFDP_OK;
+    const int nch = tap_chunks(B, H * W, C), vec = tap_vec(C);
+    NFDP_REQUIRE(vec == 1 || ((((uintptr_t)x | (uintptr_t)T) & 15) == 0), NFDP_ESHAPE, "tap_coupling: tensors must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    double* part = nullptr;
+    if (!inverse) {
+        NFDP_REQUIRE(nch == 1 || ws || !ldj, NFDP_EINVAL, "tap_coupling: needs nfdp_tap_coupling_ws_bytes of workspace");
+        part = (nch > 1 && ldj) ? reinterpret_cast<double*>(ws) : nullptr;
+    }
+    double* l = inverse ? nullptr : ldj;
+    const float* lc = inverse ? nullptr : ldj_const;
+#define NFDP_TC(INVV, V) hipLaunchKernelGGL((tap_coupling_kernel<INVV, V>), dim3(B, nch), dim3(kBlock), 0, s, x, T, H, W, C, add, mul, f, l, lc, part)
+    if (inverse) { if (vec == 4) NFDP_TC(true, 4); else if (vec == 2) NFDP_TC(true, 2); else NFDP_TC(true, 1); }
+    else { if (vec == 4) NFDP_TC(false, 4); else if (vec == 2) NFDP_TC(false, 2); else NFDP_TC(false, 1); }
+#undef NFDP_TC
+    if (part)
+        hipLaunchKernelGGL(coupling_ldj_finish_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ldj, B, part, nch, ldj_const);
+    NFDP_CHECK_LAUNCH("tap_coupling");
     return NFDP_OK;
 }
 

@@ -355,14 +355,15 @@ def actnorm_invconv_fwd(xh, scale, bias, w, out=None):
     _need(xh, torch.float32, "actnorm_invconv_fwd"); _dense(xh, "actnorm_invconv_fwd")
     out = torch.empty_like(xh) if out is None else out
     c = xh.shape[-1]
-    if c >= _WIDE_C and c % 8 == 0:
+    if c >= _WIDE_C and c % 8 == 0 and c not in _FLOW_HEAD_C:
         return _mfma_1x1(actnorm_fwd(xh, scale, bias), w, out)
     _call("nfdp_actnorm_invconv_fwd_f32", _ptr(xh), _ptr(out), xh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(w),
           _stream(), label=f"pixel_linear_kernel<{c},pre_affine>", flops=2.0 * xh.numel() * c, nbytes=8.0 * xh.numel())
     return out
 
 
-_FLOW_HEAD_C = (4, 8, 12, 16, 24, 48)
+_FLOW_HEAD_C = (4, 8, 12, 16, 24, 32, 48, 64, 96)      # templated instances of pixel_linear.hip that beat the MFMA route (C = 192: 130 us
+                                                        # for 512 pixels against 37 us for ActNorm + pack + exact-fp32 MFMA conv)
 
 
 def flow_head_fwd(xh, scale, bias, w, logabsdet, out=None):
@@ -388,7 +389,7 @@ def invconv_actnorm_inv(yh, scale, bias, winv, out=None):
     _need(yh, torch.float32, "invconv_actnorm_inv"); _dense(yh, "invconv_actnorm_inv")
     out = torch.empty_like(yh) if out is None else out
     c = yh.shape[-1]
-    if c >= _WIDE_C and c % 8 == 0:
+    if c >= _WIDE_C and c % 8 == 0 and c not in _FLOW_HEAD_C:
         _mfma_1x1(yh, winv, out)
         return actnorm_inv(out, scale, bias, out=out)
     _call("nfdp_invconv_actnorm_inv_f32", _ptr(yh), _ptr(out), yh.numel() // c, c, _ptr(scale), _ptr(bias), _ptr(winv),
@@ -477,6 +478,24 @@ def coupling_fwd(xh, hh, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.
         return
     _call("nfdp_coupling_fwd_f32", _ptr(xh), _ptr(hh), b, h * w, c, _ptr(ldj), _ptr(ldj_const), _stream(),
           label="coupling_kernel<fwd>", nbytes=4.0 * xh.numel() * 2)
+
+
+def tap_coupling(xh, t, add, mul, mul_exp: float, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.Tensor], inverse: bool) -> None:
+    """Tap shift-sum of the ZeroConv2d's tap contributions `t` [B,H,W,9*C] + affine coupling on xh [B,H,W,C] in place, one pass."""
+    _dense(xh, "tap_coupling"); _dense(t, "tap_coupling")
+    _need(xh, torch.float32, "tap_coupling"); _need(t, torch.float32, "tap_coupling")
+    b, h, w, c = xh.shape
+    if t.shape[-1] != 9 * c:
+        raise ValueError(f"tap_coupling: {t.shape[-1]} tap contributions for {c} channels")
+    ws = None
+    if not inverse and ldj is not None:
+        _need(ldj, torch.float64, "tap_coupling ldj")
+        nbytes = lib().nfdp_tap_coupling_ws_bytes(b, h * w, c)
+        if nbytes:
+            ws = torch.empty(nbytes, device=xh.device, dtype=torch.uint8)
+    _call("nfdp_tap_coupling_f32", _ptr(xh), _ptr(t), b, h, w, c, _ptr(add), _ptr(mul), float(mul_exp), _ptr(None if inverse else ldj),
+          _ptr(None if inverse else ldj_const), _ptr(ws), int(inverse), _stream(),
+          label=f"tap_coupling<{'inv' if inverse else 'fwd'}>", nbytes=4.0 * (t.numel() + xh.numel()))
 
 
 def coupling_inv(yh, hh):
@@ -1453,9 +1472,11 @@ def pack_taps(w_oihw: torch.Tensor, compute: int) -> torch.Tensor:
 
 
 def conv3x3_narrow(xh: torch.Tensor, w_oihw: torch.Tensor, *, add=None, mul=None, mul_exp: float = 0.0, relu: bool = False,
-                   compute: int = F32, packed_taps: Optional[torch.Tensor] = None, co: Optional[int] = None) -> torch.Tensor:
+                   compute: int = F32, packed_taps: Optional[torch.Tensor] = None, co: Optional[int] = None,
+                   return_taps: bool = False) -> torch.Tensor:
     """3x3 'same' conv with Cin >> Cout as a pointwise GEMM to the 9*Cout tap contributions (one wide, fast 1x1 conv)
-    followed by the tap shift-sum with the conv kernel's epilogue act((acc + add) * exp(mul_exp * mul))."""
+    followed by the tap shift-sum with the conv kernel's epilogue act((acc + add) * exp(mul_exp * mul)).
+    return_taps: stop after the GEMM and return T [B,H,W,9*Cout] (for tap_coupling)."""
     if w_oihw is not None:
         co, ci, k, _ = w_oihw.shape
         if k != 3:
@@ -1464,6 +1485,8 @@ def conv3x3_narrow(xh: torch.Tensor, w_oihw: torch.Tensor, *, add=None, mul=None
     if packed_taps is None:
         packed_taps = pack_taps(w_oihw, compute)
     t = conv2d(xh, packed_taps, 9 * co, 1, compute=compute, out_dtype=F32)
+    if return_taps:
+        return t
     out = torch.empty((b, h, w, co), device=xh.device, dtype=torch.float32)
     _call("nfdp_tap_shift_sum_f32", _ptr(t), _ptr(out), b, h, w, co, _ptr(add), _ptr(mul), float(mul_exp), int(relu), _stream())
     return out
@@ -1503,7 +1526,7 @@ def coupling_mlp_supported(c: int, n_features: int) -> bool:
 
 
 def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: torch.Tensor, logs: torch.Tensor,
-                       mul_exp: float) -> torch.Tensor:
+                       mul_exp: float, return_taps: bool = False) -> torch.Tensor:
     """NN(x_a) of an affine coupling for any image size (bf16 mode): im2col of the C/2-channel half -> the per-pixel three-GEMM
     chain with the hidden activations on chip (nfdp_coupling_mlp_bf16) -> tap shift-sum with the ZeroConv2d epilogue.
     xh_a: [B,H,W,C/2] fp32 pixel-strided view; returns h = (log_s | t) [B,H,W,C] fp32."""
@@ -1512,6 +1535,8 @@ def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: t
     t = torch.empty((b, h, w, 9 * c), device=xh_a.device, dtype=torch.float32)
     _call("nfdp_coupling_mlp_bf16", _ptr(xcol), xcol.shape[-1], b * h * w, _ptr(packed), _ptr(t), c, _stream(),
           label=f"coupling_mlp<{c}> hw{h}", flops=2.0 * b * h * w * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c))
+    if return_taps:
+        return t
     out = torch.empty((b, h, w, c), device=xh_a.device, dtype=torch.float32)
     _call("nfdp_tap_shift_sum_f32", _ptr(t), _ptr(out), b, h, w, c, _ptr(bias), _ptr(logs), float(mul_exp), 0, _stream())
     return out

@@ -161,13 +161,34 @@ class AffineCoupling(Transform):
                                             zc.logscale_factor)
         return self.net.forward_nhwc(xh[..., : c // 2], compute=self.compute)
 
+    def _net_taps_nhwc(self, xh: Tensor):
+        """bf16 mode outside the whole-image kernels: the network up to the output conv's TAP CONTRIBUTIONS T [B,H,W,9C] (the
+        shift-sum, the ZeroConv2d epilogue and the coupling then run as one pass, K.tap_coupling); None where the path does not apply."""
+        if K.compute_enum(self.compute) != K.BF16 or xh.dtype != torch.float32 or not self.net.fused_ready():
+            return None
+        b, hh, ww, c = xh.shape
+        if self.fused and b * hh * ww >= 1024 and K.coupling_mlp_supported(c, self.n_features):
+            zc = self.net[-1]
+            return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
+                                        return_taps=True)
+        t, _ = self.net.forward_nhwc(xh[..., : c // 2], compute=self.compute, return_taps=True) if self._taps_ok() else (None, None)
+        return t
+
+    def _taps_ok(self) -> bool:
+        zc = self.net[-1]
+        return K.use_tap_conv(zc.in_channels, zc.out_channels, zc.filter_size, K.BF16)
+
     def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], ldj_const: Optional[Tensor] = None) -> Tensor:
         """In place on xh's second channel half.  ldj_const: device [2] fp32 added before the coupling sum."""
         packed = self._fused_pack(xh)
         if packed is not None:
             K.coupling_fused(xh, packed, ldj, ldj_const, inverse=False)
             return xh
-        c = xh.shape[-1]
+        t = self._net_taps_nhwc(xh)
+        if t is not None:
+            zc = self.net[-1]
+            K.tap_coupling(xh, t, zc.bias, zc.logs.view(-1), zc.logscale_factor, ldj, ldj_const, inverse=False)
+            return xh
         h = self._net_nhwc(xh)
         K.coupling_fwd(xh, h, ldj, ldj_const)
         return xh
@@ -176,6 +197,11 @@ class AffineCoupling(Transform):
         packed = self._fused_pack(yh)
         if packed is not None:
             K.coupling_fused(yh, packed, None, None, inverse=True)
+            return yh
+        t = self._net_taps_nhwc(yh)
+        if t is not None:
+            zc = self.net[-1]
+            K.tap_coupling(yh, t, zc.bias, zc.logs.view(-1), zc.logscale_factor, None, None, inverse=True)
             return yh
         h = self._net_nhwc(yh)
         K.coupling_inv(yh, h)

@@ -81,6 +81,14 @@ class ZeroConv2d(nn.Module):
         self.logscale_factor = logscale
         self._cache = _PackedCache()
 
+    def taps_nhwc(self, xh: Tensor, compute: Optional[str] = None) -> Optional[Tensor]:
+        """The tap contributions T [B,H,W,9*Cout] of this conv (its pointwise-GEMM half) where forward_nhwc would take the tap form,
+        else None: AffineCoupling hands T to K.tap_coupling, which adds the taps up and applies the coupling in one pass."""
+        c = K.compute_enum(compute)
+        if xh.dtype == torch.bfloat16 and K.use_tap_conv(self.in_channels, self.out_channels, self.filter_size, c):
+            return K.conv3x3_narrow(xh, self.weight, compute=c, packed_taps=self._cache.get_taps(self.weight, c), return_taps=True)
+        return None
+
     def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None) -> Tensor:
         c = K.compute_enum(compute)
         if xh.dtype == torch.bfloat16 and K.use_tap_conv(self.in_channels, self.out_channels, self.filter_size, c):
@@ -200,11 +208,16 @@ class CouplingNet(nn.Sequential):
             self._fused_train_key = key
         return self._fused_train
 
-    def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None) -> Tensor:
+    def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None, return_taps: bool = False) -> Tensor:
+        """return_taps: (T, None) when the output conv runs in its tap form (T = its tap contributions, for K.tap_coupling), else
+        (None, h)."""
         c = K.compute_enum(compute)
         hid = K.BF16 if c == K.BF16 else K.F32
         h = self[0].forward_nhwc(xh, relu=True, compute=compute, out_dtype=hid)
         h = self[2].forward_nhwc(h, relu=True, compute=compute, out_dtype=hid)
+        if return_taps:
+            t = self[4].taps_nhwc(h, compute=compute)
+            return (t, None) if t is not None else (None, self[4].forward_nhwc(h, compute=compute))
         return self[4].forward_nhwc(h, compute=compute)
 
     def forward(self, x: Tensor) -> Tensor:
