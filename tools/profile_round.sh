@@ -19,3 +19,9 @@ done
 python3 tools/pmc_summary.py "$OUT/pmc_summary.json" "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_WAVE_CYCLES "$OUT"/pmc_TCC_HIT_sum > /dev/null
 find "$OUT/stats" -name "*kernel_stats.csv" -exec cp {} "$OUT/bench_kernel_stats.csv" \;
 ls "$OUT"
+# 3. the other configs: kernel stats of the CelebA-shape forward / inverse (tools/bench_celeba.py) and of the training step
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/celeba" -o celeba -- python3 tools/bench_celeba.py > "$OUT/celeba_under_rocprof.txt" 2>&1 || true
+find "$OUT/celeba" -name "*kernel_stats.csv" -exec cp {} "$OUT/celeba_kernel_stats.csv" \;
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train" -o train -- python3 bench.py --train --steps 5 --warmup 2 --no-graph > "$OUT/train_under_rocprof.json" 2> "$OUT/train_under_rocprof.err" || true
+find "$OUT/train" -name "*kernel_stats.csv" -exec cp {} "$OUT/train_kernel_stats.csv" \;
+ls "$OUT"
