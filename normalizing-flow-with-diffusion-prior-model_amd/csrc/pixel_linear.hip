@@ -181,6 +181,102 @@ __global__ void __launch_bounds__(kBlock) pixel_linear_generic_kernel(const floa
     }
 }
 
+// Wide C (64, 96, 192: the deeper levels of 4- and 5-level models) on the exact-fp32 matrix cores.  As one FMA chain per lane
+// (pixel_linear_kernel) a lane walks C/4 x C serial FMAs: 25 us for the 2048 pixels of a C = 96 level, 130 us for the 512 pixels of a
+// C = 192 level.  Per pixel the product is a C x C matrix-vector product; v_mfma_f32_32x32x2_f32 takes exactly this shape: A = W (rows =
+// output channel, 2 input channels per instruction, this lane's elements straight from global memory), B = the 32-pixel tile (lane =
+// pixel, lane half = which of the two input channels, from LDS, ActNorm folded into the read), C/2 chained instructions per 32 x 32
+// outputs.  A workgroup owns 32 pixels; wave r computes output rows 32 r .. 32 r + 31 (C/32 waves); all reads of the tile happen
+// before any write, so in place is safe.  Products and sums are fp32, input channels ascending (as the FMA chain).
+template <int C, int MODE>
+__global__ void __launch_bounds__(64 * (C / 32)) pixel_linear_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, long npix,
+                                                                        const float* __restrict__ w, const float* __restrict__ scale,
+                                                                        const float* __restrict__ bias,
+                                                                        const float* __restrict__ logabsdet, float hw,
+                                                                        float* __restrict__ ldj_const_out) {
+    static_assert(C % 32 == 0, "whole 32-row tiles");
+    constexpr int NW = C / 32, NT = 64 * NW, LD = C + 1, KP = C / 2;
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* X = smem;                                 // [32][LD]
+    float* es = smem + 32 * LD;                      // [C]
+    float* bs = es + C;                              // [C]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long p0 = (long)blockIdx.x * 32;
+    const int np = (int)((npix - p0) < 32 ? (npix - p0) : 32);
+    if (MODE != kMatvec)
+        for (int c = tid; c < C; c += NT) {
+            es[c] = expf(MODE == kPostAffine ? -scale[c] : scale[c]);
+            bs[c] = bias[c];
+        }
+    if (ldj_const_out != nullptr && blockIdx.x == 0 && wave == 0) {
+        double sacc = 0.0;
+        for (int c = lane; c < C; c += 64) sacc += (double)scale[c];
+        sacc = wave_sum_d(sacc);
+        if (lane == 0) {
+            ldj_const_out[0] = __fmul_rn(hw, (float)sacc);
+            ldj_const_out[1] = logabsdet ? __fmul_rn(hw, logabsdet[0]) : 0.0f;
+        }
+    }
+    // this lane's W elements first (global latency under the tile load): row 32 wave + (lane & 31), input channels 2 j + (lane >> 5)
+    const int m0 = lane & 31, kh = lane >> 5;
+    // (16-byte loads along the lane's row, both lane halves the same addresses: a quarter of the memory instructions of 4-byte loads at
+    // stride 8; the half then picks its two of every four elements)
+    const float4* wrow4 = reinterpret_cast<const float4*>(w + (long)(32 * wave + m0) * C);
+    float a[KP];
+#pragma unroll
+    for (int i = 0; i < C / 4; ++i) {
+        const float4 v = wrow4[i];
+        a[2 * i] = kh ? v.y : v.x;
+        a[2 * i + 1] = kh ? v.w : v.z;
+    }
+    const float4* src4 = reinterpret_cast<const float4*>(x + p0 * C);
+    for (int i = tid; i < 32 * C / 4; i += NT) {
+        const int e = i * 4, r = e / C, c = e % C;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < np) v = src4[i];
+        float* d = X + r * LD + c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* xrow = X + m0 * LD + kh;
+#pragma unroll
+    for (int j = 0; j < KP; ++j) {
+        float b = xrow[2 * j];
+        if (MODE == kPreAffine) b = es[2 * j + kh] * (b + bs[2 * j + kh]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b, acc, 0, 0, 0);
+    }
+    __syncthreads();                                 // every wave has read the tile
+    float* orow = X + m0 * LD + 32 * wave + 4 * kh;  // D row held by (register r, lane half): (r & 3) + 8 (r >> 2) + 4 kh
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int o = (r & 3) + 8 * (r >> 2);
+        float v = acc[r];
+        if (MODE == kPostAffine) v = __fsub_rn(__fmul_rn(v, es[32 * wave + 4 * kh + o]), bs[32 * wave + 4 * kh + o]);
+        orow[o] = v;
+    }
+    __syncthreads();
+    float4* dst4 = reinterpret_cast<float4*>(y + p0 * C);
+    for (int i = tid; i < np * C / 4; i += NT) {
+        const int e = i * 4;
+        const float* q = X + (e / C) * LD + (e % C);
+        dst4[i] = make_float4(q[0], q[1], q[2], q[3]);
+    }
+}
+
+template <int C, int MODE>
+int launch_mfma(const float* x, float* y, long npix, const float* w, const float* scale, const float* bias, const float* lad, float hw,
+                float* cst, hipStream_t s) {
+    const size_t lds = ((size_t)32 * (C + 1) + 2 * C) * sizeof(float);
+    hipLaunchKernelGGL((pixel_linear_mfma_kernel<C, MODE>), dim3((unsigned)cdiv(npix, 32)), dim3(64 * (C / 32)), lds, s, x, y, npix, w,
+                       scale, bias, lad, hw, cst);
+    return NFDP_OK;
+}
+
 template <int C, int MODE>
 int launch_templated(const float* x, float* y, long npix, const float* w, const float* scale, const float* bias,
                      const float* lad, float hw, float* cst, hipStream_t s) {
@@ -208,6 +304,7 @@ int dispatch(const char* what, const float* x, float* y, long npix, int C, const
     NFDP_REQUIRE(npix >= 0 && C > 0, NFDP_ESHAPE, "%s: bad shape npix=%ld C=%d", what, npix, C);
     if (npix == 0) return NFDP_OK;
     hipStream_t s = as_stream(stream);
+    const bool al16 = ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w) & 15) == 0);
     switch (C) {
         case 4: launch_templated<4, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
         case 8: launch_templated<8, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
@@ -217,9 +314,10 @@ int dispatch(const char* what, const float* x, float* y, long npix, int C, const
         case 48: launch_templated<48, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
         // deeper models (L = 4, 5: CelebA 128x128 is L = 5): C = 2^(l+2) * {1, 3}
         case 32: launch_templated<32, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
-        case 64: launch_templated<64, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
-        case 96: launch_templated<96, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
-        case 192: launch_templated<192, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        // wide C: the exact-fp32 matrix cores (16-byte aligned tensors; else the FMA-chain kernel)
+        case 64: if (al16) launch_mfma<64, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); else launch_templated<64, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 96: if (al16) launch_mfma<96, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); else launch_templated<96, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
+        case 192: if (al16) launch_mfma<192, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); else launch_templated<192, MODE>(x, y, npix, w, scale, bias, lad, hw, cst, s); break;
         default: {
             NFDP_REQUIRE(x != y, NFDP_EINVAL, "%s: in-place needs a templated C (got %d)", what, C);
             NFDP_REQUIRE(cst == nullptr, NFDP_EUNSUPPORTED, "%s: fused log-det constants need a templated C (got %d)", what, C);

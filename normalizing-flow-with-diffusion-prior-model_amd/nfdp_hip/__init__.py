@@ -362,8 +362,7 @@ def actnorm_invconv_fwd(xh, scale, bias, w, out=None):
     return out
 
 
-_FLOW_HEAD_C = (4, 8, 12, 16, 24, 32, 48, 64, 96)      # templated instances of pixel_linear.hip that beat the MFMA route (C = 192: 130 us
-                                                        # for 512 pixels against 37 us for ActNorm + pack + exact-fp32 MFMA conv)
+_FLOW_HEAD_C = (4, 8, 12, 16, 24, 32, 48, 64, 96, 192)      # the templated instances of pixel_linear.hip (64 / 96 / 192: fp32 MFMA)
 
 
 def flow_head_fwd(xh, scale, bias, w, logabsdet, out=None):
