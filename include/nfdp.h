@@ -52,7 +52,7 @@ int nfdp_squeeze_nhwc_f32(const float* x, int x_ld, float* y, int B, int C, int 
 /* Squeeze.invert, transforms.py:238: y is [B,h,w,C4] (16-byte aligned) -> x [B,2h,2w,C4/4]. */
 int nfdp_unsqueeze_nhwc_f32(const float* y, float* x, int B, int C4, int h, int w, nfdp_stream_t stream);
 /* How compute = NFDP_F32 forms its products in the small-problem conv kernel (U-Net layers of the reverse-diffusion step):
- * 0 (default) v_mfma_f32_16x16x4_f32, the exact k-ordered fp32 FMA chain; 1: each operand split into three bf16 values
+ * 0 v_mfma_f32_16x16x4_f32, the exact k-ordered fp32 FMA chain; 1 (default): each operand split into three bf16 values
  * (v = h + m + l exactly) and six v_mfma_f32_16x16x32_bf16 per product term set {hh, hm, mh, mm, hl, lh} with fp32 accumulation -
  * the dropped terms are below 2^-24 relative, the result is as close to the fp64 value as the fp32 chain (2e-7 vs 5e-7 at
  * K = 576..4608) at 2.7x fewer matrix-pipe cycles.  Process-wide switch (not per call); storage stays fp32. */

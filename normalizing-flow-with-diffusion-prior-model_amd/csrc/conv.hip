@@ -24,7 +24,8 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int BK = 32;
-int g_f32_products = 0;          // nfdp_set_f32_products: 0 exact fp32 MFMA chain, 1 three-way bf16 split + six bf16 MFMAs
+int g_f32_products = 1;          // nfdp_set_f32_products: 0 exact fp32 MFMA chain, 1 (default since round 4) three-way bf16 split + six bf16
+                                 // MFMAs: as close to fp64 as the fp32 chain (2-4e-7 either way), 2.7x fewer matrix-pipe cycles
 
 struct ConvParams {
     const void* x;

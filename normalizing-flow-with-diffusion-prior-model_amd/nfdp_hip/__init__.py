@@ -110,9 +110,13 @@ _param_epoch = 0
 
 
 def set_f32_products(mode: str) -> None:
-    """'exact' (v_mfma_f32_16x16x4_f32, default) | 'bf16x6' (three-way bf16 split of both operands, six bf16 MFMAs, fp32-chain
-    accuracy) for the small fp32 convs (nfdp_set_f32_products)."""
+    """'exact' (v_mfma_f32_16x16x4_f32) | 'bf16x6' (default: three-way bf16 split of both operands, six bf16 MFMAs, fp32-chain
+    accuracy) for the fp32 convs (nfdp_set_f32_products)."""
     _check(lib().nfdp_set_f32_products({"exact": 0, "bf16x6": 1}[mode]))
+
+
+def get_f32_products() -> str:
+    return ("exact", "bf16x6")[int(lib().nfdp_get_f32_products())]
 
 
 def param_epoch() -> int:

@@ -336,6 +336,8 @@ def test_f32_products_on_bf16_matrix_cores():
     ref_e = torch.relu((ref + add.double()) * torch.exp(3.0 * mul.double()))
     packed = K.conv_pack(wt.to(DEV), K.F32)
     errs = {}
+    default_mode = K.get_f32_products()
+    assert default_mode == "bf16x6"
     try:
         for mode in ("exact", "bf16x6"):
             K.set_f32_products(mode)
@@ -344,7 +346,7 @@ def test_f32_products_on_bf16_matrix_cores():
             errs[mode] = max(float((got.cpu().double() - ref).abs().max() / ref.abs().max()),
                              float((got_e.cpu().double() - ref_e).abs().max() / ref_e.abs().max()))
     finally:
-        K.set_f32_products("exact")
+        K.set_f32_products(default_mode)
     assert errs["exact"] < 2e-6 and errs["bf16x6"] < 2e-6, errs
     # the tiled conv kernel (short K: not the split-K path) takes the same switch
     x2 = torch.randn(4, 16, 16, 12, generator=g)
@@ -357,7 +359,7 @@ def test_f32_products_on_bf16_matrix_cores():
             got2 = K.conv2d(x2.to(DEV), p2, 96, 3)
             assert float((got2.cpu().double() - ref2).abs().max() / ref2.abs().max()) < 2e-6, mode
     finally:
-        K.set_f32_products("exact")
+        K.set_f32_products(default_mode)
 
 
 def test_coupling_chunked_matches_per_sample_kernel():
