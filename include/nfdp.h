@@ -185,6 +185,13 @@ int nfdp_coupling_fwd_chunked_f32(float* x, const float* h, int B, int HW, int C
  * nfdp_coupling_fused_pack from the nine parameter tensors of one coupling network in the reference's layouts:
  * w1 [512,C/2,3,3], scale1/bias1 [512], w2 [512,512(,1,1)], scale2/bias2 [512], w3 [C,512,3,3], bias3 [C], logs3 [C]. */
 int nfdp_coupling_fused_supported(int H, int W, int C, int n_features);
+/* Inference-only geometries on top of those: the wide last levels of a 5-level model on 128x128x3 (H = W = 8 with C = 96, H = W = 4 with
+ * C = 192; coupling_fused_wide_kernel: whole images per workgroup, the 3x3 output conv as one accumulation over (tap, hidden channel)
+ * with the hidden tile read at the shifted pixel).  nfdp_coupling_fused_has_head: 1 when the launch includes the flow head (ActNorm +
+ * 1x1 conv, glow.py:46-47 / :61-62), 0 when it is the coupling layer alone (C = 192) and nfdp_stepflow_fused_bf16 /
+ * nfdp_level_fused_bf16 refuse the geometry: run nfdp_flow_head_fwd_f32 / nfdp_invconv_actnorm_inv_f32, then nfdp_coupling_fused_bf16. */
+int nfdp_coupling_fused_infer_supported(int H, int W, int C, int n_features);
+int nfdp_coupling_fused_has_head(int H, int W, int C);
 /* Which image the fused kernels of a geometry read (0: geometry unsupported): 1 = nfdp_coupling_fused_pack / _pack_ex(fold_scales = 1),
  * 2 = _pack_ex(fold_scales = 2): the 16x16 levels run their GEMMs on v_mfma_f32_16x16x32_bf16 and read 16-row x 32-deep fragments.
  * nfdp_coupling_fused_bf16 / nfdp_stepflow_fused_bf16 / nfdp_level_fused_bf16 must be handed the kind this returns for their H, W, C;

@@ -511,6 +511,16 @@ def coupling_fused_supported(h: int, w: int, c: int, n_features: int) -> bool:
     return bool(lib().nfdp_coupling_fused_supported(h, w, c, n_features))
 
 
+def coupling_fused_infer_supported(h: int, w: int, c: int, n_features: int) -> bool:
+    """Geometries the fused flow-step kernels run in inference (the training kernels' set + the wide levels of 5-level models)."""
+    return bool(lib().nfdp_coupling_fused_infer_supported(h, w, c, n_features))
+
+
+def coupling_fused_has_head(h: int, w: int, c: int) -> bool:
+    """Does the fused launch of this geometry include the flow head (ActNorm + 1x1 conv)?  False: coupling layer only."""
+    return bool(lib().nfdp_coupling_fused_has_head(h, w, c))
+
+
 def coupling_fused_image_kind(h: int, w: int, c: int) -> int:
     """Which inference image the fused kernels of this geometry read: 1 (fold=True) or 2 (fold=2: 16x16x32 fragments); 0 = unsupported."""
     return int(lib().nfdp_coupling_fused_image_kind(h, w, c))
@@ -1525,7 +1535,7 @@ def pointwise_dgrad_masked(xh: torch.Tensor, packed: torch.Tensor, y_saved: torc
 
 
 def coupling_mlp_supported(c: int, n_features: int) -> bool:
-    return n_features == 512 and lib().nfdp_coupling_fused_packed_bytes(c) != 0
+    return n_features == 512 and c <= 48 and lib().nfdp_coupling_fused_packed_bytes(c) != 0
 
 
 def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: torch.Tensor, logs: torch.Tensor,

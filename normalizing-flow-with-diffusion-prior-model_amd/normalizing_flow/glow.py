@@ -38,6 +38,8 @@ class StepFlow(Transform):
         if not an.initialized():
             an.init_from(xh)
         packed = self.affcoupling._fused_pack(xh)
+        if packed is not None and not K.coupling_fused_has_head(xh.shape[1], xh.shape[2], xh.shape[3]):
+            packed = None                         # coupling-only geometry (C = 192): head as its own launch, then the fused coupling
         if packed is not None and (ldj is None or defer_logdet or logabsdet is not None):
             # whole flow step in one launch; a per-flow log|det| (if not deferred) is pre-scaled to H*W*log|det W|
             term = None
@@ -59,7 +61,7 @@ class StepFlow(Transform):
         if winv is None:
             _, winv = K.invconv_prepare(ic._w(), want_inverse=True)
         packed = self.affcoupling._fused_pack(yh)
-        if packed is not None:
+        if packed is not None and K.coupling_fused_has_head(yh.shape[1], yh.shape[2], yh.shape[3]):
             K.stepflow_fused(yh, packed, an.scale.view(-1), an.bias.view(-1), winv.reshape(-1), None, None, inverse=True)
             return yh
         self.affcoupling.invert_nhwc_(yh)
@@ -129,6 +131,8 @@ def _level_tables(flows: Sequence[StepFlow], xh: Tensor):
     """(packed images, ActNorm scales, biases) of every flow of a level when ALL of them can run on the fused kernel
     (bf16 mode, supported geometry, ActNorms initialised), else None."""
     packed = []
+    if not K.coupling_fused_has_head(xh.shape[1], xh.shape[2], xh.shape[3]):
+        return None                               # (C = 192: the fused launch is the coupling layer alone - flow by flow)
     for f in flows:
         if not f.actnorm.initialized():
             return None

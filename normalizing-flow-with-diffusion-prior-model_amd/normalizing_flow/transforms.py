@@ -140,7 +140,7 @@ class AffineCoupling(Transform):
         if not self.fused or K.compute_enum(self.compute) != K.BF16:
             return None
         _, h, w, c = xh.shape
-        if not K.coupling_fused_supported(h, w, c, self.n_features):
+        if not K.coupling_fused_infer_supported(h, w, c, self.n_features) or not self.net.fused_ready():
             return None
         return self.net.fused_packed(K.coupling_fused_image_kind(h, w, c))
 
