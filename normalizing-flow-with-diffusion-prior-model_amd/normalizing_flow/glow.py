@@ -84,6 +84,7 @@ class StepFlow(Transform):
 # key is (storage, tensor version, optimizer epoch): an in-place edit through `.data` (which has its own version counter) is
 # invisible to it - call nfdp_hip.bump_param_epoch() after such an edit, or switch the cache off.
 CACHE_WEIGHT_TERMS = True
+LOGDETS_ON_SIDE_STREAM = True      # Glow.transform_nhwc of 4- and 5-level models: the 1x1-conv log-dets on a side stream (see there)
 
 
 def set_weight_term_cache(on: bool) -> None:
@@ -255,18 +256,27 @@ class Glow(Transform):
         # per matrix, ~10-20 us) ahead of the flow kernels; the per-level sums  H*W * sum_k log|det W_k|  are folded into
         # ldj once at the end (an fp64 re-association of the reference's per-flow adds, transforms.py:131).
         lads = None
+        side = None
         if ldj is not None:
-            groups = [list(b.flows) for b in self.blocks] + [list(self.final_flows)]
-            small = [g for g in groups if g[0].invconv2d._w().shape[-1] <= 96]      # the one-launch LU holds a matrix in LDS
-            flat = _cached_terms([f for g in small for f in g], "logdets_all",
-                                 lambda: K.invconv_logdets([f.invconv2d._w() for g in small for f in g])) if small else None
-            lads, o = [], 0
-            for g in groups:
-                if g[0].invconv2d._w().shape[-1] <= 96:
-                    lads.append(flat[o:o + len(g)])
-                    o += len(g)
-                else:                          # C = 192 at the last level of a 5-level model: batched Gauss-Jordan, global workspace
-                    lads.append(_level_logdets(g))
+            # Deep models (L >= 4): the wide levels' Gauss-Jordans are not short (1.4 ms for the 16 C = 192 matrices of a 5-level model: a
+            # fifth of its forward pass) and nothing reads their result before the end, so they run on a side stream beside the first
+            # levels' flows - parallel branches of a captured graph.  (L = 3: 25 us, and a level launch holds every CU: same stream.)
+            main = torch.cuda.current_stream(xh.device)
+            if LOGDETS_ON_SIDE_STREAM and self.L >= 4:
+                side = _side_stream(xh.device)
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                groups = [list(b.flows) for b in self.blocks] + [list(self.final_flows)]
+                small = [g for g in groups if g[0].invconv2d._w().shape[-1] <= 96]      # the one-launch LU holds a matrix in LDS
+                flat = _cached_terms([f for g in small for f in g], "logdets_all",
+                                     lambda: K.invconv_logdets([f.invconv2d._w() for g in small for f in g])) if small else None
+                lads, o = [], 0
+                for g in groups:
+                    if g[0].invconv2d._w().shape[-1] <= 96:
+                        lads.append(flat[o:o + len(g)])
+                        o += len(g)
+                    else:                          # C = 192 at the last level of a 5-level model: batched Gauss-Jordan, global workspace
+                        lads.append(_level_logdets(g))
         hws = []
         for i, block in enumerate(self.blocks):
             yh, z = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True)
@@ -277,6 +287,11 @@ class Glow(Transform):
         yh = _run_flows_fwd(self.final_flows, yh, ldj, None, defer_logdet=True)
         zs.append(yh)
         if ldj is not None:
+            if side is not None:
+                main = torch.cuda.current_stream(xh.device)
+                main.wait_stream(side)
+                for lad in lads:
+                    lad.record_stream(main)
             for lad, hw in zip(lads, hws):
                 K.ldj_add_scaled(ldj, lad, lad.numel(), hw)
         return zs
