@@ -84,6 +84,10 @@ class StepFlow(Transform):
 # key is (storage, tensor version, optimizer epoch): an in-place edit through `.data` (which has its own version counter) is
 # invisible to it - call nfdp_hip.bump_param_epoch() after such an edit, or switch the cache off.
 CACHE_WEIGHT_TERMS = True
+# Glow.transform_nhwc: the Split priors' log-density terms on a side stream, joined at the end.  Measured (round 4, L3 K16 B = 512): the
+# step got 8 % SLOWER (1.90 -> 2.07 ms) - a level launch wants every CU at once, and the prior convs' workgroups in its way delay it by
+# more than they take on their own.  Off.
+PRIORS_ON_SIDE_STREAM = False
 LOGDETS_ON_SIDE_STREAM = True      # Glow.transform_nhwc of 4- and 5-level models: the 1x1-conv log-dets on a side stream (see there)
 
 
@@ -198,10 +202,10 @@ class GlowBlock(Transform):
         self.split = Split(flow_channels, learn_prior_mean_logs=learn_prior_mean_logs, compute=compute)
 
     def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor], lads: Optional[Tensor] = None,
-                       defer_logdet: bool = False):
+                       defer_logdet: bool = False, prior_stream=None):
         yh = K.squeeze(xh)                       # fresh level buffer; flows then run in place
         yh = _run_flows_fwd(self.flows, yh, ldj, lads, defer_logdet)
-        yv, z = self.split.transform_nhwc(yh, logp)
+        yv, z = self.split.transform_nhwc(yh, logp, side=prior_stream)
         return yv, z
 
     def invert_nhwc(self, yh: Tensor, zh: Optional[Tensor], temperature: float = 1.0, eps: Optional[Tensor] = None) -> Tensor:
@@ -278,14 +282,21 @@ class Glow(Transform):
                     else:                          # C = 192 at the last level of a 5-level model: batched Gauss-Jordan, global workspace
                         lads.append(_level_logdets(g))
         hws = []
+        # the Split priors' terms (a narrow 3x3 conv + the Gaussian log-density per level: ~25 us each, launch-bound) only feed logp:
+        # on a second stream they run beside the next level's flows instead of between two level launches
+        pstream = None
+        if PRIORS_ON_SIDE_STREAM and logp is not None and xh.is_cuda:
+            pstream = _side_stream(xh.device) if side is None else side
         for i, block in enumerate(self.blocks):
-            yh, z = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True)
+            yh, z = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True, prior_stream=pstream)
             hws.append(z.shape[1] * z.shape[2])
             zs.append(z)
         yh = K.squeeze(yh)
         hws.append(yh.shape[1] * yh.shape[2])
         yh = _run_flows_fwd(self.final_flows, yh, ldj, None, defer_logdet=True)
         zs.append(yh)
+        if pstream is not None and pstream is not side:
+            torch.cuda.current_stream(xh.device).wait_stream(pstream)
         if ldj is not None:
             if side is not None:
                 main = torch.cuda.current_stream(xh.device)

@@ -249,12 +249,21 @@ class Split(Transform):
         b, h, w, c = yh.shape
         return torch.zeros((b, h, w, 2 * c), device=yh.device, dtype=torch.float32)
 
-    def transform_nhwc(self, xh: Tensor, logp: Optional[Tensor]):
-        """-> (y view, z contiguous copy); logp updated in place (skipped when None, transforms.py:287)."""
+    def transform_nhwc(self, xh: Tensor, logp: Optional[Tensor], side: Optional["torch.cuda.Stream"] = None):
+        """-> (y view, z contiguous copy); logp updated in place (skipped when None, transforms.py:287).
+        side: a HIP stream for the prior term (the prior conv + log-density only feed logp, which nothing reads before the end of the
+        forward pass): forked behind the work enqueued so far, NOT joined here - the caller joins it before logp is read."""
         c = xh.shape[-1]
         yv, zv = xh[..., : c // 2], xh[..., c // 2:]
         if logp is not None:
-            K.gauss_logp(zv, self._mean_logs_nhwc(yv), 0, logp)
+            if side is not None:
+                main = torch.cuda.current_stream(xh.device)
+                side.wait_stream(main)
+                xh.record_stream(side)
+                with torch.cuda.stream(side):
+                    K.gauss_logp(zv, self._mean_logs_nhwc(yv), 0, logp)
+            else:
+                K.gauss_logp(zv, self._mean_logs_nhwc(yv), 0, logp)
         z = torch.empty(zv.shape, device=xh.device, dtype=torch.float32)
         K.copy_channels(zv, z)
         return yv, z
