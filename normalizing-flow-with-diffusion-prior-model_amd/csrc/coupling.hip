@@ -134,8 +134,11 @@ __global__ void __launch_bounds__(kBlock) tap_coupling_kernel(float* __restrict_
         vec_t xv = *reinterpret_cast<const vec_t*>(xb);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const float log_s = __fmul_rn(__fadd_rn(a_ls[j], add[c + j]), expf(__fmul_rn(f, mul[c + j])));
-            const float t = __fmul_rn(__fadd_rn(a_t[j], add[Ch + c + j]), expf(__fmul_rn(f, mul[Ch + c + j])));
+            float log_s = __fmul_rn(__fadd_rn(a_ls[j], add[c + j]), expf(__fmul_rn(f, mul[c + j])));
+            float t = __fmul_rn(__fadd_rn(a_t[j], add[Ch + c + j]), expf(__fmul_rn(f, mul[Ch + c + j])));
+            // (opaque: the two-pass path rounds (log_s | t) to fp32 in memory between the two kernels; here hipcc otherwise folds the
+            // e^{f mul} factor into the sigmoid's argument arithmetic and the results differ by an ulp)
+            asm volatile("" : "+v"(log_s), "+v"(t));
             const float s = sigmoid_p2(log_s);
             if (!INV) {
                 xv[j] = __fmul_rn(__fadd_rn(xv[j], t), s);

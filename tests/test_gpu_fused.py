@@ -333,3 +333,97 @@ def test_f32_onchip_coupling_network_against_oracle(c, hh, ww, b):
     assert_close(y, yo, 1e-5, "coupling forward")
     assert_close(ldj, lo, 1e-6, "coupling log-det")
     assert_close(m.invert(y), O.coupling_inv(yo, osd, "flows.3.affcoupling.net."), 1e-5, "coupling inverse")
+
+
+# ---- round 4: the wide levels of a 5-level model (8x8x96 with the flow head, 4x4x192 coupling only) and the one-pass tap + coupling kernel
+WIDE = [(96, 8, 5), (192, 4, 5), (192, 4, 2)]          # (C, H=W, ragged B: 4x4 workgroups own two images)
+
+
+@pytest.mark.parametrize("c,hw,b", WIDE)
+@torch.no_grad()
+def test_wide_level_kernels_match_the_conv_by_conv_path_and_the_oracle(c, hw, b):
+    """coupling_fused_wide_kernel (inference only: the 3x3 output conv as one accumulation over (tap, hidden channel), the hidden tile
+    read at the shifted pixel) against the same layer conv by conv in bf16 mode (same operands, another fp32 association of the tap sums)
+    and against the fp32 oracle; forward, inverse, round trip, determinism."""
+    assert not K.coupling_fused_supported(hw, hw, c, 512) and K.coupling_fused_infer_supported(hw, hw, c, 512)
+    assert K.coupling_fused_has_head(hw, hw, c) == (c == 96)
+    fused, sd = make(c, True)
+    plain, _ = make(c, False)
+    x = T(synth_input(f"wx{c}", (b, c, hw, hw), 5)) * 0.6
+    xd = x.to(DEV)
+    l1 = torch.zeros(b, dtype=torch.float64, device=DEV)
+    l2 = torch.zeros(b, dtype=torch.float64, device=DEV)
+    K.start_trace()
+    y1, _, _ = fused.transform(xd, l1, None)
+    labels = [e["label"] for e in K.stop_trace()]
+    assert any(lb.startswith("coupling_fused_kernel") for lb in labels), labels
+    y2, _, _ = plain.transform(xd, l2, None)
+    assert torch.equal(y1[:, : c // 2], xd[:, : c // 2])
+    assert_close(y1, y2, 1e-2, "wide vs conv-by-conv y")
+    assert_close(l1, l2, 3e-3, "wide vs conv-by-conv ldj")
+    yo, lo = O.coupling_fwd(x, sd, "flows.3.affcoupling.net.", torch.zeros(b, dtype=torch.float64))
+    assert_close(y1, yo, 3e-2, "wide vs fp32 oracle y")
+    assert_close(l1, lo, 2e-2, "wide vs fp32 oracle ldj")
+    i1, i2 = fused.invert(y1), plain.invert(y1)
+    assert_close(i1, i2, 1e-2, "wide vs conv-by-conv inverse")
+    assert relerr(i1, xd) < 2e-2
+    y1b, _, _ = fused.transform(xd, torch.zeros(b, dtype=torch.float64, device=DEV), None)
+    assert torch.equal(y1, y1b)
+
+
+@torch.no_grad()
+def test_wide_level_launch_of_several_flows_matches_flow_by_flow():
+    """The 8x8x96 level as ONE launch of several flows (flow head inside, weight ring continuous across flows, parameters fetched a flow
+    ahead) against the same flows conv by conv: forward, and the inverse of the unfused output back to the input."""
+    import numpy as np
+    from normalizing_flow import StepFlow
+    from normalizing_flow.glow import _run_flows_fwd, _run_flows_inv
+    flows = []
+    for f in range(3):
+        m = StepFlow(96, 512, compute="bf16")
+        m.load_state_dict({k: torch.from_numpy(np.array(synth_tensor(f"flows.{f}." + k, v.shape, 1, DEEP))) for k, v in m.state_dict().items()})
+        flows.append(m.to(DEV))
+    x = torch.rand(5, 8, 8, 96, device=DEV) - 0.5
+    out = {}
+    for fused in (True, False):
+        for m in flows:
+            m.affcoupling.fused = fused
+        K.start_trace()
+        ldj = torch.zeros(5, dtype=torch.float64, device=DEV)
+        y = _run_flows_fwd(flows, x.clone(), ldj, None, defer_logdet=True)
+        n_launch = len([e for e in K.stop_trace() if e["label"].startswith(("level_fused", "coupling_fused_kernel"))])
+        out[fused] = (y, ldj, n_launch)
+    assert out[True][2] == 1 and out[False][2] == 0, (out[True][2], out[False][2])      # one level launch vs none
+    assert_close(out[True][0], out[False][0], 1e-2, "level launch vs flow by flow")
+    assert_close(out[True][1], out[False][1], 3e-3, "level launch vs flow by flow: ldj")
+    for m in flows:
+        m.affcoupling.fused = True
+    xi = _run_flows_inv(flows, out[False][0].clone())
+    assert float((xi - x).abs().max()) < 1e-2
+
+
+@pytest.mark.parametrize("c,h,w,b", [(12, 64, 64, 3), (24, 32, 32, 2), (48, 16, 16, 3), (96, 8, 8, 5), (192, 4, 4, 7), (12, 20, 12, 2)])
+@torch.no_grad()
+def test_tap_coupling_is_bit_identical_to_shift_sum_then_coupling(c, h, w, b):
+    """nfdp_tap_coupling_f32 (tap shift-sum + ZeroConv2d epilogue + coupling + log-det in one pass) against nfdp_tap_shift_sum_f32
+    followed by nfdp_coupling_fwd_f32 / _inv_f32: same expressions, same tap order -> bit-identical x and ldj, chunked and unchunked
+    geometries, non-square images."""
+    g = torch.Generator().manual_seed(c * 7 + h)
+    t = (torch.randn(b, h, w, 9 * c, generator=g) * 0.3).to(DEV)
+    x0 = (torch.randn(b, h, w, c, generator=g)).to(DEV)
+    add, mul = (torch.randn(c, generator=g) * 0.1).to(DEV), (torch.randn(c, generator=g) * 0.05).to(DEV)
+    const = torch.tensor([0.75, -1.25], device=DEV)
+    hh = torch.empty(b, h, w, c, device=DEV)
+    K._call("nfdp_tap_shift_sum_f32", K._ptr(t), K._ptr(hh), b, h, w, c, K._ptr(add), K._ptr(mul), 3.0, 0, K._stream())
+    for inverse in (False, True):
+        xa, xb = x0.clone(), x0.clone()
+        la = torch.full((b,), 2.0, dtype=torch.float64, device=DEV)
+        lb = la.clone()
+        if inverse:
+            K.coupling_inv(xa, hh)
+        else:
+            K.coupling_fwd(xa, hh, la, const)
+        K.tap_coupling(xb, t, add, mul, 3.0, lb, const, inverse=inverse)
+        assert torch.equal(xa, xb), (inverse, float((xa - xb).abs().max()))
+        if not inverse:
+            assert float((la - lb).abs().max()) <= 1e-9 * float(la.abs().max()), (la, lb)      # (chunk counts differ: fp64 sums of the same terms)
