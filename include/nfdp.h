@@ -63,6 +63,9 @@ int nfdp_get_f32_products(void);
  * first C/2 channels ([npix][xcol_ld] bf16, xcol_ld >= 9*C/2 rounded up to 16), packed = nfdp_coupling_fused_pack image,
  * T [npix][9*C] fp32 (n = tap*C + co) for nfdp_tap_shift_sum_f32 (add = bias, mul = logs, mul_exp = 3).  C in {4,8,16,12,24,48}. */
 int nfdp_coupling_mlp_bf16(const void* xcol, int xcol_ld, long npix, const void* packed, float* T, int C, nfdp_stream_t stream);
+/* The same without the im2col matrix: the kernel gathers the first conv's operands from the fp32 NHWC tensor (x: the C/2-channel half of
+ * [B][H][W][*], pixel stride x_ld floats; zero padding, bf16 rounding as nfdp_im2col3x3_bf16).  One launch less per flow. */
+int nfdp_coupling_mlp_gather_bf16(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, nfdp_stream_t stream);
 /* The same network in EXACT fp32 (v_mfma_f32_32x32x2_f32: fp32 products and sums), hidden activations on chip: the fp32-accurate fast
  * path of compute="f32" (utils.py:83-89 is fp32 end to end).  Reads the C/2-channel half x [B,H,W,*] fp32 NHWC (pixel stride x_ld
  * floats) directly - the 3x3 gather of the first conv happens in the kernel - and writes T [B*H*W][9*C] fp32 (n = tap*C + co) for

@@ -1534,6 +1534,9 @@ def pointwise_dgrad_masked(xh: torch.Tensor, packed: torch.Tensor, y_saved: torc
     return dc, dmul, dadd
 
 
+MLP_GATHER = True      # coupling_net_tiled: gather the first conv's operands inside the coupling-network kernel (False: explicit im2col)
+
+
 def coupling_mlp_supported(c: int, n_features: int) -> bool:
     return n_features == 512 and c <= 48 and lib().nfdp_coupling_fused_packed_bytes(c) != 0
 
@@ -1544,10 +1547,17 @@ def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: t
     chain with the hidden activations on chip (nfdp_coupling_mlp_bf16) -> tap shift-sum with the ZeroConv2d epilogue.
     xh_a: [B,H,W,C/2] fp32 pixel-strided view; returns h = (log_s | t) [B,H,W,C] fp32."""
     b, h, w, _ = xh_a.shape
-    xcol = im2col3x3(xh_a)
     t = torch.empty((b, h, w, 9 * c), device=xh_a.device, dtype=torch.float32)
-    _call("nfdp_coupling_mlp_bf16", _ptr(xcol), xcol.shape[-1], b * h * w, _ptr(packed), _ptr(t), c, _stream(),
-          label=f"coupling_mlp<{c}> hw{h}", flops=2.0 * b * h * w * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c))
+    fl = 2.0 * b * h * w * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c)
+    vw = 4 if (c // 2) % 4 == 0 else 2
+    if MLP_GATHER and xh_a.dtype == torch.float32 and xh_a.data_ptr() % (4 * vw) == 0 and _ld(xh_a, "coupling_net_tiled") % vw == 0:
+        # the first conv's im2col inside the kernel (no xcol matrix, no im2col launch)
+        _call("nfdp_coupling_mlp_gather_bf16", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled"), b, h, w, _ptr(packed), _ptr(t), c, _stream(),
+              label=f"coupling_mlp<{c}> hw{h}", flops=fl)
+    else:
+        xcol = im2col3x3(xh_a)
+        _call("nfdp_coupling_mlp_bf16", _ptr(xcol), xcol.shape[-1], b * h * w, _ptr(packed), _ptr(t), c, _stream(),
+              label=f"coupling_mlp<{c}> hw{h}", flops=fl)
     if return_taps:
         return t
     out = torch.empty((b, h, w, c), device=xh_a.device, dtype=torch.float32)
