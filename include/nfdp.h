@@ -66,6 +66,11 @@ int nfdp_coupling_mlp_bf16(const void* xcol, int xcol_ld, long npix, const void*
 /* The same without the im2col matrix: the kernel gathers the first conv's operands from the fp32 NHWC tensor (x: the C/2-channel half of
  * [B][H][W][*], pixel stride x_ld floats; zero padding, bf16 rounding as nfdp_im2col3x3_bf16).  One launch less per flow. */
 int nfdp_coupling_mlp_gather_bf16(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, nfdp_stream_t stream);
+/* Split-product form for the exact-fp32 mode: every fp32 product as hi*hi + hi*lo + lo*hi of two-piece bf16 splits of both operands
+ * (three bf16 MFMAs against sixteen fp32-MFMA passes), fp32 accumulation; pixel error of a 48-flow inverse 4-6e-5.  packed_hi: the
+ * nfdp_coupling_fused_pack image with fold_scales = 1, packed_lo: the same call with fold_scales = 3 (low pieces).  C <= 24. */
+int nfdp_coupling_mlp_gather_bf16x3(const float* x, int x_ld, int B, int H, int W, const void* packed_hi, const void* packed_lo, float* T,
+                                    int C, nfdp_stream_t stream);
 /* The same network in EXACT fp32 (v_mfma_f32_32x32x2_f32: fp32 products and sums), hidden activations on chip: the fp32-accurate fast
  * path of compute="f32" (utils.py:83-89 is fp32 end to end).  Reads the C/2-channel half x [B,H,W,*] fp32 NHWC (pixel stride x_ld
  * floats) directly - the 3x3 gather of the first conv happens in the kernel - and writes T [B*H*W][9*C] fp32 (n = tap*C + co) for

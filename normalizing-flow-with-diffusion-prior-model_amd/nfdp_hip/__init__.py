@@ -1542,7 +1542,7 @@ def coupling_mlp_supported(c: int, n_features: int) -> bool:
 
 
 def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: torch.Tensor, logs: torch.Tensor,
-                       mul_exp: float, return_taps: bool = False) -> torch.Tensor:
+                       mul_exp: float, return_taps: bool = False, packed_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
     """NN(x_a) of an affine coupling for any image size (bf16 mode): im2col of the C/2-channel half -> the per-pixel three-GEMM
     chain with the hidden activations on chip (nfdp_coupling_mlp_bf16) -> tap shift-sum with the ZeroConv2d epilogue.
     xh_a: [B,H,W,C/2] fp32 pixel-strided view; returns h = (log_s | t) [B,H,W,C] fp32."""
@@ -1550,7 +1550,12 @@ def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: t
     t = torch.empty((b, h, w, 9 * c), device=xh_a.device, dtype=torch.float32)
     fl = 2.0 * b * h * w * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c)
     vw = 4 if (c // 2) % 4 == 0 else 2
-    if MLP_GATHER and xh_a.dtype == torch.float32 and xh_a.data_ptr() % (4 * vw) == 0 and _ld(xh_a, "coupling_net_tiled") % vw == 0:
+    if packed_lo is not None:
+        # split-product form (compute "f32", set_f32_coupling("bf16x3")): packed = high-piece image, packed_lo = low-piece image
+        _need(xh_a, torch.float32, "coupling_net_tiled")
+        _call("nfdp_coupling_mlp_gather_bf16x3", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled"), b, h, w, _ptr(packed), _ptr(packed_lo), _ptr(t),
+              c, _stream(), label=f"coupling_mlp_x3<{c}> hw{h}", flops=fl)
+    elif MLP_GATHER and xh_a.dtype == torch.float32 and xh_a.data_ptr() % (4 * vw) == 0 and _ld(xh_a, "coupling_net_tiled") % vw == 0:
         # the first conv's im2col inside the kernel (no xcol matrix, no im2col launch)
         _call("nfdp_coupling_mlp_gather_bf16", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled"), b, h, w, _ptr(packed), _ptr(t), c, _stream(),
               label=f"coupling_mlp<{c}> hw{h}", flops=fl)
@@ -1572,6 +1577,34 @@ def set_f32_fused(on: bool) -> None:
     """compute="f32": run the coupling networks on the exact-fp32 on-chip kernel (nfdp_coupling_mlp_f32, default) or conv by conv."""
     global _F32_FUSED
     _F32_FUSED = bool(on)
+
+
+_F32_COUPLING = "mfma_f32"
+
+
+def set_f32_coupling(mode: str) -> None:
+    """compute="f32": how the coupling networks form their fp32 products.  "mfma_f32" (default): v_mfma_f32_32x32x2_f32, exact fp32
+    products.  "bf16x3": each product as hi*hi + hi*lo + lo*hi of two-piece bf16 splits of both operands (three bf16 MFMAs, fp32
+    accumulation; relative product error ~4e-6, pixels of a 48-flow inverse 4-6e-5 from fp64) where the geometry has that kernel
+    (C <= 24; wider levels stay on the fp32 matrix cores)."""
+    global _F32_COUPLING
+    if mode not in ("mfma_f32", "bf16x3"):
+        raise ValueError(f"set_f32_coupling: {mode!r}")
+    _F32_COUPLING = mode
+
+
+def get_f32_coupling() -> str:
+    return _F32_COUPLING
+
+
+def coupling_mlp_x3_supported(xh_a: torch.Tensor, c: int, n_features: int) -> bool:
+    """The split-product kernel takes this coupling (mode on, C <= 24, pieces gathered with aligned vector loads)."""
+    if _F32_COUPLING != "bf16x3" or not _F32_FUSED or n_features != 512 or c > 24 or c % 4 or xh_a.dtype != torch.float32:
+        return False
+    if lib().nfdp_coupling_fused_packed_bytes(c) == 0:
+        return False
+    vw = 4 if (c // 2) % 4 == 0 else 2
+    return xh_a.data_ptr() % (4 * vw) == 0 and _ld(xh_a, "coupling_mlp_x3") % vw == 0
 
 
 def coupling_mlp_f32_supported(c: int, n_features: int) -> bool:

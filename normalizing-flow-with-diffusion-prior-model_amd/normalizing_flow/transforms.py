@@ -164,9 +164,18 @@ class AffineCoupling(Transform):
     def _net_taps_nhwc(self, xh: Tensor):
         """bf16 mode outside the whole-image kernels: the network up to the output conv's TAP CONTRIBUTIONS T [B,H,W,9C] (the
         shift-sum, the ZeroConv2d epilogue and the coupling then run as one pass, K.tap_coupling); None where the path does not apply."""
-        if K.compute_enum(self.compute) != K.BF16 or xh.dtype != torch.float32 or not self.net.fused_ready():
+        if xh.dtype != torch.float32 or not self.net.fused_ready():
             return None
         b, hh, ww, c = xh.shape
+        if K.compute_enum(self.compute) == K.F32:
+            # exact-fp32 mode with split products (K.set_f32_coupling("bf16x3")): high- and low-piece images, three bf16 MFMAs per product
+            if self.fused and K.coupling_mlp_x3_supported(xh[..., : c // 2], c, self.n_features):
+                zc = self.net[-1]
+                return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(1), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
+                                            return_taps=True, packed_lo=self.net.fused_packed(3))
+            return None
+        if K.compute_enum(self.compute) != K.BF16:
+            return None
         if self.fused and b * hh * ww >= 1024 and K.coupling_mlp_supported(c, self.n_features):
             zc = self.net[-1]
             return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,

@@ -6,7 +6,7 @@ import torch
 
 import nfdp_hip as K
 from oracle import nf_oracle as O
-from tests.util import T, assert_close, relerr
+from tests.util import T, assert_close, relerr, record
 from tests.golden.synth import synth_tensor, synth_input, DEEP
 
 pytestmark = pytest.mark.gpu
@@ -333,6 +333,54 @@ def test_f32_onchip_coupling_network_against_oracle(c, hh, ww, b):
     assert_close(y, yo, 1e-5, "coupling forward")
     assert_close(ldj, lo, 1e-6, "coupling log-det")
     assert_close(m.invert(y), O.coupling_inv(yo, osd, "flows.3.affcoupling.net."), 1e-5, "coupling inverse")
+
+
+# ---- round 4: exact-fp32 mode with split products (three bf16 MFMAs per fp32 product)
+X3_GEOMS = [(4, 16, 16, 3), (12, 16, 16, 5), (8, 8, 8, 5), (24, 8, 8, 7), (16, 4, 4, 11), (12, 6, 10, 3), (24, 32, 32, 1), (12, 64, 64, 1)]
+
+
+@pytest.mark.parametrize("c,hh,ww,b", X3_GEOMS)
+@torch.no_grad()
+def test_split_product_coupling_network_against_fp64(c, hh, ww, b):
+    """nfdp_coupling_mlp_gather_bf16x3 (K.set_f32_coupling("bf16x3")): NN(x_a) of utils.py:83-89 with every product formed from two-piece
+    bf16 splits of both operands, against the oracle evaluated in fp64 - 1e-4 of the tensor's scale is the bar, measured 1-2e-5
+    (bf16 operands: 5e-3; fp32 MFMA: 1e-6); square / non-square images, ragged pixel counts; then the coupling layer forward and
+    inverse through AffineCoupling(compute="f32"); and the kernel is deterministic."""
+    from normalizing_flow import AffineCoupling
+    m = AffineCoupling(c, n_features=512, compute="f32")
+    sd = {k: T(synth_tensor("flows.3.affcoupling." + k, v.shape, 11, DEEP)) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    osd64 = {"flows.3.affcoupling." + k: v.double() for k, v in sd.items()}
+    x = T(synth_input(f"f32x{c}_{hh}", (b, c, hh, ww), 5)) * 0.6
+    xh = K.to_nhwc(x.to(DEV)).contiguous()
+    zc = m.net[-1]
+    h_ref = O.coupling_net(x[:, : c // 2].double(), osd64, "flows.3.affcoupling.net.")
+    K.set_f32_coupling("bf16x3")
+    try:
+        assert K.coupling_mlp_x3_supported(xh[..., : c // 2], c, 512)
+        K.start_trace()
+        t = m._net_taps_nhwc(xh)
+        labels = [e["label"] for e in K.stop_trace()]
+        assert t is not None and any(lb.startswith("coupling_mlp_x3") for lb in labels), labels
+        h3 = K.coupling_net_tiled(xh[..., : c // 2], m.net.fused_packed(1), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
+                                  packed_lo=m.net.fused_packed(3))
+        h3b = K.coupling_net_tiled(xh[..., : c // 2], m.net.fused_packed(1), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
+                                   packed_lo=m.net.fused_packed(3))
+        assert torch.equal(h3, h3b)
+        e3 = relerr(K.as_nchw(h3), h_ref)
+        record(f"x3_network_relerr_c{c}_h{hh}", e3)
+        assert e3 < 1e-4, e3
+        h16 = K.coupling_net_tiled(xh[..., : c // 2], m.net.fused_packed(1), c, zc.bias, zc.logs.view(-1), zc.logscale_factor)
+        assert e3 < 0.05 * relerr(K.as_nchw(h16), h_ref)                     # two orders below bf16 operands
+        ldj = torch.zeros(b, dtype=torch.float64, device=DEV)
+        y, ldj, _ = m.transform(x.to(DEV), ldj, None)
+        yo, lo = O.coupling_fwd(x.double(), osd64, "flows.3.affcoupling.net.", torch.zeros(b, dtype=torch.float64))
+        assert_close(y, yo, 1e-4, "coupling forward (split products)")
+        assert_close(ldj, lo, 1e-5, "coupling log-det (split products)")
+        assert_close(m.invert(y), O.coupling_inv(yo, osd64, "flows.3.affcoupling.net."), 1e-4, "coupling inverse (split products)")
+    finally:
+        K.set_f32_coupling("mfma_f32")
 
 
 # ---- round 4: the wide levels of a 5-level model (8x8x96 with the flow head, 4x4x192 coupling only) and the one-pass tap + coupling kernel

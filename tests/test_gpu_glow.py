@@ -198,6 +198,49 @@ def test_north_star_full_size_properties():
         assert e_hip <= TOL, f"{what}: hip {e_hip:.2e} vs fp64 truth (fp32 oracle itself: {e_ref:.2e})"
 
 
+@torch.no_grad()
+def test_north_star_split_product_mode_meets_the_pixel_gate():
+    """compute="f32" with K.set_f32_coupling("bf16x3") (levels 0 / 1 on nfdp_coupling_mlp_gather_bf16x3, the 4x4x48 level on the fp32
+    matrix cores): L3 K16, B = 512 - bits/dim inside the 1e-4 gate against the oracle, inverse and sampled pixels within 1e-4 of the
+    oracle evaluated in fp64 (element-wise), determinism, and the split kernel really ran."""
+    from normalizing_flow import calculate_loss
+    flow, prior = _north_star("f32")
+    x_np, _, _ = images_5bit("ns", (512, 3, 32, 32), 7)
+    x = T(x_np).to(DEV)
+    K.set_f32_coupling("bf16x3")
+    try:
+        ldj, logp = z64(512), z64(512)
+        K.start_trace()
+        zs, _, _ = flow.transform(x, ldj, logp)
+        labels = [e["label"] for e in K.stop_trace()]
+        assert sum(lb.startswith("coupling_mlp_x3") for lb in labels) == 32, labels      # 16 flows at each of the two levels
+        logp += prior.compute_log_prob(zs[-1])
+        ldj_b, logp_b = z64(512), z64(512)
+        zs_b, _, _ = flow.transform(x, ldj_b, logp_b)
+        assert all(torch.equal(a, b) for a, b in zip(zs, zs_b)) and torch.equal(ldj, ldj_b)
+        sd = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
+        psd = {k: v.detach().cpu() for k, v in prior.state_dict().items()}
+        zo, ldj_o, logp_o, bpd_o = O.fwd_nll(T(x_np[:4]), sd, psd, 3, 16)
+        bpd4 = calculate_loss((ldj + logp)[:4].contiguous(), 32.0, 3072.0)
+        record("north_star_f32x3_bpd_vs_oracle", relerr(bpd4, bpd_o))
+        assert_close(bpd4, bpd_o, TOL, "bpd vs oracle (split products)")
+        for i, (a, b) in enumerate(zip(zs, zo)):
+            record(f"north_star_f32x3_z{i}_vs_oracle", relerr_elem(a[:4], b))
+            assert_close(a[:4], b, 1e-3, f"z{i} vs oracle (split products)")
+        sd64 = {k: v.double() for k, v in sd.items()}
+        z_in = [z[:4].cpu().contiguous() for z in zs]
+        g = torch.Generator().manual_seed(5)
+        eps = [torch.randn(4, 12, 8, 8, generator=g), torch.randn(4, 6, 16, 16, generator=g)]
+        for what, lat, kw in (("x_rec", z_in, {}), ("sampled pixels", [z_in[-1]], {"temperature": 0.7, "eps": eps})):
+            truth = O.glow_inv([z.double() for z in lat], sd64, 3, 16, kw.get("temperature", 1.0), [e.double() for e in eps] if kw else None)
+            hip = flow.invert([z.to(DEV) for z in lat], **({"temperature": 0.7, "eps": [e.to(DEV) for e in eps]} if kw else {}))
+            e_hip = relerr_elem(hip, truth)
+            record(f"north_star_f32x3_{what.replace(' ', '_')}_vs_fp64_truth", e_hip)
+            assert e_hip <= TOL, f"{what}: {e_hip:.2e} vs fp64 truth"
+    finally:
+        K.set_f32_coupling("mfma_f32")
+
+
 BF16_DEEP_Z_TOL = 5e-2     # 48 flows of bf16-operand networks: latents / pixels (fp32 state, 8-bit-mantissa network inputs)
 
 
