@@ -179,6 +179,18 @@ int nfdp_coupling_inv_f32(float* y, const float* h, int B, int HW, int C, nfdp_s
 size_t nfdp_tap_coupling_ws_bytes(int B, int HW, int C);
 int nfdp_tap_coupling_f32(float* x, const float* T, int B, int H, int W, int C, const float* add, const float* mul, float f, double* ldj,
                           const float* ldj_const, void* ws, int inverse, nfdp_stream_t stream);
+/* nfdp_tap_coupling_f32 with the ADJOINING flow head applied to the finished pixel in the same pass (one launch and one pass over the
+ * flow state per flow instead of two; bit-identical to them).  Forward (inverse = 0): the coupling of this flow, then the NEXT flow's
+ * ActNorm + 1x1 conv (reference glow.py:40-45 order actnorm -> invconv -> coupling; head_scale / head_bias [C], head_w [C][C]), and the
+ * next flow's two log-det constants to head_const_out [2] (may be NULL; head_logabsdet [1] or NULL).  Inverse: the coupling's inverse,
+ * then THIS flow's inverse head (head_w = W^-1: x = (W^-1 y) e^-s - b, transforms.py:86-93, :139-146).  C in {4, 8, 12, 16, 24, 32, 48}
+ * (nfdp_tap_coupling_head_supported); ws: nfdp_tap_coupling_head_ws_bytes (forward with ldj). */
+int nfdp_tap_coupling_head_supported(int C);
+size_t nfdp_tap_coupling_head_ws_bytes(int B, int HW, int C);
+int nfdp_tap_coupling_head_f32(float* x, const float* T, int B, int H, int W, int C, const float* add, const float* mul, float f,
+                               double* ldj, const float* ldj_const, void* ws, int inverse, const float* head_scale,
+                               const float* head_bias, const float* head_w, const float* head_logabsdet, float* head_const_out,
+                               nfdp_stream_t stream);
 /* coupling_fwd for large images at small batch: the pixels of a sample spread over several workgroups, chunk sums of the log-det in
  * ws (nfdp_coupling_chunked_ws_bytes; 0 = use nfdp_coupling_fwd_f32), added to ldj in chunk order by a second launch. */
 size_t nfdp_coupling_chunked_ws_bytes(int B, int HW, int C);

@@ -162,6 +162,139 @@ __global__ void __launch_bounds__(kBlock) tap_coupling_kernel(float* __restrict_
     }
 }
 
+// ----------------------------------------------------------------------------- tap sums + coupling + the adjoining flow head
+// tap_coupling_kernel with the per-pixel C x C product of the ADJOINING flow head behind the coupling, while the pixel is on chip:
+//   forward:  x <- W' (e^{s'} (y + b'))   with y the coupling's output and (s', b', W') the NEXT flow's ActNorm / 1x1 conv
+//             (reference glow.py:40-45: actnorm -> invconv -> coupling; the first flow's head stays a launch of its own);
+//   inverse:  x <- (W^-1 y) e^{-s} - b    with (s, b, W^-1) THIS flow's (transforms.py:86-93, :139-146).
+// One launch and one pass over the flow state per flow instead of two.  Same expressions in the same order as pixel_linear_kernel
+// (e^s (v + b) per element, then one fmaf chain per output over ascending input channels): bit-identical to the two launches.
+// A workgroup walks groups of PPB whole pixels: G = (C/2)/VEC threads per pixel compute the coupling for VEC channels each (as
+// tap_coupling_kernel), the finished pixels (both halves) meet in LDS, then the same thread produces the 2 VEC outputs that replace the
+// values it loaded.  Workgroup (0, 0) also emits the head's two batch-independent log-det terms (forward), as pixel_linear_kernel does.
+template <bool INV, int C>
+__global__ void __launch_bounds__(kBlock) tap_coupling_head_kernel(float* __restrict__ x, const float* __restrict__ T, int H, int W,
+                                                                   const float* __restrict__ add, const float* __restrict__ mul, float f,
+                                                                   double* __restrict__ ldj, const float* __restrict__ ldj_const,
+                                                                   double* __restrict__ part, const float* __restrict__ hscale,
+                                                                   const float* __restrict__ hbias, const float* __restrict__ hw,
+                                                                   const float* __restrict__ hlad, float* __restrict__ hconst_out) {
+    constexpr int Ch = C / 2, VEC = Ch % 4 == 0 ? 4 : 2, G = Ch / VEC, PPB = kBlock / G, LD = C + 4;
+    static_assert(C % 4 == 0 && C <= 48, "channel counts of the tiled levels");
+    typedef float vec_t __attribute__((ext_vector_type(VEC)));
+    __shared__ __attribute__((aligned(16))) float xs[PPB * LD];
+    __shared__ __attribute__((aligned(16))) float ws[C * C];
+    __shared__ float es[C], bs[C];
+    __shared__ double red[kBlock / 64];
+    const int HW = H * W, ld = 9 * C;
+    const long base = (long)blockIdx.x * HW;
+    for (int i = threadIdx.x; i < C * C; i += kBlock) ws[i] = hw[i];
+    for (int c = threadIdx.x; c < C; c += kBlock) {
+        es[c] = expf(INV ? -hscale[c] : hscale[c]);
+        bs[c] = hbias[c];
+    }
+    if (!INV && hconst_out != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 64) {
+        double sacc = 0.0;
+        for (int c = threadIdx.x; c < C; c += 64) sacc += (double)hscale[c];
+        sacc = wave_sum_d(sacc);
+        if (threadIdx.x == 0) {
+            hconst_out[0] = __fmul_rn((float)HW, (float)sacc);
+            hconst_out[1] = hlad ? __fmul_rn((float)HW, hlad[0]) : 0.0f;
+        }
+    }
+    const int per = (HW + gridDim.y - 1) / gridDim.y;
+    const int q0 = blockIdx.y * per, q1 = (q0 + per) < HW ? (q0 + per) : HW;
+    const int pl = threadIdx.x / G, g = threadIdx.x - pl * G, c = g * VEC;
+    double acc = 0.0;
+    for (int q = q0; q < q1; q += PPB) {
+        const int p = q + pl;
+        const bool valid = pl < PPB && p < q1;
+        __syncthreads();                                     // the previous group's rows are consumed (first pass: ws / es / bs staged)
+        if (valid) {
+            const int xx = p % W, y = p / W;
+            float a_ls[VEC], a_t[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { a_ls[j] = 0.f; a_t[j] = 0.f; }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                const bool ok = (unsigned)(y + dy) < (unsigned)H && (unsigned)(xx + dx) < (unsigned)W;
+                const float* row = T + (base + (ok ? p + (long)dy * W + dx : p)) * ld + tap * C + c;
+                const vec_t u = *reinterpret_cast<const vec_t*>(row), v = *reinterpret_cast<const vec_t*>(row + Ch);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) { a_ls[j] += ok ? u[j] : 0.f; a_t[j] += ok ? v[j] : 0.f; }
+            }
+            const float* xp = x + (base + p) * C + c;
+            const vec_t xa = *reinterpret_cast<const vec_t*>(xp);
+            vec_t xv = *reinterpret_cast<const vec_t*>(xp + Ch);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float log_s = __fmul_rn(__fadd_rn(a_ls[j], add[c + j]), expf(__fmul_rn(f, mul[c + j])));
+                float t = __fmul_rn(__fadd_rn(a_t[j], add[Ch + c + j]), expf(__fmul_rn(f, mul[Ch + c + j])));
+                asm volatile("" : "+v"(log_s), "+v"(t));     // (as tap_coupling_kernel: the two-pass rounding points)
+                const float s = sigmoid_p2(log_s);
+                if (!INV) {
+                    xv[j] = __fmul_rn(__fadd_rn(xv[j], t), s);
+                    acc += (double)logf(__fadd_rn(s, 1e-6f));
+                } else {
+                    xv[j] = __fsub_rn(__fdiv_rn(xv[j], __fadd_rn(s, 1e-6f)), t);
+                }
+            }
+            float* r = xs + pl * LD;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                float va = xa[j], vb = xv[j];
+                asm volatile("" : "+v"(va), "+v"(vb));       // the flow state as the two launches hand it over in memory
+                r[c + j] = INV ? va : es[c + j] * (va + bs[c + j]);
+                r[Ch + c + j] = INV ? vb : es[Ch + c + j] * (vb + bs[Ch + c + j]);
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            float v[C];
+            const float4* r4 = reinterpret_cast<const float4*>(xs + pl * LD);
+#pragma unroll
+            for (int i = 0; i < C / 4; ++i) {
+                const float4 t4 = r4[i];
+                v[4 * i] = t4.x; v[4 * i + 1] = t4.y; v[4 * i + 2] = t4.z; v[4 * i + 3] = t4.w;
+            }
+            float* xp = x + (base + p) * C + c;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                vec_t out;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    const int o = half * Ch + c + j;
+                    const float4* w4 = reinterpret_cast<const float4*>(ws + o * C);
+                    float a = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < C / 4; ++i) {
+                        const float4 wv = w4[i];
+                        a = fmaf(wv.x, v[4 * i], a);
+                        a = fmaf(wv.y, v[4 * i + 1], a);
+                        a = fmaf(wv.z, v[4 * i + 2], a);
+                        a = fmaf(wv.w, v[4 * i + 3], a);
+                    }
+                    if (INV) a = __fsub_rn(__fmul_rn(a, es[o]), bs[o]);
+                    out[j] = a;
+                }
+                *reinterpret_cast<vec_t*>(xp + half * Ch) = out;
+            }
+        }
+    }
+    if (!INV && (ldj || part)) {
+        const double s = block_sum_d(acc, red);
+        if (threadIdx.x == 0) {
+            if (part) part[(size_t)blockIdx.x * gridDim.y + blockIdx.y] = s;
+            else {
+                double v = ldj[blockIdx.x];
+                if (ldj_const) v = (v + (double)ldj_const[0]) + (double)ldj_const[1];
+                ldj[blockIdx.x] = v + s;
+            }
+        }
+    }
+}
+
 __global__ void coupling_ldj_finish_kernel(double* __restrict__ ldj, int B, const double* __restrict__ part, int nch,
                                            const float* __restrict__ ldj_const) {
     const int b = blockIdx.x * kBlock + threadIdx.x;
@@ -340,6 +473,66 @@ extern "C" int nfdp_tap_coupling_f32(float* x, const float* T, int B, int H, int
     if (part)
         hipLaunchKernelGGL(coupling_ldj_finish_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ldj, B, part, nch, ldj_const);
     NFDP_CHECK_LAUNCH("tap_coupling");
+    return NFDP_OK;
+}
+
+// chunks per sample of the head-fused pass: 1-4 groups of PPB whole pixels per workgroup, ~1024 workgroups when the batch has that many groups
+static int tap_head_ppb(int C) { return kBlock / ((C / 2) / tap_vec(C)); }
+static int tap_head_chunks(int B, int HW, int C) {
+    const int ppb = tap_head_ppb(C);
+    const long groups = (HW + ppb - 1) / ppb;
+    long k = (long)B * groups / 1024;
+    k = k < 1 ? 1 : (k > 4 ? 4 : k);
+    const long nch = (groups + k - 1) / k;
+    return (int)(nch > 256 ? 256 : nch);
+}
+
+extern "C" int nfdp_tap_coupling_head_supported(int C) {
+    return C == 4 || C == 8 || C == 12 || C == 16 || C == 24 || C == 32 || C == 48;
+}
+
+extern "C" size_t nfdp_tap_coupling_head_ws_bytes(int B, int HW, int C) {
+    if (!nfdp_tap_coupling_head_supported(C)) return 0;
+    const int nch = tap_head_chunks(B, HW, C);
+    return nch > 1 ? (size_t)B * nch * sizeof(double) : 0;
+}
+
+extern "C" int nfdp_tap_coupling_head_f32(float* x, const float* T, int B, int H, int W, int C, const float* add, const float* mul, float f,
+                                          double* ldj, const float* ldj_const, void* ws, int inverse, const float* head_scale,
+                                          const float* head_bias, const float* head_w, const float* head_logabsdet, float* head_const_out,
+                                          nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && T && add && mul && head_scale && head_bias && head_w, NFDP_EINVAL, "tap_coupling_head: null pointer");
+    NFDP_REQUIRE(B >= 0 && H > 0 && W > 0, NFDP_ESHAPE, "tap_coupling_head: bad shape");
+    NFDP_REQUIRE(nfdp_tap_coupling_head_supported(C), NFDP_EUNSUPPORTED, "tap_coupling_head: unsupported C=%d", C);
+    if (B == 0) return NFDP_OK;
+    NFDP_REQUIRE((((uintptr_t)x | (uintptr_t)T) & 15) == 0 || C % 8 != 0, NFDP_ESHAPE, "tap_coupling_head: tensors must be 16-byte aligned");
+    NFDP_REQUIRE((((uintptr_t)x | (uintptr_t)T) & 7) == 0, NFDP_ESHAPE, "tap_coupling_head: tensors must be 8-byte aligned");
+    const int nch = tap_head_chunks(B, H * W, C);
+    hipStream_t s = as_stream(stream);
+    double* part = nullptr;
+    if (!inverse) {
+        NFDP_REQUIRE(nch == 1 || ws || !ldj, NFDP_EINVAL, "tap_coupling_head: needs nfdp_tap_coupling_head_ws_bytes of workspace");
+        part = (nch > 1 && ldj) ? reinterpret_cast<double*>(ws) : nullptr;
+    }
+    double* l = inverse ? nullptr : ldj;
+    const float* lc = inverse ? nullptr : ldj_const;
+#define NFDP_TCH(CC)                                                                                                                     \
+    case CC:                                                                                                                             \
+        if (inverse)                                                                                                                     \
+            hipLaunchKernelGGL((tap_coupling_head_kernel<true, CC>), dim3(B, nch), dim3(kBlock), 0, s, x, T, H, W, add, mul, f, l, lc,  \
+                               part, head_scale, head_bias, head_w, head_logabsdet, head_const_out);                                    \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((tap_coupling_head_kernel<false, CC>), dim3(B, nch), dim3(kBlock), 0, s, x, T, H, W, add, mul, f, l, lc, \
+                               part, head_scale, head_bias, head_w, head_logabsdet, head_const_out);                                    \
+        break;
+    switch (C) {
+        NFDP_TCH(4) NFDP_TCH(8) NFDP_TCH(12) NFDP_TCH(16) NFDP_TCH(24) NFDP_TCH(32) NFDP_TCH(48)
+        default: break;
+    }
+#undef NFDP_TCH
+    if (part)
+        hipLaunchKernelGGL(coupling_ldj_finish_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ldj, B, part, nch, ldj_const);
+    NFDP_CHECK_LAUNCH("tap_coupling_head");
     return NFDP_OK;
 }
 

@@ -501,6 +501,42 @@ def tap_coupling(xh, t, add, mul, mul_exp: float, ldj: Optional[torch.Tensor], l
           label=f"tap_coupling<{'inv' if inverse else 'fwd'}>", nbytes=4.0 * (t.numel() + xh.numel()))
 
 
+TAP_HEAD_FUSION = True      # tiled levels: the adjoining flow head inside the tap + coupling pass (False: two launches per flow)
+
+
+def tap_coupling_head_supported(c: int) -> bool:
+    return TAP_HEAD_FUSION and bool(lib().nfdp_tap_coupling_head_supported(c))
+
+
+def tap_coupling_head(xh, t, add, mul, mul_exp: float, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.Tensor], inverse: bool,
+                      head_scale, head_bias, head_w, head_logabsdet=None, want_const: bool = False):
+    """tap_coupling with the adjoining flow head in the same pass (nfdp_tap_coupling_head_f32).  Forward: (head_scale, head_bias,
+    head_w) are the NEXT flow's ActNorm / 1x1-conv parameters; returns that flow's [2] log-det constants when want_const.  Inverse: THIS
+    flow's ActNorm parameters and W^-1."""
+    _dense(xh, "tap_coupling_head"); _dense(t, "tap_coupling_head")
+    _need(xh, torch.float32, "tap_coupling_head"); _need(t, torch.float32, "tap_coupling_head")
+    b, h, w, c = xh.shape
+    if t.shape[-1] != 9 * c:
+        raise ValueError(f"tap_coupling_head: {t.shape[-1]} tap contributions for {c} channels")
+    for q in (head_scale, head_bias, head_w):
+        _need(q, torch.float32, "tap_coupling_head"); _dense(q, "tap_coupling_head")
+    if head_scale.numel() != c or head_bias.numel() != c or head_w.numel() != c * c:
+        raise ValueError("tap_coupling_head: head parameter shapes")
+    ws = None
+    if not inverse and ldj is not None:
+        _need(ldj, torch.float64, "tap_coupling_head ldj")
+        nbytes = lib().nfdp_tap_coupling_head_ws_bytes(b, h * w, c)
+        if nbytes:
+            ws = torch.empty(nbytes, device=xh.device, dtype=torch.uint8)
+    cst = torch.empty(2, device=xh.device, dtype=torch.float32) if (want_const and not inverse) else None
+    _call("nfdp_tap_coupling_head_f32", _ptr(xh), _ptr(t), b, h, w, c, _ptr(add), _ptr(mul), float(mul_exp),
+          _ptr(None if inverse else ldj), _ptr(None if inverse else ldj_const), _ptr(ws), int(inverse), _ptr(head_scale), _ptr(head_bias),
+          _ptr(head_w), _ptr(None if inverse else head_logabsdet), _ptr(cst), _stream(),
+          label=f"tap_coupling_head<{'inv' if inverse else 'fwd'},{c}>", nbytes=4.0 * (t.numel() + 2 * xh.numel()),
+          flops=2.0 * xh.numel() * c)
+    return cst
+
+
 def coupling_inv(yh, hh):
     _dense(yh, "coupling_inv"); _dense(hh, "coupling_inv")
     b, h, w, c = yh.shape

@@ -31,10 +31,16 @@ class StepFlow(Transform):
         self.affcoupling = AffineCoupling(in_channels=in_channels, n_features=coupling_net_n_features, compute=compute)
 
     def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], logabsdet: Optional[Tensor] = None,
-                        defer_logdet: bool = False) -> Tensor:
+                        defer_logdet: bool = False, head_done=None, next_head=None):
         """In place on xh.  logabsdet: this flow's [1] fp32 entry of the level's batched log|det| launch;
-        defer_logdet=True leaves the 1x1-conv log-det out (the caller adds the level's sum at the end)."""
+        defer_logdet=True leaves the 1x1-conv log-det out (the caller adds the level's sum at the end).
+        head_done / next_head (the level loop, _run_flows_fwd): head_done = (const,) says the previous flow's launch already applied this
+        flow's head (const: its [2] log-det constants or None); next_head = the next flow's head parameters, handed to the coupling
+        (AffineCoupling.transform_nhwc_).  With next_head given the call returns (xh, head_done for the next flow | None)."""
         an, ic = self.actnorm, self.invconv2d
+        if head_done is not None:
+            out = self.affcoupling.transform_nhwc_(xh, ldj, head_done[0], next_head=next_head)
+            return out if next_head is None else ((out[0], (out[1],)) if isinstance(out, tuple) else (out, None))
         if not an.initialized():
             an.init_from(xh)
         packed = self.affcoupling._fused_pack(xh)
@@ -46,7 +52,7 @@ class StepFlow(Transform):
             if ldj is not None and logabsdet is not None:
                 term = K.flow_ldj_consts(an.scale.view(-1), logabsdet, xh.shape[1] * xh.shape[2])[1:]
             K.stepflow_fused(xh, packed, an.scale.view(-1), an.bias.view(-1), ic._w(), ldj, term, inverse=False)
-            return xh
+            return xh if next_head is None else (xh, None)
         const = None
         if ldj is not None:
             if logabsdet is None and not defer_logdet:
@@ -54,7 +60,16 @@ class StepFlow(Transform):
             _, const = K.flow_head_fwd(xh, an.scale.view(-1), an.bias.view(-1), ic._w(), logabsdet, out=xh)
         else:
             K.actnorm_invconv_fwd(xh, an.scale.view(-1), an.bias.view(-1), ic._w(), out=xh)
-        return self.affcoupling.transform_nhwc_(xh, ldj, const)
+        out = self.affcoupling.transform_nhwc_(xh, ldj, const, next_head=next_head)
+        return out if next_head is None else ((out[0], (out[1],)) if isinstance(out, tuple) else (out, None))
+
+    def head_params(self, ldj: Optional[Tensor], logabsdet: Optional[Tensor], defer_logdet: bool):
+        """(scale, bias, W, logabsdet | None) for a neighbour's fused pass, or None while the ActNorm awaits its data-dependent init
+        or the log-det term would have to be computed here (no level table)."""
+        an, ic = self.actnorm, self.invconv2d
+        if not an.initialized() or (ldj is not None and logabsdet is None and not defer_logdet):
+            return None
+        return an.scale.view(-1), an.bias.view(-1), ic._w(), (logabsdet if ldj is not None else None)
 
     def invert_nhwc_(self, yh: Tensor, winv: Optional[Tensor] = None) -> Tensor:
         an, ic = self.actnorm, self.invconv2d
@@ -64,7 +79,9 @@ class StepFlow(Transform):
         if packed is not None and K.coupling_fused_has_head(yh.shape[1], yh.shape[2], yh.shape[3]):
             K.stepflow_fused(yh, packed, an.scale.view(-1), an.bias.view(-1), winv.reshape(-1), None, None, inverse=True)
             return yh
-        self.affcoupling.invert_nhwc_(yh)
+        out = self.affcoupling.invert_nhwc_(yh, head=(an.scale.view(-1), an.bias.view(-1), winv.reshape(-1)))
+        if isinstance(out, tuple):                # the tap + coupling pass applied the inverse head too
+            return yh
         return K.invconv_actnorm_inv(yh, an.scale.view(-1), an.bias.view(-1), winv, out=yh)
 
     def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
@@ -160,8 +177,17 @@ def _run_flows_fwd(flows: Sequence[StepFlow], xh: Tensor, ldj: Optional[Tensor],
             return xh
     if ldj is not None and lads is None and not defer_logdet:
         lads = _level_logdets(flows)
+    done = None                                   # (const,): the previous flow's launch applied this flow's head already
     for i, f in enumerate(flows):
-        xh = f.transform_nhwc_(xh, ldj, None if lads is None else lads[i:i + 1], defer_logdet)
+        lad = None if lads is None else lads[i:i + 1]
+        nxt = None
+        if i + 1 < len(flows):                    # the next flow's head rides in this flow's tap + coupling pass where that pass exists
+            nxt = flows[i + 1].head_params(ldj, None if lads is None else lads[i + 1:i + 2], defer_logdet)
+        if nxt is None:
+            xh = f.transform_nhwc_(xh, ldj, lad, defer_logdet, head_done=done)
+            done = None
+        else:
+            xh, done = f.transform_nhwc_(xh, ldj, lad, defer_logdet, head_done=done, next_head=nxt)
     return xh
 
 

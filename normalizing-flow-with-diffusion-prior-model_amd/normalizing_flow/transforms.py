@@ -187,8 +187,11 @@ class AffineCoupling(Transform):
         zc = self.net[-1]
         return K.use_tap_conv(zc.in_channels, zc.out_channels, zc.filter_size, K.BF16)
 
-    def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], ldj_const: Optional[Tensor] = None) -> Tensor:
-        """In place on xh's second channel half.  ldj_const: device [2] fp32 added before the coupling sum."""
+    def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], ldj_const: Optional[Tensor] = None, next_head=None):
+        """In place on xh's second channel half.  ldj_const: device [2] fp32 added before the coupling sum.
+        next_head: optional (scale [C], bias [C], W [C,C], logabsdet [1] | None) of the NEXT flow's ActNorm + 1x1 conv.  Where the layer
+        runs as tap contributions + one pass (K.tap_coupling) that pass applies the head too and the call returns (xh, const) with the
+        next flow's [2] log-det constants (None when ldj is None); otherwise xh alone - the caller then runs the head itself."""
         packed = self._fused_pack(xh)
         if packed is not None:
             K.coupling_fused(xh, packed, ldj, ldj_const, inverse=False)
@@ -196,13 +199,19 @@ class AffineCoupling(Transform):
         t = self._net_taps_nhwc(xh)
         if t is not None:
             zc = self.net[-1]
+            if next_head is not None and K.tap_coupling_head_supported(xh.shape[-1]):
+                cst = K.tap_coupling_head(xh, t, zc.bias, zc.logs.view(-1), zc.logscale_factor, ldj, ldj_const, False,
+                                          next_head[0], next_head[1], next_head[2], next_head[3], want_const=ldj is not None)
+                return xh, cst
             K.tap_coupling(xh, t, zc.bias, zc.logs.view(-1), zc.logscale_factor, ldj, ldj_const, inverse=False)
             return xh
         h = self._net_nhwc(xh)
         K.coupling_fwd(xh, h, ldj, ldj_const)
         return xh
 
-    def invert_nhwc_(self, yh: Tensor) -> Tensor:
+    def invert_nhwc_(self, yh: Tensor, head=None):
+        """head: optional (scale [C], bias [C], W^-1 [C,C]) of THIS flow's ActNorm + 1x1 conv; where the layer runs as tap contributions +
+        one pass, that pass applies the inverse head too and the call returns (yh, True); otherwise yh alone."""
         packed = self._fused_pack(yh)
         if packed is not None:
             K.coupling_fused(yh, packed, None, None, inverse=True)
@@ -210,6 +219,9 @@ class AffineCoupling(Transform):
         t = self._net_taps_nhwc(yh)
         if t is not None:
             zc = self.net[-1]
+            if head is not None and K.tap_coupling_head_supported(yh.shape[-1]):
+                K.tap_coupling_head(yh, t, zc.bias, zc.logs.view(-1), zc.logscale_factor, None, None, True, head[0], head[1], head[2])
+                return yh, True
             K.tap_coupling(yh, t, zc.bias, zc.logs.view(-1), zc.logscale_factor, None, None, inverse=True)
             return yh
         h = self._net_nhwc(yh)

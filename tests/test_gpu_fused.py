@@ -475,3 +475,69 @@ def test_tap_coupling_is_bit_identical_to_shift_sum_then_coupling(c, h, w, b):
         assert torch.equal(xa, xb), (inverse, float((xa - xb).abs().max()))
         if not inverse:
             assert float((la - lb).abs().max()) <= 1e-9 * float(la.abs().max()), (la, lb)      # (chunk counts differ: fp64 sums of the same terms)
+
+
+@pytest.mark.parametrize("c,h,w,b", [(12, 64, 64, 3), (24, 32, 32, 2), (48, 16, 16, 3), (12, 20, 12, 2), (4, 14, 14, 5), (8, 7, 7, 4), (16, 6, 10, 3),
+                                     (32, 8, 8, 2)])
+@torch.no_grad()
+def test_tap_coupling_with_the_adjoining_head_is_bit_identical_to_two_launches(c, h, w, b):
+    """nfdp_tap_coupling_head_f32: forward = tap + coupling pass, then the NEXT flow's ActNorm + 1x1 conv on the finished pixel;
+    inverse = the pass, then THIS flow's inverse head - against nfdp_tap_coupling_f32 followed by the head launches
+    (nfdp_flow_head_fwd_f32 / nfdp_invconv_actnorm_inv_f32): same expressions in the same order -> bit-identical flow state and log-det
+    constants; ldj to fp64 summation order.  Ragged pixel groups (85 / 42 pixels per workgroup pass), chunked and unchunked images."""
+    assert K.tap_coupling_head_supported(c)
+    g = torch.Generator().manual_seed(c * 11 + h)
+    t = (torch.randn(b, h, w, 9 * c, generator=g) * 0.3).to(DEV)
+    x0 = (torch.randn(b, h, w, c, generator=g)).to(DEV)
+    add, mul = (torch.randn(c, generator=g) * 0.1).to(DEV), (torch.randn(c, generator=g) * 0.05).to(DEV)
+    hs, hb = (torch.randn(c, generator=g) * 0.2).to(DEV), (torch.randn(c, generator=g) * 0.3).to(DEV)
+    wm = (torch.linalg.qr(torch.randn(c, c, generator=g))[0] + 0.05 * torch.randn(c, c, generator=g)).contiguous().to(DEV)
+    lad = torch.tensor([0.3125], device=DEV)
+    const = torch.tensor([0.75, -1.25], device=DEV)
+    for inverse in (False, True):
+        xa, xb = x0.clone(), x0.clone()
+        la = torch.full((b,), 2.0, dtype=torch.float64, device=DEV)
+        lb = la.clone()
+        K.tap_coupling(xa, t, add, mul, 3.0, la, const, inverse=inverse)
+        if inverse:
+            K.invconv_actnorm_inv(xa, hs, hb, wm, out=xa)
+            K.tap_coupling_head(xb, t, add, mul, 3.0, None, None, True, hs, hb, wm.reshape(-1))
+        else:
+            _, ca = K.flow_head_fwd(xa, hs, hb, wm, lad, out=xa)
+            cb = K.tap_coupling_head(xb, t, add, mul, 3.0, lb, const, False, hs, hb, wm, lad, want_const=True)
+            assert torch.equal(ca, cb), (ca, cb)
+            assert float((la - lb).abs().max()) <= 1e-9 * float(la.abs().max()), (la, lb)
+        assert torch.equal(xa, xb), (inverse, float((xa - xb).abs().max()))
+
+
+@torch.no_grad()
+def test_level_loop_with_fused_heads_matches_flow_by_flow():
+    """glow._run_flows_fwd / _run_flows_inv on a tiled level (16x16x48, the third level of a 128x128 model): with the adjoining heads
+    inside the tap + coupling passes (K.TAP_HEAD_FUSION, default) and without - bit-identical flow state, ldj to fp64 summation order,
+    and one launch less per flow."""
+    from normalizing_flow.glow import StepFlow, _run_flows_fwd, _run_flows_inv
+    c, hw, b, nf = 48, 16, 6, 3
+    flows = []
+    for i in range(nf):
+        f = StepFlow(in_channels=c, compute="bf16")
+        f.load_state_dict({k: T(synth_tensor(f"blocks.2.flows.{i}." + k, v.shape, 3, DEEP)) for k, v in f.state_dict().items()}, strict=True)
+        flows.append(f.to(DEV))
+    x0 = K.to_nhwc(T(synth_input("lvl48", (b, c, hw, hw), 9)).to(DEV) * 0.6).contiguous()
+    outs = {}
+    for fused in (True, False):
+        K.TAP_HEAD_FUSION = fused
+        try:
+            xa = x0.clone()
+            la = torch.zeros(b, dtype=torch.float64, device=DEV)
+            K.start_trace()
+            _run_flows_fwd(flows, xa, la, None, defer_logdet=True)
+            n_fwd = len([e for e in K.stop_trace() if not e["label"].startswith("nfdp_coupling_fused_pack")])
+            ya = xa.clone()
+            _run_flows_inv(flows, ya)
+            outs[fused] = (xa, la, ya, n_fwd)
+        finally:
+            K.TAP_HEAD_FUSION = True
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][2], outs[False][2])
+    assert float((outs[True][1] - outs[False][1]).abs().max()) <= 1e-9 * float(outs[False][1].abs().max())
+    assert outs[True][3] == outs[False][3] - (nf - 1), (outs[True][3], outs[False][3])
+    assert relerr(outs[True][2], x0) < 2e-2                                            # round trip at bf16 accuracy
