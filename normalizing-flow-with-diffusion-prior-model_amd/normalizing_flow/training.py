@@ -64,7 +64,7 @@ def _slot(p):
 # (behind everything enqueued so far) and joined once per level / node; under a captured step they become parallel branches of the
 # hipGraph.  Tensors they read are kept referenced until the join, so the caching allocator cannot hand their memory to a
 # main-stream launch while the side stream still reads it.
-WGRAD_SIDE_STREAM = True
+WGRAD_SIDE_STREAM = __import__("os").environ.get("NFDP_WGRAD_SIDE_STREAM", "1") != "0"
 # Activation recomputation for the fused training path (reference trainer.py:163-167 keeps every activation): 0 = keep the
 # hidden activations of all flows (fastest, 9.7 GiB at B = 512 L3 K16); G > 0 = keep only the flow-state tensors and, in the backward
 # pass, re-run the training forward of G flows at a time from the group's saved input (bit-identical activations, so bit-identical
