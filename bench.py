@@ -566,6 +566,19 @@ def other_config_legs(args, device):
                               "workload": "Glow L5 K16 128x128x3 forward+NLL / inverse / sampling inverse (T=0.7), batch 32, hipGraph replay "
                                           "(BASELINE configs[4] shape; glow.py:172-228)"}
             log(f"leg celeba: fwd {legs['celeba']['forward_ms']} ms, inverse {legs['celeba']['inverse_ms']} ms")
+            if args.compute == "bf16":
+                # the same model in the fp32 mode: exact fp32 products, and products from two-piece bf16 splits where that kernel exists
+                # (the 64x64x12 and 32x32x24 levels; wider levels on the fp32 matrix cores / per-op fp32 kernels)
+                flow.set_compute("f32")
+                for label, mode in (("f32", "mfma_f32"), ("f32x3", "bf16x3")):
+                    KH.set_f32_coupling(mode)
+                    try:
+                        _, ldj2, logp2 = fwd()
+                        legs["celeba"][f"forward_{label}_ms"] = round(timed_graph(fwd, 4) * 1e3, 3)
+                        legs["celeba"][f"bits_per_dim_{label}"] = round(float((-(ldj2 + logp2) / (np.log(2.0) * 128 * 128 * 3) + 5.0).mean()), 6)
+                    finally:
+                        KH.set_f32_coupling("mfma_f32")
+                log(f"leg celeba fp32: {legs['celeba']['forward_f32_ms']} ms exact, {legs['celeba']['forward_f32x3_ms']} ms split products")
             del flow, prior, zs, lat
         except Exception as e:                                   # noqa: BLE001
             legs["celeba"] = {"error": f"{type(e).__name__}: {e}"}

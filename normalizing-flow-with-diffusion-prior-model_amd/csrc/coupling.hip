@@ -476,12 +476,12 @@ extern "C" int nfdp_tap_coupling_f32(float* x, const float* T, int B, int H, int
     return NFDP_OK;
 }
 
-// chunks per sample of the head-fused pass: 1-4 groups of PPB whole pixels per workgroup, ~1024 workgroups when the batch has that many groups
+// chunks per sample of the head-fused pass: 1-4 groups of PPB whole pixels per workgroup, ~768+ workgroups when the batch has that many groups (measured: 1568 one-group workgroups are slower than 800 of two)
 static int tap_head_ppb(int C) { return kBlock / ((C / 2) / tap_vec(C)); }
 static int tap_head_chunks(int B, int HW, int C) {
     const int ppb = tap_head_ppb(C);
     const long groups = (HW + ppb - 1) / ppb;
-    long k = (long)B * groups / 1024;
+    long k = (long)B * groups / 768;
     k = k < 1 ? 1 : (k > 4 ? 4 : k);
     const long nch = (groups + k - 1) / k;
     return (int)(nch > 256 ? 256 : nch);
