@@ -68,7 +68,11 @@ int nfdp_coupling_mlp_bf16(const void* xcol, int xcol_ld, long npix, const void*
 int nfdp_coupling_mlp_gather_bf16(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, nfdp_stream_t stream);
 /* Split-product form for the exact-fp32 mode: every fp32 product as hi*hi + hi*lo + lo*hi of two-piece bf16 splits of both operands
  * (three bf16 MFMAs against sixteen fp32-MFMA passes), fp32 accumulation; pixel error of a 48-flow inverse 4-6e-5.  packed_hi: the
- * nfdp_coupling_fused_pack image with fold_scales = 1, packed_lo: the same call with fold_scales = 3 (low pieces).  C <= 24. */
+ * nfdp_coupling_fused_pack image with fold_scales = 1, packed_lo: the same call with fold_scales = 3 (low pieces).  C <= 24 or C = 48. */
+/* Kernel form of the two entries around this comment: 0 (default) = the row-split form (32-pixel workgroups whose four waves split the
+ * weights; same images, bf16 results bit-identical) where the 128-pixel form would leave most CUs idle (<= 16384 pixels; C = 12, 24, 48),
+ * 1 = never, 2 = always.  The split-product form at C = 48 exists row-split only. */
+int nfdp_set_mlp_rows(int mode);
 int nfdp_coupling_mlp_gather_bf16x3(const float* x, int x_ld, int B, int H, int W, const void* packed_hi, const void* packed_lo, float* T,
                                     int C, nfdp_stream_t stream);
 /* The same network in EXACT fp32 (v_mfma_f32_32x32x2_f32: fp32 products and sums), hidden activations on chip: the fp32-accurate fast

@@ -1573,6 +1573,12 @@ def pointwise_dgrad_masked(xh: torch.Tensor, packed: torch.Tensor, y_saved: torc
 MLP_GATHER = True      # coupling_net_tiled: gather the first conv's operands inside the coupling-network kernel (False: explicit im2col)
 
 
+def set_mlp_rows(mode: str) -> None:
+    """Kernel form of the tiled coupling networks: "auto" (the row-split form - 32-pixel workgroups, the four waves split the weights -
+    where the 128-pixel form would leave most CUs idle: <= 16384 pixels), "never", "always".  bf16 results are bit-identical."""
+    _check(lib().nfdp_set_mlp_rows({"auto": 0, "never": 1, "always": 2}[mode]))
+
+
 def coupling_mlp_supported(c: int, n_features: int) -> bool:
     return n_features == 512 and c <= 48 and lib().nfdp_coupling_fused_packed_bytes(c) != 0
 
@@ -1622,7 +1628,7 @@ def set_f32_coupling(mode: str) -> None:
     """compute="f32": how the coupling networks form their fp32 products.  "mfma_f32" (default): v_mfma_f32_32x32x2_f32, exact fp32
     products.  "bf16x3": each product as hi*hi + hi*lo + lo*hi of two-piece bf16 splits of both operands (three bf16 MFMAs, fp32
     accumulation; relative product error ~4e-6, pixels of a 48-flow inverse 4-6e-5 from fp64) where the geometry has that kernel
-    (C <= 24; wider levels stay on the fp32 matrix cores)."""
+    (C <= 24 and C = 48; wider levels stay on the fp32 matrix cores)."""
     global _F32_COUPLING
     if mode not in ("mfma_f32", "bf16x3"):
         raise ValueError(f"set_f32_coupling: {mode!r}")
@@ -1634,8 +1640,8 @@ def get_f32_coupling() -> str:
 
 
 def coupling_mlp_x3_supported(xh_a: torch.Tensor, c: int, n_features: int) -> bool:
-    """The split-product kernel takes this coupling (mode on, C <= 24, pieces gathered with aligned vector loads)."""
-    if _F32_COUPLING != "bf16x3" or not _F32_FUSED or n_features != 512 or c > 24 or c % 4 or xh_a.dtype != torch.float32:
+    """The split-product kernels take this coupling (mode on, C <= 24 or C = 48, pieces gathered with aligned vector loads)."""
+    if _F32_COUPLING != "bf16x3" or not _F32_FUSED or n_features != 512 or (c > 24 and c != 48) or c % 4 or xh_a.dtype != torch.float32:
         return False
     if lib().nfdp_coupling_fused_packed_bytes(c) == 0:
         return False

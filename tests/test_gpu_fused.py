@@ -541,3 +541,72 @@ def test_level_loop_with_fused_heads_matches_flow_by_flow():
     assert float((outs[True][1] - outs[False][1]).abs().max()) <= 1e-9 * float(outs[False][1].abs().max())
     assert outs[True][3] == outs[False][3] - (nf - 1), (outs[True][3], outs[False][3])
     assert relerr(outs[True][2], x0) < 2e-2                                            # round trip at bf16 accuracy
+
+
+ROWS_GEOMS = [(48, 16, 16, 3), (48, 4, 4, 19), (24, 8, 8, 7), (24, 6, 10, 3), (12, 16, 16, 5), (12, 7, 5, 3), (48, 3, 5, 1)]
+
+
+@pytest.mark.parametrize("c,hh,ww,b", ROWS_GEOMS)
+@torch.no_grad()
+def test_row_split_tiled_network_is_bit_identical_to_the_128_pixel_form(c, hh, ww, b):
+    """coupling_mlp_rows_kernel (32-pixel workgroups, the waves split the output rows of every GEMM, hidden blocks through LDS) against
+    coupling_mlp_kernel (a wave walks its 32 pixels through all weights): same images, same bf16 operands, same k order in every
+    accumulator -> bit-identical tap contributions; ragged pixel counts (tail workgroup), images smaller than a tile, non-square images;
+    and against the oracle at the bf16 tolerance."""
+    from normalizing_flow import AffineCoupling
+    m = AffineCoupling(c, n_features=512, compute="bf16")
+    sd = {k: T(synth_tensor("flows.5.affcoupling." + k, v.shape, 13, DEEP)) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    x = T(synth_input(f"rows{c}_{hh}", (b, c, hh, ww), 5)) * 0.6
+    xh = K.to_nhwc(x.to(DEV)).contiguous()
+    zc = m.net[-1]
+    outs = {}
+    try:
+        for mode in ("never", "always"):
+            K.set_mlp_rows(mode)
+            outs[mode] = K.coupling_net_tiled(xh[..., : c // 2], m.net.fused_packed(1), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
+                                              return_taps=True).clone()
+        K.set_mlp_rows("always")
+        again = K.coupling_net_tiled(xh[..., : c // 2], m.net.fused_packed(1), c, zc.bias, zc.logs.view(-1), zc.logscale_factor, return_taps=True)
+        h_rows = K.coupling_net_tiled(xh[..., : c // 2], m.net.fused_packed(1), c, zc.bias, zc.logs.view(-1), zc.logscale_factor)
+    finally:
+        K.set_mlp_rows("auto")
+    assert torch.equal(outs["never"], outs["always"]), float((outs["never"] - outs["always"]).abs().max())
+    assert torch.equal(outs["always"], again)
+    osd = {"flows.5.affcoupling." + k: v for k, v in sd.items()}
+    assert relerr(K.as_nchw(h_rows), O.coupling_net(x[:, : c // 2], osd, "flows.5.affcoupling.net.")) < 1e-2      # bf16 operands
+
+
+@pytest.mark.parametrize("c,hh,ww,b", [(48, 4, 4, 19), (48, 16, 16, 2), (24, 8, 8, 7), (12, 6, 10, 3)])
+@torch.no_grad()
+def test_row_split_split_product_network_against_fp64(c, hh, ww, b):
+    """The row-split kernel in its split-product form (NP = 2: high / low images, three bf16 MFMAs per fp32 product; the only
+    split-product form at C = 48) against the oracle in fp64: 1e-4 of the tensor's scale is the bar, measured below 1e-5."""
+    from normalizing_flow import AffineCoupling
+    m = AffineCoupling(c, n_features=512, compute="f32")
+    sd = {k: T(synth_tensor("flows.3.affcoupling." + k, v.shape, 11, DEEP)) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    osd64 = {"flows.3.affcoupling." + k: v.double() for k, v in sd.items()}
+    x = T(synth_input(f"f32x{c}_{hh}", (b, c, hh, ww), 5)) * 0.6
+    xh = K.to_nhwc(x.to(DEV)).contiguous()
+    zc = m.net[-1]
+    h_ref = O.coupling_net(x[:, : c // 2].double(), osd64, "flows.3.affcoupling.net.")
+    K.set_f32_coupling("bf16x3")
+    K.set_mlp_rows("always")
+    try:
+        assert K.coupling_mlp_x3_supported(xh[..., : c // 2], c, 512)
+        h3 = K.coupling_net_tiled(xh[..., : c // 2], m.net.fused_packed(1), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
+                                  packed_lo=m.net.fused_packed(3))
+        e3 = relerr(K.as_nchw(h3), h_ref)
+        record(f"x3_rows_network_relerr_c{c}_h{hh}", e3)
+        assert e3 < 1e-4, e3
+        ldj = torch.zeros(b, dtype=torch.float64, device=DEV)
+        y, ldj, _ = m.transform(x.to(DEV), ldj, None)
+        yo, lo = O.coupling_fwd(x.double(), osd64, "flows.3.affcoupling.net.", torch.zeros(b, dtype=torch.float64))
+        assert_close(y, yo, 1e-4, "coupling forward (row-split split products)")
+        assert_close(ldj, lo, 1e-5, "coupling log-det (row-split split products)")
+    finally:
+        K.set_mlp_rows("auto")
+        K.set_f32_coupling("mfma_f32")
