@@ -200,8 +200,8 @@ def test_north_star_full_size_properties():
 
 @torch.no_grad()
 def test_north_star_split_product_mode_meets_the_pixel_gate():
-    """compute="f32" with K.set_f32_coupling("bf16x3") (levels 0 / 1 on nfdp_coupling_mlp_gather_bf16x3, the 4x4x48 level on the fp32
-    matrix cores): L3 K16, B = 512 - bits/dim inside the 1e-4 gate against the oracle, inverse and sampled pixels within 1e-4 of the
+    """compute="f32" with K.set_f32_coupling("bf16x3") (every level on nfdp_coupling_mlp_gather_bf16x3: 16x16x12 and 8x8x24 on the
+    128-pixel kernel, 4x4x48 on the row-split one): L3 K16, B = 512 - bits/dim inside the 1e-4 gate against the oracle, inverse and sampled pixels within 1e-4 of the
     oracle evaluated in fp64 (element-wise), determinism, and the split kernel really ran."""
     from normalizing_flow import calculate_loss
     flow, prior = _north_star("f32")
@@ -213,7 +213,7 @@ def test_north_star_split_product_mode_meets_the_pixel_gate():
         K.start_trace()
         zs, _, _ = flow.transform(x, ldj, logp)
         labels = [e["label"] for e in K.stop_trace()]
-        assert sum(lb.startswith("coupling_mlp_x3") for lb in labels) == 32, labels      # 16 flows at each of the two levels
+        assert sum(lb.startswith("coupling_mlp_x3") for lb in labels) == 48, labels      # all 16 flows of all three levels
         logp += prior.compute_log_prob(zs[-1])
         ldj_b, logp_b = z64(512), z64(512)
         zs_b, _, _ = flow.transform(x, ldj_b, logp_b)
