@@ -25,3 +25,7 @@ find "$OUT/celeba" -name "*kernel_stats.csv" -exec cp {} "$OUT/celeba_kernel_sta
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/train" -o train -- python3 bench.py --train --steps 5 --warmup 2 --no-graph > "$OUT/train_under_rocprof.json" 2> "$OUT/train_under_rocprof.err" || true
 find "$OUT/train" -name "*kernel_stats.csv" -exec cp {} "$OUT/train_kernel_stats.csv" \;
 ls "$OUT"
+# 4. the fp32 mode with split products (32x32 L3 K16 B = 512 forward, eager launches)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/f32x3" -o f32x3 -- python3 tools/trace_glow_fwd.py 32 3 512 f32 bf16x3 > "$OUT/f32x3_under_rocprof.txt" 2>&1 || true
+find "$OUT/f32x3" -name "*kernel_stats.csv" -exec cp {} "$OUT/f32x3_kernel_stats.csv" \;
+ls "$OUT"
