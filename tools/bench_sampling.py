@@ -22,8 +22,9 @@ with torch.no_grad():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         zs = prior.sample_latents(B)
+        t_host = time.perf_counter() - t0               # the host has enqueued everything (no sync inside the loop)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         assert all(torch.isfinite(z).all() for z in zs)
         print(f"B={B} T={T} S={S} {'one stream per part' if mode else 'sequential parts    '}: {dt:.3f} s per sample_latents "
-              f"= {dt / S * 1e3:.3f} ms per sampling step (3 parts), {B / dt:.1f} latent sets/s", flush=True)
+              f"= {dt / S * 1e3:.3f} ms per sampling step (3 parts), {B / dt:.1f} latent sets/s; host enqueue done after {t_host:.3f} s", flush=True)
