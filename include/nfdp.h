@@ -194,7 +194,14 @@ size_t nfdp_tap_coupling_head_ws_bytes(int B, int HW, int C);
 int nfdp_tap_coupling_head_f32(float* x, const float* T, int B, int H, int W, int C, const float* add, const float* mul, float f,
                                double* ldj, const float* ldj_const, void* ws, int inverse, const float* head_scale,
                                const float* head_bias, const float* head_w, const float* head_logabsdet, float* head_const_out,
-                               nfdp_stream_t stream);
+                               int defer_ldj, nfdp_stream_t stream);
+/* defer_ldj != 0 (forward with ldj): the launch leaves its chunk sums of log(s + 1e-6) in ws ([B][nfdp_tap_coupling_head_chunks]
+ * doubles) and does not touch ldj; nfdp_ldj_finish_level_f64 then adds the sums of up to a level's launches to ldj in ONE launch - in
+ * launch order, each with its two constants (consts[i] = that launch's ldj_const or NULL), i.e. bit-identical to the launches' own
+ * finishes - instead of one small launch per flow. */
+int nfdp_tap_coupling_head_chunks(int B, int HW, int C);
+int nfdp_ldj_finish_level_f64(double* ldj, int B, const void* const* parts, const float* const* consts, int n, int nch,
+                              nfdp_stream_t stream);
 /* coupling_fwd for large images at small batch: the pixels of a sample spread over several workgroups, chunk sums of the log-det in
  * ws (nfdp_coupling_chunked_ws_bytes; 0 = use nfdp_coupling_fwd_f32), added to ldj in chunk order by a second launch. */
 size_t nfdp_coupling_chunked_ws_bytes(int B, int HW, int C);

@@ -494,13 +494,17 @@ extern "C" int nfdp_tap_coupling_head_supported(int C) {
 extern "C" size_t nfdp_tap_coupling_head_ws_bytes(int B, int HW, int C) {
     if (!nfdp_tap_coupling_head_supported(C)) return 0;
     const int nch = tap_head_chunks(B, HW, C);
-    return nch > 1 ? (size_t)B * nch * sizeof(double) : 0;
+    return (size_t)B * nch * sizeof(double);          // (one chunk: needed only by a launch that defers its log-det sum)
+}
+
+extern "C" int nfdp_tap_coupling_head_chunks(int B, int HW, int C) {
+    return nfdp_tap_coupling_head_supported(C) ? tap_head_chunks(B, HW, C) : 0;
 }
 
 extern "C" int nfdp_tap_coupling_head_f32(float* x, const float* T, int B, int H, int W, int C, const float* add, const float* mul, float f,
                                           double* ldj, const float* ldj_const, void* ws, int inverse, const float* head_scale,
                                           const float* head_bias, const float* head_w, const float* head_logabsdet, float* head_const_out,
-                                          nfdp_stream_t stream) {
+                                          int defer_ldj, nfdp_stream_t stream) {
     NFDP_REQUIRE(x && T && add && mul && head_scale && head_bias && head_w, NFDP_EINVAL, "tap_coupling_head: null pointer");
     NFDP_REQUIRE(B >= 0 && H > 0 && W > 0, NFDP_ESHAPE, "tap_coupling_head: bad shape");
     NFDP_REQUIRE(nfdp_tap_coupling_head_supported(C), NFDP_EUNSUPPORTED, "tap_coupling_head: unsupported C=%d", C);
@@ -510,9 +514,10 @@ extern "C" int nfdp_tap_coupling_head_f32(float* x, const float* T, int B, int H
     const int nch = tap_head_chunks(B, H * W, C);
     hipStream_t s = as_stream(stream);
     double* part = nullptr;
+    const bool defer = !inverse && ldj && defer_ldj;       // chunk sums stay in ws: nfdp_ldj_finish_level_f64 adds a level's launches up at once
     if (!inverse) {
-        NFDP_REQUIRE(nch == 1 || ws || !ldj, NFDP_EINVAL, "tap_coupling_head: needs nfdp_tap_coupling_head_ws_bytes of workspace");
-        part = (nch > 1 && ldj) ? reinterpret_cast<double*>(ws) : nullptr;
+        NFDP_REQUIRE((nch == 1 && !defer) || ws || !ldj, NFDP_EINVAL, "tap_coupling_head: needs nfdp_tap_coupling_head_ws_bytes of workspace");
+        part = ((nch > 1 || defer) && ldj) ? reinterpret_cast<double*>(ws) : nullptr;
     }
     double* l = inverse ? nullptr : ldj;
     const float* lc = inverse ? nullptr : ldj_const;
@@ -530,9 +535,49 @@ extern "C" int nfdp_tap_coupling_head_f32(float* x, const float* T, int B, int H
         default: break;
     }
 #undef NFDP_TCH
-    if (part)
+    if (part && !defer)
         hipLaunchKernelGGL(coupling_ldj_finish_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, s, ldj, B, part, nch, ldj_const);
     NFDP_CHECK_LAUNCH("tap_coupling_head");
+    return NFDP_OK;
+}
+
+// The deferred log-det sums of up to 32 launches (the flows of a level) in ONE launch, in launch order and with each launch's two
+// constants, exactly as the launches' own finish kernels would have added them one after the other: bit-identical ldj.
+struct LdjLevel {
+    const double* part[32];
+    const float* cst[32];
+    int n, nch;
+};
+__global__ void ldj_finish_level_kernel(double* __restrict__ ldj, int B, const LdjLevel lv) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= B) return;
+    double v = ldj[b];
+    for (int f = 0; f < lv.n; ++f) {
+        double s = 0.0;
+        for (int q = 0; q < lv.nch; ++q) s += lv.part[f][(size_t)b * lv.nch + q];
+        if (lv.cst[f]) v = (v + (double)lv.cst[f][0]) + (double)lv.cst[f][1];
+        v = v + s;
+    }
+    ldj[b] = v;
+}
+
+extern "C" int nfdp_ldj_finish_level_f64(double* ldj, int B, const void* const* parts, const float* const* consts, int n, int nch,
+                                         nfdp_stream_t stream) {
+    NFDP_REQUIRE(ldj && parts && consts, NFDP_EINVAL, "ldj_finish_level: null pointer");
+    NFDP_REQUIRE(B >= 0 && n >= 0 && nch >= 1, NFDP_ESHAPE, "ldj_finish_level: bad shape");
+    if (B == 0 || n == 0) return NFDP_OK;
+    for (int i = 0; i < n; i += 32) {
+        LdjLevel lv;
+        lv.n = n - i < 32 ? n - i : 32;
+        lv.nch = nch;
+        for (int f = 0; f < lv.n; ++f) {
+            NFDP_REQUIRE(parts[i + f], NFDP_EINVAL, "ldj_finish_level: null partial-sum buffer");
+            lv.part[f] = reinterpret_cast<const double*>(parts[i + f]);
+            lv.cst[f] = consts[i + f];
+        }
+        hipLaunchKernelGGL(ldj_finish_level_kernel, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, as_stream(stream), ldj, B, lv);
+    }
+    NFDP_CHECK_LAUNCH("ldj_finish_level");
     return NFDP_OK;
 }
 

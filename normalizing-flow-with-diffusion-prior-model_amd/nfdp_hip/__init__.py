@@ -509,10 +509,12 @@ def tap_coupling_head_supported(c: int) -> bool:
 
 
 def tap_coupling_head(xh, t, add, mul, mul_exp: float, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.Tensor], inverse: bool,
-                      head_scale, head_bias, head_w, head_logabsdet=None, want_const: bool = False):
+                      head_scale, head_bias, head_w, head_logabsdet=None, want_const: bool = False, defer: Optional[list] = None):
     """tap_coupling with the adjoining flow head in the same pass (nfdp_tap_coupling_head_f32).  Forward: (head_scale, head_bias,
     head_w) are the NEXT flow's ActNorm / 1x1-conv parameters; returns that flow's [2] log-det constants when want_const.  Inverse: THIS
-    flow's ActNorm parameters and W^-1."""
+    flow's ActNorm parameters and W^-1.  defer (a list, forward with ldj): the launch leaves its log-det chunk sums in a workspace
+    appended to the list as (ws, ldj_const, nch) instead of adding them to ldj; ldj_finish_level(ldj, defer) adds a level's launches up
+    in one launch (bit-identical to the per-launch finishes)."""
     _dense(xh, "tap_coupling_head"); _dense(t, "tap_coupling_head")
     _need(xh, torch.float32, "tap_coupling_head"); _need(t, torch.float32, "tap_coupling_head")
     b, h, w, c = xh.shape
@@ -523,18 +525,36 @@ def tap_coupling_head(xh, t, add, mul, mul_exp: float, ldj: Optional[torch.Tenso
     if head_scale.numel() != c or head_bias.numel() != c or head_w.numel() != c * c:
         raise ValueError("tap_coupling_head: head parameter shapes")
     ws = None
+    deferring = False
     if not inverse and ldj is not None:
         _need(ldj, torch.float64, "tap_coupling_head ldj")
-        nbytes = lib().nfdp_tap_coupling_head_ws_bytes(b, h * w, c)
-        if nbytes:
-            ws = torch.empty(nbytes, device=xh.device, dtype=torch.uint8)
+        nch = int(lib().nfdp_tap_coupling_head_chunks(b, h * w, c))
+        deferring = defer is not None and nch > 1        # (one chunk: the launch adds its sum to ldj itself, nothing to save)
+        if nch > 1:
+            ws = torch.empty(b * nch, device=xh.device, dtype=torch.float64)
+        if deferring:
+            defer.append((ws, ldj_const, nch))
     cst = torch.empty(2, device=xh.device, dtype=torch.float32) if (want_const and not inverse) else None
     _call("nfdp_tap_coupling_head_f32", _ptr(xh), _ptr(t), b, h, w, c, _ptr(add), _ptr(mul), float(mul_exp),
           _ptr(None if inverse else ldj), _ptr(None if inverse else ldj_const), _ptr(ws), int(inverse), _ptr(head_scale), _ptr(head_bias),
-          _ptr(head_w), _ptr(None if inverse else head_logabsdet), _ptr(cst), _stream(),
+          _ptr(head_w), _ptr(None if inverse else head_logabsdet), _ptr(cst), int(deferring), _stream(),
           label=f"tap_coupling_head<{'inv' if inverse else 'fwd'},{c}>", nbytes=4.0 * (t.numel() + 2 * xh.numel()),
           flops=2.0 * xh.numel() * c)
     return cst
+
+
+def ldj_finish_level(ldj: torch.Tensor, deferred: list) -> None:
+    """Adds the deferred log-det sums of a level's tap_coupling_head launches to ldj (one launch; nfdp_ldj_finish_level_f64)."""
+    if not deferred:
+        return
+    _need(ldj, torch.float64, "ldj_finish_level")
+    n, nch = len(deferred), deferred[0][2]
+    if any(d[2] != nch for d in deferred):
+        raise ValueError("ldj_finish_level: launches of different geometries")
+    parts = (ctypes.c_void_p * n)(*[_ptr(d[0]) for d in deferred])
+    csts = (ctypes.c_void_p * n)(*[None if d[1] is None else _ptr(d[1]) for d in deferred])
+    _call("nfdp_ldj_finish_level_f64", _ptr(ldj), ldj.numel(), parts, csts, n, nch, _stream())
+    deferred.clear()
 
 
 def coupling_inv(yh, hh):

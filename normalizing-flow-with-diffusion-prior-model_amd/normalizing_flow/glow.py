@@ -31,7 +31,7 @@ class StepFlow(Transform):
         self.affcoupling = AffineCoupling(in_channels=in_channels, n_features=coupling_net_n_features, compute=compute)
 
     def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], logabsdet: Optional[Tensor] = None,
-                        defer_logdet: bool = False, head_done=None, next_head=None):
+                        defer_logdet: bool = False, head_done=None, next_head=None, ldj_defer=None):
         """In place on xh.  logabsdet: this flow's [1] fp32 entry of the level's batched log|det| launch;
         defer_logdet=True leaves the 1x1-conv log-det out (the caller adds the level's sum at the end).
         head_done / next_head (the level loop, _run_flows_fwd): head_done = (const,) says the previous flow's launch already applied this
@@ -39,7 +39,7 @@ class StepFlow(Transform):
         (AffineCoupling.transform_nhwc_).  With next_head given the call returns (xh, head_done for the next flow | None)."""
         an, ic = self.actnorm, self.invconv2d
         if head_done is not None:
-            out = self.affcoupling.transform_nhwc_(xh, ldj, head_done[0], next_head=next_head)
+            out = self.affcoupling.transform_nhwc_(xh, ldj, head_done[0], next_head=next_head, ldj_defer=ldj_defer)
             return out if next_head is None else ((out[0], (out[1],)) if isinstance(out, tuple) else (out, None))
         if not an.initialized():
             an.init_from(xh)
@@ -60,7 +60,7 @@ class StepFlow(Transform):
             _, const = K.flow_head_fwd(xh, an.scale.view(-1), an.bias.view(-1), ic._w(), logabsdet, out=xh)
         else:
             K.actnorm_invconv_fwd(xh, an.scale.view(-1), an.bias.view(-1), ic._w(), out=xh)
-        out = self.affcoupling.transform_nhwc_(xh, ldj, const, next_head=next_head)
+        out = self.affcoupling.transform_nhwc_(xh, ldj, const, next_head=next_head, ldj_defer=ldj_defer)
         return out if next_head is None else ((out[0], (out[1],)) if isinstance(out, tuple) else (out, None))
 
     def head_params(self, ldj: Optional[Tensor], logabsdet: Optional[Tensor], defer_logdet: bool):
@@ -178,16 +178,21 @@ def _run_flows_fwd(flows: Sequence[StepFlow], xh: Tensor, ldj: Optional[Tensor],
     if ldj is not None and lads is None and not defer_logdet:
         lads = _level_logdets(flows)
     done = None                                   # (const,): the previous flow's launch applied this flow's head already
+    deferred = [] if ldj is not None else None    # log-det sums of the head-fused passes: added to ldj by ONE launch behind the loop
     for i, f in enumerate(flows):
         lad = None if lads is None else lads[i:i + 1]
         nxt = None
         if i + 1 < len(flows):                    # the next flow's head rides in this flow's tap + coupling pass where that pass exists
             nxt = flows[i + 1].head_params(ldj, None if lads is None else lads[i + 1:i + 2], defer_logdet)
         if nxt is None:
+            if deferred:                          # before this flow adds its own term: ldj sees the flows' terms in flow order
+                K.ldj_finish_level(ldj, deferred)
             xh = f.transform_nhwc_(xh, ldj, lad, defer_logdet, head_done=done)
             done = None
         else:
-            xh, done = f.transform_nhwc_(xh, ldj, lad, defer_logdet, head_done=done, next_head=nxt)
+            xh, done = f.transform_nhwc_(xh, ldj, lad, defer_logdet, head_done=done, next_head=nxt, ldj_defer=deferred)
+    if deferred:
+        K.ldj_finish_level(ldj, deferred)
     return xh
 
 

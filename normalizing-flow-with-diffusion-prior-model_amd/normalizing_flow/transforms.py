@@ -187,7 +187,7 @@ class AffineCoupling(Transform):
         zc = self.net[-1]
         return K.use_tap_conv(zc.in_channels, zc.out_channels, zc.filter_size, K.BF16)
 
-    def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], ldj_const: Optional[Tensor] = None, next_head=None):
+    def transform_nhwc_(self, xh: Tensor, ldj: Optional[Tensor], ldj_const: Optional[Tensor] = None, next_head=None, ldj_defer=None):
         """In place on xh's second channel half.  ldj_const: device [2] fp32 added before the coupling sum.
         next_head: optional (scale [C], bias [C], W [C,C], logabsdet [1] | None) of the NEXT flow's ActNorm + 1x1 conv.  Where the layer
         runs as tap contributions + one pass (K.tap_coupling) that pass applies the head too and the call returns (xh, const) with the
@@ -200,8 +200,10 @@ class AffineCoupling(Transform):
         if t is not None:
             zc = self.net[-1]
             if next_head is not None and K.tap_coupling_head_supported(xh.shape[-1]):
+                # (ldj_defer: the level loop's list - this launch's log-det sums are added to ldj by one launch at the end of the level)
                 cst = K.tap_coupling_head(xh, t, zc.bias, zc.logs.view(-1), zc.logscale_factor, ldj, ldj_const, False,
-                                          next_head[0], next_head[1], next_head[2], next_head[3], want_const=ldj is not None)
+                                          next_head[0], next_head[1], next_head[2], next_head[3], want_const=ldj is not None,
+                                          defer=ldj_defer)
                 return xh, cst
             K.tap_coupling(xh, t, zc.bias, zc.logs.view(-1), zc.logscale_factor, ldj, ldj_const, inverse=False)
             return xh

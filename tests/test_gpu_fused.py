@@ -507,6 +507,17 @@ def test_tap_coupling_with_the_adjoining_head_is_bit_identical_to_two_launches(c
             cb = K.tap_coupling_head(xb, t, add, mul, 3.0, lb, const, False, hs, hb, wm, lad, want_const=True)
             assert torch.equal(ca, cb), (ca, cb)
             assert float((la - lb).abs().max()) <= 1e-9 * float(la.abs().max()), (la, lb)
+            # deferred log-det sums: two launches leave their chunk sums behind, one finish adds both - as two immediate launches do
+            xc, xd = x0.clone(), x0.clone()
+            lc, ld = torch.full((b,), 2.0, dtype=torch.float64, device=DEV), torch.full((b,), 2.0, dtype=torch.float64, device=DEV)
+            pend = []
+            for xx, ll, dd in ((xc, lc, None), (xd, ld, pend)):
+                K.tap_coupling_head(xx, t, add, mul, 3.0, ll, const, False, hs, hb, wm, lad, defer=dd)
+                K.tap_coupling_head(xx, t, add, mul, 3.0, ll, None, False, hs, hb, wm, lad, defer=dd)
+            if pend:                                                                  # (chunked geometries defer; one-chunk launches add themselves)
+                assert len(pend) == 2 and torch.equal(ld, torch.full_like(ld, 2.0))
+            K.ldj_finish_level(ld, pend)
+            assert torch.equal(xc, xd) and torch.equal(lc, ld), float((lc - ld).abs().max())
         assert torch.equal(xa, xb), (inverse, float((xa - xb).abs().max()))
 
 
@@ -531,13 +542,15 @@ def test_level_loop_with_fused_heads_matches_flow_by_flow():
             la = torch.zeros(b, dtype=torch.float64, device=DEV)
             K.start_trace()
             _run_flows_fwd(flows, xa, la, None, defer_logdet=True)
-            n_fwd = len([e for e in K.stop_trace() if not e["label"].startswith("nfdp_coupling_fused_pack")])
+            n_fwd = len([e for e in K.stop_trace() if not e["label"].startswith(("nfdp_coupling_fused_pack", "nfdp_ldj_finish_level"))])
             ya = xa.clone()
             _run_flows_inv(flows, ya)
             outs[fused] = (xa, la, ya, n_fwd)
         finally:
             K.TAP_HEAD_FUSION = True
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs[True][2], outs[False][2])
+    # (ldj: the fused passes defer their chunk sums to ONE finish launch per level that adds them in flow order; the two-launch path
+    #  uses other chunk counts: fp64 sums of the same terms)
     assert float((outs[True][1] - outs[False][1]).abs().max()) <= 1e-9 * float(outs[False][1].abs().max())
     assert outs[True][3] == outs[False][3] - (nf - 1), (outs[True][3], outs[False][3])
     assert relerr(outs[True][2], x0) < 2e-2                                            # round trip at bf16 accuracy
