@@ -40,6 +40,17 @@ def test_argument_validation_without_gpu():
     assert l.nfdp_conv_packed_bytes(512, 6, 3, 3, 1) == 512 * 64 * 2
     assert l.nfdp_conv_packed_bytes(12, 512, 3, 3, 0) == 16 * 4608 * 4
     assert l.nfdp_actnorm_init_ws_bytes(512) > 0
+    # round 4 entries: host-side predicates and argument checks of the tiled-level kernels
+    assert [c for c in range(2, 200, 2) if l.nfdp_tap_coupling_head_supported(c)] == [4, 8, 12, 16, 24, 32, 48]
+    assert l.nfdp_tap_coupling_head_chunks(32, 64 * 64, 12) == 25 and l.nfdp_tap_coupling_head_chunks(512, 16, 48) == 1
+    assert l.nfdp_tap_coupling_head_ws_bytes(32, 64 * 64, 12) == 32 * 25 * 8 and l.nfdp_tap_coupling_head_ws_bytes(4, 16, 96) == 0
+    assert l.nfdp_set_mlp_rows(3) == -1 and l.nfdp_set_mlp_rows(0) == 0
+    assert l.nfdp_coupling_mlp_gather_bf16x3(p, 6, 1, 4, 4, p, None, p, 12, None) == -1                        # no low-piece image
+    assert l.nfdp_coupling_mlp_gather_bf16x3(p, 48, 1, 4, 4, p, p, p, 96, None) == -3                         # C = 96: NFDP_EUNSUPPORTED
+    assert l.nfdp_coupling_mlp_gather_bf16(p + 4, 6, 1, 4, 4, p, p, 12, None) == -2                           # x not 8-byte aligned
+    assert l.nfdp_tap_coupling_head_f32(p, p, 1, 4, 4, 20, p, p, 3.0, None, None, None, 0, p, p, p, None, None, 0, None) == -3
+    assert l.nfdp_ldj_finish_level_f64(None, 4, None, None, 2, 1, None) == -1
+    assert l.nfdp_ldj_finish_level_f64(p, 0, ctypes.byref(ctypes.c_void_p(p)), ctypes.byref(ctypes.c_void_p(None)), 1, 1, None) == 0
     # empty batches are a no-op, not an error
     assert l.nfdp_squeeze_nhwc_f32(p, 3, p, 0, 3, 4, 4, None) == 0
     assert l.nfdp_coupling_fwd_f32(p, p, 0, 4, 4, None, None, None) == 0
