@@ -180,9 +180,12 @@ __global__ void __launch_bounds__(TI * 32) gauss_jordan_reg_kernel(const float* 
                 else a[x][y] = ((j == k) ? 0.0 : a[x][y]) - f * r;
             }
         }
-        if (tid == 0) pivlog[k] = log(fabs(pv));
+        if (tid == 0) pivlog[k] = pv;                               // (its log after the loop: an fp64 log by ONE thread in every step kept
+                                                                    //  the other 511 waiting at the next barrier)
         // the next step writes the other LDS buffers; its first barrier orders this step's reads before step k+2's writes
     }
+    __syncthreads();
+    for (int k = tid; k < C; k += TI * 32) pivlog[k] = log(fabs(pivlog[k]));
     __syncthreads();
     if (tid == 0) {
         double sum = 0.0;

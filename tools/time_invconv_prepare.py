@@ -2,7 +2,7 @@ import os, sys
 sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "normalizing-flow-with-diffusion-prior-model_amd")]
 import numpy as np, torch
 import nfdp_hip as K
-for c in (12, 24, 48, 4, 8, 16):
+for c in (12, 24, 48, 96, 192, 4, 8, 16):
     w = (torch.linalg.qr(torch.randn(16, c, c))[0] + 0.1 * torch.randn(16, c, c)).contiguous().cuda()
     lad, winv = K.invconv_prepare(w, True)
     ref = torch.linalg.inv(w.double())
