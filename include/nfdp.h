@@ -69,6 +69,14 @@ int nfdp_coupling_mlp_gather_bf16(const float* x, int x_ld, int B, int H, int W,
 /* Split-product form for the exact-fp32 mode: every fp32 product as hi*hi + hi*lo + lo*hi of two-piece bf16 splits of both operands
  * (three bf16 MFMAs against sixteen fp32-MFMA passes), fp32 accumulation; pixel error of a 48-flow inverse 4-6e-5.  packed_hi: the
  * nfdp_coupling_fused_pack image with fold_scales = 1, packed_lo: the same call with fold_scales = 3 (low pieces).  C <= 24 or C = 48. */
+/* The same two networks on v_mfma_f32_16x16x32_bf16 (C = 4, 12): packed_hi = the fold_scales = 2 image, packed_lo = NULL (bf16
+ * operands) or the fold_scales = 4 image (low pieces: split products).  nfdp_coupling_mlp_image_kind(C, B*H*W, split) says which
+ * image kind a call of that size takes (2: this entry; 1: nfdp_coupling_mlp_gather_bf16 / _bf16x3); nfdp_set_mlp_k16(0) turns the
+ * 16x16x32 form off. */
+int nfdp_set_mlp_k16(int on);
+int nfdp_coupling_mlp_image_kind(int C, long npix, int split);
+int nfdp_coupling_mlp_gather_k16(const float* x, int x_ld, int B, int H, int W, const void* packed_hi, const void* packed_lo, float* T,
+                                 int C, nfdp_stream_t stream);
 /* Kernel form of the two entries around this comment: 0 (default) = the row-split form (32-pixel workgroups whose four waves split the
  * weights; same images, bf16 results bit-identical) where the 128-pixel form would leave most CUs idle (<= 16384 pixels; C = 12, 24, 48),
  * 1 = never, 2 = always.  The split-product form at C = 48 exists row-split only. */

@@ -1603,8 +1603,22 @@ def coupling_mlp_supported(c: int, n_features: int) -> bool:
     return n_features == 512 and c <= 48 and lib().nfdp_coupling_fused_packed_bytes(c) != 0
 
 
+def coupling_mlp_image_kind(xh_a: torch.Tensor, c: int, split: bool = False) -> int:
+    """Which image pair coupling_net_tiled wants for this call: 2 = the 16x16x32-form images (fused_packed(2), low pieces
+    fused_packed(4); C = 4, 12 beyond the row-split kernel's sizes), 1 = fused_packed(1) / fused_packed(3)."""
+    b, h, w, _ = xh_a.shape
+    if xh_a.dtype != torch.float32 or xh_a.data_ptr() % 8 or _ld(xh_a, "coupling_mlp_image_kind") % 2 or not MLP_GATHER:
+        return 1
+    return int(lib().nfdp_coupling_mlp_image_kind(c, b * h * w, int(split)))
+
+
+def set_mlp_k16(on: bool) -> None:
+    """Tiled coupling networks of C = 4, 12 on v_mfma_f32_16x16x32_bf16 (default) or on the 32x32x16 kernels."""
+    _check(lib().nfdp_set_mlp_k16(int(bool(on))))
+
+
 def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: torch.Tensor, logs: torch.Tensor,
-                       mul_exp: float, return_taps: bool = False, packed_lo: Optional[torch.Tensor] = None) -> torch.Tensor:
+                       mul_exp: float, return_taps: bool = False, packed_lo: Optional[torch.Tensor] = None, kind: int = 1) -> torch.Tensor:
     """NN(x_a) of an affine coupling for any image size (bf16 mode): im2col of the C/2-channel half -> the per-pixel three-GEMM
     chain with the hidden activations on chip (nfdp_coupling_mlp_bf16) -> tap shift-sum with the ZeroConv2d epilogue.
     xh_a: [B,H,W,C/2] fp32 pixel-strided view; returns h = (log_s | t) [B,H,W,C] fp32."""
@@ -1612,7 +1626,12 @@ def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: t
     t = torch.empty((b, h, w, 9 * c), device=xh_a.device, dtype=torch.float32)
     fl = 2.0 * b * h * w * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c)
     vw = 4 if (c // 2) % 4 == 0 else 2
-    if packed_lo is not None:
+    if kind == 2:
+        # 16x16x32 form: packed = the fold-2 image, packed_lo = None or the fold-4 image (coupling_mlp_image_kind chose them)
+        _need(xh_a, torch.float32, "coupling_net_tiled")
+        _call("nfdp_coupling_mlp_gather_k16", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled"), b, h, w, _ptr(packed), _ptr(packed_lo), _ptr(t),
+              c, _stream(), label=f"coupling_mlp{'_x3' if packed_lo is not None else ''}<{c}> hw{h}", flops=fl)
+    elif packed_lo is not None:
         # split-product form (compute "f32", set_f32_coupling("bf16x3")): packed = high-piece image, packed_lo = low-piece image
         _need(xh_a, torch.float32, "coupling_net_tiled")
         _call("nfdp_coupling_mlp_gather_bf16x3", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled"), b, h, w, _ptr(packed), _ptr(packed_lo), _ptr(t),

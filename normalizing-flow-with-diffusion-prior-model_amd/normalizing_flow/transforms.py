@@ -152,7 +152,8 @@ class AffineCoupling(Transform):
         if self.fused and K.compute_enum(self.compute) == K.BF16 and b * hh * ww >= 1024 and \
                 K.coupling_mlp_supported(c, self.n_features) and self.net.fused_ready():
             zc = self.net[-1]
-            return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(), c, zc.bias, zc.logs.view(-1), zc.logscale_factor)
+            kind = K.coupling_mlp_image_kind(xh[..., : c // 2], c)
+            return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(kind), c, zc.bias, zc.logs.view(-1), zc.logscale_factor, kind=kind)
         if self.fused and K.compute_enum(self.compute) == K.F32 and xh.dtype == torch.float32 and \
                 K.coupling_mlp_f32_supported(c, self.n_features) and self.net.fused_ready():
             # exact fp32 with the hidden activations on chip (any image size): 3x3 gather + three fp32-MFMA GEMMs in one launch
@@ -171,15 +172,17 @@ class AffineCoupling(Transform):
             # exact-fp32 mode with split products (K.set_f32_coupling("bf16x3")): high- and low-piece images, three bf16 MFMAs per product
             if self.fused and K.coupling_mlp_x3_supported(xh[..., : c // 2], c, self.n_features):
                 zc = self.net[-1]
-                return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(1), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
-                                            return_taps=True, packed_lo=self.net.fused_packed(3))
+                kind = K.coupling_mlp_image_kind(xh[..., : c // 2], c, split=True)
+                return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(kind), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
+                                            return_taps=True, packed_lo=self.net.fused_packed(kind + 2), kind=kind)
             return None
         if K.compute_enum(self.compute) != K.BF16:
             return None
         if self.fused and b * hh * ww >= 1024 and K.coupling_mlp_supported(c, self.n_features):
             zc = self.net[-1]
-            return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
-                                        return_taps=True)
+            kind = K.coupling_mlp_image_kind(xh[..., : c // 2], c)
+            return K.coupling_net_tiled(xh[..., : c // 2], self.net.fused_packed(kind), c, zc.bias, zc.logs.view(-1), zc.logscale_factor,
+                                        return_taps=True, kind=kind)
         t, _ = self.net.forward_nhwc(xh[..., : c // 2], compute=self.compute, return_taps=True) if self._taps_ok() else (None, None)
         return t
 

@@ -623,3 +623,47 @@ def test_row_split_split_product_network_against_fp64(c, hh, ww, b):
     finally:
         K.set_mlp_rows("auto")
         K.set_f32_coupling("mfma_f32")
+
+
+@pytest.mark.parametrize("c,hh,ww,b", [(12, 64, 64, 5), (12, 16, 16, 3), (4, 14, 14, 5), (12, 6, 10, 3), (4, 3, 5, 1), (12, 32, 32, 17)])
+@torch.no_grad()
+def test_k16_tiled_network_matches_the_32x32_form_and_the_oracle(c, hh, ww, b):
+    """coupling_mlp16_kernel (the tiled network on v_mfma_f32_16x16x32_bf16, images of kinds 2 / 4) against coupling_mlp_kernel /
+    coupling_mlp_x3_kernel (kinds 1 / 3): same bf16 operands / pieces, another grouping of the fp32 accumulation (32-deep k-steps) -
+    bf16: within a few bf16 roundings of hidden activations (2e-3 of the tensor's scale), split products: 1e-5 between the two; the split-product form against the oracle in fp64 (1e-4 is the bar); ragged pixel
+    counts, images smaller than a tile; determinism; and the auto choice (nfdp_coupling_mlp_image_kind)."""
+    from normalizing_flow import AffineCoupling
+    m = AffineCoupling(c, n_features=512, compute="f32")
+    sd = {k: T(synth_tensor("flows.7.affcoupling." + k, v.shape, 17, DEEP)) for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, strict=True)
+    m.to(DEV)
+    osd64 = {"flows.7.affcoupling." + k: v.double() for k, v in sd.items()}
+    x = T(synth_input(f"k16_{c}_{hh}", (b, c, hh, ww), 5)) * 0.6
+    xh = K.to_nhwc(x.to(DEV)).contiguous()
+    xa = xh[..., : c // 2]
+    zc = m.net[-1]
+    args = (c, zc.bias, zc.logs.view(-1), zc.logscale_factor)
+    K.set_mlp_rows("never")
+    try:
+        t32 = K.coupling_net_tiled(xa, m.net.fused_packed(1), *args, return_taps=True)
+        t16 = K.coupling_net_tiled(xa, m.net.fused_packed(2), *args, return_taps=True, kind=2)
+        t16b = K.coupling_net_tiled(xa, m.net.fused_packed(2), *args, return_taps=True, kind=2)
+        assert torch.equal(t16, t16b)
+        assert relerr(t16, t32) < 2e-3, relerr(t16, t32)      # (bf16 operands: an fp32 sum an ulp apart can round a hidden activation the other way)
+        x32 = K.coupling_net_tiled(xa, m.net.fused_packed(1), *args, packed_lo=m.net.fused_packed(3))
+        x16 = K.coupling_net_tiled(xa, m.net.fused_packed(2), *args, packed_lo=m.net.fused_packed(4), kind=2)
+        assert relerr(x16, x32) < 1e-5, relerr(x16, x32)
+        h_ref = O.coupling_net(x[:, : c // 2].double(), osd64, "flows.7.affcoupling.net.")
+        e = relerr(K.as_nchw(x16), h_ref)
+        record(f"x3_k16_network_relerr_c{c}_h{hh}", e)
+        assert e < 1e-4, e
+    finally:
+        K.set_mlp_rows("auto")
+    npix = b * hh * ww
+    want = 2 if (c == 4 or npix > 16384) else 1                       # C = 12 up to 16384 pixels: the row-split form (kind-1 images)
+    assert K.coupling_mlp_image_kind(xa, c) == want and K.coupling_mlp_image_kind(xa, c, split=True) == want
+    K.set_mlp_k16(False)
+    try:
+        assert K.coupling_mlp_image_kind(xa, c) == 1
+    finally:
+        K.set_mlp_k16(True)

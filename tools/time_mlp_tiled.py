@@ -15,11 +15,13 @@ for c, hw, b in ((12, 64, 32), (24, 32, 32), (48, 16, 32), (12, 16, 512), (24, 8
     m.to(dev)
     xh = (torch.rand(b, hw, hw, c, device=dev) - 0.5)
     zc = m.net[-1]
-    hi, lo = m.net.fused_packed(1), m.net.fused_packed(3)
-    for name, kw in (("bf16", {}), ("bf16x3", {"packed_lo": lo})):
-        if name == "bf16x3" and c > 24 and c != 48:
+    for name, split in (("bf16", False), ("bf16x3", True)):
+        if split and c > 24 and c != 48:
             continue
-        fn = lambda: K.coupling_net_tiled(xh[..., : c // 2], hi, c, zc.bias, zc.logs.view(-1), zc.logscale_factor, return_taps=True, **kw)
+        kind = K.coupling_mlp_image_kind(xh[..., : c // 2], c, split=split)        # 2: the 16x16x32 form (C = 4, 12 beyond the row-split sizes)
+        hi = m.net.fused_packed(kind)
+        kw = {"packed_lo": m.net.fused_packed(kind + 2)} if split else {}
+        fn = lambda: K.coupling_net_tiled(xh[..., : c // 2], hi, c, zc.bias, zc.logs.view(-1), zc.logscale_factor, return_taps=True, kind=kind, **kw)
         for _ in range(3):
             fn()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -31,4 +33,4 @@ for c, hw, b in ((12, 64, 32), (24, 32, 32), (48, 16, 32), (12, 16, 512), (24, 8
         torch.cuda.synchronize()
         us = ev[0].elapsed_time(ev[1]) / 20 * 1e3
         fl = 2.0 * b * hw * hw * (9 * (c // 2) * 512 + 512 * 512 + 9 * 512 * c) * (3 if name == "bf16x3" else 1)
-        print(f"C={c:3d} {hw}x{hw} B={b:3d} {name:7s}: {us:8.1f} us  {fl / us / 1e6:7.0f} TFLOP/s of bf16 MFMA", flush=True)
+        print(f"C={c:3d} {hw}x{hw} B={b:3d} {name:7s} kind {kind}: {us:8.1f} us  {fl / us / 1e6:7.0f} TFLOP/s of bf16 MFMA", flush=True)
