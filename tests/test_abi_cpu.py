@@ -45,6 +45,10 @@ def test_argument_validation_without_gpu():
     assert l.nfdp_tap_coupling_head_chunks(32, 64 * 64, 12) == 25 and l.nfdp_tap_coupling_head_chunks(512, 16, 48) == 1
     assert l.nfdp_tap_coupling_head_ws_bytes(32, 64 * 64, 12) == 32 * 25 * 8 and l.nfdp_tap_coupling_head_ws_bytes(4, 16, 96) == 0
     assert l.nfdp_set_mlp_rows(3) == -1 and l.nfdp_set_mlp_rows(0) == 0
+    assert [l.nfdp_coupling_mlp_image_kind(c, n, 0) for c, n in ((12, 131072), (12, 16384), (4, 100), (24, 131072), (48, 8192))] == [2, 1, 2, 1, 1]
+    assert l.nfdp_set_mlp_k16(0) == 0 and l.nfdp_coupling_mlp_image_kind(12, 131072, 1) == 1 and l.nfdp_set_mlp_k16(1) == 0
+    assert l.nfdp_coupling_mlp_gather_k16(p, 12, 1, 4, 4, p, None, p, 24, None) == -3                         # C = 24 has no 16x16x32 image
+    assert l.nfdp_coupling_fused_packed_bytes(12) > 0
     assert l.nfdp_coupling_mlp_gather_bf16x3(p, 6, 1, 4, 4, p, None, p, 12, None) == -1                        # no low-piece image
     assert l.nfdp_coupling_mlp_gather_bf16x3(p, 48, 1, 4, 4, p, p, p, 96, None) == -3                         # C = 96: NFDP_EUNSUPPORTED
     assert l.nfdp_coupling_mlp_gather_bf16(p + 4, 6, 1, 4, 4, p, p, 12, None) == -2                           # x not 8-byte aligned
