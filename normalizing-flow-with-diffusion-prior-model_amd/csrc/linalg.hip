@@ -475,7 +475,9 @@ extern "C" int nfdp_invconv_prepare_f32(const float* w, int n, int C, float* log
     } else if (C <= 128) {
         hipLaunchKernelGGL((gauss_jordan_reg_kernel<32, 4, 4>), dim3(n), dim3(1024), 0, as_stream(stream), w, C, logabsdet, winv);
     } else if (C <= 192) {
-        hipLaunchKernelGGL((gauss_jordan_reg_kernel<16, 12, 6>), dim3(n), dim3(512), 0, as_stream(stream), w, C, logabsdet, winv);
+        // (32 x 32 threads with 6 x 6 elements each: 5.9 us per pivot step; 16 x 32 threads with 12 x 6: 6.1 - the step is a latency chain
+        //  of two 16-wave barriers, the candidate scan and an fp64 division, not its 72 or 36 updates per thread)
+        hipLaunchKernelGGL((gauss_jordan_reg_kernel<32, 6, 6>), dim3(n), dim3(1024), 0, as_stream(stream), w, C, logabsdet, winv);
     } else {
         NFDP_REQUIRE(ws, NFDP_EINVAL, "invconv_prepare: workspace required for C=%d", C);
         hipLaunchKernelGGL((gauss_jordan_kernel<false>), dim3(n), dim3(kBlock), red, as_stream(stream), w, C, logabsdet,
