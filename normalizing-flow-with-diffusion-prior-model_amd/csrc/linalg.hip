@@ -110,6 +110,8 @@ __global__ void __launch_bounds__(TI * 32) gauss_jordan_reg_kernel(const float* 
     __shared__ int pivrow[CP];
     __shared__ int kof[CP];
     __shared__ double pivlog[CP];
+    __shared__ double pinv[2][2];                                   // the pivot and its reciprocal, by the pivot's owner
+    static_assert(TI == 16 || TI == 32, "a wave is two rows of threads; candidates reduced by xor-shuffles");
     const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
     const float* wm = w + (size_t)blockIdx.x * C * C;
     double a[NBR][NBC];
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(TI * 32) gauss_jordan_reg_kernel(const float* 
                 const int i = ti + TI * x;
                 double v = 0.0;
 #pragma unroll
-                for (int y = 0; y < NBC; ++y) if (y == kb) v = a[x][y];
+                for (int y = 0; y < NBC; ++y) if (y == kb) v = a[x][y];      // (kb is uniform: scalar branches, no select chain)
                 fcol[buf][i] = v;                                   // column k, all rows (read in step 3)
                 v = fabs(v);
                 if (i < C && !used[i] && (v > best || (v == best && i < bi))) { best = v; bi = i; }
@@ -142,18 +144,22 @@ __global__ void __launch_bounds__(TI * 32) gauss_jordan_reg_kernel(const float* 
             cand_i[buf][ti] = bi;
         }
         __syncthreads();
-        double pb = -1.0;
-        int p = 1 << 30;
-#pragma unroll 8
-        for (int q = 0; q < TI; ++q) {
-            const double v = cand_v[buf][q];
-            const int i = cand_i[buf][q];
-            if (v > pb || (v == pb && i < p)) { pb = v; p = i; }
+        // the pivot: largest |candidate|, lowest row on ties.  Every wave reduces the TI candidates across its lanes (lane l takes
+        // candidate l % TI; five xor-shuffle steps) - with every thread walking all TI candidates through LDS the scan was a quarter
+        // of the step's VALU time on each of the 16 waves (the step is VALU-bound: four waves share a SIMD).
+        double pb = cand_v[buf][tid % TI];
+        int p = cand_i[buf][tid % TI];
+#pragma unroll
+        for (int o = 1; o < TI; o <<= 1) {
+            const double ov = __shfl_xor(pb, o);
+            const int oi = __shfl_xor(p, o);
+            if (ov > pb || (ov == pb && oi < p)) { pb = ov; p = oi; }
         }
         // bookkeeping by one thread, BEFORE this step's second barrier: the next step's candidate search reads used[] right
         // after it (written at the end of the step it raced with that search: a pivot row could be chosen twice)
         if (tid == 0) { used[p] = 1; pivrow[k] = p; kof[p] = k; }
-        // 2. the owners of row p publish it
+        // 2. the owners of row p publish it; the owner of the pivot itself also publishes 1 / pivot (ONE fp64 division per step,
+        //    not one per thread)
         if (ti == p % TI) {
             const int pxl = p / TI;
 #pragma unroll
@@ -162,23 +168,44 @@ __global__ void __launch_bounds__(TI * 32) gauss_jordan_reg_kernel(const float* 
 #pragma unroll
                 for (int x = 0; x < NBR; ++x) if (x == pxl) v = a[x][y];
                 rowk[buf][tj + 32 * y] = v;
+                if (y == kb && tj == kt) { pinv[buf][0] = v; pinv[buf][1] = 1.0 / v; }
             }
         }
         __syncthreads();
-        const double pv = rowk[buf][k];
-        const double inv = 1.0 / pv;
-        // 3. in-place update of this thread's elements
+        const double pv = pinv[buf][0];
+        const double inv = pinv[buf][1];
+        // 3. in-place update of this thread's elements.  Only ONE wave holds row p (a wave is two values of ti): the others skip the
+        //    row test (wave-uniform branch)
+        const bool wave_has_p = ((p % TI) >> 1) == (tid >> 6);
+        // column k of the old matrix counts as zero in the update (its values are the multipliers f): its owners clear it first -
+        // kb is uniform, so the column index is static inside a scalar branch and the update itself is a bare fma per element
+#pragma unroll
+        for (int y = 0; y < NBC; ++y) {
+            if (y == kb) {
+                if (tj == kt) {
+#pragma unroll
+                    for (int x = 0; x < NBR; ++x) a[x][y] = 0.0;
+                }
+            }
+        }
+        double rr[NBC], ff[NBR];
 #pragma unroll
         for (int y = 0; y < NBC; ++y) {
             const int j = tj + 32 * y;
-            const double r = (j == k) ? inv : rowk[buf][j] * inv;   // new pivot row element
+            rr[y] = (j == k) ? inv : rowk[buf][j] * inv;                // new pivot row element
+        }
 #pragma unroll
-            for (int x = 0; x < NBR; ++x) {
-                const int i = ti + TI * x;
-                const double f = fcol[buf][i];
-                if (i == p) a[x][y] = r;
-                else a[x][y] = ((j == k) ? 0.0 : a[x][y]) - f * r;
-            }
+        for (int x = 0; x < NBR; ++x) ff[x] = fcol[buf][ti + TI * x];
+        if (wave_has_p) {
+#pragma unroll
+            for (int y = 0; y < NBC; ++y)
+#pragma unroll
+                for (int x = 0; x < NBR; ++x) a[x][y] = (ti + TI * x == p) ? rr[y] : a[x][y] - ff[x] * rr[y];
+        } else {
+#pragma unroll
+            for (int y = 0; y < NBC; ++y)
+#pragma unroll
+                for (int x = 0; x < NBR; ++x) a[x][y] = a[x][y] - ff[x] * rr[y];
         }
         if (tid == 0) pivlog[k] = pv;                               // (its log after the loop: an fp64 log by ONE thread in every step kept
                                                                     //  the other 511 waiting at the next barrier)
