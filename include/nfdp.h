@@ -132,6 +132,12 @@ int nfdp_invconv_prepare_f32(const float* w, int n, int C, float* logabsdet, flo
  * launch: every 1x1 convolution of a Glow forward pass (torch.slogdet(W.double())[1].float(), transforms.py:131, K*L times
  * per pass in the reference).  w, C: HOST arrays of n device pointers / sizes; logabsdet: device [n]. */
 int nfdp_invconv_logdets_f32(const float* const* w, const int* C, int n, float* logabsdet, nfdp_stream_t stream);
+/* W^-1 (and log|det W|) of n matrices of DIFFERENT sizes in one launch (the 1x1 convs of all levels of a model ahead of its inverse
+ * pass, InvConv2d.invert transforms.py:139-146): w / C / winv are HOST arrays of device pointers / sizes / output pointers; sizes
+ * from nfdp_invconv_inverses_supported (4, 8, 12, 16, 24, 48: one wave per matrix, fp64 Gauss-Jordan as nfdp_invconv_prepare_f32 -
+ * same results). */
+int nfdp_invconv_inverses_supported(int C);
+int nfdp_invconv_inverses_f32(const float* const* w, const int* C, int n, float* logabsdet, float* const* winv, nfdp_stream_t stream);
 /* y[p,:] = W x[p,:]   (conv2d with a [C,C,1,1] kernel, transforms.py:132 / :144 with W^-1). */
 int nfdp_invconv_apply_f32(const float* x, float* y, long npix, int C, const float* w, nfdp_stream_t stream);
 /* Fused flow head, glow.py:46-47: y = W (exp(scale)*(x+bias)). */

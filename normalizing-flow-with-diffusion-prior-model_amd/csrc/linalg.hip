@@ -409,6 +409,33 @@ __global__ void __launch_bounds__(64) gj_wave_kernel(const float* __restrict__ w
 }
 static bool gj_wave_ok(int C) { return C == 4 || C == 8 || C == 12 || C == 16 || C == 24 || C == 48; }
 
+// The same for matrices of DIFFERENT sizes in one launch (the inverses of all levels of a model: a 3-level model's inverse pass ran
+// three launches, 94 + 20 + 20 us, one in front of each level; together they take as long as the largest).
+constexpr int kMaxGjMats = 96;
+struct GjTable {
+    const float* w[kMaxGjMats];
+    float* winv[kMaxGjMats];
+    int C[kMaxGjMats];
+};
+__global__ void __launch_bounds__(64) gj_wave_multi_kernel(const GjTable tab, float* __restrict__ logabsdet) {
+    const float* wm = tab.w[blockIdx.x];
+    float* out = tab.winv[blockIdx.x];
+    const int C = tab.C[blockIdx.x];
+    const int lane = threadIdx.x;
+    __shared__ int prow_s[64];
+    double r = 0.0;
+    switch (C) {                                                   // wave-uniform
+        case 4: r = gj_inverse_regs<4>(wm, out, lane, prow_s); break;
+        case 8: r = gj_inverse_regs<8>(wm, out, lane, prow_s); break;
+        case 12: r = gj_inverse_regs<12>(wm, out, lane, prow_s); break;
+        case 16: r = gj_inverse_regs<16>(wm, out, lane, prow_s); break;
+        case 24: r = gj_inverse_regs<24>(wm, out, lane, prow_s); break;
+        case 48: r = gj_inverse_regs<48>(wm, out, lane, prow_s); break;
+        default: break;
+    }
+    if (lane == 0) logabsdet[blockIdx.x] = (float)r;
+}
+
 // One WAVE per matrix (C <= 64): lane = row, so a step needs no workgroup barrier - the argmax is one DPP wave reduction,
 // the pivot row is read as LDS broadcasts, every lane updates its own row.  LDS ops of one wave execute in order.
 __global__ void __launch_bounds__(64) logdet_wave_kernel(const LogdetTable tab, float* __restrict__ logabsdet) {
@@ -511,6 +538,29 @@ extern "C" int nfdp_invconv_prepare_f32(const float* w, int n, int C, float* log
                            winv, reinterpret_cast<double*>(ws));
     }
     NFDP_CHECK_LAUNCH("invconv_prepare");
+    return NFDP_OK;
+}
+
+extern "C" int nfdp_invconv_inverses_supported(int C) { return gj_wave_ok(C) ? 1 : 0; }
+
+extern "C" int nfdp_invconv_inverses_f32(const float* const* w, const int* C, int n, float* logabsdet, float* const* winv,
+                                         nfdp_stream_t stream) {
+    NFDP_REQUIRE(w && C && logabsdet && winv, NFDP_EINVAL, "invconv_inverses: null pointer");
+    NFDP_REQUIRE(n >= 0, NFDP_ESHAPE, "invconv_inverses: bad count");
+    // w, C, winv: HOST arrays (device pointers / sizes); the kernel receives them by value, kMaxGjMats per launch
+    for (int done = 0; done < n; done += kMaxGjMats) {
+        GjTable tab;
+        const int m = (n - done) < kMaxGjMats ? (n - done) : kMaxGjMats;
+        for (int i = 0; i < m; ++i) {
+            NFDP_REQUIRE(w[done + i] && winv[done + i] && gj_wave_ok(C[done + i]), NFDP_ESHAPE,
+                         "invconv_inverses: matrix %d: null or C=%d not one of 4, 8, 12, 16, 24, 48", done + i, C[done + i]);
+            tab.w[i] = w[done + i];
+            tab.winv[i] = winv[done + i];
+            tab.C[i] = C[done + i];
+        }
+        hipLaunchKernelGGL(gj_wave_multi_kernel, dim3(m), dim3(64), 0, as_stream(stream), tab, logabsdet + done);
+    }
+    NFDP_CHECK_LAUNCH("invconv_inverses");
     return NFDP_OK;
 }
 

@@ -335,6 +335,33 @@ def invconv_logdets(ws) -> torch.Tensor:
     return out
 
 
+def invconv_inverses_supported(c: int) -> bool:
+    return bool(lib().nfdp_invconv_inverses_supported(c))
+
+
+def invconv_inverses(groups) -> list:
+    """W^-1 of several GROUPS of square matrices in ONE launch (nfdp_invconv_inverses_f32): groups = [[w, w, ...], ...], the matrices
+    of a group of one size (a level's 1x1 convs); -> one [K, C, C] tensor per group (fp64 Gauss-Jordan on the device, as
+    invconv_prepare: same results)."""
+    flat, cs, outs, optrs = [], [], [], []
+    for g in groups:
+        c = g[0].shape[-1]
+        out = torch.empty((len(g), c, c), device=g[0].device, dtype=torch.float32)
+        outs.append(out)
+        for i, w in enumerate(g):
+            _need(w, torch.float32, "invconv_inverses"); _dense(w, "invconv_inverses")
+            if w.shape[-1] != c or w.shape[-2] != c:
+                raise ValueError("invconv_inverses: a group holds matrices of one size")
+            flat.append(w.data_ptr()); cs.append(c); optrs.append(out.data_ptr() + i * c * c * 4)
+    n = len(flat)
+    if n == 0:
+        return outs
+    lad = torch.empty(n, device=groups[0][0].device, dtype=torch.float32)
+    _call("nfdp_invconv_inverses_f32", (ctypes.c_void_p * n)(*flat), (ctypes.c_int * n)(*cs), n, _ptr(lad), (ctypes.c_void_p * n)(*optrs),
+          _stream())
+    return outs
+
+
 def invconv_apply(xh, w, out=None):
     _need(xh, torch.float32, "invconv_apply"); _dense(xh, "invconv_apply")
     out = torch.empty_like(xh) if out is None else out

@@ -135,6 +135,25 @@ def _level_logdets(flows: Sequence[StepFlow]) -> Tensor:
     return _cached_terms(flows, "logdets", compute)
 
 
+INVERSES_IN_ONE_LAUNCH = os.environ.get("NFDP_INVERSES_IN_ONE_LAUNCH", "1") != "0"
+
+
+def _model_inverses(groups) -> list:
+    """W^-1 of several levels (lists of flows): the levels whose size the one-wave Gauss-Jordan takes in ONE launch
+    (K.invconv_inverses), the others level by level (_level_inverses); -> one [K, C, C] tensor per level, in order."""
+    small = [i for i, g in enumerate(groups) if INVERSES_IN_ONE_LAUNCH and K.invconv_inverses_supported(g[0].invconv2d._w().shape[-1])]
+    out = [None] * len(groups)
+    if len(small) > 1:
+        flat = [f for i in small for f in groups[i]]
+        got = _cached_terms(flat, "inverses_multi", lambda: K.invconv_inverses([[f.invconv2d._w() for f in groups[i]] for i in small]))
+        for i, w in zip(small, got):
+            out[i] = w
+    for i, g in enumerate(groups):
+        if out[i] is None:
+            out[i] = _level_inverses(g)
+    return out
+
+
 def _level_inverses(flows: Sequence[StepFlow]) -> Tensor:
     """W^-1 of all K flows of a level (fp64 Gauss-Jordan, one launch; the reference inverts per call, transforms.py:144)."""
     def compute():
@@ -356,14 +375,19 @@ class Glow(Transform):
         # Deep models (L >= 4): the deepest level runs first and needs its W^-1 at once (the sixteen C = 192 Gauss-Jordans: 1.2 ms), but
         # the other levels' inversions (0.5 ms together for a 5-level model) are not needed until their level starts: a side stream
         # computes them beside the deepest level's work - a parallel branch of a captured graph, as the log-dets of the forward pass.
-        pre, side = None, None
+        pre, side, fin = None, None, None
         if LOGDETS_ON_SIDE_STREAM and self.L >= 4 and xh.is_cuda:
             main = torch.cuda.current_stream(xh.device)
             side = _side_stream(xh.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                pre = [_level_inverses(list(b.flows)) for b in self.blocks]
-        xh = _run_flows_inv(self.final_flows, xh)
+                pre = _model_inverses([list(b.flows) for b in self.blocks])
+        elif xh.is_cuda:
+            # shallow models: the 1x1 convs of ALL levels inverted by one launch in front of the pass (one wave per matrix; a 3-level
+            # model ran three launches, one in front of each level: 94 + 20 + 20 us -> as long as the largest)
+            allinv = _model_inverses([list(b.flows) for b in self.blocks] + [list(self.final_flows)])
+            pre, fin = allinv[:-1], allinv[-1]
+        xh = _run_flows_inv(self.final_flows, xh, fin)
         xh = K.unsqueeze(xh)
         if side is not None:
             main.wait_stream(side)

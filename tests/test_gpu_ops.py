@@ -384,3 +384,19 @@ def test_coupling_chunked_matches_per_sample_kernel():
     xr = y.clone()
     K.coupling_inv(xr, h)
     assert float((xr - x).abs().max()) < 1e-4
+
+
+@torch.no_grad()
+def test_inverses_of_all_levels_in_one_launch_equal_the_per_level_launches():
+    """nfdp_invconv_inverses_f32 (W^-1 of matrices of different sizes, one wave each, ONE launch: the 1x1 convs of all levels ahead
+    of Glow.invert) against nfdp_invconv_prepare_f32 level by level: the same Gauss-Jordan -> bit-identical; and against fp64."""
+    g = torch.Generator().manual_seed(5)
+    groups = [[(torch.linalg.qr(torch.randn(c, c, generator=g))[0] + 0.1 * torch.randn(c, c, generator=g)).contiguous().to(DEV) for _ in range(k)]
+              for c, k in ((12, 16), (24, 16), (48, 16), (4, 3), (8, 1), (16, 2))]
+    assert all(K.invconv_inverses_supported(gr[0].shape[-1]) for gr in groups) and not K.invconv_inverses_supported(96)
+    outs = K.invconv_inverses(groups)
+    for gr, out in zip(groups, outs):
+        _, ref = K.invconv_prepare(torch.stack(gr), want_inverse=True)
+        assert torch.equal(out, ref)
+        truth = torch.linalg.inv(torch.stack(gr).double().cpu())
+        assert relerr(out, truth) < 1e-6
