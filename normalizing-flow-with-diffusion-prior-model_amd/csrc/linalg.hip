@@ -358,15 +358,15 @@ __device__ __forceinline__ double gj_inverse_regs(const float* __restrict__ wm, 
     for (int j = 0; j < C; ++j) a[j] = lane < C ? (double)wm[lane * C + j] : 0.0;
     bool used = lane >= C;
     int mystep = -1;
-    double logdet = 0.0;
-#pragma unroll
+    double mypiv = 1.0;                                            // lane k keeps the pivot of step k: the logs are taken after the loop,
+#pragma unroll                                                     // one per lane (an fp64 log per step sat on the serial chain)
     for (int k = 0; k < C; ++k) {
         const unsigned key = used ? 0u : ((__float_as_uint((float)fabs(a[k])) & ~63u) | (unsigned)(63 - lane));
         const int p = 63 - (int)(wave_umax(key) & 63u);
         if (lane == 0) prow_s[k] = p;                              // (LDS: a register array of the 48 pivot rows spilled)
         const double pv = readlane_f64(a[k], p);
         const double rp = 1.0 / pv;
-        logdet += log(fabs(pv));
+        if (lane == k) mypiv = pv;
         const bool mine = lane == p;
         if (mine) { used = true; mystep = k; }
         // one update formula for every row, a[j] -= f * pj with pj = a_p[j] / pv the normalised pivot row: the other rows use f = a[k];
@@ -386,6 +386,10 @@ __device__ __forceinline__ double gj_inverse_regs(const float* __restrict__ wm, 
 #pragma unroll
         for (int k = 0; k < C; ++k) winv[mystep * C + prow_s[k]] = (float)a[k];
     }
+    const double lg = lane < C ? log(fabs(mypiv)) : 0.0;
+    double logdet = 0.0;
+#pragma unroll
+    for (int k = 0; k < C; ++k) logdet += readlane_f64(lg, k);     // step order: the sum the per-step logs gave
     return logdet;
 }
 
