@@ -759,25 +759,28 @@ struct LinkFinish {
     float* dw[kMaxLinkCalls];
     int n, nblk, C, acc; float f3;
     long call_doubles;   // doubles between the partial buffers of consecutive calls
-    int wblocks;         // workgroups per call for the 1x1 conv's weight gradient: ceil(C*C / 64)
+    int wblocks;         // workgroups per call for the 1x1 conv's weight gradient: ceil(C*C / 16)
 };
 __global__ void __launch_bounds__(kBlock) flow_link_finish_kernel(const double* __restrict__ part, const LinkFinish f) {
     __shared__ double red[kBlock];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= 4 * f.n) {
-        // dW[e] (+)= sum over the workgroups' fp32 partials (behind the call's fp64 column sums), 64 elements x 4 groups per workgroup
-        const int wb = blockIdx.x - 4 * f.n, call = wb / f.wblocks, e = (wb % f.wblocks) * 64 + (tid & 63), g = tid >> 6;
+        // dW[e] (+)= sum over the workgroups' fp32 partials (behind the call's fp64 column sums), 16 elements x 16 groups per workgroup
+        // (64 x 4: every thread walked a quarter of the partials - 512 of the 2048 of a 16x16 level - in a launch of ~100 workgroups)
+        const int wb = blockIdx.x - 4 * f.n, call = wb / f.wblocks, e = (wb % f.wblocks) * 16 + (tid & 15), g = tid >> 4;
         float* dst = f.dw[call];
         if (dst == nullptr) return;
         const float* src = reinterpret_cast<const float*>(part + (size_t)call * f.call_doubles + (size_t)f.nblk * 4 * f.C);
         const int cc = f.C * f.C;
         double sum = 0.0;
         if (e < cc)
-            for (int b = g; b < f.nblk; b += 4) sum += (double)src[(size_t)b * cc + e];
+            for (int b = g; b < f.nblk; b += 16) sum += (double)src[(size_t)b * cc + e];
         red[tid] = sum;
         __syncthreads();
         if (g == 0 && e < cc) {
-            const float v = (float)((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
+            double t = 0.0;
+            for (int k = 0; k < 16; ++k) t += red[16 * k + tid];     // fixed order: deterministic
+            const float v = (float)t;
             dst[e] = f.acc ? dst[e] + v : v;
         }
         return;
@@ -786,8 +789,10 @@ __global__ void __launch_bounds__(kBlock) flow_link_finish_kernel(const double* 
     float* dst = q == 0 ? f.dscale[call] : (q == 1 ? f.dbias[call] : (q == 2 ? f.dlogs3[call] : f.dbias3[call]));
     if (dst == nullptr) return;
     const double* src = part + (size_t)call * f.call_doubles + (size_t)q * f.C;
-    const int G = kBlock / 64;                              // 4 groups of 64 threads: channel = tid % 64, blocks g, g+4, ...
-    const int c = tid & 63, g = tid >> 6;
+    // groups of NCH threads (the channel count rounded up to 16 / 32 / 64): channel = tid % NCH, workgroup partials g, g + G, ...
+    // (with 64-thread groups a C = 12 level had 48 of 256 threads at work, each walking 512 of its 2048 partials: 100 us per launch)
+    const int NCH = f.C <= 16 ? 16 : (f.C <= 32 ? 32 : 64), G = kBlock / NCH;
+    const int c = tid % NCH, g = tid / NCH;
     double sum = 0.0;
     if (c < f.C)
         for (int b = g; b < f.nblk; b += G) sum += src[(size_t)b * 4 * f.C + c];
@@ -795,7 +800,7 @@ __global__ void __launch_bounds__(kBlock) flow_link_finish_kernel(const double* 
     __syncthreads();
     if (g == 0 && c < f.C) {
         double t = 0.0;
-        for (int k = 0; k < G; ++k) t += red[k * 64 + c];
+        for (int k = 0; k < G; ++k) t += red[k * NCH + c];      // fixed order: deterministic
         const float v = (float)(q == 2 ? t * (double)f.f3 : t);
         dst[c] = f.acc ? dst[c] + v : v;
     }
@@ -874,7 +879,7 @@ extern "C" int nfdp_flow_link_finish_f32(const void* part, int n_calls, long npi
     }
     f.n = n_calls; f.nblk = (int)cdiv(npix, link_block(npix)); f.C = C; f.acc = accumulate; f.f3 = f3;
     f.call_doubles = (long)(nfdp_flow_link_bwd_part_bytes(npix, C) / sizeof(double));
-    f.wblocks = (C * C + 63) / 64;
+    f.wblocks = (C * C + 15) / 16;
     hipLaunchKernelGGL(flow_link_finish_kernel, dim3(4 * n_calls + (any_dw ? n_calls * f.wblocks : 0)), dim3(kBlock), 0, as_stream(stream),
                        reinterpret_cast<const double*>(part), f);
     NFDP_CHECK_LAUNCH("flow_link_finish");
