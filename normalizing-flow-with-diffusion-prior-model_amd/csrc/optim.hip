@@ -18,12 +18,24 @@ __global__ void __launch_bounds__(kBlock) clip_value_sumsq_kernel(float* __restr
                                                                  double* __restrict__ partial) {
     __shared__ double red[kBlock / 64];
     double acc = 0.0;
-    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < n_clip; i += (long)gridDim.x * kBlock) {
-        float v = g[i];
+    const bool touch = clip > 0.f || scale != 1.0f;
+    auto one = [&](float v) -> float {
         if (scale != 1.0f) v *= scale;
         if (clip > 0.f) v = fminf(fmaxf(v, -clip), clip);
-        if (clip > 0.f || scale != 1.0f) g[i] = v;
         acc += (double)v * (double)v;
+        return v;
+    };
+    // 16-byte accesses where the buffer allows it; a thread adds its elements' squares in index order as before, only the assignment
+    // of elements to threads differs from the element-by-element loop (the partial sums are fp64)
+    const long n4 = (((uintptr_t)g & 15) == 0) ? n_clip / 4 : 0;
+    for (long q = blockIdx.x * (long)kBlock + threadIdx.x; q < n4; q += (long)gridDim.x * kBlock) {
+        float4 v = reinterpret_cast<const float4*>(g)[q];
+        v.x = one(v.x); v.y = one(v.y); v.z = one(v.z); v.w = one(v.w);
+        if (touch) reinterpret_cast<float4*>(g)[q] = v;
+    }
+    for (long i = 4 * n4 + blockIdx.x * (long)kBlock + threadIdx.x; i < n_clip; i += (long)gridDim.x * kBlock) {
+        const float v = one(g[i]);
+        if (touch) g[i] = v;
     }
     acc = wave_sum_d(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -65,25 +77,51 @@ __global__ void __launch_bounds__(kBlock) adam_step_kernel(float* __restrict__ p
     lr = hyp_s[0];
     bias_c2_sqrt = hyp_s[2];
     const float step_size = lr / hyp_s[1];
-    for (long i = blockIdx.x * (long)kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
-        float gi = g[i];
-        if (i >= scaled_upto && grad_scale != 1.0f) {                      // elements the clip pass did not visit: 1/world here
-            gi *= grad_scale;
-            g[i] = gi;
-        }
-        if (i < n_clip && coef != 1.0f) {
-            gi *= coef;
-            g[i] = gi;                                                     // clip_grad_norm_ scales the gradients in place
-        }
-        float pi = p[i];
+    // one element: the in-place gradient scalings, then torch's Adam expressions; returns whether g changed
+    auto elem = [&](long i, float& gi, float& pi, float& mi, float& vi) -> bool {
+        bool gch = false;
+        if (i >= scaled_upto && grad_scale != 1.0f) { gi *= grad_scale; gch = true; }     // elements the clip pass did not visit: 1/world here
+        if (i < n_clip && coef != 1.0f) { gi *= coef; gch = true; }                         // clip_grad_norm_ scales the gradients in place
         if (weight_decay != 0.f) {
             if (adamw) pi *= 1.0f - lr * weight_decay;
             else gi = fmaf(weight_decay, pi, gi);
         }
-        const float mi = fmaf(beta1, m[i], (1.0f - beta1) * gi);
-        const float vi = fmaf(beta2, v[i], (1.0f - beta2) * gi * gi);
+        mi = fmaf(beta1, mi, (1.0f - beta1) * gi);
+        vi = fmaf(beta2, vi, (1.0f - beta2) * gi * gi);
         const float denom = sqrtf(vi) / bias_c2_sqrt + eps;
-        p[i] = pi - step_size * (mi / denom);
+        pi = pi - step_size * (mi / denom);
+        return gch;
+    };
+    // 16-byte accesses where the four buffers allow it (flat optimizer buffers do), the n % 4 tail element by element
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+    const long n4 = vec ? n / 4 : 0;
+    for (long q = blockIdx.x * (long)kBlock + threadIdx.x; q < n4; q += (long)gridDim.x * kBlock) {
+        float4 g4 = reinterpret_cast<const float4*>(g)[q], p4 = reinterpret_cast<const float4*>(p)[q];
+        float4 m4 = reinterpret_cast<const float4*>(m)[q], v4 = reinterpret_cast<const float4*>(v)[q];
+        float g4a[4] = {g4.x, g4.y, g4.z, g4.w};                            // gradient as scaled in place (before weight decay is folded in)
+        float gi[4] = {g4.x, g4.y, g4.z, g4.w}, pi[4] = {p4.x, p4.y, p4.z, p4.w}, mi[4] = {m4.x, m4.y, m4.z, m4.w}, vi[4] = {v4.x, v4.y, v4.z, v4.w};
+        bool gch = false;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long i = 4 * q + e;
+            if (i >= scaled_upto && grad_scale != 1.0f) { g4a[e] *= grad_scale; gch = true; }
+            if (i < n_clip && coef != 1.0f) { g4a[e] *= coef; gch = true; }
+            elem(i, gi[e], pi[e], mi[e], vi[e]);
+        }
+        if (gch) reinterpret_cast<float4*>(g)[q] = make_float4(g4a[0], g4a[1], g4a[2], g4a[3]);
+        reinterpret_cast<float4*>(p)[q] = make_float4(pi[0], pi[1], pi[2], pi[3]);
+        reinterpret_cast<float4*>(m)[q] = make_float4(mi[0], mi[1], mi[2], mi[3]);
+        reinterpret_cast<float4*>(v)[q] = make_float4(vi[0], vi[1], vi[2], vi[3]);
+    }
+    for (long i = 4 * n4 + blockIdx.x * (long)kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        float gi = g[i], pi = p[i], mi = m[i], vi = v[i];
+        float gs = gi;
+        bool gch = false;
+        if (i >= scaled_upto && grad_scale != 1.0f) { gs *= grad_scale; gch = true; }
+        if (i < n_clip && coef != 1.0f) { gs *= coef; gch = true; }
+        elem(i, gi, pi, mi, vi);
+        if (gch) g[i] = gs;
+        p[i] = pi;
         m[i] = mi;
         v[i] = vi;
     }
