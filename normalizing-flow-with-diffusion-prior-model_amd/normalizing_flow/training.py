@@ -573,12 +573,18 @@ class _StepPacks:
         self.batch = K.PackBatch(specs, K.BF16) if specs else None        # the Parameters themselves: matches() follows re-pointed .data
 
     def refresh(self) -> None:
-        if self.batch is not None:
-            self.batch.run()
+        """A new step: the layouts are stale.  The packing launch itself waits for the first get() - a model whose levels all run on the
+        fused level kernels (their own images) never asks, and 288 layouts cost 137 us at the head of every step."""
+        self._fresh = False
 
     def get(self, flow):
         i = self.index.get(id(flow))
-        return None if i is None else self.batch.views[i:i + 6]
+        if i is None:
+            return None
+        if not getattr(self, "_fresh", False):
+            self.batch.run()
+            self._fresh = True
+        return self.batch.views[i:i + 6]
 
 
 def _step_packs(glow):
@@ -872,8 +878,7 @@ def _level_fused(flows, yh: Tensor, ldj: Optional[Tensor], sp, wts: Tensor):
         net = f.affcoupling.net
         c1, c2, zc = net[0], net[2], net[4]
         packed.append(net._fused_train)
-        six = sp.get(f) if sp else None
-        bpacks.append(tuple(six[3:]) if six is not None else None)
+        bpacks.append(None)                       # (the fused backward packs its own reverse images: coupling_bwd_fused_pack_batch)
         params += [f.actnorm.scale, f.actnorm.bias, f.invconv2d.weight, c1.conv.weight, c1.actnorm.bias, c1.actnorm.scale,
                    c2.conv.weight, c2.actnorm.bias, c2.actnorm.scale, zc.weight, zc.bias, zc.logs]
     f3 = flows[0].affcoupling.net[4].logscale_factor
