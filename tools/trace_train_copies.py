@@ -21,8 +21,9 @@ cnt = collections.Counter()
 shapes = collections.defaultdict(set)
 for e in ev:
     if e.name in ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::fill_", "aten::zero_", "aten::zeros", "aten::empty_like"):
-        st = [s for s in (e.stack or []) if "normalizing" in s or "nfdp_hip" in s or "bench.py" in s]
-        key = (e.name, st[0] if st else "?")
+        st = [s for s in (e.stack or []) if ("training.py" in s or "nfdp_hip" in s or "bench.py" in s or "glow.py" in s or "utils.py" in s or "prior.py" in s)
+              and "torch/" not in s]
+        key = (e.name, " <- ".join(x.split("/")[-1][:60] for x in st[:2]) if st else "?")
         cnt[key] += 1
         shapes[key].add(str(e.input_shapes)[:80])
 for (name, where), n in cnt.most_common(40):
