@@ -218,12 +218,49 @@ def _run_flows_fwd(flows: Sequence[StepFlow], xh: Tensor, ldj: Optional[Tensor],
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device) -> "torch.cuda.Stream":
-    """One auxiliary HIP stream per device for weight-only work that can overlap the flow kernels."""
-    key = torch.device(device).index
+def _side_stream(device, main=None) -> "torch.cuda.Stream":
+    """The auxiliary HIP stream for weight-only work that overlaps the flow kernels of a pass issued on `main` (default: the
+    current stream).  One per (device, ISSUING stream): two passes issued on two streams - two branches of one captured graph, two
+    threads - must never fork into the same side stream (a second `side.wait_stream(other_main)` arriving while the side stream
+    still belonged to the first branch's capture ended in a host segfault inside hipStreamEndCapture, round 4)."""
+    dev = torch.device(device)
+    if main is None:
+        main = torch.cuda.current_stream(dev)
+    key = (dev.index, main.cuda_stream)
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
     return _SIDE_STREAMS[key]
+
+
+class _SideBranch:
+    """`with _SideBranch(device, on) as br:` - br.side is the side stream of the current stream, forked behind everything the
+    current stream holds so far (None when `on` is false).  `br.join(tensors)` makes the issuing stream wait for it and hands it
+    the tensors the side stream produced; leaving the block ALWAYS joins (also on an exception between fork and join: an un-joined
+    fork under torch.cuda.graph would surface as a capture error that hides the real one)."""
+
+    def __init__(self, device, on: bool):
+        self.main = torch.cuda.current_stream(device) if on else None
+        self.side = _side_stream(device, self.main) if on else None
+        self.joined = not on
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.main)
+        return self
+
+    def join(self, tensors=()):
+        if not self.joined:
+            self.main.wait_stream(self.side)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(self.main)
+            self.joined = True
+
+    def __exit__(self, *exc):
+        if not self.joined:
+            self.main.wait_stream(self.side)
+            self.joined = True
+        return False
 
 
 def _run_flows_inv(flows: Sequence[StepFlow], yh: Tensor, winvs: Optional[Tensor] = None) -> Tensor:
@@ -312,51 +349,45 @@ class Glow(Transform):
         # per matrix, ~10-20 us) ahead of the flow kernels; the per-level sums  H*W * sum_k log|det W_k|  are folded into
         # ldj once at the end (an fp64 re-association of the reference's per-flow adds, transforms.py:131).
         lads = None
-        side = None
-        if ldj is not None:
-            # Deep models (L >= 4): the wide levels' Gauss-Jordans are not short (1.4 ms for the 16 C = 192 matrices of a 5-level model: a
-            # fifth of its forward pass) and nothing reads their result before the end, so they run on a side stream beside the first
-            # levels' flows - parallel branches of a captured graph.  (L = 3: 25 us, and a level launch holds every CU: same stream.)
-            main = torch.cuda.current_stream(xh.device)
-            if LOGDETS_ON_SIDE_STREAM and self.L >= 4:
-                side = _side_stream(xh.device)
-                side.wait_stream(main)
-            with torch.cuda.stream(side if side is not None else main):
-                groups = [list(b.flows) for b in self.blocks] + [list(self.final_flows)]
-                small = [g for g in groups if g[0].invconv2d._w().shape[-1] <= 96]      # the one-launch LU holds a matrix in LDS
-                flat = _cached_terms([f for g in small for f in g], "logdets_all",
-                                     lambda: K.invconv_logdets([f.invconv2d._w() for g in small for f in g])) if small else None
-                lads, o = [], 0
-                for g in groups:
-                    if g[0].invconv2d._w().shape[-1] <= 96:
-                        lads.append(flat[o:o + len(g)])
-                        o += len(g)
-                    else:                          # C = 192 at the last level of a 5-level model: batched Gauss-Jordan, global workspace
-                        lads.append(_level_logdets(g))
-        hws = []
-        # the Split priors' terms (a narrow 3x3 conv + the Gaussian log-density per level: ~25 us each, launch-bound) only feed logp:
-        # on a second stream they run beside the next level's flows instead of between two level launches
-        pstream = None
-        if PRIORS_ON_SIDE_STREAM and logp is not None and xh.is_cuda:
-            pstream = _side_stream(xh.device) if side is None else side
-        for i, block in enumerate(self.blocks):
-            yh, z = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True, prior_stream=pstream)
-            hws.append(z.shape[1] * z.shape[2])
-            zs.append(z)
-        yh = K.squeeze(yh)
-        hws.append(yh.shape[1] * yh.shape[2])
-        yh = _run_flows_fwd(self.final_flows, yh, ldj, None, defer_logdet=True)
-        zs.append(yh)
-        if pstream is not None and pstream is not side:
-            torch.cuda.current_stream(xh.device).wait_stream(pstream)
-        if ldj is not None:
-            if side is not None:
-                main = torch.cuda.current_stream(xh.device)
-                main.wait_stream(side)
-                for lad in lads:
-                    lad.record_stream(main)
-            for lad, hw in zip(lads, hws):
-                K.ldj_add_scaled(ldj, lad, lad.numel(), hw)
+        # Deep models (L >= 4): the wide levels' Gauss-Jordans are not short (1.4 ms for the 16 C = 192 matrices of a 5-level model: a
+        # fifth of its forward pass) and nothing reads their result before the end, so they run on a side stream beside the first
+        # levels' flows - parallel branches of a captured graph.  (L = 3: 25 us, and a level launch holds every CU: same stream.)
+        with _SideBranch(xh.device, ldj is not None and LOGDETS_ON_SIDE_STREAM and self.L >= 4 and xh.is_cuda) as br:
+            if ldj is not None:
+                with torch.cuda.stream(br.side if br.side is not None else torch.cuda.current_stream(xh.device)):
+                    groups = [list(b.flows) for b in self.blocks] + [list(self.final_flows)]
+                    small = [g for g in groups if g[0].invconv2d._w().shape[-1] <= 96]      # the one-launch LU holds a matrix in LDS
+                    flat = _cached_terms([f for g in small for f in g], "logdets_all",
+                                         lambda: K.invconv_logdets([f.invconv2d._w() for g in small for f in g])) if small else None
+                    lads, o = [], 0
+                    for g in groups:
+                        if g[0].invconv2d._w().shape[-1] <= 96:
+                            lads.append(flat[o:o + len(g)])
+                            o += len(g)
+                        else:                      # C = 192 at the last level of a 5-level model: batched Gauss-Jordan, global workspace
+                            lads.append(_level_logdets(g))
+            hws = []
+            # the Split priors' terms (a narrow 3x3 conv + the Gaussian log-density per level: ~25 us each, launch-bound) only feed
+            # logp: on a second stream they run beside the next level's flows instead of between two level launches
+            pstream = None
+            if PRIORS_ON_SIDE_STREAM and logp is not None and xh.is_cuda:
+                pstream = _side_stream(xh.device) if br.side is None else br.side
+            try:
+                for i, block in enumerate(self.blocks):
+                    yh, z = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True, prior_stream=pstream)
+                    hws.append(z.shape[1] * z.shape[2])
+                    zs.append(z)
+                yh = K.squeeze(yh)
+                hws.append(yh.shape[1] * yh.shape[2])
+                yh = _run_flows_fwd(self.final_flows, yh, ldj, None, defer_logdet=True)
+                zs.append(yh)
+            finally:
+                if pstream is not None and pstream is not br.side:
+                    torch.cuda.current_stream(xh.device).wait_stream(pstream)
+            if ldj is not None:
+                br.join(lads)
+                for lad, hw in zip(lads, hws):
+                    K.ldj_add_scaled(ldj, lad, lad.numel(), hw)
         return zs
 
     def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[list, Tensor, Tensor]:
@@ -375,24 +406,21 @@ class Glow(Transform):
         # Deep models (L >= 4): the deepest level runs first and needs its W^-1 at once (the sixteen C = 192 Gauss-Jordans: 1.2 ms), but
         # the other levels' inversions (0.5 ms together for a 5-level model) are not needed until their level starts: a side stream
         # computes them beside the deepest level's work - a parallel branch of a captured graph, as the log-dets of the forward pass.
-        pre, side, fin = None, None, None
-        if LOGDETS_ON_SIDE_STREAM and self.L >= 4 and xh.is_cuda:
-            main = torch.cuda.current_stream(xh.device)
-            side = _side_stream(xh.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                pre = _model_inverses([list(b.flows) for b in self.blocks])
-        elif xh.is_cuda:
-            # shallow models: the 1x1 convs of ALL levels inverted by one launch in front of the pass (one wave per matrix; a 3-level
-            # model ran three launches, one in front of each level: 94 + 20 + 20 us -> as long as the largest)
-            allinv = _model_inverses([list(b.flows) for b in self.blocks] + [list(self.final_flows)])
-            pre, fin = allinv[:-1], allinv[-1]
-        xh = _run_flows_inv(self.final_flows, xh, fin)
-        xh = K.unsqueeze(xh)
-        if side is not None:
-            main.wait_stream(side)
-            for w in pre:
-                w.record_stream(main)
+        pre, fin = None, None
+        deep = bool(LOGDETS_ON_SIDE_STREAM and self.L >= 4 and xh.is_cuda)
+        with _SideBranch(xh.device, deep) as br:
+            if deep:
+                with torch.cuda.stream(br.side):
+                    pre = _model_inverses([list(b.flows) for b in self.blocks])
+            elif xh.is_cuda:
+                # shallow models: the 1x1 convs of ALL levels inverted by one launch in front of the pass (one wave per matrix; a
+                # 3-level model ran three launches, one in front of each level: 94 + 20 + 20 us -> as long as the largest)
+                allinv = _model_inverses([list(b.flows) for b in self.blocks] + [list(self.final_flows)])
+                pre, fin = allinv[:-1], allinv[-1]
+            xh = _run_flows_inv(self.final_flows, xh, fin)
+            xh = K.unsqueeze(xh)
+            if deep:
+                br.join(pre)
         j = 0
         for i, block in enumerate(reversed(self.blocks)):
             latent = get_item(latents, -(i + 2))              # None -> Split samples from its learned prior
@@ -410,6 +438,14 @@ class Glow(Transform):
         lat = [K.to_nhwc(z) for z in latents]
         eh = None if eps is None else [K.to_nhwc(e).contiguous() for e in eps]
         return K.as_nchw(self.invert_nhwc(lat, temperature, eh))
+
+    # BASELINE.json's north_star spells the call surface `Glow.forward() / inverse()`; the reference defines neither (its Glow has only
+    # transform / invert, glow.py:172, :203; SURVEY 8(b) allows the aliases).  `flow(x, ldj, logp)` therefore works like transform.
+    def forward(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[list, Tensor, Tensor]:
+        return self.transform(x, log_det_jac, logp)
+
+    def inverse(self, latents: list, temperature: float = 1.0, eps: Optional[Sequence[Tensor]] = None) -> Tensor:
+        return self.invert(latents, temperature, eps)
 
     @torch.no_grad()
     def sample(self, latents: list, postprocess_func=None, temperature: float = 1.0) -> Tensor:

@@ -417,3 +417,64 @@ def test_graphed_forward_matches_eager():
         z_ref, ll_ref = step(x)
         z, ll = graphed(x)
         assert torch.equal(z, z_ref) and torch.equal(ll, ll_ref)
+
+
+@torch.no_grad()
+def test_two_deep_transforms_on_two_streams_in_one_graph():
+    """Two Glow.transform_nhwc (and two invert_nhwc) calls of an L = 5 model issued on two streams inside ONE capture, replayed: each
+    issuing stream forks its own side stream for the 1x1-conv log-dets / inverses (glow._side_stream is keyed by the issuing
+    stream).  With one side stream per device the same capture died in hipStreamEndCapture (round 4 record)."""
+    from normalizing_flow import Glow, glow as G
+    assert G.LOGDETS_ON_SIDE_STREAM
+    flow = Glow(in_channel=3, L=5, K=2, compute="bf16")
+    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 9, DEEP)) for k, v in flow.state_dict().items()}, strict=True)
+    flow.to(DEV)
+    xs = [K.to_nhwc(T(images_5bit(f"two{i}", (2, 3, 64, 64), 21 + i)[0]).to(DEV)).contiguous() for i in range(2)]
+    ref = []
+    for x in xs:                                               # eager, one after the other, on the current stream
+        ldj = z64(2)
+        zs = flow.transform_nhwc(x, ldj, None)
+        ref.append(([z.clone() for z in zs], ldj.clone(), flow.invert_nhwc(zs).clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ldjs = [z64(2), z64(2)]
+    out = [None, None]
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(g, stream=cap):
+            for i, s in enumerate(streams):
+                s.wait_stream(cap)
+                with torch.cuda.stream(s):
+                    ldjs[i].zero_()
+                    zs = flow.transform_nhwc(xs[i], ldjs[i], None)
+                    out[i] = (zs, flow.invert_nhwc(zs))
+            for s in streams:
+                cap.wait_stream(s)
+    torch.cuda.current_stream().wait_stream(cap)
+    sides = {k for k in G._SIDE_STREAMS}
+    assert len({k[1] for k in sides if k[1] in {s.cuda_stream for s in streams}}) == 2     # one side stream per issuing stream
+    for _ in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        for i in range(2):
+            zs_ref, ldj_ref, x_ref = ref[i]
+            assert all(torch.equal(a, b) for a, b in zip(out[i][0], zs_ref))
+            assert torch.equal(ldjs[i], ldj_ref) and torch.equal(out[i][1], x_ref)
+
+
+@torch.no_grad()
+def test_forward_and_inverse_aliases():
+    """BASELINE.json's north_star names the surface Glow.forward() / inverse(); the reference only has transform / invert
+    (glow.py:172, :203).  Both spellings reach the same code."""
+    flow, _ = _north_star("f32", K_flows=1)
+    flow.to(DEV)
+    x = T(images_5bit("alias", (2, 3, 32, 32), 5)[0]).to(DEV)
+    zs, ldj, logp = flow.transform(x, z64(2), z64(2))
+    zs2, ldj2, logp2 = flow(x, z64(2), z64(2))
+    zs3, _, _ = flow.forward(x, z64(2), z64(2))
+    assert all(torch.equal(a, b) and torch.equal(a, c) for a, b, c in zip(zs, zs2, zs3))
+    assert torch.equal(ldj, ldj2) and torch.equal(logp, logp2)
+    assert torch.equal(flow.inverse(zs), flow.invert(zs))
+    assert torch.equal(flow.inverse(zs[-1:], temperature=0.0), flow.invert(zs[-1:], temperature=0.0))
