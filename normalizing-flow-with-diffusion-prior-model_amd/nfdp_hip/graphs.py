@@ -10,9 +10,50 @@ A captured graph reads the kernel-layout weight copies that existed at capture t
 re-captured after the parameters change; a training-step graph re-packs its weights inside the graph (the warm-up step's
 optimizer update invalidates every cache, so the packing launches are recorded) and can be replayed indefinitely.
 """
+import contextlib
+import threading
 from typing import Callable, Sequence
 
 import torch
+
+
+# ---------------------------------------------------------------------------------------------------------------- side branches under capture
+# ROCm 7.2's hipStreamEndCapture dies with a host segfault when the capture contains a NESTED fork: a stream forked from a stream that
+# was itself forked from the capture's origin stream.  Pure torch reproduces it - origin -> s (wait_stream) -> side (wait_stream), one
+# elementwise kernel each, joins in reverse order; `tools/probe_nested_capture.py`, profiles/r05_b_nested_capture.txt: every nested
+# variant exits with SIGSEGV inside capture_end, re-forking a joined stream and two non-nested forks are fine.  Round 4 met it as "two
+# Glow L5 passes on two streams in one graph": each pass forks a side stream for its 1x1-conv log-dets, which is a nested fork when
+# the pass itself runs on a forked stream.
+# The package therefore forks a side stream under capture ONLY from the capture's origin stream.  HIP has no query for "is this the
+# origin stream", so the origin must be known: torch.cuda.graph()'s default capture stream is (that covers `with torch.cuda.graph(g):`,
+# capture_step and Graphed), a stream passed as torch.cuda.graph(g, stream=s) is declared with `with capture_origin(s):`.  On any
+# other capturing stream the side work is issued inline on the calling stream - correct, just not overlapped.
+_declared = threading.local()
+
+
+@contextlib.contextmanager
+def capture_origin(stream: "torch.cuda.Stream"):
+    """Declare `stream` as the origin stream of the capture made inside the block (needed only with torch.cuda.graph(g, stream=stream))."""
+    held = getattr(_declared, "streams", None)
+    if held is None:
+        held = _declared.streams = []
+    held.append(stream.cuda_stream)
+    try:
+        yield stream
+    finally:
+        held.remove(stream.cuda_stream)
+
+
+def side_branch_allowed(device=None) -> bool:
+    """May the caller fork a side stream from the current stream?  Always outside a capture; under capture only when the current stream
+    is the (known) origin of the capture - see the note above."""
+    if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+        return True
+    cur = torch.cuda.current_stream(device).cuda_stream
+    if cur in getattr(_declared, "streams", ()):
+        return True
+    default = getattr(torch.cuda.graph, "default_capture_stream", None)
+    return default is not None and default.cuda_stream == cur
 
 
 class Graphed:

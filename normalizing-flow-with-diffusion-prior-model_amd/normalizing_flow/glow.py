@@ -16,6 +16,7 @@ import torch.nn as nn
 from torch import Tensor
 
 import nfdp_hip as K
+from nfdp_hip import graphs as _graphs
 from .base import Transform, acc_in, acc_out
 from .transforms import ActNorm, InvConv2d, AffineCoupling, Squeeze, Split
 from .utils import get_item
@@ -220,9 +221,8 @@ _SIDE_STREAMS = {}
 
 def _side_stream(device, main=None) -> "torch.cuda.Stream":
     """The auxiliary HIP stream for weight-only work that overlaps the flow kernels of a pass issued on `main` (default: the
-    current stream).  One per (device, ISSUING stream): two passes issued on two streams - two branches of one captured graph, two
-    threads - must never fork into the same side stream (a second `side.wait_stream(other_main)` arriving while the side stream
-    still belonged to the first branch's capture ended in a host segfault inside hipStreamEndCapture, round 4)."""
+    current stream).  One per (device, ISSUING stream): two passes issued on two streams (two threads, two eager pipelines) do not
+    serialise on one shared side stream, and a side stream never belongs to two captures."""
     dev = torch.device(device)
     if main is None:
         main = torch.cuda.current_stream(dev)
@@ -239,6 +239,9 @@ class _SideBranch:
     fork under torch.cuda.graph would surface as a capture error that hides the real one)."""
 
     def __init__(self, device, on: bool):
+        # (under capture a side stream may only be forked from the capture's origin stream: a nested fork kills hipStreamEndCapture,
+        # nfdp_hip.graphs.side_branch_allowed; elsewhere the side work is issued inline on the calling stream)
+        on = bool(on) and _graphs.side_branch_allowed(device)
         self.main = torch.cuda.current_stream(device) if on else None
         self.side = _side_stream(device, self.main) if on else None
         self.joined = not on
@@ -370,7 +373,7 @@ class Glow(Transform):
             # the Split priors' terms (a narrow 3x3 conv + the Gaussian log-density per level: ~25 us each, launch-bound) only feed
             # logp: on a second stream they run beside the next level's flows instead of between two level launches
             pstream = None
-            if PRIORS_ON_SIDE_STREAM and logp is not None and xh.is_cuda:
+            if PRIORS_ON_SIDE_STREAM and logp is not None and xh.is_cuda and _graphs.side_branch_allowed(xh.device):
                 pstream = _side_stream(xh.device) if br.side is None else br.side
             try:
                 for i, block in enumerate(self.blocks):
@@ -407,8 +410,8 @@ class Glow(Transform):
         # the other levels' inversions (0.5 ms together for a 5-level model) are not needed until their level starts: a side stream
         # computes them beside the deepest level's work - a parallel branch of a captured graph, as the log-dets of the forward pass.
         pre, fin = None, None
-        deep = bool(LOGDETS_ON_SIDE_STREAM and self.L >= 4 and xh.is_cuda)
-        with _SideBranch(xh.device, deep) as br:
+        with _SideBranch(xh.device, LOGDETS_ON_SIDE_STREAM and self.L >= 4 and xh.is_cuda) as br:
+            deep = br.side is not None
             if deep:
                 with torch.cuda.stream(br.side):
                     pre = _model_inverses([list(b.flows) for b in self.blocks])

@@ -122,6 +122,9 @@ class _OnSide:
     def __enter__(self):
         if not WGRAD_SIDE_STREAM:
             return self
+        from nfdp_hip.graphs import side_branch_allowed
+        if not side_branch_allowed():         # capturing on a stream that is not the capture's origin: a nested fork kills
+            return self                       # hipStreamEndCapture (nfdp_hip.graphs) - the weight gradients run inline instead
         dev = torch.cuda.current_device()
         side = _side_streams.get(dev)
         if side is None:

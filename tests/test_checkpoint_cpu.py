@@ -71,3 +71,40 @@ def test_diffusion_checkpoint_contains_unets(tmp_path):
     assert load_model(nf2, dp2, str(tmp_path), 2, optim=optim) == 9
     assert all(torch.equal(dp2.state_dict()[k].cpu(), v) for k, v in sd_d.items())
     assert all(torch.equal(nf2.state_dict()[k].cpu(), v) for k, v in sd_n.items())
+
+
+REF_CKPT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_ckpt")
+
+
+def test_checkpoint_written_by_the_reference_loads():
+    """tests/golden/ref_ckpt/model_gaussian_000.pt + architecture.pkl were written by the REFERENCE's own save_model
+    (normalizing_flow/prior.py:102-115) and pickle lines (run_baseline_experiment.py:65-68) after two of its training steps
+    (tools/make_ref_checkpoint.py): the file format - dict keys, state-dict keys and shapes, a populated torch-Adam state, the pickle -
+    is read by this package's load_architecture / load_model / NFBackbone and the optimizer state by init_optimizer's Adam."""
+    import json
+    from normalizing_flow import Glow, GaussianPrior, NFBackbone, load_model, load_architecture, init_optimizer
+    arch = load_architecture(REF_CKPT)
+    assert arch == {"L": 2, "K": 1, "learn_prior_mean_logs": True}
+    meta = json.loads(str(np.load(os.path.join(REF_CKPT, "ref_ckpt.npz"))["meta"]))
+    ck = torch.load(os.path.join(REF_CKPT, "model_gaussian_000.pt"), map_location="cpu")
+    assert set(ck) == {"flow", "prior_dist", "optimizer", "current_iter"} and ck["current_iter"] == meta["current_iter"]
+    flow = Glow(in_channel=meta["C"], L=arch["L"], K=arch["K"], learn_prior_mean_logs=arch["learn_prior_mean_logs"])
+    prior = GaussianPrior(2 ** (arch["L"] + 1) * meta["C"], arch["learn_prior_mean_logs"])
+    assert list(flow.state_dict().keys()) == meta["flow_keys"] == list(ck["flow"].keys())       # same keys, same ORDER
+    assert list(prior.state_dict().keys()) == meta["prior_keys"] == list(ck["prior_dist"].keys())
+    optim = init_optimizer("adam", [{"params": list(flow.parameters()) + list(prior.parameters())}], lr=1e-3)
+    assert load_model(flow, prior, REF_CKPT, 0, optim=optim) == 2
+    for k, v in ck["flow"].items():
+        assert torch.equal(flow.state_dict()[k].cpu(), v), k
+    for k, v in ck["prior_dist"].items():
+        assert torch.equal(prior.state_dict()[k].cpu(), v), k
+    # the reference's Adam state arrived: one (step, exp_avg, exp_avg_sq) per parameter, in the parameter order both sides share
+    params = list(flow.parameters()) + list(prior.parameters())
+    st = optim.state_dict()["state"]
+    assert len(st) == len(params) == len(ck["optimizer"]["state"])
+    for i, p in enumerate(params):
+        assert st[i]["exp_avg"].shape == p.shape and float(st[i]["step"]) == 2.0
+        assert torch.equal(st[i]["exp_avg_sq"].cpu(), ck["optimizer"]["state"][i]["exp_avg_sq"])
+    assert all(bool(f.actnorm.is_initialized) for f in flow.final_flows)       # the data-dependent init flags travelled too
+    nf = NFBackbone(model_dir=os.path.join(REF_CKPT, "model_gaussian_000.pt"), in_channel=meta["C"], freeze_flow=True, **arch)
+    assert all(torch.equal(nf.model.state_dict()[k].cpu(), v) for k, v in ck["flow"].items())

@@ -421,10 +421,13 @@ def test_graphed_forward_matches_eager():
 
 @torch.no_grad()
 def test_two_deep_transforms_on_two_streams_in_one_graph():
-    """Two Glow.transform_nhwc (and two invert_nhwc) calls of an L = 5 model issued on two streams inside ONE capture, replayed: each
-    issuing stream forks its own side stream for the 1x1-conv log-dets / inverses (glow._side_stream is keyed by the issuing
-    stream).  With one side stream per device the same capture died in hipStreamEndCapture (round 4 record)."""
+    """Two Glow.transform_nhwc + invert_nhwc passes of an L = 5 model issued on two streams inside ONE capture, replayed.  Round 4 died
+    in hipStreamEndCapture on exactly this: ROCm's capture cannot end when it holds a NESTED fork (a stream forked from a forked
+    stream - pure torch reproduces it, tools/probe_nested_capture.py, profiles/r05_b_nested_capture.txt), and each pass forked a side
+    stream for its 1x1-conv log-dets / inverses.  Under capture the passes now fork only from the capture's origin stream
+    (nfdp_hip.graphs.side_branch_allowed) and issue the side work inline elsewhere; results equal the eager passes bit for bit."""
     from normalizing_flow import Glow, glow as G
+    from nfdp_hip import graphs
     assert G.LOGDETS_ON_SIDE_STREAM
     flow = Glow(in_channel=3, L=5, K=2, compute="bf16")
     flow.load_state_dict({k: T(synth_tensor(k, v.shape, 9, DEEP)) for k, v in flow.state_dict().items()}, strict=True)
@@ -439,22 +442,22 @@ def test_two_deep_transforms_on_two_streams_in_one_graph():
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     ldjs = [z64(2), z64(2)]
     out = [None, None]
+    allowed = []
     g = torch.cuda.CUDAGraph()
-    cap = torch.cuda.Stream()
-    cap.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(cap):
-        with torch.cuda.graph(g, stream=cap):
-            for i, s in enumerate(streams):
-                s.wait_stream(cap)
-                with torch.cuda.stream(s):
-                    ldjs[i].zero_()
-                    zs = flow.transform_nhwc(xs[i], ldjs[i], None)
-                    out[i] = (zs, flow.invert_nhwc(zs))
-            for s in streams:
-                cap.wait_stream(s)
-    torch.cuda.current_stream().wait_stream(cap)
-    sides = {k for k in G._SIDE_STREAMS}
-    assert len({k[1] for k in sides if k[1] in {s.cuda_stream for s in streams}}) == 2     # one side stream per issuing stream
+    with torch.cuda.graph(g):
+        cap = torch.cuda.current_stream()
+        allowed.append(graphs.side_branch_allowed())           # torch.cuda.graph's own capture stream: the origin
+        for i, s in enumerate(streams):
+            s.wait_stream(cap)
+            with torch.cuda.stream(s):
+                allowed.append(graphs.side_branch_allowed())   # a forked stream: no second-level fork
+                ldjs[i].zero_()
+                zs = flow.transform_nhwc(xs[i], ldjs[i], None)
+                out[i] = (zs, flow.invert_nhwc(zs))
+        for s in streams:
+            cap.wait_stream(s)
+    assert allowed == [True, False, False]
+    assert not any(k[1] in {s.cuda_stream for s in streams} for k in G._SIDE_STREAMS)      # nothing forked from the forked streams
     for _ in range(2):
         g.replay()
         torch.cuda.synchronize()
@@ -462,6 +465,35 @@ def test_two_deep_transforms_on_two_streams_in_one_graph():
             zs_ref, ldj_ref, x_ref = ref[i]
             assert all(torch.equal(a, b) for a, b in zip(out[i][0], zs_ref))
             assert torch.equal(ldjs[i], ldj_ref) and torch.equal(out[i][1], x_ref)
+
+
+@torch.no_grad()
+def test_deep_model_capture_on_a_declared_origin_stream_keeps_its_side_branch():
+    """torch.cuda.graph(g, stream=s): the origin stream is the caller's; declared with graphs.capture_origin(s) the pass forks its
+    log-det side branch as in an ordinary capture, undeclared it runs them inline.  Both replay to the eager result."""
+    from normalizing_flow import Glow, glow as G
+    from nfdp_hip import graphs
+    flow = Glow(in_channel=3, L=4, K=1, compute="bf16")
+    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 9, DEEP)) for k, v in flow.state_dict().items()}, strict=True)
+    flow.to(DEV)
+    x = K.to_nhwc(T(images_5bit("decl", (2, 3, 32, 32), 33)[0]).to(DEV)).contiguous()
+    ldj_ref = z64(2)
+    zs_ref = [z.clone() for z in flow.transform_nhwc(x, ldj_ref, None)]
+    torch.cuda.synchronize()
+    for declare in (True, False):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        ldj = z64(2)
+        g = torch.cuda.CUDAGraph()
+        with (graphs.capture_origin(s) if declare else __import__("contextlib").nullcontext()):
+            with torch.cuda.graph(g, stream=s):
+                assert graphs.side_branch_allowed() == declare
+                ldj.zero_()
+                zs = flow.transform_nhwc(x, ldj, None)
+        assert ((x.device.index, s.cuda_stream) in G._SIDE_STREAMS) == declare
+        g.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(zs, zs_ref)) and torch.equal(ldj, ldj_ref)
 
 
 @torch.no_grad()
@@ -478,3 +510,31 @@ def test_forward_and_inverse_aliases():
     assert torch.equal(ldj, ldj2) and torch.equal(logp, logp2)
     assert torch.equal(flow.inverse(zs), flow.invert(zs))
     assert torch.equal(flow.inverse(zs[-1:], temperature=0.0), flow.invert(zs[-1:], temperature=0.0))
+
+
+@torch.no_grad()
+def test_reference_written_checkpoint_reproduces_the_reference_outputs():
+    """The reference's own checkpoint file (tests/golden/ref_ckpt, tools/make_ref_checkpoint.py) loaded through load_model, run on the
+    HIP path: latents, log-det, log-prob, bits/dim and the inverse equal what the reference computed with those weights."""
+    import json
+    import os
+    import numpy as np
+    from normalizing_flow import Glow, GaussianPrior, load_model, load_architecture, calculate_loss
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_ckpt")
+    g = np.load(os.path.join(d, "ref_ckpt.npz"))
+    meta, arch = json.loads(str(g["meta"])), load_architecture(d)
+    flow = Glow(in_channel=meta["C"], compute="f32", **arch)
+    prior = GaussianPrior(2 ** (arch["L"] + 1) * meta["C"], arch["learn_prior_mean_logs"])
+    load_model(flow, prior, d, meta["epoch"])
+    flow.to(DEV); prior.to(DEV)
+    b = meta["B"]
+    x = T(g["x"]).to(DEV)
+    ldj, logp = z64(b), z64(b)
+    zs, ldj, logp = flow.transform(x, ldj, logp)
+    logp = logp + prior.compute_log_prob(zs[-1])
+    for i, z in enumerate(zs):
+        assert_close(z, g[f"z{i}"], TOL, f"z{i}")
+    assert_close(ldj, g["ldj"], TOL, "ldj")
+    assert_close(logp, g["logp"], TOL, "logp")
+    assert_close(calculate_loss(ldj + logp, 32.0, meta["size"] ** 2 * 3.0), g["bpd"], TOL, "bits/dim")
+    assert_close(flow.invert(zs), g["x_rec"], 1e-3, "inverse")
