@@ -8,7 +8,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates, frees
- *     or retains memory and keeps no global mutable state (re-entrant per stream);
+ *     or retains memory and keeps no global mutable state (re-entrant per stream): every mode is a per-call argument (`compute`,
+ *     `form`, `variant`), the shipped build reads no environment variable.  The only state is THREAD-local: the last-error text and
+ *     the test hooks nfdp_debug_set_* (kernel-form overrides of the calling thread, used by the bit-identity tests);
  *   - activations are fp32 (or bf16 where stated), physical layout NHWC: element (b,h,w,c) of a
  *     [B,H,W,C] tensor is at ((b*H+h)*W+w)*ld + c with ld >= C the pixel stride in ELEMENTS
  *     (ld lets a kernel address a channel-half of a wider tensor in place);
@@ -34,6 +36,12 @@ extern "C" {
 
 #define NFDP_F32 0
 #define NFDP_BF16 1
+#define NFDP_F32X6 2 /* a `compute` value of the forward convs only: fp32 storage and fp32 packed weights like NFDP_F32, every product
+                      * formed on the bf16 matrix cores from three-way splits of both operands (v = h + m + l exactly; six
+                      * v_mfma_f32_16x16x32_bf16 per 32 k with fp32 accumulation: as close to the fp64 value as the fp32 FMA chain, 2e-7 vs
+                      * 5e-7 at K = 576..4608, at 2.7x fewer matrix-pipe cycles).  Non-finite or > bf16-max operands travel in the high
+                      * piece alone, so inf / NaN propagate as in NFDP_F32. */
+#define NFDP_MLP_NO_K16 4 /* bit of the `form` argument of the tiled coupling-network entries (nfdp_coupling_mlp_image_kind) */
 #define NFDP_PACK_JOB_WORDS 12 /* int64 words of one nfdp_conv_pack_weights_batch job */
 
 typedef void* nfdp_stream_t;
@@ -51,13 +59,6 @@ int nfdp_nhwc_to_nchw_f32(const float* x, float* y, int B, int C, int H, int W, 
 int nfdp_squeeze_nhwc_f32(const float* x, int x_ld, float* y, int B, int C, int H, int W, nfdp_stream_t stream);
 /* Squeeze.invert, transforms.py:238: y is [B,h,w,C4] (16-byte aligned) -> x [B,2h,2w,C4/4]. */
 int nfdp_unsqueeze_nhwc_f32(const float* y, float* x, int B, int C4, int h, int w, nfdp_stream_t stream);
-/* How compute = NFDP_F32 forms its products in the small-problem conv kernel (U-Net layers of the reverse-diffusion step):
- * 0 v_mfma_f32_16x16x4_f32, the exact k-ordered fp32 FMA chain; 1 (default): each operand split into three bf16 values
- * (v = h + m + l exactly) and six v_mfma_f32_16x16x32_bf16 per product term set {hh, hm, mh, mm, hl, lh} with fp32 accumulation -
- * the dropped terms are below 2^-24 relative, the result is as close to the fp64 value as the fp32 chain (2e-7 vs 5e-7 at
- * K = 576..4608) at 2.7x fewer matrix-pipe cycles.  Process-wide switch (not per call); storage stays fp32. */
-int nfdp_set_f32_products(int mode);
-int nfdp_get_f32_products(void);
 /* The coupling network (coupling_network utils.py:72-90: conv3x3 -> ActNorm -> ReLU -> conv1x1 -> ActNorm -> ReLU -> the nine tap
  * contributions of the ZeroConv2d) for images of ANY size, bf16 MFMA, hidden activations on chip: xcol = nfdp_im2col3x3_bf16 of the
  * first C/2 channels ([npix][xcol_ld] bf16, xcol_ld >= 9*C/2 rounded up to 16), packed = nfdp_coupling_fused_pack image,
@@ -65,24 +66,24 @@ int nfdp_get_f32_products(void);
 int nfdp_coupling_mlp_bf16(const void* xcol, int xcol_ld, long npix, const void* packed, float* T, int C, nfdp_stream_t stream);
 /* The same without the im2col matrix: the kernel gathers the first conv's operands from the fp32 NHWC tensor (x: the C/2-channel half of
  * [B][H][W][*], pixel stride x_ld floats; zero padding, bf16 rounding as nfdp_im2col3x3_bf16).  One launch less per flow. */
-int nfdp_coupling_mlp_gather_bf16(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, nfdp_stream_t stream);
-/* Split-product form for the exact-fp32 mode: every fp32 product as hi*hi + hi*lo + lo*hi of two-piece bf16 splits of both operands
- * (three bf16 MFMAs against sixteen fp32-MFMA passes), fp32 accumulation; pixel error of a 48-flow inverse 4-6e-5.  packed_hi: the
- * nfdp_coupling_fused_pack image with fold_scales = 1, packed_lo: the same call with fold_scales = 3 (low pieces).  C <= 24 or C = 48. */
+int nfdp_coupling_mlp_gather_bf16(const float* x, int x_ld, int B, int H, int W, const void* packed, float* T, int C, int form,
+                                  nfdp_stream_t stream);
 /* The same two networks on v_mfma_f32_16x16x32_bf16 (C = 4, 12): packed_hi = the fold_scales = 2 image, packed_lo = NULL (bf16
  * operands) or the fold_scales = 4 image (low pieces: split products).  nfdp_coupling_mlp_image_kind(C, B*H*W, split) says which
- * image kind a call of that size takes (2: this entry; 1: nfdp_coupling_mlp_gather_bf16 / _bf16x3); nfdp_set_mlp_k16(0) turns the
- * 16x16x32 form off. */
-int nfdp_set_mlp_k16(int on);
-int nfdp_coupling_mlp_image_kind(int C, long npix, int split);
+ * image kind a call of that size and `form` takes (2: this entry; 1: nfdp_coupling_mlp_gather_bf16 / _bf16x3).
+ * `form` - a PER-CALL argument, the library keeps no mode: bits 0-1 = kernel form of the gather entries: 0 (default) the row-split form
+ * (32-pixel workgroups whose four waves split the weights; same images, bf16 results bit-identical) where the 128-pixel form would
+ * leave most CUs idle (<= 16384 pixels; C = 12, 24, 48), 1 = never, 2 = always (the split-product form at C = 48 exists row-split
+ * only); NFDP_MLP_NO_K16: keep C = 4, 12 on the 32x32x16 kernels (image kind 1). */
+int nfdp_coupling_mlp_image_kind(int C, long npix, int split, int form);
 int nfdp_coupling_mlp_gather_k16(const float* x, int x_ld, int B, int H, int W, const void* packed_hi, const void* packed_lo, float* T,
                                  int C, nfdp_stream_t stream);
-/* Kernel form of the two entries around this comment: 0 (default) = the row-split form (32-pixel workgroups whose four waves split the
- * weights; same images, bf16 results bit-identical) where the 128-pixel form would leave most CUs idle (<= 16384 pixels; C = 12, 24, 48),
- * 1 = never, 2 = always.  The split-product form at C = 48 exists row-split only. */
-int nfdp_set_mlp_rows(int mode);
+/* Split-product form for the exact-fp32 mode: every fp32 product as hi*hi + hi*lo + lo*hi of two-piece bf16 splits of both operands
+ * (three bf16 MFMAs against sixteen fp32-MFMA passes), fp32 accumulation; pixel error of a 48-flow inverse 4-6e-5.  packed_hi: the
+ * nfdp_coupling_fused_pack image with fold_scales = 1, packed_lo: the same call with fold_scales = 3 (low pieces).  C <= 24 or C = 48
+ * (row-split form only). */
 int nfdp_coupling_mlp_gather_bf16x3(const float* x, int x_ld, int B, int H, int W, const void* packed_hi, const void* packed_lo, float* T,
-                                    int C, nfdp_stream_t stream);
+                                    int C, int form, nfdp_stream_t stream);
 /* The same network in EXACT fp32 (v_mfma_f32_32x32x2_f32: fp32 products and sums), hidden activations on chip: the fp32-accurate fast
  * path of compute="f32" (utils.py:83-89 is fp32 end to end).  Reads the C/2-channel half x [B,H,W,*] fp32 NHWC (pixel stride x_ld
  * floats) directly - the 3x3 gather of the first conv happens in the kernel - and writes T [B*H*W][9*C] fp32 (n = tap*C + co) for
@@ -161,7 +162,7 @@ int nfdp_invconv_actnorm_inv_f32(const float* y, float* x, long npix, int C, con
  * with m[n] = mul[n] if mul_exp == 0 else exp(mul[n]*mul_exp) — mul_exp = 1 gives ActNorm's exp(scale)
  * (transforms.py:80), mul_exp = 3 ZeroConv2d's exp(3*logs) (utils.py:44) straight from the raw parameters.
  * compute = NFDP_F32 uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain); NFDP_BF16 uses v_mfma_f32_16x16x32_bf16
- * with fp32 accumulation.  x/y dtypes: NFDP_F32 or NFDP_BF16 storage (bf16 storage only with bf16 compute). */
+ * with fp32 accumulation; NFDP_F32X6 (above) is NFDP_F32 with split products.  x/y dtypes: NFDP_F32 or NFDP_BF16 storage (bf16 storage only with bf16 compute). */
 size_t nfdp_conv_packed_bytes(int Cout, int Cin, int KH, int KW, int compute);
 int nfdp_conv_pack_weights(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, int compute,
                            nfdp_stream_t stream);
@@ -177,9 +178,9 @@ int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed,
 /* conv2d(torch.cat((x1, x2), dim=1)) without materialising the concatenation - the U-Net's skip connections
  * (diffusion_prior/gaussian_diffusion.py:479-486: `torch.cat((x, h.pop()), dim=1)` in front of every up-path ResnetBlock): exact fp32,
  * both inputs fp32 pixel-strided with 16-byte aligned rows, Cin1 % 8 == 0, Cin2 % 4 == 0; w_packed is the packed weight of the
- * (Cin1 + Cin2)-channel conv (nfdp_conv_pack_weights, compute NFDP_F32); `add` = bias or null. */
+ * (Cin1 + Cin2)-channel conv (nfdp_conv_pack_weights, compute NFDP_F32); `add` = bias or null; compute: NFDP_F32 or NFDP_F32X6. */
 int nfdp_conv2d_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed, float* y,
-                             int y_ld, int B, int H, int W, int Cout, int K, const float* add, nfdp_stream_t stream);
+                             int y_ld, int B, int H, int W, int Cout, int K, const float* add, int compute, nfdp_stream_t stream);
 
 /* ---------------------------------------------------------------- affine coupling (transforms.py:166-201) */
 /* x: [B,HW,C] flow tensor (x_a = channels [0,C/2), x_b = [C/2,C)); h: NN output [B,HW,C] (log_s | t).
@@ -359,17 +360,17 @@ int nfdp_zeroconv_bias_only_f32(const float* bias, const float* logs, float* h, 
  * (nullable) - gaussian_diffusion.py:267-276, :301 - on the split-K fp32 conv with the normalisation in its epilogue.  Available when a
  * workgroup's pixel tile holds whole images and its 64 output channels whole groups (H*W divides 64, (Cout/groups) divides 64 and is a
  * multiple of 4, Cout % 64 == 0, Cin % 8 == 0, K*K*Cin >= 256): the 8x8 / 4x4 / 2x2 stages.  nfdp_conv2d_gn_silu_supported returns 1
- * there; elsewhere callers run nfdp_conv2d_nhwc + nfdp_groupnorm_silu_res_f32. */
+ * there; elsewhere callers run nfdp_conv2d_nhwc + nfdp_groupnorm_silu_res_f32.  compute: NFDP_F32 or NFDP_F32X6. */
 int nfdp_conv2d_gn_silu_supported(int B, int H, int W, int Cin, int Cout, int K, int groups);
 int nfdp_conv2d_gn_silu_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin, int Cout,
                                  int K, const float* bias, int groups, const float* gamma, const float* beta, const float* scale_shift,
-                                 int ss_ld, float eps, const float* residual, int res_ld, nfdp_stream_t stream);
+                                 int ss_ld, float eps, const float* residual, int res_ld, int compute, nfdp_stream_t stream);
 /* The same Block on torch.cat((x1, x2), dim=1) (see nfdp_conv2d_cat_nhwc_f32); supported where nfdp_conv2d_gn_silu_supported(B, H, W,
  * Cin1 + Cin2, ...) is and Cin1 % 8 == 0, Cin2 % 8 == 0. */
 int nfdp_conv2d_gn_silu_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed,
                                      float* y, int y_ld, int B, int H, int W, int Cout, int K, const float* bias, int groups,
                                      const float* gamma, const float* beta, const float* scale_shift, int ss_ld, float eps,
-                                     const float* residual, int res_ld, nfdp_stream_t stream);
+                                     const float* residual, int res_ld, int compute, nfdp_stream_t stream);
 
 /* ---------------------------------------------------------------- diffusion prior: U-Net blocks
  * (diffusion_prior/gaussian_diffusion.py; the convolutions themselves use nfdp_conv2d_nhwc) */

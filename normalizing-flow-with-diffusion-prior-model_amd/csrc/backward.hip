@@ -810,7 +810,7 @@ __global__ void __launch_bounds__(kBlock) flow_link_finish_kernel(const double* 
 // pixels per workgroup of the link kernel (see flow_link_bwd_kernel); the partial buffers are laid out per workgroup, so the three
 // entry points below derive it from npix alike
 static int link_block(long npix) {
-    static const int forced = [] { const char* e = getenv("NFDP_LINK_BLOCK"); return e ? atoi(e) : 0; }();   // A/B measurements
+    static const int forced = [] { const char* e = NFDP_DIAG_ENV("NFDP_LINK_BLOCK"); return e ? atoi(e) : 0; }();   // A/B measurements
     if (forced == 64 || forced == 256) return forced;
     (void)npix;
     return 64;             // measured (rocprofv3, B = 512): 18.7 / 16.8 / 25.2 us per launch at the three levels against 22.7 / 23.0 / 32.0 with 256
@@ -818,9 +818,9 @@ static int link_block(long npix) {
 template <int C, int LB>
 static void launch_flow_link_lb(hipStream_t s, const LinkParams& p) {
     constexpr int kDyn = 2 * LB * (C + 1) * (int)sizeof(float);
-    static bool attr_set = false;
+    static NfdpPerDevice attr_set;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flow_link_bwd_kernel<C, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
+        nfdp_func_attr(reinterpret_cast<const void*>(&flow_link_bwd_kernel<C, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
         attr_set = true;
     }
     hipLaunchKernelGGL((flow_link_bwd_kernel<C, LB>), dim3((unsigned)cdiv(p.npix, LB)), dim3(LB), kDyn, s, p);
@@ -1738,7 +1738,7 @@ static bool wgrad_wide_shape_ok(long npix, int N, int Cout, int k) {
     return k == 1 && Cout == 512 && N >= 8 && N <= 512 && N % 8 == 0 && npix % W2_KC == 0 && npix >= 2 * W2_KC;
 }
 static bool wgrad_wide_ok(long npix, int N, int Cout, int k) {          // (the single-GEMM entries: switchable for A/B measurements)
-    static const bool off = [] { const char* e = getenv("NFDP_WGRAD_WIDE"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char* e = NFDP_DIAG_ENV("NFDP_WGRAD_WIDE"); return e && e[0] == '0'; }();
     return !off && wgrad_wide_shape_ok(npix, N, Cout, k);
 }
 static int wgrad_wide_tn(int N) { return N > 128 ? 256 : 128; }
@@ -1751,7 +1751,7 @@ static void wgrad_wide_plan(long npix, int N, WgradParams* p) {
     p->Npad = p->nblocks * tn;
     p->npix = npix;
     long want = 256 / ((long)p->mblocks * p->nblocks);
-    static const int want_env = [] { const char* e = getenv("NFDP_WGRAD_SLICES"); return e ? atoi(e) : 0; }();   // sweeps
+    static const int want_env = [] { const char* e = NFDP_DIAG_ENV("NFDP_WGRAD_SLICES"); return e ? atoi(e) : 0; }();   // sweeps
     if (want > npix / (8 * W2_KC)) want = npix / (8 * W2_KC);     // at least 8 stages per slice: below that the partial tiles cost more than they spread
     if (want < 1) want = 1;
     if (want_env > 0) want = want_env;
@@ -1762,9 +1762,9 @@ static void wgrad_wide_plan(long npix, int N, WgradParams* p) {
 }
 template <int TN, bool ABLK, bool BBLK>
 static void launch_wgrad_wide_t(const WgradParams& p, hipStream_t s) {
-    static bool attr_set = false;
+    static NfdpPerDevice attr_set;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_wide_kernel<TN, ABLK, BBLK>),
+        nfdp_func_attr(reinterpret_cast<const void*>(&wgrad_bf16_wide_kernel<TN, ABLK, BBLK>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, W2_NS * w2_slot_bytes<TN>());
         attr_set = true;
     }
@@ -1826,9 +1826,9 @@ extern "C" int nfdp_conv_wgrad_bf16_affine(const void* x, int x_ld, const void* 
     if (wide) {
         launch_wgrad_wide(p, s);
     } else {
-        static bool attr_set = false;
+        static NfdpPerDevice attr_set;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            nfdp_func_attr(reinterpret_cast<const void*>(&wgrad_bf16_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       4 * WD_TILE_BYTES);
             attr_set = true;
         }
@@ -1851,8 +1851,8 @@ static bool wgrad3_plan(long npix, const int* cin, int n, WgradParams* p) {
     for (int q = 0; q < n; ++q) {
         if (!wgrad_wide_shape_ok(npix, cin[q], 512, 1)) return false;
         const int tn = wgrad_wide_tn(cin[q]);
-        static const double c256 = [] { const char* e = getenv("NFDP_WGRAD3_C256"); return e ? atof(e) : 0.87; }();   // (sweeps)
-        static const double c128 = [] { const char* e = getenv("NFDP_WGRAD3_C128"); return e ? atof(e) : 0.6; }();
+        static const double c256 = [] { const char* e = NFDP_DIAG_ENV("NFDP_WGRAD3_C256"); return e ? atof(e) : 0.87; }();   // (sweeps)
+        static const double c128 = [] { const char* e = NFDP_DIAG_ENV("NFDP_WGRAD3_C128"); return e ? atof(e) : 0.6; }();
         cost[q] = tn == 256 ? c256 : c128;                 // measured us per 32-pixel stage of a workgroup
         denom += 2.0 * (double)cdiv(cin[q], tn) * cost[q];
     }
@@ -1924,9 +1924,9 @@ extern "C" int nfdp_coupling_wgrad3_bf16(const void* const* x, const int* x_ld, 
     m.first[n_gemm] = blocks;
     for (int q = n_gemm; q < 3; ++q) { m.kind[q] = 0; m.first[q + 1] = blocks; }
     hipStream_t s = as_stream(stream);
-    static bool attr_set = false;
+    static NfdpPerDevice attr_set;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        nfdp_func_attr(reinterpret_cast<const void*>(&wgrad_bf16_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   W2_NS * w2_slot_bytes<256>());
         attr_set = true;
     }
@@ -1960,9 +1960,9 @@ extern "C" int nfdp_conv_wgrad_bf16_ex(const void* x, int x_dtype, int x_ld, con
     const bool dma = xb && db && k == 1 && Cout >= 8 && Cin >= 8 && Cin % 8 == 0 && Cout % 8 == 0 && x_ld % 8 == 0 && dy_ld % 8 == 0 &&
                      (((uintptr_t)x | (uintptr_t)dy) & 15) == 0 && p.npix % WD_KC == 0;
     if (dma) {
-        static bool attr_set = false;
+        static NfdpPerDevice attr_set;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            nfdp_func_attr(reinterpret_cast<const void*>(&wgrad_bf16_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       4 * WD_TILE_BYTES);
             attr_set = true;
         }

@@ -24,8 +24,6 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int BK = 32;
-int g_f32_products = 1;          // nfdp_set_f32_products: 0 exact fp32 MFMA chain, 1 (default since round 4) three-way bf16 split + six bf16
-                                 // MFMAs: as close to fp64 as the fp32 chain (2-4e-7 either way), 2.7x fewer matrix-pipe cycles
 
 struct ConvParams {
     const void* x;
@@ -52,6 +50,8 @@ struct ConvParams {
     // channels [0, Cin1) come from x, [Cin1, Cin) from x2 (fp32, row stride x2_ld); Cin1 % 8 == 0.  Default: one source.
     const void* x2 = nullptr;
     int x2_ld = 0, Cin1 = 1 << 30;
+    // host-side only: compute = NFDP_F32X6 - fp32 storage, every product as six bf16 MFMAs on three-way split operands (the EMU kernels)
+    int emu = 0;
 };
 
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
@@ -69,7 +69,9 @@ __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const __bf16 hh = (__bf16)v[e];
-        const float r1 = v[e] - (float)hh;
+        // inf / NaN operands (and finite ones above the bf16 range, whose high piece rounds to inf) travel in h alone: v - h would be
+        // inf - inf = NaN and turn an inf result into NaN; with m = l = 0 they propagate as in the fp32 chain
+        const float r1 = __builtin_isfinite((float)hh) ? v[e] - (float)hh : 0.f;
         const __bf16 mm = (__bf16)r1;
         const float r2 = r1 - (float)mm;
         h[e] = hh; m[e] = mm; l[e] = (__bf16)r2;
@@ -912,17 +914,17 @@ void launch_cfg(ConvParams& P, hipStream_t s) {
     P.Nt = cout_pad_for(P.Cout) / BN;
     const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
     const size_t lds = 2 * (size_t)(BM + BN) * (BF16 ? 64 : 128);
-    static bool attr_set = false;   // > 64 KB of dynamic LDS must be opted into once per kernel
+    static NfdpPerDevice attr_set;   // > 64 KB of dynamic LDS must be opted into once per kernel
     if (lds > 65536 && !attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BF16, XBF16, VEC, BM, BN, WAVES_M, WAVES_N>),
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv_kernel<BF16, XBF16, VEC, BM, BN, WAVES_M, WAVES_N>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     if constexpr (!BF16) {
-        if (g_f32_products == 1) {                       // fp32 products as six bf16 MFMAs (nfdp_set_f32_products)
-            static bool attr_set_e = false;
+        if (P.emu) {                                     // fp32 products as six bf16 MFMAs (compute = NFDP_F32X6)
+            static NfdpPerDevice attr_set_e;
             if (lds > 65536 && !attr_set_e) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_kernel<BF16, XBF16, VEC, BM, BN, WAVES_M, WAVES_N, true>),
+                nfdp_func_attr(reinterpret_cast<const void*>(&conv_kernel<BF16, XBF16, VEC, BM, BN, WAVES_M, WAVES_N, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 attr_set_e = true;
             }
@@ -941,7 +943,7 @@ void launch_cfg_small(ConvParams& P, hipStream_t s) {
     const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
     const size_t lds = 2 * (size_t)(BM + BN) * (BF16 ? 64 : 128);
     if constexpr (!BF16) {
-        if (g_f32_products == 1) {
+        if (P.emu) {
             hipLaunchKernelGGL((conv_kernel<BF16, XBF16, VEC, BM, BN, 2, 2, true>), dim3(grid), dim3(kThreads), lds, s, P);
             return;
         }
@@ -968,12 +970,6 @@ void launch_by_cout(ConvParams& P, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int nfdp_set_f32_products(int mode) {
-    NFDP_REQUIRE(mode == 0 || mode == 1, NFDP_EINVAL, "set_f32_products: mode=%d (0 exact fp32 MFMA, 1 six bf16 MFMAs)", mode);
-    g_f32_products = mode;
-    return NFDP_OK;
-}
-extern "C" int nfdp_get_f32_products(void) { return g_f32_products; }
 
 extern "C" size_t nfdp_conv_packed_bytes(int Cout, int Cin, int KH, int KW, int compute) {
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
@@ -1109,9 +1105,9 @@ extern "C" int nfdp_pointwise_dgrad_masked_bf16_ex(const void* x, int x_ld, cons
     P.Nt = cout_pad_for(Cout) / PW_BN;
     const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
     hipStream_t s = as_stream(stream);
-    static bool attr_set = false;
+    static NfdpPerDevice attr_set;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        nfdp_func_attr(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   PW_LDS_BYTES);
         attr_set = true;
     }
@@ -1149,15 +1145,15 @@ extern "C" int nfdp_conv2d_gn_silu_supported(int B, int H, int W, int Cin, int C
 
 static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
                                int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
-                               const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld,
+                               const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld, int compute,
                                nfdp_stream_t stream, const float* x2, int x2_ld, int cin1);
 
 extern "C" int nfdp_conv2d_gn_silu_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
                                             int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
                                             const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld,
-                                            nfdp_stream_t stream) {
+                                            int compute, nfdp_stream_t stream) {
     return conv2d_gn_silu_impl(x, x_ld, w_packed, y, y_ld, B, H, W, Cin, Cout, K, bias, groups, gamma, beta, scale_shift, ss_ld, eps,
-                               residual, res_ld, stream, nullptr, 0, 0);
+                               residual, res_ld, compute, stream, nullptr, 0, 0);
 }
 
 // the same on torch.cat((x1, x2), dim=1) without the concatenated tensor (see nfdp_conv2d_cat_nhwc_f32)
@@ -1165,20 +1161,21 @@ extern "C" int nfdp_conv2d_gn_silu_cat_nhwc_f32(const float* x1, int x1_ld, int 
                                                 const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cout, int K,
                                                 const float* bias, int groups, const float* gamma, const float* beta,
                                                 const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld,
-                                                nfdp_stream_t stream) {
+                                                int compute, nfdp_stream_t stream) {
     NFDP_REQUIRE(x1 && x2, NFDP_EINVAL, "conv2d_gn_silu_cat: null pointer");
     NFDP_REQUIRE(Cin1 > 0 && Cin2 > 0 && Cin1 % 8 == 0 && Cin2 % 8 == 0, NFDP_EUNSUPPORTED,
                  "conv2d_gn_silu_cat: channel counts %d + %d (multiples of 8)", Cin1, Cin2);
     NFDP_REQUIRE(x2_ld >= Cin2 && x2_ld % 4 == 0 && ((uintptr_t)x2 % 16) == 0, NFDP_ESHAPE, "conv2d_gn_silu_cat: rows must be 16-byte aligned");
     return conv2d_gn_silu_impl(x1, x1_ld, w_packed, y, y_ld, B, H, W, Cin1 + Cin2, Cout, K, bias, groups, gamma, beta, scale_shift, ss_ld,
-                               eps, residual, res_ld, stream, x2, x2_ld, Cin1);
+                               eps, residual, res_ld, compute, stream, x2, x2_ld, Cin1);
 }
 
 static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
                                int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
-                               const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld,
+                               const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld, int compute,
                                nfdp_stream_t stream, const float* x2, int x2_ld, int cin1) {
     NFDP_REQUIRE(x && w_packed && y && gamma && beta, NFDP_EINVAL, "conv2d_gn_silu: null pointer");
+    NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_F32X6, NFDP_EINVAL, "conv2d_gn_silu: compute=%d (fp32 or the six-product split form)", compute);
     NFDP_REQUIRE(nfdp_conv2d_gn_silu_supported(B, H, W, Cin, Cout, K, groups), NFDP_EUNSUPPORTED,
                  "conv2d_gn_silu: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d K=%d groups=%d", B, H, W, Cin, Cout, K, groups);
     NFDP_REQUIRE(x_ld >= (x2 ? cin1 : Cin) && x_ld % 4 == 0 && y_ld >= Cout && y_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) % 16) == 0,
@@ -1202,15 +1199,15 @@ static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, f
     P.Mt = (int)cdiv(npix, 16 * pt);
     const dim3 grid(P.Mt * P.Nt);
     hipStream_t s = as_stream(stream);
-    static bool attr_set = false;
+    static NfdpPerDevice attr_set;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<8, 4, false, 4, true>),
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<8, 4, false, 4, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * SK_LD * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<4, 8, true, 4, true>),
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<4, 8, true, 4, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
         attr_set = true;
     }
-    if (g_f32_products == 1) {
+    if (compute == NFDP_F32X6) {
         if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 4, true>), grid, dim3(256), 4 * 64 * SK_LD * 4, s, P);
         else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 2, true>), grid, dim3(256), 4 * 32 * SK_LD * 4, s, P);
         else hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 1, true>), grid, dim3(256), 4 * 16 * SK_LD * 4, s, P);
@@ -1237,13 +1234,15 @@ extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void
 // conv2d(torch.cat((x1, x2), dim=1)) without the concatenated tensor (the U-Net's skip connections, reference
 // gaussian_diffusion.py:479-486): exact fp32, both inputs fp32 pixel-strided, Cin1 % 8 == 0.
 extern "C" int nfdp_conv2d_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed,
-                                        float* y, int y_ld, int B, int H, int W, int Cout, int K, const float* add, nfdp_stream_t stream) {
+                                        float* y, int y_ld, int B, int H, int W, int Cout, int K, const float* add, int compute,
+                                        nfdp_stream_t stream) {
     NFDP_REQUIRE(x1 && x2, NFDP_EINVAL, "conv2d_cat: null pointer");
+    NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_F32X6, NFDP_EINVAL, "conv2d_cat: compute=%d (fp32 or the six-product split form)", compute);
     NFDP_REQUIRE(Cin1 > 0 && Cin2 > 0 && Cin1 % 8 == 0 && Cin2 % 4 == 0, NFDP_EUNSUPPORTED,
                  "conv2d_cat: channel counts %d + %d (first a multiple of 8, second of 4)", Cin1, Cin2);
     NFDP_REQUIRE(x1_ld >= Cin1 && x2_ld >= Cin2 && x1_ld % 4 == 0 && x2_ld % 4 == 0 && (((uintptr_t)x1 | (uintptr_t)x2) % 16) == 0,
                  NFDP_ESHAPE, "conv2d_cat: input rows must be 16-byte aligned");
-    return conv2d_impl(x1, NFDP_F32, x1_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin1 + Cin2, Cout, K, K, add, nullptr, 0.f, 0, NFDP_F32,
+    return conv2d_impl(x1, NFDP_F32, x1_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin1 + Cin2, Cout, K, K, add, nullptr, 0.f, 0, compute,
                        stream, x2, x2_ld, Cin1);
 }
 
@@ -1254,7 +1253,9 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
     NFDP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NFDP_ESHAPE, "conv2d: bad shape");
     NFDP_REQUIRE(KH == KW && (KH % 2) == 1 && KH <= 7, NFDP_EUNSUPPORTED, "conv2d: kernel %dx%d (odd square <= 7 only)", KH, KW);
     NFDP_REQUIRE(x_ld >= (x2 ? cin1 : Cin) && y_ld >= Cout, NFDP_ESHAPE, "conv2d: ld smaller than channel count");
-    NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_BF16, NFDP_EINVAL, "conv2d: compute=%d", compute);
+    NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_BF16 || compute == NFDP_F32X6, NFDP_EINVAL, "conv2d: compute=%d", compute);
+    const int emu = compute == NFDP_F32X6;       // fp32 storage and packed weights; products from three-way bf16 splits
+    if (emu) compute = NFDP_F32;
     NFDP_REQUIRE((x_dtype == NFDP_F32 || x_dtype == NFDP_BF16) && (y_dtype == NFDP_F32 || y_dtype == NFDP_BF16), NFDP_EINVAL,
                  "conv2d: bad dtype");
     NFDP_REQUIRE(compute == NFDP_BF16 || (x_dtype == NFDP_F32 && y_dtype == NFDP_F32), NFDP_EUNSUPPORTED,
@@ -1267,6 +1268,7 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
     P.x_ld = x_ld; P.y_ld = y_ld; P.y_bf16 = (y_dtype == NFDP_BF16);
     P.H = H; P.W = W; P.Cin = Cin; P.Cout = Cout; P.KH = KH; P.KW = KW; P.pad = (KH - 1) / 2;
     P.K = Cin * KH * KW; P.Kpad = kpad_for(Cin, KH, KW); P.relu = relu; P.Mt = 0; P.Nt = 0; P.mul_exp = mul_exp;
+    P.emu = emu;
     if (x2) { P.x2 = x2; P.x2_ld = x2_ld; P.Cin1 = cin1; }
     const int esz = (x_dtype == NFDP_BF16) ? 2 : 4;
     // vector path: 4 consecutive k stay inside one tap and the 4-element load is naturally aligned
@@ -1280,9 +1282,9 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
         P.Mt = (int)cdiv(npix, PW_BM);
         P.Nt = cout_pad_for(Cout) / PW_BN;
         const int grid = (int)(cdiv(P.Mt, 8) * 8) * P.Nt;
-        static bool attr_set = false;
+        static NfdpPerDevice attr_set;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            nfdp_func_attr(reinterpret_cast<const void*>(&pw_gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       PW_LDS_BYTES);
             attr_set = true;
         }
@@ -1300,15 +1302,15 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
         const int pt = t64 >= 256 ? 4 : (2 * t64 >= 256 ? 2 : 1);
         P.Mt = (int)cdiv(npix, 16 * pt);
         const dim3 grid(P.Mt * P.Nt);
-        static bool sk_attr_set = false;
+        static NfdpPerDevice sk_attr_set;
         if (!sk_attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<8, 4, false, 4>),
+            nfdp_func_attr(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<8, 4, false, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * SK_LD * 4);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<4, 8, true, 4>),
+            nfdp_func_attr(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<4, 8, true, 4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
             sk_attr_set = true;
         }
-        if (g_f32_products == 1) {    // fp32 products as six bf16 MFMAs (nfdp_set_f32_products)
+        if (emu) {                    // fp32 products as six bf16 MFMAs (NFDP_F32X6)
             if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 4>), grid, dim3(256), 4 * 64 * SK_LD * 4, s, P);
             else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 2>), grid, dim3(256), 4 * 32 * SK_LD * 4, s, P);
             else hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 1>), grid, dim3(256), 4 * 16 * SK_LD * 4, s, P);

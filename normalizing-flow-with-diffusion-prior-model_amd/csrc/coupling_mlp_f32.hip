@@ -478,14 +478,14 @@ __global__ void __launch_bounds__(256) coupling_mlp_f32_rs_kernel(const float* _
 template <int C>
 int launch_mlp(const float* x, int x_ld, long npix, int H, int W, const float* img, float* T, int variant, hipStream_t s) {
     const long nwg = cdiv(npix, 32);
-    static const int forced = [] { const char* e = getenv("NFDP_F32_VARIANT"); return e ? atoi(e) : 0; }();     // A/B measurements
+    static const int forced = [] { const char* e = NFDP_DIAG_ENV("NFDP_F32_VARIANT"); return e ? atoi(e) : 0; }();     // A/B measurements
     if (variant == 0 && (forced == 1 || forced == 2)) variant = forced;
     const bool rs = variant == 2 || (variant == 0 && nwg * GeoF<C>::NG < 768);
     if (rs) {
         constexpr int kLds = NHB * 64 * 16 * (int)sizeof(float);                 // H1, then H2 in its place: 64 KB
-        static bool attr_set = false;
+        static NfdpPerDevice attr_set;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&coupling_mlp_f32_rs_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
+            nfdp_func_attr(reinterpret_cast<const void*>(&coupling_mlp_f32_rs_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
             attr_set = true;
         }
         hipLaunchKernelGGL((coupling_mlp_f32_rs_kernel<C>), dim3((unsigned)nwg), dim3(256), kLds, s, x, x_ld, npix, H, W, img, T);

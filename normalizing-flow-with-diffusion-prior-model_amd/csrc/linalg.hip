@@ -521,7 +521,7 @@ extern "C" int nfdp_invconv_prepare_f32(const float* w, int n, int C, float* log
     NFDP_REQUIRE(n >= 0 && C > 0 && C <= 256, NFDP_ESHAPE, "invconv_prepare: bad shape n=%d C=%d (C<=256)", n, C);
     if (n == 0) return NFDP_OK;
     const size_t red = (size_t)(3 * C + 4) * sizeof(double) + (size_t)(2 * C + 4) * sizeof(int) + 16;
-    static const bool wave_off = [] { const char* e = getenv("NFDP_GJ_WAVE"); return e && e[0] == '0'; }();   // A/B measurements
+    static const bool wave_off = [] { const char* e = NFDP_DIAG_ENV("NFDP_GJ_WAVE"); return e && e[0] == '0'; }();   // A/B measurements
     if (gj_wave_ok(C) && !wave_off) {
         hipLaunchKernelGGL(gj_wave_kernel, dim3(n), dim3(64), 0, as_stream(stream), w, C, logabsdet, winv);
     } else if (C <= kMaxLdsC) {

@@ -24,6 +24,45 @@ void nfdp_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// Measurement switches exist only in -DNFDP_DIAG builds (tools/build_variant.sh): environment reads for A/B runs, the NFDP_ABLATE_* /
+// *_STAMPS timing-only code paths.  The shipped library reads no environment variable and contains none of those paths.
+#ifdef NFDP_DIAG
+#include <stdlib.h>
+#define NFDP_DIAG_ENV(name) getenv(name)
+#else
+#define NFDP_DIAG_ENV(name) ((const char*)nullptr)
+#if defined(NFDP_ABLATE_NOSTREAM) || defined(NFDP_ABLATE_DMA4) || defined(NFDP_ABLATE_MFMA16) || defined(NFDP_ABLATE_NOMFMA) || \
+    defined(NFDP_FUSED_STAMPS) || defined(NFDP_FUSED_STAMPS_FINE) || defined(NFDP_FUSED_CLOCK) || defined(NFDP_BWD_ABLATE_LOADS) || \
+    defined(NFDP_BWD_ABLATE_STORES) || defined(NFDP_BWD_ABLATE_STORE_ADDR) || defined(NFDP_W2_ABLATE)
+#error "timing-only / stamping code paths need -DNFDP_DIAG (tools/build_variant.sh adds it): they must not reach the shipped library"
+#endif
+#endif
+
+// "once per DEVICE" flag for launch-site set-up (hipFuncSetAttribute is per device): `static NfdpPerDevice f; if (!f) { ...; f = true; }`
+struct NfdpPerDevice {
+    unsigned long long mask = 0;
+    static int dev() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return d & 63;
+    }
+    bool operator!() const { return !((mask >> dev()) & 1ull); }
+    NfdpPerDevice& operator=(bool v) {
+        if (v) mask |= 1ull << dev();
+        return *this;
+    }
+};
+
+// hipFuncSetAttribute with its result checked: a kernel that needs > 64 KB of dynamic LDS and did not get the opt-in fails at launch with
+// a generic error; the cause is recorded here (thread-local error text, and once on stderr).
+static inline bool nfdp_func_attr(const void* fn, hipFuncAttribute attr, int value) {
+    const hipError_t e = hipFuncSetAttribute(fn, attr, value);
+    if (e == hipSuccess) return true;
+    nfdp_set_error("hipFuncSetAttribute(%d, %d) failed: %s", (int)attr, value, hipGetErrorString(e));
+    fprintf(stderr, "nfdp: hipFuncSetAttribute(%d, %d) failed: %s\n", (int)attr, value, hipGetErrorString(e));
+    return false;
+}
+
 static inline hipStream_t as_stream(nfdp_stream_t s) { return (hipStream_t)s; }
 static inline long cdiv(long a, long b) { return (a + b - 1) / b; }
 

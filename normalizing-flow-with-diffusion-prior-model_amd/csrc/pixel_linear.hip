@@ -284,9 +284,9 @@ int launch_templated(const float* x, float* y, long npix, const float* w, const 
     const long ntiles = cdiv(npix, kTilePx);
     const int grid = (int)(ntiles < 4096 ? ntiles : 4096);
     if (lds > 65536) {                               // C = 192 (last level of a 5-level, 3-channel model): 99 KB, opted into once
-        static bool attr_set = false;
+        static NfdpPerDevice attr_set;
         if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&pixel_linear_kernel<C, MODE>),
+            nfdp_func_attr(reinterpret_cast<const void*>(&pixel_linear_kernel<C, MODE>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }

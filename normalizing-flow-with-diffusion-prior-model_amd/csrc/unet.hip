@@ -908,9 +908,9 @@ extern "C" int nfdp_groupnorm_silu_res_f32(const float* x, float* y, int B, int 
     constexpr long kGnLdsMax = 36 * 1024;                        // floats: 144 KiB of the 160 KiB LDS
     const int lds_cached = n > 256 * 16 && n <= kGnLdsMax && (C / groups) % 4 == 0 && C % 4 == 0 && ((uintptr_t)x & 15) == 0 &&
                            ((uintptr_t)y & 15) == 0 && ((uintptr_t)residual & 15) == 0;
-    static bool gn_attr = false;
+    static NfdpPerDevice gn_attr;
     if (lds_cached && !gn_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&groupnorm_silu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        nfdp_func_attr(reinterpret_cast<const void*>(&groupnorm_silu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)(kGnLdsMax * sizeof(float)));
         gn_attr = true;
     }
@@ -940,9 +940,9 @@ extern "C" int nfdp_linear_f32(const float* in, const float* w, const float* bia
     NFDP_REQUIRE(pre_act >= 0 && pre_act <= 1 && post_act >= 0 && post_act <= 2, NFDP_EINVAL, "linear: bad activation enum");
     if (B == 0) return NFDP_OK;
     const size_t lds = (size_t)(LIN_TB + LIN_TO) * (I + 1) * sizeof(float);
-    static bool attr_set = false;
+    static NfdpPerDevice attr_set;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        nfdp_func_attr(reinterpret_cast<const void*>(&linear_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (LIN_TB + LIN_TO) * 481 * (int)sizeof(float));      // 153,920 B <= 160 KiB
         attr_set = true;
     }
@@ -989,16 +989,16 @@ extern "C" int nfdp_linear_attention_f32(const float* qkv, float* out, int B, in
     NFDP_REQUIRE(dim_head == DH, NFDP_EUNSUPPORTED, "linear_attention: dim_head=%d (32 only)", dim_head);
     if (B == 0) return NFDP_OK;
     const size_t la_lds = n <= kBlock ? (size_t)2 * n * (DH + 1) * sizeof(float) : 0;
-    static bool la_attr = false;
+    static NfdpPerDevice la_attr;
     if (!la_attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_attention_kernel),
+        nfdp_func_attr(reinterpret_cast<const void*>(&linear_attention_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBlock * (DH + 1) * (int)sizeof(float));
         la_attr = true;
     }
     if (n <= kBlock && (((uintptr_t)qkv | (uintptr_t)out) & 15) == 0) {
-        static bool las_attr = false;
+        static NfdpPerDevice las_attr;
         if (!las_attr) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_attention_staged_kernel),
+            nfdp_func_attr(reinterpret_cast<const void*>(&linear_attention_staged_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBlock * (DH + 1) * (int)sizeof(float));
             las_attr = true;
         }
@@ -1046,9 +1046,9 @@ extern "C" int nfdp_attention_f32(const float* qkv, float* out, int B, int n, in
         return NFDP_OK;
     }
     const size_t lds = (size_t)2 * n * (DH + 1) * sizeof(float);
-    static bool attr_set = false;
+    static NfdpPerDevice attr_set;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        nfdp_func_attr(reinterpret_cast<const void*>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   2 * kBlock * (DH + 1) * (int)sizeof(float));
         attr_set = true;
     }

@@ -457,9 +457,9 @@ extern "C" int nfdp_linear_attention_bwd_f32(const float* qkv, const float* dout
     NFDP_REQUIRE(B >= 0 && n > 0 && n <= 256 && heads > 0, NFDP_ESHAPE, "linear_attention_bwd: n=%d outside [1,256]", n);
     if (B == 0) return NFDP_OK;
     const size_t lds = attn_bwd_lds(n, true);
-    static bool attr = false;
+    static NfdpPerDevice attr;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(linear_attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        nfdp_func_attr(reinterpret_cast<const void*>(linear_attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)attn_bwd_lds(256, true));
         attr = true;
     }
@@ -476,9 +476,9 @@ extern "C" int nfdp_attention_bwd_f32(const float* qkv, const float* dout, float
     NFDP_REQUIRE(B >= 0 && n > 0 && n <= 256 && heads > 0, NFDP_ESHAPE, "attention_bwd: n=%d outside [1,256]", n);
     if (B == 0) return NFDP_OK;
     const size_t lds = attn_bwd_lds(n, false);
-    static bool attr = false;
+    static NfdpPerDevice attr;
     if (!attr) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        nfdp_func_attr(reinterpret_cast<const void*>(attention_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)attn_bwd_lds(256, false));
         attr = true;
     }

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NFDP_LIB_PATH") or os.path.join(_HERE, "libnfdp_hip.so")   # override: profiling builds
 HEADER_PATH = os.environ.get("NFDP_HEADER_PATH") or os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "nfdp.h")
 
-F32, BF16 = 0, 1
+F32, BF16, F32X6 = 0, 1, 2          # F32X6: NFDP_F32X6, a `compute` value of the forward convs (see set_f32_products)
 _COMPUTE_NAMES = {"f32": F32, "fp32": F32, "float32": F32, "bf16": BF16, "bfloat16": BF16}
 _default_compute = os.environ.get("NFDP_COMPUTE", "f32")
 
@@ -109,14 +109,26 @@ _trace = None
 _param_epoch = 0
 
 
+# How compute = F32 forward convs form their products: a HOST-side default of this binding, handed to the library per call as the
+# `compute` argument (NFDP_F32 | NFDP_F32X6) - the library itself keeps no mode.
+_F32_PRODUCTS = "bf16x6"
+
+
 def set_f32_products(mode: str) -> None:
     """'exact' (v_mfma_f32_16x16x4_f32) | 'bf16x6' (default: three-way bf16 split of both operands, six bf16 MFMAs, fp32-chain
-    accuracy) for the fp32 convs (nfdp_set_f32_products)."""
-    _check(lib().nfdp_set_f32_products({"exact": 0, "bf16x6": 1}[mode]))
+    accuracy) for the fp32 forward convs (compute = NFDP_F32X6 in the calls)."""
+    global _F32_PRODUCTS
+    if mode not in ("exact", "bf16x6"):
+        raise ValueError(f"set_f32_products: {mode!r} (exact | bf16x6)")
+    _F32_PRODUCTS = mode
 
 
 def get_f32_products() -> str:
-    return ("exact", "bf16x6")[int(lib().nfdp_get_f32_products())]
+    return _F32_PRODUCTS
+
+
+def _f32_compute(compute: int) -> int:
+    return F32X6 if compute == F32 and _F32_PRODUCTS == "bf16x6" else compute
 
 
 def param_epoch() -> int:
@@ -488,7 +500,7 @@ def conv2d(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, *, add=Non
         if compute == BF16 and x_dt == BF16 and k == 1 and cin % 64 == 0 and cout > 64 and cout % 4 == 0 and b * h * w >= 512:
             lbl = f"pw_gemm_bf16 k1 {cin}->{cout} hw{h}"
     _call("nfdp_conv2d_nhwc", _ptr(xh), x_dt, _ld(xh, "conv2d"), _ptr(packed), _ptr(out), out_dtype, _ld(out, "conv2d"),
-          b, h, w, cin, cout, k, k, _ptr(add), _ptr(mul), float(mul_exp), int(relu), compute, _stream(),
+          b, h, w, cin, cout, k, k, _ptr(add), _ptr(mul), float(mul_exp), int(relu), _f32_compute(compute), _stream(),
           label=lbl, flops=2.0 * b * h * w * cin * k * k * cout,
           nbytes=float(b * h * w) * (cin * xh.element_size() + cout * out.element_size()))
     return out
@@ -924,7 +936,7 @@ def conv2d_cat(x1: torch.Tensor, x2: torch.Tensor, packed: torch.Tensor, cout: i
     c2 = x2.shape[3]
     out = torch.empty((b, h, w, cout), device=x1.device, dtype=torch.float32)
     _call("nfdp_conv2d_cat_nhwc_f32", _ptr(x1), _ld(x1, "conv2d_cat"), c1, _ptr(x2), _ld(x2, "conv2d_cat"), c2, _ptr(packed), _ptr(out), cout,
-          b, h, w, cout, k, _ptr(add), _stream(), label=f"conv2d_cat k{k} {c1}+{c2}->{cout} hw{h}", flops=2.0 * b * h * w * (c1 + c2) * k * k * cout)
+          b, h, w, cout, k, _ptr(add), _f32_compute(F32), _stream(), label=f"conv2d_cat k{k} {c1}+{c2}->{cout} hw{h}", flops=2.0 * b * h * w * (c1 + c2) * k * k * cout)
     return out
 
 
@@ -949,12 +961,12 @@ def conv2d_gn_silu(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bi
         c2 = x2.shape[3]
         _call("nfdp_conv2d_gn_silu_cat_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_gn_silu"), cin, _ptr(x2), _ld(x2, "conv2d_gn_silu"), c2,
               _ptr(packed), _ptr(y), cout, b, h, w, cout, k, _ptr(bias), groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld,
-              float(eps), _ptr(residual), res_ld, _stream(),
+              float(eps), _ptr(residual), res_ld, _f32_compute(F32), _stream(),
               label=f"conv_splitk_f32+gn cat k{k} {cin}+{c2}->{cout} hw{h}", flops=2.0 * b * h * w * (cin + c2) * k * k * cout)
         return y
     _call("nfdp_conv2d_gn_silu_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_gn_silu"), _ptr(packed), _ptr(y), cout, b, h, w, cin, cout, k,
-          _ptr(bias), groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, float(eps), _ptr(residual), res_ld, _stream(),
-          label=f"conv_splitk_f32+gn k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * k * k * cout)
+          _ptr(bias), groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, float(eps), _ptr(residual), res_ld, _f32_compute(F32),
+          _stream(), label=f"conv_splitk_f32+gn k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * k * k * cout)
     return y
 
 
@@ -1620,10 +1632,15 @@ def pointwise_dgrad_masked(xh: torch.Tensor, packed: torch.Tensor, y_saved: torc
 MLP_GATHER = True      # coupling_net_tiled: gather the first conv's operands inside the coupling-network kernel (False: explicit im2col)
 
 
+_MLP_FORM = 0          # host-side default of the per-call `form` argument of the tiled coupling-network entries (include/nfdp.h)
+
+
 def set_mlp_rows(mode: str) -> None:
     """Kernel form of the tiled coupling networks: "auto" (the row-split form - 32-pixel workgroups, the four waves split the weights -
-    where the 128-pixel form would leave most CUs idle: <= 16384 pixels), "never", "always".  bf16 results are bit-identical."""
-    _check(lib().nfdp_set_mlp_rows({"auto": 0, "never": 1, "always": 2}[mode]))
+    where the 128-pixel form would leave most CUs idle: <= 16384 pixels), "never", "always".  bf16 results are bit-identical.
+    A default of this binding, handed to the library per call (`form`)."""
+    global _MLP_FORM
+    _MLP_FORM = (_MLP_FORM & ~3) | {"auto": 0, "never": 1, "always": 2}[mode]
 
 
 def coupling_mlp_supported(c: int, n_features: int) -> bool:
@@ -1636,12 +1653,14 @@ def coupling_mlp_image_kind(xh_a: torch.Tensor, c: int, split: bool = False) -> 
     b, h, w, _ = xh_a.shape
     if xh_a.dtype != torch.float32 or xh_a.data_ptr() % 8 or _ld(xh_a, "coupling_mlp_image_kind") % 2 or not MLP_GATHER:
         return 1
-    return int(lib().nfdp_coupling_mlp_image_kind(c, b * h * w, int(split)))
+    return int(lib().nfdp_coupling_mlp_image_kind(c, b * h * w, int(split), _MLP_FORM))
 
 
 def set_mlp_k16(on: bool) -> None:
-    """Tiled coupling networks of C = 4, 12 on v_mfma_f32_16x16x32_bf16 (default) or on the 32x32x16 kernels."""
-    _check(lib().nfdp_set_mlp_k16(int(bool(on))))
+    """Tiled coupling networks of C = 4, 12 on v_mfma_f32_16x16x32_bf16 (default) or on the 32x32x16 kernels (per-call `form` bit
+    NFDP_MLP_NO_K16)."""
+    global _MLP_FORM
+    _MLP_FORM = (_MLP_FORM & ~4) | (0 if on else 4)
 
 
 def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: torch.Tensor, logs: torch.Tensor,
@@ -1662,10 +1681,10 @@ def coupling_net_tiled(xh_a: torch.Tensor, packed: torch.Tensor, c: int, bias: t
         # split-product form (compute "f32", set_f32_coupling("bf16x3")): packed = high-piece image, packed_lo = low-piece image
         _need(xh_a, torch.float32, "coupling_net_tiled")
         _call("nfdp_coupling_mlp_gather_bf16x3", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled"), b, h, w, _ptr(packed), _ptr(packed_lo), _ptr(t),
-              c, _stream(), label=f"coupling_mlp_x3<{c}> hw{h}", flops=fl)
+              c, _MLP_FORM, _stream(), label=f"coupling_mlp_x3<{c}> hw{h}", flops=fl)
     elif MLP_GATHER and xh_a.dtype == torch.float32 and xh_a.data_ptr() % (4 * vw) == 0 and _ld(xh_a, "coupling_net_tiled") % vw == 0:
         # the first conv's im2col inside the kernel (no xcol matrix, no im2col launch)
-        _call("nfdp_coupling_mlp_gather_bf16", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled"), b, h, w, _ptr(packed), _ptr(t), c, _stream(),
+        _call("nfdp_coupling_mlp_gather_bf16", _ptr(xh_a), _ld(xh_a, "coupling_net_tiled"), b, h, w, _ptr(packed), _ptr(t), c, _MLP_FORM, _stream(),
               label=f"coupling_mlp<{c}> hw{h}", flops=fl)
     else:
         xcol = im2col3x3(xh_a)

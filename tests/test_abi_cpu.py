@@ -44,14 +44,16 @@ def test_argument_validation_without_gpu():
     assert [c for c in range(2, 200, 2) if l.nfdp_tap_coupling_head_supported(c)] == [4, 8, 12, 16, 24, 32, 48]
     assert l.nfdp_tap_coupling_head_chunks(32, 64 * 64, 12) == 25 and l.nfdp_tap_coupling_head_chunks(512, 16, 48) == 1
     assert l.nfdp_tap_coupling_head_ws_bytes(32, 64 * 64, 12) == 32 * 25 * 8 and l.nfdp_tap_coupling_head_ws_bytes(4, 16, 96) == 0
-    assert l.nfdp_set_mlp_rows(3) == -1 and l.nfdp_set_mlp_rows(0) == 0
-    assert [l.nfdp_coupling_mlp_image_kind(c, n, 0) for c, n in ((12, 131072), (12, 16384), (4, 100), (24, 131072), (48, 8192))] == [2, 1, 2, 1, 1]
-    assert l.nfdp_set_mlp_k16(0) == 0 and l.nfdp_coupling_mlp_image_kind(12, 131072, 1) == 1 and l.nfdp_set_mlp_k16(1) == 0
+    # kernel forms are per-call arguments (`form`): nothing to set in the library
+    assert [l.nfdp_coupling_mlp_image_kind(c, n, 0, 0) for c, n in ((12, 131072), (12, 16384), (4, 100), (24, 131072), (48, 8192))] == [2, 1, 2, 1, 1]
+    assert l.nfdp_coupling_mlp_image_kind(12, 131072, 1, 4) == 1 and l.nfdp_coupling_mlp_image_kind(12, 131072, 1, 0) == 2   # NFDP_MLP_NO_K16
+    assert l.nfdp_coupling_mlp_image_kind(12, 131072, 0, 2) == 1 and l.nfdp_coupling_mlp_image_kind(12, 1024, 0, 1) == 2     # rows always / never
+    assert l.nfdp_coupling_mlp_gather_bf16(p, 6, 1, 4, 4, p, p, 12, 3, None) == -1                              # form 3 does not exist
     assert l.nfdp_coupling_mlp_gather_k16(p, 12, 1, 4, 4, p, None, p, 24, None) == -3                         # C = 24 has no 16x16x32 image
     assert l.nfdp_coupling_fused_packed_bytes(12) > 0
-    assert l.nfdp_coupling_mlp_gather_bf16x3(p, 6, 1, 4, 4, p, None, p, 12, None) == -1                        # no low-piece image
-    assert l.nfdp_coupling_mlp_gather_bf16x3(p, 48, 1, 4, 4, p, p, p, 96, None) == -3                         # C = 96: NFDP_EUNSUPPORTED
-    assert l.nfdp_coupling_mlp_gather_bf16(p + 4, 6, 1, 4, 4, p, p, 12, None) == -2                           # x not 8-byte aligned
+    assert l.nfdp_coupling_mlp_gather_bf16x3(p, 6, 1, 4, 4, p, None, p, 12, 0, None) == -1                        # no low-piece image
+    assert l.nfdp_coupling_mlp_gather_bf16x3(p, 48, 1, 4, 4, p, p, p, 96, 0, None) == -3                         # C = 96: NFDP_EUNSUPPORTED
+    assert l.nfdp_coupling_mlp_gather_bf16(p + 4, 6, 1, 4, 4, p, p, 12, 0, None) == -2                           # x not 8-byte aligned
     assert l.nfdp_tap_coupling_head_f32(p, p, 1, 4, 4, 20, p, p, 3.0, None, None, None, 0, p, p, p, None, None, 0, None) == -3
     assert l.nfdp_ldj_finish_level_f64(None, 4, None, None, 2, 1, None) == -1
     assert l.nfdp_ldj_finish_level_f64(p, 0, ctypes.byref(ctypes.c_void_p(p)), ctypes.byref(ctypes.c_void_p(None)), 1, 1, None) == 0
@@ -230,3 +232,17 @@ def test_module_apply_bumps_the_parameter_epoch():
     e0 = nfdp_hip.param_epoch()
     ActNorm(4).float()
     assert nfdp_hip.param_epoch() > e0
+
+
+def test_shipped_library_has_no_measurement_switches():
+    """The default build reads no environment variable and carries no NFDP_* switch name (A/B environment reads and the timing-only
+    NFDP_ABLATE_* / *_STAMPS code paths compile only with -DNFDP_DIAG: tools/build_variant.sh), and the process-wide mode setters of
+    earlier rounds are gone from the ABI (modes are per-call arguments: `compute`, `form`, `variant`)."""
+    import nfdp_hip.build as B
+    blob = open(B.LIB, "rb").read()
+    assert b"NFDP_" not in blob
+    l = nfdp_hip.lib()
+    for gone in ("nfdp_set_f32_products", "nfdp_get_f32_products", "nfdp_set_mlp_rows", "nfdp_set_mlp_k16"):
+        assert not hasattr(l, gone), gone
+    hdr = open(os.path.join(ROOT, "include", "nfdp.h")).read()
+    assert "nfdp_set_" not in hdr

@@ -6,7 +6,7 @@ set -e
 TAG=$1; shift
 PKG=$(dirname "$0")/../normalizing-flow-with-diffusion-prior-model_amd
 mkdir -p $PKG/build_$TAG
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result"
+F="-DNFDP_DIAG -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result"
 hipcc -x hip $F -mllvm -amdgpu-mfma-vgpr-form "$@" -c $PKG/csrc/coupling_fused_v.hip -o $PKG/build_$TAG/coupling_fused_v.o &
 hipcc -x hip $F "$@" -c $PKG/csrc/coupling_fused_a.hip -o $PKG/build_$TAG/coupling_fused_a.o &
 wait

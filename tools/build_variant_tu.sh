@@ -6,7 +6,7 @@ set -e
 TAG=$1; TU=$2; shift 2
 PKG=$(dirname "$0")/../normalizing-flow-with-diffusion-prior-model_amd
 mkdir -p $PKG/build_$TAG
-F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result"
+F="-DNFDP_DIAG -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result"
 BASE=$(basename $TU .hip)
 hipcc -x hip $F "$@" -c $PKG/csrc/$TU -o $PKG/build_$TAG/$BASE.o
 OBJS=$(ls $PKG/build/*.o | grep -v "/$BASE.o")
