@@ -40,7 +40,8 @@ extern "C" {
                       * formed on the bf16 matrix cores from three-way splits of both operands (v = h + m + l exactly; six
                       * v_mfma_f32_16x16x32_bf16 per 32 k with fp32 accumulation: as close to the fp64 value as the fp32 FMA chain, 2e-7 vs
                       * 5e-7 at K = 576..4608, at 2.7x fewer matrix-pipe cycles).  Non-finite or > bf16-max operands travel in the high
-                      * piece alone, so inf / NaN propagate as in NFDP_F32. */
+                      * piece alone: outputs they reach are non-finite exactly where NFDP_F32's are and NaN stays NaN, but an inf may
+                      * come out as NaN (inf times the other operand's signed residual pieces). */
 #define NFDP_MLP_NO_K16 4 /* bit of the `form` argument of the tiled coupling-network entries (nfdp_coupling_mlp_image_kind) */
 #define NFDP_PACK_JOB_WORDS 12 /* int64 words of one nfdp_conv_pack_weights_batch job */
 

@@ -362,19 +362,20 @@ def test_f32_products_on_bf16_matrix_cores():
         K.set_f32_products(default_mode)
 
 
-def test_f32_split_products_propagate_non_finite_operands_like_the_fp32_chain():
-    """compute = NFDP_F32X6 (three-way bf16 splits): an inf / NaN / above-bf16-range operand goes through the high piece alone, so the
-    pixels it reaches come out inf / NaN exactly where the exact fp32 chain puts them, and all other pixels stay finite and equal to
-    the clean result (v - bf16(v) = inf - inf used to turn an inf into NaN)."""
+def test_f32_split_products_keep_non_finite_operands_non_finite():
+    """compute = NFDP_F32X6 (three-way bf16 splits): an inf / NaN / above-bf16-range operand goes through the high piece alone (ADVICE
+    r4: v - bf16(v) = inf - inf used to make EVERY such operand a NaN source, also where the exact chain stays finite).  What the split
+    form can promise: the outputs an inf / NaN operand reaches are non-finite exactly where the exact fp32 chain's are, NaN stays NaN,
+    and every other output equals the clean result.  It cannot promise the SIGN of an inf: inf times the other operand's (signed)
+    residual pieces gives -inf terms, so an inf output of the exact chain may be NaN here (stated in include/nfdp.h)."""
     g = torch.Generator().manual_seed(5)
     for shape_x, shape_w in (((2, 8, 8, 72), (64, 72, 3, 3)), ((2, 16, 16, 12), (96, 12, 3, 3))):      # split-K kernel, tiled kernel
         x = torch.randn(*shape_x, generator=g)
-        wt = torch.randn(*shape_w, generator=g).abs() / 20.0 + 0.01          # positive weights: an inf never meets a weight of the other sign
-        cases = {"inf": float("inf"), "-inf": float("-inf"), "nan": float("nan"), "big": 3.4e38}
+        wt = torch.randn(*shape_w, generator=g) / 20.0
         packed = K.conv_pack(wt.to(DEV), K.F32)
         default_mode = K.get_f32_products()
         try:
-            for name, val in cases.items():
+            for name, val in {"inf": float("inf"), "-inf": float("-inf"), "nan": float("nan")}.items():
                 xv = x.clone()
                 xv[1, 3, 4, 5] = val
                 out = {}
@@ -382,12 +383,11 @@ def test_f32_split_products_propagate_non_finite_operands_like_the_fp32_chain():
                     K.set_f32_products(mode)
                     out[mode] = K.conv2d(xv.to(DEV), packed, shape_w[0], 3).cpu()
                 e, s = out["exact"], out["bf16x6"]
-                assert torch.equal(torch.isnan(e), torch.isnan(s)), name
-                assert torch.equal(torch.isinf(e) & (e > 0), torch.isinf(s) & (s > 0)), name
-                assert torch.equal(torch.isinf(e) & (e < 0), torch.isinf(s) & (s < 0)), name
+                assert torch.equal(torch.isfinite(e), torch.isfinite(s)), name
+                assert torch.equal(torch.isnan(e) & torch.isnan(s), torch.isnan(e)), name          # NaN stays NaN
                 fin = torch.isfinite(e)
-                assert fin[0].all() and not fin[1].all() or name == "big"
-                assert float((e[fin] - s[fin]).abs().max()) < 1e-4 * float(e[fin].abs().max()) or name == "big", name
+                assert fin[0].all() and not fin[1].all() and int((~fin).sum()) <= 9 * shape_w[0], name
+                assert float((e[fin] - s[fin]).abs().max()) < 1e-4 * float(e[fin].abs().max()), name
         finally:
             K.set_f32_products(default_mode)
 
