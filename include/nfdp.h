@@ -520,6 +520,18 @@ int nfdp_coupling_wgrad3_bf16(const void* const* x, const int* x_ld, const int* 
                               float* const* dw, const int* out_form, const int* out_c, const float* const* w, const float* const* bias,
                               float* const* dscale, float* const* dbias, int n_gemm, long npix, void* ws, int accumulate,
                               nfdp_stream_t stream);
+/* The same for up to nfdp_coupling_wgrad3_batch_max_flows() (16) flows of a level in ONE GEMM launch + ONE reduce launch: the GEMMs of one
+ * flow at the 8x8 / 4x4 levels of a B = 512 step fill a fraction of the chip (66 / 52 us per flow against 165 us for the 16x larger
+ * 16x16 flow); the flows' gradients are independent, so the backward pass keeps their operands and runs them here.  x / dy / dw / w / bias /
+ * dscale / dbias: HOST tables [flows][n_gemm] row-major; x_ld / x_blocked / cin / out_form / out_c: [n_gemm], shared by the flows.
+ * ws: flows * nfdp_coupling_wgrad3_batch_ws_bytes(npix, cin, n_gemm) bytes.  The slice plan does not depend on `flows`: a flow's sums are
+ * the same bits whether it travels with 15 others or alone. */
+size_t nfdp_coupling_wgrad3_batch_ws_bytes(long npix, const int* cin, int n_gemm);
+int nfdp_coupling_wgrad3_batch_max_flows(void);
+int nfdp_coupling_wgrad3_batch_bf16(const void* const* x, const int* x_ld, const int* x_blocked, const void* const* dy, const int* cin,
+                                    float* const* dw, const int* out_form, const int* out_c, const float* const* w,
+                                    const float* const* bias, float* const* dscale, float* const* dbias, int n_gemm, int flows, long npix,
+                                    void* ws, int accumulate, nfdp_stream_t stream);
 /* wt[i][o][ky][kx] = w[o][i][k-1-ky][k-1-kx]: nfdp_conv2d_nhwc on pack(wt) is the data gradient of the conv with w. */
 int nfdp_conv_flip_weights_f32(const float* w, float* wt, int O, int I, int k, nfdp_stream_t stream);
 /* Second half of a narrow 3x3 'same' conv computed as a pointwise GEMM to tap contributions T [B,H,W,9*Co] (column

@@ -1494,6 +1494,48 @@ __global__ void __launch_bounds__(kBlock) wgrad_reduce_multi_kernel(const Reduce
                      sdot, sdb);
 }
 
+// The same two launches for up to kWgradBatch flows of a level at once (blockIdx.y = flow): the GEMMs of ONE flow at the 8x8 / 4x4 levels of a
+// B = 512 step cover 32768 / 8192 pixels - a fraction of the chip, 66 / 52 us per flow against 165 us for the 16x larger level-0 flow.  The
+// flows' gradients are independent of each other, so the backward pass keeps their operands and runs all of them here, each GEMM with fewer
+// and longer pixel slices.  Shapes and slice plans are shared (WgradMulti / ReduceMulti hold them once); only pointers differ per flow.
+constexpr int kWgradBatch = 16;
+struct WgradBatchPtrs {
+    const void* x[kWgradBatch][3];
+    const void* dy[kWgradBatch][3];
+    float* ws[kWgradBatch][3];
+    float* ws_db[kWgradBatch][3];
+};
+__global__ void __launch_bounds__(W2_THREADS, 1) wgrad_bf16_multi_batch_kernel(const WgradMulti m, const WgradBatchPtrs t) {
+    extern __shared__ __attribute__((aligned(1024))) char w2_dyn_smem[];
+    const int b = blockIdx.x, f = blockIdx.y;
+    const int q = (m.n > 2 && b >= m.first[2]) ? 2 : ((m.n > 1 && b >= m.first[1]) ? 1 : 0);
+    const int bid = b - m.first[q];
+    if (bid >= m.p[q].mblocks * m.p[q].nblocks * m.p[q].ksplit) return;
+    WgradParams p = m.p[q];
+    p.x = t.x[f][q]; p.dy = t.dy[f][q]; p.ws = t.ws[f][q]; p.ws_db = t.ws_db[f][q];
+    if (m.kind[q] == 0) wgrad_wide_body<256, true, true>(p, bid, w2_dyn_smem);
+    else if (m.kind[q] == 1) wgrad_wide_body<256, true, false>(p, bid, w2_dyn_smem);
+    else wgrad_wide_body<128, true, false>(p, bid, w2_dyn_smem);
+}
+struct ReduceBatch {                                  // (by value: 2.9 KB of the 4 KB kernel-argument space)
+    const float* ws[kWgradBatch][3];
+    const float* ws_db[kWgradBatch][3];
+    float* dw[kWgradBatch][3];
+    const float* w[kWgradBatch][3];
+    const float* bias[kWgradBatch][3];
+    float* dscale[kWgradBatch][3];
+    float* dbias[kWgradBatch][3];
+    WgradOut o[3];
+    int ksplit[3], Npad[3];
+};
+__global__ void __launch_bounds__(kBlock) wgrad_reduce_multi_batch_kernel(const ReduceBatch r) {
+    __shared__ float4 red[kBlock];
+    __shared__ float sdot[kBlock], sdb[kBlock];
+    const int q = blockIdx.x / 512, m = blockIdx.x % 512, f = blockIdx.y;
+    wgrad_reduce_row(r.ws[f][q], r.ws_db[f][q], r.dw[f][q], r.ksplit[q], 512, r.Npad[q], r.o[q], r.w[f][q], r.bias[f][q], r.dscale[f][q],
+                     r.dbias[f][q], m, red, sdot, sdb);
+}
+
 // ----------------------------------------------------------------------------- tap shift-sum (narrow 3x3 convs)
 // A 3x3 conv with few output channels spends its time staging im2col rows.  Computed instead as a pointwise GEMM
 // T[p][tap*Co + co] = sum_ci x[p][ci] W[co][ci][tap] (a wide 1x1 conv: fast) followed by
@@ -1844,7 +1886,7 @@ extern "C" int nfdp_conv_wgrad_bf16_affine(const void* x, int x_ld, const void* 
 }
 
 // ---- the weight gradients of one flow's coupling network in one GEMM launch + one reduce launch (see wgrad_bf16_multi_kernel)
-static bool wgrad3_plan(long npix, const int* cin, int n, WgradParams* p) {
+static bool wgrad3_plan(long npix, const int* cin, int n, WgradParams* p, bool batched = false) {
     if (n < 1 || n > 3) return false;
     double denom = 0.0;
     double cost[3];
@@ -1862,6 +1904,13 @@ static bool wgrad3_plan(long npix, const int* cin, int n, WgradParams* p) {
         long want = (long)(256.0 / denom * cost[q]) / 8 * 8;   // slices in proportion to the stage cost: the GEMMs finish together
         if (want < 8) want = 8;
         if (want > cap) want = cap >= 8 ? cap / 8 * 8 : (cap > 0 ? cap : 1);
+        if (batched) {
+            // a level's flows in one launch: a sixteenth of the slices each (the plan does NOT depend on how many flows a call carries,
+            // so a flow's sums - and bits - are the same whether it travels with 15 others or, under activation recomputation, with 3)
+            want = (long)(256.0 / denom * cost[q] / kWgradBatch + 0.5);
+            if (want < 1) want = 1;
+            if (want > cap && cap > 0) want = cap;
+        }
         p[q].N = cin[q];
         p[q].mblocks = 2;
         p[q].nblocks = (int)cdiv(cin[q], tn);
@@ -1933,6 +1982,89 @@ extern "C" int nfdp_coupling_wgrad3_bf16(const void* const* x, const int* x_ld, 
     hipLaunchKernelGGL(wgrad_bf16_multi_kernel, dim3(blocks), dim3(W2_THREADS), W2_NS * w2_slot_bytes<256>(), s, m);
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(512 * n_gemm), dim3(kBlock), 0, s, r);
     NFDP_CHECK_LAUNCH("coupling_wgrad3");
+    return NFDP_OK;
+}
+
+// ---- ... and for several flows of a level at once (see wgrad_bf16_multi_batch_kernel).  Pointer tables are [flows][n_gemm] row-major
+// HOST arrays; shapes (x_ld, x_blocked, cin, out_form, out_c) are shared by the flows.  ws: flows * nfdp_coupling_wgrad3_batch_ws_bytes.
+extern "C" size_t nfdp_coupling_wgrad3_batch_ws_bytes(long npix, const int* cin, int n_gemm) {
+    WgradParams p[3];
+    if (!cin || !wgrad3_plan(npix, cin, n_gemm, p, true)) return 0;
+    size_t bytes = 0;
+    for (int q = 0; q < n_gemm; ++q) bytes += (size_t)p[q].ksplit * 512 * (p[q].Npad + 1) * sizeof(float);
+    return bytes;
+}
+
+extern "C" int nfdp_coupling_wgrad3_batch_max_flows(void) { return kWgradBatch; }
+
+extern "C" int nfdp_coupling_wgrad3_batch_bf16(const void* const* x, const int* x_ld, const int* x_blocked, const void* const* dy,
+                                               const int* cin, float* const* dw, const int* out_form, const int* out_c,
+                                               const float* const* w, const float* const* bias, float* const* dscale,
+                                               float* const* dbias, int n_gemm, int flows, long npix, void* ws, int accumulate,
+                                               nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && x_ld && x_blocked && dy && cin && dw && out_form && out_c && w && bias && dscale && dbias && ws, NFDP_EINVAL,
+                 "coupling_wgrad3_batch: null pointer");
+    NFDP_REQUIRE(flows >= 1 && flows <= kWgradBatch, NFDP_ESHAPE, "coupling_wgrad3_batch: 1..%d flows per call (%d)", kWgradBatch, flows);
+    WgradMulti m;
+    NFDP_REQUIRE(wgrad3_plan(npix, cin, n_gemm, m.p, true), NFDP_EUNSUPPORTED,
+                 "coupling_wgrad3_batch: 1..3 GEMMs over a multiple of %d pixels, x channels multiples of 8 up to 512", W2_KC);
+    WgradBatchPtrs t;
+    ReduceBatch r;
+    m.n = n_gemm;
+    const size_t per_flow = nfdp_coupling_wgrad3_batch_ws_bytes(npix, cin, n_gemm) / sizeof(float);
+    int blocks = 0;
+    size_t off = 0;
+    for (int q = 0; q < n_gemm; ++q) {
+        WgradParams& p = m.p[q];
+        bool affine = false;
+        for (int f = 0; f < flows; ++f) {
+            const int i = f * n_gemm + q;
+            NFDP_REQUIRE(x[i] && dy[i] && dw[i], NFDP_EINVAL, "coupling_wgrad3_batch: null pointer in GEMM %d of flow %d", q, f);
+            const bool aff = w[i] != nullptr;
+            NFDP_REQUIRE(f == 0 || aff == affine, NFDP_EINVAL, "coupling_wgrad3_batch: GEMM %d has ActNorm parameters in some flows only", q);
+            affine = aff;
+            NFDP_REQUIRE(!aff || (bias[i] && dscale[i] && dbias[i]), NFDP_EINVAL, "coupling_wgrad3_batch: w given without bias / dscale / dbias");
+            NFDP_REQUIRE((((uintptr_t)x[i] | (uintptr_t)dy[i]) & 15) == 0, NFDP_ESHAPE, "coupling_wgrad3_batch: 16-byte aligned bf16 rows");
+            float* wsf = reinterpret_cast<float*>(ws) + (size_t)f * per_flow + off;
+            t.x[f][q] = x[i]; t.dy[f][q] = dy[i]; t.ws[f][q] = wsf;
+            t.ws_db[f][q] = aff ? wsf + (size_t)p.ksplit * 512 * p.Npad : nullptr;
+            r.ws[f][q] = t.ws[f][q]; r.ws_db[f][q] = t.ws_db[f][q]; r.dw[f][q] = dw[i]; r.w[f][q] = w[i]; r.bias[f][q] = bias[i];
+            r.dscale[f][q] = dscale[i]; r.dbias[f][q] = dbias[i];
+        }
+        NFDP_REQUIRE(wgrad_out_map(out_form[q], out_c[q], 512, cin[q], 1, accumulate, &r.o[q]) && !(affine && out_form[q] == 2), NFDP_ESHAPE,
+                     "coupling_wgrad3_batch: output form %d of GEMM %d (out_c=%d Cin=%d)", out_form[q], q, out_c[q], cin[q]);
+        NFDP_REQUIRE(!x_blocked[q] || (cin[q] == 512 && x_ld[q] == 512), NFDP_ESHAPE, "coupling_wgrad3_batch: a blocked x has 512 channels");
+        NFDP_REQUIRE(x_ld[q] >= cin[q] && x_ld[q] % 8 == 0, NFDP_ESHAPE, "coupling_wgrad3_batch: x rows of whole 16-byte pieces");
+        off += (size_t)p.ksplit * 512 * (p.Npad + 1);
+        p.x = nullptr; p.dy = nullptr; p.ws = nullptr; p.ws_db = nullptr;          // (per flow: WgradBatchPtrs)
+        p.a_blocked = 1; p.b_blocked = x_blocked[q] ? 1 : 0;
+        p.x_ld = x_ld[q]; p.dy_ld = 512; p.B = 1; p.H = 1; p.W = (int)npix; p.Cin = cin[q]; p.Cout = 512; p.k = 1;
+        m.kind[q] = x_blocked[q] ? 0 : (wgrad_wide_tn(cin[q]) == 256 ? 1 : 2);
+        m.first[q] = blocks;
+        blocks += p.mblocks * p.nblocks * p.ksplit;
+        blocks = (blocks + 7) & ~7;
+        r.ksplit[q] = p.ksplit; r.Npad[q] = p.Npad;
+    }
+    m.first[n_gemm] = blocks;
+    for (int q = n_gemm; q < 3; ++q) { m.kind[q] = 0; m.first[q + 1] = blocks; }
+    for (int f = 0; f < kWgradBatch; ++f)
+        for (int q = 0; q < 3; ++q)
+            if (f >= flows || q >= n_gemm) {
+                t.x[f][q] = t.dy[f][q] = nullptr; t.ws[f][q] = t.ws_db[f][q] = nullptr;
+                r.ws[f][q] = r.ws_db[f][q] = nullptr; r.dw[f][q] = nullptr; r.w[f][q] = r.bias[f][q] = nullptr;
+                r.dscale[f][q] = r.dbias[f][q] = nullptr;
+            }
+    static_assert(sizeof(WgradMulti) + sizeof(WgradBatchPtrs) <= 4096 && sizeof(ReduceBatch) <= 4096, "kernel arguments are passed by value");
+    hipStream_t s = as_stream(stream);
+    static NfdpPerDevice attr_set;
+    if (!attr_set) {
+        nfdp_func_attr(reinterpret_cast<const void*>(&wgrad_bf16_multi_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                       W2_NS * w2_slot_bytes<256>());
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_bf16_multi_batch_kernel, dim3(blocks, flows), dim3(W2_THREADS), W2_NS * w2_slot_bytes<256>(), s, m, t);
+    hipLaunchKernelGGL(wgrad_reduce_multi_batch_kernel, dim3(512 * n_gemm, flows), dim3(kBlock), 0, s, r);
+    NFDP_CHECK_LAUNCH("coupling_wgrad3_batch");
     return NFDP_OK;
 }
 

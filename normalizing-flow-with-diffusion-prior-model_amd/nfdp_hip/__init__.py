@@ -1316,6 +1316,55 @@ def coupling_wgrad3(problems, accumulate: bool = True) -> None:
           label=f"coupling_wgrad3 x{n}", flops=sum(2.0 * npix * 512 * pr["x"].shape[-1] for pr in problems))
 
 
+def coupling_wgrad3_batch(flows, accumulate: bool = True) -> None:
+    """coupling_wgrad3 for several flows of a level in ONE GEMM launch + ONE reduce launch (nfdp_coupling_wgrad3_batch_bf16): `flows` is a
+    list of problem lists as coupling_wgrad3 takes them, all of the same shapes / forms.  More than the library's 16 flows per launch are
+    sent in chunks.  A flow's result does not depend on how many flows travel with it."""
+    if not flows:
+        return
+    n = len(flows[0])
+    if not 1 <= n <= 3 or any(len(pr) != n for pr in flows):
+        raise ValueError("coupling_wgrad3_batch: 1..3 problems per flow, the same number for every flow")
+    first = flows[0]
+    npix = first[0]["dy"].numel() // 512
+    for prs in flows:
+        for q, pr in enumerate(prs):
+            xh, dyh, ref = pr["x"], pr["dy"], first[q]
+            _need(xh, torch.bfloat16, "coupling_wgrad3_batch"); _need(dyh, torch.bfloat16, "coupling_wgrad3_batch")
+            _dense(xh, "coupling_wgrad3_batch"); _dense(dyh, "coupling_wgrad3_batch")
+            cin = xh.shape[-1]
+            if dyh.shape[-1] != 512 or dyh.numel() // 512 != npix or xh.numel() // cin != npix or cin != ref["x"].shape[-1]:
+                raise ValueError(f"coupling_wgrad3_batch: shapes differ between flows ({tuple(xh.shape)} / {tuple(dyh.shape)})")
+            for k in ("form", "form_c", "x_blocked"):
+                if pr.get(k, 0) != ref.get(k, 0):
+                    raise ValueError(f"coupling_wgrad3_batch: '{k}' differs between flows")
+            form, form_c = int(pr.get("form", 0)), int(pr.get("form_c", 0))
+            shape = {0: (512, cin, 1, 1), 1: (512, form_c, 3, 3), 2: (form_c, 512, 3, 3)}[form]
+            aff = [pr.get(k) for k in ("weight", "bias", "dscale", "dbias")]
+            if any(t is None for t in aff) != all(t is None for t in aff):
+                raise ValueError("coupling_wgrad3_batch: weight / bias / dscale / dbias go together")
+            for t in [pr["dw"]] + [t for t in aff if t is not None]:
+                _need(t, torch.float32, "coupling_wgrad3_batch"); _dense(t, "coupling_wgrad3_batch")
+            if tuple(pr["dw"].shape) != shape or (aff[0] is not None and tuple(aff[0].shape) != shape):
+                raise ValueError(f"coupling_wgrad3_batch: dw {tuple(pr['dw'].shape)}, expected {shape}")
+    ints = lambda vs: (ctypes.c_int * n)(*[int(v) for v in vs])
+    cins = ints(pr["x"].shape[-1] for pr in first)
+    per_flow = lib().nfdp_coupling_wgrad3_batch_ws_bytes(npix, cins, n)
+    if per_flow == 0:
+        raise NfdpError(f"coupling_wgrad3_batch: unsupported shapes (npix={npix}, cin={[pr['x'].shape[-1] for pr in first]})")
+    cap = int(lib().nfdp_coupling_wgrad3_batch_max_flows())
+    for c0 in range(0, len(flows), cap):
+        chunk = flows[c0:c0 + cap]
+        nf = len(chunk)
+        tab = lambda key: (ctypes.c_void_p * (nf * n))(*[None if pr.get(key) is None else _ptr(pr[key]) for prs in chunk for pr in prs])
+        ws = torch.empty(per_flow * nf, device=first[0]["x"].device, dtype=torch.uint8)
+        _call("nfdp_coupling_wgrad3_batch_bf16", tab("x"), ints(pr["x"].shape[-1] for pr in first),
+              ints(bool(pr.get("x_blocked", False)) for pr in first), tab("dy"), cins, tab("dw"), ints(pr.get("form", 0) for pr in first),
+              ints(pr.get("form_c", 0) for pr in first), tab("weight"), tab("bias"), tab("dscale"), tab("dbias"), n, nf, npix, _ptr(ws),
+              int(accumulate), _stream(), label=f"coupling_wgrad3_batch x{n} x{nf} flows",
+              flops=nf * sum(2.0 * npix * 512 * pr["x"].shape[-1] for pr in first))
+
+
 def conv_flip_weights(w_oihw: torch.Tensor) -> torch.Tensor:
     _need(w_oihw, torch.float32, "conv_flip_weights"); _dense(w_oihw, "conv_flip_weights")
     o, i, k, _ = w_oihw.shape

@@ -151,11 +151,29 @@ def _join_side() -> None:
         _side_keep.clear()
 
 
+_join_queued = [False]
+
+
+def _join_at_end_of_backward() -> None:
+    """Queue ONE engine callback per backward pass that makes the main stream wait for the side stream (and releases the tensors it
+    reads): runs after the last node, before loss.backward() returns to the caller."""
+    if _join_queued[0]:
+        return
+    _join_queued[0] = True
+
+    def done():
+        _join_queued[0] = False
+        _join_side()
+
+    torch.autograd.Variable._execution_engine.queue_callback(done)
+
+
 def _abandon_side() -> None:
     """A backward launch raised between _defer_side and _flush_side / _join_side: drop the queued closures (they would otherwise run
     in the NEXT backward pass and add stale weight gradients into .grad) and let the main stream wait for whatever the side stream
     was already given before the tensors it reads are released."""
     _side_jobs.clear()
+    _join_queued[0] = False
     try:
         _join_side()
     except Exception:                                        # noqa: BLE001 - the original error is the one to report
@@ -652,7 +670,16 @@ FUSED_TRAIN_BACKWARD = True         # ... and the data-gradient chain of each co
 WGRAD_ONE_LAUNCH = os.environ.get("NFDP_WGRAD_ONE_LAUNCH", "1") != "0"
 
 
-def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net, packed=None):
+# The weight gradients of the 8x8 / 4x4 levels' flows as ONE launch per level (K.coupling_wgrad3_batch) instead of one per flow: a single
+# flow's three GEMMs cover 32768 / 8192 pixels of a B = 512 step - 66 / 52 us per flow in isolation against 165 us for the 16x larger
+# 16x16 flow, 1.9 ms of a 13.1 ms step.  The flows' operands (hidden-activation gradients: 1.2 / 0.3 GB per level) are kept until the
+# level's data-gradient chain is through; the launch then runs on the side stream beside the NEXT level's chain and is joined by that
+# level (or, for the last node of the pass, by an engine callback before backward() returns).  Levels with more pixels per flow than
+# this keep the per-flow launches (their operands are 0.3 GB per flow, and one flow fills the chip).
+WGRAD_BATCH_MAX_PIXELS = int(os.environ.get("NFDP_WGRAD_BATCH_MAX_PIXELS", str(64 * 512)))
+
+
+def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net, packed=None, batch=None):
     """Backward of one coupling network on the fused kernels, from the gradient dc3 at the zero conv's raw output (the link kernel has
     applied its scale backward).  dx [B,H,W,C]: the coupling's input gradient, whose first half receives += the network's input
     gradient; xcol: saved im2col rows of the network's input; y1, y2: saved hidden activations (blocked layout, [Bpad,H,W,512] bf16).
@@ -680,7 +707,11 @@ def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net, packed=None):
                 dict(x=dc3_col, dy=y2, dw=gw3, form=2, form_c=co)]
     if direct:
         pr = problems(*gs)
-        if WGRAD_ONE_LAUNCH:
+        if WGRAD_ONE_LAUNCH and batch is not None and WGRAD_SIDE_STREAM:
+            batch.append(pr)                                # (the dicts keep the operands alive until the level's one launch)
+        elif WGRAD_ONE_LAUNCH and batch is not None:
+            K.coupling_wgrad3_batch([pr], True)
+        elif WGRAD_ONE_LAUNCH:
             _defer_side(lambda: K.coupling_wgrad3(pr, True), dc3_col, y2, y1, dc2, xcol, dc1)
         else:
             gw1, gb1, gs1, gw2, gb2, gs2, gw3 = gs
@@ -693,7 +724,10 @@ def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net, packed=None):
     dw3 = torch.empty_like(w3)
     dw2, ds2, db2 = torch.empty_like(w2), torch.empty(hid, device=w2.device), torch.empty(hid, device=w2.device)
     dw1, ds1, db1 = torch.empty_like(w1), torch.empty(o1, device=w1.device), torch.empty(o1, device=w1.device)
-    if WGRAD_ONE_LAUNCH:
+    if WGRAD_ONE_LAUNCH and batch is not None:
+        # the small levels' slice plan (the same bits as the level-wide launch gives this flow: the plan does not depend on the batch)
+        K.coupling_wgrad3_batch([problems(dw1, db1, ds1, dw2, db2, ds2, dw3)], False)
+    elif WGRAD_ONE_LAUNCH:
         K.coupling_wgrad3(problems(dw1, db1, ds1, dw2, db2, ds2, dw3), False)
     else:
         K.conv_wgrad_blocked(dc3_col, y2, dw3, False, form=2, form_c=co, dy_blocked=True)
@@ -759,6 +793,7 @@ class LevelFusedFn(Function):
                 g0 = (i // G) * G
                 if cache.get("g0") != g0:
                     if cache:
+                        flush_batch()                              # (small levels: the previous group's weight gradients in one launch)
                         _flush_side()                              # the side stream still reads the previous group's tensors (weight
                         _join_side()                               # gradients): join before they are released
                     cache.clear()                                  # drop the previous group's tensors before allocating the next
@@ -776,6 +811,15 @@ class LevelFusedFn(Function):
         n, P, params = ctx.n, LevelFusedFn.NP, ctx.params
         bsz, hh, ww, c = ypost.shape[1:]
         npix = bsz * hh * ww
+        # small levels: the flows' weight gradients in one launch behind the chain (under recomputation: per group of flows)
+        batch = [] if (WGRAD_ONE_LAUNCH and npix <= WGRAD_BATCH_MAX_PIXELS) else None
+
+        def flush_batch():
+            if batch:
+                prs = list(batch)
+                batch.clear()
+                _defer_side(lambda: K.coupling_wgrad3_batch(prs, True), *[t for fl in prs for pr in fl for t in (pr["x"], pr["dy"])])
+                _flush_side()
         if dy is None:
             dy = torch.zeros_like(ypost[0])
         dy = dy.contiguous()
@@ -801,13 +845,13 @@ class LevelFusedFn(Function):
             scale, bias, weight = params[P * i: P * i + 3]
             net = params[P * i + 3: P * i + 12]
             xc_i, y1_i, y2_i = hidden(i)
-            g9 = _net_backward_fused(dc3, dx, xc_i, y1_i, y2_i, net, ctx.nets[i], packed=rev[i])   # dx[..., :c/2] += network input gradient
+            g9 = _net_backward_fused(dc3, dx, xc_i, y1_i, y2_i, net, ctx.nets[i], packed=rev[i], batch=batch)   # dx[..., :c/2] += network input gradient
             head = (xpre[i], weight.detach().reshape(c, c), scale.detach().reshape(-1), bias.detach().reshape(-1))
             cpl = (ypost[i - 1], hout[i - 1], gl, l3(i - 1), f3) if i > 0 else None
             # (the 1x1 conv's weight gradient dW = sum_p dx (x) a, transforms.py:132, is left in the call's partial buffer too)
             dx_next, dc3, _ = K.flow_link_bwd(dx, part[n - i], head=head, coupling=cpl, want_a=False)
             _flush_side()                                            # one fork per flow: the coupling network's weight gradients
-            if SIDE_JOIN_EVERY and (n - i) % SIDE_JOIN_EVERY == 0 and i > 0:
+            if batch is None and SIDE_JOIN_EVERY and (n - i) % SIDE_JOIN_EVERY == 0 and i > 0:
                 _join_side()
             if g9 is not None:
                 grads[P * i + 3: P * i + 10] = list(g9)
@@ -828,6 +872,7 @@ class LevelFusedFn(Function):
         else:
             outs = [[None if t is None else torch.empty(t.numel(), device=t.device, dtype=torch.float32) for t in tup] for tup in small]
             acc = False
+        flush_batch()                                                # the level's weight gradients: one launch, on the side stream
         K.flow_link_finish(part, npix, c, f3, [o[0] for o in outs], [o[1] for o in outs], [o[2] for o in outs], [o[3] for o in outs], acc,
                            dw=[o[4] for o in outs])
         if not acc:
@@ -838,7 +883,12 @@ class LevelFusedFn(Function):
                     grads[P * hf + 2] = o[4].view_as(tup[4])
                 if cf >= 0:
                     grads[P * cf + 11], grads[P * cf + 10] = o[2].view_as(tup[2]), o[3].view_as(tup[3])
-        _join_side()
+        if batch is None or any(g is not None for g in grads):
+            _join_side()
+        else:
+            # the level's one weight-gradient launch keeps running beside the next node's chain; whoever joins the side stream next (a
+            # later level's node) - or this callback at the end of the backward pass - orders it before any consumer of the gradients
+            _join_at_end_of_backward()
         if all(g is None for g in grads):                 # every gradient of this level went straight into the optimizer's buffer
             _dist.grads_ready(ctx.params, include=True, producer_streams=tuple(_side_streams.values()))
         dl = None
