@@ -80,7 +80,6 @@ class DiffusionPrior(nn.Module):
         self.loss_type = self.priors[0].loss_type
         self.concurrent_parts = True          # one HIP stream per latent part in the sampling loops (see _sample_parts)
         self._part_streams = None
-        self.prioritize_longest_chain = False
 
     def forward(self, latents: list) -> list:
         """List of per-part losses  (reference model.py:105-119)."""
@@ -111,12 +110,9 @@ class DiffusionPrior(nn.Module):
             return [drain(make(prior, i)) for i, prior in enumerate(self.priors)]
         cur = torch.cuda.current_stream(dev)
         if self._part_streams is None or len(self._part_streams) != len(self.priors):
-            # the part with the most work per step (the largest latent) sets the wall time of the whole call: with
-            # `prioritize_longest_chain` its stream is a high-priority HIP stream, so its launches are not queued behind the short chains'
-            work = [int(p.diffusion.image_size) ** 2 for p in self.priors]
-            top = work.index(max(work))
-            self._part_streams = [torch.cuda.Stream(device=dev, priority=(-1 if (self.prioritize_longest_chain and i == top) else 0))
-                                  for i in range(len(self.priors))]
+            # (measured, round 5: the largest part's chain alone takes 1.13 s of the 1.33-1.41 s call; putting it on a high-priority HIP
+            # stream made the call 1.9 s - profiles/r05_g_sampling_parts.txt - so all parts keep default-priority streams)
+            self._part_streams = [torch.cuda.Stream(device=dev) for _ in self.priors]
         n = len(self.priors)
         chains, outs, live = [None] * n, [None] * n, []
         for i, prior in enumerate(self.priors):

@@ -26,6 +26,25 @@ with torch.no_grad():
         print(f"part {i} ({tuple(int(v) for v in shapes[i])}) alone: {timed(lambda: prior.sample_latent(B)):.3f} s", flush=True)
     dp.concurrent_parts = True
     print(f"three streams: {timed(lambda: dp.sample_latents(B)):.3f} s", flush=True)
-    dp._part_streams = None
-    dp.prioritize_longest_chain = True
-    print(f"three streams, longest chain on a high-priority stream: {timed(lambda: dp.sample_latents(B)):.3f} s", flush=True)
+    # the same with every part's stream bound to its own set of CUs (hipExtStreamCreateWithCUMask): does the longest chain lose its time
+    # to the short chains' workgroups sitting on the CUs it wants, or to the dispatch path?
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    def masked_stream(lo, hi):
+        words = (ctypes.c_uint32 * 8)(*[sum(1 << b for b in range(32) if lo <= 32 * w + b < hi) for w in range(8)])
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+        assert rc == 0, rc
+        return torch.cuda.ExternalStream(st.value)
+    for split in ((0, 160, 208, 256), (0, 192, 224, 256), (0, 128, 192, 256)):
+        dp._part_streams = [masked_stream(split[i], split[i + 1]) for i in range(3)]
+        for p_ in dp.priors:                              # the step graphs were captured on the old streams: re-capture
+            for k in [k for k in vars(p_.diffusion) if "graph" in k.lower() and k != "use_graph"]:
+                try:
+                    setattr(p_.diffusion, k, None if not isinstance(getattr(p_.diffusion, k), dict) else {})
+                except Exception:
+                    pass
+        try:
+            print(f"three streams on CU sets {split}: {timed(lambda: dp.sample_latents(B)):.3f} s", flush=True)
+        except Exception as e:
+            print(f"CU sets {split}: failed ({type(e).__name__}: {e})", flush=True)
