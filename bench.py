@@ -70,8 +70,8 @@ def step(flow, prior, u8_d, noise_d, n_bits=5):
     import nfdp_hip as K
     B = u8_d.shape[0]
     xh = K.preprocess_u8(u8_d, noise_d, n_bits)                       # preprocess_batch + rand/n_bins, NHWC out
-    ldj = torch.zeros(B, dtype=torch.float64, device=u8_d.device)     # initialize_with_zeros
-    logp = torch.zeros(B, dtype=torch.float64, device=u8_d.device)
+    acc = torch.zeros(2, B, dtype=torch.float64, device=u8_d.device)  # initialize_with_zeros: both accumulators, one fill
+    ldj, logp = acc[0], acc[1]
     zs = flow.transform_nhwc(xh, ldj, logp)                           # Glow.transform
     prior.accumulate_log_prob_nhwc(zs[-1], logp)                      # logp += prior.compute_log_prob(latents[-1])
     return K.bpd_sum(ldj, logp, 2.0 ** n_bits, 32 * 32 * 3.0)         # calculate_loss (sum, count)

@@ -183,6 +183,26 @@ int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed,
 int nfdp_conv2d_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed, float* y,
                              int y_ld, int B, int H, int W, int Cout, int K, const float* add, int compute, nfdp_stream_t stream);
 
+/* ---------------------------------------------------------------- level boundary / end of the forward pass as single launches */
+/* Split.transform (transforms.py:270-289) + the next block's Squeeze (transforms.py:226) in ONE launch: x [B,H,W,C] (the level buffer
+ * after its flows) -> z [B,H,W,C/2] (the dropped half: the latent part, contiguous), ynext [B,H/2,W/2,2C] (the kept half squeezed: the
+ * next level's buffer, 16-byte aligned) and, when logp != NULL, logp[b] += log N(z_b; mean, exp(logsd)) with (mean | logsd) =
+ * (conv3x3(kept half, w) + bias) * exp(3 logs) (ZeroConv2d, utils.py:43-44; w OIHW [C][C/2][3][3], zero padding; w = NULL: mean = logsd
+ * = 0, learn_prior_mean_logs = False) - fp32 FMA chains in (tap, ci) order, the density terms in prior.py:36's op order, fp64 sum.
+ * Replaces four launches (narrow conv, nfdp_gauss_logp_f32, nfdp_copy_channels_f32, nfdp_squeeze_nhwc_f32).  One workgroup per image
+ * with the kept half in LDS: nfdp_split_prior_squeeze_supported (C/2 in {2,4,6,8,12,24}, even H, W, <= 96 KB of LDS). */
+int nfdp_split_prior_squeeze_supported(int C, int H, int W);
+int nfdp_split_prior_squeeze_f32(const float* x, int B, int H, int W, int C, const float* w, const float* bias, const float* logs, float* z,
+                                 float* ynext, double* logp, nfdp_stream_t stream);
+/* ldj[b] += sum over levels l of hw[l] * float(sum_i v[l][i]) (the weight-only 1x1-conv log-dets of every level, transforms.py:131),
+ * per level the arithmetic of nfdp_ldj_add_scaled_f32, added in level order: bit-identical to `levels` calls of it.  v, n_sum, hw: HOST
+ * arrays of `levels` <= 8 entries (v[l]: device pointers). */
+int nfdp_ldj_add_levels_f32(double* ldj, int B, const float* const* v, const int* n_sum, const float* hw, int levels, nfdp_stream_t stream);
+/* GaussianPrior.compute_log_prob (prior.py:70-83): logp[b] += log N(z_b; mean, exp(logsd)) with the spatially constant (mean | logsd) =
+ * bias * exp(3 logs) of the ZeroConv2d on zeros formed in the kernel (bias, logs: [2*Cz]; NULL: zeros).  z [B,HW,*] pixel stride z_ld. */
+int nfdp_gauss_logp_prior_f32(const float* z, int z_ld, const float* bias, const float* logs, int B, int HW, int Cz, double* logp,
+                              nfdp_stream_t stream);
+
 /* ---------------------------------------------------------------- affine coupling (transforms.py:166-201) */
 /* x: [B,HW,C] flow tensor (x_a = channels [0,C/2), x_b = [C/2,C)); h: NN output [B,HW,C] (log_s | t).
  * fwd (transforms.py:181-184): s = sigmoid(log_s+2); x_b <- (x_b+t)*s in place; ldj[b] += sum log(s+1e-6) (fp64).

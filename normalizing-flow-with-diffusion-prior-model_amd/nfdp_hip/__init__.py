@@ -808,6 +808,45 @@ def ldj_add_scaled(ldj: torch.Tensor, v: torch.Tensor, n_sum: int, hw: float):
     _call("nfdp_ldj_add_scaled_f32", _ptr(ldj), ldj.numel(), _ptr(v), n_sum, float(hw), _stream())
 
 
+def ldj_add_levels(ldj: torch.Tensor, terms) -> None:
+    """ldj[b] += sum_l hw_l * float(sum(v_l)) for terms = [(v_l fp32 [n_l], hw_l), ...] in ONE launch (nfdp_ldj_add_levels_f32:
+    bit-identical to one ldj_add_scaled per level, in order)."""
+    _need(ldj, torch.float64, "ldj_add_levels")
+    n = len(terms)
+    for v, _ in terms:
+        _need(v, torch.float32, "ldj_add_levels"); _dense(v, "ldj_add_levels")
+    _call("nfdp_ldj_add_levels_f32", _ptr(ldj), ldj.numel(), (ctypes.c_void_p * n)(*[_ptr(v) for v, _ in terms]),
+          (ctypes.c_int * n)(*[v.numel() for v, _ in terms]), (ctypes.c_float * n)(*[float(hw) for _, hw in terms]), n, _stream())
+
+
+def split_prior_squeeze_supported(xh: torch.Tensor) -> bool:
+    b, h, w, c = xh.shape
+    return bool(xh.is_cuda and xh.dtype == torch.float32 and xh.is_contiguous()
+                and lib().nfdp_split_prior_squeeze_supported(c, h, w))
+
+
+def split_prior_squeeze(xh: torch.Tensor, weight, bias, logs, logp: Optional[torch.Tensor]):
+    """Split.transform + the next Squeeze in one launch (nfdp_split_prior_squeeze_f32): xh [B,H,W,C] contiguous ->
+    (z [B,H,W,C/2], ynext [B,H/2,W/2,2C]); logp (fp64 [B] or None) += the prior's log-density of z.  weight None: zero mean / log-sd."""
+    _need(xh, torch.float32, "split_prior_squeeze"); _dense(xh, "split_prior_squeeze")
+    b, h, w, c = xh.shape
+    if logp is not None:
+        _need(logp, torch.float64, "split_prior_squeeze")
+    z = torch.empty((b, h, w, c // 2), device=xh.device, dtype=torch.float32)
+    yn = torch.empty((b, h // 2, w // 2, 2 * c), device=xh.device, dtype=torch.float32)
+    _call("nfdp_split_prior_squeeze_f32", _ptr(xh), b, h, w, c, _ptr(weight), _ptr(bias), _ptr(logs), _ptr(z), _ptr(yn), _ptr(logp),
+          _stream(), label=f"split_prior_squeeze {c} hw{h}", flops=2.0 * b * h * w * 9 * (c // 2) * c, nbytes=float(b * h * w) * c * 8)
+    return z, yn
+
+
+def gauss_logp_prior(zh: torch.Tensor, bias, logs, logp: torch.Tensor) -> None:
+    """logp[b] += log N(z_b) under GaussianPrior's spatially constant (mean | log-sd) = bias * exp(3 logs) (nfdp_gauss_logp_prior_f32)."""
+    _need(logp, torch.float64, "gauss_logp_prior")
+    b, hh, ww, cz = zh.shape
+    _call("nfdp_gauss_logp_prior_f32", _ptr(zh), _ld(zh, "gauss_logp_prior"), _ptr(bias), _ptr(logs), b, hh * ww, cz, _ptr(logp), _stream(),
+          label="gauss_logp_prior")
+
+
 def flow_ldj_consts(scale: torch.Tensor, logabsdet: torch.Tensor, hw: float) -> torch.Tensor:
     out = torch.empty(2, device=scale.device, dtype=torch.float32)
     _call("nfdp_flow_ldj_consts_f32", _ptr(scale), scale.numel(), _ptr(logabsdet), float(hw), _ptr(out), _stream())

@@ -107,6 +107,10 @@ CACHE_WEIGHT_TERMS = True
 # more than they take on their own.  Off.
 PRIORS_ON_SIDE_STREAM = False
 LOGDETS_ON_SIDE_STREAM = True      # Glow.transform_nhwc of 4- and 5-level models: the 1x1-conv log-dets on a side stream (see there)
+# Glow.transform_nhwc: Split (prior conv + log-density + the latent's copy) and the next level's Squeeze as ONE launch per level boundary
+# (csrc/boundary.hip) where the image fits a workgroup's LDS, and the levels' weight-only log-det terms added by one launch: 22 -> 13
+# launches per forward + NLL step of a 3-level model.  False: the per-op launches (tests compare the two).
+FUSED_LEVEL_BOUNDARY = True
 
 
 def set_weight_term_cache(on: bool) -> None:
@@ -293,9 +297,18 @@ class GlowBlock(Transform):
         self.split = Split(flow_channels, learn_prior_mean_logs=learn_prior_mean_logs, compute=compute)
 
     def transform_nhwc(self, xh: Tensor, ldj: Optional[Tensor], logp: Optional[Tensor], lads: Optional[Tensor] = None,
-                       defer_logdet: bool = False, prior_stream=None):
-        yh = K.squeeze(xh)                       # fresh level buffer; flows then run in place
+                       defer_logdet: bool = False, prior_stream=None, squeezed_in: bool = False, squeeze_out: bool = False):
+        """-> (kept half, z).  squeezed_in: xh is already this level's squeezed buffer (the previous block's fused boundary wrote it);
+        squeeze_out: where the geometry allows, Split + the NEXT block's Squeeze run as one launch (K.split_prior_squeeze) and the
+        call returns (next level's squeezed buffer, z, True) - else (kept-half view, z, False)."""
+        yh = xh if squeezed_in else K.squeeze(xh)    # fresh level buffer; flows then run in place
         yh = _run_flows_fwd(self.flows, yh, ldj, lads, defer_logdet)
+        if squeeze_out:
+            if FUSED_LEVEL_BOUNDARY and prior_stream is None and K.split_prior_squeeze_supported(yh):
+                z, ynext = self.split.transform_squeeze_nhwc(yh, logp)
+                return ynext, z, True
+            yv, z = self.split.transform_nhwc(yh, logp, side=prior_stream)
+            return yv, z, False
         yv, z = self.split.transform_nhwc(yh, logp, side=prior_stream)
         return yv, z
 
@@ -376,11 +389,14 @@ class Glow(Transform):
             if PRIORS_ON_SIDE_STREAM and logp is not None and xh.is_cuda and _graphs.side_branch_allowed(xh.device):
                 pstream = _side_stream(xh.device) if br.side is None else br.side
             try:
+                squeezed = False
                 for i, block in enumerate(self.blocks):
-                    yh, z = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True, prior_stream=pstream)
+                    yh, z, squeezed = block.transform_nhwc(yh, ldj, logp, None, defer_logdet=True, prior_stream=pstream,
+                                                           squeezed_in=squeezed, squeeze_out=True)
                     hws.append(z.shape[1] * z.shape[2])
                     zs.append(z)
-                yh = K.squeeze(yh)
+                if not squeezed:
+                    yh = K.squeeze(yh)
                 hws.append(yh.shape[1] * yh.shape[2])
                 yh = _run_flows_fwd(self.final_flows, yh, ldj, None, defer_logdet=True)
                 zs.append(yh)
@@ -389,8 +405,11 @@ class Glow(Transform):
                     torch.cuda.current_stream(xh.device).wait_stream(pstream)
             if ldj is not None:
                 br.join(lads)
-                for lad, hw in zip(lads, hws):
-                    K.ldj_add_scaled(ldj, lad, lad.numel(), hw)
+                if FUSED_LEVEL_BOUNDARY and len(lads) <= 8:
+                    K.ldj_add_levels(ldj, list(zip(lads, hws)))
+                else:
+                    for lad, hw in zip(lads, hws):
+                        K.ldj_add_scaled(ldj, lad, lad.numel(), hw)
         return zs
 
     def transform(self, x: Tensor, log_det_jac: Tensor, logp: Tensor) -> Tuple[list, Tensor, Tensor]:

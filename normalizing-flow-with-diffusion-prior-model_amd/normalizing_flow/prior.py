@@ -61,8 +61,9 @@ class GaussianPrior(Prior):
         return K.zeroconv_bias_only(self.__conv.bias, self.__conv.logs.view(-1))
 
     def accumulate_log_prob_nhwc(self, zh: Tensor, logp: Tensor) -> None:
-        """logp[b] += log N(z_b)   (fp64, in place)."""
-        K.gauss_logp(zh, self._h(zh.device), 1, logp)
+        """logp[b] += log N(z_b)   (fp64, in place); one launch: the ZeroConv2d-on-zeros vector bias * exp(3 logs) is formed in it."""
+        cv = self.__conv
+        K.gauss_logp_prior(zh, None if cv is None else cv.bias, None if cv is None else cv.logs.view(-1), logp)
 
     @property
     def conv(self):

@@ -294,6 +294,13 @@ class Split(Transform):
         K.copy_channels(zv, z)
         return yv, z
 
+    def transform_squeeze_nhwc(self, xh: Tensor, logp: Optional[Tensor]):
+        """Split.transform + the NEXT block's Squeeze in one launch (K.split_prior_squeeze; check K.split_prior_squeeze_supported
+        first): -> (z contiguous, the kept half squeezed = the next level's buffer); logp updated in place (skipped when None)."""
+        cv = self.conv
+        return K.split_prior_squeeze(xh, None if cv is None else cv.weight, None if cv is None else cv.bias,
+                                     None if cv is None else cv.logs.view(-1), logp)
+
     def invert_nhwc(self, yh: Tensor, zh: Optional[Tensor], temperature: float = 1.0, eps: Optional[Tensor] = None) -> Tensor:
         b, h, w, c = yh.shape
         out = torch.empty((b, h, w, 2 * c), device=yh.device, dtype=torch.float32)

@@ -538,3 +538,39 @@ def test_reference_written_checkpoint_reproduces_the_reference_outputs():
     assert_close(logp, g["logp"], TOL, "logp")
     assert_close(calculate_loss(ldj + logp, 32.0, meta["size"] ** 2 * 3.0), g["bpd"], TOL, "bits/dim")
     assert_close(flow.invert(zs), g["x_rec"], 1e-3, "inverse")
+
+
+@pytest.mark.parametrize("compute", ["f32", "bf16"])
+@pytest.mark.parametrize("c,L,size,b", [(3, 3, 32, 5), (1, 3, 32, 4), (3, 4, 64, 2), (1, 2, 16, 3)])
+@torch.no_grad()
+def test_fused_level_boundary_against_the_per_op_launches(compute, c, L, size, b):
+    """glow.FUSED_LEVEL_BOUNDARY: Split (prior conv + log-density + latent copy) + the next Squeeze as one launch per boundary
+    (csrc/boundary.hip: fp32 FMA chains for the narrow prior conv) and the levels' weight-only log-det terms in one launch, against
+    the per-op launches: latents and log-det bit-identical (copies / the same fp64 adds), logp equal to the accuracy of the per-op
+    path's prior conv (fp32 mode: 1e-6; bf16 mode: that conv runs on bf16 operands there), and both against the oracle."""
+    from normalizing_flow import Glow, GaussianPrior, glow as G
+    flow = Glow(in_channel=c, L=L, K=2, compute=compute).to(DEV)
+    prior = GaussianPrior(2 ** (L + 1) * c).to(DEV)
+    flow.load_state_dict({k: T(synth_tensor(k, v.shape, 13, DEEP)) for k, v in flow.state_dict().items()})
+    prior.load_state_dict({k: T(synth_tensor(k, v.shape, 14, DEEP)) for k, v in prior.state_dict().items()})
+    x = (torch.rand(b, c, size, size, generator=torch.Generator().manual_seed(7 * c + L)) - 0.5).to(DEV)
+    out = {}
+    assert G.FUSED_LEVEL_BOUNDARY
+    try:
+        for fused in (True, False):
+            G.FUSED_LEVEL_BOUNDARY = fused
+            K.start_trace()
+            ldj, logp = z64(b), z64(b)
+            zs, _, _ = flow.transform(x, ldj, logp)
+            prior.accumulate_log_prob_nhwc(K.to_nhwc(zs[-1]), logp)
+            out[fused] = (zs, ldj, logp, len(K.stop_trace()))
+    finally:
+        G.FUSED_LEVEL_BOUNDARY = True
+    (zf, lf, pf, nf), (zu, lu, pu, nu) = out[True], out[False]
+    assert all(torch.equal(a, b_) for a, b_ in zip(zf, zu)) and torch.equal(lf, lu)
+    assert_close(pf, pu, 1e-6 if compute == "f32" else 2e-4, "logp, fused boundary vs per-op launches")
+    sd = {k: v.detach().cpu() for k, v in flow.state_dict().items()}
+    psd = {k: v.detach().cpu() for k, v in prior.state_dict().items()}
+    _, ldj_o, logp_o, _ = O.fwd_nll(x.cpu(), sd, psd, L, 2)
+    assert_close(pf, logp_o, TOL if compute == "f32" else 2e-3, "logp vs oracle")
+    assert_close(lf, ldj_o, TOL if compute == "f32" else 2e-2, "ldj vs oracle")
