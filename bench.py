@@ -672,6 +672,45 @@ def other_config_legs(args, device):
             legs["celeba"] = {"error": f"{type(e).__name__}: {e}"}
             log(f"leg celeba failed: {legs['celeba']['error']}")
         torch.cuda.empty_cache()
+        # ---- configs[4], second half: the diffusion prior's U-Net eps-step on the five CelebA latent parts (B = 32)
+        try:
+            from diffusion_prior import DiffusionPrior, IdentityFormater
+            Bc, Ts = 32, 50
+            fmt = IdentityFormater(5, 3, 128)
+            shapes = fmt.get_input_shapes()
+            dp = DiffusionPrior(latent_formater=fmt, unet_kwargs=dict(dim=64, dim_mults=(1, 2, 2), resnet_block_groups=16),
+                                diffusion_kwargs=dict(timesteps=Ts, sampling_timesteps=Ts, loss_type="l2", beta_schedule="cosine"),
+                                image_sizes=[int(sh[1]) for sh in shapes], latent_channels=[int(sh[0]) for sh in shapes])
+            per_part = []
+            for pr in dp.priors:                                  # each part's reverse chain alone (Ts steps, captured step graph)
+                pr.sample_latent(Bc)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                pr.sample_latent(Bc)
+                torch.cuda.synchronize()
+                per_part.append((time.perf_counter() - t0) / Ts)
+            dp.concurrent_parts = True
+            dp.sample_latents(Bc)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            zs = dp.sample_latents(Bc)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / Ts
+            if isinstance(legs.get("celeba"), dict) and "error" not in legs["celeba"]:
+                legs["celeba"]["unet_eps_step"] = {
+                    "ms_per_reverse_step_all_parts": round(dt * 1e3, 3), "ms_per_part_alone": [round(t * 1e3, 3) for t in per_part],
+                    "parts": [[int(v) for v in sh] for sh in shapes], "batch": Bc, "steps_timed": Ts, "dtype": "f32",
+                    "finite": bool(all(torch.isfinite(z).all() for z in zs)),
+                    "workload": "one p_sample step (U-Net eps-prediction + posterior update) of each of the 5 CelebA latent parts, U-Net dim 64 "
+                                "mults [1,2,2] groups 16, batch 32; all parts on one stream each (captured step graphs) / each part alone "
+                                "(BASELINE configs[4]; gaussian_diffusion.py:451-490, :706-733)"}
+                log(f"leg celeba U-Net eps-step: {round(dt * 1e3, 3)} ms for the 5 parts together; alone {[round(t * 1e3, 2) for t in per_part]}")
+            del dp, zs
+        except Exception as e:                                   # noqa: BLE001
+            if isinstance(legs.get("celeba"), dict):
+                legs["celeba"]["unet_eps_step"] = {"error": f"{type(e).__name__}: {e}"}
+            log(f"leg celeba U-Net eps-step failed: {type(e).__name__}: {e}")
+        torch.cuda.empty_cache()
         # ---- configs[3]: the diffusion-prior sampling loop
         try:
             from diffusion_prior import DiffusionPrior, IdentityFormater

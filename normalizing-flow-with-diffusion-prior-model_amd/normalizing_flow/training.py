@@ -677,6 +677,14 @@ WGRAD_ONE_LAUNCH = os.environ.get("NFDP_WGRAD_ONE_LAUNCH", "1") != "0"
 # level (or, for the last node of the pass, by an engine callback before backward() returns).  Levels with more pixels per flow than
 # this keep the per-flow launches (their operands are 0.3 GB per flow, and one flow fills the chip).
 WGRAD_BATCH_MAX_PIXELS = int(os.environ.get("NFDP_WGRAD_BATCH_MAX_PIXELS", str(64 * 512)))
+# Memory: the kept operands are 82 MB per 8x8 flow of a B = 512 step (21 MB at 4x4).  A level's flows are therefore sent in groups of
+# WGRAD_BATCH_FLOWS (the previous group joined first, which releases its operands: 0.65 GB at a time at the 8x8 level); a level of at most
+# WGRAD_BATCH_OVERLAP_PIXELS pixels per flow leaves its last group running beside the next node's chain (smaller values join it at the end
+# of its node, so nothing of it is alive when the next level allocates).  Measured, B = 512 L3 K16 (profiles/r05_m_wgrad_batch_sweep.txt):
+# groups of 8 + overlap 12.56 ms at 7.67 GiB peak; groups of 8 joined at the node's end 13.01 ms at 7.67; groups of 4 13.16 ms at 7.22;
+# groups of 2 15.5 ms at 7.07; per-flow launches (round 4) 13.36 ms at 6.84 GiB.
+WGRAD_BATCH_FLOWS = int(os.environ.get("NFDP_WGRAD_BATCH_FLOWS", "8"))
+WGRAD_BATCH_OVERLAP_PIXELS = int(os.environ.get("NFDP_WGRAD_BATCH_OVERLAP_PIXELS", str(64 * 512)))
 
 
 def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net, packed=None, batch=None):
@@ -816,6 +824,7 @@ class LevelFusedFn(Function):
 
         def flush_batch():
             if batch:
+                _join_side()                                   # the previous group (or level) is through: its operands are released
                 prs = list(batch)
                 batch.clear()
                 _defer_side(lambda: K.coupling_wgrad3_batch(prs, True), *[t for fl in prs for pr in fl for t in (pr["x"], pr["dy"])])
@@ -853,6 +862,8 @@ class LevelFusedFn(Function):
             _flush_side()                                            # one fork per flow: the coupling network's weight gradients
             if batch is None and SIDE_JOIN_EVERY and (n - i) % SIDE_JOIN_EVERY == 0 and i > 0:
                 _join_side()
+            if batch is not None and len(batch) >= WGRAD_BATCH_FLOWS:
+                flush_batch()
             if g9 is not None:
                 grads[P * i + 3: P * i + 10] = list(g9)
             dx = dx_next
@@ -883,7 +894,7 @@ class LevelFusedFn(Function):
                     grads[P * hf + 2] = o[4].view_as(tup[4])
                 if cf >= 0:
                     grads[P * cf + 11], grads[P * cf + 10] = o[2].view_as(tup[2]), o[3].view_as(tup[3])
-        if batch is None or any(g is not None for g in grads):
+        if batch is None or any(g is not None for g in grads) or npix > WGRAD_BATCH_OVERLAP_PIXELS:
             _join_side()
         else:
             # the level's one weight-gradient launch keeps running beside the next node's chain; whoever joins the side stream next (a

@@ -574,3 +574,69 @@ def test_fused_level_boundary_against_the_per_op_launches(compute, c, L, size, b
     _, ldj_o, logp_o, _ = O.fwd_nll(x.cpu(), sd, psd, L, 2)
     assert_close(pf, logp_o, TOL if compute == "f32" else 2e-3, "logp vs oracle")
     assert_close(lf, ldj_o, TOL if compute == "f32" else 2e-2, "ldj vs oracle")
+
+
+@torch.no_grad()
+def test_config4_full_size_properties():
+    """BASELINE configs[4] at its full size - Glow L = 5, K = 16 on 128x128x3, batch 32 (the shape `legs.celeba` times: 16-flow launches
+    of the wide levels, tiled coupling networks with the flow head in the tap pass, side-stream log-dets / inverses, nfdp_invconv_
+    inverses, row-split tiles at 8192 pixels): bf16 bits/dim within 1e-4 (relative) of the fp32-mode path; the first two images
+    against the CPU oracle (fp32 mode: 1e-4 on bits/dim, log-det, log-prob; bf16 mode: latents at bf16 accuracy); inverse round trip;
+    batch-slicing invariance (to rounding: kernel forms follow the pixel count); bitwise run-to-run determinism; finite sampling inverse."""
+    from normalizing_flow import Glow, GaussianPrior
+    import numpy as np
+    B, S = 32, 128
+    sdf = None
+    res = {}
+    x_np, _, _ = images_5bit("celeba_full", (B, 3, S, S), 4)
+    x = T(x_np).to(DEV)
+    for compute in ("f32", "bf16"):
+        flow = Glow(in_channel=3, L=5, K=16, compute=compute)
+        prior = GaussianPrior(192)
+        flow.load_state_dict({k: T(synth_tensor(k, v.shape, 1, DEEP)) for k, v in flow.state_dict().items()}, strict=True)
+        prior.load_state_dict({k: T(synth_tensor(k, v.shape, 2, DEEP)) for k, v in prior.state_dict().items()}, strict=True)
+        if sdf is None:
+            sdf = ({k: v.detach().clone() for k, v in flow.state_dict().items()}, {k: v.detach().clone() for k, v in prior.state_dict().items()})
+        flow.to(DEV); prior.to(DEV)
+
+        def run(xb):
+            ldj, logp = z64(xb.shape[0]), z64(xb.shape[0])
+            zs, _, _ = flow.transform(xb, ldj, logp)
+            logp = logp + prior.compute_log_prob(zs[-1])
+            return zs, ldj, logp
+        zs, ldj, logp = run(x)
+        bpd = (-(ldj + logp) / (np.log(2.0) * S * S * 3) + 5.0)
+        assert [tuple(z.shape[1:]) for z in zs] == [(6, 64, 64), (12, 32, 32), (24, 16, 16), (48, 8, 8), (192, 4, 4)]
+        assert all(bool(torch.isfinite(z).all()) for z in zs) and bool(torch.isfinite(bpd).all())
+        zs2, ldj2, logp2 = run(x)                                         # determinism
+        assert all(torch.equal(a, b_) for a, b_ in zip(zs, zs2)) and torch.equal(ldj, ldj2) and torch.equal(logp, logp2)
+        # a slice of the batch gives the slice of the result - to rounding, not bitwise: the kernel FORM follows the pixel count (3 images:
+        # row-split tiles / one-wave fp32 tiles where 32 images take the 128-pixel / 16x16x32 forms; same operands, another fp32
+        # summation order, and in bf16 mode the odd flipped rounding of a hidden activation)
+        zs3, ldj3, logp3 = run(x[5:8])
+        for i, (a, b_) in enumerate(zip(zs, zs3)):
+            assert_close(b_, a[5:8], 2e-5 if compute == "f32" else 6e-2, f"{compute} z{i} of a batch slice")
+        assert_close(ldj3, ldj[5:8], 1e-6 if compute == "f32" else 2e-3, f"{compute} log-det of a batch slice")
+        assert_close(logp3, logp[5:8], 1e-6 if compute == "f32" else 2e-3, f"{compute} log-prob of a batch slice")
+        rt = flow.invert(zs)
+        assert_close(rt, x, 2e-3 if compute == "f32" else 0.15, f"{compute} round trip")      # (bf16 operands through 2 x 80 flows)
+        record(f"config4_{compute}_round_trip", relerr_elem(rt, x))
+        smp = flow.invert(zs[-1:], temperature=0.7)
+        assert smp.shape == x.shape and bool(torch.isfinite(smp).all())
+        res[compute] = (zs, ldj, logp, bpd)
+        record(f"config4_{compute}_bpd_mean", float(bpd.mean()))
+        del flow, prior
+        torch.cuda.empty_cache()
+    rel = float((res["bf16"][3].mean() - res["f32"][3].mean()).abs() / res["f32"][3].mean().abs())
+    record("config4_bf16_bpd_vs_f32_mode", rel)
+    assert rel < 1e-4, rel
+    zo, ldj_o, logp_o, _ = O.fwd_nll(T(x_np[:2]), sdf[0], sdf[1], 5, 16)
+    bpd_o = (-(ldj_o + logp_o) / (np.log(2.0) * S * S * 3) + 5.0)
+    assert_close(res["f32"][3][:2], bpd_o, TOL, "fp32-mode bits/dim vs oracle")
+    assert_close(res["f32"][1][:2], ldj_o, TOL, "fp32-mode log-det vs oracle")
+    assert_close(res["f32"][2][:2], logp_o, TOL, "fp32-mode log-prob vs oracle")
+    assert_close(res["bf16"][3][:2], bpd_o, TOL, "bf16 bits/dim vs oracle")
+    for i, (a, b_) in enumerate(zip(res["f32"][0], zo)):
+        assert_close(a[:2], b_, 2e-4, f"fp32-mode z{i} vs oracle")
+    for i, (a, b_) in enumerate(zip(res["bf16"][0], zo)):
+        assert_close(a[:2], b_, 6e-2, f"bf16 z{i} vs oracle")
