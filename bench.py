@@ -777,7 +777,8 @@ def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(PKG, "csrc")
-    for f in ("coupling_fused_impl.inc", "coupling_fused_v.hip", "coupling_fused_a.hip"):
+    for f in ("coupling_fused_impl.inc", "fused_pack.inc", "fused_helpers.inc", "fused_wave_tile.inc", "fused_tiled_mlp.inc", "fused_rs4x4.inc",
+              "fused_rs8x8.inc", "fused_wide.inc", "fused_entry.inc", "coupling_fused_v.hip", "coupling_fused_a.hip"):
         try:
             h.update(open(os.path.join(csrc, f), "rb").read())
         except OSError:
