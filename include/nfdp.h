@@ -314,10 +314,16 @@ int nfdp_level_fused_train_bf16(float* x, int B, int H, int W, int C, int n_flow
                                 float* xpre, float* ypost, float* hout, void* y1, void* y2, void* xcol, nfdp_stream_t stream);
 /* The same with keep_hidden = 0: all flows write y1 / y2 / xcol into ONE flow-sized slot (the buffers are one flow large) - the forward
  * of a step that recomputes the hidden activations in its backward pass (normalizing_flow.training.RECOMPUTE_FLOWS: per group of flows
- * the launch is repeated from the group's saved input state xpre[first flow] with keep_hidden = 1). */
+ * the launch is repeated from the group's saved input state xpre[first flow] with keep_hidden = 1).
+ * masks (nullable; levels with nfdp_level_fused_train_has_masks: the 16x16 / 8x8 ones): the ReLU SIGNS of y1 / y2 for the reverse network,
+ * which needs the activations for nothing else - [n_flows][2 layers][Bpad*H*W / 32 tiles][16 hidden blocks][64 lanes] dwords (16 bits per
+ * lane and block, in the order of the blocked layout's fragments), 1/8 of the activations' bytes; pass it to nfdp_coupling_bwd_fused_bf16
+ * flow by flow (flow i at masks + i * 2 * Bpad*H*W * 128 bytes) in place of y1 / y2. */
+int nfdp_level_fused_train_has_masks(int H, int W, int C);
 int nfdp_level_fused_train_ex_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
                                 const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
-                                float* xpre, float* ypost, float* hout, void* y1, void* y2, void* xcol, int keep_hidden, nfdp_stream_t stream);
+                                float* xpre, float* ypost, float* hout, void* y1, void* y2, void* xcol, void* masks, int keep_hidden,
+                                nfdp_stream_t stream);
 /* Backward of the coupling network's data path in one launch (autograd of utils.py:83-89 w.r.t. its input, training step
  * normalizing_flow/trainer.py:164): dc3 [B][H*W][C] fp32 = gradient at the ZeroConv2d's raw conv output (after its scale backward);
  * y1, y2 = the hidden activations saved by nfdp_level_fused_train_bf16 (blocked layout, Bpad images).  Writes dc2, dc1 (same layout as
@@ -334,8 +340,10 @@ int nfdp_coupling_fused_pack_batch(const float* const* params, void* const* pack
 int nfdp_coupling_bwd_fused_pack_batch(const float* const* params, void* const* packed, int n, int C, nfdp_stream_t stream);
 int nfdp_coupling_bwd_fused_pack(const float* w1, const float* scale1, const float* w2, const float* scale2, const float* w3,
                                  void* packed, int C, nfdp_stream_t stream);
+/* masks (nullable): this flow's slice of nfdp_level_fused_train_ex_bf16's mask tensor; when given the kernel reads it INSTEAD of y1 / y2
+ * (which may then be NULL) - the same result bit for bit at 1/8 of the saved-activation bytes. */
 int nfdp_coupling_bwd_fused_bf16(const float* dc3, float* dx, const void* packed, const void* y1, const void* y2, void* dc1,
-                                 void* dc2, void* dc3col, int B, int H, int W, int C, nfdp_stream_t stream);
+                                 void* dc2, void* dc3col, const void* masks, int B, int H, int W, int C, nfdp_stream_t stream);
 /* The per-pixel link between two flow steps of the backward pass, in one launch: the flow head of step i backwards (1x1 conv
  * transforms.py:132, ActNorm :80) and the affine coupling of step i-1 backwards (transforms.py:179-185) with the scale backward of its
  * ZeroConv2d (utils.py:43-44).  All tensors [npix][C] fp32 rows.

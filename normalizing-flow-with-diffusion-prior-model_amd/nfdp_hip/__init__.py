@@ -723,13 +723,19 @@ def level_fused(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torc
           nbytes=8.0 * xh.numel())
 
 
-def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torch.Tensor], keep_hidden: bool = True):
+TRAIN_RELU_MASKS = True      # the training forward also writes the hidden activations' ReLU masks (1/8 of their bytes) for the reverse network
+
+
+def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torch.Tensor], keep_hidden: bool = True,
+                      want_masks: bool = False):
     """Training forward of a whole Glow level in ONE persistent launch (nfdp_level_fused_train_bf16): xh [B,H,W,C] is updated in
     place; ldj[b] += the flows' per-sample coupling log-dets only.  -> (xpre, ypost, hout [n,B,H,W,C] fp32; y1, y2
     [n,Bpad,H,W,512] bf16; xcol [n,Bpad,H,W,cols] bf16): per flow the tile before / after the flow head, the zero conv's output, the
     two hidden activations - y1 / y2 in the fused kernels' BLOCKED layout (blocked_to_rows), not [pixel][512] rows - and the im2col
     rows of the coupling network's input.  keep_hidden=False: y1 / y2 / xcol are one flow large and every flow overwrites them (returned as
-    None): the forward of a step that recomputes them in its backward pass."""
+    None): the forward of a step that recomputes them in its backward pass.
+    want_masks: a seventh result - the ReLU masks of y1 / y2 ([n, 2, Bpad*H*W*32] int32; None where the level's kernels have none, or with
+    keep_hidden=False): what coupling_bwd_fused reads instead of the activations."""
     _need(xh, torch.float32, "level_fused_train"); _dense(xh, "level_fused_train")
     b, h, wd, c = xh.shape
     n = len(packed)
@@ -749,16 +755,19 @@ def level_fused_train(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optiona
     y1 = torch.empty((nh, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
     y2 = torch.empty((nh, bpad, h, wd, 512), device=dev, dtype=torch.bfloat16)
     xcol = torch.empty((nh, bpad, h, wd, lib().nfdp_coupling_fused_im2col_cols(c, 0)), device=dev, dtype=torch.bfloat16)
+    masks = None
+    if want_masks and keep_hidden and TRAIN_RELU_MASKS and lib().nfdp_level_fused_train_has_masks(h, wd, c):
+        masks = torch.empty((n, 2, bpad * h * wd * 32), device=dev, dtype=torch.int32)
     tab = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
     ch = c // 2
     flops = n * 2.0 * b * h * wd * (9 * ch * 512 + 512 * 512 + 9 * 512 * c + c * c)
     _call("nfdp_level_fused_train_ex_bf16", _ptr(xh), b, h, wd, c, n, tab(packed), tab(scales), tab(biases), tab(ws), _ptr(ldj),
-          _ptr(xpre), _ptr(ypost), _ptr(hout), _ptr(y1), _ptr(y2), _ptr(xcol), int(keep_hidden), _stream(),
+          _ptr(xpre), _ptr(ypost), _ptr(hout), _ptr(y1), _ptr(y2), _ptr(xcol), _ptr(masks), int(keep_hidden), _stream(),
           label=f"level_fused_train<{c},{wd}> x{n}", flops=flops,
           nbytes=8.0 * xh.numel() + 12.0 * n * xh.numel() + 2048.0 * n * bpad * h * wd)
     if not keep_hidden:
-        return xpre, ypost, hout, None, None, None
-    return xpre, ypost, hout, y1, y2, xcol
+        return (xpre, ypost, hout, None, None, None) + ((None,) if want_masks else ())
+    return (xpre, ypost, hout, y1, y2, xcol) + ((masks,) if want_masks else ())
 
 
 def coupling_bwd_fused_supported(h: int, w: int, c: int, n_features: int) -> bool:
@@ -779,27 +788,37 @@ def coupling_bwd_fused_pack(w1, s1, w2, s2, w3, out: Optional[torch.Tensor] = No
     return packed
 
 
-def coupling_bwd_fused(dc3: torch.Tensor, dx: torch.Tensor, packed: torch.Tensor, y1: torch.Tensor, y2: torch.Tensor):
+def coupling_bwd_fused(dc3: torch.Tensor, dx: torch.Tensor, packed: torch.Tensor, y1: torch.Tensor, y2: torch.Tensor,
+                       masks: Optional[torch.Tensor] = None):
     """The coupling network's data-gradient chain in one launch (nfdp_coupling_bwd_fused_bf16).  dc3 [B,H,W,C] fp32 (gradient at the
     zero conv's raw output); y1, y2 [Bpad,H,W,512] bf16 as saved by level_fused_train (BLOCKED layout, Bpad >= B: whole workgroups);
     dx [B,H,W,C] fp32: its first C/2 channels receive += the network's input gradient.  -> (dc1, dc2: shaped and laid out like y1;
-    dc3col [Bpad,H,W,cols] bf16: im2col rows of dc3, ordinary rows)."""
+    dc3col [Bpad,H,W,cols] bf16: im2col rows of dc3, ordinary rows).
+    masks: this flow's [2, Bpad*H*W*32] int32 slice of level_fused_train's mask tensor - read instead of y1 / y2 (same bits out)."""
     _need(dc3, torch.float32, "coupling_bwd_fused"); _dense(dc3, "coupling_bwd_fused")
     _need(dx, torch.float32, "coupling_bwd_fused dx"); _dense(dx, "coupling_bwd_fused dx")
-    _need(y1, torch.bfloat16, "coupling_bwd_fused y1"); _dense(y1, "coupling_bwd_fused y1")
-    _need(y2, torch.bfloat16, "coupling_bwd_fused y2"); _dense(y2, "coupling_bwd_fused y2")
     b, h, w, c = dc3.shape
     grp = lib().nfdp_level_fused_train_group(h, w, c)
     bpad = (b + grp - 1) // grp * grp if grp > 0 else b
-    if tuple(dx.shape) != (b, h, w, c) or tuple(y1.shape) != (bpad, h, w, 512) or tuple(y2.shape) != (bpad, h, w, 512):
-        raise ValueError(f"coupling_bwd_fused: shapes dc3 {tuple(dc3.shape)} dx {tuple(dx.shape)} y1 {tuple(y1.shape)} y2 {tuple(y2.shape)}")
-    dc1 = torch.empty_like(y1)
-    dc2 = torch.empty_like(y2)
+    if masks is None or y1 is not None or y2 is not None:
+        _need(y1, torch.bfloat16, "coupling_bwd_fused y1"); _dense(y1, "coupling_bwd_fused y1")
+        _need(y2, torch.bfloat16, "coupling_bwd_fused y2"); _dense(y2, "coupling_bwd_fused y2")
+        if tuple(y1.shape) != (bpad, h, w, 512) or tuple(y2.shape) != (bpad, h, w, 512):
+            raise ValueError(f"coupling_bwd_fused: shapes dc3 {tuple(dc3.shape)} y1 {tuple(y1.shape)} y2 {tuple(y2.shape)}")
+    if tuple(dx.shape) != (b, h, w, c):
+        raise ValueError(f"coupling_bwd_fused: shapes dc3 {tuple(dc3.shape)} dx {tuple(dx.shape)}")
+    dc1 = torch.empty((bpad, h, w, 512), device=dc3.device, dtype=torch.bfloat16)
+    dc2 = torch.empty((bpad, h, w, 512), device=dc3.device, dtype=torch.bfloat16)
     dc3col = torch.empty((bpad, h, w, lib().nfdp_coupling_fused_im2col_cols(c, 1)), device=dc3.device, dtype=torch.bfloat16)
     ch = c // 2
     flops = 2.0 * b * h * w * (9 * c * 512 + 512 * 512 + 9 * 512 * ch)
-    _call("nfdp_coupling_bwd_fused_bf16", _ptr(dc3), _ptr(dx), _ptr(packed), _ptr(y1), _ptr(y2), _ptr(dc1), _ptr(dc2), _ptr(dc3col), b, h,
-          w, c, _stream(), label=f"coupling_bwd_fused<{c},{w}>", flops=flops, nbytes=4096.0 * bpad * h * w)
+    if masks is not None:
+        _need(masks, torch.int32, "coupling_bwd_fused masks"); _dense(masks, "coupling_bwd_fused masks")
+        if tuple(masks.shape) != (2, bpad * h * w * 32):
+            raise ValueError(f"coupling_bwd_fused: masks {tuple(masks.shape)}, expected {(2, bpad * h * w * 32)}")
+    _call("nfdp_coupling_bwd_fused_bf16", _ptr(dc3), _ptr(dx), _ptr(packed), _ptr(y1), _ptr(y2), _ptr(dc1), _ptr(dc2), _ptr(dc3col),
+          _ptr(masks), b, h, w, c, _stream(), label=f"coupling_bwd_fused<{c},{w}>{' masks' if masks is not None else ''}", flops=flops,
+          nbytes=(2048.0 + (256.0 if masks is not None else 2048.0)) * bpad * h * w)
     return dc1, dc2, dc3col
 
 

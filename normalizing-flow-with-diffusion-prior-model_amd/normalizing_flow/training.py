@@ -687,7 +687,7 @@ WGRAD_BATCH_FLOWS = int(os.environ.get("NFDP_WGRAD_BATCH_FLOWS", "8"))
 WGRAD_BATCH_OVERLAP_PIXELS = int(os.environ.get("NFDP_WGRAD_BATCH_OVERLAP_PIXELS", str(64 * 512)))
 
 
-def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net, packed=None, batch=None):
+def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net, packed=None, batch=None, masks=None):
     """Backward of one coupling network on the fused kernels, from the gradient dc3 at the zero conv's raw output (the link kernel has
     applied its scale backward).  dx [B,H,W,C]: the coupling's input gradient, whose first half receives += the network's input
     gradient; xcol: saved im2col rows of the network's input; y1, y2: saved hidden activations (blocked layout, [Bpad,H,W,512] bf16).
@@ -705,7 +705,7 @@ def _net_backward_fused(dc3, dx, xcol, y1, y2, params, net, packed=None, batch=N
                                            out=getattr(net, "_fused_bwd", None) if net is not None else None)
         if net is not None:
             object.__setattr__(net, "_fused_bwd", packed)
-    dc1, dc2, dc3_col = K.coupling_bwd_fused(dc3, dx, packed, y1, y2)
+    dc1, dc2, dc3_col = K.coupling_bwd_fused(dc3, dx, packed, y1, y2, masks=masks)     # (masks: the ReLU signs of y1 / y2 at 1/8 of their bytes)
     def problems(gw1, gb1, gs1, gw2, gb2, gs2, gw3):
         # the three weight gradients as ONE GEMM launch + one reduce (coupling_wgrad3): the 512 x 512 one first, it takes longest
         return [dict(x=y1, dy=dc2, dw=gw2, x_blocked=True, weight=w2.detach(), bias=b2.detach().reshape(-1), dscale=gs2.view(-1),
@@ -778,8 +778,8 @@ class LevelFusedFn(Function):
             ctx.save_for_backward(xpre, ypost, hout)
             ctx.fwd_args = (packed, scales, biases, ws)
         else:
-            xpre, ypost, hout, y1, y2, xcol = K.level_fused_train(y, packed, scales, biases, ws, acc)
-            ctx.save_for_backward(xpre, ypost, hout, y1, y2, xcol)
+            xpre, ypost, hout, y1, y2, xcol, masks = K.level_fused_train(y, packed, scales, biases, ws, acc, want_masks=True)
+            ctx.save_for_backward(xpre, ypost, hout, y1, y2, xcol, masks)
         ctx.params, ctx.bpacks, ctx.f3, ctx.n = params, bpacks, float(f3), n
         ctx.nets = meta[4] if len(meta) > 4 else [None] * n
         ctx.ldj_dtype = None if ldj is None else ldj.dtype
@@ -806,16 +806,16 @@ class LevelFusedFn(Function):
                         _join_side()                               # gradients): join before they are released
                     cache.clear()                                  # drop the previous group's tensors before allocating the next
                     g1 = min(g0 + G, ctx.n)
-                    _, _, _, y1g, y2g, xcolg = K.level_fused_train(xpre[g0].clone(), packed_f[g0:g1], scales_f[g0:g1], biases_f[g0:g1],
-                                                                   ws_f[g0:g1], None)
-                    cache.update(g0=g0, t=(xcolg, y1g, y2g))
-                xc, a1, a2 = cache["t"]
-                return xc[i - g0], a1[i - g0], a2[i - g0]
+                    _, _, _, y1g, y2g, xcolg, mg = K.level_fused_train(xpre[g0].clone(), packed_f[g0:g1], scales_f[g0:g1], biases_f[g0:g1],
+                                                                       ws_f[g0:g1], None, want_masks=True)
+                    cache.update(g0=g0, t=(xcolg, y1g, y2g, mg))
+                xc, a1, a2, mg = cache["t"]
+                return xc[i - g0], a1[i - g0], a2[i - g0], (None if mg is None else mg[i - g0])
         else:
-            xpre, ypost, hout, y1, y2, xcol = ctx.saved_tensors
+            xpre, ypost, hout, y1, y2, xcol, masks = ctx.saved_tensors
 
             def hidden(i):
-                return xcol[i], y1[i], y2[i]
+                return xcol[i], y1[i], y2[i], (None if masks is None else masks[i])
         n, P, params = ctx.n, LevelFusedFn.NP, ctx.params
         bsz, hh, ww, c = ypost.shape[1:]
         npix = bsz * hh * ww
@@ -853,8 +853,8 @@ class LevelFusedFn(Function):
         for i in reversed(range(n)):
             scale, bias, weight = params[P * i: P * i + 3]
             net = params[P * i + 3: P * i + 12]
-            xc_i, y1_i, y2_i = hidden(i)
-            g9 = _net_backward_fused(dc3, dx, xc_i, y1_i, y2_i, net, ctx.nets[i], packed=rev[i], batch=batch)   # dx[..., :c/2] += network input gradient
+            xc_i, y1_i, y2_i, m_i = hidden(i)
+            g9 = _net_backward_fused(dc3, dx, xc_i, y1_i, y2_i, net, ctx.nets[i], packed=rev[i], batch=batch, masks=m_i)   # dx[..., :c/2] += network input gradient
             head = (xpre[i], weight.detach().reshape(c, c), scale.detach().reshape(-1), bias.detach().reshape(-1))
             cpl = (ypost[i - 1], hout[i - 1], gl, l3(i - 1), f3) if i > 0 else None
             # (the 1x1 conv's weight gradient dW = sum_p dx (x) a, transforms.py:132, is left in the call's partial buffer too)

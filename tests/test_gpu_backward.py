@@ -782,6 +782,63 @@ def test_fused_reverse_coupling_network(hw, c, B):
     assert torch.equal(h1, g1b) and torch.equal(h2, g2b) and torch.equal(dx_b, dx)
 
 
+@pytest.mark.parametrize("hw,c,B", [(16, 12, 5), (8, 24, 7), (16, 4, 2), (8, 8, 3)])
+def test_relu_masks_of_the_training_forward_drive_the_reverse_network(hw, c, B):
+    """The training forward (nfdp_level_fused_train_ex_bf16) also writes the ReLU SIGNS of both hidden activations - one dword per lane
+    and hidden block, 1/8 of the activations' bytes - and the reverse network reads them instead of the activations: (a) every mask bit
+    equals [y > 0] of the saved activation at that (pixel, channel); (b) the reverse network's outputs (both hidden gradients, the im2col
+    rows, dx) from the masks equal those from the activations BIT FOR BIT; (c) the 4x4 level has no masks and says so."""
+    import numpy as np
+    from normalizing_flow.glow import StepFlow
+    from tests.golden.synth import synth_tensor, DEEP
+    n = 2
+    flows = []
+    for i in range(n):
+        f = StepFlow(c, 512, compute="bf16").to(DEV)
+        f.load_state_dict({k: torch.from_numpy(np.array(synth_tensor(f"flows.{i}." + k, v.shape, 21 + i, DEEP))) for k, v in f.state_dict().items()})
+        flows.append(f)
+    assert K.lib().nfdp_level_fused_train_has_masks(hw, hw, c) == 1 and K.lib().nfdp_level_fused_train_has_masks(4, 4, 48) == 0
+    x = (torch.randn(B, hw, hw, c, generator=torch.Generator().manual_seed(3)) * 0.4).to(DEV)
+    ldj = torch.zeros(B, dtype=torch.float64, device=DEV)
+    packed = [f.affcoupling.net.fused_packed_train() for f in flows]
+    scales = [f.actnorm.scale.detach().view(-1) for f in flows]
+    biases = [f.actnorm.bias.detach().view(-1) for f in flows]
+    ws = [f.invconv2d._w() for f in flows]
+    xpre, ypost, hout, y1, y2, xcol, masks = K.level_fused_train(x.clone(), packed, scales, biases, ws, ldj, want_masks=True)
+    bpad = y1.shape[1]
+    assert masks is not None and tuple(masks.shape) == (n, 2, bpad * hw * hw * 32) and masks.dtype == torch.int32
+    # without masks the launch writes the same activations
+    out2 = K.level_fused_train(x.clone(), packed, scales, biases, ws, torch.zeros_like(ldj), want_masks=False)
+    assert torch.equal(out2[3], y1) and torch.equal(out2[4], y2) and len(out2) == 6
+    # (a) decode: tile t, hidden block hb, lane l, entry e = 4 s + d: low half (value 2d) at bit 7 - e, high half (2d + 1) at bit 23 - e;
+    #     the blocked activation tensor holds the same lane's 8 bf16 of k-step s at [t][hb][s][l][0..7]
+    for i in range(n):
+        for layer, y in ((0, y1[i]), (1, y2[i])):
+            m = masks[i, layer].view(-1, 16, 64).cpu().numpy().astype(np.uint32)            # [tile][hb][lane]
+            yb = y.reshape(-1).view(torch.int16).cpu().numpy().reshape(-1, 16, 2, 64, 8)     # [tile][hb][s][lane][j]
+            for s_ in range(2):
+                for d in range(4):
+                    e = 4 * s_ + d
+                    lo = (m >> (7 - e)) & 1
+                    hi = (m >> (23 - e)) & 1
+                    assert np.array_equal(lo, (yb[:, :, s_, :, 2 * d] != 0).astype(np.uint32)), (i, layer, s_, d)
+                    assert np.array_equal(hi, (yb[:, :, s_, :, 2 * d + 1] != 0).astype(np.uint32)), (i, layer, s_, d)
+    # (b) the reverse network from masks vs from activations
+    net = flows[1].affcoupling.net
+    rev = K.coupling_bwd_fused_pack(net[0].conv.weight.detach(), net[0].actnorm.scale.detach().view(-1), net[2].conv.weight.detach(),
+                                    net[2].actnorm.scale.detach().view(-1), net[4].weight.detach())
+    dc3 = (torch.randn(B, hw, hw, c, generator=torch.Generator().manual_seed(4)) * 0.3).to(DEV)
+    dx_a = torch.randn(B, hw, hw, c, generator=torch.Generator().manual_seed(5)).to(DEV)
+    dx_b = dx_a.clone()
+    a1, a2, acol = K.coupling_bwd_fused(dc3, dx_a, rev, y1[1], y2[1])
+    b1, b2, bcol = K.coupling_bwd_fused(dc3, dx_b, rev, None, None, masks=masks[1])
+    assert torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(acol, bcol) and torch.equal(dx_a, dx_b)
+    assert float(a2.float().abs().max()) > 0
+    with pytest.raises(K.NfdpError):
+        K.coupling_bwd_fused(torch.zeros(8, 4, 4, 48, device=DEV), torch.zeros(8, 4, 4, 48, device=DEV), rev, None, None,
+                             masks=torch.zeros(2, 8 * 16 * 32, dtype=torch.int32, device=DEV))
+
+
 @pytest.mark.parametrize("npix,cin,cout,form_c", [(1024, 512, 512, 0), (640, 64, 512, 6), (2048, 128, 512, 12), (128, 512, 512, 0)])
 def test_weight_gradient_gemm_with_actnorm_gradients(npix, cin, cout, form_c):
     """nfdp_conv_wgrad_bf16_affine: dW of a Conv2dActNorm layer and, from the same GEMM, its ActNorm gradients - dbias as column sums
