@@ -111,6 +111,10 @@ LOGDETS_ON_SIDE_STREAM = True      # Glow.transform_nhwc of 4- and 5-level model
 # (csrc/boundary.hip) where the image fits a workgroup's LDS, and the levels' weight-only log-det terms added by one launch: 22 -> 13
 # launches per forward + NLL step of a 3-level model.  False: the per-op launches (tests compare the two).
 FUSED_LEVEL_BOUNDARY = True
+# ... where it pays: the boundary launch is one workgroup per IMAGE, so a small batch of large images (B = 32 at 32x32x24: 32 workgroups of
+# 1024 pixels each, 70 us) is slower than the four per-op launches it replaces (measured, CelebA shape: 5.163 vs 5.140 ms per forward).
+# Taken when the batch fills the chip's CUs halfway or an image is at most 64 pixels.
+FUSED_BOUNDARY_MIN_BATCH = 128
 
 
 def set_weight_term_cache(on: bool) -> None:
@@ -304,7 +308,8 @@ class GlowBlock(Transform):
         yh = xh if squeezed_in else K.squeeze(xh)    # fresh level buffer; flows then run in place
         yh = _run_flows_fwd(self.flows, yh, ldj, lads, defer_logdet)
         if squeeze_out:
-            if FUSED_LEVEL_BOUNDARY and prior_stream is None and K.split_prior_squeeze_supported(yh):
+            if FUSED_LEVEL_BOUNDARY and prior_stream is None and K.split_prior_squeeze_supported(yh) and (
+                    yh.shape[0] >= FUSED_BOUNDARY_MIN_BATCH or yh.shape[1] * yh.shape[2] <= 64):
                 z, ynext = self.split.transform_squeeze_nhwc(yh, logp)
                 return ynext, z, True
             yv, z = self.split.transform_nhwc(yh, logp, side=prior_stream)

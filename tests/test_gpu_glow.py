@@ -556,6 +556,8 @@ def test_fused_level_boundary_against_the_per_op_launches(compute, c, L, size, b
     x = (torch.rand(b, c, size, size, generator=torch.Generator().manual_seed(7 * c + L)) - 0.5).to(DEV)
     out = {}
     assert G.FUSED_LEVEL_BOUNDARY
+    min_batch = G.FUSED_BOUNDARY_MIN_BATCH
+    G.FUSED_BOUNDARY_MIN_BATCH = 1                          # (the default keeps the fused launch for batches that fill the chip)
     try:
         for fused in (True, False):
             G.FUSED_LEVEL_BOUNDARY = fused
@@ -566,6 +568,7 @@ def test_fused_level_boundary_against_the_per_op_launches(compute, c, L, size, b
             out[fused] = (zs, ldj, logp, len(K.stop_trace()))
     finally:
         G.FUSED_LEVEL_BOUNDARY = True
+        G.FUSED_BOUNDARY_MIN_BATCH = min_batch
     (zf, lf, pf, nf), (zu, lu, pu, nu) = out[True], out[False]
     assert all(torch.equal(a, b_) for a, b_ in zip(zf, zu)) and torch.equal(lf, lu)
     assert_close(pf, pu, 1e-6 if compute == "f32" else 2e-4, "logp, fused boundary vs per-op launches")
