@@ -107,6 +107,7 @@ CACHE_WEIGHT_TERMS = True
 # more than they take on their own.  Off.
 PRIORS_ON_SIDE_STREAM = False
 LOGDETS_ON_SIDE_STREAM = True      # Glow.transform_nhwc of 4- and 5-level models: the 1x1-conv log-dets on a side stream (see there)
+LOGDETS_SIDE_MIN_LEVELS = 4        # ... models with at least this many levels
 # Glow.transform_nhwc: Split (prior conv + log-density + the latent's copy) and the next level's Squeeze as ONE launch per level boundary
 # (csrc/boundary.hip) where the image fits a workgroup's LDS, and the levels' weight-only log-det terms added by one launch: 22 -> 13
 # launches per forward + NLL step of a 3-level model.  False: the per-op launches (tests compare the two).
@@ -373,7 +374,7 @@ class Glow(Transform):
         # Deep models (L >= 4): the wide levels' Gauss-Jordans are not short (1.4 ms for the 16 C = 192 matrices of a 5-level model: a
         # fifth of its forward pass) and nothing reads their result before the end, so they run on a side stream beside the first
         # levels' flows - parallel branches of a captured graph.  (L = 3: 25 us, and a level launch holds every CU: same stream.)
-        with _SideBranch(xh.device, ldj is not None and LOGDETS_ON_SIDE_STREAM and self.L >= 4 and xh.is_cuda) as br:
+        with _SideBranch(xh.device, ldj is not None and LOGDETS_ON_SIDE_STREAM and self.L >= LOGDETS_SIDE_MIN_LEVELS and xh.is_cuda) as br:
             if ldj is not None:
                 with torch.cuda.stream(br.side if br.side is not None else torch.cuda.current_stream(xh.device)):
                     groups = [list(b.flows) for b in self.blocks] + [list(self.final_flows)]

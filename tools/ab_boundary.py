@@ -11,17 +11,21 @@ dev = torch.device("cuda", 0)
 flow, prior, _, _ = bench.build_models(3, 16, "bf16", dev)
 _, _, u8_d, noise_d = bench.make_batch(512, 0, dev)
 res = {}
+side_levels = int(os.environ.get("AB_SIDE_LEVELS", "0"))
 with torch.no_grad():
     for rnd in range(2):
         for fused in (True, False):
-            G.FUSED_LEVEL_BOUNDARY = fused
+            if side_levels:                                  # A/B of the log-det side branch for 3-level models instead
+                G.LOGDETS_SIDE_MIN_LEVELS = 3 if fused else 4
+            else:
+                G.FUSED_LEVEL_BOUNDARY = fused
             for _ in range(2):
                 bench.step(flow, prior, u8_d, noise_d)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 out = bench.step(flow, prior, u8_d, noise_d)
-            for _ in range(5):
+            for _ in range(60):
                 g.replay()
             ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
             for e0, e1 in ev:
