@@ -599,7 +599,7 @@ def test_config4_full_size_properties():
         flow.load_state_dict({k: T(synth_tensor(k, v.shape, 1, DEEP)) for k, v in flow.state_dict().items()}, strict=True)
         prior.load_state_dict({k: T(synth_tensor(k, v.shape, 2, DEEP)) for k, v in prior.state_dict().items()}, strict=True)
         if sdf is None:
-            sdf = ({k: v.detach().clone() for k, v in flow.state_dict().items()}, {k: v.detach().clone() for k, v in prior.state_dict().items()})
+            sdf = ({k: v.detach().cpu().clone() for k, v in flow.state_dict().items()}, {k: v.detach().cpu().clone() for k, v in prior.state_dict().items()})
         flow.to(DEV); prior.to(DEV)
 
         def run(xb):
