@@ -60,11 +60,15 @@ __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
     return __builtin_bit_cast(uint2, h);
 }
 
-// EMU: the fp32 products on the bf16 matrix cores.  v = h + m + l with h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)
+// EMU: the fp32 products on the bf16 matrix cores.  v = h + m + l with three bf16 pieces (below)
 // represents an fp32 value exactly (3 x 8 significand bits), and a*b = ah*bh + (ah*bm + am*bh) + (am*bm + ah*bl + al*bh) + terms
 // below 2^-24 |a*b|: six v_mfma_f32_16x16x32_bf16 (16 cycles each, fp32 accumulation) replace eight v_mfma_f32_16x16x4_f32
 // (32 cycles each) per 32 k: 2.7x fewer matrix-pipe cycles at the accuracy of the fp32 FMA chain (measured against fp64 on
 // K = 576..4608 sums: 2e-7 relative, the chain itself 5e-7).  The splits are VALU work on the fragments already in registers.
+// The pieces are ROUNDED to nearest (h = bf16(v), m = bf16(v - h), l = bf16(v - h - m)): |m| <= 2^-9 |v|, |l| <= 2^-18 |v|, so the three
+// dropped products (m l, l m, l l) stay below 2^-27.  Pieces cut by truncation (two ANDs instead of the conversions) are cheaper but only
+// reach |m| < 2^-7, |l| < 2^-14 - and all carry v's sign: the dropped terms then add up coherently at 2^-21 per product, and the sampling
+// goldens fail (tried in round 5).
 __device__ __forceinline__ void split3(const float (&v)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -352,6 +356,9 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
 // epilogue writes float4 rows.  Roles as in pw_gemm (A := weights) so a lane owns 4 consecutive output channels.
 // Needs Cin % 8 == 0 (8 consecutive k stay inside one tap), fp32 in and out.
 constexpr int SK_LD = 64 + 4;                                  // partial-tile row stride in floats
+#ifndef NFDP_SK_NBUF
+#define NFDP_SK_NBUF 3
+#endif
 
 // PT: 16-pixel tiles per workgroup (4 = the 64 x 64 tile; 2 / 1 when 64-pixel tiles would leave CUs without a workgroup: the 8x8 and
 // 4x4 levels of a B = 64 reverse step have 4096 / 1024 pixels - every wave's MFMA chain, the critical path of the launch, shrinks
@@ -361,8 +368,9 @@ constexpr int SK_LD = 64 + 4;                                  // partial-tile r
 // of the U-Nets) and its 64 output channels are whole groups: the summed tile is already in LDS, the statistics of its (image, group)
 // sets are taken there in fp64 (two passes, like groupnorm_silu_kernel), and the launch of that kernel - 9 us at its latency floor, 22
 // per reverse step - and one round trip of the activation through memory disappear.
-template <int SK_WAVES, int SK_KL, bool EMU, int PT = 4, bool GN = false>       // waves per workgroup, consecutive k per lane per stage (a stage is 4*SK_KL deep)
-__global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const ConvParams P) {
+template <int SK_WAVES, int SK_KL, bool EMU, int PT = 4, bool GN = false, int SK_NBUF = (EMU ? NFDP_SK_NBUF : 2)>   // waves per workgroup, consecutive k per lane per stage (a stage is 4*SK_KL deep), register sets of the K pipeline
+__global__ void __launch_bounds__(SK_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, SK_WAVES / 4)))
+conv_splitk_f32_kernel(const ConvParams P) {
     constexpr int SK_BK = 4 * SK_KL, SK_THREADS = SK_WAVES * 64;
     static_assert(!EMU || SK_KL == 8, "the bf16 MFMA takes 8 consecutive k per lane");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -371,17 +379,21 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
     const int nt = blockIdx.x % P.Nt, mt = blockIdx.x / P.Nt;
     const long m0 = (long)mt * MT;
     const int n0 = nt * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the stage index is scalar)
     const int r16 = lane & 15, q = lane >> 4;
     const float* __restrict__ xg = reinterpret_cast<const float*>(P.x);
     const float* __restrict__ x2g = reinterpret_cast<const float*>(P.x2);
     const float* __restrict__ wg = reinterpret_cast<const float*>(P.w);
     const int HW = P.H * P.W;
 
-    // this lane's PT pixels (one per pixel tile) and 4 weight rows
+    // this lane's PT pixels (one per pixel tile) and 4 weight rows.  pcen / pcen2: the lane's CENTRE pixels in the two sources (always valid
+    // addresses: absent pixels point at pixel 0) - a stage then adds one wave-uniform tap offset and the lane's channel offset, where the
+    // first version recomputed (batch, y, x) -> address with 64-bit multiplies per pixel and stage (the launch was bound by that
+    // arithmetic and the split3 VALU work, ~20 us whatever the matrix shape: profiles/r05_u_small_conv.txt)
     int py[PT], px[PT];
-    long pbase[PT];
     bool pok[PT];
+    const float* pcen[PT];
+    const float* pcen2[PT];
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
         const long p = m0 + j * 16 + r16;
@@ -390,8 +402,12 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
         const long b = pc / HW;
         const int r = (int)(pc - b * HW);
         py[j] = r / P.W; px[j] = r - py[j] * P.W;
-        pbase[j] = b * HW;
+        pcen[j] = xg + pc * P.x_ld;
+        pcen2[j] = x2g ? x2g + pc * P.x2_ld : xg;
     }
+    // a stage (SK_BK consecutive k) lies inside ONE tap when Cin is a multiple of the stage depth (every 3x3 conv of the U-Nets: 64, 128,
+    // 192 channels): tap and channel base are then scalar
+    const bool one_tap = P.Cin % SK_BK == 0 && P.x2 == nullptr;
     const float* wrow[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) wrow[i] = wg + (size_t)(n0 + i * 16 + r16) * P.Kpad + SK_KL * q;
@@ -402,31 +418,41 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
 #pragma unroll
         for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    struct Frags { float4 w[4][SK_KL / 4]; float4 x[PT][SK_KL / 4]; };
-    auto load = [&](Frags& f, int kt) {
-        const int k0 = kt * SK_BK + SK_KL * q;
-        const int tap = k0 / P.Cin, ci = k0 - tap * P.Cin;
+    // (x as loaded + the lane's validity mask: the mask is applied in compute(), i.e. when the stage is consumed - applied right behind the
+    // load it made the wave wait for the data at once, and the prefetch hid nothing)
+    struct Frags { float4 w[4][SK_KL / 4]; uint4 x[PT][SK_KL / 4]; unsigned msk[PT]; };
+    auto load = [&](Frags& f, int kt_req) {
+        const bool live = kt_req < P.Kpad / SK_BK;       // (uniform) a stage beyond the end: valid addresses of the last stage, x masked
+        const int kt = live ? kt_req : P.Kpad / SK_BK - 1;
+        const int kb = kt * SK_BK;                       // wave-uniform
+        int tap, ci;
+        if (one_tap) {
+            tap = kb / P.Cin;                            // (scalar)
+            ci = kb - tap * P.Cin + SK_KL * q;
+        } else {
+            const int k0 = kb + SK_KL * q;
+            tap = k0 / P.Cin;
+            ci = k0 - tap * P.Cin;
+        }
         const int dy = tap / P.KW - P.pad, dx = tap - (tap / P.KW) * P.KW - P.pad;
-        const bool kok = k0 < P.K;
+        const bool kok = live && kb + SK_KL * q < P.K;
         const bool second = kok && ci >= P.Cin1;        // two-source input: this lane's SK_KL channels lie wholly in x2 (Cin1 % 8 == 0)
+        const int shift = dy * P.W + dx;                 // pixel offset of the tap
+        const int off1 = shift * P.x_ld + ci, off2 = shift * P.x2_ld + ci - P.Cin1;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int h = 0; h < SK_KL / 4; ++h) f.w[i][h] = *reinterpret_cast<const float4*>(wrow[i] + kt * SK_BK + 4 * h);
+            for (int h = 0; h < SK_KL / 4; ++h) f.w[i][h] = *reinterpret_cast<const float4*>(wrow[i] + kb + 4 * h);
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int y = py[j] + dy, xx = px[j] + dx;
             const bool ok = kok && pok[j] && (unsigned)y < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
-            // always load (from a clamped, valid address) and mask the bits: a "load or zero" select makes hipcc branch
-            // around every dword and wait for each one
-            const float* src = second ? x2g + (pbase[j] + (ok ? y * P.W + xx : 0)) * P.x2_ld + (ok ? ci - P.Cin1 : 0)
-                                      : xg + (pbase[j] + (ok ? y * P.W + xx : 0)) * P.x_ld + (ok ? ci : 0);
-            const unsigned msk = ok ? 0xffffffffu : 0u;
+            // always load (from a valid address: the centre pixel's first channels) and mask the bits: a "load or zero" select makes
+            // hipcc branch around every dword and wait for each one
+            const float* src = second ? pcen2[j] + (ok ? off2 : 0) : pcen[j] + (ok ? off1 : 0);
+            f.msk[j] = ok ? 0xffffffffu : 0u;
 #pragma unroll
-            for (int h = 0; h < SK_KL / 4; ++h) {
-                const uint4 v = *reinterpret_cast<const uint4*>(src + 4 * h);
-                f.x[j][h] = __builtin_bit_cast(float4, make_uint4(v.x & msk, v.y & msk, v.z & msk, v.w & msk));
-            }
+            for (int h = 0; h < SK_KL / 4; ++h) f.x[j][h] = *reinterpret_cast<const uint4*>(src + 4 * h);
         }
     };
     auto compute = [&](const Frags& f) {
@@ -439,7 +465,11 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
             }
 #pragma unroll
             for (int i = 0; i < PT; ++i) {
-                const float xv[8] = {f.x[i][0].x, f.x[i][0].y, f.x[i][0].z, f.x[i][0].w, f.x[i][1].x, f.x[i][1].y, f.x[i][1].z, f.x[i][1].w};
+                const unsigned k = f.msk[i];
+                const float xv[8] = {__builtin_bit_cast(float, f.x[i][0].x & k), __builtin_bit_cast(float, f.x[i][0].y & k),
+                                     __builtin_bit_cast(float, f.x[i][0].z & k), __builtin_bit_cast(float, f.x[i][0].w & k),
+                                     __builtin_bit_cast(float, f.x[i][1].x & k), __builtin_bit_cast(float, f.x[i][1].y & k),
+                                     __builtin_bit_cast(float, f.x[i][1].z & k), __builtin_bit_cast(float, f.x[i][1].w & k)};
                 split3(xv, xh[i], xm[i], xl[i]);
             }
 #pragma unroll
@@ -456,6 +486,12 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
                 }
             return;
         }
+        float xm_[PT][SK_KL];
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+#pragma unroll
+            for (int kk = 0; kk < SK_KL; ++kk)
+                xm_[j][kk] = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(&f.x[j][0])[kk] & f.msk[j]);
 #pragma unroll
         for (int kk = 0; kk < SK_KL; ++kk) {
 #pragma unroll
@@ -463,23 +499,32 @@ __global__ void __launch_bounds__(SK_WAVES * 64) conv_splitk_f32_kernel(const Co
                 const float a = reinterpret_cast<const float*>(&f.w[i][0])[kk];
 #pragma unroll
                 for (int j = 0; j < PT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, reinterpret_cast<const float*>(&f.x[j][0])[kk], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, xm_[j][kk], acc[i][j], 0, 0, 0);
             }
         }
     };
-    // K stages wave, wave+SK_WAVES, ...: two register sets, the loads of the next stage fly under the MFMAs of the current one
+    // K stages wave, wave+SK_WAVES, ...: NB register sets, the loads of the next NB - 1 stages fly under the MFMAs of the current one.
+    // Every wave runs the SAME number of stages (ceil(nk / SK_WAVES): a stage beyond the end re-reads the last one with its x bits masked
+    // to zero) and every load is issued unconditionally: with `if (stage exists) load(...)` hipcc put the loads under exec-masked branches
+    // and drained the whole queue (s_waitcnt vmcnt(0)) in front of every stage's MFMAs - no prefetch at all, one L2 round trip per stage,
+    // ~20 us per launch whatever the arithmetic (exact chain 20.2, split products 19.6 us at 64 x 16x16 x 64 -> 64).  The stage order
+    // per wave is unchanged, a masked stage adds exact zeros: the same sums, bit for bit.
     const int nk = P.Kpad / SK_BK;
-    Frags f0, f1;
-    int kt = wave;
-    if (kt < nk) load(f0, kt);
-    while (kt < nk) {
-        if (kt + SK_WAVES < nk) load(f1, kt + SK_WAVES);
-        compute(f0);
-        kt += SK_WAVES;
-        if (kt >= nk) break;
-        if (kt + SK_WAVES < nk) load(f0, kt + SK_WAVES);
-        compute(f1);
-        kt += SK_WAVES;
+    constexpr int NB = SK_NBUF;
+    Frags f[NB];
+    const int S = (nk + SK_WAVES - 1) / SK_WAVES;
+#pragma unroll
+    for (int b = 0; b < NB - 1; ++b) load(f[b], wave + b * SK_WAVES);
+    for (int s0 = 0; s0 < S; s0 += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (s0 + b < S) {                                       // (uniform)
+                load(f[(b + NB - 1) % NB], wave + (s0 + b + NB - 1) * SK_WAVES);
+                __builtin_amdgcn_sched_barrier(0);                  // (the prefetch is ISSUED here: hipcc otherwise sinks it to its use)
+                compute(f[b]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 
     // ---- the partial tiles meet in LDS: D[row = n = 4q + r][col = pixel = r16]
