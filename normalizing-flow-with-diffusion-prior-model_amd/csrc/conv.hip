@@ -398,12 +398,12 @@ conv_splitk_f32_kernel(const ConvParams P) {
     for (int j = 0; j < PT; ++j) {
         const long p = m0 + j * 16 + r16;
         pok[j] = p < P.npix;
-        const long pc = pok[j] ? p : 0;
-        const long b = pc / HW;
-        const int r = (int)(pc - b * HW);
+        const int pc = pok[j] ? (int)p : 0;              // (npix < 2^31: 32-bit divisions - the 64-bit ones were ~1 us of every launch)
+        const int b = pc / HW;
+        const int r = pc - b * HW;
         py[j] = r / P.W; px[j] = r - py[j] * P.W;
-        pcen[j] = xg + pc * P.x_ld;
-        pcen2[j] = x2g ? x2g + pc * P.x2_ld : xg;
+        pcen[j] = xg + (long)pc * P.x_ld;
+        pcen2[j] = x2g ? x2g + (long)pc * P.x2_ld : xg;
     }
     // a stage (SK_BK consecutive k) lies inside ONE tap when Cin is a multiple of the stage depth (every 3x3 conv of the U-Nets: 64, 128,
     // 192 channels): tap and channel base are then scalar
@@ -461,7 +461,11 @@ conv_splitk_f32_kernel(const ConvParams P) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float wv[8] = {f.w[i][0].x, f.w[i][0].y, f.w[i][0].z, f.w[i][0].w, f.w[i][1].x, f.w[i][1].y, f.w[i][1].z, f.w[i][1].w};
+#if defined(NFDP_CONV_ABLATE_SPLIT)      // timing-only build (garbage results): the three pieces without the split arithmetic
+                wh[i] = __builtin_bit_cast(bf16x8, f.w[i][0]); wm[i] = __builtin_bit_cast(bf16x8, f.w[i][1]); wl[i] = wh[i];
+#else
                 split3(wv, wh[i], wm[i], wl[i]);
+#endif
             }
 #pragma unroll
             for (int i = 0; i < PT; ++i) {
@@ -470,7 +474,11 @@ conv_splitk_f32_kernel(const ConvParams P) {
                                      __builtin_bit_cast(float, f.x[i][0].z & k), __builtin_bit_cast(float, f.x[i][0].w & k),
                                      __builtin_bit_cast(float, f.x[i][1].x & k), __builtin_bit_cast(float, f.x[i][1].y & k),
                                      __builtin_bit_cast(float, f.x[i][1].z & k), __builtin_bit_cast(float, f.x[i][1].w & k)};
+#if defined(NFDP_CONV_ABLATE_SPLIT) && NFDP_CONV_ABLATE_SPLIT == 2
+                xh[i] = __builtin_bit_cast(bf16x8, f.x[i][0]); xm[i] = __builtin_bit_cast(bf16x8, f.x[i][1]); xl[i] = xh[i];
+#else
                 split3(xv, xh[i], xm[i], xl[i]);
+#endif
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
