@@ -38,3 +38,5 @@ for cin, cout, k in ((64, 64, 1), (64, 64, 3), (128, 64, 3)):
     print(f"conv k{k} {cin}->{cout} 64x16x16 (fp32, split products): {per_launch(lambda: K.conv2d(xx, packed, cout, k, out=out)):6.2f} us per launch")
 gam, bet = torch.ones(64, device=dev), torch.zeros(64, device=dev)
 print(f"groupnorm_silu 64x16x16x64 g8:        {per_launch(lambda: K.groupnorm_silu(x, 8, gam, bet, None)):6.2f} us per launch")
+g64 = torch.ones(64, device=dev)
+print(f"chan_layernorm 64x16x16x64:           {per_launch(lambda: K.chan_layernorm(x, g64)):6.2f} us per launch")
