@@ -127,6 +127,8 @@ def clock_warmup(run, seconds=None, count=None):
     ramp and report the ramp, not the throughput; every timed region of this file therefore runs this first, then its warm-up steps,
     then the barrier (a ~20 us idle, too short for the clocks to fall back).  Returns the number of warm-up runs.
     count: a fixed number of runs instead (work with collectives inside: every rank must issue the same number)."""
+    if os.environ.get("NFDP_BENCH_FIXED_WARMUP"):            # profiling tools that difference two runs need a fixed launch count
+        count = int(os.environ["NFDP_BENCH_FIXED_WARMUP"])
     if count is not None:
         for _ in range(count):
             run()

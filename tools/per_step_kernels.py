@@ -11,7 +11,7 @@ import csv, glob, os, subprocess, sys
 out, n1, n2 = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 extra = sys.argv[sys.argv.index("--") + 1:]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-env = dict(os.environ, TMPDIR="/tmp")
+env = dict(os.environ, TMPDIR="/tmp", NFDP_BENCH_FIXED_WARMUP="0")       # (bench.py: no time-based clock warm-up - fixed launch counts)
 
 
 def run(n):
