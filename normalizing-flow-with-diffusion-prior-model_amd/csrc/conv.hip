@@ -52,6 +52,7 @@ struct ConvParams {
     int x2_ld = 0, Cin1 = 1 << 30;
     // host-side only: compute = NFDP_F32X6 - fp32 storage, every product as six bf16 MFMAs on three-way split operands (the EMU kernels)
     int emu = 0;
+    size_t wsplit_off = 0;            // byte offset of the split image behind the fp32 matrix (conv3x3_ldsx_kernel)
 };
 
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
@@ -346,6 +347,21 @@ __global__ void __launch_bounds__(kThreads) conv_kernel(const ConvParams P) {
     }
 }
 
+// the same pieces for 4 values (one 16-byte load), each piece as 4 packed bf16: element for element the arithmetic of split3
+__device__ __forceinline__ void split3x4(const float4 v4, uint2& h, uint2& m, uint2& l) {
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    bf16x4 hq, mq, lq;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        const float r1 = __builtin_isfinite((float)hh) ? v[e] - (float)hh : 0.f;
+        const __bf16 mm = (__bf16)r1;
+        const float r2 = r1 - (float)mm;
+        hq[e] = hh; mq[e] = mm; lq[e] = (__bf16)r2;
+    }
+    h = __builtin_bit_cast(uint2, hq); m = __builtin_bit_cast(uint2, mq); l = __builtin_bit_cast(uint2, lq);
+}
+
 // ----------------------------------------------------------------------------- small fp32 convs: K split over the waves
 // The U-Net layers of the reverse-diffusion step (B*H*W of a few thousand pixels, K = 9*Cin up to 1728) fill the chip with one
 // 64x64 tile per CU, and conv_kernel then spends its time on the load -> LDS -> barrier -> MFMA round trip of each of its
@@ -368,6 +384,147 @@ constexpr int SK_LD = 64 + 4;                                  // partial-tile r
 // of the U-Nets) and its 64 output channels are whole groups: the summed tile is already in LDS, the statistics of its (image, group)
 // sets are taken there in fp64 (two passes, like groupnorm_silu_kernel), and the launch of that kernel - 9 us at its latency floor, 22
 // per reverse step - and one round trip of the activation through memory disappear.
+
+// The end of the split-K convs (conv_splitk_f32_kernel, conv3x3_ldsx_kernel): the waves' partial tiles meet in LDS and are summed in wave
+// order (deterministic); then the plain epilogue (bias, scale, ReLU) or the Block epilogue (GN, see conv_splitk_f32_kernel).  `part` may
+// alias memory the main loop read: the caller synchronises the workgroup first.
+template <int SK_WAVES, int PT, bool GN>
+__device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part, const f32x4 (&acc)[4][PT], long m0, int n0, int tid,
+                                                int wave, int r16, int q) {
+    constexpr int SK_THREADS = SK_WAVES * 64, MT = 16 * PT;
+    const int HW = P.H * P.W;
+    // ---- the partial tiles meet in LDS: D[row = n = 4q + r][col = pixel = r16]
+    float* mine = part + wave * MT * SK_LD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < PT; ++j)
+            *reinterpret_cast<float4*>(mine + (j * 16 + r16) * SK_LD + i * 16 + 4 * q) =
+                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    __syncthreads();
+    constexpr int NF4 = MT * 16;                                   // float4 of the MT x 64 tile
+    if constexpr (GN) {
+        // ---- A. summed tile (+ bias) back into wave 0's region: all sums first (registers), ONE barrier, then the stores - a barrier
+        // inside the loop would be skipped by the threads without an element (MT = 16 with 512 threads) and pair up with a later one
+        constexpr int NE = (NF4 + SK_THREADS - 1) / SK_THREADS;
+        float4 sums[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + SK_THREADS * e;
+            sums[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
+            const int m = idx >> 4, n4 = (idx & 15) * 4;
+            float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
+#pragma unroll
+            for (int w = 1; w < SK_WAVES; ++w) {
+                const float4 t = *reinterpret_cast<const float4*>(part + (w * MT + m) * SK_LD + n4);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            if (P.add && n0 + n4 < P.Cout) {
+                const float4 a4 = *reinterpret_cast<const float4*>(P.add + n0 + n4);
+                v.x = __fadd_rn(v.x, a4.x); v.y = __fadd_rn(v.y, a4.y); v.z = __fadd_rn(v.z, a4.z); v.w = __fadd_rn(v.w, a4.w);
+            }
+            sums[e] = v;
+        }
+        __syncthreads();                                           // every thread has read the partial tiles
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int idx = tid + SK_THREADS * e;
+            if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
+            *reinterpret_cast<float4*>(part + (idx >> 4) * SK_LD + (idx & 15) * 4) = sums[e];
+        }
+        __syncthreads();
+        // ---- B. statistics of the tile's (image, group) sets: 32 lanes per set, fp64, mean first then the centred squares
+        const int cpg = P.Cout / P.gn_groups, gpt = 64 / cpg, ipt = MT / HW, nset = ipt * gpt, nval = HW * cpg;
+        double* stat = reinterpret_cast<double*>(part + MT * SK_LD);           // wave 1's region: free after pass A
+        const int l32 = tid & 31;
+        for (int st = tid >> 5; st < nset; st += SK_THREADS / 32) {
+            const int img = st / gpt, grp = st - img * gpt;
+            const float* src = part + (img * HW) * SK_LD + grp * cpg;
+            double s1 = 0.0;
+            for (int i = l32; i < nval; i += 32) s1 += (double)src[(i / cpg) * SK_LD + (i % cpg)];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 32);
+            const double mean = s1 / nval;
+            double s2 = 0.0;
+            for (int i = l32; i < nval; i += 32) {
+                const double d = (double)src[(i / cpg) * SK_LD + (i % cpg)] - mean;
+                s2 += d * d;
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 32);
+            if (l32 == 0) {
+                stat[2 * st] = mean;
+                stat[2 * st + 1] = 1.0 / sqrt(s2 / nval + (double)P.gn_eps);
+            }
+        }
+        __syncthreads();
+        // ---- C. normalise, scale/shift, SiLU, residual; float4 rows out
+#pragma unroll
+        for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
+            const int idx = tid + SK_THREADS * e;
+            if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
+            const int m = idx >> 4, n4 = (idx & 15) * 4;
+            const long p = m0 + m;
+            const int n = n0 + n4;
+            if (p >= P.npix || n >= P.Cout) continue;
+            const float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
+            const int st = (m / HW) * gpt + n4 / cpg;
+            const float mu = (float)stat[2 * st], rs = (float)stat[2 * st + 1];
+            const float4 ga = *reinterpret_cast<const float4*>(P.gn_gamma + n), be = *reinterpret_cast<const float4*>(P.gn_beta + n);
+            float o[4] = {v.x, v.y, v.z, v.w};
+            const float gq[4] = {ga.x, ga.y, ga.z, ga.w}, bq[4] = {be.x, be.y, be.z, be.w};
+            const float* sr = P.gn_ss ? P.gn_ss + (p / HW) * (long)P.gn_ss_ld : nullptr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[r], mu), rs), gq[r]), bq[r]);
+                if (sr) t = __fadd_rn(__fmul_rn(t, __fadd_rn(sr[n + r], 1.0f)), sr[P.Cout + n + r]);
+                o[r] = t / (1.0f + expf(-t));
+            }
+            if (P.gn_res) {
+                const float4 rv = *reinterpret_cast<const float4*>(P.gn_res + p * P.gn_res_ld + n);
+                o[0] = __fadd_rn(o[0], rv.x); o[1] = __fadd_rn(o[1], rv.y); o[2] = __fadd_rn(o[2], rv.z); o[3] = __fadd_rn(o[3], rv.w);
+            }
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + p * P.y_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
+        const int idx = tid + SK_THREADS * e;
+        if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
+        const int m = idx >> 4, n4 = (idx & 15) * 4;
+        const long p = m0 + m;
+        const int n = n0 + n4;
+        if (p >= P.npix || n >= P.Cout) continue;
+        float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
+#pragma unroll
+        for (int w = 1; w < SK_WAVES; ++w) {
+            const float4 t = *reinterpret_cast<const float4*>(part + (w * MT + m) * SK_LD + n4);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        float o[4] = {v.x, v.y, v.z, v.w};
+        if (P.add) {
+            const float4 a4 = *reinterpret_cast<const float4*>(P.add + n);
+            o[0] = __fadd_rn(o[0], a4.x); o[1] = __fadd_rn(o[1], a4.y); o[2] = __fadd_rn(o[2], a4.z); o[3] = __fadd_rn(o[3], a4.w);
+        }
+        if (P.mul) {
+            const float4 m4 = *reinterpret_cast<const float4*>(P.mul + n);
+            float mv[4] = {m4.x, m4.y, m4.z, m4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (P.mul_exp != 0.f) mv[r] = expf(__fmul_rn(mv[r], P.mul_exp));
+                o[r] = __fmul_rn(o[r], mv[r]);
+            }
+        }
+        if (P.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
+        }
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + p * P.y_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 template <int SK_WAVES, int SK_KL, bool EMU, int PT = 4, bool GN = false, int SK_NBUF = (EMU ? NFDP_SK_NBUF : 2)>   // waves per workgroup, consecutive k per lane per stage (a stage is 4*SK_KL deep), register sets of the K pipeline
 __global__ void __launch_bounds__(SK_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, SK_WAVES / 4)))
 conv_splitk_f32_kernel(const ConvParams P) {
@@ -535,136 +692,299 @@ conv_splitk_f32_kernel(const ConvParams P) {
         }
     }
 
-    // ---- the partial tiles meet in LDS: D[row = n = 4q + r][col = pixel = r16]
-    float* mine = part + wave * MT * SK_LD;
+    splitk_epilogue<SK_WAVES, PT, GN>(P, part, acc, m0, n0, tid, wave, r16, q);
+}
+
+// ----------------------------------------------------------------------------- small 3x3 convs, split products: the input tile in LDS
+// conv_splitk_f32_kernel<.., EMU> gathers every input element nine times (once per tap) straight into MFMA fragments and splits it into
+// its three bf16 pieces each time, and splits its weight fragments in every workgroup: a stage took 1.46 us for 0.64 us of matrix pipe
+// (16 global 16-byte loads per lane and stage, their masks and waits, ~250 vector instructions of split arithmetic against 96 MFMAs that
+// each hold the vector issue for 8 of their 16 cycles; profiles/r05_u_small_conv.txt).  Here
+//  * the workgroup's pixels and their halo - the flat pixel range [m0 - (W+1), m0 + MT + (W+1)) of the NHWC tensor, which holds every 3x3
+//    neighbour of the tile whatever the image geometry - are loaded ONCE, split ONCE and kept in LDS as three bf16 planes
+//    [pixel][Cin + 8].  A stage's x fragments are three ds_read_b128 per pixel tile at (pixel + tap shift, channel base) - a wave-uniform
+//    offset - and a lane whose tap falls outside the image reads the plane's zero row;
+//  * the weights are split when they are PACKED (nfdp_conv_pack_weights appends the image to the fp32 matrix of a 3x3 weight with
+//    Cin % 32 == 0, split_image_*): per (64-row tile, 32-k stage) the twelve MFMA A fragments (4 row tiles x 3 pieces) as register images
+//    of 1 KiB each - a wave's stage is twelve fully coalesced 16-byte loads and no arithmetic.
+// Same stage order per wave, same pieces, same six products in the same order, same partial-tile sum: the results are bit-identical to
+// conv_splitk_f32_kernel<4, 8, true>.  Needs KH = KW = 3, Cin % 32 == 0 (a 32-deep stage inside one tap), the planes inside the LDS.
+#ifndef NFDP_LX_NBUF
+#define NFDP_LX_NBUF 2
+#endif
+constexpr int LX_WAVES = 4, LX_NBUF = NFDP_LX_NBUF;   // waves per workgroup, register sets of the weight stream
+template <int N, typename F>
+__device__ __forceinline__ void static_for_lx(F&& f) {
+    if constexpr (N > 0) {
+        static_for_lx<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+constexpr int LX_BLOCK = 12 * 1024;                    // bytes of one (row tile, stage) block of the split image
+static inline int ldsx_np(int W, int pt) { return 16 * pt + 2 * (W + 1); }
+static inline size_t ldsx_bytes(int W, int Cin, int pt) {
+    const size_t planes = (size_t)3 * (ldsx_np(W, pt) + 1) * (Cin + 8) * 2;
+    const size_t part = (size_t)LX_WAVES * 16 * pt * SK_LD * 4;
+    return planes > part ? planes : part;
+}
+// which packed fp32 weights carry the split image ([rows][K = 9 * Cin], see nfdp_conv_packed_bytes), and where
+static inline bool split_image_shape(int rows, int Cin, int KH, int KW) {
+    return KH == 3 && KW == 3 && Cin % 32 == 0 && rows >= 64 && rows % 4 == 0;
+}
+static inline size_t split_image_bytes(int rows, int Kpad) { return (size_t)cdiv(rows, 64) * (Kpad / 32) * LX_BLOCK; }
+
+#ifdef NFDP_LX_STAMPS     // diagnostic build only: wave 0 of every 37th workgroup stores s_memtime / s_memrealtime at phase boundaries
+#define LX_STAMP(i)                                                                                                         \
+    do {                                                                                                                    \
+        if (P.part && threadIdx.x == 0 && blockIdx.x % 37 == 0) {                                                           \
+            unsigned long long* d_ = reinterpret_cast<unsigned long long*>(P.part) + (blockIdx.x / 37) * 16 + 2 * (i);      \
+            d_[0] = __builtin_amdgcn_s_memtime();                                                                           \
+            d_[1] = __builtin_amdgcn_s_memrealtime();                                                                       \
+        }                                                                                                                   \
+    } while (0)
+#else
+#define LX_STAMP(i)
+#endif
+
+template <int PT, bool GN>
+__global__ void __launch_bounds__(LX_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+conv3x3_ldsx_kernel(const ConvParams P) {
+    constexpr int MT = 16 * PT, NT_ = LX_WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nt = blockIdx.x % P.Nt, mt = blockIdx.x / P.Nt;
+    const long m0 = (long)mt * MT;
+    const int n0 = nt * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const float* __restrict__ xg = reinterpret_cast<const float*>(P.x);
+    const float* __restrict__ x2g = reinterpret_cast<const float*>(P.x2);
+    const int HW = P.H * P.W, HALO = P.W + 1, NP = MT + 2 * HALO;
+    const int RS = (P.Cin + 8) * 2;                    // plane row stride in bytes
+    const int PS = (NP + 1) * RS;                      // plane stride (row NP of a plane: zeros)
+    const int nk = P.Kpad / 32;
+#if defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 1     // timing-only build (garbage results): no main loop
+    const int S = 0;
+#else
+    const int S = (nk + LX_WAVES - 1) / LX_WAVES;      // stages per wave (the same for every wave: a stage beyond the end adds zeros)
+#endif
+    LX_STAMP(0);
+
+    // ---- staging, part 1: the loads.  16 threads take the 64 channels of a channel block of one pixel (256 contiguous bytes), a pass
+    // covers 16 pixel rows; a thread's units are (pass, channel block) pairs, requested UB at a time - no division anywhere.  Flat pixels
+    // g = m0 - HALO + row, row = 0 .. NP-1; rows outside the tensor are zeros
+    const int srow = tid >> 4, sc = (tid & 15) * 4;
+    const int npass = (NP + 15) >> 4, ncb = (P.Cin + 63) >> 6;
+    constexpr int UB = 8;
+    // Branch-free loads: every unit reads 16 bytes from a VALID address (its pixel clamped into the tensor, its channel block clamped into
+    // the row) and is masked to zeros when it is stored - a "load or zero" select makes hipcc branch around every load (~50 instructions
+    // per unit: the staging took 7 k cycles for 7 units per thread)
+    const int grow0 = (int)(m0 - HALO) + srow;          // flat pixel of this thread's row in pass 0 (npix < 2^31)
+    // (the two sources' parameters as scalars of their own: a per-lane select between two kernel-argument fields otherwise becomes a
+    // VECTOR load from the argument segment - and a full memory round trip in front of the first unit)
+    unsigned ld_1 = (unsigned)P.x_ld, ld_2 = (unsigned)P.x2_ld;
+    int cin1_s = P.Cin1, npix_s = (int)P.npix;
+    asm volatile("" : "+s"(ld_1), "+s"(ld_2), "+s"(cin1_s), "+s"(npix_s));
+    struct Units { float4 v[UB]; unsigned ok; };
+    auto stage_load = [&](Units& u, int pass0, int cb) {              // units (pass0 .. pass0 + UB - 1, cb)
+        const int c = sc + 64 * cb;
+        const bool cin = c < P.Cin;
+        const int cc = cin ? c : 0;
+        const bool first = cc < cin1_s;
+        const float* base = first ? xg + cc : x2g + (cc - cin1_s);
+        const unsigned ld = first ? ld_1 : ld_2;
+        u.ok = 0;
+#pragma unroll
+        for (int e = 0; e < UB; ++e) {
+            const int g = grow0 + 16 * (pass0 + e);
+            const bool ok = cin && g >= 0 && g < npix_s && srow + 16 * (pass0 + e) < NP;
+            const unsigned gc = (unsigned)(g < 0 ? 0 : (g < npix_s ? g : npix_s - 1));
+            u.ok |= ok ? 1u << e : 0u;
+#if defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 2     // timing-only build: no input loads
+            u.v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+#else
+            u.v[e] = *reinterpret_cast<const float4*>(base + (size_t)gc * ld);
+#endif
+        }
+    };
+    auto stage_store = [&](const Units& u, int pass0, int cb) {
+        const int c = sc + 64 * cb;
+#pragma unroll
+        for (int e = 0; e < UB; ++e) {
+            const int row = srow + 16 * (pass0 + e);
+            const unsigned k = (u.ok >> e) & 1u ? 0xffffffffu : 0u;
+            float4 v;
+            v.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, u.v[e].x) & k);
+            v.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, u.v[e].y) & k);
+            v.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, u.v[e].z) & k);
+            v.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, u.v[e].w) & k);
+            uint2 h4, m4, l4;
+            split3x4(v, h4, m4, l4);
+            if (row < NP && c < P.Cin) {
+                char* d = smem + row * RS + c * 2;
+                *reinterpret_cast<uint2*>(d) = h4;
+                *reinterpret_cast<uint2*>(d + PS) = m4;
+                *reinterpret_cast<uint2*>(d + 2 * PS) = l4;
+            }
+        }
+    };
+    Units sv[2];
+    stage_load(sv[0], 0, 0);
+
+    // ---- the weight fragments of this wave's first stages are requested behind the first x units (they fly during the staging): a lane's
+    // part of the address is lane * 16, everything else is scalar
+    const char* wimg = reinterpret_cast<const char*>(P.w) + P.wsplit_off + (size_t)nt * nk * LX_BLOCK;
+    const unsigned wlane = (unsigned)(lane * 16);
+    struct WF { bf16x8 h[4], m[4], l[4]; };
+    auto loadw = [&](WF& f, int s) {
+        int kt = wave + s * LX_WAVES;
+        kt = kt < nk ? kt : nk - 1;                    // (uniform) beyond the end: valid addresses, the x side reads zeros
+#if defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 3     // timing-only build: every stage reads the weights of stage 0 (L1-resident)
+        kt = 0;
+#endif
+        const char* wb = wimg + (size_t)kt * LX_BLOCK;               // (uniform)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f.h[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i) * 1024 + wlane);
+            f.m[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i + 1) * 1024 + wlane);
+            f.l[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i + 2) * 1024 + wlane);
+        }
+    };
+    WF wf[LX_NBUF];
+#pragma unroll
+    for (int b = 0; b < LX_NBUF - 1; ++b) loadw(wf[b], b);
+
+    // ---- staging, part 2: channel block by channel block (all passes of a block are one batch: NP <= 16 UB, see ldsx_ok), the next
+    // block's loads in flight while a block is split into the planes
+    {
+        for (int cb = 0; cb < ncb; cb += 2) {
+            if (cb + 1 < ncb) stage_load(sv[1], 0, cb + 1);
+            stage_store(sv[0], 0, cb);
+            if (cb + 1 < ncb) {
+                if (cb + 2 < ncb) stage_load(sv[0], 0, cb + 2);
+                stage_store(sv[1], 0, cb + 1);
+            }
+        }
+        for (int i = tid; i < 3 * (RS / 8); i += NT_) {               // the zero row of each plane
+            const int pl = i / (RS / 8), o = i - pl * (RS / 8);
+            *reinterpret_cast<uint2*>(smem + pl * PS + NP * RS + o * 8) = make_uint2(0u, 0u);
+        }
+    }
+
+    // this lane's PT pixels: LDS row address of the centre pixel and the 9-bit mask of the taps that fall inside its image (power-of-two
+    // image sides - every U-Net stage - by shifts; else two 32-bit divisions per pixel)
+    unsigned xrow[PT], vmask[PT];
+    const bool pow2 = (P.W & (P.W - 1)) == 0 && (HW & (HW - 1)) == 0;          // (uniform)
+    const int lw = __builtin_ctz((unsigned)P.W);
+#pragma unroll
+    for (int j = 0; j < PT; ++j) {
+        const long p = m0 + j * 16 + r16;
+        const int pc = p < P.npix ? (int)p : 0;
+        int py, px;
+        if (pow2) {
+            const int r = pc & (HW - 1);
+            py = r >> lw; px = r & (P.W - 1);
+        } else {
+            const int r = pc % HW;
+            py = r / P.W; px = r - py * P.W;
+        }
+        unsigned mk = 0;
+        if (p < P.npix) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                if ((unsigned)(py + dy) < (unsigned)P.H && (unsigned)(px + dx) < (unsigned)P.W) mk |= 1u << tap;
+            }
+        }
+        vmask[j] = mk;
+        xrow[j] = (unsigned)((j * 16 + r16 + HALO) * RS + 16 * q);
+    }
+    const unsigned zrow = (unsigned)(NP * RS + 16 * q);
+    LX_STAMP(1);
+    __syncthreads();
+    LX_STAMP(2);
+
+    struct XF { bf16x8 h[PT], m[PT], l[PT]; };
+    auto loadx = [&](XF& f, int s) {
+        const int kt = wave + s * LX_WAVES;            // (uniform)
+        const int kb = kt * 32;
+        const int tap = kb / P.Cin;                    // 9 and beyond: the zero padding of K / a stage beyond the end
+        const int ci = kb - tap * P.Cin;
+        const bool live = kt < nk && tap < 9;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int soff = (dy * P.W + dx) * RS + ci * 2;
+#pragma unroll
+        for (int j = 0; j < PT; ++j) {
+            const bool ok = live && ((vmask[j] >> (tap & 15)) & 1u);
+            const char* a = smem + (ok ? (int)xrow[j] + soff : (int)zrow);
+            f.h[j] = *reinterpret_cast<const bf16x8*>(a);
+            f.m[j] = *reinterpret_cast<const bf16x8*>(a + PS);
+            f.l[j] = *reinterpret_cast<const bf16x8*>(a + 2 * PS);
+        }
+    };
+
+    f32x4 acc[4][PT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < PT; ++j)
-            *reinterpret_cast<float4*>(mine + (j * 16 + r16) * SK_LD + i * 16 + 4 * q) =
-                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-    __syncthreads();
-    constexpr int NF4 = MT * 16;                                   // float4 of the MT x 64 tile
-    if constexpr (GN) {
-        // ---- A. summed tile (+ bias) back into wave 0's region: all sums first (registers), ONE barrier, then the stores - a barrier
-        // inside the loop would be skipped by the threads without an element (MT = 16 with 512 threads) and pair up with a later one
-        constexpr int NE = (NF4 + SK_THREADS - 1) / SK_THREADS;
-        float4 sums[NE];
+        for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const WF& fw, const XF& fx) {
+#if defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 5     // timing-only build: no matrix work (operands kept alive)
 #pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int idx = tid + SK_THREADS * e;
-            sums[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
-            const int m = idx >> 4, n4 = (idx & 15) * 4;
-            float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
+        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fw.h[i]), "v"(fw.m[i]), "v"(fw.l[i]));
 #pragma unroll
-            for (int w = 1; w < SK_WAVES; ++w) {
-                const float4 t = *reinterpret_cast<const float4*>(part + (w * MT + m) * SK_LD + n4);
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-            }
-            if (P.add && n0 + n4 < P.Cout) {
-                const float4 a4 = *reinterpret_cast<const float4*>(P.add + n0 + n4);
-                v.x = __fadd_rn(v.x, a4.x); v.y = __fadd_rn(v.y, a4.y); v.z = __fadd_rn(v.z, a4.z); v.w = __fadd_rn(v.w, a4.w);
-            }
-            sums[e] = v;
-        }
-        __syncthreads();                                           // every thread has read the partial tiles
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            const int idx = tid + SK_THREADS * e;
-            if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
-            *reinterpret_cast<float4*>(part + (idx >> 4) * SK_LD + (idx & 15) * 4) = sums[e];
-        }
-        __syncthreads();
-        // ---- B. statistics of the tile's (image, group) sets: 32 lanes per set, fp64, mean first then the centred squares
-        const int cpg = P.Cout / P.gn_groups, gpt = 64 / cpg, ipt = MT / HW, nset = ipt * gpt, nval = HW * cpg;
-        double* stat = reinterpret_cast<double*>(part + MT * SK_LD);           // wave 1's region: free after pass A
-        const int l32 = tid & 31;
-        for (int st = tid >> 5; st < nset; st += SK_THREADS / 32) {
-            const int img = st / gpt, grp = st - img * gpt;
-            const float* src = part + (img * HW) * SK_LD + grp * cpg;
-            double s1 = 0.0;
-            for (int i = l32; i < nval; i += 32) s1 += (double)src[(i / cpg) * SK_LD + (i % cpg)];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 32);
-            const double mean = s1 / nval;
-            double s2 = 0.0;
-            for (int i = l32; i < nval; i += 32) {
-                const double d = (double)src[(i / cpg) * SK_LD + (i % cpg)] - mean;
-                s2 += d * d;
-            }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 32);
-            if (l32 == 0) {
-                stat[2 * st] = mean;
-                stat[2 * st + 1] = 1.0 / sqrt(s2 / nval + (double)P.gn_eps);
-            }
-        }
-        __syncthreads();
-        // ---- C. normalise, scale/shift, SiLU, residual; float4 rows out
-#pragma unroll
-        for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
-            const int idx = tid + SK_THREADS * e;
-            if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
-            const int m = idx >> 4, n4 = (idx & 15) * 4;
-            const long p = m0 + m;
-            const int n = n0 + n4;
-            if (p >= P.npix || n >= P.Cout) continue;
-            const float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
-            const int st = (m / HW) * gpt + n4 / cpg;
-            const float mu = (float)stat[2 * st], rs = (float)stat[2 * st + 1];
-            const float4 ga = *reinterpret_cast<const float4*>(P.gn_gamma + n), be = *reinterpret_cast<const float4*>(P.gn_beta + n);
-            float o[4] = {v.x, v.y, v.z, v.w};
-            const float gq[4] = {ga.x, ga.y, ga.z, ga.w}, bq[4] = {be.x, be.y, be.z, be.w};
-            const float* sr = P.gn_ss ? P.gn_ss + (p / HW) * (long)P.gn_ss_ld : nullptr;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[r], mu), rs), gq[r]), bq[r]);
-                if (sr) t = __fadd_rn(__fmul_rn(t, __fadd_rn(sr[n + r], 1.0f)), sr[P.Cout + n + r]);
-                o[r] = t / (1.0f + expf(-t));
-            }
-            if (P.gn_res) {
-                const float4 rv = *reinterpret_cast<const float4*>(P.gn_res + p * P.gn_res_ld + n);
-                o[0] = __fadd_rn(o[0], rv.x); o[1] = __fadd_rn(o[1], rv.y); o[2] = __fadd_rn(o[2], rv.z); o[3] = __fadd_rn(o[3], rv.w);
-            }
-            *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + p * P.y_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
-        }
+        for (int j = 0; j < PT; ++j) asm volatile("" ::"v"(fx.h[j]), "v"(fx.m[j]), "v"(fx.l[j]));
         return;
-    }
+#endif
 #pragma unroll
-    for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
-        const int idx = tid + SK_THREADS * e;
-        if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
-        const int m = idx >> 4, n4 = (idx & 15) * 4;
-        const long p = m0 + m;
-        const int n = n0 + n4;
-        if (p >= P.npix || n >= P.Cout) continue;
-        float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int w = 1; w < SK_WAVES; ++w) {
-            const float4 t = *reinterpret_cast<const float4*>(part + (w * MT + m) * SK_LD + n4);
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-        }
-        float o[4] = {v.x, v.y, v.z, v.w};
-        if (P.add) {
-            const float4 a4 = *reinterpret_cast<const float4*>(P.add + n);
-            o[0] = __fadd_rn(o[0], a4.x); o[1] = __fadd_rn(o[1], a4.y); o[2] = __fadd_rn(o[2], a4.z); o[3] = __fadd_rn(o[3], a4.w);
-        }
-        if (P.mul) {
-            const float4 m4 = *reinterpret_cast<const float4*>(P.mul + n);
-            float mv[4] = {m4.x, m4.y, m4.z, m4.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (P.mul_exp != 0.f) mv[r] = expf(__fmul_rn(mv[r], P.mul_exp));
-                o[r] = __fmul_rn(o[r], mv[r]);
+            for (int j = 0; j < PT; ++j) {                         // smallest terms first (as conv_splitk_f32_kernel)
+                f32x4 c = acc[i][j];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.l[i], fx.h[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.h[i], fx.l[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.m[i], fx.m[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.m[i], fx.h[j], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.h[i], fx.m[j], c, 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.h[i], fx.h[j], c, 0, 0, 0);
             }
-        }
-        if (P.relu) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
-        }
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + p * P.y_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
-    }
+    };
+
+    // K stages wave, wave + 4, ...: the weights of the next LX_NBUF - 1 stages and the x fragments of the next one fly under a stage's
+    // MFMAs.  Stages in straight-line groups of LX_UNROLL and a remainder (a loop of guarded stages makes hipcc's wait-count insertion
+    // merge states at every join and drain the load queue in front of the prefetches)
+    constexpr int LX_XBUF = 2, LX_UNROLL = LX_NBUF * LX_XBUF / (LX_NBUF % 2 == 0 ? 2 : 1);     // lcm of the two set counts
+    XF xf[LX_XBUF];
+    auto stage = [&](auto bc, int st) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value;
+        loadw(wf[(b + LX_NBUF - 1) % LX_NBUF], st + LX_NBUF - 1);
+        loadx(xf[(b + 1) % LX_XBUF], st + 1);
+        compute(wf[b % LX_NBUF], xf[b % LX_XBUF]);
+        // the stage is ONE scheduling region: its 12 weight loads and 3 PT LDS reads are spread between its 24 PT MFMAs (issued as a
+        // block in front of them they cost ~850 cycles per stage in which the matrix pipe of this one-wave-per-SIMD kernel idles; left
+        // to the scheduler they sink to their uses in the NEXT stage - no prefetch)
+#if !(defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 5)
+        static_for_lx<12>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * PT, 0);                  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       // VMEM read
+            if constexpr (PT == 4 || (PT == 2 && g % 2 == 0) || (PT == 1 && g % 4 == 0))
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // DS read
+        });
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    loadx(xf[0], 0);
+    int st = 0;
+    for (; st + LX_UNROLL <= S; st += LX_UNROLL)
+        static_for_lx<LX_UNROLL>([&](auto bc) __attribute__((always_inline)) { stage(bc, st + decltype(bc)::value); });
+    static_for_lx<LX_UNROLL - 1>([&](auto bc) __attribute__((always_inline)) {
+        if (st + decltype(bc)::value < S) stage(bc, st + decltype(bc)::value);       // (uniform) the remainder
+    });
+    LX_STAMP(3);
+    __syncthreads();                                                // the partial tiles alias the planes
+    LX_STAMP(4);
+    splitk_epilogue<LX_WAVES, PT, GN>(P, reinterpret_cast<float*>(smem), acc, m0, n0, tid, wave, r16, q);
+    LX_STAMP(5);
 }
 
 // ----------------------------------------------------------------------------- pointwise conv on bf16 activations
@@ -906,6 +1226,41 @@ __global__ void __launch_bounds__(kThreads, 2) pw_gemm_bf16_kernel(const ConvPar
     }
 }
 
+// element (n, k) of the packed matrix of a weight w[Cout][Cin][KK] (see pack_weights_ex_kernel for flip / taps)
+__device__ __forceinline__ float packed_value(const float* __restrict__ w, int n, int k, int Cout, int Cin, int KK, int flip, int taps,
+                                              int rows, int K) {
+    if (n >= rows || k >= K) return 0.f;
+    const int Co = flip ? Cin : Cout, Ci = flip ? Cout : Cin;
+    int co, ci, tap;
+    if (taps) { tap = n / Co; co = n - tap * Co; ci = k; }
+    else { tap = k / Ci; ci = k - tap * Ci; co = n; }
+    return flip ? w[((long)ci * Cin + co) * KK + (KK - 1 - tap)] : w[((long)co * Cin + ci) * KK + tap];
+}
+// The split image behind a packed fp32 3x3 weight (conv3x3_ldsx_kernel): blocks (64-row tile nt, 32-k stage kt) of 12 KiB, in a block the
+// A fragments (row tile i, piece h / m / l) as register images: lane = r16 + 16 q holds row nt*64 + i*16 + r16, k = kt*32 + 8q .. +7.
+// One thread per (block, i, lane): 8 values -> 3 x 16 bytes, with split3 - the arithmetic the gathering kernel does per launch.
+__device__ __forceinline__ void split_image_write(const float* __restrict__ w, char* __restrict__ img, long t, int Cout, int Cin, int KK,
+                                                  int flip, int taps, int rows, int K, int Kpad) {
+    const int lane = (int)(t & 63), i = (int)((t >> 6) & 3);
+    const long blk = t >> 8;
+    const int nkk = Kpad / 32, kt = (int)(blk % nkk), nt = (int)(blk / nkk);
+    const int n = nt * 64 + i * 16 + (lane & 15), k0 = kt * 32 + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = packed_value(w, n, k0 + e, Cout, Cin, KK, flip, taps, rows, K);
+    bf16x8 h, m, l;
+    split3(v, h, m, l);
+    char* d = img + blk * LX_BLOCK + (3 * i) * 1024 + lane * 16;
+    *reinterpret_cast<bf16x8*>(d) = h;
+    *reinterpret_cast<bf16x8*>(d + 1024) = m;
+    *reinterpret_cast<bf16x8*>(d + 2048) = l;
+}
+__global__ void split_image_kernel(const float* __restrict__ w, char* __restrict__ img, int Cout, int Cin, int KK, int flip, int taps,
+                                   int rows, int K, int Kpad, long total) {
+    for (long t = blockIdx.x * (long)kThreads + threadIdx.x; t < total; t += (long)gridDim.x * kThreads)
+        split_image_write(w, img, t, Cout, Cin, KK, flip, taps, rows, K, Kpad);
+}
+
 // OIHW fp32 -> [Cout_pad][Kpad] in the compute dtype, k = (ky*KW+kx)*Cin+ci, zero padded
 template <bool BF16>
 __global__ void pack_weights_kernel(const float* __restrict__ w, void* __restrict__ out, int Cout, int Cin, int KH, int KW,
@@ -1026,7 +1381,18 @@ void launch_by_cout(ConvParams& P, hipStream_t s) {
 
 extern "C" size_t nfdp_conv_packed_bytes(int Cout, int Cin, int KH, int KW, int compute) {
     if (Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
-    return (size_t)cout_pad_for(Cout) * kpad_for(Cin, KH, KW) * (compute == NFDP_BF16 ? 2 : 4);
+    const size_t matrix = (size_t)cout_pad_for(Cout) * kpad_for(Cin, KH, KW) * (compute == NFDP_BF16 ? 2 : 4);
+    // fp32 3x3 weights with Cin % 32 == 0 also carry their three-way bf16 split as MFMA fragment images (conv3x3_ldsx_kernel)
+    return matrix + (compute != NFDP_BF16 && split_image_shape(Cout, Cin, KH, KW) ? split_image_bytes(Cout, kpad_for(Cin, KH, KW)) : 0);
+}
+
+// the split image behind the fp32 matrix of a qualifying weight (rows x Ci x 3 x 3 after flip)
+static void launch_split_image(const float* w_oihw, void* w_packed, int Cout, int Cin, int KK, int flip, int rows, int Ci, hipStream_t s) {
+    const int K = Ci * KK, Kpad = kpad_for(Ci, 3, 3);
+    char* img = reinterpret_cast<char*>(w_packed) + (size_t)cout_pad_for(rows) * Kpad * 4;
+    const long total = (long)cdiv(rows, 64) * (Kpad / 32) * 256;
+    hipLaunchKernelGGL(split_image_kernel, dim3(stream_grid(total, kThreads)), dim3(kThreads), 0, s, w_oihw, img, Cout, Cin, KK, flip, 0,
+                       rows, K, Kpad, total);
 }
 
 extern "C" int nfdp_conv_pack_weights(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, int compute,
@@ -1043,6 +1409,8 @@ extern "C" int nfdp_conv_pack_weights(const float* w_oihw, void* w_packed, int C
     else
         hipLaunchKernelGGL((pack_weights_kernel<false>), dim3(grid), dim3(kThreads), 0, as_stream(stream), w_oihw, w_packed,
                            Cout, Cin, KH, KW, K, Kpad, total);
+    if (compute == NFDP_F32 && split_image_shape(Cout, Cin, KH, KW))
+        launch_split_image(w_oihw, w_packed, Cout, Cin, KH * KW, 0, Cout, Cin, as_stream(stream));
     NFDP_CHECK_LAUNCH("conv_pack_weights");
     return NFDP_OK;
 }
@@ -1069,6 +1437,8 @@ extern "C" int nfdp_conv_pack_weights_ex(const float* w_oihw, void* w_packed, in
     else
         hipLaunchKernelGGL((pack_weights_ex_kernel<false>), dim3(grid), dim3(kThreads), 0, as_stream(stream), w_oihw, w_packed, Cout, Cin,
                            KK, flip, taps, rows, K, Kpad, total);
+    if (compute == NFDP_F32 && !taps && split_image_shape(Co, Ci, KH, KW))
+        launch_split_image(w_oihw, w_packed, Cout, Cin, KK, flip, Co, Ci, as_stream(stream));
     NFDP_CHECK_LAUNCH("conv_pack_weights_ex");
     return NFDP_OK;
 }
@@ -1100,6 +1470,12 @@ __global__ void pack_weights_batch_kernel(const long* __restrict__ jobs) {
         if (BF16) reinterpret_cast<__bf16*>(out)[i] = (__bf16)v;
         else reinterpret_cast<float*>(out)[i] = v;
     }
+    if (!BF16 && j[11]) {                                           // a qualifying 3x3 weight: its split image behind the matrix
+        char* img = reinterpret_cast<char*>(out) + total * 4;
+        const long nthreads = (long)((rows + 63) / 64) * (Kpad / 32) * 256;
+        for (long t = blockIdx.x * (long)kThreads + threadIdx.x; t < nthreads; t += (long)gridDim.x * kThreads)
+            split_image_write(w, img, t, Cout, Cin, KK, flip, taps, rows, K, Kpad);
+    }
 }
 
 extern "C" int nfdp_conv_pack_job(const float* w_oihw, void* w_packed, int Cout, int Cin, int KH, int KW, int flip, int taps, long* job) {
@@ -1111,7 +1487,8 @@ extern "C" int nfdp_conv_pack_job(const float* w_oihw, void* w_packed, int Cout,
     const int Kpad = taps ? kpad_for(Ci, 1, 1) : kpad_for(Ci, KH, KW);
     job[0] = (long)(uintptr_t)w_oihw; job[1] = (long)(uintptr_t)w_packed;
     job[2] = Cout; job[3] = Cin; job[4] = KK; job[5] = flip ? 1 : 0; job[6] = taps ? 1 : 0; job[7] = rows; job[8] = K; job[9] = Kpad;
-    job[10] = (long)cout_pad_for(rows) * Kpad; job[11] = 0;
+    job[10] = (long)cout_pad_for(rows) * Kpad;
+    job[11] = (!taps && split_image_shape(Co, Ci, KH, KW)) ? 1 : 0;      // (read by the fp32 batch kernel only)
     return NFDP_OK;
 }
 
@@ -1175,6 +1552,43 @@ extern "C" int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const v
                                                 float* dadd, void* ws, nfdp_stream_t stream) {
     return nfdp_pointwise_dgrad_masked_bf16_ex(x, x_ld, w_packed, y_saved, y_ld, mul, f, npix, Cin, Cout, dc, dc_ld, dmul, dadd, ws, 0,
                                                stream);
+}
+
+// ---- the LDS-staged form of the split-product 3x3 convs (conv3x3_ldsx_kernel): taken where its geometry holds
+static thread_local int g_conv_ldsx = 1;                          // test hook (thread-local): 0 = always the gathering kernel
+extern "C" void nfdp_debug_set_conv_ldsx(int v) { g_conv_ldsx = v; }
+constexpr size_t kLdsxMax = 160 * 1024;
+#ifdef NFDP_LX_STAMPS
+static thread_local void* g_lx_stamps = nullptr;
+extern "C" void nfdp_debug_set_conv_stamps(void* p) { g_lx_stamps = p; }
+#endif
+static bool ldsx_ok(const ConvParams& P, int pt) {
+    return g_conv_ldsx && split_image_shape(P.Cout, P.Cin, P.KH, P.KW) && (P.x2 == nullptr || P.Cin1 % 4 == 0) &&
+           ldsx_np(P.W, pt) <= 128 &&                  // the staging takes a channel block's pixel rows as one batch of 8 passes x 16 rows
+           ldsx_bytes(P.W, P.Cin, pt) <= kLdsxMax;
+}
+template <bool GN>
+static void launch_ldsx(const ConvParams& P, int pt, dim3 grid, hipStream_t s) {
+    static NfdpPerDevice attr_set;
+    if (!attr_set) {
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<4, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsxMax);
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<2, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsxMax);
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<1, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsxMax);
+        attr_set = true;
+    }
+    const size_t lds = ldsx_bytes(P.W, P.Cin, pt);
+    ConvParams Q = P;
+    Q.wsplit_off = (size_t)cout_pad_for(P.Cout) * P.Kpad * 4;
+#ifdef NFDP_LX_STAMPS
+    Q.part = reinterpret_cast<double*>(g_lx_stamps);
+    if (pt == 4) hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else if (pt == 2) hipLaunchKernelGGL((conv3x3_ldsx_kernel<2, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else hipLaunchKernelGGL((conv3x3_ldsx_kernel<1, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    return;
+#endif
+    if (pt == 4) hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else if (pt == 2) hipLaunchKernelGGL((conv3x3_ldsx_kernel<2, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else hipLaunchKernelGGL((conv3x3_ldsx_kernel<1, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
 }
 
 // ---- split-K conv with the Block epilogue (GroupNorm -> scale/shift -> SiLU -> + residual) in the same launch
@@ -1260,7 +1674,9 @@ static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, f
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
         attr_set = true;
     }
-    if (compute == NFDP_F32X6) {
+    if (compute == NFDP_F32X6 && ldsx_ok(P, pt)) {
+        launch_ldsx<true>(P, pt, grid, s);
+    } else if (compute == NFDP_F32X6) {
         if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 4, true>), grid, dim3(256), 4 * 64 * SK_LD * 4, s, P);
         else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 2, true>), grid, dim3(256), 4 * 32 * SK_LD * 4, s, P);
         else hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 1, true>), grid, dim3(256), 4 * 16 * SK_LD * 4, s, P);
@@ -1363,7 +1779,9 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
             sk_attr_set = true;
         }
-        if (emu) {                    // fp32 products as six bf16 MFMAs (NFDP_F32X6)
+        if (emu && ldsx_ok(P, pt)) {  // fp32 products as six bf16 MFMAs (NFDP_F32X6), 3x3: the input tile staged and split once in LDS
+            launch_ldsx<false>(P, pt, grid, s);
+        } else if (emu) {             // ... operands gathered per tap
             if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 4>), grid, dim3(256), 4 * 64 * SK_LD * 4, s, P);
             else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 2>), grid, dim3(256), 4 * 32 * SK_LD * 4, s, P);
             else hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 1>), grid, dim3(256), 4 * 16 * SK_LD * 4, s, P);

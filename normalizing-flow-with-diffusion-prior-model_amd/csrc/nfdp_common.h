@@ -33,7 +33,7 @@ void nfdp_set_error(const char* fmt, ...);
 #define NFDP_DIAG_ENV(name) ((const char*)nullptr)
 #if defined(NFDP_ABLATE_NOSTREAM) || defined(NFDP_ABLATE_DMA4) || defined(NFDP_ABLATE_MFMA16) || defined(NFDP_ABLATE_NOMFMA) || \
     defined(NFDP_FUSED_STAMPS) || defined(NFDP_FUSED_STAMPS_FINE) || defined(NFDP_FUSED_CLOCK) || defined(NFDP_BWD_ABLATE_LOADS) || \
-    defined(NFDP_BWD_ABLATE_STORES) || defined(NFDP_BWD_ABLATE_STORE_ADDR) || defined(NFDP_W2_ABLATE) || defined(NFDP_CONV_ABLATE_SPLIT)
+    defined(NFDP_BWD_ABLATE_STORES) || defined(NFDP_BWD_ABLATE_STORE_ADDR) || defined(NFDP_W2_ABLATE) || defined(NFDP_CONV_ABLATE_SPLIT) || defined(NFDP_LX_ABLATE) || defined(NFDP_LX_STAMPS)
 #error "timing-only / stamping code paths need -DNFDP_DIAG (tools/build_variant.sh adds it): they must not reach the shipped library"
 #endif
 #endif

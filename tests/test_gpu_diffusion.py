@@ -480,3 +480,48 @@ def test_unet_reads_skip_connections_from_both_tensors():
             K.set_conv_cat(True)
         assert sum("concat" in lb for lb in labels) == 5
         assert torch.equal(a, bref), f"{ch}x{size}x{size}"
+
+
+@pytest.mark.parametrize("b,hw,c1,c2,cout,gn", [(64, 16, 64, 0, 64, False), (64, 16, 64, 64, 64, False), (64, 8, 128, 0, 128, False),
+                                                 (64, 8, 128, 64, 128, False), (64, 4, 128, 0, 128, False), (3, 6, 64, 0, 100, False),
+                                                 (5, 16, 32, 0, 64, False), (130, 8, 64, 0, 128, True), (64, 4, 128, 128, 128, True),
+                                                 (7, 2, 192, 0, 128, True), (2, 40, 64, 0, 64, False)])
+@torch.no_grad()
+def test_lds_staged_split_product_conv_is_bit_identical_to_the_gathering_kernel(b, hw, c1, c2, cout, gn):
+    """conv3x3_ldsx_kernel (input tile + halo loaded and split once into LDS) against conv_splitk_f32_kernel<EMU> (every element gathered
+    and split per tap): same stage order, same six products, same partial sums - identical bits; 64- / 32- / 16-pixel tiles, two-source
+    inputs, ragged last tiles, images wider than a tile, the Block epilogue; and against torch fp64 (gaussian_diffusion.py:267-276)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(b + hw + c1 + c2 + cout)
+    wide = torch.randn(b, hw, hw, c1 + 8, generator=g).to(DEV)
+    x1 = wide[..., 4:4 + c1]                                         # a pixel-strided, 16-byte aligned view
+    x2 = torch.randn(b, hw, hw, c2, generator=g).to(DEV) if c2 else None
+    w = (torch.randn(cout, c1 + c2, 3, 3, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(cout, generator=g).to(DEV)
+    packed = K.conv_pack(w, K.F32)
+    assert K.get_f32_products() == "bf16x6"
+    setter = K.lib().nfdp_debug_set_conv_ldsx
+    if gn:
+        gamma, beta = (torch.randn(cout, generator=g) * 0.3 + 1).to(DEV), (torch.randn(cout, generator=g) * 0.3).to(DEV)
+        ss = (torch.randn(b, 2 * cout, generator=g) * 0.5).to(DEV)
+        res = torch.randn(b, hw, hw, cout, generator=g).to(DEV)
+        assert K.conv2d_gn_silu_supported(x1, cout, 3, 8, bias, gamma, beta, extra_cin=c2)
+        run = lambda: K.conv2d_gn_silu(x1, packed, cout, 3, bias, 8, gamma, beta, ss, residual=res, x2=x2)
+    elif c2:
+        run = lambda: K.conv2d_cat(x1, x2, packed, cout, 3, add=bias)
+    else:
+        run = lambda: K.conv2d(x1, packed, cout, 3, add=bias)
+    K.start_trace()
+    new = run()
+    labels = [e["label"] for e in K.stop_trace()]
+    assert any("splitk" in (lb or "") or "conv2d_cat" in (lb or "") for lb in labels), labels
+    setter(0)
+    try:
+        old = run()
+    finally:
+        setter(1)
+    assert torch.equal(new, old)
+    if not gn:
+        xin = torch.cat((x1, x2), dim=3) if c2 else x1
+        ref = F.conv2d(xin.permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), bias.cpu().double(), padding=1)
+        assert_close(new.permute(0, 3, 1, 2), ref, 2e-5, "LDS-staged conv vs torch fp64")
