@@ -292,6 +292,18 @@ int nfdp_stepflow_fused_bf16(float* x, const void* packed, int B, int H, int W, 
 int nfdp_level_fused_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
                           const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
                           int inverse, nfdp_stream_t stream);
+/* The wide levels of a 5-level model (8x8 with C = 96, 4x4 with C = 192) with every pixel tile's GEMM rows dealt to FOUR workgroups and a
+ * flow as three launches (hidden block rows of GEMM1 | GEMM2 + the output conv's K slice of the same hidden block | partial sums +
+ * coupling): the one-workgroup-per-tile kernels above stream a flow's whole weight image through 16 / 32 of the 256 CUs.  Same packed
+ * images and arguments as nfdp_level_fused_bf16 / nfdp_coupling_fused_bf16 (C = 192: the coupling layer alone, heads are launches of
+ * their own), plus a workspace of nfdp_level_split_ws_bytes(B, H, W, C) bytes (0: geometry unsupported), 16-byte aligned, private to the
+ * call's stream.  The output conv's sum is associated by hidden block: equal to the one-workgroup kernels up to fp32 summation order. */
+size_t nfdp_level_split_ws_bytes(int B, int H, int W, int C);
+int nfdp_coupling_fused_ws_bf16(float* x, const void* packed, int B, int H, int W, int C, double* ldj, const float* ldj_const,
+                                int inverse, void* ws, size_t ws_bytes, nfdp_stream_t stream);
+int nfdp_level_fused_ws_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
+                             const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
+                             int inverse, void* ws, size_t ws_bytes, nfdp_stream_t stream);
 /* The same launch as the FORWARD of a training step (normalizing_flow/trainer.py:155: flow.transform under autograd): besides
  * updating x in place it writes, for every flow i of the level, what the backward pass reads instead of recomputing or keeping the
  * per-op intermediates of an unfused forward -

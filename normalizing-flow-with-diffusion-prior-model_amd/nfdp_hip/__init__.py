@@ -677,6 +677,19 @@ def coupling_bwd_fused_pack_batch(nets, outs=None) -> list:
     return _pack_batch("nfdp_coupling_bwd_fused_pack_batch", 5, nets, outs, c, nbytes)
 
 
+WIDE_LEVELS_SPLIT = True     # the 8x8x96 / 4x4x192 levels: a pixel tile's GEMM rows on four workgroups, three launches per flow
+
+
+def set_wide_levels_split(on: bool) -> None:
+    """False: the one-workgroup-per-tile kernels (coupling_fused_wide_kernel) - A/B runs and the comparison test."""
+    global WIDE_LEVELS_SPLIT
+    WIDE_LEVELS_SPLIT = bool(on)
+
+
+def _split_ws_bytes(b: int, h: int, w: int, c: int) -> int:
+    return int(lib().nfdp_level_split_ws_bytes(b, h, w, c)) if WIDE_LEVELS_SPLIT else 0
+
+
 def coupling_fused(xh: torch.Tensor, packed: torch.Tensor, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.Tensor],
                    inverse: bool) -> None:
     """In place on xh [B,H,W,C]: the whole coupling layer (network + affine + log-det) in one launch (bf16 MFMA)."""
@@ -686,6 +699,12 @@ def coupling_fused(xh: torch.Tensor, packed: torch.Tensor, ldj: Optional[torch.T
         _need(ldj, torch.float64, "coupling_fused ldj")
     ch = c // 2
     flops = 2.0 * b * h * w * (9 * ch * 512 + 512 * 512 + 9 * 512 * c)
+    wsb = _split_ws_bytes(b, h, w, c)
+    if wsb:                                              # wide level: a pixel tile on four workgroups, three launches (fused_split.inc)
+        ws = torch.empty(wsb, device=xh.device, dtype=torch.uint8)
+        _call("nfdp_coupling_fused_ws_bf16", _ptr(xh), _ptr(packed), b, h, w, c, _ptr(ldj), _ptr(ldj_const), int(inverse), _ptr(ws),
+              wsb, _stream(), label=f"coupling_split<{c},{w}> {'inv' if inverse else 'fwd'}", flops=flops, nbytes=8.0 * xh.numel())
+        return
     _call("nfdp_coupling_fused_bf16", _ptr(xh), _ptr(packed), b, h, w, c, _ptr(ldj), _ptr(ldj_const), int(inverse),
           _stream(), label=f"coupling_fused_kernel<{c},{w}> {'inv' if inverse else 'fwd'}", flops=flops,
           nbytes=8.0 * xh.numel())
@@ -718,6 +737,13 @@ def level_fused(xh: torch.Tensor, packed, scales, biases, ws, ldj: Optional[torc
     tab = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
     ch = c // 2
     flops = n * 2.0 * b * h * wd * (9 * ch * 512 + 512 * 512 + 9 * 512 * c + c * c)
+    wsb = _split_ws_bytes(b, h, wd, c)
+    if wsb:                                              # wide level: a pixel tile on four workgroups, three launches per flow
+        wsp = torch.empty(wsb, device=xh.device, dtype=torch.uint8)
+        _call("nfdp_level_fused_ws_bf16", _ptr(xh), b, h, wd, c, n, tab(packed), tab(scales), tab(biases), tab(ws), _ptr(ldj),
+              int(inverse), _ptr(wsp), wsb, _stream(), label=f"level_split<{c},{wd}> x{n} {'inv' if inverse else 'fwd'}", flops=flops,
+              nbytes=8.0 * xh.numel())
+        return
     _call("nfdp_level_fused_bf16", _ptr(xh), b, h, wd, c, n, tab(packed), tab(scales), tab(biases), tab(ws), _ptr(ldj),
           int(inverse), _stream(), label=f"level_fused<{c},{wd}> x{n} {'inv' if inverse else 'fwd'}", flops=flops,
           nbytes=8.0 * xh.numel())

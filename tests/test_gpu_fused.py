@@ -387,12 +387,22 @@ def test_split_product_coupling_network_against_fp64(c, hh, ww, b):
 WIDE = [(96, 8, 5), (192, 4, 5), (192, 4, 2)]          # (C, H=W, ragged B: 4x4 workgroups own two images)
 
 
+@pytest.fixture(params=[True, False], ids=["split", "one-workgroup"])
+def wide_split(request):
+    """The wide levels' two kernel families: a pixel tile on four workgroups and three launches per flow (fused_split.inc, the default) or
+    one workgroup per tile (coupling_fused_wide_kernel)."""
+    K.set_wide_levels_split(request.param)
+    yield request.param
+    K.set_wide_levels_split(True)
+
+
 @pytest.mark.parametrize("c,hw,b", WIDE)
 @torch.no_grad()
-def test_wide_level_kernels_match_the_conv_by_conv_path_and_the_oracle(c, hw, b):
+def test_wide_level_kernels_match_the_conv_by_conv_path_and_the_oracle(c, hw, b, wide_split):
     """coupling_fused_wide_kernel (inference only: the 3x3 output conv as one accumulation over (tap, hidden channel), the hidden tile
-    read at the shifted pixel) against the same layer conv by conv in bf16 mode (same operands, another fp32 association of the tap sums)
-    and against the fp32 oracle; forward, inverse, round trip, determinism."""
+    read at the shifted pixel) and the split launches (split_gemm1 / split_gemm23 / split_coupling: the conv's sum by hidden block) against
+    the same layer conv by conv in bf16 mode (same operands, another fp32 association of the tap sums) and against the fp32 oracle;
+    forward, inverse, round trip, determinism."""
     assert not K.coupling_fused_supported(hw, hw, c, 512) and K.coupling_fused_infer_supported(hw, hw, c, 512)
     assert K.coupling_fused_has_head(hw, hw, c) == (c == 96)
     fused, sd = make(c, True)
@@ -404,7 +414,7 @@ def test_wide_level_kernels_match_the_conv_by_conv_path_and_the_oracle(c, hw, b)
     K.start_trace()
     y1, _, _ = fused.transform(xd, l1, None)
     labels = [e["label"] for e in K.stop_trace()]
-    assert any(lb.startswith("coupling_fused_kernel") for lb in labels), labels
+    assert any(lb.startswith("coupling_split" if wide_split else "coupling_fused_kernel") for lb in labels), labels
     y2, _, _ = plain.transform(xd, l2, None)
     assert torch.equal(y1[:, : c // 2], xd[:, : c // 2])
     assert_close(y1, y2, 1e-2, "wide vs conv-by-conv y")
@@ -420,7 +430,7 @@ def test_wide_level_kernels_match_the_conv_by_conv_path_and_the_oracle(c, hw, b)
 
 
 @torch.no_grad()
-def test_wide_level_launch_of_several_flows_matches_flow_by_flow():
+def test_wide_level_launch_of_several_flows_matches_flow_by_flow(wide_split):
     """The 8x8x96 level as ONE launch of several flows (flow head inside, weight ring continuous across flows, parameters fetched a flow
     ahead) against the same flows conv by conv: forward, and the inverse of the unfused output back to the input."""
     import numpy as np
@@ -439,7 +449,7 @@ def test_wide_level_launch_of_several_flows_matches_flow_by_flow():
         K.start_trace()
         ldj = torch.zeros(5, dtype=torch.float64, device=DEV)
         y = _run_flows_fwd(flows, x.clone(), ldj, None, defer_logdet=True)
-        n_launch = len([e for e in K.stop_trace() if e["label"].startswith(("level_fused", "coupling_fused_kernel"))])
+        n_launch = len([e for e in K.stop_trace() if e["label"].startswith(("level_fused", "level_split", "coupling_fused_kernel"))])
         out[fused] = (y, ldj, n_launch)
     assert out[True][2] == 1 and out[False][2] == 0, (out[True][2], out[False][2])      # one level launch vs none
     assert_close(out[True][0], out[False][0], 1e-2, "level launch vs flow by flow")
