@@ -690,6 +690,12 @@ def _split_ws_bytes(b: int, h: int, w: int, c: int) -> int:
     return int(lib().nfdp_level_split_ws_bytes(b, h, w, c)) if WIDE_LEVELS_SPLIT else 0
 
 
+def level_fused_takes_heads(h: int, w: int, c: int) -> bool:
+    """Can level_fused run this geometry's flows WITH their flow heads?  The one-workgroup kernels: coupling_fused_has_head (not at
+    4x4x192); the split launches of the wide levels take the head at both widths."""
+    return bool(coupling_fused_has_head(h, w, c)) or _split_ws_bytes(1, h, w, c) > 0
+
+
 def coupling_fused(xh: torch.Tensor, packed: torch.Tensor, ldj: Optional[torch.Tensor], ldj_const: Optional[torch.Tensor],
                    inverse: bool) -> None:
     """In place on xh [B,H,W,C]: the whole coupling layer (network + affine + log-det) in one launch (bf16 MFMA)."""

@@ -182,8 +182,8 @@ def _level_tables(flows: Sequence[StepFlow], xh: Tensor):
     """(packed images, ActNorm scales, biases) of every flow of a level when ALL of them can run on the fused kernel
     (bf16 mode, supported geometry, ActNorms initialised), else None."""
     packed = []
-    if not K.coupling_fused_has_head(xh.shape[1], xh.shape[2], xh.shape[3]):
-        return None                               # (C = 192: the fused launch is the coupling layer alone - flow by flow)
+    if not K.level_fused_takes_heads(xh.shape[1], xh.shape[2], xh.shape[3]):
+        return None                               # (C = 192 on the one-workgroup kernels: the fused launch is the coupling layer alone - flow by flow)
     for f in flows:
         if not f.actnorm.initialized():
             return None

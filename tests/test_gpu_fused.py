@@ -429,19 +429,24 @@ def test_wide_level_kernels_match_the_conv_by_conv_path_and_the_oracle(c, hw, b,
     assert torch.equal(y1, y1b)
 
 
+@pytest.mark.parametrize("c,hw", [(96, 8), (192, 4)])
 @torch.no_grad()
-def test_wide_level_launch_of_several_flows_matches_flow_by_flow(wide_split):
-    """The 8x8x96 level as ONE launch of several flows (flow head inside, weight ring continuous across flows, parameters fetched a flow
-    ahead) against the same flows conv by conv: forward, and the inverse of the unfused output back to the input."""
+def test_wide_level_launch_of_several_flows_matches_flow_by_flow(wide_split, c, hw):
+    """A wide level as ONE call of several flows with the flow heads inside - the 8x8x96 level on either kernel family (one persistent
+    launch: weight ring continuous across flows, parameters fetched a flow ahead; or 2 n + 1 split launches: a flow's partial sums and
+    coupling inside the next flow's first launch), the 4x4x192 level on the split launches (head_apply_wide) - against the same flows conv
+    by conv: forward, and the inverse of the unfused output back to the input."""
     import numpy as np
     from normalizing_flow import StepFlow
     from normalizing_flow.glow import _run_flows_fwd, _run_flows_inv
+    if c == 192 and not wide_split:
+        pytest.skip("the one-workgroup kernel of the 4x4x192 level is the coupling layer alone: no level call")
     flows = []
     for f in range(3):
-        m = StepFlow(96, 512, compute="bf16")
+        m = StepFlow(c, 512, compute="bf16")
         m.load_state_dict({k: torch.from_numpy(np.array(synth_tensor(f"flows.{f}." + k, v.shape, 1, DEEP))) for k, v in m.state_dict().items()})
         flows.append(m.to(DEV))
-    x = torch.rand(5, 8, 8, 96, device=DEV) - 0.5
+    x = torch.rand(5, hw, hw, c, device=DEV) - 0.5
     out = {}
     for fused in (True, False):
         for m in flows:
@@ -456,7 +461,9 @@ def test_wide_level_launch_of_several_flows_matches_flow_by_flow(wide_split):
     assert_close(out[True][1], out[False][1], 3e-3, "level launch vs flow by flow: ldj")
     for m in flows:
         m.affcoupling.fused = True
+    K.start_trace()
     xi = _run_flows_inv(flows, out[False][0].clone())
+    assert len([e for e in K.stop_trace() if e["label"].startswith(("level_fused", "level_split"))]) == 1
     assert float((xi - x).abs().max()) < 1e-2
 
 
