@@ -853,15 +853,18 @@ conv3x3_ldsx_kernel(const ConvParams P) {
 #pragma unroll
     for (int b = 0; b < LX_NBUF - 1; ++b) loadw(wf[b], b);
 
-    // ---- staging, part 2: channel block by channel block (all passes of a block are one batch: NP <= 16 UB, see ldsx_ok), the next
-    // block's loads in flight while a block is split into the planes
+    // ---- staging, part 2: batch by batch (a batch = UB passes of one channel block; b -> (channel block b / npb, first pass (b % npb) UB)),
+    // the next batch's loads in flight while a batch is split into the planes
     {
-        for (int cb = 0; cb < ncb; cb += 2) {
-            if (cb + 1 < ncb) stage_load(sv[1], 0, cb + 1);
-            stage_store(sv[0], 0, cb);
-            if (cb + 1 < ncb) {
-                if (cb + 2 < ncb) stage_load(sv[0], 0, cb + 2);
-                stage_store(sv[1], 0, cb + 1);
+        const int npb = (npass + UB - 1) / UB, nb = ncb * npb;         // (uniform)
+        auto bcb = [&](int bi) { return bi / npb; };
+        auto bp0 = [&](int bi) { return (bi - (bi / npb) * npb) * UB; };
+        for (int bi = 0; bi < nb; bi += 2) {
+            if (bi + 1 < nb) stage_load(sv[1], bp0(bi + 1), bcb(bi + 1));
+            stage_store(sv[0], bp0(bi), bcb(bi));
+            if (bi + 1 < nb) {
+                if (bi + 2 < nb) stage_load(sv[0], bp0(bi + 2), bcb(bi + 2));
+                stage_store(sv[1], bp0(bi + 1), bcb(bi + 1));
             }
         }
         for (int i = tid; i < 3 * (RS / 8); i += NT_) {               // the zero row of each plane
@@ -1564,7 +1567,7 @@ extern "C" void nfdp_debug_set_conv_stamps(void* p) { g_lx_stamps = p; }
 #endif
 static bool ldsx_ok(const ConvParams& P, int pt) {
     return g_conv_ldsx && split_image_shape(P.Cout, P.Cin, P.KH, P.KW) && (P.x2 == nullptr || P.Cin1 % 4 == 0) &&
-           ldsx_np(P.W, pt) <= 128 &&                  // the staging takes a channel block's pixel rows as one batch of 8 passes x 16 rows
+           ldsx_np(P.W, pt) <= 1024 &&                 // (images up to ~500 pixels wide: beyond, the halo dwarfs the tile)
            ldsx_bytes(P.W, P.Cin, pt) <= kLdsxMax;
 }
 template <bool GN>

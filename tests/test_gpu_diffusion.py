@@ -485,7 +485,8 @@ def test_unet_reads_skip_connections_from_both_tensors():
 @pytest.mark.parametrize("b,hw,c1,c2,cout,gn", [(64, 16, 64, 0, 64, False), (64, 16, 64, 64, 64, False), (64, 8, 128, 0, 128, False),
                                                  (64, 8, 128, 64, 128, False), (64, 4, 128, 0, 128, False), (3, 6, 64, 0, 100, False),
                                                  (5, 16, 32, 0, 64, False), (130, 8, 64, 0, 128, True), (64, 4, 128, 128, 128, True),
-                                                 (7, 2, 192, 0, 128, True), (2, 40, 64, 0, 64, False)])
+                                                 (7, 2, 192, 0, 128, True), (2, 40, 64, 0, 64, False), (8, 32, 64, 0, 64, False),
+                                                 (4, 32, 64, 64, 64, False)])
 @torch.no_grad()
 def test_lds_staged_split_product_conv_is_bit_identical_to_the_gathering_kernel(b, hw, c1, c2, cout, gn):
     """conv3x3_ldsx_kernel (input tile + halo loaded and split once into LDS) against conv_splitk_f32_kernel<EMU> (every element gathered
