@@ -752,6 +752,185 @@ __global__ void __launch_bounds__(LB) flow_link_bwd_kernel(const LinkParams p) {
     }
 }
 
+// The same launch with TPP threads per pixel (C = 24: 2, C = 48: 4; one wave per channel part, 64 pixels per workgroup as above, so the
+// partial buffers keep their layout).  With one thread per pixel the C = 48 launch of a B = 512 step is 128 one-wave workgroups whose serial
+// parts - 2304 FMAs of the C x C product per lane, four 32x32x2 MFMA tiles over 32 steps, four column sums of 64 dependent LDS reads - set
+// its 25 us (35 us beside the weight-gradient stream); here a thread forms C / TPP outputs of the product (the same k-ascending FMA chain
+// per output), a wave takes one MFMA tile over all 64 pixels (the same step order per tile), and the four column sums run side by side,
+// one per wave, after the rest (the same 64-row fp64 sums): bit-identical results.
+template <int C, int TPP>
+__global__ void __launch_bounds__(64 * TPP) flow_link_bwd_split_kernel(const LinkParams p) {
+    constexpr int Ch = C / 2, TS = C + 1, CPT = C / TPP, CQ = Ch / TPP, NT = 64 * TPP;
+    static_assert(C % TPP == 0 && Ch % TPP == 0 && CPT % 4 == 0 && CQ % 2 == 0, "channel parts");
+    extern __shared__ __attribute__((aligned(16))) float link_dyn[];
+    float* wt_s = link_dyn;                               // [C][C]
+    float* es_s = wt_s + C * C;
+    float* bs_s = es_s + C;
+    float* fac_s = bs_s + C;
+    float* tq = fac_s + C;                                // four [64][TS] tiles: dx_in -> q0 | a -> (free) | dy | q2, then dc3 in tile 1
+    float* T0 = tq, *T1 = tq + 64 * TS, *T2 = tq + 2 * 64 * TS, *T3 = tq + 3 * 64 * TS;
+    const int tid = threadIdx.x, pl = tid & 63;
+    const int part = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long px = (long)blockIdx.x * 64 + pl;
+    const bool live = px < p.npix;
+    const bool head = p.xpre != nullptr, cpl = p.ypost != nullptr;
+    if (head) {
+        for (int i = tid; i < C * C; i += NT) wt_s[i] = p.wt[i];
+        for (int c = tid; c < C; c += NT) { es_s[c] = expf(p.scale[c]); bs_s[c] = p.bias[c]; }
+    }
+    if (cpl)
+        for (int c = tid; c < C; c += NT) fac_s[c] = expf(__fmul_rn(p.f3, p.logs3[c]));
+    const int cs = part * CPT;                            // this thread's channels of the head phase
+    double* out = p.part + (size_t)blockIdx.x * 4 * C;
+    if (head) {
+        // the pixel's dx_in row into tile 0 (every part its CPT channels)
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) v = *reinterpret_cast<const float4*>(p.dx_in + px * C + cs + c);
+            float* d = T0 + pl * TS + cs + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        float da[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) da[c] = 0.f;
+#pragma unroll 2
+        for (int k = 0; k < C; ++k) {
+            const float xv = T0[pl * TS + k];
+            const float* wr = wt_s + k * C + cs;
+#pragma unroll
+            for (int c = 0; c < CPT; c += 4) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wr + c);
+                da[c] = fmaf(w4.x, xv, da[c]); da[c + 1] = fmaf(w4.y, xv, da[c + 1]);
+                da[c + 2] = fmaf(w4.z, xv, da[c + 2]); da[c + 3] = fmaf(w4.w, xv, da[c + 3]);
+            }
+        }
+        float q0[CPT];
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4) {
+            float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) xv = *reinterpret_cast<const float4*>(p.xpre + px * C + cs + c);
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            float av[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float es = es_s[cs + c + j];
+                av[j] = __fmul_rn(es, __fadd_rn(xs[j], bs_s[cs + c + j]));
+                const float dyv = __fmul_rn(da[c + j], es);
+                q0[c + j] = __fmul_rn(da[c + j], av[j]);
+                T1[pl * TS + cs + c + j] = av[j];
+                T2[pl * TS + cs + c + j] = live ? dyv : 0.f;
+            }
+            if (live && p.a_out) *reinterpret_cast<float4*>(p.a_out + px * C + cs + c) = make_float4(av[0], av[1], av[2], av[3]);
+        }
+        __syncthreads();
+        if (p.part_w) {
+            // dW[k][c] = sum_p dx_in[p][k] a[p][c] of the workgroup's 64 pixels: tile (i, j) of the MT x MT row tiles on wave t % TPP, over
+            // all 64 pixels in the step order of flow_link_bwd_kernel<C, 64>
+            constexpr int MT = (C + 31) / 32;
+            const int lane = tid & 63, m0 = lane & 31, kk = lane >> 5;
+            float* pw = p.part_w + (size_t)blockIdx.x * C * C;
+            for (int t = part; t < MT * MT; t += TPP) {
+                const int ti = t / MT, tj = t % MT;
+                f32x16 accw;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+                const int ca = 32 * ti + m0, cb = 32 * tj + m0;
+#pragma unroll 4
+                for (int st = 0; st < 32; ++st) {
+                    const int prow = (2 * st + kk) * TS;
+                    const float av_ = ca < C ? T0[prow + ca] : 0.f;
+                    const float bv_ = cb < C ? T1[prow + cb] : 0.f;
+                    accw = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, bv_, accw, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * ti + drow32(r, kk), col = 32 * tj + m0;
+                    if (row < C && col < C) pw[row * C + col] = accw[r];
+                }
+            }
+            __syncthreads();                                   // every wave is done reading tiles 0 and 1
+        }
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) T0[pl * TS + cs + c] = live ? q0[c] : 0.f;        // column-sum quantity 0
+    } else {
+        // no head: dy = dx_in (tile 2 for the coupling's reads), quantities 0 and 1 are zero
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) v = *reinterpret_cast<const float4*>(p.dx_in + px * C + cs + c);
+            float* d = T2 + pl * TS + cs + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+    }
+    // ---- coupling of the previous flow: this thread's CQ channel pairs (c, Ch + c)
+    const int c0 = part * CQ;
+    if (cpl) {
+        const float g = (p.gl && live) ? (float)p.gl[px / p.HW] : 0.f;
+        float hl[CQ], ht[CQ], xb[CQ];
+#pragma unroll
+        for (int c = 0; c < CQ; c += 2) {
+            float2 a2 = make_float2(0.f, 0.f), b2 = a2, x2 = a2;
+            if (live) {
+                a2 = *reinterpret_cast<const float2*>(p.hout + px * C + c0 + c);
+                b2 = *reinterpret_cast<const float2*>(p.hout + px * C + Ch + c0 + c);
+                x2 = *reinterpret_cast<const float2*>(p.ypost + px * C + Ch + c0 + c);
+            }
+            hl[c] = a2.x; hl[c + 1] = a2.y; ht[c] = b2.x; ht[c + 1] = b2.y; xb[c] = x2.x; xb[c + 1] = x2.y;
+        }
+        float dxa[CQ], dxb[CQ], dc3a[CQ], dc3b[CQ];
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+            const float sg = sigmoid_p2(hl[c]);
+            const float t = ht[c];
+            const float dya = T2[pl * TS + c0 + c], dyb = T2[pl * TS + Ch + c0 + c];
+            const float dt = __fmul_rn(dyb, sg);
+            const float ds = __fadd_rn(__fmul_rn(dyb, __fadd_rn(xb[c], t)), __fdiv_rn(g, __fadd_rn(sg, 1e-6f)));
+            const float dls = __fmul_rn(__fmul_rn(ds, sg), __fsub_rn(1.0f, sg));
+            dxa[c] = dya; dxb[c] = dt;
+            dc3a[c] = __fmul_rn(dls, fac_s[c0 + c]);
+            dc3b[c] = __fmul_rn(dt, fac_s[Ch + c0 + c]);
+            T3[pl * TS + c0 + c] = live ? __fmul_rn(dls, hl[c]) : 0.f;                  // quantity 2
+            T3[pl * TS + Ch + c0 + c] = live ? __fmul_rn(dt, ht[c]) : 0.f;
+        }
+        __syncthreads();                                       // tile 1 (a) is free: quantity 3 goes there
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+            T1[pl * TS + c0 + c] = live ? dc3a[c] : 0.f;
+            T1[pl * TS + Ch + c0 + c] = live ? dc3b[c] : 0.f;
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < CQ; c += 2) {
+                *reinterpret_cast<float2*>(p.dx_out + px * C + c0 + c) = make_float2(dxa[c], dxa[c + 1]);
+                *reinterpret_cast<float2*>(p.dx_out + px * C + Ch + c0 + c) = make_float2(dxb[c], dxb[c + 1]);
+                *reinterpret_cast<float2*>(p.dc3_out + px * C + c0 + c) = make_float2(dc3a[c], dc3a[c + 1]);
+                *reinterpret_cast<float2*>(p.dc3_out + px * C + Ch + c0 + c) = make_float2(dc3b[c], dc3b[c + 1]);
+            }
+        }
+    } else if (live) {                                         // last call of a level: dx_out = dy
+#pragma unroll
+        for (int c = 0; c < CPT; c += 4) {
+            const float* d = T2 + pl * TS + cs + c;
+            *reinterpret_cast<float4*>(p.dx_out + px * C + cs + c) = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    }
+    __syncthreads();
+    // ---- the four column sums (fp64, rows in order), one quantity per wave (TPP = 2: two each)
+    for (int q = part; q < 4; q += TPP) {
+        const bool has = q < 2 ? head : cpl;
+        const float* T = q == 0 ? T0 : (q == 1 ? T2 : (q == 2 ? T3 : T1));
+        if (pl < C) {
+            double sum = 0.0;
+            if (has)
+                for (int r = 0; r < 64; ++r) sum += (double)T[r * TS + pl];
+            out[q * C + pl] = sum;
+        }
+    }
+}
+
 // One launch for a whole level: call k's partials [nblk][4][C] -> the four gradients it feeds (pointers may be null).
 constexpr int kMaxLinkCalls = 33;
 struct LinkFinish {
@@ -825,10 +1004,25 @@ static void launch_flow_link_lb(hipStream_t s, const LinkParams& p) {
     }
     hipLaunchKernelGGL((flow_link_bwd_kernel<C, LB>), dim3((unsigned)cdiv(p.npix, LB)), dim3(LB), kDyn, s, p);
 }
+static thread_local int g_link_split = 1;                 // test hook (thread-local): 0 = one thread per pixel at every C
+extern "C" void nfdp_debug_set_link_split(int v) { g_link_split = v; }
+template <int C, int TPP>
+static void launch_flow_link_split(hipStream_t s, const LinkParams& p) {
+    constexpr int kDyn = (C * C + 3 * C + 4 * 64 * (C + 1)) * (int)sizeof(float);
+    static NfdpPerDevice attr_set;
+    if (!attr_set) {
+        nfdp_func_attr(reinterpret_cast<const void*>(&flow_link_bwd_split_kernel<C, TPP>), hipFuncAttributeMaxDynamicSharedMemorySize, kDyn);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((flow_link_bwd_split_kernel<C, TPP>), dim3((unsigned)cdiv(p.npix, 64)), dim3(64 * TPP), kDyn, s, p);
+}
 template <int C>
 static void launch_flow_link(hipStream_t s, const LinkParams& p) {
-    if (link_block(p.npix) == 64) launch_flow_link_lb<C, 64>(s, p);
-    else launch_flow_link_lb<C, 256>(s, p);
+    if (link_block(p.npix) == 64) {
+        if constexpr (C == 48) { if (g_link_split) { launch_flow_link_split<48, 4>(s, p); return; } }
+        if constexpr (C == 24) { if (g_link_split) { launch_flow_link_split<24, 2>(s, p); return; } }
+        launch_flow_link_lb<C, 64>(s, p);
+    } else launch_flow_link_lb<C, 256>(s, p);
 }
 
 extern "C" size_t nfdp_flow_link_bwd_part_bytes(long npix, int C) {

@@ -1085,3 +1085,38 @@ def test_two_graph_training_step_repacks_its_weights():
         assert_close(l_c, l_e, 1e-6, f"step {k}: loss")
         assert relerr(oc.flat_param, oe.flat_param) <= 1e-6, f"step {k}: parameters {relerr(oc.flat_param, oe.flat_param):.2e}"
     assert float((oe.flat_param - oc.flat_param).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("c,hw,B", [(24, 8, 5), (48, 4, 21), (48, 4, 512), (24, 8, 64)])
+def test_link_kernel_with_several_threads_per_pixel_is_bit_identical(c, hw, B):
+    """flow_link_bwd_split_kernel (C = 24: two, C = 48: four threads per pixel; a wave per MFMA tile; the four column sums side by side)
+    against flow_link_bwd_kernel<C, 64> (one thread per pixel): every output tensor and every partial (fp64 column sums, the 1x1 conv's
+    weight-gradient tiles) bit for bit, for the three call shapes of a level, ragged last workgroups included."""
+    T4 = lambda seed, s=1.0: rnd(B, hw, hw, c, seed=seed, scale=s).to(DEV)
+    dx_in, xpre, ypost, hout = T4(1), T4(2), T4(3), T4(4, 0.5)
+    w = (torch.linalg.qr(rnd(c, c, seed=5))[0] + 0.05 * rnd(c, c, seed=6)).contiguous().to(DEV)
+    scale, bias, l3 = rnd(c, seed=7, scale=0.2).to(DEV), rnd(c, seed=8, scale=0.3).to(DEV), rnd(c, seed=9, scale=0.1).to(DEV)
+    gl = rnd(B, seed=10).double().to(DEV)
+    npix = B * hw * hw
+    setter = K.lib().nfdp_debug_set_link_split
+
+    def run():
+        part = K.flow_link_part(3, npix, c, DEV)
+        part.zero_()
+        outs = [K.flow_link_bwd(dx_in, part[0], coupling=(ypost, hout, gl, l3, 3.0)),
+                K.flow_link_bwd(dx_in, part[1], head=(xpre, w, scale, bias), coupling=(ypost, hout, gl, l3, 3.0)),
+                K.flow_link_bwd(dx_in, part[2], head=(xpre, w, scale, bias))]
+        return outs, part
+
+    new, pn = run()
+    setter(0)
+    try:
+        old, po = run()
+    finally:
+        setter(1)
+    for a, b in zip(new, old):
+        for x, y in zip(a, b):
+            assert (x is None) == (y is None)
+            if x is not None:
+                assert torch.equal(x, y)
+    assert torch.equal(pn.view(torch.int64), po.view(torch.int64))
