@@ -35,7 +35,7 @@ for _ in range(3):
     train_step()
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     train_step()
     torch.cuda.synchronize()
 
@@ -45,7 +45,8 @@ for ev in prof.events():
         continue
     if not ev.name.startswith("aten::"):
         continue
-    where = ""
+    frames = [f for f in (ev.stack or []) if "/normalizing" in f or "/nfdp_hip/" in f or "tools/" in f]
+    where = (str([tuple(sh) for sh in (ev.input_shapes or []) if sh][:2]) + "  " + " <- ".join(f.split("/")[-1].strip() for f in frames[:2]))[:170]
     a = agg[(ev.name, where)]
     a[0] += len(ev.kernels)
     a[1] += sum(k.duration for k in ev.kernels)
