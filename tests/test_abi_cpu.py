@@ -57,6 +57,17 @@ def test_argument_validation_without_gpu():
     assert l.nfdp_tap_coupling_head_f32(p, p, 1, 4, 4, 20, p, p, 3.0, None, None, None, 0, p, p, p, None, None, 0, None) == -3
     assert l.nfdp_ldj_finish_level_f64(None, 4, None, None, 2, 1, None) == -1
     assert l.nfdp_ldj_finish_level_f64(p, 0, ctypes.byref(ctypes.c_void_p(p)), ctypes.byref(ctypes.c_void_p(None)), 1, 1, None) == 0
+    # the split launches of the wide levels: workspace sizes (H1 tiles + 4 partial tiles per pixel tile + a copy of the state), refusals
+    assert l.nfdp_level_split_ws_bytes(32, 8, 8, 96) == 32 * (64 * 1024 + 4 * 64 * 96 * 4) + 32 * 64 * 96 * 4
+    assert l.nfdp_level_split_ws_bytes(5, 4, 4, 192) == 3 * (32 * 1024 + 4 * 32 * 192 * 4) + 5 * 16 * 192 * 4
+    assert l.nfdp_level_split_ws_bytes(32, 4, 4, 48) == 0 and l.nfdp_level_split_ws_bytes(0, 8, 8, 96) == 0
+    assert l.nfdp_coupling_fused_ws_bf16(p, p, 1, 4, 4, 48, None, None, 0, p, 1 << 20, None) == -3              # not a wide level
+    assert l.nfdp_coupling_fused_ws_bf16(p, p, 1, 8, 8, 96, None, None, 0, p, 16, None) == -2                   # workspace too small
+    assert l.nfdp_coupling_fused_ws_bf16(p, p, 1, 8, 8, 96, None, None, 0, None, 1 << 20, None) == -1           # no workspace
+    # packed fp32 3x3 weights with Cin % 32 == 0 carry their split image behind the matrix (12 KiB per (64-row tile, 32-k stage))
+    assert l.nfdp_conv_packed_bytes(64, 64, 3, 3, 0) == 64 * 576 * 4 + 1 * 18 * 12288
+    assert l.nfdp_conv_packed_bytes(100, 96, 3, 3, 0) == 128 * 896 * 4 + 2 * 28 * 12288
+    assert l.nfdp_conv_packed_bytes(64, 64, 3, 3, 1) == 64 * 576 * 2 and l.nfdp_conv_packed_bytes(64, 40, 3, 3, 0) == 64 * 384 * 4
     # empty batches are a no-op, not an error
     assert l.nfdp_squeeze_nhwc_f32(p, 3, p, 0, 3, 4, 4, None) == 0
     assert l.nfdp_coupling_fwd_f32(p, p, 0, 4, 4, None, None, None) == 0
