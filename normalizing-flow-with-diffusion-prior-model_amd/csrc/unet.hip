@@ -802,49 +802,109 @@ __global__ void __launch_bounds__(kBlock) linear_attention_apply_kernel(const fl
 }
 
 // ----------------------------------------------------------------------------- full attention core (:351-357), n <= 256
-// one workgroup per (b, head); K and V staged in LDS; thread i owns query i
+// one workgroup per (b, head); K and V staged in LDS (16-byte loads, all of a thread's requests in flight before it touches LDS).  A query
+// is shared by NP = 256 / npow2(n) threads, thread (i, p) taking the keys j = p, p + NP, ...: with one thread per query the 8x8 mid block
+// of a B = 64 step (n = 64) ran 64 of the 256 threads through 2 x 64 keys x 32 dependent LDS reads - 41.6 us per launch, the longest kernel
+// of a reverse step.  The row maximum is exact (a max over the parts' maxima); the parts' exp sums and value sums meet in LDS and are
+// added in part order by the thread that writes 32 / NP... of the query's outputs (NP = 1, n > 128: the one-thread arithmetic).
 __global__ void __launch_bounds__(kBlock) attention_kernel(const float* __restrict__ qkv, float* __restrict__ out, int n,
-                                                          int heads, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // K[n][33], V[n][33]
+                                                          int heads, float scale, int np_log2) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // K[n][32], V[n][32] (rows read as broadcast float4: the lanes of a wave share the key), partials [NP][nq][34] (max | den | o[32])
+    constexpr int LP = DH, PP = DH + 2;
     float* Ks = sm;
-    float* Vs = sm + n * (DH + 1);
+    float* Vs = sm + n * LP;
+    float* Ps = sm + 2 * n * LP;
     const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
     const int HD = heads * DH, ld = 3 * HD;
     const float* base = qkv + (long)b * n * ld;
-    for (int e = threadIdx.x; e < n * DH; e += kBlock) {
-        const int i = e / DH, dd = e % DH;
-        Ks[i * (DH + 1) + dd] = base[(long)i * ld + HD + hd * DH + dd];
-        Vs[i * (DH + 1) + dd] = base[(long)i * ld + 2 * HD + hd * DH + dd];
+    const int tid = threadIdx.x;
+    {
+        const int r = tid >> 3, c4 = (tid & 7) * 4;                  // staging role: rows r, r + 32, ..; floats c4 .. c4 + 3
+        float4 kv[8], vv[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = r + 32 * it;
+            if (i < n) {
+                kv[it] = *reinterpret_cast<const float4*>(base + (long)i * ld + HD + hd * DH + c4);
+                vv[it] = *reinterpret_cast<const float4*>(base + (long)i * ld + 2 * HD + hd * DH + c4);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int i = r + 32 * it;
+            if (i < n) {
+                *reinterpret_cast<float4*>(Ks + i * LP + c4) = kv[it];
+                *reinterpret_cast<float4*>(Vs + i * LP + c4) = vv[it];
+            }
+        }
     }
-    __syncthreads();
-    const int i = threadIdx.x;
-    if (i >= n) return;
+    const int NP = 1 << np_log2, nq = kBlock >> np_log2;             // threads per query; query slots (n <= nq)
+    const int i = tid & (nq - 1), p = tid >> (8 - np_log2);
+    const bool active = i < n;
+    const int iq = active ? i : 0;
     float q[DH];
 #pragma unroll
-    for (int dd = 0; dd < DH; ++dd) q[dd] = __fmul_rn(base[(long)i * ld + hd * DH + dd], scale);
+    for (int dd = 0; dd < DH; dd += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(base + (long)iq * ld + hd * DH + dd);
+        q[dd] = __fmul_rn(v.x, scale); q[dd + 1] = __fmul_rn(v.y, scale); q[dd + 2] = __fmul_rn(v.z, scale); q[dd + 3] = __fmul_rn(v.w, scale);
+    }
+    __syncthreads();
     float mx = -INFINITY;
-    for (int j = 0; j < n; ++j) {
+    auto dot = [&](int j) __attribute__((always_inline)) {
+        const float4* kr = reinterpret_cast<const float4*>(Ks + j * LP);
         float sdot = 0.f;
 #pragma unroll
-        for (int dd = 0; dd < DH; ++dd) sdot = fmaf(q[dd], Ks[j * (DH + 1) + dd], sdot);
-        mx = fmaxf(mx, sdot);
+        for (int d4 = 0; d4 < DH / 4; ++d4) {
+            const float4 kv = kr[d4];
+            sdot = fmaf(q[4 * d4], kv.x, sdot); sdot = fmaf(q[4 * d4 + 1], kv.y, sdot);
+            sdot = fmaf(q[4 * d4 + 2], kv.z, sdot); sdot = fmaf(q[4 * d4 + 3], kv.w, sdot);
+        }
+        return sdot;
+    };
+    for (int j = p; j < n; j += NP) mx = fmaxf(mx, dot(j));
+    if (NP > 1) {                                                    // (uniform) the row maximum over the parts
+        Ps[(p * nq + i) * PP] = mx;
+        __syncthreads();
+        for (int pp = 0; pp < NP; ++pp) mx = fmaxf(mx, Ps[(pp * nq + i) * PP]);
+        __syncthreads();
     }
     float o[DH];
 #pragma unroll
     for (int dd = 0; dd < DH; ++dd) o[dd] = 0.f;
     float den = 0.f;
-    for (int j = 0; j < n; ++j) {
-        float sdot = 0.f;
+    for (int j = p; j < n; j += NP) {
+        const float pr = expf(dot(j) - mx);
+        den += pr;
+        const float4* vr = reinterpret_cast<const float4*>(Vs + j * LP);
 #pragma unroll
-        for (int dd = 0; dd < DH; ++dd) sdot = fmaf(q[dd], Ks[j * (DH + 1) + dd], sdot);
-        const float p = expf(sdot - mx);
-        den += p;
-#pragma unroll
-        for (int dd = 0; dd < DH; ++dd) o[dd] = fmaf(p, Vs[j * (DH + 1) + dd], o[dd]);
+        for (int d4 = 0; d4 < DH / 4; ++d4) {
+            const float4 vv = vr[d4];
+            o[4 * d4] = fmaf(pr, vv.x, o[4 * d4]); o[4 * d4 + 1] = fmaf(pr, vv.y, o[4 * d4 + 1]);
+            o[4 * d4 + 2] = fmaf(pr, vv.z, o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(pr, vv.w, o[4 * d4 + 3]);
+        }
     }
-    float* orow = out + ((long)b * n + i) * HD + hd * DH;
+    if (NP == 1) {
+        if (!active) return;
+        float* orow = out + ((long)b * n + i) * HD + hd * DH;
 #pragma unroll
-    for (int dd = 0; dd < DH; ++dd) orow[dd] = o[dd] / den;
+        for (int dd = 0; dd < DH; ++dd) orow[dd] = o[dd] / den;
+        return;
+    }
+    float* mine = Ps + (p * nq + i) * PP;
+    mine[1] = den;
+#pragma unroll
+    for (int dd = 0; dd < DH; ++dd) mine[2 + dd] = o[dd];
+    __syncthreads();
+    // thread (i, p) finishes the outputs dd = p, p + NP, ... of query i: parts added in order
+    if (!active) return;
+    float dsum = 0.f;
+    for (int pp = 0; pp < NP; ++pp) dsum += Ps[(pp * nq + i) * PP + 1];
+    float* orow = out + ((long)b * n + i) * HD + hd * DH;
+    for (int dd = p; dd < DH; dd += NP) {
+        float v = 0.f;
+        for (int pp = 0; pp < NP; ++pp) v += Ps[(pp * nq + i) * PP + 2 + dd];
+        orow[dd] = v / dsum;
+    }
 }
 
 // n > 256: queries in chunks of 256 over blockIdx.y, keys / values streamed through LDS in chunks of 256, the same two passes
@@ -1087,14 +1147,17 @@ extern "C" int nfdp_attention_f32(const float* qkv, float* out, int B, int n, in
         NFDP_CHECK_LAUNCH("attention (long)");
         return NFDP_OK;
     }
-    const size_t lds = (size_t)2 * n * (DH + 1) * sizeof(float);
+    // threads per query: 256 / npow2(n), at most 32 (the finishing loop deals the 32 outputs of a query to its threads)
+    int np_log2 = 0;
+    while ((n << (np_log2 + 1)) <= kBlock && np_log2 < 5) ++np_log2;
+    const size_t lds = ((size_t)2 * n * DH + (np_log2 ? (size_t)kBlock * (DH + 2) : 0)) * sizeof(float);
     static NfdpPerDevice attr_set;
     if (!attr_set) {
         nfdp_func_attr(reinterpret_cast<const void*>(&attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * kBlock * (DH + 1) * (int)sizeof(float));
+                                  (2 * kBlock * (DH + 1) + kBlock * (DH + 2)) * (int)sizeof(float));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(kBlock), lds, as_stream(stream), qkv, out, n, heads, scale);
+    hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(kBlock), lds, as_stream(stream), qkv, out, n, heads, scale, np_log2);
     NFDP_CHECK_LAUNCH("attention");
     return NFDP_OK;
 }
