@@ -292,6 +292,14 @@ int nfdp_stepflow_fused_bf16(float* x, const void* packed, int B, int H, int W, 
 int nfdp_level_fused_bf16(float* x, int B, int H, int W, int C, int n_flows, const void* const* packed,
                           const float* const* scale, const float* const* bias, const float* const* w, double* ldj,
                           int inverse, nfdp_stream_t stream);
+/* A 1x1 conv (split-product fp32 arithmetic, weights packed by nfdp_conv_pack_weights with compute = NFDP_F32: Cin % 32 == 0, Cin <= 128)
+ * with the channel LayerNorm of its INPUT (pre_gain [Cin]: PreNorm -> to_qkv, gaussian_diffusion.py:212-220) and / or of its OUTPUT
+ * (post_gain [Cout], Cout <= 128, then + residual: LinearAttention.to_out -> LayerNorm -> Residual, :160-166, :314-318) in one launch;
+ * LayerNorm as nfdp_chan_layernorm_f32 ((x - mean) * rsqrt(var + eps) * gain, biased variance).  bias may be null. */
+int nfdp_conv1x1_ln_supported(long npix, int Cin, int Cout, int pre, int post);
+int nfdp_conv1x1_ln_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, long npix, int Cin, int Cout,
+                        const float* bias, const float* pre_gain, const float* post_gain, const float* residual, int res_ld, float eps,
+                        nfdp_stream_t stream);
 /* The wide levels of a 5-level model (8x8 with C = 96, 4x4 with C = 192) with every pixel tile's GEMM rows dealt to FOUR workgroups and a
  * flow as three launches (hidden block rows of GEMM1 | GEMM2 + the output conv's K slice of the same hidden block | partial sums +
  * coupling): the one-workgroup-per-tile kernels above stream a flow's whole weight image through 16 / 32 of the 256 CUs.  Same packed

@@ -729,7 +729,9 @@ static inline size_t ldsx_bytes(int W, int Cin, int pt) {
 }
 // which packed fp32 weights carry the split image ([rows][K = 9 * Cin], see nfdp_conv_packed_bytes), and where
 static inline bool split_image_shape(int rows, int Cin, int KH, int KW) {
-    return KH == 3 && KW == 3 && Cin % 32 == 0 && rows >= 64 && rows % 4 == 0;
+    // 3x3 (conv3x3_ldsx_kernel) and the narrow 1x1 convs of the U-Nets' attention blocks (conv1x1_ln_kernel; Cin <= 128 keeps the
+    // 512 -> 512 convs of the coupling networks, repacked every training step in fp32 mode, out of it)
+    return ((KH == 3 && KW == 3) || (KH == 1 && KW == 1 && Cin <= 128)) && Cin % 32 == 0 && rows >= 64 && rows % 4 == 0;
 }
 static inline size_t split_image_bytes(int rows, int Kpad) { return (size_t)cdiv(rows, 64) * (Kpad / 32) * LX_BLOCK; }
 
@@ -988,6 +990,197 @@ conv3x3_ldsx_kernel(const ConvParams P) {
     LX_STAMP(4);
     splitk_epilogue<LX_WAVES, PT, GN>(P, reinterpret_cast<float*>(smem), acc, m0, n0, tid, wave, r16, q);
     LX_STAMP(5);
+}
+
+// ----------------------------------------------------------------------------- 1x1 convs of the attention blocks with their LayerNorms
+// Residual(PreNorm(dim, LinearAttention | Attention)) (reference gaussian_diffusion.py:160-166, :212-220, :305-358) is, per block, a channel
+// LayerNorm, the to_qkv 1x1 conv, the attention core, the to_out 1x1 conv, a second LayerNorm (linear attention) and the residual add: five
+// launches of 4-11 us, each at the floor of a dependent launch.  conv1x1_ln_kernel runs a 1x1 conv with split products without LDS - a
+// wave owns 16 pixels over the whole K: its x fragments come straight from memory in MFMA shape (a lane's 8 consecutive channels of its
+// pixel per 32-deep stage), the weight fragments pre-split from the packed image (split_image_*) - and, because the four q-lanes of a
+// pixel together hold ALL its input channels, the LayerNorm of the INPUT is two xor-shuffles away (LNPRE: to_qkv); a workgroup that covers
+// all output channels (NTT 64-channel tiles, Cout <= 128) holds all outputs of its pixels the same way (LNPOST: to_out's LayerNorm + the
+// block's residual).  LayerNorm arithmetic as chan_layernorm_kernel: fp64 mean, fp64 centred squares, ((x - m) r) g.  Three launches per
+// block.  Cin % 32 == 0, Cin <= 128.
+struct LnConv {
+    const float* pre_gain;       // LNPRE: gain[Cin]
+    const float* post_gain;      // LNPOST: gain[Cout]
+    const float* residual;       // LNPOST: added after the LayerNorm ([npix][res_ld]); null: none
+    int res_ld;
+    float eps;
+};
+template <int NS, int NTT, bool LNPRE, bool LNPOST>
+__global__ void __launch_bounds__(256) conv1x1_ln_kernel(const ConvParams P, const LnConv ln) {
+    static_assert(!LNPOST || NTT >= 1, "tiles");
+    const int nt0 = LNPOST ? 0 : (int)(blockIdx.x % P.Nt);
+    const int mt = LNPOST ? (int)blockIdx.x : (int)(blockIdx.x / P.Nt);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const long p = (long)mt * 64 + wave * 16 + r16;
+    const bool pok = p < P.npix;
+    const long pc = pok ? p : 0;
+    const float* __restrict__ xg = reinterpret_cast<const float*>(P.x);
+    const int nk = P.Kpad / 32;                         // (<= NS)
+    const char* wimg = reinterpret_cast<const char*>(P.w) + P.wsplit_off + lane * 16;
+    float4 xv[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = 32 * s + 8 * q;
+        const bool live = c < P.Cin;                    // (Cin % 32 == 0: a whole stage is inside or outside)
+        const float* src = xg + pc * P.x_ld + (live ? c : 0);
+        xv[s][0] = *reinterpret_cast<const float4*>(src);
+        xv[s][1] = *reinterpret_cast<const float4*>(src + 4);
+        if (!live || !pok) { xv[s][0] = make_float4(0.f, 0.f, 0.f, 0.f); xv[s][1] = xv[s][0]; }
+    }
+    bf16x8 wf[NS][12];                                  // [stage][3 i + piece] of the running row tile
+    auto loadw = [&](int nt, int s) __attribute__((always_inline)) {
+        const char* wb = wimg + ((size_t)nt * nk + (s < nk ? s : nk - 1)) * LX_BLOCK;     // (uniform; beyond the end: valid, x is zero)
+#pragma unroll
+        for (int f = 0; f < 12; ++f) wf[s][f] = *reinterpret_cast<const bf16x8*>(wb + f * 1024);
+    };
+#pragma unroll
+    for (int s = 0; s < NS; ++s) loadw(nt0, s);
+    float4 gpre[NS][2];
+    if constexpr (LNPRE) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = 32 * s + 8 * q;
+            const float* gs = ln.pre_gain + (c < P.Cin ? c : 0);
+            gpre[s][0] = *reinterpret_cast<const float4*>(gs);
+            gpre[s][1] = *reinterpret_cast<const float4*>(gs + 4);
+        }
+    }
+    float4 rres[NTT][4];
+    if constexpr (LNPOST) {
+        if (ln.residual != nullptr) {
+#pragma unroll
+            for (int t = 0; t < NTT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n = 64 * t + 16 * i + 4 * q;
+                    rres[t][i] = (pok && n < P.Cout) ? *reinterpret_cast<const float4*>(ln.residual + p * ln.res_ld + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+        }
+    }
+    if constexpr (LNPRE) {                              // LayerNorm of the pixel's input row: its channels sit in the 4 q-lanes of the pixel
+        double s1 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            s1 += ((double)xv[s][0].x + (double)xv[s][0].y) + ((double)xv[s][0].z + (double)xv[s][0].w) +
+                  ((double)xv[s][1].x + (double)xv[s][1].y) + ((double)xv[s][1].z + (double)xv[s][1].w);
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const double mean = s1 / P.Cin;
+        double s2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            if (32 * s + 8 * q < P.Cin) {
+                const float vals[8] = {xv[s][0].x, xv[s][0].y, xv[s][0].z, xv[s][0].w, xv[s][1].x, xv[s][1].y, xv[s][1].z, xv[s][1].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const double d = vals[e] - mean; s2 += d * d; }
+            }
+        }
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float m = (float)mean, r = rsqrtf(__fadd_rn((float)(s2 / P.Cin), ln.eps));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bool live = 32 * s + 8 * q < P.Cin && pok;
+            float4& a = xv[s][0]; float4& b = xv[s][1];
+            const float4 g0 = gpre[s][0], g1 = gpre[s][1];
+            a.x = live ? __fmul_rn(__fmul_rn(__fsub_rn(a.x, m), r), g0.x) : 0.f; a.y = live ? __fmul_rn(__fmul_rn(__fsub_rn(a.y, m), r), g0.y) : 0.f;
+            a.z = live ? __fmul_rn(__fmul_rn(__fsub_rn(a.z, m), r), g0.z) : 0.f; a.w = live ? __fmul_rn(__fmul_rn(__fsub_rn(a.w, m), r), g0.w) : 0.f;
+            b.x = live ? __fmul_rn(__fmul_rn(__fsub_rn(b.x, m), r), g1.x) : 0.f; b.y = live ? __fmul_rn(__fmul_rn(__fsub_rn(b.y, m), r), g1.y) : 0.f;
+            b.z = live ? __fmul_rn(__fmul_rn(__fsub_rn(b.z, m), r), g1.z) : 0.f; b.w = live ? __fmul_rn(__fmul_rn(__fsub_rn(b.w, m), r), g1.w) : 0.f;
+        }
+    }
+    bf16x8 xh[NS], xm[NS], xl[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float x8[8] = {xv[s][0].x, xv[s][0].y, xv[s][0].z, xv[s][0].w, xv[s][1].x, xv[s][1].y, xv[s][1].z, xv[s][1].w};
+        split3(x8, xh[s], xm[s], xl[s]);
+    }
+    f32x4 acc[NTT][4];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                // smallest terms first
+                const bf16x8 wh = wf[s][3 * i], wm = wf[s][3 * i + 1], wl = wf[s][3 * i + 2];
+                f32x4 c = acc[t][i];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[s], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[s], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[s], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[s], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[s], c, 0, 0, 0);
+                acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[s], c, 0, 0, 0);
+            }
+            if (t + 1 < NTT) loadw(nt0 + t + 1, s);      // the next row tile's stage s into the registers this stage just released
+        }
+    }
+    // D[row = channel 16 i + 4 q + r][col = pixel r16]: a lane holds 4 consecutive channels of its pixel per row tile
+    float o[NTT][4][4];
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = 64 * (nt0 + t) + 16 * i + 4 * q;
+            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P.add && n < P.Cout) a4 = *reinterpret_cast<const float4*>(P.add + n);
+            o[t][i][0] = __fadd_rn(acc[t][i][0], a4.x); o[t][i][1] = __fadd_rn(acc[t][i][1], a4.y);
+            o[t][i][2] = __fadd_rn(acc[t][i][2], a4.z); o[t][i][3] = __fadd_rn(acc[t][i][3], a4.w);
+        }
+    if constexpr (LNPOST) {                             // LayerNorm over the pixel's Cout outputs (the 4 q-lanes of the pixel), gain, + residual
+        double s1 = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (64 * t + 16 * i + 4 * q < P.Cout) s1 += ((double)o[t][i][0] + (double)o[t][i][1]) + ((double)o[t][i][2] + (double)o[t][i][3]);
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const double mean = s1 / P.Cout;
+        double s2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < NTT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (64 * t + 16 * i + 4 * q < P.Cout) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const double d = o[t][i][r] - mean; s2 += d * d; }
+                }
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float m = (float)mean, rs = rsqrtf(__fadd_rn((float)(s2 / P.Cout), ln.eps));
+#pragma unroll
+        for (int t = 0; t < NTT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = 64 * t + 16 * i + 4 * q;
+                if (n >= P.Cout) continue;
+                const float4 g4 = *reinterpret_cast<const float4*>(ln.post_gain + n);
+                const float gq[4] = {g4.x, g4.y, g4.z, g4.w};
+                const float rq[4] = {rres[t][i].x, rres[t][i].y, rres[t][i].z, rres[t][i].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = __fmul_rn(__fmul_rn(__fsub_rn(o[t][i][r], m), rs), gq[r]);
+                    if (ln.residual != nullptr) v = __fadd_rn(v, rq[r]);
+                    o[t][i][r] = v;
+                }
+            }
+    }
+    if (!pok) return;
+    float* yrow = reinterpret_cast<float*>(P.y) + p * P.y_ld;
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = 64 * (nt0 + t) + 16 * i + 4 * q;
+            if (n < P.Cout) *reinterpret_cast<float4*>(yrow + n) = make_float4(o[t][i][0], o[t][i][1], o[t][i][2], o[t][i][3]);
+        }
 }
 
 // ----------------------------------------------------------------------------- pointwise conv on bf16 activations
@@ -1391,7 +1584,7 @@ extern "C" size_t nfdp_conv_packed_bytes(int Cout, int Cin, int KH, int KW, int 
 
 // the split image behind the fp32 matrix of a qualifying weight (rows x Ci x 3 x 3 after flip)
 static void launch_split_image(const float* w_oihw, void* w_packed, int Cout, int Cin, int KK, int flip, int rows, int Ci, hipStream_t s) {
-    const int K = Ci * KK, Kpad = kpad_for(Ci, 3, 3);
+    const int K = Ci * KK, Kpad = KK == 9 ? kpad_for(Ci, 3, 3) : kpad_for(Ci, 1, 1);
     char* img = reinterpret_cast<char*>(w_packed) + (size_t)cout_pad_for(rows) * Kpad * 4;
     const long total = (long)cdiv(rows, 64) * (Kpad / 32) * 256;
     hipLaunchKernelGGL(split_image_kernel, dim3(stream_grid(total, kThreads)), dim3(kThreads), 0, s, w_oihw, img, Cout, Cin, KK, flip, 0,
@@ -1566,7 +1759,7 @@ static thread_local void* g_lx_stamps = nullptr;
 extern "C" void nfdp_debug_set_conv_stamps(void* p) { g_lx_stamps = p; }
 #endif
 static bool ldsx_ok(const ConvParams& P, int pt) {
-    return g_conv_ldsx && split_image_shape(P.Cout, P.Cin, P.KH, P.KW) && (P.x2 == nullptr || P.Cin1 % 4 == 0) &&
+    return g_conv_ldsx && P.KH == 3 && split_image_shape(P.Cout, P.Cin, P.KH, P.KW) && (P.x2 == nullptr || P.Cin1 % 4 == 0) &&
            ldsx_np(P.W, pt) <= 1024 &&                 // (images up to ~500 pixels wide: beyond, the halo dwarfs the tile)
            ldsx_bytes(P.W, P.Cin, pt) <= kLdsxMax;
 }
@@ -1716,6 +1909,53 @@ extern "C" int nfdp_conv2d_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, co
                  NFDP_ESHAPE, "conv2d_cat: input rows must be 16-byte aligned");
     return conv2d_impl(x1, NFDP_F32, x1_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin1 + Cin2, Cout, K, K, add, nullptr, 0.f, 0, compute,
                        stream, x2, x2_ld, Cin1);
+}
+
+// 1x1 conv with the channel LayerNorm of its input (pre_gain) and / or of its output (post_gain, + residual) in the same launch: the
+// to_qkv / to_out convs of the U-Nets' attention blocks (conv1x1_ln_kernel).  fp32 tensors, split-product arithmetic (compute = NFDP_F32X6).
+extern "C" int nfdp_conv1x1_ln_supported(long npix, int Cin, int Cout, int pre, int post) {
+    if (npix <= 0 || !split_image_shape(Cout, Cin, 1, 1) || Cout % 4 != 0) return 0;
+    if (post && Cout > 128) return 0;                    // the output LayerNorm needs all outputs of a pixel in one workgroup
+    return pre || post;
+}
+extern "C" int nfdp_conv1x1_ln_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, long npix, int Cin, int Cout,
+                                   const float* bias, const float* pre_gain, const float* post_gain, const float* residual, int res_ld,
+                                   float eps, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && w_packed && y, NFDP_EINVAL, "conv1x1_ln: null pointer");
+    NFDP_REQUIRE(nfdp_conv1x1_ln_supported(npix, Cin, Cout, pre_gain != nullptr, post_gain != nullptr), NFDP_EUNSUPPORTED,
+                 "conv1x1_ln: unsupported shape npix=%ld Cin=%d Cout=%d (Cin %% 32, Cin <= 128; output LayerNorm: Cout <= 128)", npix, Cin, Cout);
+    NFDP_REQUIRE(!residual || post_gain, NFDP_EINVAL, "conv1x1_ln: a residual goes with the output LayerNorm");
+    NFDP_REQUIRE(x_ld >= Cin && x_ld % 4 == 0 && y_ld >= Cout && y_ld % 4 == 0 && (!residual || (res_ld >= Cout && res_ld % 4 == 0)) &&
+                 (((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)pre_gain | (uintptr_t)post_gain | (uintptr_t)residual) % 16) == 0,
+                 NFDP_ESHAPE, "conv1x1_ln: rows and vectors must be 16-byte aligned");
+    ConvParams P;
+    P.x = x; P.w = w_packed; P.y = y; P.add = bias; P.mul = nullptr; P.npix = npix;
+    P.x_ld = x_ld; P.y_ld = y_ld; P.y_bf16 = 0;
+    P.H = 1; P.W = 1; P.Cin = Cin; P.Cout = Cout; P.KH = 1; P.KW = 1; P.pad = 0;
+    P.K = Cin; P.Kpad = kpad_for(Cin, 1, 1); P.relu = 0; P.mul_exp = 0.f;
+    P.Nt = (int)cdiv(Cout, 64); P.Mt = (int)cdiv(npix, 64);
+    P.wsplit_off = (size_t)cout_pad_for(Cout) * P.Kpad * 4;
+    LnConv ln{pre_gain, post_gain, residual, res_ld, eps};
+    hipStream_t s = as_stream(stream);
+    const bool ns2 = P.Kpad / 32 <= 2;
+    const dim3 blk(256);
+    if (post_gain) {
+        const dim3 grid(P.Mt);
+        const bool two = P.Nt == 2;
+        if (pre_gain) {
+            if (ns2) { if (two) hipLaunchKernelGGL((conv1x1_ln_kernel<2, 2, true, true>), grid, blk, 0, s, P, ln); else hipLaunchKernelGGL((conv1x1_ln_kernel<2, 1, true, true>), grid, blk, 0, s, P, ln); }
+            else { if (two) hipLaunchKernelGGL((conv1x1_ln_kernel<4, 2, true, true>), grid, blk, 0, s, P, ln); else hipLaunchKernelGGL((conv1x1_ln_kernel<4, 1, true, true>), grid, blk, 0, s, P, ln); }
+        } else {
+            if (ns2) { if (two) hipLaunchKernelGGL((conv1x1_ln_kernel<2, 2, false, true>), grid, blk, 0, s, P, ln); else hipLaunchKernelGGL((conv1x1_ln_kernel<2, 1, false, true>), grid, blk, 0, s, P, ln); }
+            else { if (two) hipLaunchKernelGGL((conv1x1_ln_kernel<4, 2, false, true>), grid, blk, 0, s, P, ln); else hipLaunchKernelGGL((conv1x1_ln_kernel<4, 1, false, true>), grid, blk, 0, s, P, ln); }
+        }
+    } else {
+        const dim3 grid(P.Mt * P.Nt);
+        if (ns2) hipLaunchKernelGGL((conv1x1_ln_kernel<2, 1, true, false>), grid, blk, 0, s, P, ln);
+        else hipLaunchKernelGGL((conv1x1_ln_kernel<4, 1, true, false>), grid, blk, 0, s, P, ln);
+    }
+    NFDP_CHECK_LAUNCH("conv1x1_ln");
+    return NFDP_OK;
 }
 
 static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,

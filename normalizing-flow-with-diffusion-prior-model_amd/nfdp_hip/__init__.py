@@ -1069,6 +1069,44 @@ def chan_layernorm(xh: torch.Tensor, gain: torch.Tensor, residual: Optional[torc
     return y
 
 
+_CONV_LN_FUSED = True
+
+
+def set_conv_ln_fused(on: bool) -> None:
+    """The attention blocks' 1x1 convs with their channel LayerNorms in the same launch (default) or as separate launches."""
+    global _CONV_LN_FUSED
+    _CONV_LN_FUSED = bool(on)
+
+
+def conv1x1_ln_supported(xh: torch.Tensor, cout: int, pre: bool, post: bool, *vectors) -> bool:
+    """nfdp_conv1x1_ln_f32 takes this input (fp32 NHWC, no grad, split-product fp32 mode) and these vectors (16-byte aligned)?"""
+    if not (_CONV_LN_FUSED and _F32_PRODUCTS == "bf16x6" and xh.is_cuda and xh.dtype == torch.float32 and xh.dim() == 4 and
+            xh.stride(3) == 1 and not torch.is_grad_enabled()):
+        return False
+    if xh.data_ptr() % 16 or xh.stride(2) % 4 or any(v is not None and v.data_ptr() % 16 for v in vectors):
+        return False
+    b, h, w, cin = xh.shape
+    return bool(lib().nfdp_conv1x1_ln_supported(b * h * w, cin, cout, int(pre), int(post)))
+
+
+def conv1x1_ln(xh: torch.Tensor, packed: torch.Tensor, cout: int, bias=None, pre_gain=None, post_gain=None, residual=None,
+               eps: float = 1e-5) -> torch.Tensor:
+    """1x1 conv of LayerNorm(xh) (pre_gain) and / or LayerNorm of the conv's output (post_gain) + residual, in one launch
+    (nfdp_conv1x1_ln_f32; check conv1x1_ln_supported first).  packed: conv_pack(w, F32)."""
+    b, h, w, cin = xh.shape
+    y = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
+    res_ld = 0
+    if residual is not None:
+        _need(residual, torch.float32, "conv1x1_ln residual"); _dense(residual, "conv1x1_ln residual")
+        assert residual.shape == y.shape
+        res_ld = cout
+    _call("nfdp_conv1x1_ln_f32", _ptr(xh), _ld(xh, "conv1x1_ln"), _ptr(packed), _ptr(y), cout, b * h * w, cin, cout, _ptr(bias),
+          _ptr(pre_gain), _ptr(post_gain), _ptr(residual), res_ld, float(eps), _stream(),
+          label=f"conv1x1_ln{'+pre' if pre_gain is not None else ''}{'+post' if post_gain is not None else ''} {cin}->{cout}",
+          flops=2.0 * b * h * w * cin * cout)
+    return y
+
+
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], pre_act: int = 0, post_act: int = 0):
     """x [B,I] -> [B,O]; pre_act 1 = SiLU; post_act 1 = GELU(erf), 2 = SiLU."""
     _need(x, torch.float32, "linear"); _dense(x, "linear"); _dense(w, "linear")

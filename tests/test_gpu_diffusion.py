@@ -526,3 +526,51 @@ def test_lds_staged_split_product_conv_is_bit_identical_to_the_gathering_kernel(
         xin = torch.cat((x1, x2), dim=3) if c2 else x1
         ref = F.conv2d(xin.permute(0, 3, 1, 2).cpu().double(), w.cpu().double(), bias.cpu().double(), padding=1)
         assert_close(new.permute(0, 3, 1, 2), ref, 2e-5, "LDS-staged conv vs torch fp64")
+
+
+@pytest.mark.parametrize("b,hw,dim,kind", [(64, 16, 64, "linear"), (64, 8, 128, "linear"), (5, 6, 64, "linear"), (64, 8, 128, "full"),
+                                           (3, 4, 128, "full"), (7, 4, 96, "linear")])
+@torch.no_grad()
+def test_attention_block_with_layernorms_inside_the_1x1_convs(b, hw, dim, kind):
+    """Residual(PreNorm(dim, LinearAttention | Attention)) with the channel LayerNorms inside the 1x1 convs' launches
+    (nfdp_conv1x1_ln_f32: LayerNorm of the input in to_qkv's launch; LayerNorm of the output + residual in to_out's) against the
+    five-launch form (same LayerNorm arithmetic, the convs' products in another K association: 2e-5) and against torch; ragged pixel
+    tiles, 64 / 96 / 128 channels."""
+    from diffusion_prior.gaussian_diffusion import LinearAttention, Attention, PreNorm, Residual, _attn_block_nhwc
+    torch.manual_seed(b + hw + dim)
+    att = (LinearAttention if kind == "linear" else Attention)(dim)
+    blk = Residual(PreNorm(dim, att)).to(DEV)
+    for p_ in blk.parameters():
+        p_.data.copy_(torch.randn_like(p_) * (0.2 if p_.dim() > 1 else 0.3) + (1.0 if p_.dim() == 4 and p_.shape[0] == 1 else 0.0))
+    x = torch.randn(b, hw, hw, dim, device=DEV)
+    K.start_trace()
+    fused = _attn_block_nhwc(blk, x, "f32")
+    labels = [e["label"] for e in K.stop_trace()]
+    assert sum(lb.startswith("conv1x1_ln") for lb in labels) == (2 if kind == "linear" else 1), labels
+    assert not any(lb.startswith("chan_layernorm") for lb in labels), labels
+    K.set_conv_ln_fused(False)
+    try:
+        plain = _attn_block_nhwc(blk, x, "f32")
+    finally:
+        K.set_conv_ln_fused(True)
+    assert_close(fused, plain, 2e-5, "LayerNorms inside the convs vs five launches")
+    # torch reference of the block (reference gaussian_diffusion.py:200-209, :305-358)
+    xc = x.permute(0, 3, 1, 2).double().cpu()
+    ln = lambda t, g: (t - t.mean(1, keepdim=True)) * (t.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt() * g.double().cpu()
+    xn = ln(xc, blk.fn.norm.g)
+    qkv = torch.nn.functional.conv2d(xn, att.to_qkv.weight.double().cpu())
+    q, k, v = [t.reshape(b, att.heads, att.dim_head, hw * hw) for t in qkv.chunk(3, dim=1)]
+    if kind == "linear":
+        q = q.softmax(dim=-2) * att.scale
+        k = k.softmax(dim=-1)
+        v = v / (hw * hw)
+        ctx = torch.einsum("bhdn,bhen->bhde", k, v)
+        out = torch.einsum("bhde,bhdn->bhen", ctx, q).reshape(b, -1, hw, hw)
+        out = torch.nn.functional.conv2d(out, att.to_out[0].weight.double().cpu(), att.to_out[0].bias.double().cpu())
+        out = ln(out, att.to_out[1].g)
+    else:
+        sim = torch.einsum("bhdi,bhdj->bhij", q * att.scale, k)
+        out = torch.einsum("bhij,bhdj->bhid", sim.softmax(dim=-1), v)
+        out = out.permute(0, 1, 3, 2).reshape(b, -1, hw, hw)
+        out = torch.nn.functional.conv2d(out, att.to_out.weight.double().cpu(), att.to_out.bias.double().cpu())
+    assert_close(fused.permute(0, 3, 1, 2), out + xc, 5e-5, "attention block vs torch fp64")
