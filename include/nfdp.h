@@ -421,6 +421,27 @@ int nfdp_conv2d_gn_silu_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, const
                                      const float* gamma, const float* beta, const float* scale_shift, int ss_ld, float eps,
                                      const float* residual, int res_ld, int compute, nfdp_stream_t stream);
 
+/* ResnetBlock.forward :297-302 with block1's GroupNorm -> x*(scale+1)+shift -> SiLU (:267-276) applied by block2's conv instead of a
+ * launch between the two convs - for the stages where a conv workgroup's pixel tile is a PART of an image, so that the one-launch Block
+ * above does not apply.  (1) nfdp_conv2d_stats_nhwc_f32 = nfdp_conv2d_nhwc / nfdp_conv2d_cat_nhwc_f32 (x2 = NULL, Cin2 = 0: one source)
+ * on the split-K fp32 conv, which also writes sums[(tile * groups + g) * 2 + {0, 1}] = fp64 sum of the tile's outputs of group g / of their
+ * squares; nfdp_conv2d_stats_tile returns the pixels per tile (a divisor of H*W; sums holds B*H*W/tile * groups * 2 doubles) or 0 when the
+ * problem does not qualify.  (2) nfdp_conv2d_gnin_nhwc_f32: 3x3 conv (split products) over SiLU(GN(x)*(scale+1)+shift), x the RAW output of
+ * (1), the statistics taken from in_sums (in_tile = (1)'s tile), the normalisation formed while the input tile is staged in LDS - the same
+ * expressions in the same order as nfdp_groupnorm_silu_f32.  out_groups > 0: followed by block2's own Block epilogue (GroupNorm, optional
+ * scale/shift, SiLU, + residual) as in nfdp_conv2d_gn_silu_nhwc_f32; out_groups = 0: the plain conv (+ bias).  nfdp_conv2d_gnin_supported
+ * says whether (2) is available for the geometry. */
+int nfdp_conv2d_stats_tile(int B, int H, int W, int Cin, int Cout, int K, int groups);
+int nfdp_conv2d_stats_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed, float* y,
+                               int y_ld, int B, int H, int W, int Cout, int K, const float* bias, int groups, double* sums, int compute,
+                               nfdp_stream_t stream);
+int nfdp_conv2d_gnin_supported(int B, int H, int W, int Cin, int Cout, int in_groups, int out_groups);
+int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double* in_sums, int in_tile, int in_groups, const float* in_gamma,
+                              const float* in_beta, const float* in_scale_shift, int in_ss_ld, float in_eps, const void* w_packed, float* y,
+                              int y_ld, int B, int H, int W, int Cin, int Cout, const float* bias, int out_groups, const float* out_gamma,
+                              const float* out_beta, const float* out_scale_shift, int out_ss_ld, float out_eps, const float* residual,
+                              int res_ld, nfdp_stream_t stream);
+
 /* ---------------------------------------------------------------- diffusion prior: U-Net blocks
  * (diffusion_prior/gaussian_diffusion.py; the convolutions themselves use nfdp_conv2d_nhwc) */
 /* WeightStandardizedConv2d.forward :189-197: out[o] = (w[o]-mean_o) * rsqrt(var_o(biased) + eps) over fan_in. */

@@ -53,6 +53,19 @@ struct ConvParams {
     // host-side only: compute = NFDP_F32X6 - fp32 storage, every product as six bf16 MFMAs on three-way split operands (the EMU kernels)
     int emu = 0;
     size_t wsplit_off = 0;            // byte offset of the split image behind the fp32 matrix (conv3x3_ldsx_kernel)
+    // GroupNorm of this conv's OUTPUT applied by the conv that reads it (ResnetBlock: block1's norm inside block2's conv): the plain
+    // split-K epilogue also writes, per (pixel tile, group), the fp64 sums of the outputs and of their squares:
+    // gs_out[(tile * gs_groups + group) * 2 + {0, 1}]; a tile is a 1 / 2^k part of one image (nfdp_conv2d_stats_tile)
+    double* gs_out = nullptr;
+    int gs_groups = 0;
+    // ... and the reading side (conv3x3_ldsx_kernel<.., GNIN = true>): x is the RAW output of such a conv; what enters the products is
+    // SiLU(GN(x) * (scale + 1) + shift) (Block.forward, reference gaussian_diffusion.py:267-276), formed while the tile is staged
+    const double* gi_stats = nullptr; // the producer's sums, gi_parts tiles per image
+    const float* gi_gamma = nullptr;
+    const float* gi_beta = nullptr;
+    const float* gi_ss = nullptr;     // [B][2*Cin] rows (scale | shift), row stride gi_ss_ld; null: none
+    int gi_ss_ld = 0, gi_groups = 0, gi_parts = 0;
+    float gi_eps = 0.f;
 };
 
 __device__ __forceinline__ uint2 pack_bf16x4(float4 v) {
@@ -489,6 +502,7 @@ __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part
         }
         return;
     }
+    double gs1 = 0.0, gs2 = 0.0;                                   // (gs_out) this thread's 4 channels: always the same group
 #pragma unroll
     for (int e = 0; e < (NF4 + SK_THREADS - 1) / SK_THREADS; ++e) {
         const int idx = tid + SK_THREADS * e;
@@ -508,6 +522,14 @@ __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part
             const float4 a4 = *reinterpret_cast<const float4*>(P.add + n);
             o[0] = __fadd_rn(o[0], a4.x); o[1] = __fadd_rn(o[1], a4.y); o[2] = __fadd_rn(o[2], a4.z); o[3] = __fadd_rn(o[3], a4.w);
         }
+        if (P.gs_out) {                                            // (uniform; host: no mul / relu, whole tiles, Cout % 64 == 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double d = (double)o[r];
+                gs1 += d;
+                gs2 += d * d;
+            }
+        }
         if (P.mul) {
             const float4 m4 = *reinterpret_cast<const float4*>(P.mul + n);
             float mv[4] = {m4.x, m4.y, m4.z, m4.w};
@@ -522,6 +544,32 @@ __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part
             for (int r = 0; r < 4; ++r) o[r] = fmaxf(o[r], 0.f);
         }
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + p * P.y_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (P.gs_out) {
+        // the tile's sums per group: lanes that hold the same group meet by xor-shuffles (lane bits 4, 5: other pixels; the low bits below
+        // cpg / 4: the group's other channel quads), the waves in LDS, summed in wave order - fp64 throughout, a fixed association
+        __shared__ double gsw[SK_WAVES][16][2];
+        const int cpg = P.Cout / P.gs_groups, lpg = cpg >> 2;      // lanes (of the low 16) per group
+        gs1 += __shfl_xor(gs1, 16); gs2 += __shfl_xor(gs2, 16);
+        gs1 += __shfl_xor(gs1, 32); gs2 += __shfl_xor(gs2, 32);
+        for (int o = 1; o < lpg; o <<= 1) {
+            gs1 += __shfl_xor(gs1, o);
+            gs2 += __shfl_xor(gs2, o);
+        }
+        const int lane = tid & 63;
+        if (lane < 16 && (lane & (lpg - 1)) == 0) {
+            gsw[wave][lane / lpg][0] = gs1;
+            gsw[wave][lane / lpg][1] = gs2;
+        }
+        __syncthreads();
+        const int gpt = 64 / cpg;                                  // groups of this 64-channel tile
+        if (tid < 2 * gpt) {
+            const int g = tid >> 1, k = tid & 1;
+            double t = gsw[0][g][k];
+#pragma unroll
+            for (int w = 1; w < SK_WAVES; ++w) t += gsw[w][g][k];
+            P.gs_out[((m0 / MT) * P.gs_groups + n0 / cpg + g) * 2 + k] = t;
+        }
     }
 }
 
@@ -722,8 +770,15 @@ __device__ __forceinline__ void static_for_lx(F&& f) {
 }
 constexpr int LX_BLOCK = 12 * 1024;                    // bytes of one (row tile, stage) block of the split image
 static inline int ldsx_np(int W, int pt) { return 16 * pt + 2 * (W + 1); }
-static inline size_t ldsx_bytes(int W, int Cin, int pt) {
-    const size_t planes = (size_t)3 * (ldsx_np(W, pt) + 1) * (Cin + 8) * 2;
+// (GNIN) samples a workgroup's staged pixel range can touch, and its coefficient tables behind the planes: (mean, rstd) per (sample,
+// group), gamma | beta per channel, (scale + 1) | shift per (sample, channel)
+static inline int ldsx_gi_samples(int W, int HW, int pt) { return (ldsx_np(W, pt) - 2) / HW + 2; }
+static inline size_t ldsx_gi_bytes(int W, int HW, int Cin, int groups, int pt) {
+    return (size_t)(ldsx_gi_samples(W, HW, pt) * (2 * groups + 2 * Cin) + 2 * Cin) * 4;
+}
+static inline size_t ldsx_planes_bytes(int W, int Cin, int pt) { return (size_t)3 * (ldsx_np(W, pt) + 1) * (Cin + 8) * 2; }
+static inline size_t ldsx_bytes(int W, int Cin, int pt, int HW = 0, int gi_groups = 0) {
+    const size_t planes = ldsx_planes_bytes(W, Cin, pt) + (gi_groups ? ldsx_gi_bytes(W, HW, Cin, gi_groups, pt) : 0);
     const size_t part = (size_t)LX_WAVES * 16 * pt * SK_LD * 4;
     return planes > part ? planes : part;
 }
@@ -748,7 +803,7 @@ static inline size_t split_image_bytes(int rows, int Kpad) { return (size_t)cdiv
 #define LX_STAMP(i)
 #endif
 
-template <int PT, bool GN>
+template <int PT, bool GN, bool GNIN = false>
 __global__ void __launch_bounds__(LX_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv3x3_ldsx_kernel(const ConvParams P) {
     constexpr int MT = 16 * PT, NT_ = LX_WAVES * 64;
@@ -771,6 +826,43 @@ conv3x3_ldsx_kernel(const ConvParams P) {
 #endif
     LX_STAMP(0);
 
+    // ---- (GNIN) the GroupNorm of the input: x holds the RAW output of the producing conv, whose epilogue left per (tile, group) the fp64
+    // sums of the values and of their squares (gi_parts tiles per image).  The samples this workgroup's pixel range touches get their
+    // (mean, rstd) below, while the first x units fly
+    float* const gi_mr = reinterpret_cast<float*>(smem + 3 * PS);              // [nbl][groups] (mean, rstd)
+    const int gi_nbl = GNIN ? (NP - 2) / HW + 2 : 0;
+    float* const gi_gb = gi_mr + gi_nbl * 2 * P.gi_groups;                     // [Cin] gamma, [Cin] beta
+    float* const gi_sh = gi_gb + 2 * P.Cin;                                    // [nbl][Cin] scale + 1, [nbl][Cin] shift
+    const int lhw = __builtin_ctz((unsigned)HW);                               // (GNIN: HW is a power of two)
+    const int gi_b0 = (int)((m0 > HALO ? m0 - HALO : 0) >> lhw);              // first sample of the range
+    const int gi_lcpg = GNIN ? __builtin_ctz((unsigned)(P.Cin / P.gi_groups)) : 0;   // (channels per group: a power of two)
+    // this thread's first-round pieces of the tables are requested here, in front of the x units and the weights in the load queue: LP
+    // lanes per (sample, group) set take the set's tiles side by side (one L2 round trip instead of one per tile)
+    double2 gi_v0 = make_double2(0.0, 0.0);
+    float4 gi_g0 = make_float4(0.f, 0.f, 0.f, 0.f), gi_b0v = gi_g0, gi_s0 = gi_g0, gi_h0 = gi_g0;
+    if constexpr (GNIN) {
+        const int nB = (int)(P.npix >> lhw), q4 = P.Cin / 4;
+        const int LP = P.gi_parts < 16 ? P.gi_parts : 16, lsh = __builtin_ctz((unsigned)LP);          // (tiles per image: a power of two)
+        const int nset = gi_nbl * P.gi_groups;
+        {
+            const int st = tid >> lsh, j = tid & (LP - 1);
+            const int stc = st < nset ? st : nset - 1;
+            const int bl = stc / P.gi_groups, g = stc - bl * P.gi_groups;
+            const int b = gi_b0 + bl < nB ? gi_b0 + bl : nB - 1;
+            gi_v0 = *reinterpret_cast<const double2*>(P.gi_stats + (((size_t)b * P.gi_parts + j) * P.gi_groups + g) * 2);
+        }
+        if (tid < q4) {
+            gi_g0 = *reinterpret_cast<const float4*>(P.gi_gamma + 4 * tid);
+            gi_b0v = *reinterpret_cast<const float4*>(P.gi_beta + 4 * tid);
+        }
+        if (P.gi_ss && tid < gi_nbl * q4) {
+            const int bl = tid / q4, c4 = (tid - bl * q4) * 4;
+            const int b = gi_b0 + bl < nB ? gi_b0 + bl : nB - 1;
+            const float* sr = P.gi_ss + (size_t)b * P.gi_ss_ld;
+            gi_s0 = *reinterpret_cast<const float4*>(sr + c4);
+            gi_h0 = *reinterpret_cast<const float4*>(sr + P.Cin + c4);
+        }
+    }
     // ---- staging, part 1: the loads.  16 threads take the 64 channels of a channel block of one pixel (256 contiguous bytes), a pass
     // covers 16 pixel rows; a thread's units are (pass, channel block) pairs, requested UB at a time - no division anywhere.  Flat pixels
     // g = m0 - HALO + row, row = 0 .. NP-1; rows outside the tensor are zeros
@@ -810,15 +902,44 @@ conv3x3_ldsx_kernel(const ConvParams P) {
     };
     auto stage_store = [&](const Units& u, int pass0, int cb) {
         const int c = sc + 64 * cb;
+        const int cl = c < P.Cin ? c : 0;
+        float4 ga, be;
+        if constexpr (GNIN) {
+            ga = *reinterpret_cast<const float4*>(gi_gb + cl);
+            be = *reinterpret_cast<const float4*>(gi_gb + P.Cin + cl);
+        }
 #pragma unroll
         for (int e = 0; e < UB; ++e) {
             const int row = srow + 16 * (pass0 + e);
             const unsigned k = (u.ok >> e) & 1u ? 0xffffffffu : 0u;
+            float4 x4 = u.v[e];
+            if (GNIN && 16 * (pass0 + e) < NP) {                   // (uniform: a pass wholly beyond the range is masked anyway)
+                // the same expressions in the same order as groupnorm_silu_kernel (unet.hip); masked units compute on valid data
+                const int g = grow0 + 16 * (pass0 + e);
+                const int gc = g < 0 ? 0 : (g < npix_s ? g : npix_s - 1);
+                int bl = (gc >> lhw) - gi_b0;
+                bl = bl < gi_nbl ? bl : gi_nbl - 1;                // (rows beyond the range: masked units)
+                const float2 mr = *reinterpret_cast<const float2*>(gi_mr + 2 * (bl * P.gi_groups + (cl >> gi_lcpg)));
+                float o[4] = {x4.x, x4.y, x4.z, x4.w};
+                const float gq[4] = {ga.x, ga.y, ga.z, ga.w}, bq[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[r], mr.x), mr.y), gq[r]), bq[r]);
+                if (P.gi_ss) {                                     // (uniform)
+                    const float4 s1 = *reinterpret_cast<const float4*>(gi_sh + bl * P.Cin + cl);
+                    const float4 sh = *reinterpret_cast<const float4*>(gi_sh + (gi_nbl + bl) * P.Cin + cl);
+                    const float sq[4] = {s1.x, s1.y, s1.z, s1.w}, hq[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = __fadd_rn(__fmul_rn(o[r], sq[r]), hq[r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = o[r] / (1.0f + expf(-o[r]));
+                x4 = make_float4(o[0], o[1], o[2], o[3]);
+            }
             float4 v;
-            v.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, u.v[e].x) & k);
-            v.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, u.v[e].y) & k);
-            v.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, u.v[e].z) & k);
-            v.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, u.v[e].w) & k);
+            v.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x4.x) & k);
+            v.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x4.y) & k);
+            v.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x4.z) & k);
+            v.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x4.w) & k);
             uint2 h4, m4, l4;
             split3x4(v, h4, m4, l4);
             if (row < NP && c < P.Cin) {
@@ -855,12 +976,64 @@ conv3x3_ldsx_kernel(const ConvParams P) {
 #pragma unroll
     for (int b = 0; b < LX_NBUF - 1; ++b) loadw(wf[b], b);
 
+    // ---- (GNIN) the coefficient tables from what was requested at the top (the rounds beyond the first: small batches of large images)
+    if constexpr (GNIN) {
+        const int nB = (int)(P.npix >> lhw), cpg = P.Cin / P.gi_groups, q4 = P.Cin / 4;
+        const int LP = P.gi_parts < 16 ? P.gi_parts : 16, lsh = __builtin_ctz((unsigned)LP);
+        const int nset = gi_nbl * P.gi_groups;
+        for (int st0 = 0; st0 < nset; st0 += NT_ >> lsh) {                                             // (uniform)
+            const int st = st0 + (tid >> lsh), j = tid & (LP - 1);
+            const int stc = st < nset ? st : nset - 1;
+            const int bl = stc / P.gi_groups, g = stc - bl * P.gi_groups;
+            const int b = gi_b0 + bl < nB ? gi_b0 + bl : nB - 1;
+            const double* sp = P.gi_stats + ((size_t)b * P.gi_parts * P.gi_groups + g) * 2;
+            double g1 = gi_v0.x, g2 = gi_v0.y;
+            for (int i = st0 == 0 ? j + LP : j; i < P.gi_parts; i += LP) {
+                const double2 v = *reinterpret_cast<const double2*>(sp + (size_t)i * P.gi_groups * 2);
+                if (st0 != 0 && i == j) { g1 = v.x; g2 = v.y; }
+                else { g1 += v.x; g2 += v.y; }
+            }
+            for (int o = 1; o < LP; o <<= 1) {                                                         // a fixed association
+                g1 += __shfl_xor(g1, o);
+                g2 += __shfl_xor(g2, o);
+            }
+            if (st < nset && j == 0) {
+                const double rn = 1.0 / ((double)HW * cpg);                                            // (a power of two: exact)
+                const double mean = g1 * rn;
+                double var = g2 * rn - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                gi_mr[2 * st] = (float)mean;
+                gi_mr[2 * st + 1] = (float)(1.0 / sqrt(var + (double)P.gi_eps));
+            }
+        }
+        for (int i = tid; i < q4; i += NT_) {
+            const float4 gv = i == tid ? gi_g0 : *reinterpret_cast<const float4*>(P.gi_gamma + 4 * i);
+            const float4 bv = i == tid ? gi_b0v : *reinterpret_cast<const float4*>(P.gi_beta + 4 * i);
+            *reinterpret_cast<float4*>(gi_gb + 4 * i) = gv;
+            *reinterpret_cast<float4*>(gi_gb + P.Cin + 4 * i) = bv;
+        }
+        if (P.gi_ss) {
+            for (int i = tid; i < gi_nbl * q4; i += NT_) {
+                const int bl = i / q4, c4 = (i - bl * q4) * 4;
+                const int b = gi_b0 + bl < nB ? gi_b0 + bl : nB - 1;
+                const float* sr = P.gi_ss + (size_t)b * P.gi_ss_ld;
+                const float4 sc = i == tid ? gi_s0 : *reinterpret_cast<const float4*>(sr + c4);
+                const float4 sh = i == tid ? gi_h0 : *reinterpret_cast<const float4*>(sr + P.Cin + c4);
+                *reinterpret_cast<float4*>(gi_sh + bl * P.Cin + c4) =
+                    make_float4(__fadd_rn(sc.x, 1.0f), __fadd_rn(sc.y, 1.0f), __fadd_rn(sc.z, 1.0f), __fadd_rn(sc.w, 1.0f));
+                *reinterpret_cast<float4*>(gi_sh + (gi_nbl + bl) * P.Cin + c4) = sh;
+            }
+        }
+    }
+
+    LX_STAMP(6);
     // ---- staging, part 2: batch by batch (a batch = UB passes of one channel block; b -> (channel block b / npb, first pass (b % npb) UB)),
     // the next batch's loads in flight while a batch is split into the planes
     {
         const int npb = (npass + UB - 1) / UB, nb = ncb * npb;         // (uniform)
         auto bcb = [&](int bi) { return bi / npb; };
         auto bp0 = [&](int bi) { return (bi - (bi / npb) * npb) * UB; };
+        if constexpr (GNIN) __syncthreads();                           // the coefficient tables are complete
         for (int bi = 0; bi < nb; bi += 2) {
             if (bi + 1 < nb) stage_load(sv[1], bp0(bi + 1), bcb(bi + 1));
             stage_store(sv[0], bp0(bi), bcb(bi));
@@ -1758,33 +1931,66 @@ constexpr size_t kLdsxMax = 160 * 1024;
 static thread_local void* g_lx_stamps = nullptr;
 extern "C" void nfdp_debug_set_conv_stamps(void* p) { g_lx_stamps = p; }
 #endif
+constexpr size_t kLdsxStatic = 1024;                              // the epilogue's group-sum scratch (splitk_epilogue: gsw)
 static bool ldsx_ok(const ConvParams& P, int pt) {
     return g_conv_ldsx && P.KH == 3 && split_image_shape(P.Cout, P.Cin, P.KH, P.KW) && (P.x2 == nullptr || P.Cin1 % 4 == 0) &&
            ldsx_np(P.W, pt) <= 1024 &&                 // (images up to ~500 pixels wide: beyond, the halo dwarfs the tile)
-           ldsx_bytes(P.W, P.Cin, pt) <= kLdsxMax;
+           ldsx_bytes(P.W, P.Cin, pt, P.H * P.W, P.gi_stats ? P.gi_groups : 0) + kLdsxStatic <= kLdsxMax;
 }
+template <bool GN, bool GNIN>
+static void launch_ldsx_t(const ConvParams& P, int pt, dim3 grid, hipStream_t s);
 template <bool GN>
 static void launch_ldsx(const ConvParams& P, int pt, dim3 grid, hipStream_t s) {
+    if (P.gi_stats) launch_ldsx_t<GN, true>(P, pt, grid, s);
+    else launch_ldsx_t<GN, false>(P, pt, grid, s);
+}
+template <bool GN, bool GNIN>
+static void launch_ldsx_t(const ConvParams& P, int pt, dim3 grid, hipStream_t s) {
     static NfdpPerDevice attr_set;
     if (!attr_set) {
-        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<4, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsxMax);
-        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<2, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsxMax);
-        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<1, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsxMax);
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<4, GN, GNIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<2, GN, GNIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<1, GN, GNIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
         attr_set = true;
     }
-    const size_t lds = ldsx_bytes(P.W, P.Cin, pt);
+    const size_t lds = ldsx_bytes(P.W, P.Cin, pt, P.H * P.W, GNIN ? P.gi_groups : 0);
     ConvParams Q = P;
     Q.wsplit_off = (size_t)cout_pad_for(P.Cout) * P.Kpad * 4;
 #ifdef NFDP_LX_STAMPS
     Q.part = reinterpret_cast<double*>(g_lx_stamps);
-    if (pt == 4) hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
-    else if (pt == 2) hipLaunchKernelGGL((conv3x3_ldsx_kernel<2, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
-    else hipLaunchKernelGGL((conv3x3_ldsx_kernel<1, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    if (pt == 4) hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else if (pt == 2) hipLaunchKernelGGL((conv3x3_ldsx_kernel<2, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else hipLaunchKernelGGL((conv3x3_ldsx_kernel<1, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
     return;
 #endif
-    if (pt == 4) hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
-    else if (pt == 2) hipLaunchKernelGGL((conv3x3_ldsx_kernel<2, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
-    else hipLaunchKernelGGL((conv3x3_ldsx_kernel<1, GN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    if (pt == 4) hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else if (pt == 2) hipLaunchKernelGGL((conv3x3_ldsx_kernel<2, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else hipLaunchKernelGGL((conv3x3_ldsx_kernel<1, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+}
+
+// ---- a ResnetBlock's first GroupNorm carried from block1's conv to block2's conv (ConvParams::gs_* / gi_*)
+struct ConvExtra {
+    double* gs_out = nullptr;         // producer: per (tile, group) sums of the outputs and their squares
+    int gs_groups = 0;
+    const double* gi_stats = nullptr; // consumer: the producer's sums ...
+    const float* gi_gamma = nullptr;  // ... and the norm's parameters
+    const float* gi_beta = nullptr;
+    const float* gi_ss = nullptr;
+    int gi_ss_ld = 0, gi_groups = 0, gi_parts = 0;
+    float gi_eps = 0.f;
+};
+static void apply_extra(ConvParams& P, const ConvExtra* ex) {
+    if (!ex) return;
+    P.gs_out = ex->gs_out; P.gs_groups = ex->gs_groups;
+    P.gi_stats = ex->gi_stats; P.gi_gamma = ex->gi_gamma; P.gi_beta = ex->gi_beta; P.gi_ss = ex->gi_ss;
+    P.gi_ss_ld = ex->gi_ss_ld; P.gi_groups = ex->gi_groups; P.gi_parts = ex->gi_parts; P.gi_eps = ex->gi_eps;
+}
+static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+// pixels per workgroup of the plain split-K conv for this problem (conv2d_impl's rule), 0 when it takes another kernel
+static int splitk_tile_pixels(long npix, int Cin, int Cout, int K) {
+    if (Cin % 8 != 0 || Cout < 64 || Cout % 4 != 0 || kpad_for(Cin, K, K) < 8 * 32 || cdiv(npix, 64) * cdiv(Cout, 64) > 1024) return 0;
+    const long t64 = cdiv(npix, 64) * cdiv(Cout, 64);
+    return 16 * (t64 >= 256 ? 4 : (2 * t64 >= 256 ? 2 : 1));
 }
 
 // ---- split-K conv with the Block epilogue (GroupNorm -> scale/shift -> SiLU -> + residual) in the same launch
@@ -1809,7 +2015,7 @@ extern "C" int nfdp_conv2d_gn_silu_supported(int B, int H, int W, int Cin, int C
 static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
                                int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
                                const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld, int compute,
-                               nfdp_stream_t stream, const float* x2, int x2_ld, int cin1);
+                               nfdp_stream_t stream, const float* x2, int x2_ld, int cin1, const ConvExtra* ex = nullptr);
 
 extern "C" int nfdp_conv2d_gn_silu_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
                                             int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
@@ -1836,7 +2042,7 @@ extern "C" int nfdp_conv2d_gn_silu_cat_nhwc_f32(const float* x1, int x1_ld, int 
 static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
                                int Cout, int K, const float* bias, int groups, const float* gamma, const float* beta,
                                const float* scale_shift, int ss_ld, float eps, const float* residual, int res_ld, int compute,
-                               nfdp_stream_t stream, const float* x2, int x2_ld, int cin1) {
+                               nfdp_stream_t stream, const float* x2, int x2_ld, int cin1, const ConvExtra* ex) {
     NFDP_REQUIRE(x && w_packed && y && gamma && beta, NFDP_EINVAL, "conv2d_gn_silu: null pointer");
     NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_F32X6, NFDP_EINVAL, "conv2d_gn_silu: compute=%d (fp32 or the six-product split form)", compute);
     NFDP_REQUIRE(nfdp_conv2d_gn_silu_supported(B, H, W, Cin, Cout, K, groups), NFDP_EUNSUPPORTED,
@@ -1857,8 +2063,11 @@ static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, f
     P.gn_gamma = gamma; P.gn_beta = beta; P.gn_ss = scale_shift; P.gn_ss_ld = ss_ld; P.gn_res = residual; P.gn_res_ld = res_ld;
     P.gn_groups = groups; P.gn_eps = eps;
     if (x2) { P.x2 = x2; P.x2_ld = x2_ld; P.Cin1 = cin1; }
+    apply_extra(P, ex);
     P.Nt = (int)cdiv(Cout, 64);
     const int pt = gn_pixel_tiles(npix, Cout, H * W);
+    NFDP_REQUIRE(!P.gi_stats || (compute == NFDP_F32X6 && ldsx_ok(P, pt)), NFDP_EUNSUPPORTED,
+                 "conv2d_gnin: the input GroupNorm rides in the LDS-staged 3x3 conv only (nfdp_conv2d_gnin_supported)");
     P.Mt = (int)cdiv(npix, 16 * pt);
     const dim3 grid(P.Mt * P.Nt);
     hipStream_t s = as_stream(stream);
@@ -1887,7 +2096,8 @@ static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, f
 
 static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
                        int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
-                       float mul_exp, int relu, int compute, nfdp_stream_t stream, const void* x2, int x2_ld, int cin1);
+                       float mul_exp, int relu, int compute, nfdp_stream_t stream, const void* x2, int x2_ld, int cin1,
+                       const ConvExtra* ex = nullptr);
 
 extern "C" int nfdp_conv2d_nhwc(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
                                 int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
@@ -1909,6 +2119,79 @@ extern "C" int nfdp_conv2d_cat_nhwc_f32(const float* x1, int x1_ld, int Cin1, co
                  NFDP_ESHAPE, "conv2d_cat: input rows must be 16-byte aligned");
     return conv2d_impl(x1, NFDP_F32, x1_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin1 + Cin2, Cout, K, K, add, nullptr, 0.f, 0, compute,
                        stream, x2, x2_ld, Cin1);
+}
+
+// ---- ResnetBlock (reference gaussian_diffusion.py:279-302): block1's GroupNorm -> scale/shift -> SiLU inside block2's conv.  A GroupNorm
+// needs a whole (sample, group) before its first output; where a conv's workgroup tile is PART of an image (the 16x16 / 8x8 stages at
+// sampling batch sizes) the norm was a launch of its own between the two convs.  Now block1's conv also leaves the fp64 sums of every
+// (tile, group) (nfdp_conv2d_stats_nhwc_f32), and block2's conv - which stages its input tile in LDS anyway - adds them up per sample and
+// normalises while it stages (nfdp_conv2d_gnin_nhwc_f32): the normalised tensor is never written, one launch of ~6 us per ResnetBlock gone.
+extern "C" int nfdp_conv2d_stats_tile(int B, int H, int W, int Cin, int Cout, int K, int groups) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || groups <= 0 || (K % 2) != 1 || K > 7) return 0;
+    if (Cout % 64 != 0 || Cout % groups != 0) return 0;
+    const int cpg = Cout / groups, HW = H * W;
+    if (!pow2(cpg) || cpg < 4 || cpg > 64) return 0;
+    const int mt = splitk_tile_pixels((long)B * HW, Cin, Cout, K);
+    return (mt > 0 && HW % mt == 0) ? mt : 0;          // whole tiles, each inside one image
+}
+
+extern "C" int nfdp_conv2d_stats_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed,
+                                          float* y, int y_ld, int B, int H, int W, int Cout, int K, const float* bias, int groups,
+                                          double* sums, int compute, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x1 && sums, NFDP_EINVAL, "conv2d_stats: null pointer");
+    NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_F32X6, NFDP_EINVAL, "conv2d_stats: compute=%d (fp32 or the six-product split form)", compute);
+    NFDP_REQUIRE((x2 == nullptr) == (Cin2 == 0) && Cin1 > 0 && Cin2 >= 0, NFDP_EINVAL, "conv2d_stats: second source and Cin2 go together");
+    NFDP_REQUIRE(nfdp_conv2d_stats_tile(B, H, W, Cin1 + Cin2, Cout, K, groups) != 0, NFDP_EUNSUPPORTED,
+                 "conv2d_stats: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d K=%d groups=%d", B, H, W, Cin1 + Cin2, Cout, K, groups);
+    NFDP_REQUIRE(x1_ld % 4 == 0 && y_ld % 4 == 0 && (((uintptr_t)x1 | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)sums) % 16) == 0, NFDP_ESHAPE,
+                 "conv2d_stats: rows and vectors must be 16-byte aligned");
+    if (x2) {
+        NFDP_REQUIRE(Cin1 % 8 == 0 && Cin2 % 4 == 0 && x2_ld >= Cin2 && x2_ld % 4 == 0 && ((uintptr_t)x2 % 16) == 0, NFDP_ESHAPE,
+                     "conv2d_stats: two sources: %d + %d channels (first a multiple of 8, second of 4), 16-byte aligned rows", Cin1, Cin2);
+    }
+    ConvExtra ex;
+    ex.gs_out = sums; ex.gs_groups = groups;
+    return conv2d_impl(x1, NFDP_F32, x1_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin1 + Cin2, Cout, K, K, bias, nullptr, 0.f, 0, compute, stream,
+                       x2, x2_ld, x2 ? Cin1 : 0, &ex);
+}
+
+extern "C" int nfdp_conv2d_gnin_supported(int B, int H, int W, int Cin, int Cout, int in_groups, int out_groups) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || in_groups <= 0 || in_groups % 2 != 0 || Cin % in_groups != 0) return 0;
+    const int cpg = Cin / in_groups, HW = H * W;
+    if (!pow2(cpg) || cpg < 4 || !pow2(HW) || !g_conv_ldsx) return 0;
+    const long npix = (long)B * HW;
+    int pt;
+    if (out_groups > 0) {
+        if (!nfdp_conv2d_gn_silu_supported(B, H, W, Cin, Cout, 3, out_groups)) return 0;
+        pt = gn_pixel_tiles(npix, Cout, HW);
+    } else {
+        pt = splitk_tile_pixels(npix, Cin, Cout, 3) / 16;
+    }
+    if (pt == 0 || !split_image_shape(Cout, Cin, 3, 3) || ldsx_np(W, pt) > 1024) return 0;
+    return ldsx_bytes(W, Cin, pt, HW, in_groups) + kLdsxStatic <= kLdsxMax;
+}
+
+extern "C" int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double* in_sums, int in_tile, int in_groups, const float* in_gamma,
+                                         const float* in_beta, const float* in_scale_shift, int in_ss_ld, float in_eps, const void* w_packed,
+                                         float* y, int y_ld, int B, int H, int W, int Cin, int Cout, const float* bias, int out_groups,
+                                         const float* out_gamma, const float* out_beta, const float* out_scale_shift, int out_ss_ld,
+                                         float out_eps, const float* residual, int res_ld, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && in_sums && in_gamma && in_beta && w_packed && y, NFDP_EINVAL, "conv2d_gnin: null pointer");
+    NFDP_REQUIRE(nfdp_conv2d_gnin_supported(B, H, W, Cin, Cout, in_groups, out_groups), NFDP_EUNSUPPORTED,
+                 "conv2d_gnin: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d groups %d -> %d", B, H, W, Cin, Cout, in_groups, out_groups);
+    NFDP_REQUIRE(in_tile > 0 && (H * W) % in_tile == 0, NFDP_ESHAPE, "conv2d_gnin: in_tile=%d does not divide the image (nfdp_conv2d_stats_tile)", in_tile);
+    NFDP_REQUIRE(in_scale_shift == nullptr || in_ss_ld >= 2 * Cin, NFDP_ESHAPE, "conv2d_gnin: scale_shift rows shorter than 2*Cin");
+    NFDP_REQUIRE(x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)in_sums | (uintptr_t)in_gamma | (uintptr_t)in_beta | (uintptr_t)in_scale_shift) % 16) == 0 &&
+                 in_ss_ld % 4 == 0, NFDP_ESHAPE, "conv2d_gnin: rows and vectors must be 16-byte aligned");
+    NFDP_REQUIRE(out_groups > 0 || residual == nullptr, NFDP_EINVAL, "conv2d_gnin: a residual goes with the output Block (out_groups > 0)");
+    ConvExtra ex;
+    ex.gi_stats = in_sums; ex.gi_gamma = in_gamma; ex.gi_beta = in_beta; ex.gi_ss = in_scale_shift; ex.gi_ss_ld = in_ss_ld;
+    ex.gi_groups = in_groups; ex.gi_parts = (H * W) / in_tile; ex.gi_eps = in_eps;
+    if (out_groups > 0)
+        return conv2d_gn_silu_impl(x, x_ld, w_packed, y, y_ld, B, H, W, Cin, Cout, 3, bias, out_groups, out_gamma, out_beta, out_scale_shift,
+                                   out_ss_ld, out_eps, residual, res_ld, NFDP_F32X6, stream, nullptr, 0, 0, &ex);
+    return conv2d_impl(x, NFDP_F32, x_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin, Cout, 3, 3, bias, nullptr, 0.f, 0, NFDP_F32X6, stream,
+                       nullptr, 0, 0, &ex);
 }
 
 // 1x1 conv with the channel LayerNorm of its input (pre_gain) and / or of its output (post_gain, + residual) in the same launch: the
@@ -1960,7 +2243,8 @@ extern "C" int nfdp_conv1x1_ln_f32(const float* x, int x_ld, const void* w_packe
 
 static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packed, void* y, int y_dtype, int y_ld,
                        int B, int H, int W, int Cin, int Cout, int KH, int KW, const float* add, const float* mul,
-                       float mul_exp, int relu, int compute, nfdp_stream_t stream, const void* x2, int x2_ld, int cin1) {
+                       float mul_exp, int relu, int compute, nfdp_stream_t stream, const void* x2, int x2_ld, int cin1,
+                       const ConvExtra* ex) {
     NFDP_REQUIRE(x && w_packed && y, NFDP_EINVAL, "conv2d: null pointer");
     NFDP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, NFDP_ESHAPE, "conv2d: bad shape");
     NFDP_REQUIRE(KH == KW && (KH % 2) == 1 && KH <= 7, NFDP_EUNSUPPORTED, "conv2d: kernel %dx%d (odd square <= 7 only)", KH, KW);
@@ -1982,6 +2266,7 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
     P.K = Cin * KH * KW; P.Kpad = kpad_for(Cin, KH, KW); P.relu = relu; P.Mt = 0; P.Nt = 0; P.mul_exp = mul_exp;
     P.emu = emu;
     if (x2) { P.x2 = x2; P.x2_ld = x2_ld; P.Cin1 = cin1; }
+    apply_extra(P, ex);
     const int esz = (x_dtype == NFDP_BF16) ? 2 : 4;
     // vector path: 4 consecutive k stay inside one tap and the 4-element load is naturally aligned
     const bool vec = (Cin % 4 == 0) && (x_ld % 4 == 0) && (((uintptr_t)x) % (4 * esz) == 0);
@@ -2022,6 +2307,8 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
             sk_attr_set = true;
         }
+        NFDP_REQUIRE(!P.gi_stats || (emu && ldsx_ok(P, pt)), NFDP_EUNSUPPORTED,
+                     "conv2d_gnin: the input GroupNorm rides in the LDS-staged 3x3 conv only (nfdp_conv2d_gnin_supported)");
         if (emu && ldsx_ok(P, pt)) {  // fp32 products as six bf16 MFMAs (NFDP_F32X6), 3x3: the input tile staged and split once in LDS
             launch_ldsx<false>(P, pt, grid, s);
         } else if (emu) {             // ... operands gathered per tap
@@ -2036,6 +2323,7 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
         NFDP_CHECK_LAUNCH("conv2d (split-K fp32)");
         return NFDP_OK;
     }
+    NFDP_REQUIRE(!P.gs_out && !P.gi_stats, NFDP_EUNSUPPORTED, "conv2d_stats / conv2d_gnin: this problem does not take the split-K kernels");
     if (compute == NFDP_F32) {
         if (vec) launch_by_cout<false, false, true>(P, s);
         else launch_by_cout<false, false, false>(P, s);

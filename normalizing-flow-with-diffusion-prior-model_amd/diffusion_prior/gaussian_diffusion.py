@@ -223,9 +223,30 @@ class ResnetBlock(nn.Module):
             if not (K.compute_enum(compute) == K.F32 and not torch.is_grad_enabled() and isinstance(self.res_conv, _Conv)
                     and K.cat_sources_ok(xh, x2)):
                 xh, x2 = K.concat_channels(xh, x2), None
-        h = self.block1.forward_nhwc(xh, ss, compute, x2=x2)
+        b1, b2 = self.block1, self.block2
+        if K.compute_enum(compute) == K.F32 and not torch.is_grad_enabled() and b2.proj.k == 3:
+            # where a conv workgroup's tile is a part of an image (the one-launch Block does not apply) block1's GroupNorm rides in
+            # block2's conv: block1's conv leaves the group sums, block2's conv normalises while it stages its input tile
+            e2 = 0 if x2 is None else x2.shape[3]
+            p1 = (b1.proj.bias, b1.norm.weight, b1.norm.bias)
+            if not K.conv2d_gn_silu_supported(xh, b1.proj.cout, b1.proj.k, b1.norm.num_groups, *p1, extra_cin=e2):
+                fused2 = K.conv2d_gn_silu_shape_supported(xh.shape[0], xh.shape[1], xh.shape[2], b2.proj.cin, b2.proj.cout, 3, b2.norm.num_groups)
+                if K.conv2d_gn_carried_supported(xh, b1.proj.cout, b1.proj.k, b1.norm.num_groups, b2.norm.num_groups, fused2, *p1,
+                                                 b2.proj.bias, b2.norm.weight, b2.norm.bias, ss, extra_cin=e2):
+                    cenum = K.compute_enum(compute)
+                    raw, sums, tile = K.conv2d_stats(xh, b1.proj.packed(cenum), b1.proj.cout, b1.proj.k, b1.proj.bias, b1.norm.num_groups, x2=x2)
+                    res = self.res_conv.forward_nhwc(xh, compute, x2=x2) if isinstance(self.res_conv, _Conv) else xh
+                    res = res.contiguous()
+                    if fused2:
+                        return K.conv2d_gnin(raw, sums, tile, b1.norm.num_groups, b1.norm.weight, b1.norm.bias, ss, b2.proj.packed(cenum),
+                                             b2.proj.cout, b2.proj.bias, out_groups=b2.norm.num_groups, out_gamma=b2.norm.weight,
+                                             out_beta=b2.norm.bias, residual=res)
+                    h2 = K.conv2d_gnin(raw, sums, tile, b1.norm.num_groups, b1.norm.weight, b1.norm.bias, ss, b2.proj.packed(cenum),
+                                       b2.proj.cout, b2.proj.bias)
+                    return K.groupnorm_silu(h2, b2.norm.num_groups, b2.norm.weight, b2.norm.bias, None, 1e-5, res)
+        h = b1.forward_nhwc(xh, ss, compute, x2=x2)
         res = self.res_conv.forward_nhwc(xh, compute, x2=x2) if isinstance(self.res_conv, _Conv) else xh
-        return self.block2.forward_nhwc(h, None, compute, residual=res.contiguous())   # h + res folded into block2's epilogue
+        return b2.forward_nhwc(h, None, compute, residual=res.contiguous())   # h + res folded into block2's epilogue
 
 
 class LinearAttention(nn.Module):

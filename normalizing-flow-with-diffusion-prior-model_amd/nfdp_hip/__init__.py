@@ -1002,6 +1002,11 @@ def conv2d_gn_silu_supported(xh: torch.Tensor, cout: int, k: int, groups: int, *
     return bool(lib().nfdp_conv2d_gn_silu_supported(b, h, w, cin, cout, k, groups))
 
 
+def conv2d_gn_silu_shape_supported(b: int, h: int, w: int, cin: int, cout: int, k: int, groups: int) -> bool:
+    """conv2d_gn_silu_supported for a fresh (aligned, dense) input of this shape."""
+    return bool(_CONV_GN_FUSED and lib().nfdp_conv2d_gn_silu_supported(b, h, w, cin, cout, k, groups))
+
+
 def cat_sources_ok(x1: torch.Tensor, x2: torch.Tensor) -> bool:
     """Can a conv read torch.cat((x1, x2), dim=-1) from the two tensors (nfdp_conv2d_cat_nhwc_f32 / _gn_silu_cat_)?"""
     if not (_CONV_CAT and x1.is_cuda and x1.dtype == torch.float32 and x2.dtype == torch.float32 and x1.dim() == 4 and x2.dim() == 4):
@@ -1057,6 +1062,74 @@ def conv2d_gn_silu(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bi
     _call("nfdp_conv2d_gn_silu_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_gn_silu"), _ptr(packed), _ptr(y), cout, b, h, w, cin, cout, k,
           _ptr(bias), groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, float(eps), _ptr(residual), res_ld, _f32_compute(F32),
           _stream(), label=f"conv_splitk_f32+gn k{k} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * k * k * cout)
+    return y
+
+
+_CONV_GN_CARRIED = True
+
+
+def set_conv_gn_carried(on: bool) -> None:
+    """ResnetBlock: block1's GroupNorm inside block2's conv where a conv tile is part of an image (default) or as a launch of its own."""
+    global _CONV_GN_CARRIED
+    _CONV_GN_CARRIED = bool(on)
+
+
+def conv2d_gn_carried_supported(xh: torch.Tensor, cmid: int, k: int, groups1: int, groups2: int, fused2: bool, *vectors,
+                                extra_cin: int = 0) -> bool:
+    """Both halves of the carried GroupNorm are available: conv (xh [+ extra_cin channels of a second source]) -> cmid with group sums
+    (nfdp_conv2d_stats_*), then the 3x3 conv cmid -> cmid that normalises on load (nfdp_conv2d_gnin_*; fused2: with its own Block
+    epilogue).  fp32 NHWC, no grad, split-product fp32 mode, 16-byte aligned vectors."""
+    if not (_CONV_GN_CARRIED and _F32_PRODUCTS == "bf16x6" and xh.is_cuda and xh.dtype == torch.float32 and xh.dim() == 4 and
+            xh.stride(3) == 1 and not torch.is_grad_enabled()):
+        return False
+    if xh.data_ptr() % 16 or xh.stride(2) % 4 or any(v is not None and v.data_ptr() % 16 for v in vectors):
+        return False
+    b, h, w, cin = xh.shape
+    if not lib().nfdp_conv2d_stats_tile(b, h, w, cin + extra_cin, cmid, k, groups1):
+        return False
+    return bool(lib().nfdp_conv2d_gnin_supported(b, h, w, cmid, cmid, groups1, groups2 if fused2 else 0))
+
+
+def conv2d_stats(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bias, groups: int, x2: Optional[torch.Tensor] = None):
+    """conv2d (of torch.cat((xh, x2), -1) when x2 is given) that also leaves the fp64 (sum, sum of squares) of every (pixel tile, group) of
+    its output (nfdp_conv2d_stats_nhwc_f32) -> (y, sums [tiles, groups, 2], pixels per tile)."""
+    _need(xh, torch.float32, "conv2d_stats")
+    b, h, w, c1 = xh.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    tile = int(lib().nfdp_conv2d_stats_tile(b, h, w, c1 + c2, cout, k, groups))
+    if tile <= 0:
+        raise ValueError(f"conv2d_stats: unsupported geometry {tuple(xh.shape)} (+{c2}) -> {cout}, k={k}, groups={groups}")
+    y = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
+    sums = torch.empty((b * h * w // tile, groups, 2), device=xh.device, dtype=torch.float64)
+    _call("nfdp_conv2d_stats_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_stats"), c1, _ptr(x2), 0 if x2 is None else _ld(x2, "conv2d_stats"), c2,
+          _ptr(packed), _ptr(y), cout, b, h, w, cout, k, _ptr(bias), groups, _ptr(sums), _f32_compute(F32), _stream(),
+          label=f"conv_splitk_f32+sums{' cat' if c2 else ''} k{k} {c1}{'+' + str(c2) if c2 else ''}->{cout} hw{h}", flops=2.0 * b * h * w * (c1 + c2) * k * k * cout)
+    return y, sums, tile
+
+
+def conv2d_gnin(xh: torch.Tensor, sums: torch.Tensor, tile: int, in_groups: int, in_gamma, in_beta, in_scale_shift, packed: torch.Tensor,
+                cout: int, bias, in_eps: float = 1e-5, out_groups: int = 0, out_gamma=None, out_beta=None, out_scale_shift=None,
+                out_eps: float = 1e-5, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 conv over SiLU(GroupNorm(xh) * (scale + 1) + shift), xh the raw output and `sums` the group sums of conv2d_stats
+    (nfdp_conv2d_gnin_nhwc_f32); out_groups > 0: followed by the conv's own Block epilogue (+ residual)."""
+    _need(xh, torch.float32, "conv2d_gnin"); _need(sums, torch.float64, "conv2d_gnin")
+    b, h, w, cin = xh.shape
+    y = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
+
+    def _ss_ld(ss, c):
+        if ss is None:
+            return 0
+        assert ss.shape == (b, 2 * c) and ss.stride(1) == 1
+        return ss.stride(0) if b > 1 else 2 * c
+    res_ld = 0
+    if residual is not None:
+        _need(residual, torch.float32, "conv2d_gnin residual"); _dense(residual, "conv2d_gnin residual")
+        assert residual.shape == y.shape
+        res_ld = cout
+    _call("nfdp_conv2d_gnin_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_gnin"), _ptr(sums), int(tile), in_groups, _ptr(in_gamma), _ptr(in_beta),
+          _ptr(in_scale_shift), _ss_ld(in_scale_shift, cin), float(in_eps), _ptr(packed), _ptr(y), cout, b, h, w, cin, cout, _ptr(bias),
+          out_groups, _ptr(out_gamma), _ptr(out_beta), _ptr(out_scale_shift), _ss_ld(out_scale_shift, cout), float(out_eps), _ptr(residual),
+          res_ld, _stream(), label=f"conv3x3_ldsx gn-in{'+gn' if out_groups else ''} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * 9 * cout)
     return y
 
 

@@ -68,6 +68,19 @@ def test_argument_validation_without_gpu():
     assert l.nfdp_conv_packed_bytes(64, 64, 3, 3, 0) == 64 * 576 * 4 + 1 * 18 * 12288
     assert l.nfdp_conv_packed_bytes(100, 96, 3, 3, 0) == 128 * 896 * 4 + 2 * 28 * 12288
     assert l.nfdp_conv_packed_bytes(64, 64, 3, 3, 1) == 64 * 576 * 2 and l.nfdp_conv_packed_bytes(64, 40, 3, 3, 0) == 64 * 384 * 4
+    # a ResnetBlock's first GroupNorm carried into its second conv: the producer's tile (a part of an image), the consumer's geometry
+    assert l.nfdp_conv2d_stats_tile(64, 16, 16, 64, 64, 3, 8) == 64 and l.nfdp_conv2d_stats_tile(64, 8, 8, 192, 128, 3, 8) == 32
+    assert l.nfdp_conv2d_stats_tile(4, 16, 16, 64, 64, 3, 8) == 16 and l.nfdp_conv2d_stats_tile(64, 4, 4, 64, 64, 3, 8) == 16
+    assert l.nfdp_conv2d_stats_tile(1100, 4, 4, 64, 64, 3, 8) == 0         # a tile of several images: the one-launch Block's case
+    assert l.nfdp_conv2d_stats_tile(64, 16, 16, 64, 96, 3, 8) == 0 and l.nfdp_conv2d_stats_tile(64, 16, 16, 64, 64, 3, 32) == 0
+    assert l.nfdp_conv2d_gnin_supported(64, 16, 16, 64, 64, 8, 0) == 1 and l.nfdp_conv2d_gnin_supported(64, 8, 8, 128, 128, 8, 0) == 1
+    assert l.nfdp_conv2d_gnin_supported(64, 12, 12, 64, 64, 8, 0) == 0     # H*W not a power of two
+    assert l.nfdp_conv2d_gnin_supported(64, 16, 16, 160, 64, 8, 0) == 0    # 20 channels per group / no split image beyond 128 inputs
+    assert l.nfdp_conv2d_gnin_supported(64, 16, 16, 64, 64, 8, 8) == 0 and l.nfdp_conv2d_gnin_supported(64, 4, 4, 64, 64, 8, 8) == 1
+    assert l.nfdp_conv2d_stats_nhwc_f32(p, 64, 64, None, 0, 0, p, p, 64, 64, 16, 16, 64, 3, None, 8, None, 0, None) == -1
+    assert l.nfdp_conv2d_stats_nhwc_f32(p, 64, 64, None, 0, 0, p, p, 64, 64, 12, 12, 96, 3, None, 8, p, 0, None) == -3
+    assert l.nfdp_conv2d_gnin_nhwc_f32(p, 64, p, 48, 8, p, p, None, 0, 1e-5, p, p, 64, 64, 16, 16, 64, 64, None, 0, None, None, None, 0,
+                                       1e-5, None, 0, None) == -2           # in_tile does not divide the image
     # empty batches are a no-op, not an error
     assert l.nfdp_squeeze_nhwc_f32(p, 3, p, 0, 3, 4, 4, None) == 0
     assert l.nfdp_coupling_fwd_f32(p, p, 0, 4, 4, None, None, None) == 0

@@ -574,3 +574,88 @@ def test_attention_block_with_layernorms_inside_the_1x1_convs(b, hw, dim, kind):
         out = out.permute(0, 1, 3, 2).reshape(b, -1, hw, hw)
         out = torch.nn.functional.conv2d(out, att.to_out.weight.double().cpu(), att.to_out.bias.double().cpu())
     assert_close(fused.permute(0, 3, 1, 2), out + xc, 5e-5, "attention block vs torch fp64")
+
+
+@pytest.mark.parametrize("b,hw,cin,c2,cout,groups", [(64, 16, 64, 0, 64, 8), (64, 16, 64, 64, 64, 8), (64, 8, 128, 0, 128, 8), (64, 8, 128, 64, 128, 8),
+                                                     (3, 16, 64, 0, 128, 16), (5, 8, 64, 0, 64, 4), (2, 32, 32, 0, 64, 8)])
+@torch.no_grad()
+def test_resnet_block_with_the_first_groupnorm_inside_the_second_conv(b, hw, cin, c2, cout, groups):
+    """ResnetBlock (reference gaussian_diffusion.py:279-302) where a conv workgroup's tile is a part of an image: block1's conv leaves the
+    fp64 group sums of its tiles (nfdp_conv2d_stats_nhwc_f32), block2's conv normalises its input while staging it
+    (nfdp_conv2d_gnin_nhwc_f32) - against the launch-per-op form (same conv, same GroupNorm expressions; the statistics are sums of
+    per-tile fp64 sums instead of a two-pass fp64 mean / variance: 2e-6) and against torch fp64.  Two-source input (the skip
+    connections), 8 / 16 channels per group, 2-64 tiles per image."""
+    from diffusion_prior.gaussian_diffusion import ResnetBlock
+    torch.manual_seed(b * 131 + hw + cin + c2 + cout)
+    blk = ResnetBlock(cin + c2, cout, time_emb_dim=256, groups=groups).to(DEV)
+    for p_ in blk.parameters():
+        p_.data.copy_(torch.randn_like(p_) * (0.15 if p_.dim() > 1 else 0.3) + (1.0 if p_.dim() == 1 and p_.shape[0] == cout else 0.0))
+    x = torch.randn(b, hw, hw, cin, device=DEV)
+    x2 = torch.randn(b, hw, hw, c2, device=DEV) if c2 else None
+    temb = torch.randn(b, 256, device=DEV)
+    inp = (x, x2) if c2 else x
+    # the group sums against torch, the raw conv output against the plain conv (the same kernel: bit-identical)
+    cen = K.compute_enum("f32")
+    raw, sums, tile = K.conv2d_stats(x, blk.block1.proj.packed(cen), cout, 3, blk.block1.proj.bias, groups, x2=x2)
+    plain = blk.block1.proj.forward_nhwc(x, "f32", x2=x2) if c2 else K.conv2d(x, blk.block1.proj.packed(cen), cout, 3, add=blk.block1.proj.bias,
+                                                                               compute=cen, out_dtype=K.F32)
+    assert torch.equal(raw, plain)
+    assert (hw * hw) % tile == 0 and sums.shape == (b * hw * hw // tile, groups, 2)
+    rt = raw.double().reshape(b * hw * hw // tile, tile, groups, cout // groups)
+    assert_close(sums[..., 0], rt.sum(dim=(1, 3)), 1e-12, "group sums")
+    assert_close(sums[..., 1], (rt * rt).sum(dim=(1, 3)), 1e-12, "group sums of squares")
+    K.start_trace()
+    carried = blk.forward_nhwc(inp, temb, "f32")
+    labels = [e["label"] for e in K.stop_trace()]
+    assert sum("+sums" in lb for lb in labels) == 1 and sum("gn-in" in lb for lb in labels) == 1, labels
+    assert sum(lb.startswith("groupnorm_silu") for lb in labels) == 1, labels
+    K.set_conv_gn_carried(False)
+    try:
+        K.start_trace()
+        plain_out = blk.forward_nhwc(inp, temb, "f32")
+        labels = [e["label"] for e in K.stop_trace()]
+        assert not any("gn-in" in lb or "+sums" in lb for lb in labels), labels
+    finally:
+        K.set_conv_gn_carried(True)
+    assert_close(carried, plain_out, 2e-6, "GroupNorm carried into the next conv vs launch per op")
+    # torch fp64 reference of the block
+    xc = (torch.cat((x, x2), dim=3) if c2 else x).permute(0, 3, 1, 2).double().cpu()
+    F_ = torch.nn.functional
+
+    def ws(wt):
+        wd = wt.double().cpu()
+        m = wd.mean(dim=(1, 2, 3), keepdim=True)
+        v = wd.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+        return (wd - m) * (v + 1e-5).rsqrt()
+    ssr = F_.linear(F_.silu(temb.double().cpu()), blk.mlp[1].weight.double().cpu(), blk.mlp[1].bias.double().cpu())
+    sc, sh = ssr[:, :cout, None, None], ssr[:, cout:, None, None]
+    h = F_.conv2d(xc, ws(blk.block1.proj.weight), blk.block1.proj.bias.double().cpu(), padding=1)
+    h = F_.group_norm(h, groups, blk.block1.norm.weight.double().cpu(), blk.block1.norm.bias.double().cpu(), 1e-5)
+    h = F_.silu(h * (sc + 1) + sh)
+    h = F_.conv2d(h, ws(blk.block2.proj.weight), blk.block2.proj.bias.double().cpu(), padding=1)
+    h = F_.silu(F_.group_norm(h, groups, blk.block2.norm.weight.double().cpu(), blk.block2.norm.bias.double().cpu(), 1e-5))
+    r = F_.conv2d(xc, blk.res_conv.weight.double().cpu(), blk.res_conv.bias.double().cpu()) if cin + c2 != cout else xc
+    assert_close(carried.permute(0, 3, 1, 2), h + r, 5e-5, "ResnetBlock vs torch fp64")
+
+
+@pytest.mark.parametrize("b,hw,c,groups,with_res", [(64, 4, 64, 8, True), (260, 8, 64, 16, False), (130, 4, 128, 8, True)])
+@torch.no_grad()
+def test_conv_normalising_on_load_with_its_own_block_epilogue(b, hw, c, groups, with_res):
+    """nfdp_conv2d_gnin_nhwc_f32 with out_groups > 0 (tiles that hold whole images: the input GroupNorm from one tile's sums, the conv's own
+    GroupNorm -> SiLU -> + residual in its epilogue) against conv -> GroupNorm launch -> one-launch Block."""
+    torch.manual_seed(b + hw + c)
+    w1, w2 = torch.randn(c, c, 3, 3, device=DEV) * 0.05, torch.randn(c, c, 3, 3, device=DEV) * 0.05
+    b1, b2 = torch.randn(c, device=DEV) * 0.1, torch.randn(c, device=DEV) * 0.1
+    g1, be1, g2, be2 = [torch.randn(c, device=DEV) * 0.3 + o for o in (1.0, 0.0, 1.0, 0.0)]
+    ss = torch.randn(b, 2 * c, device=DEV) * 0.3
+    res = torch.randn(b, hw, hw, c, device=DEV) if with_res else None
+    x = torch.randn(b, hw, hw, c, device=DEV)
+    cen = K.compute_enum("f32")
+    p1, p2 = K.conv_pack(w1, cen), K.conv_pack(w2, cen)
+    assert K.lib().nfdp_conv2d_gnin_supported(b, hw, hw, c, c, groups, groups)
+    raw, sums, tile = K.conv2d_stats(x, p1, c, 3, b1, groups)
+    assert tile == hw * hw or (hw * hw) % tile == 0
+    got = K.conv2d_gnin(raw, sums, tile, groups, g1, be1, ss, p2, c, b2, out_groups=groups, out_gamma=g2, out_beta=be2, residual=res)
+    h = K.groupnorm_silu(K.conv2d(x, p1, c, 3, add=b1, compute=cen, out_dtype=K.F32), groups, g1, be1, ss, 1e-5)
+    want = K.conv2d_gn_silu(h, p2, c, 3, b2, groups, g2, be2, None, 1e-5, res)
+    assert_close(got, want, 2e-6, "normalise-on-load + Block epilogue vs three launches")
