@@ -435,6 +435,18 @@ int nfdp_conv2d_stats_tile(int B, int H, int W, int Cin, int Cout, int K, int gr
 int nfdp_conv2d_stats_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed, float* y,
                                int y_ld, int B, int H, int W, int Cout, int K, const float* bias, int groups, double* sums, int compute,
                                nfdp_stream_t stream);
+/* ResnetBlock's res_conv (:288, :301: a 1x1 conv of the block's INPUT) in the launch of block1's 3x3 conv: y = conv3x3(x) + bias as
+ * nfdp_conv2d_stats_nhwc_f32 (sums NULL: without the group sums), y_res = conv1x1(x) + bias_res from a second accumulator set over the
+ * centre tap of the staged input tile.  w_res_packed = nfdp_conv_pack_weights of the [Cout][Cin][1][1] weight (fp32).  Split products. */
+int nfdp_conv2d_res_supported(int B, int H, int W, int Cin, int Cout);
+int nfdp_conv2d_res_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed, float* y,
+                             int y_ld, int B, int H, int W, int Cout, const float* bias, int groups, double* sums, const void* w_res_packed,
+                             const float* bias_res, float* y_res, int y_res_ld, nfdp_stream_t stream);
+/* Upsample :169-173 (nn.Upsample(scale_factor=2, mode="nearest") -> Conv2d 3x3 pad 1) in one launch: x [B][H/2][W/2][Cin] (rows x_ld) is
+ * read through the index map of its upsampling; y [B][H][W][Cout]; H, W = OUTPUT sides (powers of two).  Split products. */
+int nfdp_conv2d_up2_supported(int B, int H, int W, int Cin, int Cout);
+int nfdp_conv2d_up2_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin, int Cout,
+                             const float* bias, nfdp_stream_t stream);
 int nfdp_conv2d_gnin_supported(int B, int H, int W, int Cin, int Cout, int in_groups, int out_groups);
 int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double* in_sums, int in_tile, int in_groups, const float* in_gamma,
                               const float* in_beta, const float* in_scale_shift, int in_ss_ld, float in_eps, const void* w_packed, float* y,

@@ -60,6 +60,14 @@ struct ConvParams {
     int gs_groups = 0;
     // ... and the reading side (conv3x3_ldsx_kernel<.., GNIN = true>): x is the RAW output of such a conv; what enters the products is
     // SiLU(GN(x) * (scale + 1) + shift) (Block.forward, reference gaussian_diffusion.py:267-276), formed while the tile is staged
+    // ... and ResnetBlock's res_conv (a 1x1 conv of the SAME input, reference :288, :301) in the launch of block1's 3x3 conv
+    // (conv3x3_ldsx_kernel<.., RES = true>): a second accumulator set over the centre tap of the staged tile, weights from w2's split image
+    const void* w2 = nullptr;         // packed fp32 1x1 weight with its split image at w2split_off
+    size_t w2split_off = 0;
+    const float* add2 = nullptr;      // its bias (nullable)
+    float* y2 = nullptr;              // its output [npix][y2_ld]
+    int y2_ld = 0;
+    int up2 = 0;                      // conv3x3_ldsx_kernel<.., UP>: x is [B][H/2][W/2][Cin], read as its nearest-neighbour x2 upsampling (:169-173)
     const double* gi_stats = nullptr; // the producer's sums, gi_parts tiles per image
     const float* gi_gamma = nullptr;
     const float* gi_beta = nullptr;
@@ -401,9 +409,10 @@ constexpr int SK_LD = 64 + 4;                                  // partial-tile r
 // The end of the split-K convs (conv_splitk_f32_kernel, conv3x3_ldsx_kernel): the waves' partial tiles meet in LDS and are summed in wave
 // order (deterministic); then the plain epilogue (bias, scale, ReLU) or the Block epilogue (GN, see conv_splitk_f32_kernel).  `part` may
 // alias memory the main loop read: the caller synchronises the workgroup first.
-template <int SK_WAVES, int PT, bool GN>
+template <int SK_WAVES, int PT, bool GN, bool SECOND = false>    // SECOND: the res_conv tile of conv3x3_ldsx_kernel<.., RES> (y2, add2; plain)
 __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part, const f32x4 (&acc)[4][PT], long m0, int n0, int tid,
                                                 int wave, int r16, int q) {
+    static_assert(!(GN && SECOND), "the second output is a plain conv");
     constexpr int SK_THREADS = SK_WAVES * 64, MT = 16 * PT;
     const int HW = P.H * P.W;
     // ---- the partial tiles meet in LDS: D[row = n = 4q + r][col = pixel = r16]
@@ -518,6 +527,14 @@ __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
         }
         float o[4] = {v.x, v.y, v.z, v.w};
+        if constexpr (SECOND) {
+            if (P.add2) {
+                const float4 a4 = *reinterpret_cast<const float4*>(P.add2 + n);
+                o[0] = __fadd_rn(o[0], a4.x); o[1] = __fadd_rn(o[1], a4.y); o[2] = __fadd_rn(o[2], a4.z); o[3] = __fadd_rn(o[3], a4.w);
+            }
+            *reinterpret_cast<float4*>(P.y2 + p * P.y2_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
+            continue;
+        }
         if (P.add) {
             const float4 a4 = *reinterpret_cast<const float4*>(P.add + n);
             o[0] = __fadd_rn(o[0], a4.x); o[1] = __fadd_rn(o[1], a4.y); o[2] = __fadd_rn(o[2], a4.z); o[3] = __fadd_rn(o[3], a4.w);
@@ -545,7 +562,7 @@ __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part
         }
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(P.y) + p * P.y_ld + n) = make_float4(o[0], o[1], o[2], o[3]);
     }
-    if (P.gs_out) {
+    if (!SECOND && P.gs_out) {
         // the tile's sums per group: lanes that hold the same group meet by xor-shuffles (lane bits 4, 5: other pixels; the low bits below
         // cpg / 4: the group's other channel quads), the waves in LDS, summed in wave order - fp64 throughout, a fixed association
         __shared__ double gsw[SK_WAVES][16][2];
@@ -784,9 +801,10 @@ static inline size_t ldsx_bytes(int W, int Cin, int pt, int HW = 0, int gi_group
 }
 // which packed fp32 weights carry the split image ([rows][K = 9 * Cin], see nfdp_conv_packed_bytes), and where
 static inline bool split_image_shape(int rows, int Cin, int KH, int KW) {
-    // 3x3 (conv3x3_ldsx_kernel) and the narrow 1x1 convs of the U-Nets' attention blocks (conv1x1_ln_kernel; Cin <= 128 keeps the
+    // 3x3 (conv3x3_ldsx_kernel) and the narrow 1x1 convs of the U-Nets (conv1x1_ln_kernel: Cin <= 128; the bound keeps the
     // 512 -> 512 convs of the coupling networks, repacked every training step in fp32 mode, out of it)
-    return ((KH == 3 && KW == 3) || (KH == 1 && KW == 1 && Cin <= 128)) && Cin % 32 == 0 && rows >= 64 && rows % 4 == 0;
+    // (the ResnetBlocks' res_conv over a skip concatenation: up to 256 inputs)
+    return ((KH == 3 && KW == 3) || (KH == 1 && KW == 1 && Cin <= 256)) && Cin % 32 == 0 && rows >= 64 && rows % 4 == 0;
 }
 static inline size_t split_image_bytes(int rows, int Kpad) { return (size_t)cdiv(rows, 64) * (Kpad / 32) * LX_BLOCK; }
 
@@ -803,7 +821,7 @@ static inline size_t split_image_bytes(int rows, int Kpad) { return (size_t)cdiv
 #define LX_STAMP(i)
 #endif
 
-template <int PT, bool GN, bool GNIN = false>
+template <int PT, bool GN, bool GNIN = false, bool RES = false, bool UP = false>
 __global__ void __launch_bounds__(LX_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv3x3_ldsx_kernel(const ConvParams P) {
     constexpr int MT = 16 * PT, NT_ = LX_WAVES * 64;
@@ -878,6 +896,7 @@ conv3x3_ldsx_kernel(const ConvParams P) {
     unsigned ld_1 = (unsigned)P.x_ld, ld_2 = (unsigned)P.x2_ld;
     int cin1_s = P.Cin1, npix_s = (int)P.npix;
     asm volatile("" : "+s"(ld_1), "+s"(ld_2), "+s"(cin1_s), "+s"(npix_s));
+    const int up_lw = UP ? __builtin_ctz((unsigned)P.W) : 0, up_lhw = UP ? __builtin_ctz((unsigned)HW) : 2;
     struct Units { float4 v[UB]; unsigned ok; };
     auto stage_load = [&](Units& u, int pass0, int cb) {              // units (pass0 .. pass0 + UB - 1, cb)
         const int c = sc + 64 * cb;
@@ -891,7 +910,13 @@ conv3x3_ldsx_kernel(const ConvParams P) {
         for (int e = 0; e < UB; ++e) {
             const int g = grow0 + 16 * (pass0 + e);
             const bool ok = cin && g >= 0 && g < npix_s && srow + 16 * (pass0 + e) < NP;
-            const unsigned gc = (unsigned)(g < 0 ? 0 : (g < npix_s ? g : npix_s - 1));
+            unsigned gc = (unsigned)(g < 0 ? 0 : (g < npix_s ? g : npix_s - 1));
+            if constexpr (UP) {
+                // Upsample(scale 2, nearest) -> conv (reference :169-173) without the upsampled tensor: output-grid pixel (b, y, x) reads
+                // source pixel (b, y / 2, x / 2) of the half-size tensor (power-of-two sides: shifts)
+                const unsigned r = gc & (unsigned)(HW - 1), yy = r >> up_lw, xx = r & (unsigned)(P.W - 1);
+                gc = ((gc >> up_lhw) << (up_lhw - 2)) + ((yy >> 1) << (up_lw - 1)) + (xx >> 1);
+            }
             u.ok |= ok ? 1u << e : 0u;
 #if defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 2     // timing-only build: no input loads
             u.v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1151,6 +1176,24 @@ conv3x3_ldsx_kernel(const ConvParams P) {
 #endif
         __builtin_amdgcn_sched_barrier(0);
     };
+    // (RES) res_conv = a 1x1 conv of the same input: the centre tap of the staged tile against w2's split image, K stages dealt to the
+    // waves like the 3x3 conv's, a second accumulator set; the first stage's weights fly under the main loop
+    const int nk2 = RES ? (P.Cin + 31) / 32 : 0;
+    const char* wimg2 = reinterpret_cast<const char*>(P.w2) + P.w2split_off + (size_t)nt * nk2 * LX_BLOCK;
+    auto loadw2 = [&](WF& f, int s2) {
+        int kt = wave + s2 * LX_WAVES;
+        kt = kt < nk2 ? kt : nk2 - 1;                  // (uniform) beyond the end: valid addresses, the x side reads zeros
+        const char* wb = wimg2 + (size_t)kt * LX_BLOCK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f.h[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i) * 1024 + wlane);
+            f.m[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i + 1) * 1024 + wlane);
+            f.l[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i + 2) * 1024 + wlane);
+        }
+    };
+    WF wres;
+    if constexpr (RES) loadw2(wres, 0);
+
     loadx(xf[0], 0);
     int st = 0;
     for (; st + LX_UNROLL <= S; st += LX_UNROLL)
@@ -1158,10 +1201,47 @@ conv3x3_ldsx_kernel(const ConvParams P) {
     static_for_lx<LX_UNROLL - 1>([&](auto bc) __attribute__((always_inline)) {
         if (st + decltype(bc)::value < S) stage(bc, st + decltype(bc)::value);       // (uniform) the remainder
     });
+    f32x4 acc2[RES ? 4 : 1][RES ? PT : 1];
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < PT; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int S2 = (nk2 + LX_WAVES - 1) / LX_WAVES;
+        for (int s2 = 0; s2 < S2; ++s2) {                           // (1-2 stages per wave: not pipelined)
+            const int kt = wave + s2 * LX_WAVES;
+            XF fx;
+#pragma unroll
+            for (int j = 0; j < PT; ++j) {
+                const bool ok = kt < nk2 && ((vmask[j] >> 4) & 1u);
+                const char* a = smem + (ok ? (int)xrow[j] + kt * 64 : (int)zrow);
+                fx.h[j] = *reinterpret_cast<const bf16x8*>(a);
+                fx.m[j] = *reinterpret_cast<const bf16x8*>(a + PS);
+                fx.l[j] = *reinterpret_cast<const bf16x8*>(a + 2 * PS);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < PT; ++j) {                     // the six products of `compute`, smallest terms first
+                    f32x4 c = acc2[i][j];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.l[i], fx.h[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.h[i], fx.l[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.m[i], fx.m[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.m[i], fx.h[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.h[i], fx.m[j], c, 0, 0, 0);
+                    acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.h[i], fx.h[j], c, 0, 0, 0);
+                }
+            if (s2 + 1 < S2) loadw2(wres, s2 + 1);
+        }
+    }
     LX_STAMP(3);
     __syncthreads();                                                // the partial tiles alias the planes
     LX_STAMP(4);
     splitk_epilogue<LX_WAVES, PT, GN>(P, reinterpret_cast<float*>(smem), acc, m0, n0, tid, wave, r16, q);
+    if constexpr (RES) {
+        __syncthreads();                                            // the first tile's partial sums have been read
+        splitk_epilogue<LX_WAVES, PT, false, true>(P, reinterpret_cast<float*>(smem), reinterpret_cast<const f32x4 (&)[4][PT]>(acc2), m0, n0, tid, wave, r16, q);
+    }
     LX_STAMP(5);
 }
 
@@ -1937,35 +2017,34 @@ static bool ldsx_ok(const ConvParams& P, int pt) {
            ldsx_np(P.W, pt) <= 1024 &&                 // (images up to ~500 pixels wide: beyond, the halo dwarfs the tile)
            ldsx_bytes(P.W, P.Cin, pt, P.H * P.W, P.gi_stats ? P.gi_groups : 0) + kLdsxStatic <= kLdsxMax;
 }
-template <bool GN, bool GNIN>
+template <bool GN, bool GNIN, bool RES, bool UP = false>
 static void launch_ldsx_t(const ConvParams& P, int pt, dim3 grid, hipStream_t s);
 template <bool GN>
 static void launch_ldsx(const ConvParams& P, int pt, dim3 grid, hipStream_t s) {
-    if (P.gi_stats) launch_ldsx_t<GN, true>(P, pt, grid, s);
-    else launch_ldsx_t<GN, false>(P, pt, grid, s);
+    if (P.w2) launch_ldsx_t<GN, false, true>(P, pt, grid, s);         // (host: never together with gi_stats / up2)
+    else if (P.gi_stats) launch_ldsx_t<GN, true, false>(P, pt, grid, s);
+    else if (!GN && P.up2) launch_ldsx_t<false, false, false, true>(P, pt, grid, s);
+    else launch_ldsx_t<GN, false, false>(P, pt, grid, s);
 }
-template <bool GN, bool GNIN>
+template <bool GN, bool GNIN, bool RES, bool UP>
 static void launch_ldsx_t(const ConvParams& P, int pt, dim3 grid, hipStream_t s) {
     static NfdpPerDevice attr_set;
     if (!attr_set) {
-        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<4, GN, GNIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
-        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<2, GN, GNIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
-        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<1, GN, GNIN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<4, GN, GNIN, RES, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<2, GN, GNIN, RES, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<1, GN, GNIN, RES, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
         attr_set = true;
     }
     const size_t lds = ldsx_bytes(P.W, P.Cin, pt, P.H * P.W, GNIN ? P.gi_groups : 0);
     ConvParams Q = P;
     Q.wsplit_off = (size_t)cout_pad_for(P.Cout) * P.Kpad * 4;
+    if (RES) Q.w2split_off = (size_t)cout_pad_for(P.Cout) * kpad_for(P.Cin, 1, 1) * 4;
 #ifdef NFDP_LX_STAMPS
     Q.part = reinterpret_cast<double*>(g_lx_stamps);
-    if (pt == 4) hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
-    else if (pt == 2) hipLaunchKernelGGL((conv3x3_ldsx_kernel<2, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
-    else hipLaunchKernelGGL((conv3x3_ldsx_kernel<1, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
-    return;
 #endif
-    if (pt == 4) hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
-    else if (pt == 2) hipLaunchKernelGGL((conv3x3_ldsx_kernel<2, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
-    else hipLaunchKernelGGL((conv3x3_ldsx_kernel<1, GN, GNIN>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    if (pt == 4) hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, GN, GNIN, RES, UP>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else if (pt == 2) hipLaunchKernelGGL((conv3x3_ldsx_kernel<2, GN, GNIN, RES, UP>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+    else hipLaunchKernelGGL((conv3x3_ldsx_kernel<1, GN, GNIN, RES, UP>), grid, dim3(LX_WAVES * 64), lds, s, Q);
 }
 
 // ---- a ResnetBlock's first GroupNorm carried from block1's conv to block2's conv (ConvParams::gs_* / gi_*)
@@ -1978,9 +2057,14 @@ struct ConvExtra {
     const float* gi_ss = nullptr;
     int gi_ss_ld = 0, gi_groups = 0, gi_parts = 0;
     float gi_eps = 0.f;
+    const void* w2 = nullptr;         // res_conv in the same launch (ConvParams::w2 ...)
+    const float* add2 = nullptr;
+    float* y2 = nullptr;
+    int y2_ld = 0, up2 = 0;
 };
 static void apply_extra(ConvParams& P, const ConvExtra* ex) {
     if (!ex) return;
+    P.w2 = ex->w2; P.add2 = ex->add2; P.y2 = ex->y2; P.y2_ld = ex->y2_ld; P.up2 = ex->up2;
     P.gs_out = ex->gs_out; P.gs_groups = ex->gs_groups;
     P.gi_stats = ex->gi_stats; P.gi_gamma = ex->gi_gamma; P.gi_beta = ex->gi_beta; P.gi_ss = ex->gi_ss;
     P.gi_ss_ld = ex->gi_ss_ld; P.gi_groups = ex->gi_groups; P.gi_parts = ex->gi_parts; P.gi_eps = ex->gi_eps;
@@ -2066,8 +2150,8 @@ static int conv2d_gn_silu_impl(const float* x, int x_ld, const void* w_packed, f
     apply_extra(P, ex);
     P.Nt = (int)cdiv(Cout, 64);
     const int pt = gn_pixel_tiles(npix, Cout, H * W);
-    NFDP_REQUIRE(!P.gi_stats || (compute == NFDP_F32X6 && ldsx_ok(P, pt)), NFDP_EUNSUPPORTED,
-                 "conv2d_gnin: the input GroupNorm rides in the LDS-staged 3x3 conv only (nfdp_conv2d_gnin_supported)");
+    NFDP_REQUIRE((!P.gi_stats && !P.w2) || (compute == NFDP_F32X6 && ldsx_ok(P, pt)), NFDP_EUNSUPPORTED,
+                 "conv2d_gnin / conv2d_res: available in the LDS-staged 3x3 conv only (nfdp_conv2d_gnin_supported / nfdp_conv2d_res_supported)");
     P.Mt = (int)cdiv(npix, 16 * pt);
     const dim3 grid(P.Mt * P.Nt);
     hipStream_t s = as_stream(stream);
@@ -2155,6 +2239,60 @@ extern "C" int nfdp_conv2d_stats_nhwc_f32(const float* x1, int x1_ld, int Cin1, 
                        x2, x2_ld, x2 ? Cin1 : 0, &ex);
 }
 
+// ResnetBlock's res_conv (1x1, the same input) in block1's launch: y = conv3x3(x) (+ the group sums when `sums` is given, see above),
+// y_res = conv1x1(x).  Both weights packed fp32 with their split images; the LDS-staged kernel only.
+extern "C" int nfdp_conv2d_res_supported(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !g_conv_ldsx) return 0;
+    const int pt = splitk_tile_pixels((long)B * H * W, Cin, Cout, 3) / 16;
+    if (pt == 0 || !split_image_shape(Cout, Cin, 3, 3) || !split_image_shape(Cout, Cin, 1, 1) || ldsx_np(W, pt) > 1024) return 0;
+    return ldsx_bytes(W, Cin, pt) + kLdsxStatic <= kLdsxMax;
+}
+
+extern "C" int nfdp_conv2d_res_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed,
+                                        float* y, int y_ld, int B, int H, int W, int Cout, const float* bias, int groups, double* sums,
+                                        const void* w_res_packed, const float* bias_res, float* y_res, int y_res_ld, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x1 && w_res_packed && y_res, NFDP_EINVAL, "conv2d_res: null pointer");
+    NFDP_REQUIRE((x2 == nullptr) == (Cin2 == 0) && Cin1 > 0 && Cin2 >= 0, NFDP_EINVAL, "conv2d_res: second source and Cin2 go together");
+    NFDP_REQUIRE(nfdp_conv2d_res_supported(B, H, W, Cin1 + Cin2, Cout), NFDP_EUNSUPPORTED,
+                 "conv2d_res: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin1 + Cin2, Cout);
+    NFDP_REQUIRE(!sums || nfdp_conv2d_stats_tile(B, H, W, Cin1 + Cin2, Cout, 3, groups) != 0, NFDP_EUNSUPPORTED,
+                 "conv2d_res: no group sums for B=%d H=%d W=%d Cin=%d Cout=%d groups=%d (nfdp_conv2d_stats_tile)", B, H, W, Cin1 + Cin2, Cout, groups);
+    NFDP_REQUIRE(x1_ld % 4 == 0 && y_ld % 4 == 0 && y_res_ld >= Cout && y_res_ld % 4 == 0 &&
+                 (((uintptr_t)x1 | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)sums | (uintptr_t)bias_res | (uintptr_t)y_res) % 16) == 0, NFDP_ESHAPE,
+                 "conv2d_res: rows and vectors must be 16-byte aligned");
+    if (x2) {
+        NFDP_REQUIRE(Cin1 % 8 == 0 && Cin2 % 4 == 0 && x2_ld >= Cin2 && x2_ld % 4 == 0 && ((uintptr_t)x2 % 16) == 0, NFDP_ESHAPE,
+                     "conv2d_res: two sources: %d + %d channels (first a multiple of 8, second of 4), 16-byte aligned rows", Cin1, Cin2);
+    }
+    ConvExtra ex;
+    ex.gs_out = sums; ex.gs_groups = groups;
+    ex.w2 = w_res_packed; ex.add2 = bias_res; ex.y2 = y_res; ex.y2_ld = y_res_ld;
+    return conv2d_impl(x1, NFDP_F32, x1_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin1 + Cin2, Cout, 3, 3, bias, nullptr, 0.f, 0, NFDP_F32X6, stream,
+                       x2, x2_ld, x2 ? Cin1 : 0, &ex);
+}
+
+// Upsample (reference :169-173: nn.Upsample(scale_factor = 2, mode = "nearest") -> Conv2d 3x3) as one launch: x [B][H/2][W/2][Cin] is read
+// through the index map of its x2 nearest-neighbour upsampling while the input tile is staged; H, W: the OUTPUT sides (powers of two).
+extern "C" int nfdp_conv2d_up2_supported(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H < 2 || W < 2 || Cin <= 0 || Cout <= 0 || !g_conv_ldsx || !pow2(H) || !pow2(W)) return 0;
+    const int pt = splitk_tile_pixels((long)B * H * W, Cin, Cout, 3) / 16;
+    if (pt == 0 || !split_image_shape(Cout, Cin, 3, 3) || ldsx_np(W, pt) > 1024) return 0;
+    return ldsx_bytes(W, Cin, pt) + kLdsxStatic <= kLdsxMax;
+}
+
+extern "C" int nfdp_conv2d_up2_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin,
+                                        int Cout, const float* bias, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x, NFDP_EINVAL, "conv2d_up2: null pointer");
+    NFDP_REQUIRE(nfdp_conv2d_up2_supported(B, H, W, Cin, Cout), NFDP_EUNSUPPORTED,
+                 "conv2d_up2: unsupported geometry B=%d H=%d W=%d (output) Cin=%d Cout=%d", B, H, W, Cin, Cout);
+    NFDP_REQUIRE(x_ld % 4 == 0 && y_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias) % 16) == 0, NFDP_ESHAPE,
+                 "conv2d_up2: rows and vectors must be 16-byte aligned");
+    ConvExtra ex;
+    ex.up2 = 1;
+    return conv2d_impl(x, NFDP_F32, x_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin, Cout, 3, 3, bias, nullptr, 0.f, 0, NFDP_F32X6, stream,
+                       nullptr, 0, 0, &ex);
+}
+
 extern "C" int nfdp_conv2d_gnin_supported(int B, int H, int W, int Cin, int Cout, int in_groups, int out_groups) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || in_groups <= 0 || in_groups % 2 != 0 || Cin % in_groups != 0) return 0;
     const int cpg = Cin / in_groups, HW = H * W;
@@ -2197,7 +2335,7 @@ extern "C" int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double*
 // 1x1 conv with the channel LayerNorm of its input (pre_gain) and / or of its output (post_gain, + residual) in the same launch: the
 // to_qkv / to_out convs of the U-Nets' attention blocks (conv1x1_ln_kernel).  fp32 tensors, split-product arithmetic (compute = NFDP_F32X6).
 extern "C" int nfdp_conv1x1_ln_supported(long npix, int Cin, int Cout, int pre, int post) {
-    if (npix <= 0 || !split_image_shape(Cout, Cin, 1, 1) || Cout % 4 != 0) return 0;
+    if (npix <= 0 || !split_image_shape(Cout, Cin, 1, 1) || Cin > 128 || Cout % 4 != 0) return 0;
     if (post && Cout > 128) return 0;                    // the output LayerNorm needs all outputs of a pixel in one workgroup
     return pre || post;
 }
@@ -2307,8 +2445,8 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
             sk_attr_set = true;
         }
-        NFDP_REQUIRE(!P.gi_stats || (emu && ldsx_ok(P, pt)), NFDP_EUNSUPPORTED,
-                     "conv2d_gnin: the input GroupNorm rides in the LDS-staged 3x3 conv only (nfdp_conv2d_gnin_supported)");
+        NFDP_REQUIRE((!P.gi_stats && !P.w2 && !P.up2) || (emu && ldsx_ok(P, pt)), NFDP_EUNSUPPORTED,
+                     "conv2d_gnin / conv2d_res / conv2d_up2: available in the LDS-staged 3x3 conv only (nfdp_conv2d_*_supported)");
         if (emu && ldsx_ok(P, pt)) {  // fp32 products as six bf16 MFMAs (NFDP_F32X6), 3x3: the input tile staged and split once in LDS
             launch_ldsx<false>(P, pt, grid, s);
         } else if (emu) {             // ... operands gathered per tap
@@ -2323,7 +2461,8 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
         NFDP_CHECK_LAUNCH("conv2d (split-K fp32)");
         return NFDP_OK;
     }
-    NFDP_REQUIRE(!P.gs_out && !P.gi_stats, NFDP_EUNSUPPORTED, "conv2d_stats / conv2d_gnin: this problem does not take the split-K kernels");
+    NFDP_REQUIRE(!P.gs_out && !P.gi_stats && !P.w2 && !P.up2, NFDP_EUNSUPPORTED,
+                 "conv2d_stats / conv2d_gnin / conv2d_res / conv2d_up2: this problem does not take the split-K kernels");
     if (compute == NFDP_F32) {
         if (vec) launch_by_cout<false, false, true>(P, s);
         else launch_by_cout<false, false, false>(P, s);

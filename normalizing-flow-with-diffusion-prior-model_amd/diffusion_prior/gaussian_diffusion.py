@@ -234,9 +234,14 @@ class ResnetBlock(nn.Module):
                 if K.conv2d_gn_carried_supported(xh, b1.proj.cout, b1.proj.k, b1.norm.num_groups, b2.norm.num_groups, fused2, *p1,
                                                  b2.proj.bias, b2.norm.weight, b2.norm.bias, ss, extra_cin=e2):
                     cenum = K.compute_enum(compute)
-                    raw, sums, tile = K.conv2d_stats(xh, b1.proj.packed(cenum), b1.proj.cout, b1.proj.k, b1.proj.bias, b1.norm.num_groups, x2=x2)
-                    res = self.res_conv.forward_nhwc(xh, compute, x2=x2) if isinstance(self.res_conv, _Conv) else xh
-                    res = res.contiguous()
+                    rc = self.res_conv
+                    if isinstance(rc, _Conv) and b1.proj.k == 3 and K.conv2d_res_supported(xh, rc.cout, rc.bias, extra_cin=e2):
+                        # ... and the 1x1 res_conv of the same input from a second accumulator set of the same launch
+                        raw, sums, tile, res = K.conv2d_stats(xh, b1.proj.packed(cenum), b1.proj.cout, 3, b1.proj.bias, b1.norm.num_groups,
+                                                              x2=x2, res=(rc.packed(cenum), rc.bias))
+                    else:
+                        raw, sums, tile = K.conv2d_stats(xh, b1.proj.packed(cenum), b1.proj.cout, b1.proj.k, b1.proj.bias, b1.norm.num_groups, x2=x2)
+                        res = (rc.forward_nhwc(xh, compute, x2=x2) if isinstance(rc, _Conv) else xh).contiguous()
                     if fused2:
                         return K.conv2d_gnin(raw, sums, tile, b1.norm.num_groups, b1.norm.weight, b1.norm.bias, ss, b2.proj.packed(cenum),
                                              b2.proj.cout, b2.proj.bias, out_groups=b2.norm.num_groups, out_gamma=b2.norm.weight,
@@ -450,7 +455,11 @@ class Unet(_EpochOnApply, nn.Module):
             x = rb(block2, (x, hs.pop()))
             x = _attn_block_nhwc(attn, x, c)
             if isinstance(upsample, nn.Sequential):
-                x = upsample[1].forward_nhwc(K.upsample2x(x), c)         # nearest x2 + 3x3  (:169-173)
+                up = upsample[1]
+                if K.compute_enum(c) == K.F32 and K.conv2d_up2_supported(x, up.cout, up.bias):
+                    x = K.conv2d_up2(x, up.packed(K.F32), up.cout, up.bias)   # nearest x2 + 3x3 (:169-173): the upsampling is an index map
+                else:
+                    x = up.forward_nhwc(K.upsample2x(x), c)
             else:
                 x = upsample.forward_nhwc(x, c)
         x = rb(self.final_res_block, (x, r))

@@ -1090,9 +1090,30 @@ def conv2d_gn_carried_supported(xh: torch.Tensor, cmid: int, k: int, groups1: in
     return bool(lib().nfdp_conv2d_gnin_supported(b, h, w, cmid, cmid, groups1, groups2 if fused2 else 0))
 
 
-def conv2d_stats(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bias, groups: int, x2: Optional[torch.Tensor] = None):
+_CONV_RES_FUSED = True
+
+
+def set_conv_res_fused(on: bool) -> None:
+    """ResnetBlock: the 1x1 res_conv in the launch of block1's 3x3 conv (default, where conv2d_res_supported) or as a launch of its own."""
+    global _CONV_RES_FUSED
+    _CONV_RES_FUSED = bool(on)
+
+
+def conv2d_res_supported(xh: torch.Tensor, cout: int, *vectors, extra_cin: int = 0) -> bool:
+    """conv2d_stats(..., res=...) is available: the 3x3 conv of this input takes the LDS-staged kernel and the 1x1 weight has a split image."""
+    if not (_CONV_RES_FUSED and _F32_PRODUCTS == "bf16x6" and xh.is_cuda and xh.dtype == torch.float32 and xh.dim() == 4 and
+            xh.stride(3) == 1 and not torch.is_grad_enabled()):
+        return False
+    if xh.data_ptr() % 16 or xh.stride(2) % 4 or any(v is not None and v.data_ptr() % 16 for v in vectors):
+        return False
+    b, h, w, cin = xh.shape
+    return bool(lib().nfdp_conv2d_res_supported(b, h, w, cin + extra_cin, cout))
+
+
+def conv2d_stats(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bias, groups: int, x2: Optional[torch.Tensor] = None, res=None):
     """conv2d (of torch.cat((xh, x2), -1) when x2 is given) that also leaves the fp64 (sum, sum of squares) of every (pixel tile, group) of
-    its output (nfdp_conv2d_stats_nhwc_f32) -> (y, sums [tiles, groups, 2], pixels per tile)."""
+    its output (nfdp_conv2d_stats_nhwc_f32) -> (y, sums [tiles, groups, 2], pixels per tile).  res = (packed 1x1 weight, bias): the 1x1
+    conv of the same input in the same launch (nfdp_conv2d_res_nhwc_f32; k = 3, check conv2d_res_supported) -> (y, sums, tile, y_res)."""
     _need(xh, torch.float32, "conv2d_stats")
     b, h, w, c1 = xh.shape
     c2 = 0 if x2 is None else x2.shape[3]
@@ -1101,6 +1122,14 @@ def conv2d_stats(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bias
         raise ValueError(f"conv2d_stats: unsupported geometry {tuple(xh.shape)} (+{c2}) -> {cout}, k={k}, groups={groups}")
     y = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
     sums = torch.empty((b * h * w // tile, groups, 2), device=xh.device, dtype=torch.float64)
+    if res is not None:
+        assert k == 3
+        yr = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
+        _call("nfdp_conv2d_res_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_stats"), c1, _ptr(x2), 0 if x2 is None else _ld(x2, "conv2d_stats"), c2,
+              _ptr(packed), _ptr(y), cout, b, h, w, cout, _ptr(bias), groups, _ptr(sums), _ptr(res[0]), _ptr(res[1]), _ptr(yr), cout, _stream(),
+              label=f"conv3x3_ldsx+sums+res{' cat' if c2 else ''} {c1}{'+' + str(c2) if c2 else ''}->{cout} hw{h}",
+              flops=2.0 * b * h * w * (c1 + c2) * 10 * cout)
+        return y, sums, tile, yr
     _call("nfdp_conv2d_stats_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_stats"), c1, _ptr(x2), 0 if x2 is None else _ld(x2, "conv2d_stats"), c2,
           _ptr(packed), _ptr(y), cout, b, h, w, cout, k, _ptr(bias), groups, _ptr(sums), _f32_compute(F32), _stream(),
           label=f"conv_splitk_f32+sums{' cat' if c2 else ''} k{k} {c1}{'+' + str(c2) if c2 else ''}->{cout} hw{h}", flops=2.0 * b * h * w * (c1 + c2) * k * k * cout)
@@ -1130,6 +1159,40 @@ def conv2d_gnin(xh: torch.Tensor, sums: torch.Tensor, tile: int, in_groups: int,
           _ptr(in_scale_shift), _ss_ld(in_scale_shift, cin), float(in_eps), _ptr(packed), _ptr(y), cout, b, h, w, cin, cout, _ptr(bias),
           out_groups, _ptr(out_gamma), _ptr(out_beta), _ptr(out_scale_shift), _ss_ld(out_scale_shift, cout), float(out_eps), _ptr(residual),
           res_ld, _stream(), label=f"conv3x3_ldsx gn-in{'+gn' if out_groups else ''} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * 9 * cout)
+    return y
+
+
+_CONV_UP_FUSED = True
+
+
+def set_conv_up_fused(on: bool) -> None:
+    """Upsample (nearest x2 -> 3x3 conv) as one launch where conv2d_up2_supported (default) or as two."""
+    global _CONV_UP_FUSED
+    _CONV_UP_FUSED = bool(on)
+
+
+def conv2d_up2_supported(xh: torch.Tensor, cout: int, bias=None) -> bool:
+    if not (_CONV_UP_FUSED and _F32_PRODUCTS == "bf16x6" and xh.is_cuda and xh.dtype == torch.float32 and xh.dim() == 4 and
+            xh.stride(3) == 1 and not torch.is_grad_enabled()):
+        return False
+    if xh.data_ptr() % 16 or xh.stride(2) % 4 or (bias is not None and bias.data_ptr() % 16):
+        return False
+    b, h, w, cin = xh.shape
+    return _is_dense_pixels(xh) and bool(lib().nfdp_conv2d_up2_supported(b, 2 * h, 2 * w, cin, cout))
+
+
+def _is_dense_pixels(xh: torch.Tensor) -> bool:
+    """Pixels at one stride (row = pixel index * stride(2)): what a flat pixel index into [B, H, W] needs."""
+    b, h, w, _ = xh.shape
+    return xh.stride(1) == w * xh.stride(2) and xh.stride(0) == h * xh.stride(1)
+
+
+def conv2d_up2(xh: torch.Tensor, packed: torch.Tensor, cout: int, bias=None) -> torch.Tensor:
+    """conv3x3(nearest-x2 upsampling of xh) without the upsampled tensor (nfdp_conv2d_up2_nhwc_f32; check conv2d_up2_supported)."""
+    b, h, w, cin = xh.shape
+    y = torch.empty((b, 2 * h, 2 * w, cout), device=xh.device, dtype=torch.float32)
+    _call("nfdp_conv2d_up2_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_up2"), _ptr(packed), _ptr(y), cout, b, 2 * h, 2 * w, cin, cout, _ptr(bias),
+          _stream(), label=f"conv3x3_ldsx up2 {cin}->{cout} hw{2 * h}", flops=2.0 * b * 4 * h * w * cin * 9 * cout)
     return y
 
 

@@ -470,7 +470,8 @@ def test_unet_reads_skip_connections_from_both_tensors():
         a = u.forward_nhwc(x, t)
         labels = [e["label"] for e in K.stop_trace()]
         assert not any("concat" in lb for lb in labels), labels
-        assert sum("cat" in lb for lb in labels) == 10, labels               # 5 ResnetBlocks x (3x3 conv + 1x1 res_conv)
+        # 5 ResnetBlocks x (3x3 conv + 1x1 res_conv), the two in one launch where the res_conv rides in block1's conv
+        assert sum(2 if "+res" in lb else 1 for lb in labels if "cat" in lb) == 10, labels
         K.set_conv_cat(False)
         try:
             K.start_trace()
@@ -659,3 +660,22 @@ def test_conv_normalising_on_load_with_its_own_block_epilogue(b, hw, c, groups, 
     h = K.groupnorm_silu(K.conv2d(x, p1, c, 3, add=b1, compute=cen, out_dtype=K.F32), groups, g1, be1, ss, 1e-5)
     want = K.conv2d_gn_silu(h, p2, c, 3, b2, groups, g2, be2, None, 1e-5, res)
     assert_close(got, want, 2e-6, "normalise-on-load + Block epilogue vs three launches")
+
+
+@pytest.mark.parametrize("b,hw,cin,cout", [(64, 8, 128, 64), (3, 4, 64, 64), (2, 16, 96, 128), (64, 2, 128, 128)])
+@torch.no_grad()
+def test_upsample_conv_in_one_launch_is_bit_identical(b, hw, cin, cout):
+    """Upsample (reference gaussian_diffusion.py:169-173: nearest x2 -> Conv2d 3x3) with the upsampling as an index map of the conv's
+    staging (nfdp_conv2d_up2_nhwc_f32) against upsample launch + conv: the same kernel on the same values - bit for bit."""
+    torch.manual_seed(b + hw + cin)
+    x = torch.randn(b, hw, hw, cin, device=DEV)
+    w = torch.randn(cout, cin, 3, 3, device=DEV) * 0.05
+    bias = torch.randn(cout, device=DEV)
+    packed = K.conv_pack(w, K.F32)
+    assert K.conv2d_up2_supported(x, cout, bias)
+    got = K.conv2d_up2(x, packed, cout, bias)
+    want = K.conv2d(K.upsample2x(x), packed, cout, 3, add=bias, compute=K.compute_enum("f32"), out_dtype=K.F32)
+    assert got.shape == (b, 2 * hw, 2 * hw, cout) and torch.equal(got, want)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.permute(0, 3, 1, 2).double().cpu(), scale_factor=2, mode="nearest"),
+                                     w.double().cpu(), bias.double().cpu(), padding=1)
+    assert_close(got.permute(0, 3, 1, 2), ref, 2e-5, "upsample + conv vs torch fp64")
