@@ -295,7 +295,8 @@ int nfdp_level_fused_bf16(float* x, int B, int H, int W, int C, int n_flows, con
 /* A 1x1 conv (split-product fp32 arithmetic, weights packed by nfdp_conv_pack_weights with compute = NFDP_F32: Cin % 32 == 0, Cin <= 128)
  * with the channel LayerNorm of its INPUT (pre_gain [Cin]: PreNorm -> to_qkv, gaussian_diffusion.py:212-220) and / or of its OUTPUT
  * (post_gain [Cout], Cout <= 128, then + residual: LinearAttention.to_out -> LayerNorm -> Residual, :160-166, :314-318) in one launch;
- * LayerNorm as nfdp_chan_layernorm_f32 ((x - mean) * rsqrt(var + eps) * gain, biased variance).  bias may be null. */
+ * LayerNorm as nfdp_chan_layernorm_f32 ((x - mean) * rsqrt(var + eps) * gain, biased variance).  bias may be null.  With neither gain
+ * it is the plain 1x1 conv whose epilogue adds the residual (Attention.to_out + x, :160-166, :356-358). */
 int nfdp_conv1x1_ln_supported(long npix, int Cin, int Cout, int pre, int post);
 int nfdp_conv1x1_ln_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, long npix, int Cin, int Cout,
                         const float* bias, const float* pre_gain, const float* post_gain, const float* residual, int res_ld, float eps,
@@ -445,6 +446,12 @@ int nfdp_conv2d_res_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* 
 /* Upsample :169-173 (nn.Upsample(scale_factor=2, mode="nearest") -> Conv2d 3x3 pad 1) in one launch: x [B][H/2][W/2][Cin] (rows x_ld) is
  * read through the index map of its upsampling; y [B][H][W][Cout]; H, W = OUTPUT sides (powers of two).  Split products. */
 int nfdp_conv2d_up2_supported(int B, int H, int W, int Cin, int Cout);
+/* Downsample :176-180 (Rearrange "b c (h p1) (w p2) -> b (c p1 p2) h w" -> Conv2d 1x1) in one launch: the 1x1 weight [Cout][4C][1][1]
+ * viewed as [Cout][C][2][2] is a 2x2 conv with stride 2 on the un-rearranged tensor.  x [B][2H][2W][C] (rows x_ld), w_packed =
+ * nfdp_conv_pack_weights(view, Cout, C, 2, 2, NFDP_F32), y [B][H][W][Cout]; H, W = OUTPUT sides.  compute: NFDP_F32 or NFDP_F32X6. */
+int nfdp_conv2d_squeeze_supported(int B, int H, int W, int C, int Cout);
+int nfdp_conv2d_squeeze_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int C, int Cout,
+                                 const float* bias, int compute, nfdp_stream_t stream);
 int nfdp_conv2d_up2_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin, int Cout,
                              const float* bias, nfdp_stream_t stream);
 int nfdp_conv2d_gnin_supported(int B, int H, int W, int Cin, int Cout, int in_groups, int out_groups);

@@ -67,6 +67,7 @@ struct ConvParams {
     const float* add2 = nullptr;      // its bias (nullable)
     float* y2 = nullptr;              // its output [npix][y2_ld]
     int y2_ld = 0;
+    int sq = 0;                       // conv_splitk_f32_kernel: KH = KW = 2, stride 2, no padding on x [B][2H][2W][Cin] (Downsample, :176-180)
     int up2 = 0;                      // conv3x3_ldsx_kernel<.., UP>: x is [B][H/2][W/2][Cin], read as its nearest-neighbour x2 upsampling (:169-173)
     const double* gi_stats = nullptr; // the producer's sums, gi_parts tiles per image
     const float* gi_gamma = nullptr;
@@ -624,9 +625,11 @@ conv_splitk_f32_kernel(const ConvParams P) {
         const int b = pc / HW;
         const int r = pc - b * HW;
         py[j] = r / P.W; px[j] = r - py[j] * P.W;
-        pcen[j] = xg + (long)pc * P.x_ld;
+        // (sq) output pixel (b, y, x) reads the 2 x 2 block at (2y, 2x) of the 2H x 2W source: the "centre" is the block's first pixel
+        pcen[j] = xg + (P.sq ? (((long)b * 2 * P.H + 2 * py[j]) * 2 * P.W + 2 * px[j]) : (long)pc) * P.x_ld;
         pcen2[j] = x2g ? x2g + (long)pc * P.x2_ld : xg;
     }
+    const int wsrc = P.sq ? 2 * P.W : P.W;               // pixels per source row
     // a stage (SK_BK consecutive k) lies inside ONE tap when Cin is a multiple of the stage depth (every 3x3 conv of the U-Nets: 64, 128,
     // 192 channels): tap and channel base are then scalar
     const bool one_tap = P.Cin % SK_BK == 0 && P.x2 == nullptr;
@@ -659,7 +662,7 @@ conv_splitk_f32_kernel(const ConvParams P) {
         const int dy = tap / P.KW - P.pad, dx = tap - (tap / P.KW) * P.KW - P.pad;
         const bool kok = live && kb + SK_KL * q < P.K;
         const bool second = kok && ci >= P.Cin1;        // two-source input: this lane's SK_KL channels lie wholly in x2 (Cin1 % 8 == 0)
-        const int shift = dy * P.W + dx;                 // pixel offset of the tap
+        const int shift = dy * wsrc + dx;                // pixel offset of the tap
         const int off1 = shift * P.x_ld + ci, off2 = shift * P.x2_ld + ci - P.Cin1;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -668,7 +671,7 @@ conv_splitk_f32_kernel(const ConvParams P) {
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const int y = py[j] + dy, xx = px[j] + dx;
-            const bool ok = kok && pok[j] && (unsigned)y < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
+            const bool ok = kok && pok[j] && (P.sq || ((unsigned)y < (unsigned)P.H && (unsigned)xx < (unsigned)P.W));
             // always load (from a valid address: the centre pixel's first channels) and mask the bits: a "load or zero" select makes
             // hipcc branch around every dword and wait for each one
             const float* src = second ? pcen2[j] + (ok ? off2 : 0) : pcen[j] + (ok ? off1 : 0);
@@ -1432,7 +1435,15 @@ __global__ void __launch_bounds__(256) conv1x1_ln_kernel(const ConvParams P, con
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int n = 64 * (nt0 + t) + 16 * i + 4 * q;
-            if (n < P.Cout) *reinterpret_cast<float4*>(yrow + n) = make_float4(o[t][i][0], o[t][i][1], o[t][i][2], o[t][i][3]);
+            if (n >= P.Cout) continue;
+            if constexpr (!LNPOST) {                    // a residual without the output LayerNorm (Attention's to_out + x, :160-166)
+                if (ln.residual != nullptr) {
+                    const float4 rv = *reinterpret_cast<const float4*>(ln.residual + p * ln.res_ld + n);
+                    o[t][i][0] = __fadd_rn(o[t][i][0], rv.x); o[t][i][1] = __fadd_rn(o[t][i][1], rv.y);
+                    o[t][i][2] = __fadd_rn(o[t][i][2], rv.z); o[t][i][3] = __fadd_rn(o[t][i][3], rv.w);
+                }
+            }
+            *reinterpret_cast<float4*>(yrow + n) = make_float4(o[t][i][0], o[t][i][1], o[t][i][2], o[t][i][3]);
         }
 }
 
@@ -2271,6 +2282,54 @@ extern "C" int nfdp_conv2d_res_nhwc_f32(const float* x1, int x1_ld, int Cin1, co
                        x2, x2_ld, x2 ? Cin1 : 0, &ex);
 }
 
+// Downsample (reference :176-180: Rearrange("b c (h p1) (w p2) -> b (c p1 p2) h w") -> Conv2d 1x1) as one launch: the rearranged channel
+// index is c * 4 + p1 * 2 + p2, so the 1x1 weight [Cout][4C] viewed as [Cout][C][2][2] is the weight of a 2x2 conv with stride 2 on the
+// un-rearranged tensor.  x [B][2H][2W][C], w_packed = nfdp_conv_pack_weights of that view (KH = KW = 2), y [B][H][W][Cout]; the split-K conv.
+extern "C" int nfdp_conv2d_squeeze_supported(int B, int H, int W, int C, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Cout <= 0 || C % 32 != 0) return 0;
+    if (Cout < 64 || Cout % 4 != 0 || kpad_for(C, 2, 2) < 8 * 32 || cdiv((long)B * H * W, 64) * cdiv(Cout, 64) > 1024) return 0;
+    return (long)B * H * W * 4 < (1L << 31) - 4096;
+}
+
+extern "C" int nfdp_conv2d_squeeze_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int C,
+                                            int Cout, const float* bias, int compute, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && w_packed && y, NFDP_EINVAL, "conv2d_squeeze: null pointer");
+    NFDP_REQUIRE(compute == NFDP_F32 || compute == NFDP_F32X6, NFDP_EINVAL, "conv2d_squeeze: compute=%d (fp32 or the six-product split form)", compute);
+    NFDP_REQUIRE(nfdp_conv2d_squeeze_supported(B, H, W, C, Cout), NFDP_EUNSUPPORTED,
+                 "conv2d_squeeze: unsupported geometry B=%d H=%d W=%d (output) C=%d Cout=%d", B, H, W, C, Cout);
+    NFDP_REQUIRE(x_ld >= C && x_ld % 4 == 0 && y_ld >= Cout && y_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias) % 16) == 0, NFDP_ESHAPE,
+                 "conv2d_squeeze: rows and vectors must be 16-byte aligned");
+    const long npix = (long)B * H * W;
+    ConvParams P;
+    P.x = x; P.w = w_packed; P.y = y; P.add = bias; P.mul = nullptr; P.npix = npix;
+    P.x_ld = x_ld; P.y_ld = y_ld; P.y_bf16 = 0;
+    P.H = H; P.W = W; P.Cin = C; P.Cout = Cout; P.KH = 2; P.KW = 2; P.pad = 0;
+    P.K = 4 * C; P.Kpad = kpad_for(C, 2, 2); P.relu = 0; P.mul_exp = 0.f;
+    P.sq = 1;
+    P.Nt = (int)cdiv(Cout, 64);
+    const int pt = splitk_tile_pixels(npix, C, Cout, 2) / 16;
+    P.Mt = (int)cdiv(npix, 16 * pt);
+    const dim3 grid(P.Mt * P.Nt);
+    hipStream_t s = as_stream(stream);
+    static NfdpPerDevice attr_set;
+    if (!attr_set) {
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<8, 4, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 64 * SK_LD * 4);
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv_splitk_f32_kernel<4, 8, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * SK_LD * 4);
+        attr_set = true;
+    }
+    if (compute == NFDP_F32X6) {
+        if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 4>), grid, dim3(256), 4 * 64 * SK_LD * 4, s, P);
+        else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 2>), grid, dim3(256), 4 * 32 * SK_LD * 4, s, P);
+        else hipLaunchKernelGGL((conv_splitk_f32_kernel<4, 8, true, 1>), grid, dim3(256), 4 * 16 * SK_LD * 4, s, P);
+    } else {
+        if (pt == 4) hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false, 4>), grid, dim3(512), 8 * 64 * SK_LD * 4, s, P);
+        else if (pt == 2) hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false, 2>), grid, dim3(512), 8 * 32 * SK_LD * 4, s, P);
+        else hipLaunchKernelGGL((conv_splitk_f32_kernel<8, 4, false, 1>), grid, dim3(512), 8 * 16 * SK_LD * 4, s, P);
+    }
+    NFDP_CHECK_LAUNCH("conv2d_squeeze");
+    return NFDP_OK;
+}
+
 // Upsample (reference :169-173: nn.Upsample(scale_factor = 2, mode = "nearest") -> Conv2d 3x3) as one launch: x [B][H/2][W/2][Cin] is read
 // through the index map of its x2 nearest-neighbour upsampling while the input tile is staged; H, W: the OUTPUT sides (powers of two).
 extern "C" int nfdp_conv2d_up2_supported(int B, int H, int W, int Cin, int Cout) {
@@ -2337,7 +2396,7 @@ extern "C" int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double*
 extern "C" int nfdp_conv1x1_ln_supported(long npix, int Cin, int Cout, int pre, int post) {
     if (npix <= 0 || !split_image_shape(Cout, Cin, 1, 1) || Cin > 128 || Cout % 4 != 0) return 0;
     if (post && Cout > 128) return 0;                    // the output LayerNorm needs all outputs of a pixel in one workgroup
-    return pre || post;
+    return 1;                                            // (neither LayerNorm: the plain conv, for its residual epilogue)
 }
 extern "C" int nfdp_conv1x1_ln_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, long npix, int Cin, int Cout,
                                    const float* bias, const float* pre_gain, const float* post_gain, const float* residual, int res_ld,
@@ -2345,7 +2404,6 @@ extern "C" int nfdp_conv1x1_ln_f32(const float* x, int x_ld, const void* w_packe
     NFDP_REQUIRE(x && w_packed && y, NFDP_EINVAL, "conv1x1_ln: null pointer");
     NFDP_REQUIRE(nfdp_conv1x1_ln_supported(npix, Cin, Cout, pre_gain != nullptr, post_gain != nullptr), NFDP_EUNSUPPORTED,
                  "conv1x1_ln: unsupported shape npix=%ld Cin=%d Cout=%d (Cin %% 32, Cin <= 128; output LayerNorm: Cout <= 128)", npix, Cin, Cout);
-    NFDP_REQUIRE(!residual || post_gain, NFDP_EINVAL, "conv1x1_ln: a residual goes with the output LayerNorm");
     NFDP_REQUIRE(x_ld >= Cin && x_ld % 4 == 0 && y_ld >= Cout && y_ld % 4 == 0 && (!residual || (res_ld >= Cout && res_ld % 4 == 0)) &&
                  (((uintptr_t)x | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)pre_gain | (uintptr_t)post_gain | (uintptr_t)residual) % 16) == 0,
                  NFDP_ESHAPE, "conv1x1_ln: rows and vectors must be 16-byte aligned");
@@ -2372,8 +2430,13 @@ extern "C" int nfdp_conv1x1_ln_f32(const float* x, int x_ld, const void* w_packe
         }
     } else {
         const dim3 grid(P.Mt * P.Nt);
-        if (ns2) hipLaunchKernelGGL((conv1x1_ln_kernel<2, 1, true, false>), grid, blk, 0, s, P, ln);
-        else hipLaunchKernelGGL((conv1x1_ln_kernel<4, 1, true, false>), grid, blk, 0, s, P, ln);
+        if (pre_gain) {
+            if (ns2) hipLaunchKernelGGL((conv1x1_ln_kernel<2, 1, true, false>), grid, blk, 0, s, P, ln);
+            else hipLaunchKernelGGL((conv1x1_ln_kernel<4, 1, true, false>), grid, blk, 0, s, P, ln);
+        } else {
+            if (ns2) hipLaunchKernelGGL((conv1x1_ln_kernel<2, 1, false, false>), grid, blk, 0, s, P, ln);
+            else hipLaunchKernelGGL((conv1x1_ln_kernel<4, 1, false, false>), grid, blk, 0, s, P, ln);
+        }
     }
     NFDP_CHECK_LAUNCH("conv1x1_ln");
     return NFDP_OK;

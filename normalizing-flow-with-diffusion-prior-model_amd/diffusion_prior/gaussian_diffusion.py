@@ -89,6 +89,14 @@ class _Conv(nn.Module):
             self._packed, self._key = K.conv_pack(w, compute), key
         return self._packed
 
+    def packed2x2(self) -> Tensor:
+        """Downsample's 1x1 weight [Cout][4C] as the 2x2 / stride-2 weight [Cout][C][2][2] it is on the un-rearranged tensor
+        (rearranged channel = c * 4 + p1 * 2 + p2, reference :176-180), packed fp32."""
+        key = (self.weight.data_ptr(), self.weight._version, K.param_epoch())
+        if key != getattr(self, "_key22", None):
+            self._packed22, self._key22 = K.conv_pack(self.weight.detach().view(self.cout, self.cin // 4, 2, 2), K.F32), key
+        return self._packed22
+
     def forward_nhwc(self, xh: Tensor, compute: Optional[str] = None, x2: Optional[Tensor] = None) -> Tensor:
         """x2: the input is torch.cat((xh, x2), dim=channels), read from the two tensors (exact-fp32 inference; K.cat_sources_ok)."""
         c = K.compute_enum(compute)
@@ -298,7 +306,10 @@ def _attn_block_nhwc(res: Residual, xh: Tensor, compute=None) -> Tensor:
         o = conv.forward_nhwc(a, compute)
         return K.chan_layernorm(o, gpost, residual=xh)       # LayerNorm(to_out conv) + x
     a = K.attention(qkv, att.heads, att.dim_head, att.scale)
-    return K.add(att.to_out.forward_nhwc(a, compute), xh)
+    conv = att.to_out
+    if c == K.F32 and K.conv1x1_ln_supported(a, conv.cout, False, False, conv.bias, xh):
+        return K.conv1x1_ln(a, conv.packed(c), conv.cout, bias=conv.bias, residual=xh.contiguous())   # to_out + x in one launch
+    return K.add(conv.forward_nhwc(a, compute), xh)
 
 
 # ----------------------------------------------------------------------------- model (:363-490)
@@ -444,7 +455,11 @@ class Unet(_EpochOnApply, nn.Module):
             x = _attn_block_nhwc(attn, x, c)
             hs.append(x)
             if isinstance(downsample, nn.Sequential):
-                x = downsample[1].forward_nhwc(K.squeeze(x), c)          # Rearrange(p1 p2) + 1x1  (:176-180)
+                dn = downsample[1]
+                if K.compute_enum(c) == K.F32 and K.conv2d_squeeze_supported(x, dn.cout, dn.bias):
+                    x = K.conv2d_squeeze(x, dn.packed2x2(), dn.cout, dn.bias)   # Rearrange(p1 p2) + 1x1 (:176-180) = a 2x2 stride-2 conv
+                else:
+                    x = dn.forward_nhwc(K.squeeze(x), c)
             else:
                 x = downsample.forward_nhwc(x, c)
         x = rb(self.mid_block1, x)

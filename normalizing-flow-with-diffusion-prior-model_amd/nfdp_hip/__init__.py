@@ -1196,6 +1196,34 @@ def conv2d_up2(xh: torch.Tensor, packed: torch.Tensor, cout: int, bias=None) -> 
     return y
 
 
+_CONV_SQ_FUSED = True
+
+
+def set_conv_squeeze_fused(on: bool) -> None:
+    """Downsample (2x2 squeeze -> 1x1 conv) as one launch where conv2d_squeeze_supported (default) or as two."""
+    global _CONV_SQ_FUSED
+    _CONV_SQ_FUSED = bool(on)
+
+
+def conv2d_squeeze_supported(xh: torch.Tensor, cout: int, bias=None) -> bool:
+    if not (_CONV_SQ_FUSED and xh.is_cuda and xh.dtype == torch.float32 and xh.dim() == 4 and xh.stride(3) == 1 and
+            not torch.is_grad_enabled()):
+        return False
+    b, h, w, c = xh.shape
+    if xh.data_ptr() % 16 or xh.stride(2) % 4 or (bias is not None and bias.data_ptr() % 16) or h % 2 or w % 2 or not _is_dense_pixels(xh):
+        return False
+    return bool(lib().nfdp_conv2d_squeeze_supported(b, h // 2, w // 2, c, cout))
+
+
+def conv2d_squeeze(xh: torch.Tensor, packed2x2: torch.Tensor, cout: int, bias=None) -> torch.Tensor:
+    """conv1x1(squeeze(xh)) as the 2x2 / stride-2 conv it is (nfdp_conv2d_squeeze_nhwc_f32); packed2x2 = conv_pack(w.view(cout, C, 2, 2), F32)."""
+    b, h, w, c = xh.shape
+    y = torch.empty((b, h // 2, w // 2, cout), device=xh.device, dtype=torch.float32)
+    _call("nfdp_conv2d_squeeze_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_squeeze"), _ptr(packed2x2), _ptr(y), cout, b, h // 2, w // 2, c, cout,
+          _ptr(bias), _f32_compute(F32), _stream(), label=f"conv_splitk_f32 squeeze {c}x4->{cout} hw{h // 2}", flops=2.0 * b * h * w * c * cout)
+    return y
+
+
 def chan_layernorm(xh: torch.Tensor, gain: torch.Tensor, residual: Optional[torch.Tensor] = None, eps: float = 1e-5):
     _need(xh, torch.float32, "chan_layernorm"); _dense(xh, "chan_layernorm")
     c = xh.shape[-1]
@@ -1238,7 +1266,8 @@ def conv1x1_ln(xh: torch.Tensor, packed: torch.Tensor, cout: int, bias=None, pre
         res_ld = cout
     _call("nfdp_conv1x1_ln_f32", _ptr(xh), _ld(xh, "conv1x1_ln"), _ptr(packed), _ptr(y), cout, b * h * w, cin, cout, _ptr(bias),
           _ptr(pre_gain), _ptr(post_gain), _ptr(residual), res_ld, float(eps), _stream(),
-          label=f"conv1x1_ln{'+pre' if pre_gain is not None else ''}{'+post' if post_gain is not None else ''} {cin}->{cout}",
+          label=f"conv1x1_ln{'+pre' if pre_gain is not None else ''}{'+post' if post_gain is not None else ''}"
+                f"{'+res' if residual is not None and post_gain is None else ''} {cin}->{cout}",
           flops=2.0 * b * h * w * cin * cout)
     return y
 

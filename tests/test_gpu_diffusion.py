@@ -547,8 +547,8 @@ def test_attention_block_with_layernorms_inside_the_1x1_convs(b, hw, dim, kind):
     K.start_trace()
     fused = _attn_block_nhwc(blk, x, "f32")
     labels = [e["label"] for e in K.stop_trace()]
-    assert sum(lb.startswith("conv1x1_ln") for lb in labels) == (2 if kind == "linear" else 1), labels
-    assert not any(lb.startswith("chan_layernorm") for lb in labels), labels
+    assert sum(lb.startswith("conv1x1_ln") for lb in labels) == 2, labels      # (full attention: to_out + x in the conv's epilogue)
+    assert not any(lb.startswith("chan_layernorm") or lb.startswith("nfdp_add") for lb in labels), labels
     K.set_conv_ln_fused(False)
     try:
         plain = _attn_block_nhwc(blk, x, "f32")
@@ -679,3 +679,23 @@ def test_upsample_conv_in_one_launch_is_bit_identical(b, hw, cin, cout):
     ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.permute(0, 3, 1, 2).double().cpu(), scale_factor=2, mode="nearest"),
                                      w.double().cpu(), bias.double().cpu(), padding=1)
     assert_close(got.permute(0, 3, 1, 2), ref, 2e-5, "upsample + conv vs torch fp64")
+
+
+@pytest.mark.parametrize("b,hw,c,cout", [(64, 16, 64, 64), (3, 8, 64, 128), (2, 32, 96, 64), (5, 4, 128, 128)])
+@torch.no_grad()
+def test_downsample_as_a_stride_two_conv(b, hw, c, cout):
+    """Downsample (reference gaussian_diffusion.py:176-180: Rearrange 'b c (h p1) (w p2) -> b (c p1 p2) h w' -> Conv2d 1x1) as the 2x2 /
+    stride-2 conv it is on the un-rearranged tensor (nfdp_conv2d_squeeze_nhwc_f32) against squeeze launch + 1x1 conv (2e-6: another K
+    association) and against torch fp64 with einops' channel order spelled out."""
+    torch.manual_seed(b + hw + c)
+    x = torch.randn(b, hw, hw, c, device=DEV)
+    w = torch.randn(cout, 4 * c, 1, 1, device=DEV) * 0.05
+    bias = torch.randn(cout, device=DEV)
+    assert K.conv2d_squeeze_supported(x, cout, bias)
+    got = K.conv2d_squeeze(x, K.conv_pack(w.view(cout, c, 2, 2), K.F32), cout, bias)
+    want = K.conv2d(K.squeeze(x), K.conv_pack(w, K.F32), cout, 1, add=bias, compute=K.compute_enum("f32"), out_dtype=K.F32)
+    assert_close(got, want, 2e-6, "stride-2 conv vs squeeze + 1x1")
+    xc = x.permute(0, 3, 1, 2).double().cpu()
+    xr = xc.reshape(b, c, hw // 2, 2, hw // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(b, 4 * c, hw // 2, hw // 2)   # (c p1 p2)
+    ref = torch.nn.functional.conv2d(xr, w.double().cpu(), bias.double().cpu())
+    assert_close(got.permute(0, 3, 1, 2), ref, 2e-5, "Downsample vs torch fp64")
