@@ -1827,6 +1827,14 @@ void launch_by_cout(ConvParams& P, hipStream_t s) {
         launch_cfg_small<BF16, XBF16, VEC>(P, s);
         return;
     }
+    if constexpr (!BF16) {
+        // a narrow fp32 output at sampling sizes (the U-Nets' final 1x1 conv, 64 -> 2..16 over 16 k pixels): 256-pixel tiles are 64
+        // workgroups on 256 CUs; 64-pixel tiles fill the chip (10.8 -> us per call at B = 64, 16x16)
+        if (tile_n_for(P.Cout) == 16 && cdiv(P.npix, 256) < 256) {
+            launch_cfg<BF16, XBF16, VEC, 64, 16, 4, 1>(P, s);
+            return;
+        }
+    }
     switch (tile_n_for(P.Cout)) {
         case 16: launch_cfg<BF16, XBF16, VEC, 256, 16, 4, 1>(P, s); break;
         case 32: launch_cfg<BF16, XBF16, VEC, 256, 32, 4, 1>(P, s); break;

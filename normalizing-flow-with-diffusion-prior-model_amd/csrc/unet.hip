@@ -1172,6 +1172,139 @@ extern "C" int nfdp_upsample_nearest2x_f32(const float* x, float* y, int B, int 
     return NFDP_OK;
 }
 
+// ----------------------------------------------------------------------------- Unet.init_conv: 7x7 over 1-4 input channels (:383)
+// K = 49 * Cin <= 196 with Cin not a multiple of 4: the implicit-GEMM kernel gathers it element by element (13.6 us for the 16x16 / B = 64
+// latent part - 0.2 GFLOP).  A direct conv on the vector ALU: a workgroup takes 64 consecutive pixels x 64 output channels, a thread 4
+// consecutive pixels of one image row (W % 4 == 0) x 4 outputs - lane = (output quad, pixel group), so that a pixel's 64 outputs leave
+// the wave as one 256-byte row.  The pixels and their halo (the flat range [m0 - 3(W+1), m0 + 64 + 3(W+1)) holds every 7x7 neighbour
+// whatever the geometry) and the 64 outputs' weights ([49][Cin][Cout] copy of the parameter, nfdp_conv_k7_pack_f32: a straight 16-byte
+// copy) sit in LDS; per row of taps and channel the thread reads its 10-pixel window once (a column outside the image is zeroed there:
+// validity belongs to the SOURCE column, whichever of the 4 pixels and 7 taps reads it) and one float4 of weights per tap feeds 16 FMAs
+// (fp32 chains, tap-major, channel-minor).  Tried on the way: workgroups of 4 or 16 outputs (16 CUs write 16-byte pieces of every output
+// row: 10.5 us whatever the inner loop), weights through the scalar cache (s_load_dwordx16 per (tap, channel): ~700 cycles each, 28 us).
+__global__ void conv_k7_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin) {
+    const int n = Cout * Cin * 49;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int o = i % Cout, r = i / Cout, ci = r % Cin, tap = r / Cin;
+        out[i] = w[((size_t)o * Cin + ci) * 49 + tap];
+    }
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(256) conv_k7_narrow_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ wk,
+                                                            const float* __restrict__ bias, float* __restrict__ y, int y_ld, int npix,
+                                                            int H, int W, int Cout) {
+    extern __shared__ __attribute__((aligned(16))) float k7sm[];
+    const int HALO = 3 * (W + 1), NP = 64 + 2 * HALO;
+    float* ws = k7sm;                                   // [49 * CIN][64]
+    float* xs = k7sm + 49 * CIN * 64;                   // [NP][CIN]
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64, tid = threadIdx.x;
+    {   // weights: 49 * CIN rows of 16 float4, all requested before the first is stored
+        constexpr int NV = 49 * CIN * 16, NE = (NV + 255) / 256;
+        float4 v[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = e * 256 + tid, ic = i < NV ? i : NV - 1;
+            const int row = ic >> 4, q4 = (ic & 15) * 4;
+            const int n = n0 + q4 < Cout ? n0 + q4 : 0;                 // (Cout % 4 == 0; beyond Cout: a valid address, never used)
+            v[e] = *reinterpret_cast<const float4*>(wk + (size_t)row * Cout + n);
+        }
+        for (int i = tid; i < NP * CIN; i += 256) {                     // (NP * CIN <= 256 * 4 for W <= 32: 1-4 round trips)
+            const int g = m0 - HALO + i / CIN, c = i % CIN;
+            const int gc = g < 0 ? 0 : (g < npix ? g : npix - 1);
+            const float t = x[(size_t)gc * x_ld + c];
+            xs[i] = (g >= 0 && g < npix) ? t : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            const int i = e * 256 + tid;
+            if (i < NV) *reinterpret_cast<float4*>(ws + 4 * i) = v[e];
+        }
+    }
+    __syncthreads();
+    const int oq = tid & 15, pg = tid >> 4;             // output quad, pixel group
+    const int p0 = m0 + 4 * pg;                         // 4 pixels of one row (npix % 4 == 0: all four or none)
+    if (p0 >= npix || n0 + 4 * oq >= Cout) return;
+    const int r = p0 % (H * W), py = r / W, px0 = r % W;
+    float acc[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[k][o] = 0.f;
+#pragma unroll 1
+    for (int dy = -3; dy <= 3; ++dy) {
+        const bool rowok = (unsigned)(py + dy) < (unsigned)H;
+        const float* xrow = xs + (4 * pg + HALO + dy * W - 3) * CIN;
+        float xw[CIN][10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const bool ok = rowok && (unsigned)(px0 + j - 3) < (unsigned)W;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float v = xrow[j * CIN + ci];
+                xw[ci][j] = ok ? v : 0.f;
+            }
+        }
+        const float* wrow = ws + (dy + 3) * 7 * CIN * 64 + 4 * oq;
+#pragma unroll
+        for (int dx = 0; dx < 7; ++dx)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float4 wv = *reinterpret_cast<const float4*>(wrow + (dx * CIN + ci) * 64);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xv = xw[ci][k + dx];
+                    acc[k][0] = __fmaf_rn(xv, wv.x, acc[k][0]); acc[k][1] = __fmaf_rn(xv, wv.y, acc[k][1]);
+                    acc[k][2] = __fmaf_rn(xv, wv.z, acc[k][2]); acc[k][3] = __fmaf_rn(xv, wv.w, acc[k][3]);
+                }
+            }
+    }
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b4 = *reinterpret_cast<const float4*>(bias + n0 + 4 * oq);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        *reinterpret_cast<float4*>(y + (size_t)(p0 + k) * y_ld + n0 + 4 * oq) =
+            make_float4(__fadd_rn(acc[k][0], b4.x), __fadd_rn(acc[k][1], b4.y), __fadd_rn(acc[k][2], b4.z), __fadd_rn(acc[k][3], b4.w));
+}
+
+static size_t k7_lds_bytes(int W, int Cin) { return (size_t)(49 * Cin * 64 + (64 + 6 * (W + 1)) * Cin) * 4; }
+
+extern "C" int nfdp_conv_k7_narrow_supported(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || W % 4 != 0 || Cin < 1 || Cin > 4 || Cout < 4 || Cout % 4 != 0) return 0;
+    return (long)B * H * W < (1L << 31) - 4096 && k7_lds_bytes(W, Cin) <= 64 * 1024;
+}
+
+// w_k7 [49][Cin][Cout] fp32 from the [Cout][Cin][7][7] parameter
+extern "C" int nfdp_conv_k7_pack_f32(const float* w_oihw, float* w_k7, int Cout, int Cin, nfdp_stream_t stream) {
+    NFDP_REQUIRE(w_oihw && w_k7, NFDP_EINVAL, "conv_k7_pack: null pointer");
+    NFDP_REQUIRE(Cin >= 1 && Cout >= 1, NFDP_ESHAPE, "conv_k7_pack: bad shape");
+    hipLaunchKernelGGL(conv_k7_pack_kernel, dim3(stream_grid((long)Cout * Cin * 49, kBlock)), dim3(kBlock), 0, as_stream(stream), w_oihw, w_k7, Cout, Cin);
+    NFDP_CHECK_LAUNCH("conv_k7_pack");
+    return NFDP_OK;
+}
+
+// y [npix][y_ld] = conv7x7(x [B][H][W][Cin] (rows x_ld), padding 3) + bias; w_k7 from nfdp_conv_k7_pack_f32.
+extern "C" int nfdp_conv_k7_narrow_f32(const float* x, int x_ld, const float* w_k7, const float* bias, float* y, int y_ld, int B, int H,
+                                       int W, int Cin, int Cout, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && w_k7 && y, NFDP_EINVAL, "conv_k7_narrow: null pointer");
+    NFDP_REQUIRE(nfdp_conv_k7_narrow_supported(B, H, W, Cin, Cout), NFDP_EUNSUPPORTED,
+                 "conv_k7_narrow: unsupported geometry B=%d H=%d W=%d (%% 4) Cin=%d (1..4) Cout=%d (%% 4)", B, H, W, Cin, Cout);
+    NFDP_REQUIRE(x_ld >= Cin && y_ld >= Cout && y_ld % 4 == 0 && (((uintptr_t)y | (uintptr_t)bias | (uintptr_t)w_k7) % 16) == 0, NFDP_ESHAPE,
+                 "conv_k7_narrow: output rows, weights and bias must be 16-byte aligned");
+    const int npix = B * H * W;
+    const dim3 grid((npix + 63) / 64, (Cout + 63) / 64);
+    const size_t lds = k7_lds_bytes(W, Cin);
+    hipStream_t s = as_stream(stream);
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL(conv_k7_narrow_kernel<1>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break;
+        case 2: hipLaunchKernelGGL(conv_k7_narrow_kernel<2>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break;
+        case 3: hipLaunchKernelGGL(conv_k7_narrow_kernel<3>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break;
+        default: hipLaunchKernelGGL(conv_k7_narrow_kernel<4>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break;
+    }
+    NFDP_CHECK_LAUNCH("conv_k7_narrow");
+    return NFDP_OK;
+}
+
 extern "C" int nfdp_add_f32(const float* a, const float* b, float* out, long n, nfdp_stream_t stream) {
     NFDP_REQUIRE(a && b && out, NFDP_EINVAL, "add: null pointer");
     NFDP_REQUIRE(n >= 0, NFDP_ESHAPE, "add: bad size");

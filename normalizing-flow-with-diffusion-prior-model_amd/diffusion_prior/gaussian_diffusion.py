@@ -89,6 +89,13 @@ class _Conv(nn.Module):
             self._packed, self._key = K.conv_pack(w, compute), key
         return self._packed
 
+    def packed_k7(self) -> Tensor:
+        """Unet.init_conv's weight in the layout of the direct 7x7 kernel (K.conv_k7_pack)."""
+        key = (self.weight.data_ptr(), self.weight._version, K.param_epoch())
+        if key != getattr(self, "_key_k7", None):
+            self._packed_k7, self._key_k7 = K.conv_k7_pack(self.weight.detach()), key
+        return self._packed_k7
+
     def packed2x2(self) -> Tensor:
         """Downsample's 1x1 weight [Cout][4C] as the 2x2 / stride-2 weight [Cout][C][2][2] it is on the un-rearranged tensor
         (rearranged channel = c * 4 + p1 * 2 + p2, reference :176-180), packed fp32."""
@@ -443,7 +450,11 @@ class Unet(_EpochOnApply, nn.Module):
     def forward_nhwc(self, xh: Tensor, time: Tensor, x_self_cond_h: Optional[Tensor] = None) -> Tensor:
         c = self.compute
         xh = self.with_self_cond(xh, x_self_cond_h)
-        x = self.init_conv.forward_nhwc(xh, c)
+        ic = self.init_conv
+        if K.compute_enum(c) == K.F32 and ic.k == 7 and K.conv_k7_narrow_supported(xh, ic.cout, ic.bias):
+            x = K.conv_k7_narrow(xh, ic.packed_k7(), ic.cout, ic.bias)     # 7x7 over 1-4 latent channels: the direct fp32 kernel
+        else:
+            x = ic.forward_nhwc(xh, c)
         r = x
         ss = self._scale_shifts_for(time)
         rb = lambda blk, inp: blk.forward_nhwc(inp, None, c, scale_shift=ss[id(blk)])

@@ -1162,6 +1162,43 @@ def conv2d_gnin(xh: torch.Tensor, sums: torch.Tensor, tile: int, in_groups: int,
     return y
 
 
+_CONV_K7_NARROW = True
+
+
+def set_conv_k7_narrow(on: bool) -> None:
+    """Unet.init_conv over 1-4 input channels on the direct fp32 kernel (default) or on the implicit-GEMM conv."""
+    global _CONV_K7_NARROW
+    _CONV_K7_NARROW = bool(on)
+
+
+def conv_k7_narrow_supported(xh: torch.Tensor, cout: int, bias=None) -> bool:
+    if not (_CONV_K7_NARROW and xh.is_cuda and xh.dtype == torch.float32 and xh.dim() == 4 and (xh.stride(3) == 1 or xh.shape[3] == 1) and
+            not torch.is_grad_enabled() and _is_dense_pixels(xh)):
+        return False
+    b, h, w, cin = xh.shape
+    return (bias is None or bias.data_ptr() % 16 == 0) and bool(lib().nfdp_conv_k7_narrow_supported(b, h, w, cin, cout))
+
+
+def conv_k7_pack(w_oihw: torch.Tensor) -> torch.Tensor:
+    """[Cout][Cin][7][7] -> the [49][Cin][Cout] copy conv_k7_narrow reads (nfdp_conv_k7_pack_f32)."""
+    _need(w_oihw, torch.float32, "conv_k7_pack"); _dense(w_oihw, "conv_k7_pack")
+    cout, cin = w_oihw.shape[:2]
+    assert tuple(w_oihw.shape[2:]) == (7, 7)
+    out = torch.empty(cout * cin * 49, device=w_oihw.device, dtype=torch.float32)
+    _call("nfdp_conv_k7_pack_f32", _ptr(w_oihw), _ptr(out), cout, cin, _stream())
+    return out
+
+
+def conv_k7_narrow(xh: torch.Tensor, w_k7: torch.Tensor, cout: int, bias=None) -> torch.Tensor:
+    """7x7 conv (padding 3) over 1-4 input channels as exact fp32 FMA chains (nfdp_conv_k7_narrow_f32); w_k7 = conv_k7_pack(weight)."""
+    b, h, w, cin = xh.shape
+    assert w_k7.numel() == cout * cin * 49
+    y = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
+    _call("nfdp_conv_k7_narrow_f32", _ptr(xh), _ld(xh, "conv_k7_narrow"), _ptr(w_k7), _ptr(bias), _ptr(y), cout, b, h, w, cin, cout, _stream(),
+          label=f"conv_k7_narrow {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * 49 * cout)
+    return y
+
+
 _CONV_UP_FUSED = True
 
 

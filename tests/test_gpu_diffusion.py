@@ -699,3 +699,21 @@ def test_downsample_as_a_stride_two_conv(b, hw, c, cout):
     xr = xc.reshape(b, c, hw // 2, 2, hw // 2, 2).permute(0, 1, 3, 5, 2, 4).reshape(b, 4 * c, hw // 2, hw // 2)   # (c p1 p2)
     ref = torch.nn.functional.conv2d(xr, w.double().cpu(), bias.double().cpu())
     assert_close(got.permute(0, 3, 1, 2), ref, 2e-5, "Downsample vs torch fp64")
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(64, 16, 16, 2, 64), (3, 8, 8, 4, 64), (2, 20, 12, 3, 20), (5, 4, 4, 1, 128), (1, 64, 64, 2, 64)])
+@torch.no_grad()
+def test_direct_7x7_conv_over_few_input_channels(b, h, w, cin, cout):
+    """Unet.init_conv (reference gaussian_diffusion.py:383) on the direct fp32 kernel (nfdp_conv_k7_narrow_f32: 64 pixels x 64 outputs per
+    workgroup, FMA chains over (tap, channel)) against the implicit-GEMM conv and torch fp64; 1-4 input channels, non-square / non-power-of-two
+    images, partial pixel tiles."""
+    torch.manual_seed(b + h + cin + cout)
+    x = torch.randn(b, h, w, cin, device=DEV)
+    wt = torch.randn(cout, cin, 7, 7, device=DEV) * 0.1
+    bias = torch.randn(cout, device=DEV)
+    assert K.conv_k7_narrow_supported(x, cout, bias)
+    got = K.conv_k7_narrow(x, K.conv_k7_pack(wt), cout, bias)
+    want = K.conv2d(x, K.conv_pack(wt, K.F32), cout, 7, add=bias, compute=K.compute_enum("f32"), out_dtype=K.F32)
+    assert_close(got, want, 5e-6, "direct 7x7 vs implicit GEMM")
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), bias.double().cpu(), padding=3)
+    assert_close(got.permute(0, 3, 1, 2), ref, 1e-5, "direct 7x7 vs torch fp64")
