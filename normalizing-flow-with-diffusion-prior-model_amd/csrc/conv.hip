@@ -1447,6 +1447,317 @@ __global__ void __launch_bounds__(256) conv1x1_ln_kernel(const ConvParams P, con
         }
 }
 
+// ----------------------------------------------------------------------------- LinearAttention with its to_qkv projection inside
+// Residual(PreNorm(dim, LinearAttention)) (reference gaussian_diffusion.py:305-333) as conv1x1_ln (LayerNorm + to_qkv) -> attention core
+// writes and re-reads the [B][n][3 * heads * 32] qkv tensor (25 MB at B = 64, 16x16: the projection launch is bound by writing it, 13.7 us,
+// and the core starts by staging its slice of it).  Here the workgroup of a (sample, head) forms its own 96 qkv rows: a wave takes 16-pixel
+// tiles, loads the pixels' C input channels in MFMA shape, normalises them (LayerNorm as conv1x1_ln_kernel: the four q-lanes of a pixel
+// hold its channels), splits them once and multiplies them with the head's six 16-row tiles of the packed weight's split image - k and v
+// land in the LDS arrays the core works on, q stays in registers until the core wants it.  Same products in the same order as
+// conv1x1_ln_kernel and the same core as linear_attention_staged_kernel (unet.hip); against the two launches the q / k / v rows agree to
+// 1-2 ulp and the outputs to 4e-7 relative (linear) / 5e-6 element-wise (softmax attention).
+// n = 64 NPT pixels (8x8, 16x16), C = 32 NS input channels (64, 128), dim_head 32.
+// The q / k / v rows of one (sample, head) for the calling wave's pixel tiles (tile = wave + 4 t): acc[t][rt], rt = q0 q1 k0 k1 v0 v1,
+// D[row = channel 16 (rt & 1) + 4 q + r][col = pixel r16].  LayerNorm and products as conv1x1_ln_kernel.
+template <int NS, int NPT>
+__device__ __forceinline__ void head_qkv_rows(const float* __restrict__ x, int x_ld, const float* __restrict__ gain, const char* wimg,
+                                              int b, int hd, int HD, float eps, int wave, int r16, int q, f32x4 (&acc)[NPT][6]) {
+    constexpr int DHc = 32, n = 64 * NPT, C = 32 * NS;
+    // Everything is requested up front - the tiles' input rows, the first
+    // stage's 18 weight fragments - and a K stage is outer: its weights are loaded once per wave and meet all NPT tiles (tile-outer,
+    // every tile waited for its own x rows and 18 L2 round trips per stage: the phase took ~10 us of the launch)
+    float4 xv[NPT][NS][2];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int pix = (wave + 4 * t) * 16 + r16;
+        const float* src = x + ((size_t)b * n + pix) * x_ld + 8 * q;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            xv[t][s][0] = *reinterpret_cast<const float4*>(src + 32 * s);
+            xv[t][s][1] = *reinterpret_cast<const float4*>(src + 32 * s + 4);
+        }
+    }
+    struct WS { bf16x8 h[6], m[6], l[6]; };
+    auto loadw = [&](WS& f, int s) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rt = 0; rt < 6; ++rt) {
+            const int row = (rt >> 1) * HD + hd * DHc + 16 * (rt & 1);              // (uniform)
+            const char* wb = wimg + ((size_t)(row >> 6) * NS + s) * LX_BLOCK + 3 * ((row & 63) >> 4) * 1024;
+            f.h[rt] = *reinterpret_cast<const bf16x8*>(wb);
+            f.m[rt] = *reinterpret_cast<const bf16x8*>(wb + 1024);
+            f.l[rt] = *reinterpret_cast<const bf16x8*>(wb + 2048);
+        }
+    };
+    WS wq[2];
+    loadw(wq[0], 0);
+    float4 gpre[NS][2];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        gpre[s][0] = *reinterpret_cast<const float4*>(gain + 32 * s + 8 * q);
+        gpre[s][1] = *reinterpret_cast<const float4*>(gain + 32 * s + 8 * q + 4);
+    }
+    bf16x8 xh[NPT][NS], xm[NPT][NS], xl[NPT][NS];
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        double s1 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            s1 += ((double)xv[t][s][0].x + (double)xv[t][s][0].y) + ((double)xv[t][s][0].z + (double)xv[t][s][0].w) +
+                  ((double)xv[t][s][1].x + (double)xv[t][s][1].y) + ((double)xv[t][s][1].z + (double)xv[t][s][1].w);
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const double mean = s1 / C;
+        double s2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float vals[8] = {xv[t][s][0].x, xv[t][s][0].y, xv[t][s][0].z, xv[t][s][0].w, xv[t][s][1].x, xv[t][s][1].y, xv[t][s][1].z, xv[t][s][1].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const double d = vals[e] - mean; s2 += d * d; }
+        }
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float m = (float)mean, r = rsqrtf(__fadd_rn((float)(s2 / C), eps));
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 a = xv[t][s][0], c = xv[t][s][1], g0 = gpre[s][0], g1 = gpre[s][1];
+            const float x8[8] = {__fmul_rn(__fmul_rn(__fsub_rn(a.x, m), r), g0.x), __fmul_rn(__fmul_rn(__fsub_rn(a.y, m), r), g0.y),
+                                 __fmul_rn(__fmul_rn(__fsub_rn(a.z, m), r), g0.z), __fmul_rn(__fmul_rn(__fsub_rn(a.w, m), r), g0.w),
+                                 __fmul_rn(__fmul_rn(__fsub_rn(c.x, m), r), g1.x), __fmul_rn(__fmul_rn(__fsub_rn(c.y, m), r), g1.y),
+                                 __fmul_rn(__fmul_rn(__fsub_rn(c.z, m), r), g1.z), __fmul_rn(__fmul_rn(__fsub_rn(c.w, m), r), g1.w)};
+            split3(x8, xh[t][s], xm[t][s], xl[t][s]);
+        }
+    }
+    // per tile: row tiles q0 q1 k0 k1 v0 v1, side by side (no dependent MFMA pairs)
+#pragma unroll
+    for (int t = 0; t < NPT; ++t)
+#pragma unroll
+        for (int rt = 0; rt < 6; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (s + 1 < NS) loadw(wq[(s + 1) & 1], s + 1);
+        const WS& w = wq[s & 1];
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) {
+            // the six products of conv1x1_ln_kernel in its order per accumulator, the accumulators interleaved
+#pragma unroll
+            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[rt], xh[t][s], acc[t][rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xl[t][s], acc[t][rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m[rt], xm[t][s], acc[t][rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m[rt], xh[t][s], acc[t][rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xm[t][s], acc[t][rt], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xh[t][s], acc[t][rt], 0, 0, 0);
+        }
+    }
+}
+
+template <int NS, int NPT>
+__global__ void __launch_bounds__(256) linattn_qkv_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ gain,
+                                                         const char* __restrict__ wimg0, float* __restrict__ out, int heads, float scale,
+                                                         float eps) {
+    constexpr int DHc = 32, LP = DHc + 1, n = 64 * NPT, C = 32 * NS;
+    __shared__ float kmax[DHc], ksum[DHc];
+    __shared__ __attribute__((aligned(16))) float ctx4[DHc][DHc];
+    __shared__ float part[8][DHc];
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    float* ksm = lsm;
+    float* vsm = lsm + n * LP;
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, HD = heads * DHc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q = lane >> 4;
+    const char* wimg = wimg0 + lane * 16;
+    // ---- 0. qkv rows of this head for the wave's pixel tiles
+    f32x4 acc[NPT][6];
+    head_qkv_rows<NS, NPT>(x, x_ld, gain, wimg, b, hd, HD, eps, wave, r16, q, acc);
+    // D[row = channel 16 j + 4 q + r][col = pixel r16]: k and v into the core's LDS arrays, q stays in its accumulators
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int pix = (wave + 4 * t) * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* kd = ksm + pix * LP + 16 * j + 4 * q;
+            float* vd = vsm + pix * LP + 16 * j + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { kd[e] = acc[t][2 + j][e]; vd[e] = acc[t][4 + j][e]; }
+        }
+    }
+    __syncthreads();
+    // ---- 1.-4.: linear_attention_staged_kernel's core (unet.hip), n a compile-time constant
+    const int d = tid % DHc, grp = tid / DHc;
+    const int r = tid >> 3, c4 = (tid & 7) * 4;
+    float mx = -INFINITY;
+    for (int i = grp; i < n; i += 8) mx = fmaxf(mx, ksm[i * LP + d]);
+    part[grp][d] = mx;
+    __syncthreads();
+    if (tid < DHc) {
+        float mm = part[0][d];
+        for (int g = 1; g < 8; ++g) mm = fmaxf(mm, part[g][d]);
+        kmax[d] = mm;
+    }
+    __syncthreads();
+    float sm = 0.f;
+    {
+        const float km = kmax[d];
+        for (int i = grp; i < n; i += 8) {
+            const float ev = expf(ksm[i * LP + d] - km);
+            ksm[i * LP + d] = ev;
+            sm += ev;
+        }
+    }
+    __syncthreads();
+    part[grp][d] = sm;
+    __syncthreads();
+    if (tid < DHc) {
+        float ss = 0.f;
+        for (int g = 0; g < 8; ++g) ss += part[g][d];
+        ksum[d] = ss;
+    }
+    __syncthreads();
+    {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < n; ++i) {
+            const float p = ksm[i * LP + d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(p, vsm[i * LP + 4 * grp + j], acc[j]);
+        }
+        const float f = 1.0f / (ksum[d] * (float)n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ctx4[d][4 * grp + j] = acc[j] * f;
+    }
+    __syncthreads();
+    float* qs = ksm;
+    float* os = vsm;
+#pragma unroll
+    for (int t = 0; t < NPT; ++t) {
+        const int pix = (wave + 4 * t) * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float* qd = qs + pix * LP + 16 * j + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qd[e] = acc[t][j][e];
+        }
+    }
+    __syncthreads();
+    if (tid < n) {
+        const int i = tid;
+        float qv[DHc];
+        float mq = -INFINITY;
+#pragma unroll
+        for (int dd = 0; dd < DHc; ++dd) { qv[dd] = qs[i * LP + dd]; mq = fmaxf(mq, qv[dd]); }
+        float sq = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DHc; ++dd) { qv[dd] = expf(qv[dd] - mq); sq += qv[dd]; }
+#pragma unroll
+        for (int dd = 0; dd < DHc; ++dd) qv[dd] = __fmul_rn(qv[dd] / sq, scale);
+        float acc[DHc];
+#pragma unroll
+        for (int e = 0; e < DHc; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DHc; ++dd) {
+#pragma unroll
+            for (int e4 = 0; e4 < DHc / 4; ++e4) {
+                const float4 c = *reinterpret_cast<const float4*>(&ctx4[dd][4 * e4]);
+                acc[4 * e4 + 0] = fmaf(c.x, qv[dd], acc[4 * e4 + 0]);
+                acc[4 * e4 + 1] = fmaf(c.y, qv[dd], acc[4 * e4 + 1]);
+                acc[4 * e4 + 2] = fmaf(c.z, qv[dd], acc[4 * e4 + 2]);
+                acc[4 * e4 + 3] = fmaf(c.w, qv[dd], acc[4 * e4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < DHc; ++e) os[i * LP + e] = acc[e];
+    }
+    __syncthreads();
+    float* obase = out + (size_t)b * n * HD + hd * DHc;
+#pragma unroll
+    for (int it = 0; it < n / 32; ++it) {
+        const int i = r + 32 * it;
+        const float* od = os + i * LP + c4;
+        *reinterpret_cast<float4*>(obase + (size_t)i * HD + c4) = make_float4(od[0], od[1], od[2], od[3]);
+    }
+}
+
+// The same for Attention (reference :336-358; the mid block, n = 64 keys): to_qkv inside attention_kernel's launch (unet.hip: four
+// threads per query over the keys p, p + 4, ...; row maximum = max over the parts' maxima, exp sums and value sums added in part order).
+template <int NS>
+__global__ void __launch_bounds__(256) attn_qkv_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ gain,
+                                                      const char* __restrict__ wimg0, float* __restrict__ out, int heads, float scale,
+                                                      float eps) {
+    constexpr int DHc = 32, n = 64, NP = 4, nq = 64, PP = DHc + 2;
+    __shared__ __attribute__((aligned(16))) float Ks[n * DHc], Vs[n * DHc], Qs[n * DHc], Ps[NP * nq * PP];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, HD = heads * DHc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q16 = lane >> 4;
+    {
+        f32x4 acc[1][6];
+        head_qkv_rows<NS, 1>(x, x_ld, gain, wimg0 + lane * 16, b, hd, HD, eps, wave, r16, q16, acc);
+        const int pix = wave * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int o = pix * DHc + 16 * j + 4 * q16;
+            *reinterpret_cast<float4*>(Qs + o) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
+            *reinterpret_cast<float4*>(Ks + o) = make_float4(acc[0][2 + j][0], acc[0][2 + j][1], acc[0][2 + j][2], acc[0][2 + j][3]);
+            *reinterpret_cast<float4*>(Vs + o) = make_float4(acc[0][4 + j][0], acc[0][4 + j][1], acc[0][4 + j][2], acc[0][4 + j][3]);
+        }
+    }
+    __syncthreads();
+    const int i = tid & (nq - 1), p = tid >> 6;
+    float qv[DHc];
+#pragma unroll
+    for (int dd = 0; dd < DHc; dd += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(Qs + i * DHc + dd);
+        qv[dd] = __fmul_rn(v.x, scale); qv[dd + 1] = __fmul_rn(v.y, scale); qv[dd + 2] = __fmul_rn(v.z, scale); qv[dd + 3] = __fmul_rn(v.w, scale);
+    }
+    float mx = -INFINITY;
+    auto dot = [&](int j) __attribute__((always_inline)) {
+        const float4* kr = reinterpret_cast<const float4*>(Ks + j * DHc);
+        float sdot = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < DHc / 4; ++d4) {
+            const float4 kv = kr[d4];
+            sdot = fmaf(qv[4 * d4], kv.x, sdot); sdot = fmaf(qv[4 * d4 + 1], kv.y, sdot);
+            sdot = fmaf(qv[4 * d4 + 2], kv.z, sdot); sdot = fmaf(qv[4 * d4 + 3], kv.w, sdot);
+        }
+        return sdot;
+    };
+    for (int j = p; j < n; j += NP) mx = fmaxf(mx, dot(j));
+    Ps[(p * nq + i) * PP] = mx;
+    __syncthreads();
+    for (int pp = 0; pp < NP; ++pp) mx = fmaxf(mx, Ps[(pp * nq + i) * PP]);
+    __syncthreads();
+    float o[DHc];
+#pragma unroll
+    for (int dd = 0; dd < DHc; ++dd) o[dd] = 0.f;
+    float den = 0.f;
+    for (int j = p; j < n; j += NP) {
+        const float pr = expf(dot(j) - mx);
+        den += pr;
+        const float4* vr = reinterpret_cast<const float4*>(Vs + j * DHc);
+#pragma unroll
+        for (int d4 = 0; d4 < DHc / 4; ++d4) {
+            const float4 vv = vr[d4];
+            o[4 * d4] = fmaf(pr, vv.x, o[4 * d4]); o[4 * d4 + 1] = fmaf(pr, vv.y, o[4 * d4 + 1]);
+            o[4 * d4 + 2] = fmaf(pr, vv.z, o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(pr, vv.w, o[4 * d4 + 3]);
+        }
+    }
+    float* mine = Ps + (p * nq + i) * PP;
+    mine[1] = den;
+#pragma unroll
+    for (int dd = 0; dd < DHc; ++dd) mine[2 + dd] = o[dd];
+    __syncthreads();
+    float dsum = 0.f;
+    for (int pp = 0; pp < NP; ++pp) dsum += Ps[(pp * nq + i) * PP + 1];
+    float* orow = out + ((size_t)b * n + i) * HD + hd * DHc;
+    for (int dd = p; dd < DHc; dd += NP) {
+        float v = 0.f;
+        for (int pp = 0; pp < NP; ++pp) v += Ps[(pp * nq + i) * PP + 2 + dd];
+        orow[dd] = v / dsum;
+    }
+}
+
 // ----------------------------------------------------------------------------- pointwise conv on bf16 activations
 // The 512->512 1x1 convs of the training path (forward and data gradient) and the 512 -> 9*C tap GEMMs read a bf16
 // activation tensor whose rows ARE the GEMM's K-contiguous operand rows: no gather, no conversion.  Both operands go
@@ -2397,6 +2708,61 @@ extern "C" int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double*
                                    out_ss_ld, out_eps, residual, res_ld, NFDP_F32X6, stream, nullptr, 0, 0, &ex);
     return conv2d_impl(x, NFDP_F32, x_ld, w_packed, y, NFDP_F32, y_ld, B, H, W, Cin, Cout, 3, 3, bias, nullptr, 0.f, 0, NFDP_F32X6, stream,
                        nullptr, 0, 0, &ex);
+}
+
+// PreNorm -> LinearAttention (to_qkv + core) in one launch (linattn_qkv_kernel): x [B][n][C] (rows x_ld), w_packed = the to_qkv weight
+// [3 * heads * 32][C][1][1] packed fp32 (with its split image), out [B][n][heads * 32].
+extern "C" int nfdp_linear_attention_qkv_supported(int n, int C, int heads, int dim_head) {
+    return (n == 64 || n == 256) && (C == 64 || C == 128) && dim_head == 32 && heads >= 1 && heads <= 8 &&
+           split_image_shape(3 * heads * 32, C, 1, 1);
+}
+extern "C" int nfdp_linear_attention_qkv_f32(const float* x, int x_ld, const float* pre_gain, const void* w_packed, float* out, int B, int n,
+                                             int C, int heads, int dim_head, float scale, float eps, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && pre_gain && w_packed && out, NFDP_EINVAL, "linear_attention_qkv: null pointer");
+    NFDP_REQUIRE(B >= 0, NFDP_ESHAPE, "linear_attention_qkv: bad shape");
+    NFDP_REQUIRE(nfdp_linear_attention_qkv_supported(n, C, heads, dim_head), NFDP_EUNSUPPORTED,
+                 "linear_attention_qkv: n=%d (64, 256) C=%d (64, 128) heads=%d dim_head=%d (32)", n, C, heads, dim_head);
+    NFDP_REQUIRE(x_ld >= C && x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)pre_gain | (uintptr_t)out) % 16) == 0, NFDP_ESHAPE,
+                 "linear_attention_qkv: rows and vectors must be 16-byte aligned");
+    if (B == 0) return NFDP_OK;
+    const int rows = 3 * heads * 32;
+    const char* wimg = reinterpret_cast<const char*>(w_packed) + (size_t)cout_pad_for(rows) * kpad_for(C, 1, 1) * 4;
+    const size_t lds = (size_t)2 * n * 33 * sizeof(float);
+    hipStream_t s = as_stream(stream);
+    static NfdpPerDevice attr_set;
+    if (!attr_set) {
+        nfdp_func_attr(reinterpret_cast<const void*>(&linattn_qkv_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 33 * 4);
+        nfdp_func_attr(reinterpret_cast<const void*>(&linattn_qkv_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 33 * 4);
+        attr_set = true;
+    }
+    const dim3 grid(B * heads), blk(256);
+    if (C == 64 && n == 256) hipLaunchKernelGGL((linattn_qkv_kernel<2, 4>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
+    else if (C == 64) hipLaunchKernelGGL((linattn_qkv_kernel<2, 1>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
+    else if (n == 256) hipLaunchKernelGGL((linattn_qkv_kernel<4, 4>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
+    else hipLaunchKernelGGL((linattn_qkv_kernel<4, 1>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
+    NFDP_CHECK_LAUNCH("linear_attention_qkv");
+    return NFDP_OK;
+}
+
+// PreNorm -> Attention (to_qkv + softmax core) in one launch (attn_qkv_kernel): n = 64 keys, C in {64, 128}.
+extern "C" int nfdp_attention_qkv_supported(int n, int C, int heads, int dim_head) {
+    return n == 64 && (C == 64 || C == 128) && dim_head == 32 && heads >= 1 && heads <= 8 && split_image_shape(3 * heads * 32, C, 1, 1);
+}
+extern "C" int nfdp_attention_qkv_f32(const float* x, int x_ld, const float* pre_gain, const void* w_packed, float* out, int B, int n, int C,
+                                      int heads, int dim_head, float scale, float eps, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && pre_gain && w_packed && out, NFDP_EINVAL, "attention_qkv: null pointer");
+    NFDP_REQUIRE(B >= 0, NFDP_ESHAPE, "attention_qkv: bad shape");
+    NFDP_REQUIRE(nfdp_attention_qkv_supported(n, C, heads, dim_head), NFDP_EUNSUPPORTED,
+                 "attention_qkv: n=%d (64) C=%d (64, 128) heads=%d dim_head=%d (32)", n, C, heads, dim_head);
+    NFDP_REQUIRE(x_ld >= C && x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)pre_gain | (uintptr_t)out) % 16) == 0, NFDP_ESHAPE,
+                 "attention_qkv: rows and vectors must be 16-byte aligned");
+    if (B == 0) return NFDP_OK;
+    const char* wimg = reinterpret_cast<const char*>(w_packed) + (size_t)cout_pad_for(3 * heads * 32) * kpad_for(C, 1, 1) * 4;
+    hipStream_t s = as_stream(stream);
+    if (C == 64) hipLaunchKernelGGL((attn_qkv_kernel<2>), dim3(B * heads), dim3(256), 0, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
+    else hipLaunchKernelGGL((attn_qkv_kernel<4>), dim3(B * heads), dim3(256), 0, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
+    NFDP_CHECK_LAUNCH("attention_qkv");
+    return NFDP_OK;
 }
 
 // 1x1 conv with the channel LayerNorm of its input (pre_gain) and / or of its output (post_gain, + residual) in the same launch: the

@@ -300,19 +300,26 @@ def _attn_block_nhwc(res: Residual, xh: Tensor, compute=None) -> Tensor:
     c = K.compute_enum(compute)
     gpre = pre.norm.g.view(-1)
     hidden = att.heads * att.dim_head
+    a = None
+    lin = isinstance(att, LinearAttention)
+    if c == K.F32 and K.linear_attention_qkv_supported(xh, att.heads, att.dim_head, gpre, linear=lin):
+        # ... and to_qkv inside the attention core's launch: the qkv tensor is never written (two launches per block)
+        a = K.linear_attention_qkv(xh, gpre, att.to_qkv.packed(c), att.heads, att.dim_head, att.scale, linear=lin)
     # no-grad exact-fp32 calls: the LayerNorms ride in the 1x1 convs' launches (nfdp_conv1x1_ln_f32: five launches per block -> three)
-    if c == K.F32 and K.conv1x1_ln_supported(xh, 3 * hidden, True, False, gpre):
+    elif c == K.F32 and K.conv1x1_ln_supported(xh, 3 * hidden, True, False, gpre):
         qkv = K.conv1x1_ln(xh, att.to_qkv.packed(c), 3 * hidden, pre_gain=gpre)
     else:
         qkv = att.to_qkv.forward_nhwc(K.chan_layernorm(xh, gpre), compute)
     if isinstance(att, LinearAttention):
-        a = K.linear_attention(qkv, att.heads, att.dim_head, att.scale)
+        if a is None:
+            a = K.linear_attention(qkv, att.heads, att.dim_head, att.scale)
         conv, gpost = att.to_out[0], att.to_out[1].g.view(-1)
         if c == K.F32 and K.conv1x1_ln_supported(a, conv.cout, False, True, conv.bias, gpost, xh):
             return K.conv1x1_ln(a, conv.packed(c), conv.cout, bias=conv.bias, post_gain=gpost, residual=xh.contiguous())
         o = conv.forward_nhwc(a, compute)
         return K.chan_layernorm(o, gpost, residual=xh)       # LayerNorm(to_out conv) + x
-    a = K.attention(qkv, att.heads, att.dim_head, att.scale)
+    if a is None:
+        a = K.attention(qkv, att.heads, att.dim_head, att.scale)
     conv = att.to_out
     if c == K.F32 and K.conv1x1_ln_supported(a, conv.cout, False, False, conv.bias, xh):
         return K.conv1x1_ln(a, conv.packed(c), conv.cout, bias=conv.bias, residual=xh.contiguous())   # to_out + x in one launch

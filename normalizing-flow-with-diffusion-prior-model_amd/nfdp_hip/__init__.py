@@ -1364,6 +1364,42 @@ def linear_attention(qkv: torch.Tensor, heads: int, dim_head: int, scale: float)
     return out
 
 
+_ATTN_QKV_FUSED = True
+
+
+def set_attention_qkv_fused(on: bool) -> None:
+    """PreNorm -> LinearAttention with the to_qkv projection inside the attention launch (default, where supported) or as two launches."""
+    global _ATTN_QKV_FUSED
+    _ATTN_QKV_FUSED = bool(on)
+
+
+def linear_attention_qkv_supported(xh: torch.Tensor, heads: int, dim_head: int, gain, linear: bool = True) -> bool:
+    """to_qkv inside the attention core's launch is available for this input (linear: LinearAttention, else Attention)?"""
+    if not (_ATTN_QKV_FUSED and _CONV_LN_FUSED and _F32_PRODUCTS == "bf16x6" and xh.is_cuda and xh.dtype == torch.float32 and xh.dim() == 4 and
+            xh.stride(3) == 1 and not torch.is_grad_enabled() and _is_dense_pixels(xh)):
+        return False
+    if xh.data_ptr() % 16 or xh.stride(2) % 4 or gain.data_ptr() % 16:
+        return False
+    b, h, w, c = xh.shape
+    fn = lib().nfdp_linear_attention_qkv_supported if linear else lib().nfdp_attention_qkv_supported
+    return bool(fn(h * w, c, heads, dim_head))
+
+
+def linear_attention_qkv(xh: torch.Tensor, gain: torch.Tensor, packed: torch.Tensor, heads: int, dim_head: int, scale: float,
+                         eps: float = 1e-5, linear: bool = True) -> torch.Tensor:
+    """LinearAttention(LayerNorm(xh)) core (linear=False: Attention's) with its to_qkv projection in the same launch
+    (nfdp_linear_attention_qkv_f32 / nfdp_attention_qkv_f32; check linear_attention_qkv_supported first).  packed: conv_pack(to_qkv.weight, F32)."""
+    b, h, w, c = xh.shape
+    out = torch.empty((b, h, w, heads * dim_head), device=xh.device, dtype=torch.float32)
+    if not linear:
+        _call("nfdp_attention_qkv_f32", _ptr(xh), _ld(xh, "attention_qkv"), _ptr(gain), _ptr(packed), _ptr(out), b, h * w, c, heads,
+              dim_head, float(scale), float(eps), _stream(), label=f"attention+qkv {c} hw{h}", flops=2.0 * b * h * w * c * 3 * heads * dim_head)
+        return out
+    _call("nfdp_linear_attention_qkv_f32", _ptr(xh), _ld(xh, "linear_attention_qkv"), _ptr(gain), _ptr(packed), _ptr(out), b, h * w, c, heads,
+          dim_head, float(scale), float(eps), _stream(), label=f"linear_attention+qkv {c} hw{h}", flops=2.0 * b * h * w * c * 3 * heads * dim_head)
+    return out
+
+
 def attention(qkv: torch.Tensor, heads: int, dim_head: int, scale: float) -> torch.Tensor:
     _need(qkv, torch.float32, "attention"); _dense(qkv, "attention")
     b, h, w, _ = qkv.shape

@@ -547,8 +547,17 @@ def test_attention_block_with_layernorms_inside_the_1x1_convs(b, hw, dim, kind):
     K.start_trace()
     fused = _attn_block_nhwc(blk, x, "f32")
     labels = [e["label"] for e in K.stop_trace()]
-    assert sum(lb.startswith("conv1x1_ln") for lb in labels) == 2, labels      # (full attention: to_out + x in the conv's epilogue)
+    # (full attention: to_out + x in the conv's epilogue; linear attention at 8x8 / 16x16 with 64 / 128 channels: to_qkv inside the core)
+    nq = sum("+qkv" in lb for lb in labels)
+    assert nq == (1 if (hw in (8, 16) if kind == "linear" else hw == 8) else 0), labels
+    assert sum(lb.startswith("conv1x1_ln") for lb in labels) + nq == 2, labels
     assert not any(lb.startswith("chan_layernorm") or lb.startswith("nfdp_add") for lb in labels), labels
+    if nq:                                                                       # the same products, the same core: rounding level (q / k / v rows 1-2 ulp)
+        K.set_attention_qkv_fused(False)
+        try:
+            assert_close(fused, _attn_block_nhwc(blk, x, "f32"), 1e-5, "to_qkv inside the attention core vs two launches")
+        finally:
+            K.set_attention_qkv_fused(True)
     K.set_conv_ln_fused(False)
     try:
         plain = _attn_block_nhwc(blk, x, "f32")
