@@ -472,6 +472,13 @@ int nfdp_conv2d_squeeze_nhwc_f32(const float* x, int x_ld, const void* w_packed,
                                  const float* bias, int compute, nfdp_stream_t stream);
 int nfdp_conv2d_up2_nhwc_f32(const float* x, int x_ld, const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cin, int Cout,
                              const float* bias, nfdp_stream_t stream);
+/* ... and beside the one-launch Block (nfdp_conv2d_gn_silu_(cat_)nhwc_f32 without its residual; x2 = NULL, Cin2 = 0: one source): y = the
+ * Block of block1, y_res = conv1x1(x) + bias_res. */
+int nfdp_conv2d_gn_silu_res_supported(int B, int H, int W, int Cin, int Cout, int groups);
+int nfdp_conv2d_gn_silu_res_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed, float* y,
+                                     int y_ld, int B, int H, int W, int Cout, const float* bias, int groups, const float* gamma,
+                                     const float* beta, const float* scale_shift, int ss_ld, float eps, const void* w_res_packed,
+                                     const float* bias_res, float* y_res, int y_res_ld, nfdp_stream_t stream);
 int nfdp_conv2d_gnin_supported(int B, int H, int W, int Cin, int Cout, int in_groups, int out_groups);
 int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double* in_sums, int in_tile, int in_groups, const float* in_gamma,
                               const float* in_beta, const float* in_scale_shift, int in_ss_ld, float in_eps, const void* w_packed, float* y,

@@ -2400,9 +2400,16 @@ static void apply_extra(ConvParams& P, const ConvExtra* ex) {
     P.gi_ss_ld = ex->gi_ss_ld; P.gi_groups = ex->gi_groups; P.gi_parts = ex->gi_parts; P.gi_eps = ex->gi_eps;
 }
 static inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+// Beyond 1024 tiles of 64 x 64 the gathering split-K kernel loses to the implicit-GEMM kernel - but the LDS-staged 3x3 kernel does not (the
+// 64 -> 64 convs of a 32 x 6 x 64 x 64 latent part: 114.5 us on conv_kernel, 9.7 GFLOP at 20 % of the bf16 peak; the same FLOPs at 32 x 32
+// take 42.7 us staged): large problems stay in the split-K family when that kernel takes them (W, Cin: its 64-pixel tile with halo in LDS).
+static inline bool big_ldsx_shape(int W, int Cin, int Cout, int K) {
+    return K == 3 && g_conv_ldsx && split_image_shape(Cout, Cin, 3, 3) && ldsx_np(W, 4) <= 1024 && ldsx_bytes(W, Cin, 4) + kLdsxStatic <= kLdsxMax;
+}
 // pixels per workgroup of the plain split-K conv for this problem (conv2d_impl's rule), 0 when it takes another kernel
-static int splitk_tile_pixels(long npix, int Cin, int Cout, int K) {
-    if (Cin % 8 != 0 || Cout < 64 || Cout % 4 != 0 || kpad_for(Cin, K, K) < 8 * 32 || cdiv(npix, 64) * cdiv(Cout, 64) > 1024) return 0;
+static int splitk_tile_pixels(long npix, int Cin, int Cout, int K, int W) {
+    if (Cin % 8 != 0 || Cout < 64 || Cout % 4 != 0 || kpad_for(Cin, K, K) < 8 * 32) return 0;
+    if (cdiv(npix, 64) * cdiv(Cout, 64) > 1024 && !big_ldsx_shape(W, Cin, Cout, K)) return 0;
     const long t64 = cdiv(npix, 64) * cdiv(Cout, 64);
     return 16 * (t64 >= 256 ? 4 : (2 * t64 >= 256 ? 2 : 1));
 }
@@ -2545,7 +2552,7 @@ extern "C" int nfdp_conv2d_stats_tile(int B, int H, int W, int Cin, int Cout, in
     if (Cout % 64 != 0 || Cout % groups != 0) return 0;
     const int cpg = Cout / groups, HW = H * W;
     if (!pow2(cpg) || cpg < 4 || cpg > 64) return 0;
-    const int mt = splitk_tile_pixels((long)B * HW, Cin, Cout, K);
+    const int mt = splitk_tile_pixels((long)B * HW, Cin, Cout, K, W);
     return (mt > 0 && HW % mt == 0) ? mt : 0;          // whole tiles, each inside one image
 }
 
@@ -2573,7 +2580,7 @@ extern "C" int nfdp_conv2d_stats_nhwc_f32(const float* x1, int x1_ld, int Cin1, 
 // y_res = conv1x1(x).  Both weights packed fp32 with their split images; the LDS-staged kernel only.
 extern "C" int nfdp_conv2d_res_supported(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || !g_conv_ldsx) return 0;
-    const int pt = splitk_tile_pixels((long)B * H * W, Cin, Cout, 3) / 16;
+    const int pt = splitk_tile_pixels((long)B * H * W, Cin, Cout, 3, W) / 16;
     if (pt == 0 || !split_image_shape(Cout, Cin, 3, 3) || !split_image_shape(Cout, Cin, 1, 1) || ldsx_np(W, pt) > 1024) return 0;
     return ldsx_bytes(W, Cin, pt) + kLdsxStatic <= kLdsxMax;
 }
@@ -2626,7 +2633,7 @@ extern "C" int nfdp_conv2d_squeeze_nhwc_f32(const float* x, int x_ld, const void
     P.K = 4 * C; P.Kpad = kpad_for(C, 2, 2); P.relu = 0; P.mul_exp = 0.f;
     P.sq = 1;
     P.Nt = (int)cdiv(Cout, 64);
-    const int pt = splitk_tile_pixels(npix, C, Cout, 2) / 16;
+    const int pt = splitk_tile_pixels(npix, C, Cout, 2, W) / 16;
     P.Mt = (int)cdiv(npix, 16 * pt);
     const dim3 grid(P.Mt * P.Nt);
     hipStream_t s = as_stream(stream);
@@ -2653,7 +2660,7 @@ extern "C" int nfdp_conv2d_squeeze_nhwc_f32(const float* x, int x_ld, const void
 // through the index map of its x2 nearest-neighbour upsampling while the input tile is staged; H, W: the OUTPUT sides (powers of two).
 extern "C" int nfdp_conv2d_up2_supported(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H < 2 || W < 2 || Cin <= 0 || Cout <= 0 || !g_conv_ldsx || !pow2(H) || !pow2(W)) return 0;
-    const int pt = splitk_tile_pixels((long)B * H * W, Cin, Cout, 3) / 16;
+    const int pt = splitk_tile_pixels((long)B * H * W, Cin, Cout, 3, W) / 16;
     if (pt == 0 || !split_image_shape(Cout, Cin, 3, 3) || ldsx_np(W, pt) > 1024) return 0;
     return ldsx_bytes(W, Cin, pt) + kLdsxStatic <= kLdsxMax;
 }
@@ -2671,6 +2678,36 @@ extern "C" int nfdp_conv2d_up2_nhwc_f32(const float* x, int x_ld, const void* w_
                        nullptr, 0, 0, &ex);
 }
 
+// ... and the same beside the one-launch Block (tiles that hold whole images: the 4x4 / 2x2 stages): y = SiLU(GN(conv3x3(x) + bias) *
+// (scale + 1) + shift) as nfdp_conv2d_gn_silu_(cat_)nhwc_f32, y_res = conv1x1(x) + bias_res.
+extern "C" int nfdp_conv2d_gn_silu_res_supported(int B, int H, int W, int Cin, int Cout, int groups) {
+    if (!nfdp_conv2d_gn_silu_supported(B, H, W, Cin, Cout, 3, groups) || !g_conv_ldsx) return 0;
+    const int pt = gn_pixel_tiles((long)B * H * W, Cout, H * W);
+    if (pt == 0 || !split_image_shape(Cout, Cin, 3, 3) || !split_image_shape(Cout, Cin, 1, 1) || ldsx_np(W, pt) > 1024) return 0;
+    return ldsx_bytes(W, Cin, pt) + kLdsxStatic <= kLdsxMax;
+}
+
+extern "C" int nfdp_conv2d_gn_silu_res_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2,
+                                                const void* w_packed, float* y, int y_ld, int B, int H, int W, int Cout, const float* bias,
+                                                int groups, const float* gamma, const float* beta, const float* scale_shift, int ss_ld,
+                                                float eps, const void* w_res_packed, const float* bias_res, float* y_res, int y_res_ld,
+                                                nfdp_stream_t stream) {
+    NFDP_REQUIRE(x1 && w_res_packed && y_res, NFDP_EINVAL, "conv2d_gn_silu_res: null pointer");
+    NFDP_REQUIRE((x2 == nullptr) == (Cin2 == 0) && Cin1 > 0 && Cin2 >= 0, NFDP_EINVAL, "conv2d_gn_silu_res: second source and Cin2 go together");
+    NFDP_REQUIRE(nfdp_conv2d_gn_silu_res_supported(B, H, W, Cin1 + Cin2, Cout, groups), NFDP_EUNSUPPORTED,
+                 "conv2d_gn_silu_res: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d groups=%d", B, H, W, Cin1 + Cin2, Cout, groups);
+    NFDP_REQUIRE(y_res_ld >= Cout && y_res_ld % 4 == 0 && (((uintptr_t)bias_res | (uintptr_t)y_res) % 16) == 0, NFDP_ESHAPE,
+                 "conv2d_gn_silu_res: the second output's rows and bias must be 16-byte aligned");
+    if (x2) {
+        NFDP_REQUIRE(Cin1 % 8 == 0 && Cin2 % 8 == 0 && x2_ld >= Cin2 && x2_ld % 4 == 0 && ((uintptr_t)x2 % 16) == 0, NFDP_ESHAPE,
+                     "conv2d_gn_silu_res: two sources: %d + %d channels (multiples of 8), 16-byte aligned rows", Cin1, Cin2);
+    }
+    ConvExtra ex;
+    ex.w2 = w_res_packed; ex.add2 = bias_res; ex.y2 = y_res; ex.y2_ld = y_res_ld;
+    return conv2d_gn_silu_impl(x1, x1_ld, w_packed, y, y_ld, B, H, W, Cin1 + Cin2, Cout, 3, bias, groups, gamma, beta, scale_shift, ss_ld, eps,
+                               nullptr, 0, NFDP_F32X6, stream, x2, x2_ld, x2 ? Cin1 : 0, &ex);
+}
+
 extern "C" int nfdp_conv2d_gnin_supported(int B, int H, int W, int Cin, int Cout, int in_groups, int out_groups) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || in_groups <= 0 || in_groups % 2 != 0 || Cin % in_groups != 0) return 0;
     const int cpg = Cin / in_groups, HW = H * W;
@@ -2681,7 +2718,7 @@ extern "C" int nfdp_conv2d_gnin_supported(int B, int H, int W, int Cin, int Cout
         if (!nfdp_conv2d_gn_silu_supported(B, H, W, Cin, Cout, 3, out_groups)) return 0;
         pt = gn_pixel_tiles(npix, Cout, HW);
     } else {
-        pt = splitk_tile_pixels(npix, Cin, Cout, 3) / 16;
+        pt = splitk_tile_pixels(npix, Cin, Cout, 3, W) / 16;
     }
     if (pt == 0 || !split_image_shape(Cout, Cin, 3, 3) || ldsx_np(W, pt) > 1024) return 0;
     return ldsx_bytes(W, Cin, pt, HW, in_groups) + kLdsxStatic <= kLdsxMax;
@@ -2866,7 +2903,8 @@ static int conv2d_impl(const void* x, int x_dtype, int x_ld, const void* w_packe
     }
     // small fp32 problems with a long K: every wave takes a quarter of the K tiles of a 64 x 64 output tile
     if (compute == NFDP_F32 && Cin % 8 == 0 && x_ld % 4 == 0 && ((uintptr_t)x % 16) == 0 && Cout >= 64 && Cout % 4 == 0 &&
-        y_ld % 4 == 0 && ((uintptr_t)y % 16) == 0 && P.Kpad >= 8 * 32 && cdiv(npix, 64) * cdiv(Cout, 64) <= 1024 &&
+        y_ld % 4 == 0 && ((uintptr_t)y % 16) == 0 && P.Kpad >= 8 * 32 &&
+        (cdiv(npix, 64) * cdiv(Cout, 64) <= 1024 || (emu && (x2 == nullptr || cin1 % 4 == 0) && big_ldsx_shape(W, Cin, Cout, KH))) &&
         (add == nullptr || (uintptr_t)add % 16 == 0) && (mul == nullptr || (uintptr_t)mul % 16 == 0)) {
         P.Nt = (int)cdiv(Cout, 64);
         // pixel tiles per workgroup: 64-pixel tiles unless they leave CUs without a workgroup (then 32 or 16 pixels)

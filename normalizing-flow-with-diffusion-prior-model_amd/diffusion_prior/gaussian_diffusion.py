@@ -244,6 +244,14 @@ class ResnetBlock(nn.Module):
             # block2's conv: block1's conv leaves the group sums, block2's conv normalises while it stages its input tile
             e2 = 0 if x2 is None else x2.shape[3]
             p1 = (b1.proj.bias, b1.norm.weight, b1.norm.bias)
+            rc0 = self.res_conv
+            if isinstance(rc0, _Conv) and b1.proj.k == 3 and \
+                    K.conv2d_gn_silu_res_supported(xh, b1.proj.cout, b1.norm.num_groups, *p1, rc0.bias, ss, extra_cin=e2):
+                # tiles that hold whole images (4x4 / 2x2 stages): block1 as ONE launch, with the res_conv from a second accumulator set
+                cenum = K.compute_enum(compute)
+                h, res = K.conv2d_gn_silu_res(xh, b1.proj.packed(cenum), b1.proj.cout, b1.proj.bias, b1.norm.num_groups, b1.norm.weight,
+                                              b1.norm.bias, ss, rc0.packed(cenum), rc0.bias, x2=x2)
+                return b2.forward_nhwc(h, None, compute, residual=res)
             if not K.conv2d_gn_silu_supported(xh, b1.proj.cout, b1.proj.k, b1.norm.num_groups, *p1, extra_cin=e2):
                 fused2 = K.conv2d_gn_silu_shape_supported(xh.shape[0], xh.shape[1], xh.shape[2], b2.proj.cin, b2.proj.cout, 3, b2.norm.num_groups)
                 if K.conv2d_gn_carried_supported(xh, b1.proj.cout, b1.proj.k, b1.norm.num_groups, b2.norm.num_groups, fused2, *p1,

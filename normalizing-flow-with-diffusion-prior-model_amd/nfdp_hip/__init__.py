@@ -1261,6 +1261,33 @@ def conv2d_squeeze(xh: torch.Tensor, packed2x2: torch.Tensor, cout: int, bias=No
     return y
 
 
+def conv2d_gn_silu_res_supported(xh: torch.Tensor, cout: int, groups: int, *vectors, extra_cin: int = 0) -> bool:
+    """conv2d_gn_silu_res is available (the one-launch Block on the LDS-staged kernel + a split image for the 1x1 weight)?"""
+    if not (_CONV_RES_FUSED and _F32_PRODUCTS == "bf16x6" and conv2d_gn_silu_supported(xh, cout, 3, groups, *vectors, extra_cin=extra_cin)):
+        return False
+    b, h, w, cin = xh.shape
+    return bool(lib().nfdp_conv2d_gn_silu_res_supported(b, h, w, cin + extra_cin, cout, groups))
+
+
+def conv2d_gn_silu_res(xh: torch.Tensor, packed: torch.Tensor, cout: int, bias, groups: int, gamma, beta, scale_shift, packed_res: torch.Tensor,
+                       bias_res, eps: float = 1e-5, x2: Optional[torch.Tensor] = None):
+    """Block (3x3 WS-conv -> GroupNorm -> scale/shift -> SiLU) and the 1x1 res_conv of the same input in one launch
+    (nfdp_conv2d_gn_silu_res_nhwc_f32) -> (h, res)."""
+    b, h, w, c1 = xh.shape
+    c2 = 0 if x2 is None else x2.shape[3]
+    y = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
+    yr = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
+    ss_ld = 0
+    if scale_shift is not None:
+        assert scale_shift.shape == (b, 2 * cout) and scale_shift.stride(1) == 1
+        ss_ld = scale_shift.stride(0) if b > 1 else 2 * cout
+    _call("nfdp_conv2d_gn_silu_res_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_gn_silu_res"), c1, _ptr(x2), 0 if x2 is None else _ld(x2, "conv2d_gn_silu_res"),
+          c2, _ptr(packed), _ptr(y), cout, b, h, w, cout, _ptr(bias), groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift), ss_ld, float(eps),
+          _ptr(packed_res), _ptr(bias_res), _ptr(yr), cout, _stream(),
+          label=f"conv_splitk_f32+gn+res{' cat' if c2 else ''} {c1}{'+' + str(c2) if c2 else ''}->{cout} hw{h}", flops=2.0 * b * h * w * (c1 + c2) * 10 * cout)
+    return y, yr
+
+
 def chan_layernorm(xh: torch.Tensor, gain: torch.Tensor, residual: Optional[torch.Tensor] = None, eps: float = 1e-5):
     _need(xh, torch.float32, "chan_layernorm"); _dense(xh, "chan_layernorm")
     c = xh.shape[-1]

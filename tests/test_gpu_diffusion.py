@@ -587,14 +587,15 @@ def test_attention_block_with_layernorms_inside_the_1x1_convs(b, hw, dim, kind):
 
 
 @pytest.mark.parametrize("b,hw,cin,c2,cout,groups", [(64, 16, 64, 0, 64, 8), (64, 16, 64, 64, 64, 8), (64, 8, 128, 0, 128, 8), (64, 8, 128, 64, 128, 8),
-                                                     (3, 16, 64, 0, 128, 16), (5, 8, 64, 0, 64, 4), (2, 32, 32, 0, 64, 8)])
+                                                     (3, 16, 64, 0, 128, 16), (5, 8, 64, 0, 64, 4), (2, 32, 32, 0, 64, 8), (20, 64, 64, 0, 64, 16), (18, 64, 64, 64, 64, 16)])
 @torch.no_grad()
 def test_resnet_block_with_the_first_groupnorm_inside_the_second_conv(b, hw, cin, c2, cout, groups):
     """ResnetBlock (reference gaussian_diffusion.py:279-302) where a conv workgroup's tile is a part of an image: block1's conv leaves the
     fp64 group sums of its tiles (nfdp_conv2d_stats_nhwc_f32), block2's conv normalises its input while staging it
     (nfdp_conv2d_gnin_nhwc_f32) - against the launch-per-op form (same conv, same GroupNorm expressions; the statistics are sums of
     per-tile fp64 sums instead of a two-pass fp64 mean / variance: 2e-6) and against torch fp64.  Two-source input (the skip
-    connections), 8 / 16 channels per group, 2-64 tiles per image."""
+    connections), 4 / 8 / 16 channels per group, 2-64 tiles per image; the 64x64 cases are the largest CelebA latent part's stage (more than
+    1024 output tiles: the LDS-staged kernel keeps them in the split-K family)."""
     from diffusion_prior.gaussian_diffusion import ResnetBlock
     torch.manual_seed(b * 131 + hw + cin + c2 + cout)
     blk = ResnetBlock(cin + c2, cout, time_emb_dim=256, groups=groups).to(DEV)
@@ -726,3 +727,31 @@ def test_direct_7x7_conv_over_few_input_channels(b, h, w, cin, cout):
     assert_close(got, want, 5e-6, "direct 7x7 vs implicit GEMM")
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), wt.double().cpu(), bias.double().cpu(), padding=3)
     assert_close(got.permute(0, 3, 1, 2), ref, 1e-5, "direct 7x7 vs torch fp64")
+
+
+@pytest.mark.parametrize("b,hw,cin,c2,cout,groups", [(64, 4, 64, 64, 64, 8), (64, 2, 128, 64, 128, 8), (64, 4, 64, 0, 128, 8), (7, 4, 128, 128, 128, 16)])
+@torch.no_grad()
+def test_resnet_block_of_whole_image_tiles_with_the_res_conv_in_block1s_launch(b, hw, cin, c2, cout, groups):
+    """ResnetBlock where a conv tile holds whole images (the 4x4 / 2x2 stages): block1 as one launch (conv + GroupNorm + SiLU) that also
+    forms the 1x1 res_conv of the same input (nfdp_conv2d_gn_silu_res_nhwc_f32) against the form with a res_conv launch (the 1x1 products in
+    another K association: 2e-6) and the launch count."""
+    from diffusion_prior.gaussian_diffusion import ResnetBlock
+    torch.manual_seed(b * 7 + hw + cin + c2 + cout)
+    blk = ResnetBlock(cin + c2, cout, time_emb_dim=256, groups=groups).to(DEV)
+    for p_ in blk.parameters():
+        p_.data.copy_(torch.randn_like(p_) * (0.15 if p_.dim() > 1 else 0.3) + (1.0 if p_.dim() == 1 and p_.shape[0] == cout else 0.0))
+    x = torch.randn(b, hw, hw, cin, device=DEV)
+    x2 = torch.randn(b, hw, hw, c2, device=DEV) if c2 else None
+    temb = torch.randn(b, 256, device=DEV)
+    inp = (x, x2) if c2 else x
+    blk.forward_nhwc(inp, temb, "f32")                                       # (packs the weights)
+    K.start_trace()
+    fused = blk.forward_nhwc(inp, temb, "f32")
+    labels = [e["label"] for e in K.stop_trace()]
+    assert sum("+gn+res" in lb for lb in labels) == 1 and len([lb for lb in labels if not lb.startswith("nfdp_linear")]) == 2, labels
+    K.set_conv_res_fused(False)
+    try:
+        plain = blk.forward_nhwc(inp, temb, "f32")
+    finally:
+        K.set_conv_res_fused(True)
+    assert_close(fused, plain, 2e-6, "res_conv in block1's launch vs its own launch")
