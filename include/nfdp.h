@@ -484,7 +484,14 @@ int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double* in_sums, i
                               const float* in_beta, const float* in_scale_shift, int in_ss_ld, float in_eps, const void* w_packed, float* y,
                               int y_ld, int B, int H, int W, int Cin, int Cout, const float* bias, int out_groups, const float* out_gamma,
                               const float* out_beta, const float* out_scale_shift, int out_ss_ld, float out_eps, const float* residual,
-                              int res_ld, nfdp_stream_t stream);
+                              int res_ld, int sums_groups, double* sums_out, nfdp_stream_t stream);
+/* Block.forward :267-276 after a conv that left its group sums (nfdp_conv2d_stats_nhwc_f32, or nfdp_conv2d_gnin_nhwc_f32 with out_groups = 0
+ * and sums_out: the sums of ITS output in sums_groups groups, tile = nfdp_conv2d_stats_tile): GroupNorm -> x*(scale+1)+shift -> SiLU ->
+ * + residual as nfdp_groupnorm_silu_res_f32, the statistics from the sums - no reduction, workgroups of whole pixel rows. */
+int nfdp_groupnorm_silu_sums_supported(int B, int HW, int C, int groups, int tile);
+int nfdp_groupnorm_silu_sums_f32(const float* x, float* y, const double* sums, int tile, int B, int HW, int C, int groups, const float* gamma,
+                                 const float* beta, const float* scale_shift, int ss_ld, float eps, const float* residual,
+                                 nfdp_stream_t stream);
 
 /* ---------------------------------------------------------------- diffusion prior: U-Net blocks
  * (diffusion_prior/gaussian_diffusion.py; the convolutions themselves use nfdp_conv2d_nhwc) */

@@ -2728,7 +2728,8 @@ extern "C" int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double*
                                          const float* in_beta, const float* in_scale_shift, int in_ss_ld, float in_eps, const void* w_packed,
                                          float* y, int y_ld, int B, int H, int W, int Cin, int Cout, const float* bias, int out_groups,
                                          const float* out_gamma, const float* out_beta, const float* out_scale_shift, int out_ss_ld,
-                                         float out_eps, const float* residual, int res_ld, nfdp_stream_t stream) {
+                                         float out_eps, const float* residual, int res_ld, int sums_groups, double* sums_out,
+                                         nfdp_stream_t stream) {
     NFDP_REQUIRE(x && in_sums && in_gamma && in_beta && w_packed && y, NFDP_EINVAL, "conv2d_gnin: null pointer");
     NFDP_REQUIRE(nfdp_conv2d_gnin_supported(B, H, W, Cin, Cout, in_groups, out_groups), NFDP_EUNSUPPORTED,
                  "conv2d_gnin: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d groups %d -> %d", B, H, W, Cin, Cout, in_groups, out_groups);
@@ -2737,7 +2738,10 @@ extern "C" int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double*
     NFDP_REQUIRE(x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)in_sums | (uintptr_t)in_gamma | (uintptr_t)in_beta | (uintptr_t)in_scale_shift) % 16) == 0 &&
                  in_ss_ld % 4 == 0, NFDP_ESHAPE, "conv2d_gnin: rows and vectors must be 16-byte aligned");
     NFDP_REQUIRE(out_groups > 0 || residual == nullptr, NFDP_EINVAL, "conv2d_gnin: a residual goes with the output Block (out_groups > 0)");
+    NFDP_REQUIRE(!sums_out || (out_groups == 0 && nfdp_conv2d_stats_tile(B, H, W, Cin, Cout, 3, sums_groups) != 0 && (uintptr_t)sums_out % 16 == 0),
+                 NFDP_EUNSUPPORTED, "conv2d_gnin: no group sums of the output for this geometry (nfdp_conv2d_stats_tile; out_groups must be 0)");
     ConvExtra ex;
+    ex.gs_out = sums_out; ex.gs_groups = sums_groups;
     ex.gi_stats = in_sums; ex.gi_gamma = in_gamma; ex.gi_beta = in_beta; ex.gi_ss = in_scale_shift; ex.gi_ss_ld = in_ss_ld;
     ex.gi_groups = in_groups; ex.gi_parts = (H * W) / in_tile; ex.gi_eps = in_eps;
     if (out_groups > 0)

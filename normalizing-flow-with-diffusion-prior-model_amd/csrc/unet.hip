@@ -991,6 +991,108 @@ extern "C" int nfdp_groupnorm_silu_res_f32(const float* x, float* y, int B, int 
                                            const float* beta, const float* scale_shift, int ss_ld, float eps,
                                            const float* residual, nfdp_stream_t stream);
 
+// ----------------------------------------------------------------------------- GroupNorm + SiLU with statistics that came with the tensor
+// Block 2 of a ResnetBlock where a conv tile is a part of an image: the conv's epilogue left the fp64 (sum, sum of squares) of every
+// (pixel tile, group) (nfdp_conv2d_stats_nhwc_f32 / nfdp_conv2d_gnin_nhwc_f32), so the norm needs no reduction of its own and no
+// (sample, group) workgroups: a workgroup takes 4096 / C consecutive pixels with ALL their channels (whole 4 C-byte rows: the grouped
+// kernel reads 16 bytes of every row per workgroup when a group is 4 channels wide), adds the image's tile sums up (LP lanes per group,
+// a fixed xor tree, as conv3x3_ldsx_kernel<.., GNIN>), and streams.  Same expressions in the same order as groupnorm_silu_kernel.
+__global__ void __launch_bounds__(kBlock) groupnorm_silu_sums_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                    const double* __restrict__ sums, int parts, int HW, int C, int groups,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    const float* __restrict__ ss, int ss_ld, float eps,
+                                                                    const float* __restrict__ res) {
+    __shared__ float2 mr[64];                           // (mean, rstd) per group
+    const int q4 = C >> 2, pxw = 4096 / C;              // float4 per pixel row, pixels per workgroup (1024 units, 4 per thread)
+    const long p0 = (long)blockIdx.x * pxw;
+    const int b = (int)(p0 / HW);
+    const int tid = threadIdx.x;
+    float4 v[4], rv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                       // the rows first: they fly while the statistics are formed
+        const int u = tid + kBlock * k;
+        v[k] = *reinterpret_cast<const float4*>(x + (p0 + u / q4) * C + (u % q4) * 4);
+    }
+    if (res) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int u = tid + kBlock * k;
+            rv[k] = *reinterpret_cast<const float4*>(res + (p0 + u / q4) * C + (u % q4) * 4);
+        }
+    }
+    const int cpg = C / groups;
+    const int LP = parts < 16 ? parts : 16, lsh = __builtin_ctz((unsigned)LP);
+    for (int g0 = 0; g0 < groups; g0 += kBlock >> lsh) {                 // (uniform)
+        const int g = g0 + (tid >> lsh), j = tid & (LP - 1), gc = g < groups ? g : groups - 1;
+        const double* sp = sums + ((size_t)b * parts * groups + gc) * 2;
+        double g1 = 0.0, g2 = 0.0;
+        for (int i = j; i < parts; i += LP) {
+            const double2 t = *reinterpret_cast<const double2*>(sp + (size_t)i * groups * 2);
+            g1 += t.x;
+            g2 += t.y;
+        }
+        for (int o = 1; o < LP; o <<= 1) {
+            g1 += __shfl_xor(g1, o);
+            g2 += __shfl_xor(g2, o);
+        }
+        if (g < groups && j == 0) {
+            const double rn = 1.0 / ((double)HW * cpg);
+            const double mean = g1 * rn;
+            double var = g2 * rn - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            mr[g] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+        }
+    }
+    __syncthreads();
+    const float* sr = ss ? ss + (long)b * ss_ld : nullptr;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int u = tid + kBlock * k;
+        const int c0 = (u % q4) * 4;
+        const long off = (p0 + u / q4) * C + c0;
+        const float2 st = mr[c0 / cpg];
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c0), be = *reinterpret_cast<const float4*>(beta + c0);
+        float o[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        const float gq[4] = {ga.x, ga.y, ga.z, ga.w}, bq[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[r], st.x), st.y), gq[r]), bq[r]);
+            if (sr) t = __fadd_rn(__fmul_rn(t, __fadd_rn(sr[c0 + r], 1.0f)), sr[C + c0 + r]);
+            o[r] = t / (1.0f + expf(-t));
+        }
+        if (res) {
+            o[0] = __fadd_rn(o[0], rv[k].x); o[1] = __fadd_rn(o[1], rv[k].y); o[2] = __fadd_rn(o[2], rv[k].z); o[3] = __fadd_rn(o[3], rv[k].w);
+        }
+        *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int nfdp_groupnorm_silu_sums_supported(int B, int HW, int C, int groups, int tile) {
+    if (B <= 0 || HW <= 0 || C < 4 || groups <= 0 || groups > 64 || tile <= 0 || C % groups != 0 || HW % tile != 0) return 0;
+    const int cpg = C / groups, parts = HW / tile;
+    if (4096 % C != 0 || cpg % 4 != 0 || (parts & (parts - 1)) != 0) return 0;
+    const int pxw = 4096 / C;
+    return HW % pxw == 0 && (((long)HW * cpg) & ((long)HW * cpg - 1)) == 0;          // whole workgroups inside one image; 1 / n exact
+}
+
+// y = SiLU(GroupNorm(x) * (scale + 1) + shift) + residual as nfdp_groupnorm_silu_res_f32, statistics from `sums`
+// ([B * HW / tile][groups][2] fp64 (sum, sum of squares): nfdp_conv2d_stats_nhwc_f32 / nfdp_conv2d_gnin_nhwc_f32's sums_out).
+extern "C" int nfdp_groupnorm_silu_sums_f32(const float* x, float* y, const double* sums, int tile, int B, int HW, int C, int groups,
+                                            const float* gamma, const float* beta, const float* scale_shift, int ss_ld, float eps,
+                                            const float* residual, nfdp_stream_t stream) {
+    NFDP_REQUIRE(x && y && sums && gamma && beta, NFDP_EINVAL, "groupnorm_silu_sums: null pointer");
+    NFDP_REQUIRE(nfdp_groupnorm_silu_sums_supported(B, HW, C, groups, tile), NFDP_EUNSUPPORTED,
+                 "groupnorm_silu_sums: unsupported shape B=%d HW=%d C=%d groups=%d tile=%d", B, HW, C, groups, tile);
+    NFDP_REQUIRE(!scale_shift || ss_ld >= 2 * C, NFDP_ESHAPE, "groupnorm_silu_sums: ss_ld < 2C");
+    NFDP_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)sums | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)residual) % 16) == 0, NFDP_ESHAPE,
+                 "groupnorm_silu_sums: tensors and vectors must be 16-byte aligned");
+    const long nwg = (long)B * HW / (4096 / C);
+    hipLaunchKernelGGL(groupnorm_silu_sums_kernel, dim3((unsigned)nwg), dim3(kBlock), 0, as_stream(stream), x, y, sums, HW / tile, HW, C, groups,
+                       gamma, beta, scale_shift, ss_ld, eps, residual);
+    NFDP_CHECK_LAUNCH("groupnorm_silu_sums");
+    return NFDP_OK;
+}
+
 extern "C" int nfdp_groupnorm_silu_f32(const float* x, float* y, int B, int HW, int C, int groups, const float* gamma,
                                        const float* beta, const float* scale_shift, int ss_ld, float eps,
                                        nfdp_stream_t stream) {

@@ -269,9 +269,16 @@ class ResnetBlock(nn.Module):
                         return K.conv2d_gnin(raw, sums, tile, b1.norm.num_groups, b1.norm.weight, b1.norm.bias, ss, b2.proj.packed(cenum),
                                              b2.proj.cout, b2.proj.bias, out_groups=b2.norm.num_groups, out_gamma=b2.norm.weight,
                                              out_beta=b2.norm.bias, residual=res)
+                    g2 = b2.norm.num_groups
+                    if K.groupnorm_silu_sums_supported(raw.shape[0], raw.shape[1], raw.shape[2], b2.proj.cin, b2.proj.cout, g2, b2.norm.weight,
+                                                       b2.norm.bias, res):
+                        # block2's own norm: its conv leaves ITS group sums too, the norm is then a streaming pass without reductions
+                        h2, sums2, tile2 = K.conv2d_gnin(raw, sums, tile, b1.norm.num_groups, b1.norm.weight, b1.norm.bias, ss,
+                                                         b2.proj.packed(cenum), b2.proj.cout, b2.proj.bias, sums_groups=g2)
+                        return K.groupnorm_silu_sums(h2, sums2, tile2, g2, b2.norm.weight, b2.norm.bias, None, 1e-5, res)
                     h2 = K.conv2d_gnin(raw, sums, tile, b1.norm.num_groups, b1.norm.weight, b1.norm.bias, ss, b2.proj.packed(cenum),
                                        b2.proj.cout, b2.proj.bias)
-                    return K.groupnorm_silu(h2, b2.norm.num_groups, b2.norm.weight, b2.norm.bias, None, 1e-5, res)
+                    return K.groupnorm_silu(h2, g2, b2.norm.weight, b2.norm.bias, None, 1e-5, res)
         h = b1.forward_nhwc(xh, ss, compute, x2=x2)
         res = self.res_conv.forward_nhwc(xh, compute, x2=x2) if isinstance(self.res_conv, _Conv) else xh
         return b2.forward_nhwc(h, None, compute, residual=res.contiguous())   # h + res folded into block2's epilogue

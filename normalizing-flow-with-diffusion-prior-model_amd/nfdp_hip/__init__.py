@@ -1138,9 +1138,10 @@ def conv2d_stats(xh: torch.Tensor, packed: torch.Tensor, cout: int, k: int, bias
 
 def conv2d_gnin(xh: torch.Tensor, sums: torch.Tensor, tile: int, in_groups: int, in_gamma, in_beta, in_scale_shift, packed: torch.Tensor,
                 cout: int, bias, in_eps: float = 1e-5, out_groups: int = 0, out_gamma=None, out_beta=None, out_scale_shift=None,
-                out_eps: float = 1e-5, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+                out_eps: float = 1e-5, residual: Optional[torch.Tensor] = None, sums_groups: int = 0):
     """3x3 conv over SiLU(GroupNorm(xh) * (scale + 1) + shift), xh the raw output and `sums` the group sums of conv2d_stats
-    (nfdp_conv2d_gnin_nhwc_f32); out_groups > 0: followed by the conv's own Block epilogue (+ residual)."""
+    (nfdp_conv2d_gnin_nhwc_f32); out_groups > 0: followed by the conv's own Block epilogue (+ residual).  sums_groups > 0 (with
+    out_groups = 0): also the group sums of ITS output -> (y, sums, tile) for groupnorm_silu_sums."""
     _need(xh, torch.float32, "conv2d_gnin"); _need(sums, torch.float64, "conv2d_gnin")
     b, h, w, cin = xh.shape
     y = torch.empty((b, h, w, cout), device=xh.device, dtype=torch.float32)
@@ -1155,10 +1156,51 @@ def conv2d_gnin(xh: torch.Tensor, sums: torch.Tensor, tile: int, in_groups: int,
         _need(residual, torch.float32, "conv2d_gnin residual"); _dense(residual, "conv2d_gnin residual")
         assert residual.shape == y.shape
         res_ld = cout
+    osums, otile = None, 0
+    if sums_groups:
+        otile = int(lib().nfdp_conv2d_stats_tile(b, h, w, cin, cout, 3, sums_groups))
+        assert otile > 0 and out_groups == 0
+        osums = torch.empty((b * h * w // otile, sums_groups, 2), device=xh.device, dtype=torch.float64)
     _call("nfdp_conv2d_gnin_nhwc_f32", _ptr(xh), _ld(xh, "conv2d_gnin"), _ptr(sums), int(tile), in_groups, _ptr(in_gamma), _ptr(in_beta),
           _ptr(in_scale_shift), _ss_ld(in_scale_shift, cin), float(in_eps), _ptr(packed), _ptr(y), cout, b, h, w, cin, cout, _ptr(bias),
           out_groups, _ptr(out_gamma), _ptr(out_beta), _ptr(out_scale_shift), _ss_ld(out_scale_shift, cout), float(out_eps), _ptr(residual),
-          res_ld, _stream(), label=f"conv3x3_ldsx gn-in{'+gn' if out_groups else ''} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * 9 * cout)
+          res_ld, sums_groups, _ptr(osums), _stream(),
+          label=f"conv3x3_ldsx gn-in{'+gn' if out_groups else ''}{'+sums' if sums_groups else ''} {cin}->{cout} hw{h}", flops=2.0 * b * h * w * cin * 9 * cout)
+    return (y, osums, otile) if sums_groups else y
+
+
+_GN_FROM_SUMS = True
+
+
+def set_groupnorm_from_sums(on: bool) -> None:
+    """Block 2's GroupNorm from the group sums its conv left (streaming kernel, default) or with its own reductions."""
+    global _GN_FROM_SUMS
+    _GN_FROM_SUMS = bool(on)
+
+
+def groupnorm_silu_sums_supported(b: int, h: int, w: int, cin: int, c: int, groups: int, *vectors) -> bool:
+    """Block 2 (3x3 conv cin -> c on the normalise-on-load kernel, then GroupNorm) can take its norm's statistics from the conv's sums?"""
+    if not _GN_FROM_SUMS or any(v is not None and v.data_ptr() % 16 for v in vectors):
+        return False
+    tile = int(lib().nfdp_conv2d_stats_tile(b, h, w, cin, c, 3, groups))
+    return tile > 0 and bool(lib().nfdp_groupnorm_silu_sums_supported(b, h * w, c, groups, tile))
+
+
+def groupnorm_silu_sums(xh: torch.Tensor, sums: torch.Tensor, tile: int, groups: int, gamma, beta, scale_shift: Optional[torch.Tensor],
+                        eps: float = 1e-5, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """groupnorm_silu with the statistics from the producing conv's per-tile group sums (nfdp_groupnorm_silu_sums_f32)."""
+    _need(xh, torch.float32, "groupnorm_silu_sums"); _dense(xh, "groupnorm_silu_sums"); _need(sums, torch.float64, "groupnorm_silu_sums")
+    b, h, w, c = xh.shape
+    if residual is not None:
+        _need(residual, torch.float32, "groupnorm_silu_sums residual"); _dense(residual, "groupnorm_silu_sums residual")
+        assert residual.shape == xh.shape
+    y = torch.empty_like(xh)
+    ss_ld = 0
+    if scale_shift is not None:
+        assert scale_shift.shape == (b, 2 * c) and scale_shift.stride(1) == 1
+        ss_ld = scale_shift.stride(0) if b > 1 else 2 * c
+    _call("nfdp_groupnorm_silu_sums_f32", _ptr(xh), _ptr(y), _ptr(sums), int(tile), b, h * w, c, groups, _ptr(gamma), _ptr(beta), _ptr(scale_shift),
+          ss_ld, float(eps), _ptr(residual), _stream(), label="groupnorm_silu_sums_kernel", nbytes=8.0 * xh.numel())
     return y
 
 

@@ -80,7 +80,10 @@ def test_argument_validation_without_gpu():
     assert l.nfdp_conv2d_stats_nhwc_f32(p, 64, 64, None, 0, 0, p, p, 64, 64, 16, 16, 64, 3, None, 8, None, 0, None) == -1
     assert l.nfdp_conv2d_stats_nhwc_f32(p, 64, 64, None, 0, 0, p, p, 64, 64, 12, 12, 96, 3, None, 8, p, 0, None) == -3
     assert l.nfdp_conv2d_gnin_nhwc_f32(p, 64, p, 48, 8, p, p, None, 0, 1e-5, p, p, 64, 64, 16, 16, 64, 64, None, 0, None, None, None, 0,
-                                       1e-5, None, 0, None) == -2           # in_tile does not divide the image
+                                       1e-5, None, 0, 0, None, None) == -2  # in_tile does not divide the image
+    assert l.nfdp_groupnorm_silu_sums_supported(64, 256, 64, 8, 64) == 1 and l.nfdp_groupnorm_silu_sums_supported(32, 4096, 64, 16, 64) == 1
+    assert l.nfdp_groupnorm_silu_sums_supported(64, 256, 192, 8, 64) == 0 and l.nfdp_groupnorm_silu_sums_supported(64, 256, 64, 8, 48) == 0
+    assert l.nfdp_groupnorm_silu_sums_f32(p, p, None, 64, 64, 256, 64, 8, p, p, None, 0, 1e-5, None, None) == -1
     # empty batches are a no-op, not an error
     assert l.nfdp_squeeze_nhwc_f32(p, 3, p, 0, 3, 4, 4, None) == 0
     assert l.nfdp_coupling_fwd_f32(p, p, 0, 4, 4, None, None, None) == 0
