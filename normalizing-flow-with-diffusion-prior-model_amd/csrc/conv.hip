@@ -68,6 +68,7 @@ struct ConvParams {
     float* y2 = nullptr;              // its output [npix][y2_ld]
     int y2_ld = 0;
     int sq = 0;                       // conv_splitk_f32_kernel: KH = KW = 2, stride 2, no padding on x [B][2H][2W][Cin] (Downsample, :176-180)
+    int tw = 0, th = 0;               // conv3x3_ldsx_kernel: tw > 0: a workgroup's pixels are a th x tw block of one image (wide images) instead of a flat range
     int up2 = 0;                      // conv3x3_ldsx_kernel<.., UP>: x is [B][H/2][W/2][Cin], read as its nearest-neighbour x2 upsampling (:169-173)
     const double* gi_stats = nullptr; // the producer's sums, gi_parts tiles per image
     const float* gi_gamma = nullptr;
@@ -410,10 +411,15 @@ constexpr int SK_LD = 64 + 4;                                  // partial-tile r
 // The end of the split-K convs (conv_splitk_f32_kernel, conv3x3_ldsx_kernel): the waves' partial tiles meet in LDS and are summed in wave
 // order (deterministic); then the plain epilogue (bias, scale, ReLU) or the Block epilogue (GN, see conv_splitk_f32_kernel).  `part` may
 // alias memory the main loop read: the caller synchronises the workgroup first.
-template <int SK_WAVES, int PT, bool GN, bool SECOND = false>    // SECOND: the res_conv tile of conv3x3_ldsx_kernel<.., RES> (y2, add2; plain)
+template <int SK_WAVES, int PT, bool GN, bool SECOND = false, bool T2D = false>    // SECOND: the res_conv tile of conv3x3_ldsx_kernel<.., RES> (y2, add2; plain); T2D: block tiles
 __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part, const f32x4 (&acc)[4][PT], long m0, int n0, int tid,
-                                                int wave, int r16, int q) {
+                                                int wave, int r16, int q, long tile) {
     static_assert(!(GN && SECOND), "the second output is a plain conv");
+    // pixel m of the tile: m0 + m, or (P.tw: a th x tw block whose first pixel is m0) row m / tw, column m % tw of the block
+    auto pix = [&](int m) -> long {
+        if constexpr (T2D) return m0 + (long)(m / P.tw) * P.W + (m % P.tw);
+        else return m0 + m;
+    };
     constexpr int SK_THREADS = SK_WAVES * 64, MT = 16 * PT;
     const int HW = P.H * P.W;
     // ---- the partial tiles meet in LDS: D[row = n = 4q + r][col = pixel = r16]
@@ -518,7 +524,7 @@ __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part
         const int idx = tid + SK_THREADS * e;
         if (NF4 % SK_THREADS != 0 && idx >= NF4) continue;
         const int m = idx >> 4, n4 = (idx & 15) * 4;
-        const long p = m0 + m;
+        const long p = pix(m);
         const int n = n0 + n4;
         if (p >= P.npix || n >= P.Cout) continue;
         float4 v = *reinterpret_cast<const float4*>(part + m * SK_LD + n4);
@@ -586,7 +592,7 @@ __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part
             double t = gsw[0][g][k];
 #pragma unroll
             for (int w = 1; w < SK_WAVES; ++w) t += gsw[w][g][k];
-            P.gs_out[((m0 / MT) * P.gs_groups + n0 / cpg + g) * 2 + k] = t;
+            P.gs_out[(tile * P.gs_groups + n0 / cpg + g) * 2 + k] = t;
         }
     }
 }
@@ -760,7 +766,7 @@ conv_splitk_f32_kernel(const ConvParams P) {
         }
     }
 
-    splitk_epilogue<SK_WAVES, PT, GN>(P, part, acc, m0, n0, tid, wave, r16, q);
+    splitk_epilogue<SK_WAVES, PT, GN>(P, part, acc, m0, n0, tid, wave, r16, q, mt);
 }
 
 // ----------------------------------------------------------------------------- small 3x3 convs, split products: the input tile in LDS
@@ -824,9 +830,10 @@ static inline size_t split_image_bytes(int rows, int Kpad) { return (size_t)cdiv
 #define LX_STAMP(i)
 #endif
 
-template <int PT, bool GN, bool GNIN = false, bool RES = false, bool UP = false>
+template <int PT, bool GN, bool GNIN = false, bool RES = false, bool UP = false, bool T2D = false>
 __global__ void __launch_bounds__(LX_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv3x3_ldsx_kernel(const ConvParams P) {
+    static_assert(!T2D || (PT == 4 && !GN), "block tiles: 64 pixels, plain epilogue");
     constexpr int MT = 16 * PT, NT_ = LX_WAVES * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nt = blockIdx.x % P.Nt, mt = blockIdx.x / P.Nt;
@@ -836,7 +843,22 @@ conv3x3_ldsx_kernel(const ConvParams P) {
     const int r16 = lane & 15, q = lane >> 4;
     const float* __restrict__ xg = reinterpret_cast<const float*>(P.x);
     const float* __restrict__ x2g = reinterpret_cast<const float*>(P.x2);
-    const int HW = P.H * P.W, HALO = P.W + 1, NP = MT + 2 * HALO;
+    // The staged pixels: the flat range [m0 - (W+1), m0 + MT + (W+1)) - or, on wide images (P.tw), the (th+2) x (tw+2) block around the
+    // workgroup's th x tw block of ONE image (at W = 64 the flat range of a 64-pixel tile is three image rows, 194 pixels; the 8 x 8
+    // block with its ring is 100).  LDS row of a pixel: flat index + HALO, or (ty+1) * PW + tx + 1; a tap shifts by dy * PW + dx either way.
+    constexpr bool t2d = T2D;
+    const int HW = P.H * P.W;
+    const int PW = t2d ? P.tw + 2 : P.W;               // pixels per staged row
+    const int HALO = t2d ? PW + 1 : P.W + 1, NP = t2d ? (P.th + 2) * PW : MT + 2 * HALO;
+    int tb = 0, ty0 = 0, tx0 = 0;                      // (t2d) image, first row / column of the block
+    if (t2d) {
+        const int tpr = P.W / P.tw, tpi = (P.H / P.th) * tpr;
+        tb = mt / tpi;
+        const int r = mt - tb * tpi;
+        ty0 = (r / tpr) * P.th;
+        tx0 = (r - (r / tpr) * tpr) * P.tw;
+    }
+    const long ep0 = t2d ? (long)tb * HW + (long)ty0 * P.W + tx0 : m0;         // the epilogue's first pixel
     const int RS = (P.Cin + 8) * 2;                    // plane row stride in bytes
     const int PS = (NP + 1) * RS;                      // plane stride (row NP of a plane: zeros)
     const int nk = P.Kpad / 32;
@@ -855,7 +877,7 @@ conv3x3_ldsx_kernel(const ConvParams P) {
     float* const gi_gb = gi_mr + gi_nbl * 2 * P.gi_groups;                     // [Cin] gamma, [Cin] beta
     float* const gi_sh = gi_gb + 2 * P.Cin;                                    // [nbl][Cin] scale + 1, [nbl][Cin] shift
     const int lhw = __builtin_ctz((unsigned)HW);                               // (GNIN: HW is a power of two)
-    const int gi_b0 = (int)((m0 > HALO ? m0 - HALO : 0) >> lhw);              // first sample of the range
+    const int gi_b0 = t2d ? tb : (int)((m0 > HALO ? m0 - HALO : 0) >> lhw);   // first sample of the range
     const int gi_lcpg = GNIN ? __builtin_ctz((unsigned)(P.Cin / P.gi_groups)) : 0;   // (channels per group: a power of two)
     // this thread's first-round pieces of the tables are requested here, in front of the x units and the weights in the load queue: LP
     // lanes per (sample, group) set take the set's tiles side by side (one L2 round trip instead of one per tile)
@@ -899,6 +921,19 @@ conv3x3_ldsx_kernel(const ConvParams P) {
     unsigned ld_1 = (unsigned)P.x_ld, ld_2 = (unsigned)P.x2_ld;
     int cin1_s = P.Cin1, npix_s = (int)P.npix;
     asm volatile("" : "+s"(ld_1), "+s"(ld_2), "+s"(cin1_s), "+s"(npix_s));
+    // global pixel of staged row `row` (pass p: row = srow + 16 p) and whether it exists; absent rows read a valid pixel and are masked
+    auto staged_pixel = [&](int pass, bool& ok) -> int {
+        const int row = srow + 16 * pass;
+        if (!t2d) {
+            const int g = grow0 + 16 * pass;
+            ok = g >= 0 && g < npix_s && row < NP;
+            return g < 0 ? 0 : (g < npix_s ? g : npix_s - 1);
+        }
+        const int hy = row / PW, hx = row - hy * PW;
+        const int yy = ty0 - 1 + hy, xx = tx0 - 1 + hx;
+        ok = row < NP && (unsigned)yy < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
+        return tb * HW + (ok ? yy * P.W + xx : 0);
+    };
     const int up_lw = UP ? __builtin_ctz((unsigned)P.W) : 0, up_lhw = UP ? __builtin_ctz((unsigned)HW) : 2;
     struct Units { float4 v[UB]; unsigned ok; };
     auto stage_load = [&](Units& u, int pass0, int cb) {              // units (pass0 .. pass0 + UB - 1, cb)
@@ -911,9 +946,9 @@ conv3x3_ldsx_kernel(const ConvParams P) {
         u.ok = 0;
 #pragma unroll
         for (int e = 0; e < UB; ++e) {
-            const int g = grow0 + 16 * (pass0 + e);
-            const bool ok = cin && g >= 0 && g < npix_s && srow + 16 * (pass0 + e) < NP;
-            unsigned gc = (unsigned)(g < 0 ? 0 : (g < npix_s ? g : npix_s - 1));
+            bool okp;
+            unsigned gc = (unsigned)staged_pixel(pass0 + e, okp);
+            const bool ok = cin && okp;
             if constexpr (UP) {
                 // Upsample(scale 2, nearest) -> conv (reference :169-173) without the upsampled tensor: output-grid pixel (b, y, x) reads
                 // source pixel (b, y / 2, x / 2) of the half-size tensor (power-of-two sides: shifts)
@@ -943,8 +978,8 @@ conv3x3_ldsx_kernel(const ConvParams P) {
             float4 x4 = u.v[e];
             if (GNIN && 16 * (pass0 + e) < NP) {                   // (uniform: a pass wholly beyond the range is masked anyway)
                 // the same expressions in the same order as groupnorm_silu_kernel (unet.hip); masked units compute on valid data
-                const int g = grow0 + 16 * (pass0 + e);
-                const int gc = g < 0 ? 0 : (g < npix_s ? g : npix_s - 1);
+                bool okp;
+                const int gc = staged_pixel(pass0 + e, okp);
                 int bl = (gc >> lhw) - gi_b0;
                 bl = bl < gi_nbl ? bl : gi_nbl - 1;                // (rows beyond the range: masked units)
                 const float2 mr = *reinterpret_cast<const float2*>(gi_mr + 2 * (bl * P.gi_groups + (cl >> gi_lcpg)));
@@ -1083,6 +1118,19 @@ conv3x3_ldsx_kernel(const ConvParams P) {
     const int lw = __builtin_ctz((unsigned)P.W);
 #pragma unroll
     for (int j = 0; j < PT; ++j) {
+        if (t2d) {                                     // (uniform) pixel j * 16 + r16 of the th x tw block: always inside the image
+            const int idx = j * 16 + r16, ty = idx / P.tw, tx = idx - ty * P.tw;
+            const int py = ty0 + ty, px = tx0 + tx;
+            unsigned mk = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+                if ((unsigned)(py + dy) < (unsigned)P.H && (unsigned)(px + dx) < (unsigned)P.W) mk |= 1u << tap;
+            }
+            vmask[j] = mk;
+            xrow[j] = (unsigned)(((ty + 1) * PW + tx + 1) * RS + 16 * q);
+            continue;
+        }
         const long p = m0 + j * 16 + r16;
         const int pc = p < P.npix ? (int)p : 0;
         int py, px;
@@ -1117,7 +1165,7 @@ conv3x3_ldsx_kernel(const ConvParams P) {
         const int ci = kb - tap * P.Cin;
         const bool live = kt < nk && tap < 9;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int soff = (dy * P.W + dx) * RS + ci * 2;
+        const int soff = (dy * PW + dx) * RS + ci * 2;
 #pragma unroll
         for (int j = 0; j < PT; ++j) {
             const bool ok = live && ((vmask[j] >> (tap & 15)) & 1u);
@@ -1240,10 +1288,10 @@ conv3x3_ldsx_kernel(const ConvParams P) {
     LX_STAMP(3);
     __syncthreads();                                                // the partial tiles alias the planes
     LX_STAMP(4);
-    splitk_epilogue<LX_WAVES, PT, GN>(P, reinterpret_cast<float*>(smem), acc, m0, n0, tid, wave, r16, q);
+    splitk_epilogue<LX_WAVES, PT, GN, false, T2D>(P, reinterpret_cast<float*>(smem), acc, ep0, n0, tid, wave, r16, q, mt);
     if constexpr (RES) {
         __syncthreads();                                            // the first tile's partial sums have been read
-        splitk_epilogue<LX_WAVES, PT, false, true>(P, reinterpret_cast<float*>(smem), reinterpret_cast<const f32x4 (&)[4][PT]>(acc2), m0, n0, tid, wave, r16, q);
+        splitk_epilogue<LX_WAVES, PT, false, true, T2D>(P, reinterpret_cast<float*>(smem), reinterpret_cast<const f32x4 (&)[4][PT]>(acc2), ep0, n0, tid, wave, r16, q, mt);
     }
     LX_STAMP(5);
 }
@@ -2334,7 +2382,7 @@ extern "C" int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const v
 }
 
 // ---- the LDS-staged form of the split-product 3x3 convs (conv3x3_ldsx_kernel): taken where its geometry holds
-static thread_local int g_conv_ldsx = 1;                          // test hook (thread-local): 0 = always the gathering kernel
+static thread_local int g_conv_ldsx = 1;                          // test hook (thread-local): 0 = always the gathering kernel, 2 = flat tiles only
 extern "C" void nfdp_debug_set_conv_ldsx(int v) { g_conv_ldsx = v; }
 constexpr size_t kLdsxMax = 160 * 1024;
 #ifdef NFDP_LX_STAMPS
@@ -2365,10 +2413,29 @@ static void launch_ldsx_t(const ConvParams& P, int pt, dim3 grid, hipStream_t s)
         nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<1, GN, GNIN, RES, UP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
         attr_set = true;
     }
-    const size_t lds = ldsx_bytes(P.W, P.Cin, pt, P.H * P.W, GNIN ? P.gi_groups : 0);
+    size_t lds = ldsx_bytes(P.W, P.Cin, pt, P.H * P.W, GNIN ? P.gi_groups : 0);
     ConvParams Q = P;
     Q.wsplit_off = (size_t)cout_pad_for(P.Cout) * P.Kpad * 4;
     if (RES) Q.w2split_off = (size_t)cout_pad_for(P.Cout) * kpad_for(P.Cin, 1, 1) * 4;
+    // wide images: 8 x 8 pixel blocks (100 staged pixels) instead of flat 64-pixel ranges (64 + 2 (W + 1))
+    if constexpr (!GN) {
+        if (pt == 4 && g_conv_ldsx != 2 && P.W >= 32 && P.W % 8 == 0 && P.H % 8 == 0) {
+            Q.tw = 8; Q.th = 8;
+            const size_t planes = (size_t)3 * (10 * 10 + 1) * (P.Cin + 8) * 2 + (GNIN ? ldsx_gi_bytes(P.W, P.H * P.W, P.Cin, P.gi_groups, pt) : 0);
+            const size_t part = (size_t)LX_WAVES * 64 * SK_LD * 4;
+            lds = planes > part ? planes : part;
+            static NfdpPerDevice attr2d;
+            if (!attr2d) {
+                nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<4, false, GNIN, RES, UP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
+                attr2d = true;
+            }
+#ifdef NFDP_LX_STAMPS
+            Q.part = reinterpret_cast<double*>(g_lx_stamps);
+#endif
+            hipLaunchKernelGGL((conv3x3_ldsx_kernel<4, false, GNIN, RES, UP, true>), grid, dim3(LX_WAVES * 64), lds, s, Q);
+            return;
+        }
+    }
 #ifdef NFDP_LX_STAMPS
     Q.part = reinterpret_cast<double*>(g_lx_stamps);
 #endif

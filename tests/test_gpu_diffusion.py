@@ -612,9 +612,11 @@ def test_resnet_block_with_the_first_groupnorm_inside_the_second_conv(b, hw, cin
                                                                                compute=cen, out_dtype=K.F32)
     assert torch.equal(raw, plain)
     assert (hw * hw) % tile == 0 and sums.shape == (b * hw * hw // tile, groups, 2)
-    rt = raw.double().reshape(b * hw * hw // tile, tile, groups, cout // groups)
-    assert_close(sums[..., 0], rt.sum(dim=(1, 3)), 1e-12, "group sums")
-    assert_close(sums[..., 1], (rt * rt).sum(dim=(1, 3)), 1e-12, "group sums of squares")
+    # (the tiles of an image are flat pixel ranges or, on wide images, 8 x 8 blocks: what is pinned is an image's total)
+    rt = raw.double().reshape(b, hw * hw, groups, cout // groups)
+    st = sums.reshape(b, hw * hw // tile, groups, 2).sum(dim=1)
+    assert_close(st[..., 0], rt.sum(dim=(1, 3)), 1e-12, "group sums")
+    assert_close(st[..., 1], (rt * rt).sum(dim=(1, 3)), 1e-12, "group sums of squares")
     K.start_trace()
     carried = blk.forward_nhwc(inp, temb, "f32")
     labels = [e["label"] for e in K.stop_trace()]
@@ -755,3 +757,29 @@ def test_resnet_block_of_whole_image_tiles_with_the_res_conv_in_block1s_launch(b
     finally:
         K.set_conv_res_fused(True)
     assert_close(fused, plain, 2e-6, "res_conv in block1's launch vs its own launch")
+
+
+@pytest.mark.parametrize("b,h,w,c1,c2,cout", [(20, 64, 64, 64, 0, 64), (5, 32, 32, 64, 64, 64), (3, 64, 32, 128, 0, 128), (18, 64, 64, 64, 64, 64)])
+@torch.no_grad()
+def test_block_tiles_of_the_staged_conv_are_bit_identical_to_flat_tiles(b, h, w, c1, c2, cout):
+    """conv3x3_ldsx_kernel on wide images: a workgroup's 64 pixels as an 8 x 8 block of one image (100 staged pixels) instead of a flat range
+    (64 + 2 (W + 1)) - the same K order per output, so the same bits as the flat tiles (debug switch 2); one- and two-source inputs,
+    non-square images, more than 1024 output tiles."""
+    torch.manual_seed(b + h + w + c1 + c2)
+    x = torch.randn(b, h, w, c1, device=DEV)
+    x2 = torch.randn(b, h, w, c2, device=DEV) if c2 else None
+    wt = torch.randn(cout, c1 + c2, 3, 3, device=DEV) * 0.05
+    bias = torch.randn(cout, device=DEV)
+    packed = K.conv_pack(wt, K.F32)
+    cen = K.compute_enum("f32")
+    run = (lambda: K.conv2d_cat(x, x2, packed, cout, 3, add=bias)) if c2 else (lambda: K.conv2d(x, packed, cout, 3, add=bias, compute=cen, out_dtype=K.F32))
+    blocks = run()
+    K.lib().nfdp_debug_set_conv_ldsx(2)
+    try:
+        flat = run()
+    finally:
+        K.lib().nfdp_debug_set_conv_ldsx(1)
+    assert torch.equal(blocks, flat)
+    xc = (torch.cat((x, x2), dim=3) if c2 else x).permute(0, 3, 1, 2).double().cpu()
+    ref = torch.nn.functional.conv2d(xc, wt.double().cpu(), bias.double().cpu(), padding=1)
+    assert_close(blocks.permute(0, 3, 1, 2), ref, 2e-5, "staged conv on block tiles vs torch fp64")
