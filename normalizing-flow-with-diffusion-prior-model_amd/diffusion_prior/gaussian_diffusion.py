@@ -265,6 +265,18 @@ class ResnetBlock(nn.Module):
                     else:
                         raw, sums, tile = K.conv2d_stats(xh, b1.proj.packed(cenum), b1.proj.cout, b1.proj.k, b1.proj.bias, b1.norm.num_groups, x2=x2)
                         res = (rc.forward_nhwc(xh, compute, x2=x2) if isinstance(rc, _Conv) else xh).contiguous()
+                    g1, g2 = b1.norm.num_groups, b2.norm.num_groups
+                    nb, nh, nw = raw.shape[:3]
+                    if (nb * nh * nw // 64) * -(-b2.proj.cout // 64) > K.GN_ON_LOAD_MAX_TILES and not fused2 and \
+                            K.groupnorm_silu_sums_supported(nb, nh, nw, xh.shape[3] + e2, b1.proj.cout, g1, b1.norm.weight, b1.norm.bias, ss) and \
+                            K.groupnorm_silu_sums_supported(nb, nh, nw, b2.proj.cin, b2.proj.cout, g2, b2.norm.weight, b2.norm.bias, res) and \
+                            b1.proj.k == 3:
+                        # more than one chip-wide wave of conv workgroups: normalising while staging repeats the norm's arithmetic per
+                        # tile halo and output-channel tile (+47 us on a 62 us conv at 32 x 64 x 64 x 64) where the streaming norm that
+                        # reads the conv's sums takes 13 us - both norms as launches of that kind, both convs leaving their sums
+                        h1 = K.groupnorm_silu_sums(raw, sums, tile, g1, b1.norm.weight, b1.norm.bias, ss, 1e-5)
+                        raw2, sums2, tile2 = K.conv2d_stats(h1, b2.proj.packed(cenum), b2.proj.cout, 3, b2.proj.bias, g2)
+                        return K.groupnorm_silu_sums(raw2, sums2, tile2, g2, b2.norm.weight, b2.norm.bias, None, 1e-5, res)
                     if fused2:
                         return K.conv2d_gnin(raw, sums, tile, b1.norm.num_groups, b1.norm.weight, b1.norm.bias, ss, b2.proj.packed(cenum),
                                              b2.proj.cout, b2.proj.bias, out_groups=b2.norm.num_groups, out_gamma=b2.norm.weight,

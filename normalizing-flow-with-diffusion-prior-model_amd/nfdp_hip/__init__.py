@@ -1170,6 +1170,7 @@ def conv2d_gnin(xh: torch.Tensor, sums: torch.Tensor, tile: int, in_groups: int,
 
 
 _GN_FROM_SUMS = True
+GN_ON_LOAD_MAX_TILES = 256         # ResnetBlock: block1's norm rides in block2's conv up to this many 64 x 64 output tiles (one wave of the chip)
 
 
 def set_groupnorm_from_sums(on: bool) -> None:

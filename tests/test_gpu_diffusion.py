@@ -620,8 +620,13 @@ def test_resnet_block_with_the_first_groupnorm_inside_the_second_conv(b, hw, cin
     K.start_trace()
     carried = blk.forward_nhwc(inp, temb, "f32")
     labels = [e["label"] for e in K.stop_trace()]
-    assert sum("+sums" in lb and "gn-in" not in lb for lb in labels) == 1 and sum("gn-in" in lb for lb in labels) == 1, labels
-    assert sum(lb.startswith("groupnorm_silu") for lb in labels) == 1, labels
+    big = (b * hw * hw // 64) * (-(-cout // 64)) > K.GN_ON_LOAD_MAX_TILES       # more than a chip-wide wave of conv workgroups:
+    if big:                                                                      # both norms as streaming launches that read the convs' sums
+        assert sum("+sums" in lb for lb in labels) == 2 and sum("gn-in" in lb for lb in labels) == 0, labels
+        assert sum(lb.startswith("groupnorm_silu_sums") for lb in labels) == 2, labels
+    else:
+        assert sum("+sums" in lb and "gn-in" not in lb for lb in labels) == 1 and sum("gn-in" in lb for lb in labels) == 1, labels
+        assert sum(lb.startswith("groupnorm_silu") for lb in labels) == 1, labels   # block2's norm (from its conv's sums where supported)
     K.set_conv_gn_carried(False)
     try:
         K.start_trace()
