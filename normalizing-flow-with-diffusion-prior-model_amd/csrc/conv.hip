@@ -1507,9 +1507,9 @@ __global__ void __launch_bounds__(256) conv1x1_ln_kernel(const ConvParams P, con
 // n = 64 NPT pixels (8x8, 16x16), C = 32 NS input channels (64, 128), dim_head 32.
 // The q / k / v rows of one (sample, head) for the calling wave's pixel tiles (tile = wave + 4 t): acc[t][rt], rt = q0 q1 k0 k1 v0 v1,
 // D[row = channel 16 (rt & 1) + 4 q + r][col = pixel r16].  LayerNorm and products as conv1x1_ln_kernel.
-template <int NS, int NPT>
+template <int NS, int NPT, int RT0 = 0, int NRT = 6>      // row tiles RT0 .. RT0 + NRT - 1 of (q0 q1 k0 k1 v0 v1)
 __device__ __forceinline__ void head_qkv_rows(const float* __restrict__ x, int x_ld, const float* __restrict__ gain, const char* wimg,
-                                              int b, int hd, int HD, float eps, int wave, int r16, int q, f32x4 (&acc)[NPT][6]) {
+                                              int b, int hd, int HD, float eps, int wave, int r16, int q, f32x4 (&acc)[NPT][NRT]) {
     constexpr int DHc = 32, n = 64 * NPT, C = 32 * NS;
     // Everything is requested up front - the tiles' input rows, the first
     // stage's 18 weight fragments - and a K stage is outer: its weights are loaded once per wave and meet all NPT tiles (tile-outer,
@@ -1525,11 +1525,11 @@ __device__ __forceinline__ void head_qkv_rows(const float* __restrict__ x, int x
             xv[t][s][1] = *reinterpret_cast<const float4*>(src + 32 * s + 4);
         }
     }
-    struct WS { bf16x8 h[6], m[6], l[6]; };
+    struct WS { bf16x8 h[NRT], m[NRT], l[NRT]; };
     auto loadw = [&](WS& f, int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int rt = 0; rt < 6; ++rt) {
-            const int row = (rt >> 1) * HD + hd * DHc + 16 * (rt & 1);              // (uniform)
+        for (int rt = 0; rt < NRT; ++rt) {
+            const int row = ((rt + RT0) >> 1) * HD + hd * DHc + 16 * ((rt + RT0) & 1);          // (uniform)
             const char* wb = wimg + ((size_t)(row >> 6) * NS + s) * LX_BLOCK + 3 * ((row & 63) >> 4) * 1024;
             f.h[rt] = *reinterpret_cast<const bf16x8*>(wb);
             f.m[rt] = *reinterpret_cast<const bf16x8*>(wb + 1024);
@@ -1579,7 +1579,7 @@ __device__ __forceinline__ void head_qkv_rows(const float* __restrict__ x, int x
 #pragma unroll
     for (int t = 0; t < NPT; ++t)
 #pragma unroll
-        for (int rt = 0; rt < 6; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         if (s + 1 < NS) loadw(wq[(s + 1) & 1], s + 1);
@@ -1588,17 +1588,17 @@ __device__ __forceinline__ void head_qkv_rows(const float* __restrict__ x, int x
         for (int t = 0; t < NPT; ++t) {
             // the six products of conv1x1_ln_kernel in its order per accumulator, the accumulators interleaved
 #pragma unroll
-            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[rt], xh[t][s], acc[t][rt], 0, 0, 0);
+            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[rt], xh[t][s], acc[t][rt], 0, 0, 0);
 #pragma unroll
-            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xl[t][s], acc[t][rt], 0, 0, 0);
+            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xl[t][s], acc[t][rt], 0, 0, 0);
 #pragma unroll
-            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m[rt], xm[t][s], acc[t][rt], 0, 0, 0);
+            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m[rt], xm[t][s], acc[t][rt], 0, 0, 0);
 #pragma unroll
-            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m[rt], xh[t][s], acc[t][rt], 0, 0, 0);
+            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m[rt], xh[t][s], acc[t][rt], 0, 0, 0);
 #pragma unroll
-            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xm[t][s], acc[t][rt], 0, 0, 0);
+            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xm[t][s], acc[t][rt], 0, 0, 0);
 #pragma unroll
-            for (int rt = 0; rt < 6; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xh[t][s], acc[t][rt], 0, 0, 0);
+            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xh[t][s], acc[t][rt], 0, 0, 0);
         }
     }
 }
@@ -1726,6 +1726,139 @@ __global__ void __launch_bounds__(256) linattn_qkv_kernel(const float* __restric
         const float* od = os + i * LP + c4;
         *reinterpret_cast<float4*>(obase + (size_t)i * HD + c4) = make_float4(od[0], od[1], od[2], od[3]);
     }
+}
+
+// Long sequences (n a multiple of 256: the 32x32 / 64x64 stages of the CelebA latent parts): linear attention runs as two launches over
+// 256-pixel chunks (unet.hip: linear_attention_partial_kernel - a chunk's column maxima, exp sums and context; linear_attention_apply_kernel -
+// the chunks merged, the chunk's outputs).  With to_qkv inside, the first forms its chunk's k / v rows and the second its q rows from x:
+// the [B][n][384] tensor (201 MB at 32 x 64 x 64: written by the projection, read by both launches) is never formed; x is read twice.
+template <int NS>
+__global__ void __launch_bounds__(256) linattn_partial_qkv_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ gain,
+                                                                 const char* __restrict__ wimg0, float* __restrict__ ws, int n, int heads,
+                                                                 float eps) {
+    constexpr int DHc = 32, CH = 256, REC = 2 * DHc + DHc * DHc;
+    __shared__ float kmax[DHc];
+    __shared__ float part[8][DHc];
+    __shared__ float ksm[CH][DHc + 1], vsm[CH][DHc + 1];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, c = blockIdx.y, HD = heads * DHc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q16 = lane >> 4;
+    {
+        f32x4 acc[4][4];
+        head_qkv_rows<NS, 4, 2, 4>(x + ((size_t)b * n + (size_t)c * CH) * x_ld, x_ld, gain, wimg0 + lane * 16, 0, hd, HD, eps, wave, r16, q16, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int pix = (wave + 4 * t) * 16 + r16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ksm[pix][16 * j + 4 * q16 + e] = acc[t][j][e];
+                    vsm[pix][16 * j + 4 * q16 + e] = acc[t][2 + j][e];
+                }
+        }
+    }
+    __syncthreads();
+    const int d = tid % DHc, grp = tid / DHc;
+    float m = -INFINITY;
+    for (int i = grp; i < CH; i += 8) m = fmaxf(m, ksm[i][d]);
+    part[grp][d] = m;
+    __syncthreads();
+    if (tid < DHc) {
+        float mm = part[0][d];
+        for (int g = 1; g < 8; ++g) mm = fmaxf(mm, part[g][d]);
+        kmax[d] = mm;
+    }
+    __syncthreads();
+    const float km = kmax[d];
+    float sm = 0.f;
+    for (int i = grp; i < CH; i += 8) sm += expf(ksm[i][d] - km);
+    __syncthreads();
+    part[grp][d] = sm;
+    __syncthreads();
+    float* rec = ws + ((size_t)blockIdx.x * gridDim.y + c) * REC;
+    if (tid < DHc) {
+        float ss = 0.f;
+        for (int g = 0; g < 8; ++g) ss += part[g][d];
+        rec[d] = km;
+        rec[DHc + d] = ss;
+    }
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < CH; ++i) {
+        const float pexp = expf(ksm[i][d] - km);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = fmaf(pexp, vsm[i][4 * grp + j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rec[2 * DHc + d * DHc + 4 * grp + j] = acc[j];
+}
+
+template <int NS>
+__global__ void __launch_bounds__(256) linattn_apply_qkv_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ gain,
+                                                               const char* __restrict__ wimg0, const float* __restrict__ ws,
+                                                               float* __restrict__ out, int n, int heads, float scale, float eps) {
+    constexpr int DHc = 32, CH = 256, REC = 2 * DHc + DHc * DHc;
+    __shared__ float gm[DHc], gs[DHc], ctx[DHc][DHc + 1];
+    __shared__ float qs[CH][DHc + 1], os[CH][DHc + 1];
+    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, c = blockIdx.y, nch = gridDim.y, HD = heads * DHc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, q16 = lane >> 4;
+    {   // the chunk's q rows first: their loads fly while the chunks' records are merged
+        f32x4 acc[4][2];
+        head_qkv_rows<NS, 4, 0, 2>(x + ((size_t)b * n + (size_t)c * CH) * x_ld, x_ld, gain, wimg0 + lane * 16, 0, hd, HD, eps, wave, r16, q16, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int pix = (wave + 4 * t) * 16 + r16;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) qs[pix][16 * j + 4 * q16 + e] = acc[t][j][e];
+        }
+    }
+    const float* recs = ws + (size_t)blockIdx.x * nch * REC;
+    const int d = tid % DHc, grp = tid / DHc;
+    if (tid < DHc) {
+        float m = -INFINITY;
+        for (int k = 0; k < nch; ++k) m = fmaxf(m, recs[k * REC + d]);
+        float ssum = 0.f;
+        for (int k = 0; k < nch; ++k) ssum += recs[k * REC + DHc + d] * expf(recs[k * REC + d] - m);
+        gm[d] = m;
+        gs[d] = ssum;
+    }
+    __syncthreads();
+    {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nch; ++k) {
+            const float r = expf(recs[k * REC + d] - gm[d]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(recs[k * REC + 2 * DHc + d * DHc + 4 * grp + j], r, acc[j]);
+        }
+        const float norm = 1.0f / (gs[d] * (float)n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ctx[d][4 * grp + j] = acc[j] * norm;
+    }
+    __syncthreads();
+    {
+        const int i = tid;
+        float qv[DHc];
+        float mq = -INFINITY;
+#pragma unroll
+        for (int dd = 0; dd < DHc; ++dd) { qv[dd] = qs[i][dd]; mq = fmaxf(mq, qv[dd]); }
+        float sq = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < DHc; ++dd) { qv[dd] = expf(qv[dd] - mq); sq += qv[dd]; }
+#pragma unroll
+        for (int dd = 0; dd < DHc; ++dd) qv[dd] = __fmul_rn(qv[dd] / sq, scale);
+        for (int e = 0; e < DHc; ++e) {
+            float acc = 0.f;
+#pragma unroll
+            for (int dd = 0; dd < DHc; ++dd) acc = fmaf(ctx[dd][e], qv[dd], acc);
+            os[i][e] = acc;
+        }
+    }
+    __syncthreads();
+    float* obase = out + ((size_t)b * n + (size_t)c * CH) * HD + hd * DHc;
+    for (int e = tid; e < CH * DHc; e += 256) obase[(size_t)(e / DHc) * HD + e % DHc] = os[e / DHc][e % DHc];
 }
 
 // The same for Attention (reference :336-358; the mid block, n = 64 keys): to_qkv inside attention_kernel's launch (unet.hip: four
@@ -2821,12 +2954,18 @@ extern "C" int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double*
 // PreNorm -> LinearAttention (to_qkv + core) in one launch (linattn_qkv_kernel): x [B][n][C] (rows x_ld), w_packed = the to_qkv weight
 // [3 * heads * 32][C][1][1] packed fp32 (with its split image), out [B][n][heads * 32].
 extern "C" int nfdp_linear_attention_qkv_supported(int n, int C, int heads, int dim_head) {
-    return (n == 64 || n == 256) && (C == 64 || C == 128) && dim_head == 32 && heads >= 1 && heads <= 8 &&
+    return (n == 64 || (n >= 256 && n % 256 == 0)) && (C == 64 || C == 128) && dim_head == 32 && heads >= 1 && heads <= 8 &&
            split_image_shape(3 * heads * 32, C, 1, 1);
 }
+// n > 256: the chunked form's workspace (a record of column maxima, exp sums and context per (sample, head, 256-pixel chunk)); else 0
+extern "C" size_t nfdp_linear_attention_qkv_ws_bytes(int B, int n, int heads) {
+    if (B <= 0 || n <= 256 || heads <= 0) return 0;
+    return (size_t)B * heads * (n / 256) * (2 * 32 + 32 * 32) * sizeof(float);
+}
 extern "C" int nfdp_linear_attention_qkv_f32(const float* x, int x_ld, const float* pre_gain, const void* w_packed, float* out, int B, int n,
-                                             int C, int heads, int dim_head, float scale, float eps, nfdp_stream_t stream) {
+                                             int C, int heads, int dim_head, float scale, float eps, void* ws, nfdp_stream_t stream) {
     NFDP_REQUIRE(x && pre_gain && w_packed && out, NFDP_EINVAL, "linear_attention_qkv: null pointer");
+    NFDP_REQUIRE(n <= 256 || (ws && (uintptr_t)ws % 16 == 0), NFDP_EINVAL, "linear_attention_qkv: n > 256 needs the workspace (nfdp_linear_attention_qkv_ws_bytes)");
     NFDP_REQUIRE(B >= 0, NFDP_ESHAPE, "linear_attention_qkv: bad shape");
     NFDP_REQUIRE(nfdp_linear_attention_qkv_supported(n, C, heads, dim_head), NFDP_EUNSUPPORTED,
                  "linear_attention_qkv: n=%d (64, 256) C=%d (64, 128) heads=%d dim_head=%d (32)", n, C, heads, dim_head);
@@ -2842,6 +2981,19 @@ extern "C" int nfdp_linear_attention_qkv_f32(const float* x, int x_ld, const flo
         nfdp_func_attr(reinterpret_cast<const void*>(&linattn_qkv_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 33 * 4);
         nfdp_func_attr(reinterpret_cast<const void*>(&linattn_qkv_kernel<4, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 33 * 4);
         attr_set = true;
+    }
+    if (n > 256) {
+        const dim3 grid2(B * heads, n / 256);
+        float* wsf = reinterpret_cast<float*>(ws);
+        if (C == 64) {
+            hipLaunchKernelGGL((linattn_partial_qkv_kernel<2>), grid2, dim3(256), 0, s, x, x_ld, pre_gain, wimg, wsf, n, heads, eps);
+            hipLaunchKernelGGL((linattn_apply_qkv_kernel<2>), grid2, dim3(256), 0, s, x, x_ld, pre_gain, wimg, wsf, out, n, heads, scale, eps);
+        } else {
+            hipLaunchKernelGGL((linattn_partial_qkv_kernel<4>), grid2, dim3(256), 0, s, x, x_ld, pre_gain, wimg, wsf, n, heads, eps);
+            hipLaunchKernelGGL((linattn_apply_qkv_kernel<4>), grid2, dim3(256), 0, s, x, x_ld, pre_gain, wimg, wsf, out, n, heads, scale, eps);
+        }
+        NFDP_CHECK_LAUNCH("linear_attention_qkv (chunked)");
+        return NFDP_OK;
     }
     const dim3 grid(B * heads), blk(256);
     if (C == 64 && n == 256) hipLaunchKernelGGL((linattn_qkv_kernel<2, 4>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);

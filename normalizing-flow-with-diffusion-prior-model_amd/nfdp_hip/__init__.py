@@ -1465,8 +1465,10 @@ def linear_attention_qkv(xh: torch.Tensor, gain: torch.Tensor, packed: torch.Ten
         _call("nfdp_attention_qkv_f32", _ptr(xh), _ld(xh, "attention_qkv"), _ptr(gain), _ptr(packed), _ptr(out), b, h * w, c, heads,
               dim_head, float(scale), float(eps), _stream(), label=f"attention+qkv {c} hw{h}", flops=2.0 * b * h * w * c * 3 * heads * dim_head)
         return out
+    nbytes = lib().nfdp_linear_attention_qkv_ws_bytes(b, h * w, heads)
+    ws = torch.empty(nbytes, device=xh.device, dtype=torch.uint8) if nbytes else None   # n > 256: chunked over the grid, two launches
     _call("nfdp_linear_attention_qkv_f32", _ptr(xh), _ld(xh, "linear_attention_qkv"), _ptr(gain), _ptr(packed), _ptr(out), b, h * w, c, heads,
-          dim_head, float(scale), float(eps), _stream(), label=f"linear_attention+qkv {c} hw{h}", flops=2.0 * b * h * w * c * 3 * heads * dim_head)
+          dim_head, float(scale), float(eps), _ptr(ws), _stream(), label=f"linear_attention+qkv {c} hw{h}", flops=2.0 * b * h * w * c * 3 * heads * dim_head)
     return out
 
 
