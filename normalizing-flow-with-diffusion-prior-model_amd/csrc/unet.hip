@@ -838,8 +838,9 @@ __global__ void __launch_bounds__(kBlock) attention_kernel(const float* __restri
             }
         }
     }
-    const int NP = 1 << np_log2, nq = kBlock >> np_log2;             // threads per query; query slots (n <= nq)
-    const int i = tid & (nq - 1), p = tid >> (8 - np_log2);
+    const int NP = 1 << np_log2, nq = kBlock >> np_log2;             // threads per query; query slots of this workgroup
+    const int si = tid & (nq - 1), p = tid >> (8 - np_log2);
+    const int i = blockIdx.y * nq + si;                              // (gridDim.y workgroups share a (sample, head): nq queries each, all keys)
     const bool active = i < n;
     const int iq = active ? i : 0;
     float q[DH];
@@ -863,9 +864,9 @@ __global__ void __launch_bounds__(kBlock) attention_kernel(const float* __restri
     };
     for (int j = p; j < n; j += NP) mx = fmaxf(mx, dot(j));
     if (NP > 1) {                                                    // (uniform) the row maximum over the parts
-        Ps[(p * nq + i) * PP] = mx;
+        Ps[(p * nq + si) * PP] = mx;
         __syncthreads();
-        for (int pp = 0; pp < NP; ++pp) mx = fmaxf(mx, Ps[(pp * nq + i) * PP]);
+        for (int pp = 0; pp < NP; ++pp) mx = fmaxf(mx, Ps[(pp * nq + si) * PP]);
         __syncthreads();
     }
     float o[DH];
@@ -890,7 +891,7 @@ __global__ void __launch_bounds__(kBlock) attention_kernel(const float* __restri
         for (int dd = 0; dd < DH; ++dd) orow[dd] = o[dd] / den;
         return;
     }
-    float* mine = Ps + (p * nq + i) * PP;
+    float* mine = Ps + (p * nq + si) * PP;
     mine[1] = den;
 #pragma unroll
     for (int dd = 0; dd < DH; ++dd) mine[2 + dd] = o[dd];
@@ -898,11 +899,11 @@ __global__ void __launch_bounds__(kBlock) attention_kernel(const float* __restri
     // thread (i, p) finishes the outputs dd = p, p + NP, ... of query i: parts added in order
     if (!active) return;
     float dsum = 0.f;
-    for (int pp = 0; pp < NP; ++pp) dsum += Ps[(pp * nq + i) * PP + 1];
+    for (int pp = 0; pp < NP; ++pp) dsum += Ps[(pp * nq + si) * PP + 1];
     float* orow = out + ((long)b * n + i) * HD + hd * DH;
     for (int dd = p; dd < DH; dd += NP) {
         float v = 0.f;
-        for (int pp = 0; pp < NP; ++pp) v += Ps[(pp * nq + i) * PP + 2 + dd];
+        for (int pp = 0; pp < NP; ++pp) v += Ps[(pp * nq + si) * PP + 2 + dd];
         orow[dd] = v / dsum;
     }
 }
@@ -1249,9 +1250,12 @@ extern "C" int nfdp_attention_f32(const float* qkv, float* out, int B, int n, in
         NFDP_CHECK_LAUNCH("attention (long)");
         return NFDP_OK;
     }
-    // threads per query: 256 / npow2(n), at most 32 (the finishing loop deals the 32 outputs of a query to its threads)
+    // threads per query: 256 / npow2(queries per workgroup), at most 32 (the finishing loop deals the 32 outputs of a query to its
+    // threads).  More than 64 queries are dealt to several workgroups of 64 (each stages all keys): with one thread per query a
+    // 256-query head walked 2 x 256 keys x 32 dependent LDS reads per thread - 159 us for the 16x16 mid block of a 6 x 64 x 64 latent part
+    const int qpw = n > 64 ? 64 : n, qc = (int)cdiv(n, qpw);
     int np_log2 = 0;
-    while ((n << (np_log2 + 1)) <= kBlock && np_log2 < 5) ++np_log2;
+    while ((qpw << (np_log2 + 1)) <= kBlock && np_log2 < 5) ++np_log2;
     const size_t lds = ((size_t)2 * n * DH + (np_log2 ? (size_t)kBlock * (DH + 2) : 0)) * sizeof(float);
     static NfdpPerDevice attr_set;
     if (!attr_set) {
@@ -1259,7 +1263,7 @@ extern "C" int nfdp_attention_f32(const float* qkv, float* out, int B, int n, in
                                   (2 * kBlock * (DH + 1) + kBlock * (DH + 2)) * (int)sizeof(float));
         attr_set = true;
     }
-    hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(kBlock), lds, as_stream(stream), qkv, out, n, heads, scale, np_log2);
+    hipLaunchKernelGGL(attention_kernel, dim3(B * heads, qc), dim3(kBlock), lds, as_stream(stream), qkv, out, n, heads, scale, np_log2);
     NFDP_CHECK_LAUNCH("attention");
     return NFDP_OK;
 }
