@@ -456,7 +456,7 @@ int nfdp_conv2d_res_supported(int B, int H, int W, int Cin, int Cout);
 int nfdp_conv2d_res_nhwc_f32(const float* x1, int x1_ld, int Cin1, const float* x2, int x2_ld, int Cin2, const void* w_packed, float* y,
                              int y_ld, int B, int H, int W, int Cout, const float* bias, int groups, double* sums, const void* w_res_packed,
                              const float* bias_res, float* y_res, int y_res_ld, nfdp_stream_t stream);
-/* Unet.init_conv :383 (Conv2d(channels, init_dim, 7, padding=3)) for 1-4 input channels: y [B*H*W][y_ld] = conv7x7(x [B][H][W][Cin], rows
+/* Unet.init_conv :383 (Conv2d(channels, init_dim, 7, padding=3)) for 1-8 input channels: y [B*H*W][y_ld] = conv7x7(x [B][H][W][Cin], rows
  * x_ld) + bias as fp32 FMA chains over (tap, channel) on the vector ALU; W % 4 == 0, Cout % 4 == 0.  w_k7 = nfdp_conv_k7_pack_f32 of the
  * [Cout][Cin][7][7] parameter: [49][Cin][Cout] fp32. */
 int nfdp_conv_k7_narrow_supported(int B, int H, int W, int Cin, int Cout);

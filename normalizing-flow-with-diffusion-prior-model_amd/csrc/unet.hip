@@ -1278,7 +1278,7 @@ extern "C" int nfdp_upsample_nearest2x_f32(const float* x, float* y, int B, int 
     return NFDP_OK;
 }
 
-// ----------------------------------------------------------------------------- Unet.init_conv: 7x7 over 1-4 input channels (:383)
+// ----------------------------------------------------------------------------- Unet.init_conv: 7x7 over 1-8 input channels (:383)
 // K = 49 * Cin <= 196 with Cin not a multiple of 4: the implicit-GEMM kernel gathers it element by element (13.6 us for the 16x16 / B = 64
 // latent part - 0.2 GFLOP).  A direct conv on the vector ALU: a workgroup takes 64 consecutive pixels x 64 output channels, a thread 4
 // consecutive pixels of one image row (W % 4 == 0) x 4 outputs - lane = (output quad, pixel group), so that a pixel's 64 outputs leave
@@ -1315,11 +1315,21 @@ __global__ void __launch_bounds__(256) conv_k7_narrow_kernel(const float* __rest
             const int n = n0 + q4 < Cout ? n0 + q4 : 0;                 // (Cout % 4 == 0; beyond Cout: a valid address, never used)
             v[e] = *reinterpret_cast<const float4*>(wk + (size_t)row * Cout + n);
         }
-        for (int i = tid; i < NP * CIN; i += 256) {                     // (NP * CIN <= 256 * 4 for W <= 32: 1-4 round trips)
-            const int g = m0 - HALO + i / CIN, c = i % CIN;
-            const int gc = g < 0 ? 0 : (g < npix ? g : npix - 1);
-            const float t = x[(size_t)gc * x_ld + c];
-            xs[i] = (g >= 0 && g < npix) ? t : 0.f;
+        for (int i0 = 0; i0 < NP * CIN; i0 += 256 * 4) {               // four loads in flight (wide images: NP * CIN runs to 10 x 256)
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e * 256 + tid, ic = i < NP * CIN ? i : NP * CIN - 1;
+                const int g = m0 - HALO + ic / CIN, c = ic % CIN;
+                const int gc = g < 0 ? 0 : (g < npix ? g : npix - 1);
+                const float tv = x[(size_t)gc * x_ld + c];
+                t[e] = (g >= 0 && g < npix) ? tv : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = i0 + e * 256 + tid;
+                if (i < NP * CIN) xs[i] = t[e];
+            }
         }
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
@@ -1376,8 +1386,11 @@ __global__ void __launch_bounds__(256) conv_k7_narrow_kernel(const float* __rest
 static size_t k7_lds_bytes(int W, int Cin) { return (size_t)(49 * Cin * 64 + (64 + 6 * (W + 1)) * Cin) * 4; }
 
 extern "C" int nfdp_conv_k7_narrow_supported(int B, int H, int W, int Cin, int Cout) {
-    if (B <= 0 || H <= 0 || W <= 0 || W % 4 != 0 || Cin < 1 || Cin > 4 || Cout < 4 || Cout % 4 != 0) return 0;
-    return (long)B * H * W < (1L << 31) - 4096 && k7_lds_bytes(W, Cin) <= 64 * 1024;
+    if (B <= 0 || H <= 0 || W <= 0 || W % 4 != 0 || Cin < 1 || Cin > 8 || Cout < 4 || Cout % 4 != 0) return 0;
+    // (the flat halo of a 7x7 window is six image rows: at W = 64 a 64-pixel tile stages 454 pixels, and with 6 channels the launch takes
+    // 140 us against the implicit-GEMM kernel's 101 - wide images with more than 4 channels stay there)
+    if (Cin > 4 && W > 32) return 0;
+    return (long)B * H * W < (1L << 31) - 4096 && k7_lds_bytes(W, Cin) <= 144 * 1024;
 }
 
 // w_k7 [49][Cin][Cout] fp32 from the [Cout][Cin][7][7] parameter
@@ -1394,19 +1407,27 @@ extern "C" int nfdp_conv_k7_narrow_f32(const float* x, int x_ld, const float* w_
                                        int W, int Cin, int Cout, nfdp_stream_t stream) {
     NFDP_REQUIRE(x && w_k7 && y, NFDP_EINVAL, "conv_k7_narrow: null pointer");
     NFDP_REQUIRE(nfdp_conv_k7_narrow_supported(B, H, W, Cin, Cout), NFDP_EUNSUPPORTED,
-                 "conv_k7_narrow: unsupported geometry B=%d H=%d W=%d (%% 4) Cin=%d (1..4) Cout=%d (%% 4)", B, H, W, Cin, Cout);
+                 "conv_k7_narrow: unsupported geometry B=%d H=%d W=%d (%% 4) Cin=%d (1..8) Cout=%d (%% 4)", B, H, W, Cin, Cout);
     NFDP_REQUIRE(x_ld >= Cin && y_ld >= Cout && y_ld % 4 == 0 && (((uintptr_t)y | (uintptr_t)bias | (uintptr_t)w_k7) % 16) == 0, NFDP_ESHAPE,
                  "conv_k7_narrow: output rows, weights and bias must be 16-byte aligned");
     const int npix = B * H * W;
     const dim3 grid((npix + 63) / 64, (Cout + 63) / 64);
     const size_t lds = k7_lds_bytes(W, Cin);
     hipStream_t s = as_stream(stream);
-    switch (Cin) {
-        case 1: hipLaunchKernelGGL(conv_k7_narrow_kernel<1>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break;
-        case 2: hipLaunchKernelGGL(conv_k7_narrow_kernel<2>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break;
-        case 3: hipLaunchKernelGGL(conv_k7_narrow_kernel<3>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break;
-        default: hipLaunchKernelGGL(conv_k7_narrow_kernel<4>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break;
+    static NfdpPerDevice attr_set;
+    if (!attr_set) {                                    // (5-8 channels: the 64 outputs' weights alone are 61-98 KB)
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv_k7_narrow_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv_k7_narrow_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv_k7_narrow_kernel<7>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        nfdp_func_attr(reinterpret_cast<const void*>(&conv_k7_narrow_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        attr_set = true;
     }
+#define NFDP_K7_CASE(CI) case CI: hipLaunchKernelGGL(conv_k7_narrow_kernel<CI>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break
+    switch (Cin) {
+        NFDP_K7_CASE(1); NFDP_K7_CASE(2); NFDP_K7_CASE(3); NFDP_K7_CASE(4); NFDP_K7_CASE(5); NFDP_K7_CASE(6); NFDP_K7_CASE(7);
+        default: hipLaunchKernelGGL(conv_k7_narrow_kernel<8>, grid, dim3(256), lds, s, x, x_ld, w_k7, bias, y, y_ld, npix, H, W, Cout); break;
+    }
+#undef NFDP_K7_CASE
     NFDP_CHECK_LAUNCH("conv_k7_narrow");
     return NFDP_OK;
 }

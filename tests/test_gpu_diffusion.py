@@ -718,11 +718,12 @@ def test_downsample_as_a_stride_two_conv(b, hw, c, cout):
     assert_close(got.permute(0, 3, 1, 2), ref, 2e-5, "Downsample vs torch fp64")
 
 
-@pytest.mark.parametrize("b,h,w,cin,cout", [(64, 16, 16, 2, 64), (3, 8, 8, 4, 64), (2, 20, 12, 3, 20), (5, 4, 4, 1, 128), (1, 64, 64, 2, 64)])
+@pytest.mark.parametrize("b,h,w,cin,cout", [(64, 16, 16, 2, 64), (3, 8, 8, 4, 64), (2, 20, 12, 3, 20), (5, 4, 4, 1, 128), (1, 64, 64, 2, 64), (3, 32, 32, 6, 64), (2, 16, 16, 8, 128),
+                                               (2, 8, 8, 5, 64), (2, 8, 8, 7, 64)])
 @torch.no_grad()
 def test_direct_7x7_conv_over_few_input_channels(b, h, w, cin, cout):
     """Unet.init_conv (reference gaussian_diffusion.py:383) on the direct fp32 kernel (nfdp_conv_k7_narrow_f32: 64 pixels x 64 outputs per
-    workgroup, FMA chains over (tap, channel)) against the implicit-GEMM conv and torch fp64; 1-4 input channels, non-square / non-power-of-two
+    workgroup, FMA chains over (tap, channel)) against the implicit-GEMM conv and torch fp64; 1-8 input channels, non-square / non-power-of-two
     images, partial pixel tiles."""
     torch.manual_seed(b + h + cin + cout)
     x = torch.randn(b, h, w, cin, device=DEV)
