@@ -769,1175 +769,8 @@ conv_splitk_f32_kernel(const ConvParams P) {
     splitk_epilogue<SK_WAVES, PT, GN>(P, part, acc, m0, n0, tid, wave, r16, q, mt);
 }
 
-// ----------------------------------------------------------------------------- small 3x3 convs, split products: the input tile in LDS
-// conv_splitk_f32_kernel<.., EMU> gathers every input element nine times (once per tap) straight into MFMA fragments and splits it into
-// its three bf16 pieces each time, and splits its weight fragments in every workgroup: a stage took 1.46 us for 0.64 us of matrix pipe
-// (16 global 16-byte loads per lane and stage, their masks and waits, ~250 vector instructions of split arithmetic against 96 MFMAs that
-// each hold the vector issue for 8 of their 16 cycles; profiles/r05_u_small_conv.txt).  Here
-//  * the workgroup's pixels and their halo - the flat pixel range [m0 - (W+1), m0 + MT + (W+1)) of the NHWC tensor, which holds every 3x3
-//    neighbour of the tile whatever the image geometry - are loaded ONCE, split ONCE and kept in LDS as three bf16 planes
-//    [pixel][Cin + 8].  A stage's x fragments are three ds_read_b128 per pixel tile at (pixel + tap shift, channel base) - a wave-uniform
-//    offset - and a lane whose tap falls outside the image reads the plane's zero row;
-//  * the weights are split when they are PACKED (nfdp_conv_pack_weights appends the image to the fp32 matrix of a 3x3 weight with
-//    Cin % 32 == 0, split_image_*): per (64-row tile, 32-k stage) the twelve MFMA A fragments (4 row tiles x 3 pieces) as register images
-//    of 1 KiB each - a wave's stage is twelve fully coalesced 16-byte loads and no arithmetic.
-// Same stage order per wave, same pieces, same six products in the same order, same partial-tile sum: the results are bit-identical to
-// conv_splitk_f32_kernel<4, 8, true>.  Needs KH = KW = 3, Cin % 32 == 0 (a 32-deep stage inside one tap), the planes inside the LDS.
-#ifndef NFDP_LX_NBUF
-#define NFDP_LX_NBUF 2
-#endif
-constexpr int LX_WAVES = 4, LX_NBUF = NFDP_LX_NBUF;   // waves per workgroup, register sets of the weight stream
-template <int N, typename F>
-__device__ __forceinline__ void static_for_lx(F&& f) {
-    if constexpr (N > 0) {
-        static_for_lx<N - 1>(f);
-        f(std::integral_constant<int, N - 1>{});
-    }
-}
-constexpr int LX_BLOCK = 12 * 1024;                    // bytes of one (row tile, stage) block of the split image
-static inline int ldsx_np(int W, int pt) { return 16 * pt + 2 * (W + 1); }
-// (GNIN) samples a workgroup's staged pixel range can touch, and its coefficient tables behind the planes: (mean, rstd) per (sample,
-// group), gamma | beta per channel, (scale + 1) | shift per (sample, channel)
-static inline int ldsx_gi_samples(int W, int HW, int pt) { return (ldsx_np(W, pt) - 2) / HW + 2; }
-static inline size_t ldsx_gi_bytes(int W, int HW, int Cin, int groups, int pt) {
-    return (size_t)(ldsx_gi_samples(W, HW, pt) * (2 * groups + 2 * Cin) + 2 * Cin) * 4;
-}
-static inline size_t ldsx_planes_bytes(int W, int Cin, int pt) { return (size_t)3 * (ldsx_np(W, pt) + 1) * (Cin + 8) * 2; }
-static inline size_t ldsx_bytes(int W, int Cin, int pt, int HW = 0, int gi_groups = 0) {
-    const size_t planes = ldsx_planes_bytes(W, Cin, pt) + (gi_groups ? ldsx_gi_bytes(W, HW, Cin, gi_groups, pt) : 0);
-    const size_t part = (size_t)LX_WAVES * 16 * pt * SK_LD * 4;
-    return planes > part ? planes : part;
-}
-// which packed fp32 weights carry the split image ([rows][K = 9 * Cin], see nfdp_conv_packed_bytes), and where
-static inline bool split_image_shape(int rows, int Cin, int KH, int KW) {
-    // 3x3 (conv3x3_ldsx_kernel) and the narrow 1x1 convs of the U-Nets (conv1x1_ln_kernel: Cin <= 128; the bound keeps the
-    // 512 -> 512 convs of the coupling networks, repacked every training step in fp32 mode, out of it)
-    // (the ResnetBlocks' res_conv over a skip concatenation: up to 256 inputs)
-    return ((KH == 3 && KW == 3) || (KH == 1 && KW == 1 && Cin <= 256)) && Cin % 32 == 0 && rows >= 64 && rows % 4 == 0;
-}
-static inline size_t split_image_bytes(int rows, int Kpad) { return (size_t)cdiv(rows, 64) * (Kpad / 32) * LX_BLOCK; }
-
-#ifdef NFDP_LX_STAMPS     // diagnostic build only: wave 0 of every 37th workgroup stores s_memtime / s_memrealtime at phase boundaries
-#define LX_STAMP(i)                                                                                                         \
-    do {                                                                                                                    \
-        if (P.part && threadIdx.x == 0 && blockIdx.x % 37 == 0) {                                                           \
-            unsigned long long* d_ = reinterpret_cast<unsigned long long*>(P.part) + (blockIdx.x / 37) * 16 + 2 * (i);      \
-            d_[0] = __builtin_amdgcn_s_memtime();                                                                           \
-            d_[1] = __builtin_amdgcn_s_memrealtime();                                                                       \
-        }                                                                                                                   \
-    } while (0)
-#else
-#define LX_STAMP(i)
-#endif
-
-template <int PT, bool GN, bool GNIN = false, bool RES = false, bool UP = false, bool T2D = false>
-__global__ void __launch_bounds__(LX_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-conv3x3_ldsx_kernel(const ConvParams P) {
-    static_assert(!T2D || (PT == 4 && !GN), "block tiles: 64 pixels, plain epilogue");
-    constexpr int MT = 16 * PT, NT_ = LX_WAVES * 64;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nt = blockIdx.x % P.Nt, mt = blockIdx.x / P.Nt;
-    const long m0 = (long)mt * MT;
-    const int n0 = nt * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, q = lane >> 4;
-    const float* __restrict__ xg = reinterpret_cast<const float*>(P.x);
-    const float* __restrict__ x2g = reinterpret_cast<const float*>(P.x2);
-    // The staged pixels: the flat range [m0 - (W+1), m0 + MT + (W+1)) - or, on wide images (P.tw), the (th+2) x (tw+2) block around the
-    // workgroup's th x tw block of ONE image (at W = 64 the flat range of a 64-pixel tile is three image rows, 194 pixels; the 8 x 8
-    // block with its ring is 100).  LDS row of a pixel: flat index + HALO, or (ty+1) * PW + tx + 1; a tap shifts by dy * PW + dx either way.
-    constexpr bool t2d = T2D;
-    const int HW = P.H * P.W;
-    const int PW = t2d ? P.tw + 2 : P.W;               // pixels per staged row
-    const int HALO = t2d ? PW + 1 : P.W + 1, NP = t2d ? (P.th + 2) * PW : MT + 2 * HALO;
-    int tb = 0, ty0 = 0, tx0 = 0;                      // (t2d) image, first row / column of the block
-    if (t2d) {
-        const int tpr = P.W / P.tw, tpi = (P.H / P.th) * tpr;
-        tb = mt / tpi;
-        const int r = mt - tb * tpi;
-        ty0 = (r / tpr) * P.th;
-        tx0 = (r - (r / tpr) * tpr) * P.tw;
-    }
-    const long ep0 = t2d ? (long)tb * HW + (long)ty0 * P.W + tx0 : m0;         // the epilogue's first pixel
-    const int RS = (P.Cin + 8) * 2;                    // plane row stride in bytes
-    const int PS = (NP + 1) * RS;                      // plane stride (row NP of a plane: zeros)
-    const int nk = P.Kpad / 32;
-#if defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 1     // timing-only build (garbage results): no main loop
-    const int S = 0;
-#else
-    const int S = (nk + LX_WAVES - 1) / LX_WAVES;      // stages per wave (the same for every wave: a stage beyond the end adds zeros)
-#endif
-    LX_STAMP(0);
-
-    // ---- (GNIN) the GroupNorm of the input: x holds the RAW output of the producing conv, whose epilogue left per (tile, group) the fp64
-    // sums of the values and of their squares (gi_parts tiles per image).  The samples this workgroup's pixel range touches get their
-    // (mean, rstd) below, while the first x units fly
-    float* const gi_mr = reinterpret_cast<float*>(smem + 3 * PS);              // [nbl][groups] (mean, rstd)
-    const int gi_nbl = GNIN ? (NP - 2) / HW + 2 : 0;
-    float* const gi_gb = gi_mr + gi_nbl * 2 * P.gi_groups;                     // [Cin] gamma, [Cin] beta
-    float* const gi_sh = gi_gb + 2 * P.Cin;                                    // [nbl][Cin] scale + 1, [nbl][Cin] shift
-    const int lhw = __builtin_ctz((unsigned)HW);                               // (GNIN: HW is a power of two)
-    const int gi_b0 = t2d ? tb : (int)((m0 > HALO ? m0 - HALO : 0) >> lhw);   // first sample of the range
-    const int gi_lcpg = GNIN ? __builtin_ctz((unsigned)(P.Cin / P.gi_groups)) : 0;   // (channels per group: a power of two)
-    // this thread's first-round pieces of the tables are requested here, in front of the x units and the weights in the load queue: LP
-    // lanes per (sample, group) set take the set's tiles side by side (one L2 round trip instead of one per tile)
-    double2 gi_v0 = make_double2(0.0, 0.0);
-    float4 gi_g0 = make_float4(0.f, 0.f, 0.f, 0.f), gi_b0v = gi_g0, gi_s0 = gi_g0, gi_h0 = gi_g0;
-    if constexpr (GNIN) {
-        const int nB = (int)(P.npix >> lhw), q4 = P.Cin / 4;
-        const int LP = P.gi_parts < 16 ? P.gi_parts : 16, lsh = __builtin_ctz((unsigned)LP);          // (tiles per image: a power of two)
-        const int nset = gi_nbl * P.gi_groups;
-        {
-            const int st = tid >> lsh, j = tid & (LP - 1);
-            const int stc = st < nset ? st : nset - 1;
-            const int bl = stc / P.gi_groups, g = stc - bl * P.gi_groups;
-            const int b = gi_b0 + bl < nB ? gi_b0 + bl : nB - 1;
-            gi_v0 = *reinterpret_cast<const double2*>(P.gi_stats + (((size_t)b * P.gi_parts + j) * P.gi_groups + g) * 2);
-        }
-        if (tid < q4) {
-            gi_g0 = *reinterpret_cast<const float4*>(P.gi_gamma + 4 * tid);
-            gi_b0v = *reinterpret_cast<const float4*>(P.gi_beta + 4 * tid);
-        }
-        if (P.gi_ss && tid < gi_nbl * q4) {
-            const int bl = tid / q4, c4 = (tid - bl * q4) * 4;
-            const int b = gi_b0 + bl < nB ? gi_b0 + bl : nB - 1;
-            const float* sr = P.gi_ss + (size_t)b * P.gi_ss_ld;
-            gi_s0 = *reinterpret_cast<const float4*>(sr + c4);
-            gi_h0 = *reinterpret_cast<const float4*>(sr + P.Cin + c4);
-        }
-    }
-    // ---- staging, part 1: the loads.  16 threads take the 64 channels of a channel block of one pixel (256 contiguous bytes), a pass
-    // covers 16 pixel rows; a thread's units are (pass, channel block) pairs, requested UB at a time - no division anywhere.  Flat pixels
-    // g = m0 - HALO + row, row = 0 .. NP-1; rows outside the tensor are zeros
-    const int srow = tid >> 4, sc = (tid & 15) * 4;
-    const int npass = (NP + 15) >> 4, ncb = (P.Cin + 63) >> 6;
-    constexpr int UB = 8;
-    // Branch-free loads: every unit reads 16 bytes from a VALID address (its pixel clamped into the tensor, its channel block clamped into
-    // the row) and is masked to zeros when it is stored - a "load or zero" select makes hipcc branch around every load (~50 instructions
-    // per unit: the staging took 7 k cycles for 7 units per thread)
-    const int grow0 = (int)(m0 - HALO) + srow;          // flat pixel of this thread's row in pass 0 (npix < 2^31)
-    // (the two sources' parameters as scalars of their own: a per-lane select between two kernel-argument fields otherwise becomes a
-    // VECTOR load from the argument segment - and a full memory round trip in front of the first unit)
-    unsigned ld_1 = (unsigned)P.x_ld, ld_2 = (unsigned)P.x2_ld;
-    int cin1_s = P.Cin1, npix_s = (int)P.npix;
-    asm volatile("" : "+s"(ld_1), "+s"(ld_2), "+s"(cin1_s), "+s"(npix_s));
-    // global pixel of staged row `row` (pass p: row = srow + 16 p) and whether it exists; absent rows read a valid pixel and are masked
-    auto staged_pixel = [&](int pass, bool& ok) -> int {
-        const int row = srow + 16 * pass;
-        if (!t2d) {
-            const int g = grow0 + 16 * pass;
-            ok = g >= 0 && g < npix_s && row < NP;
-            return g < 0 ? 0 : (g < npix_s ? g : npix_s - 1);
-        }
-        const int hy = row / PW, hx = row - hy * PW;
-        const int yy = ty0 - 1 + hy, xx = tx0 - 1 + hx;
-        ok = row < NP && (unsigned)yy < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
-        return tb * HW + (ok ? yy * P.W + xx : 0);
-    };
-    const int up_lw = UP ? __builtin_ctz((unsigned)P.W) : 0, up_lhw = UP ? __builtin_ctz((unsigned)HW) : 2;
-    struct Units { float4 v[UB]; unsigned ok; };
-    auto stage_load = [&](Units& u, int pass0, int cb) {              // units (pass0 .. pass0 + UB - 1, cb)
-        const int c = sc + 64 * cb;
-        const bool cin = c < P.Cin;
-        const int cc = cin ? c : 0;
-        const bool first = cc < cin1_s;
-        const float* base = first ? xg + cc : x2g + (cc - cin1_s);
-        const unsigned ld = first ? ld_1 : ld_2;
-        u.ok = 0;
-#pragma unroll
-        for (int e = 0; e < UB; ++e) {
-            bool okp;
-            unsigned gc = (unsigned)staged_pixel(pass0 + e, okp);
-            const bool ok = cin && okp;
-            if constexpr (UP) {
-                // Upsample(scale 2, nearest) -> conv (reference :169-173) without the upsampled tensor: output-grid pixel (b, y, x) reads
-                // source pixel (b, y / 2, x / 2) of the half-size tensor (power-of-two sides: shifts)
-                const unsigned r = gc & (unsigned)(HW - 1), yy = r >> up_lw, xx = r & (unsigned)(P.W - 1);
-                gc = ((gc >> up_lhw) << (up_lhw - 2)) + ((yy >> 1) << (up_lw - 1)) + (xx >> 1);
-            }
-            u.ok |= ok ? 1u << e : 0u;
-#if defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 2     // timing-only build: no input loads
-            u.v[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-#else
-            u.v[e] = *reinterpret_cast<const float4*>(base + (size_t)gc * ld);
-#endif
-        }
-    };
-    auto stage_store = [&](const Units& u, int pass0, int cb) {
-        const int c = sc + 64 * cb;
-        const int cl = c < P.Cin ? c : 0;
-        float4 ga, be;
-        if constexpr (GNIN) {
-            ga = *reinterpret_cast<const float4*>(gi_gb + cl);
-            be = *reinterpret_cast<const float4*>(gi_gb + P.Cin + cl);
-        }
-#pragma unroll
-        for (int e = 0; e < UB; ++e) {
-            const int row = srow + 16 * (pass0 + e);
-            const unsigned k = (u.ok >> e) & 1u ? 0xffffffffu : 0u;
-            float4 x4 = u.v[e];
-            if (GNIN && 16 * (pass0 + e) < NP) {                   // (uniform: a pass wholly beyond the range is masked anyway)
-                // the same expressions in the same order as groupnorm_silu_kernel (unet.hip); masked units compute on valid data
-                bool okp;
-                const int gc = staged_pixel(pass0 + e, okp);
-                int bl = (gc >> lhw) - gi_b0;
-                bl = bl < gi_nbl ? bl : gi_nbl - 1;                // (rows beyond the range: masked units)
-                const float2 mr = *reinterpret_cast<const float2*>(gi_mr + 2 * (bl * P.gi_groups + (cl >> gi_lcpg)));
-                float o[4] = {x4.x, x4.y, x4.z, x4.w};
-                const float gq[4] = {ga.x, ga.y, ga.z, ga.w}, bq[4] = {be.x, be.y, be.z, be.w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(o[r], mr.x), mr.y), gq[r]), bq[r]);
-                if (P.gi_ss) {                                     // (uniform)
-                    const float4 s1 = *reinterpret_cast<const float4*>(gi_sh + bl * P.Cin + cl);
-                    const float4 sh = *reinterpret_cast<const float4*>(gi_sh + (gi_nbl + bl) * P.Cin + cl);
-                    const float sq[4] = {s1.x, s1.y, s1.z, s1.w}, hq[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = __fadd_rn(__fmul_rn(o[r], sq[r]), hq[r]);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = o[r] / (1.0f + expf(-o[r]));
-                x4 = make_float4(o[0], o[1], o[2], o[3]);
-            }
-            float4 v;
-            v.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x4.x) & k);
-            v.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x4.y) & k);
-            v.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x4.z) & k);
-            v.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x4.w) & k);
-            uint2 h4, m4, l4;
-            split3x4(v, h4, m4, l4);
-            if (row < NP && c < P.Cin) {
-                char* d = smem + row * RS + c * 2;
-                *reinterpret_cast<uint2*>(d) = h4;
-                *reinterpret_cast<uint2*>(d + PS) = m4;
-                *reinterpret_cast<uint2*>(d + 2 * PS) = l4;
-            }
-        }
-    };
-    Units sv[2];
-    stage_load(sv[0], 0, 0);
-
-    // ---- the weight fragments of this wave's first stages are requested behind the first x units (they fly during the staging): a lane's
-    // part of the address is lane * 16, everything else is scalar
-    const char* wimg = reinterpret_cast<const char*>(P.w) + P.wsplit_off + (size_t)nt * nk * LX_BLOCK;
-    const unsigned wlane = (unsigned)(lane * 16);
-    struct WF { bf16x8 h[4], m[4], l[4]; };
-    auto loadw = [&](WF& f, int s) {
-        int kt = wave + s * LX_WAVES;
-        kt = kt < nk ? kt : nk - 1;                    // (uniform) beyond the end: valid addresses, the x side reads zeros
-#if defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 3     // timing-only build: every stage reads the weights of stage 0 (L1-resident)
-        kt = 0;
-#endif
-        const char* wb = wimg + (size_t)kt * LX_BLOCK;               // (uniform)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f.h[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i) * 1024 + wlane);
-            f.m[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i + 1) * 1024 + wlane);
-            f.l[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i + 2) * 1024 + wlane);
-        }
-    };
-    WF wf[LX_NBUF];
-#pragma unroll
-    for (int b = 0; b < LX_NBUF - 1; ++b) loadw(wf[b], b);
-
-    // ---- (GNIN) the coefficient tables from what was requested at the top (the rounds beyond the first: small batches of large images)
-    if constexpr (GNIN) {
-        const int nB = (int)(P.npix >> lhw), cpg = P.Cin / P.gi_groups, q4 = P.Cin / 4;
-        const int LP = P.gi_parts < 16 ? P.gi_parts : 16, lsh = __builtin_ctz((unsigned)LP);
-        const int nset = gi_nbl * P.gi_groups;
-        for (int st0 = 0; st0 < nset; st0 += NT_ >> lsh) {                                             // (uniform)
-            const int st = st0 + (tid >> lsh), j = tid & (LP - 1);
-            const int stc = st < nset ? st : nset - 1;
-            const int bl = stc / P.gi_groups, g = stc - bl * P.gi_groups;
-            const int b = gi_b0 + bl < nB ? gi_b0 + bl : nB - 1;
-            const double* sp = P.gi_stats + ((size_t)b * P.gi_parts * P.gi_groups + g) * 2;
-            double g1 = gi_v0.x, g2 = gi_v0.y;
-            for (int i = st0 == 0 ? j + LP : j; i < P.gi_parts; i += LP) {
-                const double2 v = *reinterpret_cast<const double2*>(sp + (size_t)i * P.gi_groups * 2);
-                if (st0 != 0 && i == j) { g1 = v.x; g2 = v.y; }
-                else { g1 += v.x; g2 += v.y; }
-            }
-            for (int o = 1; o < LP; o <<= 1) {                                                         // a fixed association
-                g1 += __shfl_xor(g1, o);
-                g2 += __shfl_xor(g2, o);
-            }
-            if (st < nset && j == 0) {
-                const double rn = 1.0 / ((double)HW * cpg);                                            // (a power of two: exact)
-                const double mean = g1 * rn;
-                double var = g2 * rn - mean * mean;
-                var = var > 0.0 ? var : 0.0;
-                gi_mr[2 * st] = (float)mean;
-                gi_mr[2 * st + 1] = (float)(1.0 / sqrt(var + (double)P.gi_eps));
-            }
-        }
-        for (int i = tid; i < q4; i += NT_) {
-            const float4 gv = i == tid ? gi_g0 : *reinterpret_cast<const float4*>(P.gi_gamma + 4 * i);
-            const float4 bv = i == tid ? gi_b0v : *reinterpret_cast<const float4*>(P.gi_beta + 4 * i);
-            *reinterpret_cast<float4*>(gi_gb + 4 * i) = gv;
-            *reinterpret_cast<float4*>(gi_gb + P.Cin + 4 * i) = bv;
-        }
-        if (P.gi_ss) {
-            for (int i = tid; i < gi_nbl * q4; i += NT_) {
-                const int bl = i / q4, c4 = (i - bl * q4) * 4;
-                const int b = gi_b0 + bl < nB ? gi_b0 + bl : nB - 1;
-                const float* sr = P.gi_ss + (size_t)b * P.gi_ss_ld;
-                const float4 sc = i == tid ? gi_s0 : *reinterpret_cast<const float4*>(sr + c4);
-                const float4 sh = i == tid ? gi_h0 : *reinterpret_cast<const float4*>(sr + P.Cin + c4);
-                *reinterpret_cast<float4*>(gi_sh + bl * P.Cin + c4) =
-                    make_float4(__fadd_rn(sc.x, 1.0f), __fadd_rn(sc.y, 1.0f), __fadd_rn(sc.z, 1.0f), __fadd_rn(sc.w, 1.0f));
-                *reinterpret_cast<float4*>(gi_sh + (gi_nbl + bl) * P.Cin + c4) = sh;
-            }
-        }
-    }
-
-    LX_STAMP(6);
-    // ---- staging, part 2: batch by batch (a batch = UB passes of one channel block; b -> (channel block b / npb, first pass (b % npb) UB)),
-    // the next batch's loads in flight while a batch is split into the planes
-    {
-        const int npb = (npass + UB - 1) / UB, nb = ncb * npb;         // (uniform)
-        auto bcb = [&](int bi) { return bi / npb; };
-        auto bp0 = [&](int bi) { return (bi - (bi / npb) * npb) * UB; };
-        if constexpr (GNIN) __syncthreads();                           // the coefficient tables are complete
-        for (int bi = 0; bi < nb; bi += 2) {
-            if (bi + 1 < nb) stage_load(sv[1], bp0(bi + 1), bcb(bi + 1));
-            stage_store(sv[0], bp0(bi), bcb(bi));
-            if (bi + 1 < nb) {
-                if (bi + 2 < nb) stage_load(sv[0], bp0(bi + 2), bcb(bi + 2));
-                stage_store(sv[1], bp0(bi + 1), bcb(bi + 1));
-            }
-        }
-        for (int i = tid; i < 3 * (RS / 8); i += NT_) {               // the zero row of each plane
-            const int pl = i / (RS / 8), o = i - pl * (RS / 8);
-            *reinterpret_cast<uint2*>(smem + pl * PS + NP * RS + o * 8) = make_uint2(0u, 0u);
-        }
-    }
-
-    // this lane's PT pixels: LDS row address of the centre pixel and the 9-bit mask of the taps that fall inside its image (power-of-two
-    // image sides - every U-Net stage - by shifts; else two 32-bit divisions per pixel)
-    unsigned xrow[PT], vmask[PT];
-    const bool pow2 = (P.W & (P.W - 1)) == 0 && (HW & (HW - 1)) == 0;          // (uniform)
-    const int lw = __builtin_ctz((unsigned)P.W);
-#pragma unroll
-    for (int j = 0; j < PT; ++j) {
-        if (t2d) {                                     // (uniform) pixel j * 16 + r16 of the th x tw block: always inside the image
-            const int idx = j * 16 + r16, ty = idx / P.tw, tx = idx - ty * P.tw;
-            const int py = ty0 + ty, px = tx0 + tx;
-            unsigned mk = 0;
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                if ((unsigned)(py + dy) < (unsigned)P.H && (unsigned)(px + dx) < (unsigned)P.W) mk |= 1u << tap;
-            }
-            vmask[j] = mk;
-            xrow[j] = (unsigned)(((ty + 1) * PW + tx + 1) * RS + 16 * q);
-            continue;
-        }
-        const long p = m0 + j * 16 + r16;
-        const int pc = p < P.npix ? (int)p : 0;
-        int py, px;
-        if (pow2) {
-            const int r = pc & (HW - 1);
-            py = r >> lw; px = r & (P.W - 1);
-        } else {
-            const int r = pc % HW;
-            py = r / P.W; px = r - py * P.W;
-        }
-        unsigned mk = 0;
-        if (p < P.npix) {
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-                if ((unsigned)(py + dy) < (unsigned)P.H && (unsigned)(px + dx) < (unsigned)P.W) mk |= 1u << tap;
-            }
-        }
-        vmask[j] = mk;
-        xrow[j] = (unsigned)((j * 16 + r16 + HALO) * RS + 16 * q);
-    }
-    const unsigned zrow = (unsigned)(NP * RS + 16 * q);
-    LX_STAMP(1);
-    __syncthreads();
-    LX_STAMP(2);
-
-    struct XF { bf16x8 h[PT], m[PT], l[PT]; };
-    auto loadx = [&](XF& f, int s) {
-        const int kt = wave + s * LX_WAVES;            // (uniform)
-        const int kb = kt * 32;
-        const int tap = kb / P.Cin;                    // 9 and beyond: the zero padding of K / a stage beyond the end
-        const int ci = kb - tap * P.Cin;
-        const bool live = kt < nk && tap < 9;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int soff = (dy * PW + dx) * RS + ci * 2;
-#pragma unroll
-        for (int j = 0; j < PT; ++j) {
-            const bool ok = live && ((vmask[j] >> (tap & 15)) & 1u);
-            const char* a = smem + (ok ? (int)xrow[j] + soff : (int)zrow);
-            f.h[j] = *reinterpret_cast<const bf16x8*>(a);
-            f.m[j] = *reinterpret_cast<const bf16x8*>(a + PS);
-            f.l[j] = *reinterpret_cast<const bf16x8*>(a + 2 * PS);
-        }
-    };
-
-    f32x4 acc[4][PT];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < PT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](const WF& fw, const XF& fx) {
-#if defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 5     // timing-only build: no matrix work (operands kept alive)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(fw.h[i]), "v"(fw.m[i]), "v"(fw.l[i]));
-#pragma unroll
-        for (int j = 0; j < PT; ++j) asm volatile("" ::"v"(fx.h[j]), "v"(fx.m[j]), "v"(fx.l[j]));
-        return;
-#endif
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < PT; ++j) {                         // smallest terms first (as conv_splitk_f32_kernel)
-                f32x4 c = acc[i][j];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.l[i], fx.h[j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.h[i], fx.l[j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.m[i], fx.m[j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.m[i], fx.h[j], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.h[i], fx.m[j], c, 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw.h[i], fx.h[j], c, 0, 0, 0);
-            }
-    };
-
-    // K stages wave, wave + 4, ...: the weights of the next LX_NBUF - 1 stages and the x fragments of the next one fly under a stage's
-    // MFMAs.  Stages in straight-line groups of LX_UNROLL and a remainder (a loop of guarded stages makes hipcc's wait-count insertion
-    // merge states at every join and drain the load queue in front of the prefetches)
-    constexpr int LX_XBUF = 2, LX_UNROLL = LX_NBUF * LX_XBUF / (LX_NBUF % 2 == 0 ? 2 : 1);     // lcm of the two set counts
-    XF xf[LX_XBUF];
-    auto stage = [&](auto bc, int st) __attribute__((always_inline)) {
-        constexpr int b = decltype(bc)::value;
-        loadw(wf[(b + LX_NBUF - 1) % LX_NBUF], st + LX_NBUF - 1);
-        loadx(xf[(b + 1) % LX_XBUF], st + 1);
-        compute(wf[b % LX_NBUF], xf[b % LX_XBUF]);
-        // the stage is ONE scheduling region: its 12 weight loads and 3 PT LDS reads are spread between its 24 PT MFMAs (issued as a
-        // block in front of them they cost ~850 cycles per stage in which the matrix pipe of this one-wave-per-SIMD kernel idles; left
-        // to the scheduler they sink to their uses in the NEXT stage - no prefetch)
-#if !(defined(NFDP_LX_ABLATE) && NFDP_LX_ABLATE == 5)
-        static_for_lx<12>([&](auto gc) __attribute__((always_inline)) {
-            constexpr int g = decltype(gc)::value;
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * PT, 0);                  // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       // VMEM read
-            if constexpr (PT == 4 || (PT == 2 && g % 2 == 0) || (PT == 1 && g % 4 == 0))
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                   // DS read
-        });
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // (RES) res_conv = a 1x1 conv of the same input: the centre tap of the staged tile against w2's split image, K stages dealt to the
-    // waves like the 3x3 conv's, a second accumulator set; the first stage's weights fly under the main loop
-    const int nk2 = RES ? (P.Cin + 31) / 32 : 0;
-    const char* wimg2 = reinterpret_cast<const char*>(P.w2) + P.w2split_off + (size_t)nt * nk2 * LX_BLOCK;
-    auto loadw2 = [&](WF& f, int s2) {
-        int kt = wave + s2 * LX_WAVES;
-        kt = kt < nk2 ? kt : nk2 - 1;                  // (uniform) beyond the end: valid addresses, the x side reads zeros
-        const char* wb = wimg2 + (size_t)kt * LX_BLOCK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f.h[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i) * 1024 + wlane);
-            f.m[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i + 1) * 1024 + wlane);
-            f.l[i] = *reinterpret_cast<const bf16x8*>(wb + (3 * i + 2) * 1024 + wlane);
-        }
-    };
-    WF wres;
-    if constexpr (RES) loadw2(wres, 0);
-
-    loadx(xf[0], 0);
-    int st = 0;
-    for (; st + LX_UNROLL <= S; st += LX_UNROLL)
-        static_for_lx<LX_UNROLL>([&](auto bc) __attribute__((always_inline)) { stage(bc, st + decltype(bc)::value); });
-    static_for_lx<LX_UNROLL - 1>([&](auto bc) __attribute__((always_inline)) {
-        if (st + decltype(bc)::value < S) stage(bc, st + decltype(bc)::value);       // (uniform) the remainder
-    });
-    f32x4 acc2[RES ? 4 : 1][RES ? PT : 1];
-    if constexpr (RES) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < PT; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int S2 = (nk2 + LX_WAVES - 1) / LX_WAVES;
-        for (int s2 = 0; s2 < S2; ++s2) {                           // (1-2 stages per wave: not pipelined)
-            const int kt = wave + s2 * LX_WAVES;
-            XF fx;
-#pragma unroll
-            for (int j = 0; j < PT; ++j) {
-                const bool ok = kt < nk2 && ((vmask[j] >> 4) & 1u);
-                const char* a = smem + (ok ? (int)xrow[j] + kt * 64 : (int)zrow);
-                fx.h[j] = *reinterpret_cast<const bf16x8*>(a);
-                fx.m[j] = *reinterpret_cast<const bf16x8*>(a + PS);
-                fx.l[j] = *reinterpret_cast<const bf16x8*>(a + 2 * PS);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < PT; ++j) {                     // the six products of `compute`, smallest terms first
-                    f32x4 c = acc2[i][j];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.l[i], fx.h[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.h[i], fx.l[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.m[i], fx.m[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.m[i], fx.h[j], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.h[i], fx.m[j], c, 0, 0, 0);
-                    acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wres.h[i], fx.h[j], c, 0, 0, 0);
-                }
-            if (s2 + 1 < S2) loadw2(wres, s2 + 1);
-        }
-    }
-    LX_STAMP(3);
-    __syncthreads();                                                // the partial tiles alias the planes
-    LX_STAMP(4);
-    splitk_epilogue<LX_WAVES, PT, GN, false, T2D>(P, reinterpret_cast<float*>(smem), acc, ep0, n0, tid, wave, r16, q, mt);
-    if constexpr (RES) {
-        __syncthreads();                                            // the first tile's partial sums have been read
-        splitk_epilogue<LX_WAVES, PT, false, true, T2D>(P, reinterpret_cast<float*>(smem), reinterpret_cast<const f32x4 (&)[4][PT]>(acc2), ep0, n0, tid, wave, r16, q, mt);
-    }
-    LX_STAMP(5);
-}
-
-// ----------------------------------------------------------------------------- 1x1 convs of the attention blocks with their LayerNorms
-// Residual(PreNorm(dim, LinearAttention | Attention)) (reference gaussian_diffusion.py:160-166, :212-220, :305-358) is, per block, a channel
-// LayerNorm, the to_qkv 1x1 conv, the attention core, the to_out 1x1 conv, a second LayerNorm (linear attention) and the residual add: five
-// launches of 4-11 us, each at the floor of a dependent launch.  conv1x1_ln_kernel runs a 1x1 conv with split products without LDS - a
-// wave owns 16 pixels over the whole K: its x fragments come straight from memory in MFMA shape (a lane's 8 consecutive channels of its
-// pixel per 32-deep stage), the weight fragments pre-split from the packed image (split_image_*) - and, because the four q-lanes of a
-// pixel together hold ALL its input channels, the LayerNorm of the INPUT is two xor-shuffles away (LNPRE: to_qkv); a workgroup that covers
-// all output channels (NTT 64-channel tiles, Cout <= 128) holds all outputs of its pixels the same way (LNPOST: to_out's LayerNorm + the
-// block's residual).  LayerNorm arithmetic as chan_layernorm_kernel: fp64 mean, fp64 centred squares, ((x - m) r) g.  Three launches per
-// block.  Cin % 32 == 0, Cin <= 128.
-struct LnConv {
-    const float* pre_gain;       // LNPRE: gain[Cin]
-    const float* post_gain;      // LNPOST: gain[Cout]
-    const float* residual;       // LNPOST: added after the LayerNorm ([npix][res_ld]); null: none
-    int res_ld;
-    float eps;
-};
-template <int NS, int NTT, bool LNPRE, bool LNPOST>
-__global__ void __launch_bounds__(256) conv1x1_ln_kernel(const ConvParams P, const LnConv ln) {
-    static_assert(!LNPOST || NTT >= 1, "tiles");
-    const int nt0 = LNPOST ? 0 : (int)(blockIdx.x % P.Nt);
-    const int mt = LNPOST ? (int)blockIdx.x : (int)(blockIdx.x / P.Nt);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, q = lane >> 4;
-    const long p = (long)mt * 64 + wave * 16 + r16;
-    const bool pok = p < P.npix;
-    const long pc = pok ? p : 0;
-    const float* __restrict__ xg = reinterpret_cast<const float*>(P.x);
-    const int nk = P.Kpad / 32;                         // (<= NS)
-    const char* wimg = reinterpret_cast<const char*>(P.w) + P.wsplit_off + lane * 16;
-    float4 xv[NS][2];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const int c = 32 * s + 8 * q;
-        const bool live = c < P.Cin;                    // (Cin % 32 == 0: a whole stage is inside or outside)
-        const float* src = xg + pc * P.x_ld + (live ? c : 0);
-        xv[s][0] = *reinterpret_cast<const float4*>(src);
-        xv[s][1] = *reinterpret_cast<const float4*>(src + 4);
-        if (!live || !pok) { xv[s][0] = make_float4(0.f, 0.f, 0.f, 0.f); xv[s][1] = xv[s][0]; }
-    }
-    bf16x8 wf[NS][12];                                  // [stage][3 i + piece] of the running row tile
-    auto loadw = [&](int nt, int s) __attribute__((always_inline)) {
-        const char* wb = wimg + ((size_t)nt * nk + (s < nk ? s : nk - 1)) * LX_BLOCK;     // (uniform; beyond the end: valid, x is zero)
-#pragma unroll
-        for (int f = 0; f < 12; ++f) wf[s][f] = *reinterpret_cast<const bf16x8*>(wb + f * 1024);
-    };
-#pragma unroll
-    for (int s = 0; s < NS; ++s) loadw(nt0, s);
-    float4 gpre[NS][2];
-    if constexpr (LNPRE) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int c = 32 * s + 8 * q;
-            const float* gs = ln.pre_gain + (c < P.Cin ? c : 0);
-            gpre[s][0] = *reinterpret_cast<const float4*>(gs);
-            gpre[s][1] = *reinterpret_cast<const float4*>(gs + 4);
-        }
-    }
-    float4 rres[NTT][4];
-    if constexpr (LNPOST) {
-        if (ln.residual != nullptr) {
-#pragma unroll
-            for (int t = 0; t < NTT; ++t)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n = 64 * t + 16 * i + 4 * q;
-                    rres[t][i] = (pok && n < P.Cout) ? *reinterpret_cast<const float4*>(ln.residual + p * ln.res_ld + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-        }
-    }
-    if constexpr (LNPRE) {                              // LayerNorm of the pixel's input row: its channels sit in the 4 q-lanes of the pixel
-        double s1 = 0.0;
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            s1 += ((double)xv[s][0].x + (double)xv[s][0].y) + ((double)xv[s][0].z + (double)xv[s][0].w) +
-                  ((double)xv[s][1].x + (double)xv[s][1].y) + ((double)xv[s][1].z + (double)xv[s][1].w);
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        const double mean = s1 / P.Cin;
-        double s2 = 0.0;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (32 * s + 8 * q < P.Cin) {
-                const float vals[8] = {xv[s][0].x, xv[s][0].y, xv[s][0].z, xv[s][0].w, xv[s][1].x, xv[s][1].y, xv[s][1].z, xv[s][1].w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const double d = vals[e] - mean; s2 += d * d; }
-            }
-        }
-        s2 += __shfl_xor(s2, 16, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        const float m = (float)mean, r = rsqrtf(__fadd_rn((float)(s2 / P.Cin), ln.eps));
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const bool live = 32 * s + 8 * q < P.Cin && pok;
-            float4& a = xv[s][0]; float4& b = xv[s][1];
-            const float4 g0 = gpre[s][0], g1 = gpre[s][1];
-            a.x = live ? __fmul_rn(__fmul_rn(__fsub_rn(a.x, m), r), g0.x) : 0.f; a.y = live ? __fmul_rn(__fmul_rn(__fsub_rn(a.y, m), r), g0.y) : 0.f;
-            a.z = live ? __fmul_rn(__fmul_rn(__fsub_rn(a.z, m), r), g0.z) : 0.f; a.w = live ? __fmul_rn(__fmul_rn(__fsub_rn(a.w, m), r), g0.w) : 0.f;
-            b.x = live ? __fmul_rn(__fmul_rn(__fsub_rn(b.x, m), r), g1.x) : 0.f; b.y = live ? __fmul_rn(__fmul_rn(__fsub_rn(b.y, m), r), g1.y) : 0.f;
-            b.z = live ? __fmul_rn(__fmul_rn(__fsub_rn(b.z, m), r), g1.z) : 0.f; b.w = live ? __fmul_rn(__fmul_rn(__fsub_rn(b.w, m), r), g1.w) : 0.f;
-        }
-    }
-    bf16x8 xh[NS], xm[NS], xl[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        const float x8[8] = {xv[s][0].x, xv[s][0].y, xv[s][0].z, xv[s][0].w, xv[s][1].x, xv[s][1].y, xv[s][1].z, xv[s][1].w};
-        split3(x8, xh[s], xm[s], xl[s]);
-    }
-    f32x4 acc[NTT][4];
-#pragma unroll
-    for (int t = 0; t < NTT; ++t) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                // smallest terms first
-                const bf16x8 wh = wf[s][3 * i], wm = wf[s][3 * i + 1], wl = wf[s][3 * i + 2];
-                f32x4 c = acc[t][i];
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh[s], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl[s], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm[s], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh[s], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm[s], c, 0, 0, 0);
-                acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh[s], c, 0, 0, 0);
-            }
-            if (t + 1 < NTT) loadw(nt0 + t + 1, s);      // the next row tile's stage s into the registers this stage just released
-        }
-    }
-    // D[row = channel 16 i + 4 q + r][col = pixel r16]: a lane holds 4 consecutive channels of its pixel per row tile
-    float o[NTT][4][4];
-#pragma unroll
-    for (int t = 0; t < NTT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = 64 * (nt0 + t) + 16 * i + 4 * q;
-            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (P.add && n < P.Cout) a4 = *reinterpret_cast<const float4*>(P.add + n);
-            o[t][i][0] = __fadd_rn(acc[t][i][0], a4.x); o[t][i][1] = __fadd_rn(acc[t][i][1], a4.y);
-            o[t][i][2] = __fadd_rn(acc[t][i][2], a4.z); o[t][i][3] = __fadd_rn(acc[t][i][3], a4.w);
-        }
-    if constexpr (LNPOST) {                             // LayerNorm over the pixel's Cout outputs (the 4 q-lanes of the pixel), gain, + residual
-        double s1 = 0.0;
-#pragma unroll
-        for (int t = 0; t < NTT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (64 * t + 16 * i + 4 * q < P.Cout) s1 += ((double)o[t][i][0] + (double)o[t][i][1]) + ((double)o[t][i][2] + (double)o[t][i][3]);
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        const double mean = s1 / P.Cout;
-        double s2 = 0.0;
-#pragma unroll
-        for (int t = 0; t < NTT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (64 * t + 16 * i + 4 * q < P.Cout) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { const double d = o[t][i][r] - mean; s2 += d * d; }
-                }
-        s2 += __shfl_xor(s2, 16, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        const float m = (float)mean, rs = rsqrtf(__fadd_rn((float)(s2 / P.Cout), ln.eps));
-#pragma unroll
-        for (int t = 0; t < NTT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = 64 * t + 16 * i + 4 * q;
-                if (n >= P.Cout) continue;
-                const float4 g4 = *reinterpret_cast<const float4*>(ln.post_gain + n);
-                const float gq[4] = {g4.x, g4.y, g4.z, g4.w};
-                const float rq[4] = {rres[t][i].x, rres[t][i].y, rres[t][i].z, rres[t][i].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = __fmul_rn(__fmul_rn(__fsub_rn(o[t][i][r], m), rs), gq[r]);
-                    if (ln.residual != nullptr) v = __fadd_rn(v, rq[r]);
-                    o[t][i][r] = v;
-                }
-            }
-    }
-    if (!pok) return;
-    float* yrow = reinterpret_cast<float*>(P.y) + p * P.y_ld;
-#pragma unroll
-    for (int t = 0; t < NTT; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = 64 * (nt0 + t) + 16 * i + 4 * q;
-            if (n >= P.Cout) continue;
-            if constexpr (!LNPOST) {                    // a residual without the output LayerNorm (Attention's to_out + x, :160-166)
-                if (ln.residual != nullptr) {
-                    const float4 rv = *reinterpret_cast<const float4*>(ln.residual + p * ln.res_ld + n);
-                    o[t][i][0] = __fadd_rn(o[t][i][0], rv.x); o[t][i][1] = __fadd_rn(o[t][i][1], rv.y);
-                    o[t][i][2] = __fadd_rn(o[t][i][2], rv.z); o[t][i][3] = __fadd_rn(o[t][i][3], rv.w);
-                }
-            }
-            *reinterpret_cast<float4*>(yrow + n) = make_float4(o[t][i][0], o[t][i][1], o[t][i][2], o[t][i][3]);
-        }
-}
-
-// ----------------------------------------------------------------------------- LinearAttention with its to_qkv projection inside
-// Residual(PreNorm(dim, LinearAttention)) (reference gaussian_diffusion.py:305-333) as conv1x1_ln (LayerNorm + to_qkv) -> attention core
-// writes and re-reads the [B][n][3 * heads * 32] qkv tensor (25 MB at B = 64, 16x16: the projection launch is bound by writing it, 13.7 us,
-// and the core starts by staging its slice of it).  Here the workgroup of a (sample, head) forms its own 96 qkv rows: a wave takes 16-pixel
-// tiles, loads the pixels' C input channels in MFMA shape, normalises them (LayerNorm as conv1x1_ln_kernel: the four q-lanes of a pixel
-// hold its channels), splits them once and multiplies them with the head's six 16-row tiles of the packed weight's split image - k and v
-// land in the LDS arrays the core works on, q stays in registers until the core wants it.  Same products in the same order as
-// conv1x1_ln_kernel and the same core as linear_attention_staged_kernel (unet.hip); against the two launches the q / k / v rows agree to
-// 1-2 ulp and the outputs to 4e-7 relative (linear) / 5e-6 element-wise (softmax attention).
-// n = 64 NPT pixels (8x8, 16x16), C = 32 NS input channels (64, 128), dim_head 32.
-// The q / k / v rows of one (sample, head) for the calling wave's pixel tiles (tile = wave + 4 t): acc[t][rt], rt = q0 q1 k0 k1 v0 v1,
-// D[row = channel 16 (rt & 1) + 4 q + r][col = pixel r16].  LayerNorm and products as conv1x1_ln_kernel.
-template <int NS, int NPT, int RT0 = 0, int NRT = 6>      // row tiles RT0 .. RT0 + NRT - 1 of (q0 q1 k0 k1 v0 v1)
-__device__ __forceinline__ void head_qkv_rows(const float* __restrict__ x, int x_ld, const float* __restrict__ gain, const char* wimg,
-                                              int b, int hd, int HD, float eps, int wave, int r16, int q, f32x4 (&acc)[NPT][NRT]) {
-    constexpr int DHc = 32, n = 64 * NPT, C = 32 * NS;
-    // Everything is requested up front - the tiles' input rows, the first
-    // stage's 18 weight fragments - and a K stage is outer: its weights are loaded once per wave and meet all NPT tiles (tile-outer,
-    // every tile waited for its own x rows and 18 L2 round trips per stage: the phase took ~10 us of the launch)
-    float4 xv[NPT][NS][2];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int pix = (wave + 4 * t) * 16 + r16;
-        const float* src = x + ((size_t)b * n + pix) * x_ld + 8 * q;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            xv[t][s][0] = *reinterpret_cast<const float4*>(src + 32 * s);
-            xv[t][s][1] = *reinterpret_cast<const float4*>(src + 32 * s + 4);
-        }
-    }
-    struct WS { bf16x8 h[NRT], m[NRT], l[NRT]; };
-    auto loadw = [&](WS& f, int s) __attribute__((always_inline)) {
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) {
-            const int row = ((rt + RT0) >> 1) * HD + hd * DHc + 16 * ((rt + RT0) & 1);          // (uniform)
-            const char* wb = wimg + ((size_t)(row >> 6) * NS + s) * LX_BLOCK + 3 * ((row & 63) >> 4) * 1024;
-            f.h[rt] = *reinterpret_cast<const bf16x8*>(wb);
-            f.m[rt] = *reinterpret_cast<const bf16x8*>(wb + 1024);
-            f.l[rt] = *reinterpret_cast<const bf16x8*>(wb + 2048);
-        }
-    };
-    WS wq[2];
-    loadw(wq[0], 0);
-    float4 gpre[NS][2];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        gpre[s][0] = *reinterpret_cast<const float4*>(gain + 32 * s + 8 * q);
-        gpre[s][1] = *reinterpret_cast<const float4*>(gain + 32 * s + 8 * q + 4);
-    }
-    bf16x8 xh[NPT][NS], xm[NPT][NS], xl[NPT][NS];
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        double s1 = 0.0;
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            s1 += ((double)xv[t][s][0].x + (double)xv[t][s][0].y) + ((double)xv[t][s][0].z + (double)xv[t][s][0].w) +
-                  ((double)xv[t][s][1].x + (double)xv[t][s][1].y) + ((double)xv[t][s][1].z + (double)xv[t][s][1].w);
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
-        const double mean = s1 / C;
-        double s2 = 0.0;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const float vals[8] = {xv[t][s][0].x, xv[t][s][0].y, xv[t][s][0].z, xv[t][s][0].w, xv[t][s][1].x, xv[t][s][1].y, xv[t][s][1].z, xv[t][s][1].w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const double d = vals[e] - mean; s2 += d * d; }
-        }
-        s2 += __shfl_xor(s2, 16, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        const float m = (float)mean, r = rsqrtf(__fadd_rn((float)(s2 / C), eps));
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const float4 a = xv[t][s][0], c = xv[t][s][1], g0 = gpre[s][0], g1 = gpre[s][1];
-            const float x8[8] = {__fmul_rn(__fmul_rn(__fsub_rn(a.x, m), r), g0.x), __fmul_rn(__fmul_rn(__fsub_rn(a.y, m), r), g0.y),
-                                 __fmul_rn(__fmul_rn(__fsub_rn(a.z, m), r), g0.z), __fmul_rn(__fmul_rn(__fsub_rn(a.w, m), r), g0.w),
-                                 __fmul_rn(__fmul_rn(__fsub_rn(c.x, m), r), g1.x), __fmul_rn(__fmul_rn(__fsub_rn(c.y, m), r), g1.y),
-                                 __fmul_rn(__fmul_rn(__fsub_rn(c.z, m), r), g1.z), __fmul_rn(__fmul_rn(__fsub_rn(c.w, m), r), g1.w)};
-            split3(x8, xh[t][s], xm[t][s], xl[t][s]);
-        }
-    }
-    // per tile: row tiles q0 q1 k0 k1 v0 v1, side by side (no dependent MFMA pairs)
-#pragma unroll
-    for (int t = 0; t < NPT; ++t)
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        if (s + 1 < NS) loadw(wq[(s + 1) & 1], s + 1);
-        const WS& w = wq[s & 1];
-#pragma unroll
-        for (int t = 0; t < NPT; ++t) {
-            // the six products of conv1x1_ln_kernel in its order per accumulator, the accumulators interleaved
-#pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.l[rt], xh[t][s], acc[t][rt], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xl[t][s], acc[t][rt], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m[rt], xm[t][s], acc[t][rt], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.m[rt], xh[t][s], acc[t][rt], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xm[t][s], acc[t][rt], 0, 0, 0);
-#pragma unroll
-            for (int rt = 0; rt < NRT; ++rt) acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.h[rt], xh[t][s], acc[t][rt], 0, 0, 0);
-        }
-    }
-}
-
-template <int NS, int NPT>
-__global__ void __launch_bounds__(256) linattn_qkv_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ gain,
-                                                         const char* __restrict__ wimg0, float* __restrict__ out, int heads, float scale,
-                                                         float eps) {
-    constexpr int DHc = 32, LP = DHc + 1, n = 64 * NPT, C = 32 * NS;
-    __shared__ float kmax[DHc], ksum[DHc];
-    __shared__ __attribute__((aligned(16))) float ctx4[DHc][DHc];
-    __shared__ float part[8][DHc];
-    extern __shared__ __attribute__((aligned(16))) float lsm[];
-    float* ksm = lsm;
-    float* vsm = lsm + n * LP;
-    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, HD = heads * DHc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, q = lane >> 4;
-    const char* wimg = wimg0 + lane * 16;
-    // ---- 0. qkv rows of this head for the wave's pixel tiles
-    f32x4 acc[NPT][6];
-    head_qkv_rows<NS, NPT>(x, x_ld, gain, wimg, b, hd, HD, eps, wave, r16, q, acc);
-    // D[row = channel 16 j + 4 q + r][col = pixel r16]: k and v into the core's LDS arrays, q stays in its accumulators
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int pix = (wave + 4 * t) * 16 + r16;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float* kd = ksm + pix * LP + 16 * j + 4 * q;
-            float* vd = vsm + pix * LP + 16 * j + 4 * q;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { kd[e] = acc[t][2 + j][e]; vd[e] = acc[t][4 + j][e]; }
-        }
-    }
-    __syncthreads();
-    // ---- 1.-4.: linear_attention_staged_kernel's core (unet.hip), n a compile-time constant
-    const int d = tid % DHc, grp = tid / DHc;
-    const int r = tid >> 3, c4 = (tid & 7) * 4;
-    float mx = -INFINITY;
-    for (int i = grp; i < n; i += 8) mx = fmaxf(mx, ksm[i * LP + d]);
-    part[grp][d] = mx;
-    __syncthreads();
-    if (tid < DHc) {
-        float mm = part[0][d];
-        for (int g = 1; g < 8; ++g) mm = fmaxf(mm, part[g][d]);
-        kmax[d] = mm;
-    }
-    __syncthreads();
-    float sm = 0.f;
-    {
-        const float km = kmax[d];
-        for (int i = grp; i < n; i += 8) {
-            const float ev = expf(ksm[i * LP + d] - km);
-            ksm[i * LP + d] = ev;
-            sm += ev;
-        }
-    }
-    __syncthreads();
-    part[grp][d] = sm;
-    __syncthreads();
-    if (tid < DHc) {
-        float ss = 0.f;
-        for (int g = 0; g < 8; ++g) ss += part[g][d];
-        ksum[d] = ss;
-    }
-    __syncthreads();
-    {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < n; ++i) {
-            const float p = ksm[i * LP + d];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = fmaf(p, vsm[i * LP + 4 * grp + j], acc[j]);
-        }
-        const float f = 1.0f / (ksum[d] * (float)n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ctx4[d][4 * grp + j] = acc[j] * f;
-    }
-    __syncthreads();
-    float* qs = ksm;
-    float* os = vsm;
-#pragma unroll
-    for (int t = 0; t < NPT; ++t) {
-        const int pix = (wave + 4 * t) * 16 + r16;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float* qd = qs + pix * LP + 16 * j + 4 * q;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) qd[e] = acc[t][j][e];
-        }
-    }
-    __syncthreads();
-    if (tid < n) {
-        const int i = tid;
-        float qv[DHc];
-        float mq = -INFINITY;
-#pragma unroll
-        for (int dd = 0; dd < DHc; ++dd) { qv[dd] = qs[i * LP + dd]; mq = fmaxf(mq, qv[dd]); }
-        float sq = 0.f;
-#pragma unroll
-        for (int dd = 0; dd < DHc; ++dd) { qv[dd] = expf(qv[dd] - mq); sq += qv[dd]; }
-#pragma unroll
-        for (int dd = 0; dd < DHc; ++dd) qv[dd] = __fmul_rn(qv[dd] / sq, scale);
-        float acc[DHc];
-#pragma unroll
-        for (int e = 0; e < DHc; ++e) acc[e] = 0.f;
-#pragma unroll
-        for (int dd = 0; dd < DHc; ++dd) {
-#pragma unroll
-            for (int e4 = 0; e4 < DHc / 4; ++e4) {
-                const float4 c = *reinterpret_cast<const float4*>(&ctx4[dd][4 * e4]);
-                acc[4 * e4 + 0] = fmaf(c.x, qv[dd], acc[4 * e4 + 0]);
-                acc[4 * e4 + 1] = fmaf(c.y, qv[dd], acc[4 * e4 + 1]);
-                acc[4 * e4 + 2] = fmaf(c.z, qv[dd], acc[4 * e4 + 2]);
-                acc[4 * e4 + 3] = fmaf(c.w, qv[dd], acc[4 * e4 + 3]);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < DHc; ++e) os[i * LP + e] = acc[e];
-    }
-    __syncthreads();
-    float* obase = out + (size_t)b * n * HD + hd * DHc;
-#pragma unroll
-    for (int it = 0; it < n / 32; ++it) {
-        const int i = r + 32 * it;
-        const float* od = os + i * LP + c4;
-        *reinterpret_cast<float4*>(obase + (size_t)i * HD + c4) = make_float4(od[0], od[1], od[2], od[3]);
-    }
-}
-
-// Long sequences (n a multiple of 256: the 32x32 / 64x64 stages of the CelebA latent parts): linear attention runs as two launches over
-// 256-pixel chunks (unet.hip: linear_attention_partial_kernel - a chunk's column maxima, exp sums and context; linear_attention_apply_kernel -
-// the chunks merged, the chunk's outputs).  With to_qkv inside, the first forms its chunk's k / v rows and the second its q rows from x:
-// the [B][n][384] tensor (201 MB at 32 x 64 x 64: written by the projection, read by both launches) is never formed; x is read twice.
-template <int NS>
-__global__ void __launch_bounds__(256) linattn_partial_qkv_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ gain,
-                                                                 const char* __restrict__ wimg0, float* __restrict__ ws, int n, int heads,
-                                                                 float eps) {
-    constexpr int DHc = 32, CH = 256, REC = 2 * DHc + DHc * DHc;
-    __shared__ float kmax[DHc];
-    __shared__ float part[8][DHc];
-    __shared__ float ksm[CH][DHc + 1], vsm[CH][DHc + 1];
-    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, c = blockIdx.y, HD = heads * DHc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, q16 = lane >> 4;
-    {
-        f32x4 acc[4][4];
-        head_qkv_rows<NS, 4, 2, 4>(x + ((size_t)b * n + (size_t)c * CH) * x_ld, x_ld, gain, wimg0 + lane * 16, 0, hd, HD, eps, wave, r16, q16, acc);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int pix = (wave + 4 * t) * 16 + r16;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ksm[pix][16 * j + 4 * q16 + e] = acc[t][j][e];
-                    vsm[pix][16 * j + 4 * q16 + e] = acc[t][2 + j][e];
-                }
-        }
-    }
-    __syncthreads();
-    const int d = tid % DHc, grp = tid / DHc;
-    float m = -INFINITY;
-    for (int i = grp; i < CH; i += 8) m = fmaxf(m, ksm[i][d]);
-    part[grp][d] = m;
-    __syncthreads();
-    if (tid < DHc) {
-        float mm = part[0][d];
-        for (int g = 1; g < 8; ++g) mm = fmaxf(mm, part[g][d]);
-        kmax[d] = mm;
-    }
-    __syncthreads();
-    const float km = kmax[d];
-    float sm = 0.f;
-    for (int i = grp; i < CH; i += 8) sm += expf(ksm[i][d] - km);
-    __syncthreads();
-    part[grp][d] = sm;
-    __syncthreads();
-    float* rec = ws + ((size_t)blockIdx.x * gridDim.y + c) * REC;
-    if (tid < DHc) {
-        float ss = 0.f;
-        for (int g = 0; g < 8; ++g) ss += part[g][d];
-        rec[d] = km;
-        rec[DHc + d] = ss;
-    }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < CH; ++i) {
-        const float pexp = expf(ksm[i][d] - km);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = fmaf(pexp, vsm[i][4 * grp + j], acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rec[2 * DHc + d * DHc + 4 * grp + j] = acc[j];
-}
-
-template <int NS>
-__global__ void __launch_bounds__(256) linattn_apply_qkv_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ gain,
-                                                               const char* __restrict__ wimg0, const float* __restrict__ ws,
-                                                               float* __restrict__ out, int n, int heads, float scale, float eps) {
-    constexpr int DHc = 32, CH = 256, REC = 2 * DHc + DHc * DHc;
-    __shared__ float gm[DHc], gs[DHc], ctx[DHc][DHc + 1];
-    __shared__ float qs[CH][DHc + 1], os[CH][DHc + 1];
-    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, c = blockIdx.y, nch = gridDim.y, HD = heads * DHc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, q16 = lane >> 4;
-    {   // the chunk's q rows first: their loads fly while the chunks' records are merged
-        f32x4 acc[4][2];
-        head_qkv_rows<NS, 4, 0, 2>(x + ((size_t)b * n + (size_t)c * CH) * x_ld, x_ld, gain, wimg0 + lane * 16, 0, hd, HD, eps, wave, r16, q16, acc);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int pix = (wave + 4 * t) * 16 + r16;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) qs[pix][16 * j + 4 * q16 + e] = acc[t][j][e];
-        }
-    }
-    const float* recs = ws + (size_t)blockIdx.x * nch * REC;
-    const int d = tid % DHc, grp = tid / DHc;
-    if (tid < DHc) {
-        float m = -INFINITY;
-        for (int k = 0; k < nch; ++k) m = fmaxf(m, recs[k * REC + d]);
-        float ssum = 0.f;
-        for (int k = 0; k < nch; ++k) ssum += recs[k * REC + DHc + d] * expf(recs[k * REC + d] - m);
-        gm[d] = m;
-        gs[d] = ssum;
-    }
-    __syncthreads();
-    {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < nch; ++k) {
-            const float r = expf(recs[k * REC + d] - gm[d]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] = fmaf(recs[k * REC + 2 * DHc + d * DHc + 4 * grp + j], r, acc[j]);
-        }
-        const float norm = 1.0f / (gs[d] * (float)n);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) ctx[d][4 * grp + j] = acc[j] * norm;
-    }
-    __syncthreads();
-    {
-        const int i = tid;
-        float qv[DHc];
-        float mq = -INFINITY;
-#pragma unroll
-        for (int dd = 0; dd < DHc; ++dd) { qv[dd] = qs[i][dd]; mq = fmaxf(mq, qv[dd]); }
-        float sq = 0.f;
-#pragma unroll
-        for (int dd = 0; dd < DHc; ++dd) { qv[dd] = expf(qv[dd] - mq); sq += qv[dd]; }
-#pragma unroll
-        for (int dd = 0; dd < DHc; ++dd) qv[dd] = __fmul_rn(qv[dd] / sq, scale);
-        for (int e = 0; e < DHc; ++e) {
-            float acc = 0.f;
-#pragma unroll
-            for (int dd = 0; dd < DHc; ++dd) acc = fmaf(ctx[dd][e], qv[dd], acc);
-            os[i][e] = acc;
-        }
-    }
-    __syncthreads();
-    float* obase = out + ((size_t)b * n + (size_t)c * CH) * HD + hd * DHc;
-    for (int e = tid; e < CH * DHc; e += 256) obase[(size_t)(e / DHc) * HD + e % DHc] = os[e / DHc][e % DHc];
-}
-
-// The same for Attention (reference :336-358; the mid block, n = 64 keys): to_qkv inside attention_kernel's launch (unet.hip: four
-// threads per query over the keys p, p + 4, ...; row maximum = max over the parts' maxima, exp sums and value sums added in part order).
-template <int NS>
-__global__ void __launch_bounds__(256) attn_qkv_kernel(const float* __restrict__ x, int x_ld, const float* __restrict__ gain,
-                                                      const char* __restrict__ wimg0, float* __restrict__ out, int heads, float scale,
-                                                      float eps) {
-    constexpr int DHc = 32, n = 64, NP = 4, nq = 64, PP = DHc + 2;
-    __shared__ __attribute__((aligned(16))) float Ks[n * DHc], Vs[n * DHc], Qs[n * DHc], Ps[NP * nq * PP];
-    const int b = blockIdx.x / heads, hd = blockIdx.x % heads, HD = heads * DHc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, q16 = lane >> 4;
-    {
-        f32x4 acc[1][6];
-        head_qkv_rows<NS, 1>(x, x_ld, gain, wimg0 + lane * 16, b, hd, HD, eps, wave, r16, q16, acc);
-        const int pix = wave * 16 + r16;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int o = pix * DHc + 16 * j + 4 * q16;
-            *reinterpret_cast<float4*>(Qs + o) = make_float4(acc[0][j][0], acc[0][j][1], acc[0][j][2], acc[0][j][3]);
-            *reinterpret_cast<float4*>(Ks + o) = make_float4(acc[0][2 + j][0], acc[0][2 + j][1], acc[0][2 + j][2], acc[0][2 + j][3]);
-            *reinterpret_cast<float4*>(Vs + o) = make_float4(acc[0][4 + j][0], acc[0][4 + j][1], acc[0][4 + j][2], acc[0][4 + j][3]);
-        }
-    }
-    __syncthreads();
-    const int i = tid & (nq - 1), p = tid >> 6;
-    float qv[DHc];
-#pragma unroll
-    for (int dd = 0; dd < DHc; dd += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(Qs + i * DHc + dd);
-        qv[dd] = __fmul_rn(v.x, scale); qv[dd + 1] = __fmul_rn(v.y, scale); qv[dd + 2] = __fmul_rn(v.z, scale); qv[dd + 3] = __fmul_rn(v.w, scale);
-    }
-    float mx = -INFINITY;
-    auto dot = [&](int j) __attribute__((always_inline)) {
-        const float4* kr = reinterpret_cast<const float4*>(Ks + j * DHc);
-        float sdot = 0.f;
-#pragma unroll
-        for (int d4 = 0; d4 < DHc / 4; ++d4) {
-            const float4 kv = kr[d4];
-            sdot = fmaf(qv[4 * d4], kv.x, sdot); sdot = fmaf(qv[4 * d4 + 1], kv.y, sdot);
-            sdot = fmaf(qv[4 * d4 + 2], kv.z, sdot); sdot = fmaf(qv[4 * d4 + 3], kv.w, sdot);
-        }
-        return sdot;
-    };
-    for (int j = p; j < n; j += NP) mx = fmaxf(mx, dot(j));
-    Ps[(p * nq + i) * PP] = mx;
-    __syncthreads();
-    for (int pp = 0; pp < NP; ++pp) mx = fmaxf(mx, Ps[(pp * nq + i) * PP]);
-    __syncthreads();
-    float o[DHc];
-#pragma unroll
-    for (int dd = 0; dd < DHc; ++dd) o[dd] = 0.f;
-    float den = 0.f;
-    for (int j = p; j < n; j += NP) {
-        const float pr = expf(dot(j) - mx);
-        den += pr;
-        const float4* vr = reinterpret_cast<const float4*>(Vs + j * DHc);
-#pragma unroll
-        for (int d4 = 0; d4 < DHc / 4; ++d4) {
-            const float4 vv = vr[d4];
-            o[4 * d4] = fmaf(pr, vv.x, o[4 * d4]); o[4 * d4 + 1] = fmaf(pr, vv.y, o[4 * d4 + 1]);
-            o[4 * d4 + 2] = fmaf(pr, vv.z, o[4 * d4 + 2]); o[4 * d4 + 3] = fmaf(pr, vv.w, o[4 * d4 + 3]);
-        }
-    }
-    float* mine = Ps + (p * nq + i) * PP;
-    mine[1] = den;
-#pragma unroll
-    for (int dd = 0; dd < DHc; ++dd) mine[2 + dd] = o[dd];
-    __syncthreads();
-    float dsum = 0.f;
-    for (int pp = 0; pp < NP; ++pp) dsum += Ps[(pp * nq + i) * PP + 1];
-    float* orow = out + ((size_t)b * n + i) * HD + hd * DHc;
-    for (int dd = p; dd < DHc; dd += NP) {
-        float v = 0.f;
-        for (int pp = 0; pp < NP; ++pp) v += Ps[(pp * nq + i) * PP + 2 + dd];
-        orow[dd] = v / dsum;
-    }
-}
+#include "conv_ldsx.inc"      // the LDS-staged split-product 3x3 conv
+#include "conv_attn.inc"      // 1x1 convs with LayerNorms, attention cores with to_qkv inside
 
 // ----------------------------------------------------------------------------- pointwise conv on bf16 activations
 // The 512->512 1x1 convs of the training path (forward and data gradient) and the 512 -> 9*C tap GEMMs read a bf16
