@@ -301,11 +301,11 @@ int nfdp_conv1x1_ln_supported(long npix, int Cin, int Cout, int pre, int post);
 /* PreNorm -> LinearAttention without the qkv tensor (:212-220, :305-333): the workgroup of a (sample, head) forms its own q / k / v rows
  * (LayerNorm of x with pre_gain, to_qkv: the products of nfdp_conv1x1_ln_f32 in the same order) and runs nfdp_linear_attention_f32's core on
  * them.  x [B][n][C] (rows x_ld), w_packed = nfdp_conv_pack_weights of to_qkv's [3*heads*32][C][1][1] weight (fp32), out [B][n][heads*32].
- * n = 64 or a multiple of 256 (beyond 256: two launches over 256-pixel chunks as nfdp_linear_attention_chunked_f32, with a workspace of
+ * n <= 64 or a multiple of 256 (beyond 256: two launches over 256-pixel chunks as nfdp_linear_attention_chunked_f32, with a workspace of
  * nfdp_linear_attention_qkv_ws_bytes; ws may be NULL up to 256), C in {64, 128}, dim_head 32. */
 int nfdp_linear_attention_qkv_supported(int n, int C, int heads, int dim_head);
 size_t nfdp_linear_attention_qkv_ws_bytes(int B, int n, int heads);
-/* ... and PreNorm -> Attention (:336-358: softmax(q k^T * scale) v) the same way, nfdp_attention_f32's core; n = 64, C in {64, 128}. */
+/* ... and PreNorm -> Attention (:336-358: softmax(q k^T * scale) v) the same way, nfdp_attention_f32's core; n <= 64, C in {64, 128}. */
 int nfdp_attention_qkv_supported(int n, int C, int heads, int dim_head);
 int nfdp_attention_qkv_f32(const float* x, int x_ld, const float* pre_gain, const void* w_packed, float* out, int B, int n, int C, int heads,
                            int dim_head, float scale, float eps, nfdp_stream_t stream);

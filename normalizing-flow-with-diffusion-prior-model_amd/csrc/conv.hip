@@ -1787,7 +1787,7 @@ extern "C" int nfdp_conv2d_gnin_nhwc_f32(const float* x, int x_ld, const double*
 // PreNorm -> LinearAttention (to_qkv + core) in one launch (linattn_qkv_kernel): x [B][n][C] (rows x_ld), w_packed = the to_qkv weight
 // [3 * heads * 32][C][1][1] packed fp32 (with its split image), out [B][n][heads * 32].
 extern "C" int nfdp_linear_attention_qkv_supported(int n, int C, int heads, int dim_head) {
-    return (n == 64 || (n >= 256 && n % 256 == 0)) && (C == 64 || C == 128) && dim_head == 32 && heads >= 1 && heads <= 8 &&
+    return ((n >= 1 && n <= 64) || (n >= 256 && n % 256 == 0)) && (C == 64 || C == 128) && dim_head == 32 && heads >= 1 && heads <= 8 &&
            split_image_shape(3 * heads * 32, C, 1, 1);
 }
 // n > 256: the chunked form's workspace (a record of column maxima, exp sums and context per (sample, head, 256-pixel chunk)); else 0
@@ -1801,7 +1801,7 @@ extern "C" int nfdp_linear_attention_qkv_f32(const float* x, int x_ld, const flo
     NFDP_REQUIRE(n <= 256 || (ws && (uintptr_t)ws % 16 == 0), NFDP_EINVAL, "linear_attention_qkv: n > 256 needs the workspace (nfdp_linear_attention_qkv_ws_bytes)");
     NFDP_REQUIRE(B >= 0, NFDP_ESHAPE, "linear_attention_qkv: bad shape");
     NFDP_REQUIRE(nfdp_linear_attention_qkv_supported(n, C, heads, dim_head), NFDP_EUNSUPPORTED,
-                 "linear_attention_qkv: n=%d (64, 256) C=%d (64, 128) heads=%d dim_head=%d (32)", n, C, heads, dim_head);
+                 "linear_attention_qkv: n=%d (<= 64 or a multiple of 256) C=%d (64, 128) heads=%d dim_head=%d (32)", n, C, heads, dim_head);
     NFDP_REQUIRE(x_ld >= C && x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)pre_gain | (uintptr_t)out) % 16) == 0, NFDP_ESHAPE,
                  "linear_attention_qkv: rows and vectors must be 16-byte aligned");
     if (B == 0) return NFDP_OK;
@@ -1829,31 +1829,35 @@ extern "C" int nfdp_linear_attention_qkv_f32(const float* x, int x_ld, const flo
         return NFDP_OK;
     }
     const dim3 grid(B * heads), blk(256);
-    if (C == 64 && n == 256) hipLaunchKernelGGL((linattn_qkv_kernel<2, 4>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
-    else if (C == 64) hipLaunchKernelGGL((linattn_qkv_kernel<2, 1>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
-    else if (n == 256) hipLaunchKernelGGL((linattn_qkv_kernel<4, 4>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
-    else hipLaunchKernelGGL((linattn_qkv_kernel<4, 1>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
+    if (n < 64) {                                        // ragged: the 4x4 / 2x2 stages, odd image sizes
+        const size_t lds1 = (size_t)2 * 64 * 33 * sizeof(float);
+        if (C == 64) hipLaunchKernelGGL((linattn_qkv_kernel<2, 1, true>), grid, blk, lds1, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps, n);
+        else hipLaunchKernelGGL((linattn_qkv_kernel<4, 1, true>), grid, blk, lds1, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps, n);
+    } else if (C == 64 && n == 256) hipLaunchKernelGGL((linattn_qkv_kernel<2, 4>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps, n);
+    else if (C == 64) hipLaunchKernelGGL((linattn_qkv_kernel<2, 1>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps, n);
+    else if (n == 256) hipLaunchKernelGGL((linattn_qkv_kernel<4, 4>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps, n);
+    else hipLaunchKernelGGL((linattn_qkv_kernel<4, 1>), grid, blk, lds, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps, n);
     NFDP_CHECK_LAUNCH("linear_attention_qkv");
     return NFDP_OK;
 }
 
 // PreNorm -> Attention (to_qkv + softmax core) in one launch (attn_qkv_kernel): n = 64 keys, C in {64, 128}.
 extern "C" int nfdp_attention_qkv_supported(int n, int C, int heads, int dim_head) {
-    return n == 64 && (C == 64 || C == 128) && dim_head == 32 && heads >= 1 && heads <= 8 && split_image_shape(3 * heads * 32, C, 1, 1);
+    return n >= 1 && n <= 64 && (C == 64 || C == 128) && dim_head == 32 && heads >= 1 && heads <= 8 && split_image_shape(3 * heads * 32, C, 1, 1);
 }
 extern "C" int nfdp_attention_qkv_f32(const float* x, int x_ld, const float* pre_gain, const void* w_packed, float* out, int B, int n, int C,
                                       int heads, int dim_head, float scale, float eps, nfdp_stream_t stream) {
     NFDP_REQUIRE(x && pre_gain && w_packed && out, NFDP_EINVAL, "attention_qkv: null pointer");
     NFDP_REQUIRE(B >= 0, NFDP_ESHAPE, "attention_qkv: bad shape");
     NFDP_REQUIRE(nfdp_attention_qkv_supported(n, C, heads, dim_head), NFDP_EUNSUPPORTED,
-                 "attention_qkv: n=%d (64) C=%d (64, 128) heads=%d dim_head=%d (32)", n, C, heads, dim_head);
+                 "attention_qkv: n=%d (<= 64) C=%d (64, 128) heads=%d dim_head=%d (32)", n, C, heads, dim_head);
     NFDP_REQUIRE(x_ld >= C && x_ld % 4 == 0 && (((uintptr_t)x | (uintptr_t)pre_gain | (uintptr_t)out) % 16) == 0, NFDP_ESHAPE,
                  "attention_qkv: rows and vectors must be 16-byte aligned");
     if (B == 0) return NFDP_OK;
     const char* wimg = reinterpret_cast<const char*>(w_packed) + (size_t)cout_pad_for(3 * heads * 32) * kpad_for(C, 1, 1) * 4;
     hipStream_t s = as_stream(stream);
-    if (C == 64) hipLaunchKernelGGL((attn_qkv_kernel<2>), dim3(B * heads), dim3(256), 0, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
-    else hipLaunchKernelGGL((attn_qkv_kernel<4>), dim3(B * heads), dim3(256), 0, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps);
+    if (C == 64) hipLaunchKernelGGL((attn_qkv_kernel<2>), dim3(B * heads), dim3(256), 0, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps, n);
+    else hipLaunchKernelGGL((attn_qkv_kernel<4>), dim3(B * heads), dim3(256), 0, s, x, x_ld, pre_gain, wimg, out, heads, scale, eps, n);
     NFDP_CHECK_LAUNCH("attention_qkv");
     return NFDP_OK;
 }
