@@ -20,7 +20,9 @@ with torch.no_grad():
         d = pr.diffusion if hasattr(pr, "diffusion") else pr
         k = [k for k in d._graphs if k[0] == "step"][0]
         graphs.append(d._graphs[k])
-    streams = [torch.cuda.Stream() for _ in graphs]
+    prio = [int(v) for v in sys.argv[1:4]] if len(sys.argv) >= 4 else [0, 0, 0]      # stream priorities (-1 = high) of the three chains
+    print("stream priorities", prio)
+    streams = [torch.cuda.Stream(priority=p) for p in prio]
     names = ["16x16", "8x8", "4x4"]
     for r in (1, 2, 3):
         for sub in itertools.combinations(range(3), r):
