@@ -589,7 +589,8 @@ def test_attention_block_with_layernorms_inside_the_1x1_convs(b, hw, dim, kind):
 
 
 @pytest.mark.parametrize("b,hw,cin,c2,cout,groups", [(64, 16, 64, 0, 64, 8), (64, 16, 64, 64, 64, 8), (64, 8, 128, 0, 128, 8), (64, 8, 128, 64, 128, 8),
-                                                     (3, 16, 64, 0, 128, 16), (5, 8, 64, 0, 64, 4), (2, 32, 32, 0, 64, 8), (20, 64, 64, 0, 64, 16), (18, 64, 64, 64, 64, 16)])
+                                                     (3, 16, 64, 0, 128, 16), (5, 8, 64, 0, 64, 4), (2, 32, 32, 0, 64, 8), (20, 64, 64, 0, 64, 16), (18, 64, 64, 64, 64, 16),
+                                                     (64, 8, 128, 128, 128, 8), (9, 16, 64, 0, 128, 2), (6, 16, 96, 32, 64, 8)])
 @torch.no_grad()
 def test_resnet_block_with_the_first_groupnorm_inside_the_second_conv(b, hw, cin, c2, cout, groups):
     """ResnetBlock (reference gaussian_diffusion.py:279-302) where a conv workgroup's tile is a part of an image: block1's conv leaves the
