@@ -792,3 +792,26 @@ def test_block_tiles_of_the_staged_conv_are_bit_identical_to_flat_tiles(b, h, w,
     xc = (torch.cat((x, x2), dim=3) if c2 else x).permute(0, 3, 1, 2).double().cpu()
     ref = torch.nn.functional.conv2d(xc, wt.double().cpu(), bias.double().cpu(), padding=1)
     assert_close(blocks.permute(0, 3, 1, 2), ref, 2e-5, "staged conv on block tiles vs torch fp64")
+
+
+@torch.no_grad()
+def test_unet_in_exact_fp32_products_mode_takes_the_unfused_paths_and_agrees():
+    """nfdp_hip.set_f32_products("exact") (fp32 MFMA chain instead of the bf16 splits): the split-product fusions (GroupNorm carried, res_conv,
+    Upsample, to_qkv inside attention, LayerNorms in the 1x1 convs) are gated off, Downsample-as-a-conv and the direct 7x7 kernel stay; the
+    U-Net's output agrees with the default mode to the products' rounding."""
+    from diffusion_prior import Unet
+    torch.manual_seed(3)
+    u = Unet(dim=64, dim_mults=(1, 2), channels=2, resnet_block_groups=8).to(DEV)
+    x = torch.randn(8, 16, 16, 2, device=DEV)
+    t = torch.randint(0, 1000, (8,), device=DEV)
+    want = u.forward_nhwc(x, t)
+    K.set_f32_products("exact")
+    try:
+        K.start_trace()
+        got = u.forward_nhwc(x, t)
+        labels = [e["label"] for e in K.stop_trace()]
+    finally:
+        K.set_f32_products("bf16x6")
+    assert not any(("gn-in" in lb) or ("+qkv" in lb) or lb.startswith("conv1x1_ln") or ("up2" in lb) or ("+res" in lb) for lb in labels), labels
+    assert any("squeeze" in lb and lb.startswith("conv_splitk") for lb in labels) and any(lb.startswith("conv_k7_narrow") for lb in labels), labels
+    assert_close(got, want, 2e-5, "U-Net: exact fp32 products vs split products")
