@@ -592,7 +592,12 @@ __device__ __forceinline__ void splitk_epilogue(const ConvParams& P, float* part
             double t = gsw[0][g][k];
 #pragma unroll
             for (int w = 1; w < SK_WAVES; ++w) t += gsw[w][g][k];
-            P.gs_out[(tile * P.gs_groups + n0 / cpg + g) * 2 + k] = t;
+            if constexpr (T2D && PT == 8) {                        // the consumers count 64-pixel tiles: this one's sums, then a zero record
+                P.gs_out[((2 * tile) * P.gs_groups + n0 / cpg + g) * 2 + k] = t;
+                P.gs_out[((2 * tile + 1) * P.gs_groups + n0 / cpg + g) * 2 + k] = 0.0;
+            } else {
+                P.gs_out[(tile * P.gs_groups + n0 / cpg + g) * 2 + k] = t;
+            }
         }
     }
 }
@@ -1348,7 +1353,7 @@ extern "C" int nfdp_pointwise_dgrad_masked_bf16(const void* x, int x_ld, const v
 }
 
 // ---- the LDS-staged form of the split-product 3x3 convs (conv3x3_ldsx_kernel): taken where its geometry holds
-static thread_local int g_conv_ldsx = 1;                          // test hook (thread-local): 0 = always the gathering kernel, 2 = flat tiles only
+static thread_local int g_conv_ldsx = 1;                          // test hook (thread-local): 0 = always the gathering kernel, 2 = flat tiles only, 3 = no 128-pixel tiles
 extern "C" void nfdp_debug_set_conv_ldsx(int v) { g_conv_ldsx = v; }
 constexpr size_t kLdsxMax = 160 * 1024;
 #ifdef NFDP_LX_STAMPS
@@ -1384,6 +1389,30 @@ static void launch_ldsx_t(const ConvParams& P, int pt, dim3 grid, hipStream_t s)
     Q.wsplit_off = (size_t)cout_pad_for(P.Cout) * P.Kpad * 4;
     if (RES) Q.w2split_off = (size_t)cout_pad_for(P.Cout) * kpad_for(P.Cin, 1, 1) * 4;
     // wide images: 8 x 8 pixel blocks (100 staged pixels) instead of flat 64-pixel ranges (64 + 2 (W + 1))
+    if constexpr (!GN && !GNIN && !RES) {
+        // ... and 16 x 8 blocks (128 pixels per workgroup: a stage's twelve weight fragments meet twice the MFMAs; the accumulators live in
+        // AGPRs, no spills) where that still leaves two chip-wide waves of workgroups: 79 -> 71 us for the 64 -> 64 conv at 32 x 64 x 64
+        if (pt == 4 && g_conv_ldsx == 1 && P.W >= 32 && P.W % 8 == 0 && P.H % 16 == 0 && (P.npix / 128) * P.Nt >= 512) {
+            Q.tw = 8; Q.th = 16; Q.Mt = (int)(P.npix / 128);
+            const size_t planes = (size_t)3 * (18 * 10 + 1) * (P.Cin + 8) * 2;
+            const size_t part = (size_t)LX_WAVES * 128 * SK_LD * 4;
+            lds = planes > part ? planes : part;
+            if (lds + kLdsxStatic <= kLdsxMax) {
+                static NfdpPerDevice attr8;
+                if (!attr8) {
+                    nfdp_func_attr(reinterpret_cast<const void*>(&conv3x3_ldsx_kernel<8, false, false, false, UP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLdsxMax - kLdsxStatic));
+                    attr8 = true;
+                }
+#ifdef NFDP_LX_STAMPS
+                Q.part = reinterpret_cast<double*>(g_lx_stamps);
+#endif
+                hipLaunchKernelGGL((conv3x3_ldsx_kernel<8, false, false, false, UP, true>), dim3(Q.Mt * Q.Nt), dim3(LX_WAVES * 64), lds, s, Q);
+                return;
+            }
+            Q.Mt = P.Mt;
+            lds = ldsx_bytes(P.W, P.Cin, pt, P.H * P.W, 0);
+        }
+    }
     if constexpr (!GN) {
         if (pt == 4 && g_conv_ldsx != 2 && P.W >= 32 && P.W % 8 == 0 && P.H % 8 == 0) {
             Q.tw = 8; Q.th = 8;
